@@ -1,0 +1,839 @@
+"""TEST INFRASTRUCTURE ONLY -- big-integer oracle for the MSM / NTT / Groth16 hot path.
+
+This module is *the checker*, never the product.  Only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import anything under oracle/.
+
+It restates, with plain Python integers, the algorithms the reference
+(NilFoundation/crypto3-zk) reaches through its un-vendored dependencies
+crypto3-algebra / crypto3-math (no version pin exists; the only pin-like datum is the
+CI ref NilFoundation/crypto3@1bd56b12f410f3f1a4891076705a9261a6b1efaa,
+.github/workflows/pull-request.yml:29):
+
+  * algebra::multiexp                       -> msm_naive / msm_pippenger
+      call sites: zk/snark/systems/ppzksnark/r1cs_gg_ppzksnark/prover.hpp:108-139,
+                  zk/commitments/polynomial/kzg.hpp:143-148,409-435
+  * kc_multiexp_with_mixed_addition         -> kc_multiexp
+      zk/commitments/polynomial/knowledge_commitment_multiexp.hpp:57-108
+  * evaluation_domain::fft / inverse_fft    -> ntt / intt (definition: out[i] = sum_j in[j] w^(ij))
+      call sites: zk/snark/reductions/r1cs_to_qap.hpp:250-310
+  * r1cs_to_qap::witness_map                -> witness_map   (r1cs_to_qap.hpp:219-325)
+  * r1cs_to_qap::instance_map_with_evaluation -> qap_evaluate_at (r1cs_to_qap.hpp:138-187)
+  * r1cs_gg_ppzksnark_generator (fixed trapdoor) -> groth16_keygen (generator.hpp:86-236)
+  * r1cs_gg_ppzksnark_prover::process       -> groth16_prove (prover.hpp:73-158)
+  * ipp2 prove_commitment_{v,w} (the KAT carrier) -> ipp2_prove_commitment_{v,w}
+      zk/snark/systems/ppzksnark/r1cs_gg_ppzksnark/ipp2/prover.hpp:99-290, ipp2/srs.hpp:44-56
+
+Parity pin: the bellperson-derived known-answer vectors of
+test/systems/ppzksnark/r1cs_gg_ppzksnark/r1cs_gg_ppzksnark_aggregation_conformity.cpp
+(:578-862 Fr chains, :864-930 G1/G2 MSM) and test/commitment/kzg.cpp:75-103 are reproduced by
+tests/test_oracle_kat.py from tests/golden/ref_kat.json.  NTT outputs and full Groth16 proofs
+are NOT pinned by any reference test ("parity unpinned" there): the NTT is pinned to the
+mathematical DFT definition, Groth16 proofs to the trapdoor ("in the exponent") identities.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+MASK64 = (1 << 64) - 1
+
+
+# --------------------------------------------------------------------------------------
+# deterministic PRNG shared with oracle/zk_oracle.cpp and the HIP library's test helpers
+# --------------------------------------------------------------------------------------
+class SplitMix64:
+    def __init__(self, seed: int):
+        self.s = seed & MASK64
+
+    def next(self) -> int:
+        self.s = (self.s + 0x9E3779B97F4A7C15) & MASK64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+        return z ^ (z >> 31)
+
+    def next_mod(self, modulus: int) -> int:
+        """4 little-endian 64-bit limbs reduced mod `modulus` (same rule as the C++ oracle)."""
+        v = 0
+        for i in range(4):
+            v |= self.next() << (64 * i)
+        return v % modulus
+
+
+# --------------------------------------------------------------------------------------
+# fields
+# --------------------------------------------------------------------------------------
+class Fq:
+    """Prime field ops on plain ints."""
+
+    def __init__(self, p: int):
+        self.p = p
+        self.zero = 0
+        self.one = 1
+
+    def add(self, a, b):
+        return (a + b) % self.p
+
+    def sub(self, a, b):
+        return (a - b) % self.p
+
+    def neg(self, a):
+        return (-a) % self.p
+
+    def mul(self, a, b):
+        return (a * b) % self.p
+
+    def sqr(self, a):
+        return (a * a) % self.p
+
+    def inv(self, a):
+        return pow(a, -1, self.p)
+
+    def is_zero(self, a):
+        return a % self.p == 0
+
+    def eq(self, a, b):
+        return (a - b) % self.p == 0
+
+    def from_int(self, k):
+        return k % self.p
+
+
+class Fq2:
+    """Fq[u]/(u^2+1) on (c0, c1) tuples (both BLS12-381 and BN254 use u^2 = -1)."""
+
+    def __init__(self, p: int):
+        self.p = p
+        self.zero = (0, 0)
+        self.one = (1, 0)
+
+    def add(self, a, b):
+        return ((a[0] + b[0]) % self.p, (a[1] + b[1]) % self.p)
+
+    def sub(self, a, b):
+        return ((a[0] - b[0]) % self.p, (a[1] - b[1]) % self.p)
+
+    def neg(self, a):
+        return ((-a[0]) % self.p, (-a[1]) % self.p)
+
+    def mul(self, a, b):
+        p = self.p
+        return ((a[0] * b[0] - a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p)
+
+    def sqr(self, a):
+        return self.mul(a, a)
+
+    def inv(self, a):
+        p = self.p
+        n = pow(a[0] * a[0] + a[1] * a[1], -1, p)
+        return (a[0] * n % p, (-a[1]) * n % p)
+
+    def is_zero(self, a):
+        return a[0] % self.p == 0 and a[1] % self.p == 0
+
+    def eq(self, a, b):
+        return self.is_zero(self.sub(a, b))
+
+    def from_int(self, k):
+        return (k % self.p, 0)
+
+
+# --------------------------------------------------------------------------------------
+# short Weierstrass y^2 = x^3 + b, Jacobian coordinates; affine None = infinity
+# --------------------------------------------------------------------------------------
+class Group:
+    def __init__(self, F, b, gen, order: int, name: str):
+        self.F = F
+        self.b = b
+        self.gen = gen  # affine (x, y)
+        self.order = order
+        self.name = name
+
+    # ---- affine helpers
+    def on_curve(self, P) -> bool:
+        if P is None:
+            return True
+        F = self.F
+        x, y = P
+        return F.eq(F.sqr(y), F.add(F.mul(F.sqr(x), x), self.b))
+
+    def neg(self, P):
+        if P is None:
+            return None
+        return (P[0], self.F.neg(P[1]))
+
+    # ---- Jacobian
+    def to_jac(self, P):
+        if P is None:
+            return (self.F.one, self.F.one, self.F.zero)
+        return (P[0], P[1], self.F.one)
+
+    def to_affine(self, J):
+        F = self.F
+        X, Y, Z = J
+        if F.is_zero(Z):
+            return None
+        zi = F.inv(Z)
+        zi2 = F.sqr(zi)
+        return (F.mul(X, zi2), F.mul(Y, F.mul(zi2, zi)))
+
+    def jdbl(self, J):
+        F = self.F
+        X, Y, Z = J
+        if F.is_zero(Z) or F.is_zero(Y):
+            return (F.one, F.one, F.zero)
+        A = F.sqr(X)
+        B = F.sqr(Y)
+        C = F.sqr(B)
+        t = F.sub(F.sub(F.sqr(F.add(X, B)), A), C)
+        D = F.add(t, t)
+        E = F.add(F.add(A, A), A)
+        Fv = F.sqr(E)
+        X3 = F.sub(Fv, F.add(D, D))
+        C8 = F.add(C, C)
+        C8 = F.add(C8, C8)
+        C8 = F.add(C8, C8)
+        Y3 = F.sub(F.mul(E, F.sub(D, X3)), C8)
+        Z3 = F.mul(F.add(Y, Y), Z)
+        return (X3, Y3, Z3)
+
+    def jadd(self, P, Q):
+        F = self.F
+        X1, Y1, Z1 = P
+        X2, Y2, Z2 = Q
+        if F.is_zero(Z1):
+            return Q
+        if F.is_zero(Z2):
+            return P
+        Z1Z1 = F.sqr(Z1)
+        Z2Z2 = F.sqr(Z2)
+        U1 = F.mul(X1, Z2Z2)
+        U2 = F.mul(X2, Z1Z1)
+        S1 = F.mul(Y1, F.mul(Z2, Z2Z2))
+        S2 = F.mul(Y2, F.mul(Z1, Z1Z1))
+        if F.eq(U1, U2):
+            if F.eq(S1, S2):
+                return self.jdbl(P)
+            return (F.one, F.one, F.zero)
+        H = F.sub(U2, U1)
+        R = F.sub(S2, S1)
+        HH = F.sqr(H)
+        HHH = F.mul(H, HH)
+        V = F.mul(U1, HH)
+        X3 = F.sub(F.sub(F.sqr(R), HHH), F.add(V, V))
+        Y3 = F.sub(F.mul(R, F.sub(V, X3)), F.mul(S1, HHH))
+        Z3 = F.mul(F.mul(Z1, Z2), H)
+        return (X3, Y3, Z3)
+
+    def jmul(self, J, k: int):
+        F = self.F
+        R = (F.one, F.one, F.zero)
+        if k < 0:
+            J = (J[0], F.neg(J[1]), J[2])
+            k = -k
+        for bit in bin(k)[2:] if k else "":
+            R = self.jdbl(R)
+            if bit == "1":
+                R = self.jadd(R, J)
+        return R
+
+    # ---- convenience on affine points
+    def mul(self, P, k: int):
+        return self.to_affine(self.jmul(self.to_jac(P), k % self.order))
+
+    def add(self, P, Q):
+        return self.to_affine(self.jadd(self.to_jac(P), self.to_jac(Q)))
+
+    def batch_mul_gen(self, ks: Sequence[int]):
+        """[k]G for many k, with a fixed-base 8-bit window table (keeps fixture generation fast)."""
+        F = self.F
+        W = 8
+        nwin = (self.order.bit_length() + W - 1) // W
+        table = []
+        base = self.to_jac(self.gen)
+        for _ in range(nwin):
+            row = [(F.one, F.one, F.zero)]
+            for i in range(1, 1 << W):
+                row.append(self.jadd(row[-1], base))
+            table.append(row)
+            for _ in range(W):
+                base = self.jdbl(base)
+        out = []
+        for k in ks:
+            k %= self.order
+            acc = (F.one, F.one, F.zero)
+            w = 0
+            while k:
+                d = k & ((1 << W) - 1)
+                if d:
+                    acc = self.jadd(acc, table[w][d])
+                k >>= W
+                w += 1
+            out.append(self.to_affine(acc))
+        return out
+
+
+@dataclass
+class Curve:
+    name: str
+    p: int
+    r: int
+    g1: Group
+    g2: Group
+    fr_generator: int  # multiplicative generator of Fr* (crypto3 arithmetic_params convention)
+    two_adicity: int
+
+    def root_of_unity(self, log_m: int) -> int:
+        """w = g^((r-1)/2^log_m): the conventional 2^log_m-th primitive root.  The reference's choice
+        lives in crypto3-algebra (not in tree); the C ABI therefore takes w as an argument."""
+        assert log_m <= self.two_adicity
+        return pow(self.fr_generator, (self.r - 1) >> log_m, self.r)
+
+
+def _make_bls12_381() -> Curve:
+    p = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+    r = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    g1 = (
+        0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+        0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1,
+    )
+    g2 = (
+        (
+            0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+            0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E,
+        ),
+        (
+            0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+            0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE,
+        ),
+    )
+    return Curve(
+        "bls12_381",
+        p,
+        r,
+        Group(Fq(p), 4, g1, r, "bls12_381_g1"),
+        Group(Fq2(p), (4, 4), g2, r, "bls12_381_g2"),
+        7,
+        32,
+    )
+
+
+def _make_bn254() -> Curve:
+    p = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    r = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    g2 = (
+        (
+            10857046999023057135944570762232829481370756359578518086990519993285655852781,
+            11559732032986387107991004021392285783925812861821192530917403151452391805634,
+        ),
+        (
+            8495653923123431417604973247489272438418190587263600148770280649306958101930,
+            4082367875863433681332203403145435568316851327593401208105741076214120093531,
+        ),
+    )
+    f2 = Fq2(p)
+    b2 = f2.mul((3, 0), f2.inv((9, 1)))  # 3/(9+u)
+    return Curve(
+        "bn254",
+        p,
+        r,
+        Group(Fq(p), 3, (1, 2), r, "bn254_g1"),
+        Group(f2, b2, g2, r, "bn254_g2"),
+        5,
+        28,
+    )
+
+
+BLS12_381 = _make_bls12_381()
+BN254 = _make_bn254()
+CURVES = {"bls12_381": BLS12_381, "bn254": BN254}
+
+
+# --------------------------------------------------------------------------------------
+# MSM
+# --------------------------------------------------------------------------------------
+def msm_naive(G: Group, bases: Sequence, scalars: Sequence[int]):
+    """sum_i s_i * P_i by double-and-add; the definition every MSM algorithm must hit."""
+    F = G.F
+    acc = (F.one, F.one, F.zero)
+    for P, s in zip(bases, scalars):
+        if P is None or s % G.order == 0:
+            continue
+        acc = G.jadd(acc, G.jmul(G.to_jac(P), s % G.order))
+    return G.to_affine(acc)
+
+
+def msm_pippenger(G: Group, bases: Sequence, scalars: Sequence[int], c: Optional[int] = None):
+    """Bucket method (BDLO12 as in the libff lineage of algebra::multiexp): unsigned c-bit digits,
+    windows from the top, per-window bucket accumulation and running-sum reduction."""
+    F = G.F
+    n = len(bases)
+    if n == 0:
+        return None
+    if c is None:
+        lg = max(1, n.bit_length() - 1)
+        c = max(1, lg - (lg // 3 - 2)) if lg >= 6 else max(1, lg)
+    nbits = max((s % G.order).bit_length() for s in scalars) if scalars else 0
+    groups = (nbits + c - 1) // c
+    inf = (F.one, F.one, F.zero)
+    result = inf
+    for k in range(groups - 1, -1, -1):
+        for _ in range(c):
+            result = G.jdbl(result)
+        buckets = [inf] * (1 << c)
+        for P, s in zip(bases, scalars):
+            if P is None:
+                continue
+            d = ((s % G.order) >> (k * c)) & ((1 << c) - 1)
+            if d:
+                buckets[d] = G.jadd(buckets[d], G.to_jac(P))
+        running = inf
+        for i in range((1 << c) - 1, 0, -1):
+            running = G.jadd(running, buckets[i])
+            result = G.jadd(result, running)
+    return G.to_affine(result)
+
+
+def kc_multiexp(G2g: Group, G1g: Group, indices, values, min_idx, max_idx, scalars):
+    """knowledge_commitment_multiexp.hpp:57-108 -- sparse vector of (g in G2, h in G1) pairs:
+    skip 0, add 1-scalars directly, MSM on the rest.  Returns (g_sum, h_sum) affine."""
+    import bisect
+
+    off = bisect.bisect_left(indices, min_idx)
+    acc_g = None
+    acc_h = None
+    p = []
+    gg = []
+    hh = []
+    r = G1g.order
+    for pos in range(off, len(indices)):
+        idx = indices[pos]
+        if idx >= max_idx:
+            break
+        s = scalars[idx - min_idx] % r
+        g, h = values[pos]
+        if s == 0:
+            continue
+        if s == 1:
+            acc_g = G2g.add(acc_g, g)
+            acc_h = G1g.add(acc_h, h)
+        else:
+            p.append(s)
+            gg.append(g)
+            hh.append(h)
+    return (G2g.add(acc_g, msm_naive(G2g, gg, p)), G1g.add(acc_h, msm_naive(G1g, hh, p)))
+
+
+# --------------------------------------------------------------------------------------
+# NTT
+# --------------------------------------------------------------------------------------
+def dft_naive(a: Sequence[int], w: int, r: int) -> List[int]:
+    n = len(a)
+    out = []
+    for i in range(n):
+        wi = pow(w, i, r)
+        acc = 0
+        x = 1
+        for j in range(n):
+            acc = (acc + a[j] * x) % r
+            x = x * wi % r
+        out.append(acc)
+    return out
+
+
+def ntt(a: Sequence[int], w: int, r: int) -> List[int]:
+    """Natural order in, natural order out: out[i] = sum_j a[j] w^(ij).  Iterative radix-2 DIT
+    (bit-reverse then butterflies), the classic in-place form of evaluation_domain::fft."""
+    n = len(a)
+    lg = n.bit_length() - 1
+    assert 1 << lg == n
+    a = list(a)
+    for i in range(n):
+        j = int(bin(i)[2:].zfill(lg)[::-1], 2) if lg else 0
+        if i < j:
+            a[i], a[j] = a[j], a[i]
+    m = 1
+    while m < n:
+        wm = pow(w, n // (2 * m), r)
+        for k in range(0, n, 2 * m):
+            x = 1
+            for j in range(m):
+                t = x * a[k + j + m] % r
+                u = a[k + j]
+                a[k + j] = (u + t) % r
+                a[k + j + m] = (u - t) % r
+                x = x * wm % r
+        m *= 2
+    return a
+
+
+def intt(a: Sequence[int], w: int, r: int) -> List[int]:
+    n = len(a)
+    ninv = pow(n, -1, r)
+    return [x * ninv % r for x in ntt(a, pow(w, -1, r), r)]
+
+
+def multiply_by_coset(a: Sequence[int], g: int, r: int) -> List[int]:
+    """math::multiply_by_coset: a[i] *= g^i (r1cs_to_qap.hpp:266-269)."""
+    out = []
+    x = 1
+    for v in a:
+        out.append(v * x % r)
+        x = x * g % r
+    return out
+
+
+def stockham_model(a: Sequence[int], w: int, r: int, radices: Sequence[int]) -> List[int]:
+    """Index-exact model of the multi-pass Stockham decomposition used by the HIP kernels
+    (crypto3-zk_amd/csrc/ntt.hip): pass with radix R and running sub-transform size Ns:
+        u[t]  = x[j + t*m/R] * w_{Ns*R}^(k t),  k = j mod Ns
+        v     = DFT_R(u)
+        y[(j-k)*R + k + t'*Ns] = v[t']
+    Used by the CPU tests to pin the index math against dft_naive before any GPU run."""
+    m = len(a)
+    x = list(a)
+    Ns = 1
+    for R in radices:
+        y = [0] * m
+        wsub = pow(w, m // (Ns * R), r)  # primitive (Ns*R)-th root
+        wR = pow(w, m // R, r)
+        for j in range(m // R):
+            k = j % Ns
+            u = [x[j + t * (m // R)] * pow(wsub, k * t, r) % r for t in range(R)]
+            v = dft_naive(u, wR, r)
+            base = (j - k) * R + k
+            for t in range(R):
+                y[base + t * Ns] = v[t]
+        x = y
+        Ns *= R
+    assert Ns == m
+    return x
+
+
+# --------------------------------------------------------------------------------------
+# R1CS / QAP / Groth16
+# --------------------------------------------------------------------------------------
+@dataclass
+class R1CS:
+    """constraints[i] = (a, b, c), each a list of (variable_index, coeff); index 0 = constant 1.
+    r1cs.hpp:61-64,125-133."""
+
+    num_inputs: int
+    num_aux: int
+    constraints: List[Tuple[list, list, list]]
+
+    @property
+    def num_variables(self):
+        return self.num_inputs + self.num_aux
+
+    @property
+    def num_constraints(self):
+        return len(self.constraints)
+
+
+def r1cs_example_field_input(r: int, num_constraints: int, num_inputs: int, seed: int):
+    """test/systems/ppzksnark/r1cs_examples.hpp:77-140 with a, b drawn from SplitMix64(seed)."""
+    rng = SplitMix64(seed)
+    a = rng.next_mod(r)
+    b = rng.next_mod(r)
+    full = [a, b]
+    cons = []
+    for i in range(num_constraints - 1):
+        if i % 2:
+            A = [(i + 1, 1)]
+            B = [(i + 2, 1)]
+            C = [(i + 3, 1)]
+            tmp = a * b % r
+        else:
+            B = [(0, 1)]
+            A = [(i + 1, 1), (i + 2, 1)]
+            C = [(i + 3, 1)]
+            tmp = (a + b) % r
+        full.append(tmp)
+        a, b = b, tmp
+        cons.append((A, B, C))
+    nvars = 2 + num_constraints
+    A = []
+    B = []
+    fin = 0
+    for i in range(1, nvars):
+        A.append((i, 1))
+        B.append((i, 1))
+        fin = (fin + full[i - 1]) % r
+    C = [(nvars, 1)]
+    cons.append((A, B, C))
+    full.append(fin * fin % r)
+    cs = R1CS(num_inputs, nvars - num_inputs, cons)
+    assert len(full) == nvars
+    return cs, full[:num_inputs], full[num_inputs:]
+
+
+def _lc_eval(lc, full, r):
+    acc = 0
+    for idx, coeff in lc:
+        acc += coeff * (1 if idx == 0 else full[idx - 1])
+    return acc % r
+
+
+def r1cs_is_satisfied(cs: R1CS, primary, aux, r):
+    full = list(primary) + list(aux)
+    for A, B, C in cs.constraints:
+        if (_lc_eval(A, full, r) * _lc_eval(B, full, r) - _lc_eval(C, full, r)) % r:
+            return False
+    return True
+
+
+def swap_AB_if_beneficial(cs: R1CS) -> R1CS:
+    """r1cs.hpp:193-215."""
+    ta = set()
+    tb = set()
+    for A, B, _ in cs.constraints:
+        ta.update(i for i, _ in A)
+        tb.update(i for i, _ in B)
+    if len(tb) > len(ta):
+        return R1CS(cs.num_inputs, cs.num_aux, [(B, A, C) for A, B, C in cs.constraints])
+    return cs
+
+
+def domain_size(cs: R1CS) -> int:
+    need = cs.num_constraints + cs.num_inputs + 1
+    m = 1
+    while m < need:
+        m *= 2
+    return m
+
+
+def lagrange_at(m: int, w: int, t: int, r: int) -> List[int]:
+    """evaluate_all_lagrange_polynomials on {w^i}: L_i(t) = (t^m - 1) w^i / (m (t - w^i))."""
+    tm = pow(t, m, r)
+    if tm == 1:  # t in the domain
+        out = [0] * m
+        x = 1
+        for i in range(m):
+            if x == t % r:
+                out[i] = 1
+            x = x * w % r
+        return out
+    z = (tm - 1) * pow(m, -1, r) % r
+    out = []
+    x = 1
+    for i in range(m):
+        out.append(z * x % r * pow((t - x) % r, -1, r) % r)
+        x = x * w % r
+    return out
+
+
+def qap_evaluate_at(cs: R1CS, t: int, w: int, r: int):
+    """r1cs_to_qap.hpp:138-187: (At, Bt, Ct, Ht, Zt) with At/Bt/Ct of length num_variables+1."""
+    m = domain_size(cs)
+    u = lagrange_at(m, w, t, r)
+    nv = cs.num_variables
+    At = [0] * (nv + 1)
+    Bt = [0] * (nv + 1)
+    Ct = [0] * (nv + 1)
+    for i in range(cs.num_inputs + 1):
+        At[i] = u[cs.num_constraints + i]
+    for i, (A, B, C) in enumerate(cs.constraints):
+        for idx, co in A:
+            At[idx] = (At[idx] + u[i] * co) % r
+        for idx, co in B:
+            Bt[idx] = (Bt[idx] + u[i] * co) % r
+        for idx, co in C:
+            Ct[idx] = (Ct[idx] + u[i] * co) % r
+    Ht = [pow(t, i, r) for i in range(m + 1)]
+    Zt = (pow(t, m, r) - 1) % r
+    return At, Bt, Ct, Ht, Zt
+
+
+def witness_map(cs: R1CS, primary, aux, w: int, g: int, r: int) -> List[int]:
+    """r1cs_to_qap.hpp:219-325 with d1=d2=d3=0: coefficients of H, length m+1."""
+    m = domain_size(cs)
+    full = list(primary) + list(aux)
+    aA = [0] * m
+    aB = [0] * m
+    aC = [0] * m
+    for i in range(cs.num_inputs + 1):
+        aA[i + cs.num_constraints] = full[i - 1] if i > 0 else 1
+    for i, (A, B, C) in enumerate(cs.constraints):
+        aA[i] = (aA[i] + _lc_eval(A, full, r)) % r
+        aB[i] = (aB[i] + _lc_eval(B, full, r)) % r
+        aC[i] = (aC[i] + _lc_eval(C, full, r)) % r
+    aA = ntt(multiply_by_coset(intt(aA, w, r), g, r), w, r)
+    aB = ntt(multiply_by_coset(intt(aB, w, r), g, r), w, r)
+    aC = ntt(multiply_by_coset(intt(aC, w, r), g, r), w, r)
+    zinv = pow((pow(g, m, r) - 1) % r, -1, r)  # divide_by_z_on_coset: Z(g w^i) = g^m - 1
+    H = [((aA[i] * aB[i] - aC[i]) % r) * zinv % r for i in range(m)]
+    H = multiply_by_coset(intt(H, w, r), pow(g, -1, r), r)
+    return H + [0]
+
+
+@dataclass
+class Groth16Key:
+    alpha_g1: object
+    beta_g1: object
+    beta_g2: object
+    delta_g1: object
+    delta_g2: object
+    A_query: list  # G1, len N+1
+    B_query: list  # (G2, G1) dense, len N+1 (None entries where B_i(t) == 0)
+    H_query: list  # G1, len m-1
+    L_query: list  # G1, len N-n
+    cs: R1CS
+
+
+def groth16_keygen(curve: Curve, cs: R1CS, trapdoor, w: int) -> Groth16Key:
+    """generator.hpp:86-236 with fixed (t, alpha, beta, gamma, delta) and the standard generators
+    (the reference draws random generators; deterministic_basic_process :240-377 fixes them)."""
+    r = curve.r
+    t, alpha, beta, gamma, delta = trapdoor
+    cs = swap_AB_if_beneficial(cs)
+    At, Bt, Ct, Ht, Zt = qap_evaluate_at(cs, t, w, r)
+    dinv = pow(delta, -1, r)
+    n = cs.num_inputs
+    N = cs.num_variables
+    Lt = [(beta * At[i] + alpha * Bt[i] + Ct[i]) * dinv % r for i in range(n + 1, N + 1)]
+    m = domain_size(cs)
+    Hs = [Ht[i] * Zt % r * dinv % r for i in range(m - 1)]
+    g1, g2 = curve.g1, curve.g2
+    A_query = g1.batch_mul_gen(At)
+    Bh = g1.batch_mul_gen(Bt)
+    Bg = g2.batch_mul_gen(Bt)
+    return Groth16Key(
+        g1.mul(g1.gen, alpha),
+        g1.mul(g1.gen, beta),
+        g2.mul(g2.gen, beta),
+        g1.mul(g1.gen, delta),
+        g2.mul(g2.gen, delta),
+        A_query,
+        list(zip(Bg, Bh)),
+        g1.batch_mul_gen(Hs),
+        g1.batch_mul_gen(Lt),
+        cs,
+    )
+
+
+def groth16_prove(curve: Curve, pk: Groth16Key, primary, aux, rr: int, ss: int, w: int):
+    """prover.hpp:73-158 with (r, s) injected.  Returns affine (A in G1, B in G2, C in G1)."""
+    r = curve.r
+    g1, g2 = curve.g1, curve.g2
+    cs = pk.cs
+    H = witness_map(cs, primary, aux, w, curve.fr_generator, r)
+    m = domain_size(cs)
+    assert H[m - 1] == 0 and H[m] == 0
+    cpa = [1] + list(primary) + list(aux)
+    N = cs.num_variables
+    n = cs.num_inputs
+    eA = msm_naive(g1, pk.A_query[: N + 1], cpa[: N + 1])
+    eBg = msm_naive(g2, [b[0] for b in pk.B_query], cpa[: N + 1])
+    eBh = msm_naive(g1, [b[1] for b in pk.B_query], cpa[: N + 1])
+    eH = msm_naive(g1, pk.H_query[: m - 1], H[: m - 1])
+    eL = msm_naive(g1, pk.L_query, cpa[n + 1 : N + 1])
+    gA = g1.add(g1.add(pk.alpha_g1, eA), g1.mul(pk.delta_g1, rr))
+    gB1 = g1.add(g1.add(pk.beta_g1, eBh), g1.mul(pk.delta_g1, ss))
+    gB2 = g2.add(g2.add(pk.beta_g2, eBg), g2.mul(pk.delta_g2, ss))
+    gC = g1.add(g1.add(eH, eL), g1.add(g1.mul(gA, ss), g1.mul(gB1, rr)))
+    gC = g1.add(gC, g1.neg(g1.mul(pk.delta_g1, rr * ss % r)))
+    return gA, gB2, gC
+
+
+def groth16_expected_in_exponent(curve: Curve, cs: R1CS, primary, aux, trapdoor, rr, ss, w):
+    """The proof a correct prover must output, computed from the trapdoor instead of the key
+    (comment formulas prover.hpp:141,145,151-153): three scalar multiplications of the generators."""
+    r = curve.r
+    t, alpha, beta, gamma, delta = trapdoor
+    cs = swap_AB_if_beneficial(cs)
+    At, Bt, Ct, Ht, Zt = qap_evaluate_at(cs, t, w, r)
+    cpa = [1] + list(primary) + list(aux)
+    a = (alpha + sum(x * y for x, y in zip(cpa, At)) + rr * delta) % r
+    b = (beta + sum(x * y for x, y in zip(cpa, Bt)) + ss * delta) % r
+    c_w = sum(x * y for x, y in zip(cpa, Ct)) % r
+    # A(t)B(t) - C(t) = H(t) Z(t)
+    a0 = (a - alpha - rr * delta) % r
+    b0 = (b - beta - ss * delta) % r
+    hz = (a0 * b0 - c_w) % r
+    n = cs.num_inputs
+    N = cs.num_variables
+    dinv = pow(delta, -1, r)
+    l = sum(cpa[i] * ((beta * At[i] + alpha * Bt[i] + Ct[i]) % r) for i in range(n + 1, N + 1)) % r
+    c = ((hz + l) * dinv + ss * a + rr * b - rr * ss % r * delta) % r
+    g1, g2 = curve.g1, curve.g2
+    return g1.mul(g1.gen, a), g2.mul(g2.gen, b), g1.mul(g1.gen, c)
+
+
+# --------------------------------------------------------------------------------------
+# the reference's KAT carrier (SnarkPack commitment-key openings)
+# --------------------------------------------------------------------------------------
+def ipp2_poly_coeffs(tr: Sequence[int], r_shift: int, r: int) -> List[int]:
+    """ipp2/prover.hpp:140-155."""
+    c = [1]
+    p2 = r_shift % r
+    for x in tr:
+        c = c + [cj * (x * p2 % r) % r for cj in c]
+        p2 = p2 * p2 % r
+    return c
+
+
+def ipp2_poly_eval(tr: Sequence[int], z: int, r_shift: int, r: int) -> int:
+    """ipp2/prover.hpp:99-125."""
+    pw = z * r_shift % r
+    res = 1
+    for x in tr:
+        res = res * (1 + x * pw) % r
+        pw = pw * pw % r
+    return res
+
+
+def _quotient_by_linear(f: Sequence[int], fz: int, z: int, r: int) -> List[int]:
+    """(f(X) - fz)/(X - z), padded with zeros to len(f) (ipp2/prover.hpp:171-200)."""
+    g = list(f)
+    g[0] = (g[0] - fz) % r
+    n = len(g)
+    q = [0] * n
+    carry = 0
+    for i in range(n - 1, 0, -1):
+        carry = (g[i] + carry * z) % r
+        q[i - 1] = carry
+    assert (g[0] + carry * z) % r == 0, "remainder must vanish"
+    return q
+
+
+def structured_generators(G: Group, n: int, s: int):
+    """ipp2/srs.hpp:44-56: {s^i * G}."""
+    out = [G.gen]
+    for _ in range(1, n):
+        out.append(G.mul(out[-1], s))
+    return out
+
+
+def ipp2_prove_commitment_v(curve: Curve, n, alpha, beta, tr, z):
+    r = curve.r
+    f = ipp2_poly_coeffs(tr, 1, r)
+    fz = ipp2_poly_eval(tr, z, 1, r)
+    q = _quotient_by_linear(f, fz, z, r)
+    ha = structured_generators(curve.g2, n, alpha)
+    hb = structured_generators(curve.g2, n, beta)
+    return q, ha, hb
+
+
+def ipp2_prove_commitment_w(curve: Curve, n, alpha, beta, tr, r_shift, z):
+    r = curve.r
+    f = [0] * n + ipp2_poly_coeffs(tr, r_shift, r)
+    fwz = ipp2_poly_eval(tr, z, r_shift, r) * pow(z, n, r) % r
+    q = _quotient_by_linear(f, fwz, z, r)
+    ga = structured_generators(curve.g1, 2 * n, alpha)
+    gb = structured_generators(curve.g1, 2 * n, beta)
+    return q, ga, gb
+
+
+# --------------------------------------------------------------------------------------
+# limb helpers shared by the tests (canonical little-endian u64 limbs at the C ABI)
+# --------------------------------------------------------------------------------------
+def to_limbs(v: int, n: int) -> List[int]:
+    return [(v >> (64 * i)) & MASK64 for i in range(n)]
+
+
+def from_limbs(limbs: Sequence[int]) -> int:
+    v = 0
+    for i, l in enumerate(limbs):
+        v |= int(l) << (64 * i)
+    return v
