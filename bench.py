@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json headline metric on MI355X: MSM Mpoints/s, BLS12-381 G1, 2^20 points.
+
+One step = one pass of the hot path (zkhip_msm_dev: scalars and bases resident in HBM, Jacobian result
+left in HBM) over one batch of synthetic input.  N = 1: BASELINE configs[1].  N > 1 (one process per GPU,
+launched by torch.distributed.run): point-range sharding -- every rank owns 2^20 bases and scalars of a
+job of N * 2^20 points, computes its partial sum, then one all-gather of the 144-byte partial results
+over RCCL and an on-device fold (weak scaling; no other collective on the data path).
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+LOG_N = 20
+ALG_BYTES_PER_POINT = 128  # BLS12-381 G1: 96 B affine base + 32 B scalar, each read once
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def load_pkg():
+    pkg_dir = os.path.join(ROOT, "crypto3-zk_amd")
+    spec = importlib.util.spec_from_file_location("crypto3_zk_amd", os.path.join(pkg_dir, "__init__.py"),
+                                                  submodule_search_locations=[pkg_dir])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["crypto3_zk_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def random_scalars(np, n, seed):
+    """uniform in [0, r) by rejection from 255-bit draws; (n, 4) u64 canonical little-endian"""
+    r_limbs = [0xffffffff00000001, 0x53bda402fffe5bfe, 0x3339d80809a1d805, 0x73eda753299d7d48]
+    rng = np.random.default_rng(seed)
+    out = np.empty((n, 4), dtype=np.uint64)
+    todo = np.arange(n)
+    while todo.size:
+        v = rng.integers(0, 1 << 64, size=(todo.size, 4), dtype=np.uint64)
+        v[:, 3] &= np.uint64((1 << 63) - 1)
+        lt = np.zeros(todo.size, dtype=bool)
+        eq = np.ones(todo.size, dtype=bool)
+        for k in (3, 2, 1, 0):
+            lt |= eq & (v[:, k] < np.uint64(r_limbs[k]))
+            eq &= v[:, k] == np.uint64(r_limbs[k])
+        out[todo[lt]] = v[lt]
+        todo = todo[~lt]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=LOG_N, help="points per GPU = 2^log_n (default: the BASELINE size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch  # first: libzkhip.so must share torch's HIP runtime
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: zkhip has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)  # nccl == RCCL on ROCm
+
+    zk = load_pkg()
+    ctx = zk.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+
+    n = 1 << args.log_n
+    # synthetic input: bases P_i = k_i * G (device fixed-base kernel), scalars uniform in [0, r); per-rank seeds
+    ks = random_scalars(np, n, 1000 + rank)
+    bases = ctx.bases_from_scalars(zk.BLS12_381, zk.G1, ks)
+    scalars = random_scalars(np, n, 2000 + rank)
+    d_scalars = torch.from_numpy(scalars.view(np.int64)).to(f"cuda:{local_rank}")
+    d_out = torch.zeros(3 * 6, dtype=torch.int64, device=f"cuda:{local_rank}")
+    d_gather = torch.zeros(world * 3 * 6, dtype=torch.int64, device=f"cuda:{local_rank}") if world > 1 else None
+    d_total = torch.zeros(3 * 6, dtype=torch.int64, device=f"cuda:{local_rank}")
+
+    def step():
+        ctx.msm_dev(bases, d_scalars.data_ptr(), d_out.data_ptr(), 0, n)
+        if world > 1:
+            dist.all_gather_into_tensor(d_gather, d_out)
+            ctx.jacobian_sum_dev(zk.BLS12_381, zk.G1, d_gather.data_ptr(), world, d_total.data_ptr())
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.profile_reset()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ctx.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    prof = ctx.profile_dump()
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * n * args.steps / elapsed / 1e6
+        dom_ms, dom_cnt = prof.get("msm_bucket_acc", (0.0, 0))
+        dom_avg_ms = dom_ms / max(1, dom_cnt)
+        achieved = (ALG_BYTES_PER_POINT * n) / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
+        line = {
+            "metric": "MSM Mpoints/sec, BLS12-381 G1 Pippenger, 2^%d points per GPU" % args.log_n,
+            "value": round(value, 4),
+            "unit": "Mpoints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 limbs (381-bit Montgomery Fq, 255-bit Fr)",
+            "data": "synthetic",
+            "config": {"workload": "BLS12-381 G1 Pippenger MSM, 2^%d random points/scalars per GPU, bases resident" % args.log_n,
+                       "points_per_gpu": n, "parallelism": "point-range shard x%d + all-gather of partial sums" % world},
+            "roofline": {"bound": "hbm", "kernel": "msm_bucket_acc", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "avg_launch_ms": round(dom_avg_ms, 4), "algorithmic_bytes_per_launch": ALG_BYTES_PER_POINT * n},
+            "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(np, bases)
+        print(json.dumps(line), flush=True)
+    fence()
+    bases.free()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(np, bases):
+    """The oracle's BDLO12 Pippenger (the CPU restatement of algebra::multiexp with chunks = #threads, as
+    prover.hpp:94-99) timed on this host on a bounded sample of the same workload.  Reported, not a target."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cport as cp
+
+    cores = cp.num_threads()
+    sample = min(bases.n, 1 << 19)
+    pts, inf = bases.download(0, sample)
+    hb = cp.Bases(0, 1, pts, inf)
+    sc = random_scalars(np, sample, 77)
+    t0 = time.perf_counter()
+    hb.msm(sc, chunks=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample / dt / 1e6, 5), "unit": "Mpoints/s", "cores": cores, "kind": "port",
+            "sample": "2^%d of the 2^20 points, one MSM, chunks = %d OpenMP threads, %.1f s" % (sample.bit_length() - 1, cores, dt)}
+
+
+if __name__ == "__main__":
+    main()

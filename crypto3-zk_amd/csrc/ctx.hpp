@@ -1,0 +1,151 @@
+// Host-side context shared by the kernel families: stream, workspace arena, per-kernel HIP-event profiler.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/zkhip.h"
+
+#define ZK_HIP_CHECK(ctx, expr)                                                                  \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess) {                                                                 \
+            (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(e__);              \
+            return e__ == hipErrorOutOfMemory ? ZKHIP_ERR_OOM : ZKHIP_ERR_HIP;                   \
+        }                                                                                        \
+    } while (0)
+
+#define ZK_TRY(expr)              \
+    do {                          \
+        int rc__ = (expr);        \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+struct zkhip_bases {
+    int curve, group;
+    size_t n;
+    size_t stride_u32;  // u32 words per affine point (2 * coordinate limbs)
+    uint32_t *d;        // Montgomery-form affine points, (0,0) = infinity
+};
+
+struct ZkEventPair {
+    hipEvent_t a, b;
+};
+
+struct ZkProfile {
+    bool on = false;
+    std::vector<std::pair<std::string, ZkEventPair>> pending;
+    std::vector<ZkEventPair> pool;
+    std::map<std::string, std::pair<double, uint64_t>> acc;
+};
+
+struct NttTables;  // ntt.hip
+
+struct zkhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string last_error;
+    // bump-allocated workspace, grown on demand, reused across calls
+    char *ws = nullptr;
+    size_t ws_cap = 0, ws_off = 0;
+    // pinned staging for small results
+    void *pinned = nullptr;
+    size_t pinned_cap = 0;
+    // options
+    int opt_msm_window_bits = 0;
+    int opt_msm_segment_log = 5;
+    int opt_ntt_radix_log = 8;
+    int opt_ntt_tile_log = 3;
+    ZkProfile prof;
+    std::vector<NttTables *> ntt_tables;
+
+    int ws_reserve(size_t bytes) {
+        if (bytes <= ws_cap) return 0;
+        if (ws) {
+            hipError_t e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) {
+                last_error = hipGetErrorString(e);
+                return ZKHIP_ERR_HIP;
+            }
+            (void)hipFree(ws);
+            ws = nullptr;
+            ws_cap = 0;
+        }
+        size_t cap = bytes + (bytes >> 3) + (1 << 20);
+        hipError_t e = hipMalloc((void **)&ws, cap);
+        if (e != hipSuccess) {
+            last_error = std::string("hipMalloc(workspace): ") + hipGetErrorString(e);
+            return ZKHIP_ERR_OOM;
+        }
+        ws_cap = cap;
+        return 0;
+    }
+    void ws_reset() { ws_off = 0; }
+    template <class T>
+    T *ws_take(size_t count) {
+        size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+        T *p = reinterpret_cast<T *>(ws + ws_off);
+        ws_off += bytes;
+        return p;
+    }
+    static size_t ws_round(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+
+    // ---- profiler
+    void prof_begin(const char *name) {
+        if (!prof.on) return;
+        ZkEventPair ev;
+        if (!prof.pool.empty()) {
+            ev = prof.pool.back();
+            prof.pool.pop_back();
+        } else {
+            (void)hipEventCreate(&ev.a);
+            (void)hipEventCreate(&ev.b);
+        }
+        (void)hipEventRecord(ev.a, stream);
+        prof.pending.emplace_back(name, ev);
+    }
+    void prof_end() {
+        if (!prof.on) return;
+        (void)hipEventRecord(prof.pending.back().second.b, stream);
+    }
+    void prof_collect() {
+        if (prof.pending.empty()) return;
+        (void)hipStreamSynchronize(stream);
+        for (auto &p : prof.pending) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, p.second.a, p.second.b);
+            auto &a = prof.acc[p.first];
+            a.first += ms;
+            a.second += 1;
+            prof.pool.push_back(p.second);
+        }
+        prof.pending.clear();
+    }
+};
+
+// launch + profile wrapper: ZK_LAUNCH(ctx, "name", kernel, grid, block, lds, args...)
+#define ZK_LAUNCH(ctx, name, kernel, grid, block, lds, ...)                        \
+    do {                                                                           \
+        (ctx)->prof_begin(name);                                                   \
+        hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, __VA_ARGS__);  \
+        (ctx)->prof_end();                                                         \
+        ZK_HIP_CHECK(ctx, hipGetLastError());                                      \
+    } while (0)
+
+// implemented in msm.hip / ntt.hip
+int zk_msm_run(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac);
+size_t zk_coord_limbs64(int curve, int group);  // u64 limbs per coordinate (Fq: 6/4, Fq2: 12/8)
+int zk_bases_to_mont(zkhip_ctx *ctx, zkhip_bases *b, const uint8_t *d_inf);
+int zk_bases_from_mont(zkhip_ctx *ctx, const zkhip_bases *b, size_t offset, size_t n, uint32_t *d_out, uint8_t *d_inf);
+int zk_bases_mul(zkhip_ctx *ctx, zkhip_bases *b, const uint32_t *d_base_canonical /* nullable: generator */, const uint32_t *d_scalars);
+int zk_jac_sum(zkhip_ctx *ctx, int curve, int group, const uint32_t *d_pts, size_t count, uint32_t *d_out);
+int zk_jac_to_affine(zkhip_ctx *ctx, int curve, int group, const uint32_t *d_jac, uint32_t *d_aff, uint8_t *d_inf);
+int zk_ntt_run(zkhip_ctx *ctx, int curve, uint32_t *d_data, size_t log_m, size_t batch, const uint64_t *omega, int inverse,
+               const uint64_t *coset);
+void zk_ntt_free_tables(zkhip_ctx *ctx);

@@ -1,0 +1,380 @@
+// Pippenger multi-scalar multiplication for gfx950 (MI355X), G1 and G2 of BLS12-381 / BN254.
+//
+// Replaces algebra::multiexp<multiexp_method_BDLO12> / multiexp_with_mixed_addition as called at
+//   zk/snark/systems/ppzksnark/r1cs_gg_ppzksnark/prover.hpp:108-139   (A, B, H, L queries)
+//   zk/commitments/polynomial/kzg.hpp:143-148, 409-435                  (KZG commit)
+//   zk/commitments/polynomial/knowledge_commitment_multiexp.hpp:107     (sparse (G2,G1) query)
+//
+// Data layout in HBM
+//   bases    : n x {x, y}            Montgomery form, u32 limbs, AoS, (0,0) = infinity   (resident)
+//   scalars  : n x 8 u32             canonical little-endian
+//   dig      : W x n u32             signed c-bit digit of scalar i in window w: (|d|-1) | sign<<31, NONE if d = 0
+//   hist/offs: W*B (+1) u32          bucket sizes / exclusive prefix (B = 2^(c-1) buckets per window)
+//   idx      : (#non-zero digits) u32  point index | sign<<31, grouped by (window, bucket)
+//   buckets  : W*B XYZZ              bucket sums
+//   segsum   : W*nseg XYZZ           per-segment weighted sums of the bucket reduction
+//   winsum   : W XYZZ                per-window sums
+//
+// Kernels (all integer VALU; no MFMA -- this is modular arithmetic, not a dense contraction):
+//   msm_digits      scalar -> signed digits + bucket histogram      (streams 32 B/scalar, coalesced)
+//   msm_scan        exclusive prefix over W*B counters
+//   msm_scatter     counting-sort scatter of point indices by (window, bucket)
+//   msm_bucket_acc  one lane per bucket: gather affine points, XYZZ mixed additions     <- dominant
+//   msm_bucket_red  running-sum reduction of L-bucket segments, weighted by segment offset
+//   msm_window_sum  LDS tree reduction of segment sums, one workgroup per window
+//   msm_final       Horner over the windows, XYZZ -> Jacobian, Montgomery -> canonical
+// Point order inside a bucket depends on atomic arrival order; the group law is exact, so the sum
+// (compared in affine) does not.
+#include <algorithm>
+
+#define ZK_NOINLINE_MUL 1
+#include "ctx.hpp"
+#include "curve.hpp"
+
+using namespace zkhip;
+
+#include "msm_recode.hpp"
+
+__global__ __launch_bounds__(256) void msm_digits(const uint32_t *__restrict__ scalars, uint32_t n, int c, int W,
+                                                  uint32_t *__restrict__ dig, uint32_t *__restrict__ hist) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *s = scalars + (size_t)i * 8;
+    const uint32_t B = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (int w = 0; w < W; ++w) {
+        uint32_t out = msm_recode(s, w, c, carry);
+        if (out != DIG_NONE) atomicAdd(&hist[(size_t)w * B + (out & 0x7FFFFFFFu)], 1u);
+        dig[(size_t)w * n + i] = out;
+    }
+}
+
+// exclusive scan of `count` u32 counters by one 1024-thread workgroup; offs[count] = total; cursor = copy
+__global__ __launch_bounds__(1024) void msm_scan(const uint32_t *__restrict__ hist, uint32_t count, uint32_t *__restrict__ offs,
+                                                 uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t part[1024];
+    uint32_t t = threadIdx.x;
+    uint32_t per = (count + 1023) / 1024;
+    uint32_t lo = min(count, t * per), hi = min(count, lo + per);
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += hist[i];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - s;
+    for (uint32_t i = lo; i < hi; ++i) {
+        offs[i] = run;
+        cursor[i] = run;
+        run += hist[i];
+    }
+    if (t == 1023) offs[count] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void msm_scatter(const uint32_t *__restrict__ dig, uint32_t n, int c, uint32_t *__restrict__ cursor,
+                                                   uint32_t *__restrict__ idx) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t w = blockIdx.y;
+    if (i >= n) return;
+    const uint32_t B = 1u << (c - 1);
+    uint32_t d = dig[(size_t)w * n + i];
+    if (d == DIG_NONE) return;
+    uint32_t pos = atomicAdd(&cursor[(size_t)w * B + (d & 0x7FFFFFFFu)], 1u);
+    idx[pos] = i | (d & 0x80000000u);
+}
+
+template <class F>
+__global__ __launch_bounds__(256) void msm_bucket_acc(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ offs,
+                                                      const uint32_t *__restrict__ idx, uint32_t nbuckets, uint32_t *__restrict__ buckets) {
+    constexpr int NL = FieldIO<F>::NL;
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nbuckets) return;
+    uint32_t lo = offs[g], hi = offs[g + 1];
+    XYZZ<F> acc = XYZZ<F>::infinity();
+    for (uint32_t k = lo; k < hi; ++k) {
+        uint32_t e = idx[k];
+        Affine<F> p = affine_load<F>(bases + (size_t)(e & 0x7FFFFFFFu) * (2 * NL));
+        acc = xyzz_madd(acc, p, (e >> 31) != 0);
+    }
+    xyzz_store<F>(buckets + (size_t)g * (4 * NL), acc);
+}
+
+// segment `seg` of window `w` covers buckets [seg*L, seg*L + L) (bucket b holds digit value b + 1):
+//   out = sum_b (b + 1) * bucket[b]  restricted to the segment
+//       = sum_b (b - seg*L + 1) * bucket[b]  +  (seg*L) * sum_b bucket[b]
+template <class F>
+__global__ __launch_bounds__(64) void msm_bucket_red(const uint32_t *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t nseg,
+                                                     uint32_t total, uint32_t *__restrict__ segsum) {
+    constexpr int NL = FieldIO<F>::NL;
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;  // = w * nseg + seg
+    if (g >= total) return;
+    uint32_t w = g / nseg, seg = g % nseg;
+    const uint32_t *base = buckets + ((size_t)w * B + (size_t)seg * L) * (4 * NL);
+    XYZZ<F> run = XYZZ<F>::infinity(), sum = XYZZ<F>::infinity();
+    for (int b = (int)L - 1; b >= 0; --b) {
+        run = xyzz_add(run, xyzz_load<F>(base + (size_t)b * (4 * NL)));
+        sum = xyzz_add(sum, run);
+    }
+    if (seg != 0) sum = xyzz_add(sum, xyzz_mul_small(run, seg * L));
+    xyzz_store<F>(segsum + (size_t)g * (4 * NL), sum);
+}
+
+// one workgroup per window: winsum[w] = sum_seg segsum[w][seg]
+template <class F>
+__global__ __launch_bounds__(128) void msm_window_sum(const uint32_t *__restrict__ segsum, uint32_t nseg, uint32_t *__restrict__ winsum) {
+    constexpr int NL = FieldIO<F>::NL;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t w = blockIdx.x, t = threadIdx.x;
+    XYZZ<F> acc = XYZZ<F>::infinity();
+    for (uint32_t s = t; s < nseg; s += blockDim.x) acc = xyzz_add(acc, xyzz_load<F>(segsum + ((size_t)w * nseg + s) * (4 * NL)));
+    xyzz_store<F>(lds + (size_t)t * (4 * NL), acc);
+    __syncthreads();
+    for (uint32_t d = blockDim.x / 2; d >= 1; d >>= 1) {
+        if (t < d) {
+            acc = xyzz_add(xyzz_load<F>(lds + (size_t)t * (4 * NL)), xyzz_load<F>(lds + (size_t)(t + d) * (4 * NL)));
+            xyzz_store<F>(lds + (size_t)t * (4 * NL), acc);
+        }
+        __syncthreads();
+    }
+    if (t == 0) xyzz_store<F>(winsum + (size_t)w * (4 * NL), acc);
+}
+
+// result = sum_w 2^(c w) winsum[w]  (Horner from the top window), emitted as canonical Jacobian
+template <class F>
+__global__ void msm_final(const uint32_t *__restrict__ winsum, int W, int c, uint32_t *__restrict__ out_jac) {
+    constexpr int NL = FieldIO<F>::NL;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    XYZZ<F> acc = XYZZ<F>::infinity();
+    for (int w = W - 1; w >= 0; --w) {
+        if (!acc.is_inf())
+            for (int i = 0; i < c; ++i) acc = xyzz_dbl(acc);
+        acc = xyzz_add(acc, xyzz_load<F>(winsum + (size_t)w * (4 * NL)));
+    }
+    Jacobian<F> j = xyzz_to_jacobian(acc);
+    FieldIO<F>::store(out_jac, fp_from_mont(j.X));
+    FieldIO<F>::store(out_jac + NL, fp_from_mont(j.Y));
+    FieldIO<F>::store(out_jac + 2 * NL, fp_from_mont(j.Z));
+}
+
+// ---- bases maintenance ----------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(256) void bases_to_mont(uint32_t *__restrict__ pts, const uint8_t *__restrict__ inf, uint32_t n) {
+    constexpr int NL = FieldIO<F>::NL;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t *p = pts + (size_t)i * (2 * NL);
+    Affine<F> a;
+    if (inf != nullptr && inf[i]) a = Affine<F>::infinity();
+    else {
+        a = affine_load<F>(p);
+        a.x = fp_to_mont(a.x);
+        a.y = fp_to_mont(a.y);
+    }
+    affine_store<F>(p, a);
+}
+
+template <class F>
+__global__ __launch_bounds__(256) void bases_from_mont(const uint32_t *__restrict__ pts, uint32_t n, uint32_t *__restrict__ out,
+                                                       uint8_t *__restrict__ inf) {
+    constexpr int NL = FieldIO<F>::NL;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> a = affine_load<F>(pts + (size_t)i * (2 * NL));
+    inf[i] = a.is_inf() ? 1 : 0;
+    a.x = fp_from_mont(a.x);
+    a.y = fp_from_mont(a.y);
+    affine_store<F>(out + (size_t)i * (2 * NL), a);
+}
+
+// pts[i] = scalars[i] * base, double-and-add from the top bit, then one inversion per point
+template <class F>
+__global__ __launch_bounds__(64) void bases_mul(uint32_t *__restrict__ pts, const uint32_t *__restrict__ base_canonical,
+                                                const uint32_t *__restrict__ scalars, uint32_t n) {
+    constexpr int NL = FieldIO<F>::NL;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> g = affine_load<F>(base_canonical);
+    g.x = fp_to_mont(g.x);
+    g.y = fp_to_mont(g.y);
+    const uint32_t *s = scalars + (size_t)i * 8;
+    XYZZ<F> acc = XYZZ<F>::infinity();
+    for (int b = 255; b >= 0; --b) {
+        acc = xyzz_dbl(acc);
+        if ((s[b >> 5] >> (b & 31)) & 1) acc = xyzz_madd(acc, g);
+    }
+    affine_store<F>(pts + (size_t)i * (2 * NL), xyzz_to_affine(acc));
+}
+
+template <class F>
+__global__ void jac_to_affine_k(const uint32_t *__restrict__ jac, uint32_t *__restrict__ aff, uint8_t *__restrict__ inf) {
+    constexpr int NL = FieldIO<F>::NL;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    F X = fp_to_mont(FieldIO<F>::load(jac)), Y = fp_to_mont(FieldIO<F>::load(jac + NL)), Z = fp_to_mont(FieldIO<F>::load(jac + 2 * NL));
+    if (Z.is_zero()) {
+        inf[0] = 1;
+        affine_store<F>(aff, Affine<F>::infinity());
+        return;
+    }
+    F zi = fp_inv(Z);
+    F zi2 = fp_sqr(zi);
+    inf[0] = 0;
+    Affine<F> a = {fp_from_mont(X * zi2), fp_from_mont(Y * zi2 * zi)};
+    affine_store<F>(aff, a);
+}
+
+// out = sum_i jac[i] (canonical Jacobian in and out); one lane, `count` is the number of GPUs
+template <class F>
+__global__ void jac_sum_k(const uint32_t *__restrict__ jac, uint32_t count, uint32_t *__restrict__ out) {
+    constexpr int NL = FieldIO<F>::NL;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    XYZZ<F> acc = XYZZ<F>::infinity();
+    for (uint32_t i = 0; i < count; ++i) {
+        const uint32_t *p = jac + (size_t)i * 3 * NL;
+        F X = fp_to_mont(FieldIO<F>::load(p)), Y = fp_to_mont(FieldIO<F>::load(p + NL)), Z = fp_to_mont(FieldIO<F>::load(p + 2 * NL));
+        if (Z.is_zero()) continue;
+        F zz = fp_sqr(Z);
+        XYZZ<F> q = {X, Y, zz, zz * Z};  // Jacobian (X, Y, Z) is XYZZ (X, Y, Z^2, Z^3)
+        acc = xyzz_add(acc, q);
+    }
+    Jacobian<F> j = xyzz_to_jacobian(acc);
+    FieldIO<F>::store(out, fp_from_mont(j.X));
+    FieldIO<F>::store(out + NL, fp_from_mont(j.Y));
+    FieldIO<F>::store(out + 2 * NL, fp_from_mont(j.Z));
+}
+
+// ---- host side ------------------------------------------------------------------------------------
+size_t zk_coord_limbs64(int curve, int group) {
+    size_t fq = curve == CURVE_BLS12_381 ? 6 : 4;
+    return fq * (group == GROUP_G2 ? 2 : 1);
+}
+
+#define ZK_DISPATCH_CG(curve, group, ...)                               \
+    do {                                                                \
+        if (curve == CURVE_BLS12_381 && group == GROUP_G1) {            \
+            typedef CurveTraits<CURVE_BLS12_381, GROUP_G1>::F F;        \
+            __VA_ARGS__;                                                \
+        } else if (curve == CURVE_BLS12_381 && group == GROUP_G2) {     \
+            typedef CurveTraits<CURVE_BLS12_381, GROUP_G2>::F F;        \
+            __VA_ARGS__;                                                \
+        } else if (curve == CURVE_BN254 && group == GROUP_G1) {         \
+            typedef CurveTraits<CURVE_BN254, GROUP_G1>::F F;            \
+            __VA_ARGS__;                                                \
+        } else if (curve == CURVE_BN254 && group == GROUP_G2) {         \
+            typedef CurveTraits<CURVE_BN254, GROUP_G2>::F F;            \
+            __VA_ARGS__;                                                \
+        } else                                                          \
+            return ZKHIP_ERR_INVALID;                                   \
+    } while (0)
+
+int zk_bases_to_mont(zkhip_ctx *ctx, zkhip_bases *b, const uint8_t *d_inf) {
+    if (b->n == 0) return 0;
+    dim3 grid((unsigned)((b->n + 255) / 256)), block(256);
+    ZK_DISPATCH_CG(b->curve, b->group, ZK_LAUNCH(ctx, "bases_to_mont", bases_to_mont<F>, grid, block, 0, b->d, d_inf, (uint32_t)b->n));
+    return 0;
+}
+
+int zk_bases_from_mont(zkhip_ctx *ctx, const zkhip_bases *b, size_t offset, size_t n, uint32_t *d_out, uint8_t *d_inf) {
+    if (n == 0) return 0;
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    const uint32_t *src = b->d + offset * b->stride_u32;
+    ZK_DISPATCH_CG(b->curve, b->group, ZK_LAUNCH(ctx, "bases_from_mont", bases_from_mont<F>, grid, block, 0, src, (uint32_t)n, d_out, d_inf));
+    return 0;
+}
+
+int zk_bases_mul(zkhip_ctx *ctx, zkhip_bases *b, const uint32_t *d_base_canonical, const uint32_t *d_scalars) {
+    if (b->n == 0) return 0;
+    dim3 grid((unsigned)((b->n + 63) / 64)), block(64);
+    ZK_DISPATCH_CG(b->curve, b->group, ZK_LAUNCH(ctx, "bases_mul", bases_mul<F>, grid, block, 0, b->d, d_base_canonical, d_scalars, (uint32_t)b->n));
+    return 0;
+}
+
+int zk_jac_to_affine(zkhip_ctx *ctx, int curve, int group, const uint32_t *d_jac, uint32_t *d_aff, uint8_t *d_inf) {
+    ZK_DISPATCH_CG(curve, group, ZK_LAUNCH(ctx, "jac_to_affine", jac_to_affine_k<F>, dim3(1), dim3(64), 0, d_jac, d_aff, d_inf));
+    return 0;
+}
+
+int zk_jac_sum(zkhip_ctx *ctx, int curve, int group, const uint32_t *d_pts, size_t count, uint32_t *d_out) {
+    ZK_DISPATCH_CG(curve, group, ZK_LAUNCH(ctx, "jac_sum", jac_sum_k<F>, dim3(1), dim3(64), 0, d_pts, (uint32_t)count, d_out));
+    return 0;
+}
+
+static int ilog2(size_t v) {
+    int l = 0;
+    while (((size_t)2 << l) <= v) ++l;
+    return l;
+}
+
+template <class F>
+static int msm_run_t(zkhip_ctx *ctx, const uint32_t *d_bases, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac) {
+    constexpr int NL = FieldIO<F>::NL;
+    // window size: 2^(c-1) buckets per window, about n / 2^(c-1) * ... points per bucket
+    int c = ctx->opt_msm_window_bits;
+    if (c <= 0) c = std::max(2, std::min(16, ilog2(n) - 4));
+    c = std::max(2, std::min(16, c));
+    const int scalar_bits_total = 256;  // Fr < 2^255: one spare bit absorbs the signed-digit carry
+    const int W = (scalar_bits_total + c - 1) / c;
+    const uint32_t B = 1u << (c - 1);
+    const uint32_t nb = (uint32_t)W * B;
+    uint32_t L = std::min<uint32_t>(B, 1u << std::max(0, ctx->opt_msm_segment_log));
+    const uint32_t nseg = B / L;
+
+    size_t need = 0;
+    need += zkhip_ctx::ws_round((size_t)W * n * 4);        // dig
+    need += zkhip_ctx::ws_round((size_t)nb * 4);           // hist
+    need += zkhip_ctx::ws_round(((size_t)nb + 1) * 4);     // offs
+    need += zkhip_ctx::ws_round((size_t)nb * 4);           // cursor
+    need += zkhip_ctx::ws_round((size_t)W * n * 4);        // idx
+    need += zkhip_ctx::ws_round((size_t)nb * 4 * NL * 4);  // buckets
+    need += zkhip_ctx::ws_round((size_t)W * nseg * 4 * NL * 4);
+    need += zkhip_ctx::ws_round((size_t)W * 4 * NL * 4);
+    ZK_TRY(ctx->ws_reserve(need));
+    ctx->ws_reset();
+    uint32_t *dig = ctx->ws_take<uint32_t>((size_t)W * n);
+    uint32_t *hist = ctx->ws_take<uint32_t>(nb);
+    uint32_t *offs = ctx->ws_take<uint32_t>((size_t)nb + 1);
+    uint32_t *cursor = ctx->ws_take<uint32_t>(nb);
+    uint32_t *idx = ctx->ws_take<uint32_t>((size_t)W * n);
+    uint32_t *buckets = ctx->ws_take<uint32_t>((size_t)nb * 4 * NL);
+    uint32_t *segsum = ctx->ws_take<uint32_t>((size_t)W * nseg * 4 * NL);
+    uint32_t *winsum = ctx->ws_take<uint32_t>((size_t)W * 4 * NL);
+
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(hist, 0, (size_t)nb * 4, ctx->stream));
+    unsigned gn = (unsigned)((n + 255) / 256);
+    ZK_LAUNCH(ctx, "msm_digits", msm_digits, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, c, W, dig, hist);
+    ZK_LAUNCH(ctx, "msm_scan", msm_scan, dim3(1), dim3(1024), 0, hist, nb, offs, cursor);
+    ZK_LAUNCH(ctx, "msm_scatter", msm_scatter, dim3(gn, W), dim3(256), 0, dig, (uint32_t)n, c, cursor, idx);
+    ZK_LAUNCH(ctx, "msm_bucket_acc", msm_bucket_acc<F>, dim3((nb + 255) / 256), dim3(256), 0, d_bases, offs, idx, nb, buckets);
+    uint32_t tot = (uint32_t)W * nseg;
+    ZK_LAUNCH(ctx, "msm_bucket_red", msm_bucket_red<F>, dim3((tot + 63) / 64), dim3(64), 0, buckets, B, L, nseg, tot, segsum);
+    unsigned wthreads = 128;
+    size_t lds = (size_t)wthreads * 4 * NL * 4;
+    ZK_LAUNCH(ctx, "msm_window_sum", msm_window_sum<F>, dim3(W), dim3(wthreads), lds, segsum, nseg, winsum);
+    ZK_LAUNCH(ctx, "msm_final", msm_final<F>, dim3(1), dim3(64), 0, winsum, W, c, d_out_jac);
+    return 0;
+}
+
+template <class F>
+__global__ void msm_write_infinity(uint32_t *out_jac) {
+    constexpr int NL = FieldIO<F>::NL;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    F one = fp_from_mont(F::one());
+    FieldIO<F>::store(out_jac, one);
+    FieldIO<F>::store(out_jac + NL, one);
+    FieldIO<F>::store(out_jac + 2 * NL, F::zero());
+}
+
+int zk_msm_run(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac) {
+    if (offset + n > bases->n) return ZKHIP_ERR_RANGE;
+    if (n >= (1ull << 31)) return ZKHIP_ERR_RANGE;
+    const uint32_t *d_b = bases->d + offset * bases->stride_u32;
+    if (n == 0) {
+        ZK_DISPATCH_CG(bases->curve, bases->group, ZK_LAUNCH(ctx, "msm_write_infinity", msm_write_infinity<F>, dim3(1), dim3(64), 0, d_out_jac));
+        return 0;
+    }
+    ZK_DISPATCH_CG(bases->curve, bases->group, return msm_run_t<F>(ctx, d_b, n, d_scalars, d_out_jac));
+    return 0;
+}

@@ -1,0 +1,326 @@
+// Radix-2 number-theoretic transform over the scalar field (BLS12-381 Fr / BN254 Fr) for gfx950.
+//
+// Replaces evaluation_domain<F>::fft / inverse_fft and math::multiply_by_coset as called at
+//   zk/snark/reductions/r1cs_to_qap.hpp:250-315 (7 transforms per Groth16 proof),
+//   zk/snark/arithmetization/plonk/detail/column_polynomial.hpp:53,
+//   polynomial_dfs::coefficients()/resize() inside kzg.hpp:431 and basic_fri.hpp:452-455.
+// Natural order in, natural order out, out[i] = sum_j in[j] omega^(ij): the result is the DFT itself,
+// so it is bit-identical to any correct radix-2 implementation.
+//
+// Algorithm: multi-pass Stockham autosort.  m = R_1 R_2 ... R_p, R_i = 2^(s_i), s_i <= 8.  Pass i with
+// running sub-transform size Ns = R_1...R_(i-1) does, for every j in [0, m/R):
+//     k = j mod Ns;   u[t] = x[j + t m/R] * omega_(Ns R)^(k t);   v = DFT_R(u);   y[(j-k) R + k + t' Ns] = v[t']
+// (tests/test_ntt_model.py replays this index arithmetic line by line on the CPU against the O(n^2) DFT.)
+// One workgroup owns a tile of T consecutive j's x all R values of t: R*T elements staged in LDS
+// (two 16-byte planes per element so that ds_read_b128/ds_write_b128 are conflict-free), s_i radix-2 DIF
+// stages run in LDS, and the bit-reversed read-out restores natural order of t'.  Global reads are runs
+// of T*32 B, writes runs of >= T*32 B.
+//
+// Data stays CANONICAL in HBM; twiddles are kept in Montgomery form, so mont_mul(x, w) = x*w canonical
+// and no conversion pass exists.  Twiddles omega^e for arbitrary e come from a two-level table
+// (lo[e mod 2^h] * hi[e >> h], 2 * 2^h entries, L2-resident) instead of an m/2-entry table in HBM.
+// The coset pre-scale (forward) and the 1/m and coset^-1 post-scale (inverse) are fused into the first
+// load / last store.
+#include <algorithm>
+
+#include "ctx.hpp"
+#include "fp.hpp"
+
+using namespace zkhip;
+
+struct NttTables {
+    int curve;
+    size_t log_m;
+    int inverse;
+    bool has_coset;
+    uint64_t omega[4], coset[4];
+    int lo_bits;
+    uint32_t *d_lo = nullptr, *d_hi = nullptr;    // omega^i, omega^(i << lo_bits)          (Montgomery)
+    uint32_t *d_clo = nullptr, *d_chi = nullptr;  // g^i, g^(i << lo_bits), g = coset or coset^-1
+    uint32_t *d_scale = nullptr;                  // 1/m (Montgomery), inverse only
+    uint32_t *d_base = nullptr;                   // [omega_eff, g_eff] (Montgomery)
+};
+
+struct NttPass {
+    const uint32_t *in;
+    uint32_t *out;
+    uint32_t log_m, s, log_ns, log_t;
+    uint32_t tiles_per_poly;
+    const uint32_t *lo, *hi;
+    uint32_t lo_bits;
+    const uint32_t *clo, *chi;  // coset power tables (g or g^-1), or null
+    const uint32_t *scale;      // 1/m, set only on the last pass of an inverse transform
+    uint32_t pre_coset;         // multiply by g^index while loading   (first pass, forward coset)
+    uint32_t post_coset;        // multiply by g^index while storing   (last pass, inverse coset)
+};
+
+// out[i] = base^(i << shift), i < count  (Montgomery in/out)
+template <class S>
+__global__ __launch_bounds__(256) void ntt_pow_table(const uint32_t *__restrict__ base, uint32_t count, uint32_t shift,
+                                                     uint32_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    S b = fp_load<typename S::params>(base);
+    fp_store<typename S::params>(out + (size_t)i * S::NL, fp_pow_u64(b, (uint64_t)i << shift));
+}
+
+// base[0] = omega or omega^-1, base[1] = g or g^-1 (Montgomery), scale = (2^log_m)^-1
+template <class S>
+__global__ void ntt_setup(const uint32_t *__restrict__ omega_c, const uint32_t *__restrict__ coset_c, int inverse, uint32_t log_m,
+                          uint32_t *__restrict__ base, uint32_t *__restrict__ scale) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    typedef typename S::params P;
+    S w = fp_to_mont(fp_load<P>(omega_c));
+    if (inverse) w = fp_inv(w);
+    fp_store<P>(base, w);
+    if (coset_c != nullptr) {
+        S g = fp_to_mont(fp_load<P>(coset_c));
+        if (inverse) g = fp_inv(g);
+        fp_store<P>(base + S::NL, g);
+    }
+    if (inverse) {
+        S two = S::one() + S::one();
+        S m = fp_pow_u64(two, log_m);
+        fp_store<P>(scale, fp_inv(m));
+    }
+}
+
+template <class S>
+ZK_D S tw_lookup(const uint32_t *__restrict__ lo, const uint32_t *__restrict__ hi, uint32_t lo_bits, uint64_t e) {
+    typedef typename S::params P;
+    uint32_t el = (uint32_t)(e & ((1u << lo_bits) - 1));
+    uint32_t eh = (uint32_t)(e >> lo_bits);
+    S a = fp_load<P>(lo + (size_t)el * S::NL);
+    if (eh == 0) return a;
+    return a * fp_load<P>(hi + (size_t)eh * S::NL);
+}
+
+ZK_D uint32_t bitrev(uint32_t v, uint32_t bits) { return bits == 0 ? 0 : (__brev(v) >> (32 - bits)); }
+
+// LDS element e: plane 0 holds limbs 0-3 at [e], plane 1 holds limbs 4-7 at [nelem + e]
+template <class S>
+ZK_D S lds_get(const uint4 *lds, uint32_t nelem, uint32_t e) {
+    S r;
+    uint4 a = lds[e], b = lds[nelem + e];
+    r.v[0] = a.x, r.v[1] = a.y, r.v[2] = a.z, r.v[3] = a.w;
+    r.v[4] = b.x, r.v[5] = b.y, r.v[6] = b.z, r.v[7] = b.w;
+    return r;
+}
+template <class S>
+ZK_D void lds_put(uint4 *lds, uint32_t nelem, uint32_t e, const S &x) {
+    lds[e] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    lds[nelem + e] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+
+template <class S>
+__global__ __launch_bounds__(256) void ntt_pass(NttPass p) {
+    typedef typename S::params P;
+    static_assert(S::NL == 8, "Fr is 8 x u32");
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+    const uint32_t R = 1u << p.s, T = 1u << p.log_t, nelem = R * T;
+    const uint32_t tid = threadIdx.x, nth = blockDim.x;
+    uint4 *twr = lds + 2 * nelem;  // R/2 stage twiddles, two planes of R/2
+
+    const uint32_t poly = blockIdx.x / p.tiles_per_poly;
+    const uint32_t tile = blockIdx.x % p.tiles_per_poly;
+    const uint32_t log_stride = p.log_m - p.s;  // m / R
+    const uint64_t j0 = (uint64_t)tile << p.log_t;
+    const uint32_t *src = p.in + ((size_t)poly << p.log_m) * 8;
+    uint32_t *dst = p.out + ((size_t)poly << p.log_m) * 8;
+    const uint32_t ns_mask = (1u << p.log_ns) - 1;  // log_ns < 32 always (m <= 2^32)
+
+    // stage twiddles omega_R^q = omega^(q m/R), q < R/2
+    for (uint32_t q = tid; q < R / 2; q += nth) {
+        S w = tw_lookup<S>(p.lo, p.hi, p.lo_bits, (uint64_t)q << log_stride);
+        lds_put(twr, R / 2, q, w);
+    }
+    // load tile: element (t, c) <- x[j0 + c + t m/R] * omega_(Ns R)^(k t)  [* g^index on the first pass]
+    const uint32_t tw_shift = p.log_m - p.log_ns - p.s;  // omega_(Ns R) = omega^(m / (Ns R))
+    for (uint32_t e = tid; e < nelem; e += nth) {
+        uint32_t t = e >> p.log_t, c = e & (T - 1);
+        uint64_t j = j0 + c;
+        uint64_t gi = j + ((uint64_t)t << log_stride);
+        S x = fp_load<P>(src + gi * 8);
+        if (p.pre_coset) x = x * tw_lookup<S>(p.clo, p.chi, p.lo_bits, gi);
+        if (p.log_ns != 0) {
+            uint64_t k = j & ns_mask;
+            uint64_t ex = (k * t) << tw_shift;
+            if (ex != 0) x = x * tw_lookup<S>(p.lo, p.hi, p.lo_bits, ex);
+        }
+        lds_put(lds, nelem, e, x);
+    }
+    __syncthreads();
+    // s radix-2 DIF stages over t (natural in, bit-reversed out)
+    const uint32_t nbf = nelem >> 1;
+    for (uint32_t st = 0; st < p.s; ++st) {
+        const uint32_t h = R >> (st + 1);
+        for (uint32_t bf = tid; bf < nbf; bf += nth) {
+            uint32_t c = bf & (T - 1), q = bf >> p.log_t;
+            uint32_t qq = q & (h - 1);
+            uint32_t t_lo = ((q - qq) << 1) + qq;
+            uint32_t e0 = (t_lo << p.log_t) + c, e1 = ((t_lo + h) << p.log_t) + c;
+            S a = lds_get<S>(lds, nelem, e0), b = lds_get<S>(lds, nelem, e1);
+            S u = a + b, v = a - b;
+            if (h != 1) v = v * lds_get<S>(twr, R / 2, qq << st);
+            lds_put(lds, nelem, e0, u);
+            lds_put(lds, nelem, e1, v);
+        }
+        __syncthreads();
+    }
+    // store: y[(j - k) R + k + t' Ns] = v[t'], v[t'] sits at row bitrev(t')
+    for (uint32_t e = tid; e < nelem; e += nth) {
+        uint32_t tp, c;
+        if (p.log_ns >= p.log_t) {
+            tp = e >> p.log_t;
+            c = e & (T - 1);
+        } else {  // Ns < T: (c_hi, t', k_lo) with k_lo fastest makes each c_hi a contiguous run of Ns*R
+            uint32_t k_lo = e & ns_mask;
+            tp = (e >> p.log_ns) & (R - 1);
+            uint32_t c_hi = e >> (p.log_ns + p.s);
+            c = (c_hi << p.log_ns) + k_lo;
+        }
+        uint64_t j = j0 + c;
+        uint64_t k = j & ns_mask;
+        uint64_t oi = ((j - k) << p.s) + k + ((uint64_t)tp << p.log_ns);
+        S x = lds_get<S>(lds, nelem, (bitrev(tp, p.s) << p.log_t) + c);
+        if (p.scale != nullptr) x = x * fp_load<P>(p.scale);
+        if (p.post_coset) x = x * tw_lookup<S>(p.clo, p.chi, p.lo_bits, oi);
+        fp_store<P>(dst + oi * 8, x);
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------
+void zk_ntt_free_tables(zkhip_ctx *ctx) {
+    for (NttTables *t : ctx->ntt_tables) {
+        (void)hipFree(t->d_lo);
+        (void)hipFree(t->d_hi);
+        (void)hipFree(t->d_clo);
+        (void)hipFree(t->d_chi);
+        (void)hipFree(t->d_scale);
+        (void)hipFree(t->d_base);
+        delete t;
+    }
+    ctx->ntt_tables.clear();
+}
+
+template <class S>
+static int ntt_get_tables(zkhip_ctx *ctx, int curve, size_t log_m, const uint64_t *omega, int inverse, const uint64_t *coset,
+                          NttTables **out) {
+    for (NttTables *t : ctx->ntt_tables) {
+        if (t->curve == curve && t->log_m == log_m && t->inverse == inverse && t->has_coset == (coset != nullptr) &&
+            memcmp(t->omega, omega, 32) == 0 && (coset == nullptr || memcmp(t->coset, coset, 32) == 0)) {
+            *out = t;
+            return 0;
+        }
+    }
+    NttTables *t = new NttTables();
+    t->curve = curve;
+    t->log_m = log_m;
+    t->inverse = inverse;
+    t->has_coset = coset != nullptr;
+    memcpy(t->omega, omega, 32);
+    if (coset) memcpy(t->coset, coset, 32);
+    t->lo_bits = (int)((log_m + 1) / 2);
+    if (t->lo_bits < 1) t->lo_bits = 1;
+    const uint32_t nlo = 1u << t->lo_bits;
+    const uint32_t nhi = (uint32_t)(((size_t)1 << log_m) >> t->lo_bits) + 1;
+    ctx->ntt_tables.push_back(t);  // owned by the context from here on (freed in zk_ntt_free_tables)
+    uint32_t *d_in = nullptr;
+    ZK_HIP_CHECK(ctx, hipMalloc((void **)&d_in, 64));
+    ZK_HIP_CHECK(ctx, hipMalloc((void **)&t->d_base, 64));
+    ZK_HIP_CHECK(ctx, hipMalloc((void **)&t->d_scale, 32));
+    ZK_HIP_CHECK(ctx, hipMalloc((void **)&t->d_lo, (size_t)nlo * 32));
+    ZK_HIP_CHECK(ctx, hipMalloc((void **)&t->d_hi, (size_t)nhi * 32));
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_in, omega, 32, hipMemcpyHostToDevice, ctx->stream));
+    if (coset) ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_in + 8, coset, 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_LAUNCH(ctx, "ntt_setup", ntt_setup<S>, dim3(1), dim3(64), 0, d_in, coset ? d_in + 8 : (const uint32_t *)nullptr, inverse,
+              (uint32_t)log_m, t->d_base, t->d_scale);
+    ZK_LAUNCH(ctx, "ntt_pow_table", ntt_pow_table<S>, dim3((nlo + 255) / 256), dim3(256), 0, t->d_base, nlo, 0u, t->d_lo);
+    ZK_LAUNCH(ctx, "ntt_pow_table", ntt_pow_table<S>, dim3((nhi + 255) / 256), dim3(256), 0, t->d_base, nhi, (uint32_t)t->lo_bits, t->d_hi);
+    if (coset) {
+        ZK_HIP_CHECK(ctx, hipMalloc((void **)&t->d_clo, (size_t)nlo * 32));
+        ZK_HIP_CHECK(ctx, hipMalloc((void **)&t->d_chi, (size_t)nhi * 32));
+        ZK_LAUNCH(ctx, "ntt_pow_table", ntt_pow_table<S>, dim3((nlo + 255) / 256), dim3(256), 0, t->d_base + 8, nlo, 0u, t->d_clo);
+        ZK_LAUNCH(ctx, "ntt_pow_table", ntt_pow_table<S>, dim3((nhi + 255) / 256), dim3(256), 0, t->d_base + 8, nhi, (uint32_t)t->lo_bits,
+                  t->d_chi);
+    }
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_in);
+    *out = t;
+    return 0;
+}
+
+template <class S>
+static int ntt_run_t(zkhip_ctx *ctx, int curve, uint32_t *d_data, size_t log_m, size_t batch, const uint64_t *omega, int inverse,
+                     const uint64_t *coset) {
+    if (batch == 0 || log_m == 0) return 0;  // a 1-point transform is the identity (also with coset: g^0 = 1, 1/1 = 1)
+    NttTables *tb = nullptr;
+    ZK_TRY(ntt_get_tables<S>(ctx, curve, log_m, omega, inverse, coset, &tb));
+    const int smax = std::max(1, std::min(10, ctx->opt_ntt_radix_log));
+    const int np = (int)((log_m + smax - 1) / smax);
+    // split log_m into np nearly equal radices, larger ones first
+    int sv[64];
+    for (int i = 0; i < np; ++i) sv[i] = (int)(log_m / np) + (i < (int)(log_m % np) ? 1 : 0);
+    const size_t m = (size_t)1 << log_m;
+    const size_t bytes = batch * m * 32;
+    uint32_t *wsA = nullptr, *wsB = nullptr;
+    if (np > 1) {
+        size_t need = zkhip_ctx::ws_round(bytes) * ((np & 1) ? 2 : 1);
+        ZK_TRY(ctx->ws_reserve(need));
+        ctx->ws_reset();
+        wsA = ctx->ws_take<uint32_t>(bytes / 4);
+        if (np & 1) wsB = ctx->ws_take<uint32_t>(bytes / 4);
+    }
+    uint32_t log_ns = 0;
+    const uint32_t *src = d_data;
+    for (int i = 0; i < np; ++i) {
+        uint32_t *dst;
+        if (np == 1) dst = d_data;  // the single tile is the whole polynomial: read fully into LDS before any store
+        else {
+            dst = ((np - 1 - i) % 2 == 0) ? d_data : wsA;
+            if (i == 0 && dst == d_data) dst = wsB;  // odd pass count: never write the buffer being read
+        }
+        NttPass p;
+        p.in = src;
+        p.out = dst;
+        p.log_m = (uint32_t)log_m;
+        p.s = (uint32_t)sv[i];
+        p.log_ns = log_ns;
+        uint32_t log_cols = (uint32_t)log_m - p.s;  // log2(m / R)
+        p.log_t = std::min<uint32_t>((uint32_t)std::max(0, ctx->opt_ntt_tile_log), log_cols);
+        // LDS budget: R * T * 32 B <= 128 KiB
+        while (p.s + p.log_t > 12 && p.log_t > 0) --p.log_t;
+        p.tiles_per_poly = 1u << (log_cols - p.log_t);
+        p.lo = tb->d_lo;
+        p.hi = tb->d_hi;
+        p.lo_bits = (uint32_t)tb->lo_bits;
+        p.clo = tb->d_clo;
+        p.chi = tb->d_chi;
+        p.scale = (inverse && i == np - 1) ? tb->d_scale : nullptr;
+        p.pre_coset = (!inverse && coset != nullptr && i == 0) ? 1u : 0u;
+        p.post_coset = (inverse && coset != nullptr && i == np - 1) ? 1u : 0u;
+        size_t nelem = (size_t)1 << (p.s + p.log_t);
+        size_t lds = nelem * 32 + ((size_t)1 << p.s) / 2 * 32;
+        if (lds < 64) lds = 64;
+        static bool attr_set = false;
+        if (!attr_set) {
+            ZK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass<S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        size_t grid = batch * p.tiles_per_poly;
+        if (grid >= (1ull << 31)) return ZKHIP_ERR_RANGE;
+        unsigned threads = (unsigned)std::min<size_t>(256, std::max<size_t>(64, nelem / 2));
+        ZK_LAUNCH(ctx, "ntt_pass", ntt_pass<S>, dim3((unsigned)grid), dim3(threads), lds, p);
+        src = dst;
+        log_ns += p.s;
+    }
+    return 0;
+}
+
+int zk_ntt_run(zkhip_ctx *ctx, int curve, uint32_t *d_data, size_t log_m, size_t batch, const uint64_t *omega, int inverse,
+               const uint64_t *coset) {
+    if (log_m > 32) return ZKHIP_ERR_RANGE;
+    if (curve == CURVE_BLS12_381) return ntt_run_t<bls_fr>(ctx, curve, d_data, log_m, batch, omega, inverse, coset);
+    if (curve == CURVE_BN254) return ntt_run_t<bn_fr>(ctx, curve, d_data, log_m, batch, omega, inverse, coset);
+    return ZKHIP_ERR_INVALID;
+}

@@ -1,0 +1,395 @@
+// extern "C" surface of libzkhip.so (declared in include/zkhip.h).  No torch types, no CPU fallback:
+// if no HIP device is usable, zkhip_init fails and nothing else can be called.
+#include <cstdlib>
+
+#include "ctx.hpp"
+#include "zk_defs.hpp"
+
+using namespace zkhip;
+
+static int check_device(zkhip_ctx *ctx) {
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return 0;
+}
+
+extern "C" {
+
+const char *zkhip_strerror(int status) {
+    switch (status) {
+        case ZKHIP_OK: return "ok";
+        case ZKHIP_ERR_NO_DEVICE: return "no usable HIP device (zkhip has no CPU fallback)";
+        case ZKHIP_ERR_INVALID: return "invalid argument";
+        case ZKHIP_ERR_HIP: return "HIP runtime error (see zkhip_last_error)";
+        case ZKHIP_ERR_OOM: return "out of device memory";
+        case ZKHIP_ERR_RANGE: return "size or offset out of range";
+        default: return "unknown status";
+    }
+}
+
+int zkhip_init(int device_id, zkhip_ctx **out) {
+    if (!out) return ZKHIP_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ZKHIP_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= count) return ZKHIP_ERR_INVALID;
+    if (hipSetDevice(device_id) != hipSuccess) return ZKHIP_ERR_NO_DEVICE;
+    zkhip_ctx *ctx = new zkhip_ctx();
+    ctx->device = device_id;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return ZKHIP_ERR_HIP;
+    }
+    ctx->own_stream = true;
+    *out = ctx;
+    return ZKHIP_OK;
+}
+
+void zkhip_destroy(zkhip_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    zk_ntt_free_tables(ctx);
+    for (auto &p : ctx->prof.pending) {
+        (void)hipEventDestroy(p.second.a);
+        (void)hipEventDestroy(p.second.b);
+    }
+    for (auto &e : ctx->prof.pool) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *zkhip_last_error(const zkhip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int zkhip_set_stream(zkhip_ctx *ctx, void *hip_stream) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    ctx->own_stream = false;
+    return ZKHIP_OK;
+}
+
+int zkhip_sync(zkhip_ctx *ctx) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+
+int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value) {
+    if (!ctx || !name) return ZKHIP_ERR_INVALID;
+    std::string n(name);
+    if (n == "msm_window_bits") ctx->opt_msm_window_bits = (int)value;
+    else if (n == "msm_segment_log") ctx->opt_msm_segment_log = (int)value;
+    else if (n == "ntt_radix_log") ctx->opt_ntt_radix_log = (int)value;
+    else if (n == "ntt_tile_log") ctx->opt_ntt_tile_log = (int)value;
+    else return ZKHIP_ERR_INVALID;
+    return ZKHIP_OK;
+}
+
+int zkhip_malloc(zkhip_ctx *ctx, size_t bytes, void **dptr) {
+    if (!ctx || !dptr) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
+    ZK_HIP_CHECK(ctx, hipMalloc(dptr, bytes ? bytes : 1));
+    return ZKHIP_OK;
+}
+int zkhip_free(zkhip_ctx *ctx, void *dptr) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP_CHECK(ctx, hipFree(dptr));
+    return ZKHIP_OK;
+}
+int zkhip_memcpy_h2d(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+int zkhip_memcpy_d2h(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+
+// ---- bases ------------------------------------------------------------------------------------------
+static int bases_alloc(zkhip_ctx *ctx, int curve, int group, size_t n, zkhip_bases **out) {
+    if ((curve != CURVE_BLS12_381 && curve != CURVE_BN254) || (group != GROUP_G1 && group != GROUP_G2)) return ZKHIP_ERR_INVALID;
+    zkhip_bases *b = new zkhip_bases();
+    b->curve = curve;
+    b->group = group;
+    b->n = n;
+    b->stride_u32 = 2 * 2 * zk_coord_limbs64(curve, group);
+    b->d = nullptr;
+    hipError_t e = hipMalloc((void **)&b->d, std::max<size_t>(1, n) * b->stride_u32 * 4);
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("hipMalloc(bases): ") + hipGetErrorString(e);
+        delete b;
+        return ZKHIP_ERR_OOM;
+    }
+    *out = b;
+    return 0;
+}
+
+int zkhip_bases_upload(zkhip_ctx *ctx, int curve, int group, const uint64_t *affine_xy, const uint8_t *is_infinity, size_t n,
+                       zkhip_bases **out) {
+    if (!ctx || !out || (n && !affine_xy)) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
+    zkhip_bases *b = nullptr;
+    ZK_TRY(bases_alloc(ctx, curve, group, n, &b));
+    uint8_t *d_inf = nullptr;
+    int rc = 0;
+    do {
+        if (n == 0) break;
+        if (hipMemcpyAsync(b->d, affine_xy, n * b->stride_u32 * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            rc = ZKHIP_ERR_HIP;
+            break;
+        }
+        if (is_infinity) {
+            if (hipMalloc((void **)&d_inf, n) != hipSuccess) {
+                rc = ZKHIP_ERR_OOM;
+                break;
+            }
+            if (hipMemcpyAsync(d_inf, is_infinity, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+                rc = ZKHIP_ERR_HIP;
+                break;
+            }
+        }
+        rc = zk_bases_to_mont(ctx, b, d_inf);
+        if (rc) break;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
+    } while (0);
+    if (d_inf) (void)hipFree(d_inf);
+    if (rc) {
+        (void)hipFree(b->d);
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return ZKHIP_OK;
+}
+
+// standard generators, canonical u32 limbs (x | y)
+static const uint64_t GEN_BLS_G1[12] = {0xfb3af00adb22c6bbULL, 0x6c55e83ff97a1aefULL, 0xa14e3a3f171bac58ULL, 0xc3688c4f9774b905ULL,
+                                        0x2695638c4fa9ac0fULL, 0x17f1d3a73197d794ULL, 0x0caa232946c5e7e1ULL, 0xd03cc744a2888ae4ULL,
+                                        0x00db18cb2c04b3edULL, 0xfcf5e095d5d00af6ULL, 0xa09e30ed741d8ae4ULL, 0x08b3f481e3aaa0f1ULL};
+static const uint64_t GEN_BLS_G2[24] = {
+    0xd48056c8c121bdb8ULL, 0x0bac0326a805bbefULL, 0xb4510b647ae3d177ULL, 0xc6e47ad4fa403b02ULL, 0x260805272dc51051ULL, 0x024aa2b2f08f0a91ULL,
+    0xe5ac7d055d042b7eULL, 0x334cf11213945d57ULL, 0xb5da61bbdc7f5049ULL, 0x596bd0d09920b61aULL, 0x7dacd3a088274f65ULL, 0x13e02b6052719f60ULL,
+    0xe193548608b82801ULL, 0x923ac9cc3baca289ULL, 0x6d429a695160d12cULL, 0xadfd9baa8cbdd3a7ULL, 0x8cc9cdc6da2e351aULL, 0x0ce5d527727d6e11ULL,
+    0xaaa9075ff05f79beULL, 0x3f370d275cec1da1ULL, 0x267492ab572e99abULL, 0xcb3e287e85a763afULL, 0x32acd2b02bc28b99ULL, 0x0606c4a02ea734ccULL};
+static const uint64_t GEN_BN_G1[8] = {1, 0, 0, 0, 2, 0, 0, 0};
+static const uint64_t GEN_BN_G2[16] = {0x46debd5cd992f6edULL, 0x674322d4f75edaddULL, 0x426a00665e5c4479ULL, 0x1800deef121f1e76ULL,
+                                       0x97e485b7aef312c2ULL, 0xf1aa493335a9e712ULL, 0x7260bfb731fb5d25ULL, 0x198e9393920d483aULL,
+                                       0x4ce6cc0166fa7daaULL, 0xe3d1e7690c43d37bULL, 0x4aab71808dcb408fULL, 0x12c85ea5db8c6debULL,
+                                       0x55acdadcd122975bULL, 0xbc4b313370b38ef3ULL, 0xec9e99ad690c3395ULL, 0x090689d0585ff075ULL};
+
+int zkhip_bases_from_scalars(zkhip_ctx *ctx, int curve, int group, const uint64_t *base_affine_xy, const uint64_t *scalars, size_t n,
+                             zkhip_bases **out) {
+    if (!ctx || !out || (n && !scalars)) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
+    zkhip_bases *b = nullptr;
+    ZK_TRY(bases_alloc(ctx, curve, group, n, &b));
+    const uint64_t *gen = base_affine_xy;
+    if (!gen) gen = curve == CURVE_BLS12_381 ? (group == GROUP_G1 ? GEN_BLS_G1 : GEN_BLS_G2) : (group == GROUP_G1 ? GEN_BN_G1 : GEN_BN_G2);
+    uint32_t *d_s = nullptr, *d_g = nullptr;
+    int rc = 0;
+    do {
+        if (n == 0) break;
+        if (hipMalloc((void **)&d_s, n * 32) != hipSuccess || hipMalloc((void **)&d_g, b->stride_u32 * 4) != hipSuccess) {
+            rc = ZKHIP_ERR_OOM;
+            break;
+        }
+        if (hipMemcpyAsync(d_s, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(d_g, gen, b->stride_u32 * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            rc = ZKHIP_ERR_HIP;
+            break;
+        }
+        rc = zk_bases_mul(ctx, b, d_g, d_s);
+        if (rc) break;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
+    } while (0);
+    if (d_s) (void)hipFree(d_s);
+    if (d_g) (void)hipFree(d_g);
+    if (rc) {
+        (void)hipFree(b->d);
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return ZKHIP_OK;
+}
+
+int zkhip_bases_download(zkhip_ctx *ctx, const zkhip_bases *b, size_t offset, size_t n, uint64_t *affine_xy, uint8_t *is_infinity) {
+    if (!ctx || !b || (n && (!affine_xy || !is_infinity))) return ZKHIP_ERR_INVALID;
+    if (offset + n > b->n) return ZKHIP_ERR_RANGE;
+    if (n == 0) return ZKHIP_OK;
+    ZK_TRY(check_device(ctx));
+    size_t pbytes = n * b->stride_u32 * 4;
+    ZK_TRY(ctx->ws_reserve(zkhip_ctx::ws_round(pbytes) + zkhip_ctx::ws_round(n)));
+    ctx->ws_reset();
+    uint32_t *d_out = ctx->ws_take<uint32_t>(pbytes / 4);
+    uint8_t *d_inf = ctx->ws_take<uint8_t>(n);
+    ZK_TRY(zk_bases_from_mont(ctx, b, offset, n, d_out, d_inf));
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(affine_xy, d_out, pbytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(is_infinity, d_inf, n, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+
+size_t zkhip_bases_size(const zkhip_bases *b) { return b ? b->n : 0; }
+
+void zkhip_bases_free(zkhip_ctx *ctx, zkhip_bases *b) {
+    if (!b) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(b->d);
+    delete b;
+}
+
+// ---- MSM ----------------------------------------------------------------------------------------------
+int zkhip_msm_dev(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const void *d_scalars, void *d_out_jacobian) {
+    if (!ctx || !bases || !d_out_jacobian || (n && !d_scalars)) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
+    return zk_msm_run(ctx, bases, offset, n, (const uint32_t *)d_scalars, (uint32_t *)d_out_jacobian);
+}
+
+int zkhip_msm(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint64_t *scalars, uint64_t *out_jacobian) {
+    if (!ctx || !bases || !out_jacobian || (n && !scalars)) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
+    uint32_t *d_s = nullptr, *d_o = nullptr;
+    size_t obytes = 3 * zk_coord_limbs64(bases->curve, bases->group) * 8;
+    int rc = 0;
+    do {
+        if (hipMalloc((void **)&d_s, std::max<size_t>(1, n) * 32) != hipSuccess || hipMalloc((void **)&d_o, obytes) != hipSuccess) {
+            rc = ZKHIP_ERR_OOM;
+            break;
+        }
+        if (n && hipMemcpyAsync(d_s, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            rc = ZKHIP_ERR_HIP;
+            break;
+        }
+        rc = zk_msm_run(ctx, bases, offset, n, d_s, d_o);
+        if (rc) break;
+        if (hipMemcpyAsync(out_jacobian, d_o, obytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            ctx->last_error = hipGetErrorString(hipGetLastError());
+            rc = ZKHIP_ERR_HIP;
+        }
+    } while (0);
+    if (d_s) (void)hipFree(d_s);
+    if (d_o) (void)hipFree(d_o);
+    return rc;
+}
+
+int zkhip_jacobian_sum_dev(zkhip_ctx *ctx, int curve, int group, const void *d_points, size_t count, void *d_out_jacobian) {
+    if (!ctx || !d_points || !d_out_jacobian) return ZKHIP_ERR_INVALID;
+    if ((curve != CURVE_BLS12_381 && curve != CURVE_BN254) || (group != GROUP_G1 && group != GROUP_G2)) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
+    return zk_jac_sum(ctx, curve, group, (const uint32_t *)d_points, count, (uint32_t *)d_out_jacobian);
+}
+
+int zkhip_jacobian_to_affine(zkhip_ctx *ctx, int curve, int group, const uint64_t *jacobian, uint64_t *affine_xy, uint8_t *is_infinity) {
+    if (!ctx || !jacobian || !affine_xy || !is_infinity) return ZKHIP_ERR_INVALID;
+    if ((curve != CURVE_BLS12_381 && curve != CURVE_BN254) || (group != GROUP_G1 && group != GROUP_G2)) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
+    size_t cl = zk_coord_limbs64(curve, group) * 8;
+    ZK_TRY(ctx->ws_reserve(4096));
+    ctx->ws_reset();
+    uint32_t *d_j = ctx->ws_take<uint32_t>(3 * cl / 4);
+    uint32_t *d_a = ctx->ws_take<uint32_t>(2 * cl / 4);
+    uint8_t *d_i = ctx->ws_take<uint8_t>(16);
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_j, jacobian, 3 * cl, hipMemcpyHostToDevice, ctx->stream));
+    ZK_TRY(zk_jac_to_affine(ctx, curve, group, d_j, d_a, d_i));
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(affine_xy, d_a, 2 * cl, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(is_infinity, d_i, 1, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+
+// ---- NTT ----------------------------------------------------------------------------------------------
+int zkhip_ntt_dev(zkhip_ctx *ctx, int curve, void *d_data, size_t log_m, size_t batch, const uint64_t *omega, int inverse,
+                  const uint64_t *coset_gen) {
+    if (!ctx || !omega || (batch && !d_data)) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
+    return zk_ntt_run(ctx, curve, (uint32_t *)d_data, log_m, batch, omega, inverse ? 1 : 0, coset_gen);
+}
+
+int zkhip_ntt(zkhip_ctx *ctx, int curve, uint64_t *data, size_t log_m, size_t batch, const uint64_t *omega, int inverse,
+              const uint64_t *coset_gen) {
+    if (!ctx || !omega || (batch && !data)) return ZKHIP_ERR_INVALID;
+    if (log_m > 32) return ZKHIP_ERR_RANGE;
+    if (batch == 0) return ZKHIP_OK;
+    ZK_TRY(check_device(ctx));
+    size_t bytes = (batch << log_m) * 32;
+    uint32_t *d = nullptr;
+    ZK_HIP_CHECK(ctx, hipMalloc((void **)&d, bytes));
+    int rc = 0;
+    do {
+        if (hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            rc = ZKHIP_ERR_HIP;
+            break;
+        }
+        rc = zk_ntt_run(ctx, curve, d, log_m, batch, omega, inverse ? 1 : 0, coset_gen);
+        if (rc) break;
+        if (hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            ctx->last_error = hipGetErrorString(hipGetLastError());
+            rc = ZKHIP_ERR_HIP;
+        }
+    } while (0);
+    (void)hipFree(d);
+    return rc;
+}
+
+// ---- profiling ----------------------------------------------------------------------------------------
+int zkhip_profile_enable(zkhip_ctx *ctx, int on) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ctx->prof_collect();
+    ctx->prof.on = on != 0;
+    return ZKHIP_OK;
+}
+int zkhip_profile_reset(zkhip_ctx *ctx) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ctx->prof_collect();
+    ctx->prof.acc.clear();
+    return ZKHIP_OK;
+}
+int zkhip_profile_get(zkhip_ctx *ctx, const char *prefix, double *total_ms, uint64_t *launches) {
+    if (!ctx || !prefix) return ZKHIP_ERR_INVALID;
+    ctx->prof_collect();
+    double ms = 0;
+    uint64_t cnt = 0;
+    size_t pl = strlen(prefix);
+    for (auto &kv : ctx->prof.acc) {
+        if (kv.first.compare(0, pl, prefix) == 0) {
+            ms += kv.second.first;
+            cnt += kv.second.second;
+        }
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = cnt;
+    return ZKHIP_OK;
+}
+size_t zkhip_profile_dump(zkhip_ctx *ctx, char *buf, size_t cap) {
+    if (!ctx) return 0;
+    ctx->prof_collect();
+    std::string s;
+    char line[256];
+    for (auto &kv : ctx->prof.acc) {
+        snprintf(line, sizeof(line), "%s %.6f %llu\n", kv.first.c_str(), kv.second.first, (unsigned long long)kv.second.second);
+        s += line;
+    }
+    if (buf && cap) {
+        size_t k = std::min(cap - 1, s.size());
+        memcpy(buf, s.data(), k);
+        buf[k] = 0;
+    }
+    return s.size() + 1;
+}
+
+}  // extern "C"

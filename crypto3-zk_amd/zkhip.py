@@ -1,0 +1,243 @@
+"""ctypes binding of include/zkhip.h (plumbing for tests/ and bench.py; not a compute path)."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+BLS12_381, BN254 = 0, 1
+G1, G2 = 1, 2
+_FQ = {BLS12_381: 6, BN254: 4}
+
+EXPORTS = [
+    "zkhip_init", "zkhip_destroy", "zkhip_strerror", "zkhip_last_error", "zkhip_set_stream", "zkhip_sync",
+    "zkhip_set_option", "zkhip_malloc", "zkhip_free", "zkhip_memcpy_h2d", "zkhip_memcpy_d2h",
+    "zkhip_bases_upload", "zkhip_bases_from_scalars", "zkhip_bases_download", "zkhip_bases_size",
+    "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
+    "zkhip_profile_enable", "zkhip_profile_reset", "zkhip_profile_get", "zkhip_profile_dump",
+]
+
+
+class ZkhipError(RuntimeError):
+    pass
+
+
+def coord_limbs(curve: int, group: int) -> int:
+    """u64 limbs per coordinate (Fq for G1, Fq2 for G2)."""
+    return _FQ[curve] * (2 if group == G2 else 1)
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "libzkhip.so")
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", _HERE, "-j4", "all"]
+    if force:
+        subprocess.check_call(["make", "-C", _HERE, "clean"])
+    subprocess.check_call(args)
+    return lib_path()
+
+
+_LIB = None
+
+
+def load_library() -> ctypes.CDLL:
+    """Load libzkhip.so; raises if it has not been built (there is no fallback implementation)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ZkhipError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(zkhip has no CPU fallback)")
+    lib = ctypes.CDLL(path)
+    lib.zkhip_strerror.restype = ctypes.c_char_p
+    lib.zkhip_last_error.restype = ctypes.c_char_p
+    lib.zkhip_last_error.argtypes = [ctypes.c_void_p]
+    lib.zkhip_bases_size.restype = ctypes.c_size_t
+    lib.zkhip_bases_size.argtypes = [ctypes.c_void_p]
+    lib.zkhip_profile_dump.restype = ctypes.c_size_t
+    lib.zkhip_destroy.argtypes = [ctypes.c_void_p]
+    lib.zkhip_bases_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    _LIB = lib
+    return lib
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+class Context:
+    """One context per GPU per process (zkhip_init / zkhip_destroy)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self.lib.zkhip_init(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise ZkhipError(f"zkhip_init: {self.lib.zkhip_strerror(rc).decode()}")
+        self.h = h
+        self.device = device
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise ZkhipError(f"{what}: {self.lib.zkhip_strerror(rc).decode()} [{self.lib.zkhip_last_error(self.h).decode()}]")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.zkhip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle: int):
+        self._check(self.lib.zkhip_set_stream(self.h, ctypes.c_void_p(stream_handle)), "zkhip_set_stream")
+
+    def sync(self):
+        self._check(self.lib.zkhip_sync(self.h), "zkhip_sync")
+
+    def set_option(self, name: str, value: int):
+        self._check(self.lib.zkhip_set_option(self.h, name.encode(), ctypes.c_int64(value)), "zkhip_set_option")
+
+    # ---- device memory
+    def malloc(self, nbytes: int) -> int:
+        p = ctypes.c_void_p()
+        self._check(self.lib.zkhip_malloc(self.h, ctypes.c_size_t(nbytes), ctypes.byref(p)), "zkhip_malloc")
+        return p.value
+
+    def free(self, dptr: int):
+        self._check(self.lib.zkhip_free(self.h, ctypes.c_void_p(dptr)), "zkhip_free")
+
+    def h2d(self, dptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self._check(self.lib.zkhip_memcpy_h2d(self.h, ctypes.c_void_p(dptr), _p(arr), ctypes.c_size_t(arr.nbytes)), "zkhip_memcpy_h2d")
+
+    def d2h(self, arr: np.ndarray, dptr: int):
+        self._check(self.lib.zkhip_memcpy_d2h(self.h, _p(arr), ctypes.c_void_p(dptr), ctypes.c_size_t(arr.nbytes)), "zkhip_memcpy_d2h")
+
+    # ---- bases
+    def upload_bases(self, curve: int, group: int, affine: np.ndarray, inf=None) -> "Bases":
+        affine = _u64(affine)
+        n = affine.shape[0] if affine.ndim == 2 else 0
+        infa = np.ascontiguousarray(inf, dtype=np.uint8) if inf is not None else None
+        h = ctypes.c_void_p()
+        self._check(self.lib.zkhip_bases_upload(self.h, curve, group, _p(affine), _p(infa), ctypes.c_size_t(n), ctypes.byref(h)),
+                    "zkhip_bases_upload")
+        return Bases(self, h, curve, group, n)
+
+    def bases_from_scalars(self, curve: int, group: int, scalars: np.ndarray, base=None) -> "Bases":
+        scalars = _u64(scalars)
+        n = scalars.shape[0]
+        h = ctypes.c_void_p()
+        b = _u64(base) if base is not None else None
+        self._check(self.lib.zkhip_bases_from_scalars(self.h, curve, group, _p(b), _p(scalars), ctypes.c_size_t(n), ctypes.byref(h)),
+                    "zkhip_bases_from_scalars")
+        return Bases(self, h, curve, group, n)
+
+    # ---- MSM
+    def msm(self, bases: "Bases", scalars: np.ndarray, offset: int = 0, n=None) -> np.ndarray:
+        """-> Jacobian (3, coord_limbs) canonical u64."""
+        scalars = _u64(scalars)
+        n = scalars.shape[0] if n is None else n
+        out = np.zeros((3, coord_limbs(bases.curve, bases.group)), dtype=np.uint64)
+        self._check(self.lib.zkhip_msm(self.h, bases.h, ctypes.c_size_t(offset), ctypes.c_size_t(n), _p(scalars), _p(out)), "zkhip_msm")
+        return out
+
+    def msm_dev(self, bases: "Bases", d_scalars: int, d_out: int, offset: int = 0, n=None):
+        n = bases.n - offset if n is None else n
+        self._check(self.lib.zkhip_msm_dev(self.h, bases.h, ctypes.c_size_t(offset), ctypes.c_size_t(n), ctypes.c_void_p(d_scalars),
+                                           ctypes.c_void_p(d_out)), "zkhip_msm_dev")
+
+    def jacobian_sum_dev(self, curve: int, group: int, d_points: int, count: int, d_out: int):
+        self._check(self.lib.zkhip_jacobian_sum_dev(self.h, curve, group, ctypes.c_void_p(d_points), ctypes.c_size_t(count),
+                                                    ctypes.c_void_p(d_out)), "zkhip_jacobian_sum_dev")
+
+    def jacobian_to_affine(self, curve: int, group: int, jac: np.ndarray):
+        jac = _u64(jac)
+        out = np.zeros((2, coord_limbs(curve, group)), dtype=np.uint64)
+        inf = np.zeros(1, dtype=np.uint8)
+        self._check(self.lib.zkhip_jacobian_to_affine(self.h, curve, group, _p(jac), _p(out), _p(inf)), "zkhip_jacobian_to_affine")
+        return out.reshape(-1), int(inf[0])
+
+    def msm_affine(self, bases: "Bases", scalars: np.ndarray, offset: int = 0, n=None):
+        """MSM followed by the on-device Jacobian -> affine conversion: (flat affine limbs, is_infinity)."""
+        return self.jacobian_to_affine(bases.curve, bases.group, self.msm(bases, scalars, offset, n))
+
+    # ---- NTT
+    def ntt(self, curve: int, data: np.ndarray, log_m: int, omega, inverse=False, coset=None) -> np.ndarray:
+        """data (batch, m, 4) canonical u64 -> transformed copy."""
+        d = _u64(data).copy()
+        batch = d.shape[0] if d.ndim == 3 else 1
+        self._check(self.lib.zkhip_ntt(self.h, curve, _p(d), ctypes.c_size_t(log_m), ctypes.c_size_t(batch), _p(_u64(omega)),
+                                       1 if inverse else 0, _p(_u64(coset)) if coset is not None else None), "zkhip_ntt")
+        return d
+
+    def ntt_dev(self, curve: int, d_data: int, log_m: int, batch: int, omega, inverse=False, coset=None):
+        self._check(self.lib.zkhip_ntt_dev(self.h, curve, ctypes.c_void_p(d_data), ctypes.c_size_t(log_m), ctypes.c_size_t(batch),
+                                           _p(_u64(omega)), 1 if inverse else 0, _p(_u64(coset)) if coset is not None else None),
+                    "zkhip_ntt_dev")
+
+    # ---- profiling
+    def profile(self, on: bool):
+        self._check(self.lib.zkhip_profile_enable(self.h, 1 if on else 0), "zkhip_profile_enable")
+
+    def profile_reset(self):
+        self._check(self.lib.zkhip_profile_reset(self.h), "zkhip_profile_reset")
+
+    def profile_get(self, prefix: str):
+        ms = ctypes.c_double()
+        cnt = ctypes.c_uint64()
+        self._check(self.lib.zkhip_profile_get(self.h, prefix.encode(), ctypes.byref(ms), ctypes.byref(cnt)), "zkhip_profile_get")
+        return ms.value, cnt.value
+
+    def profile_dump(self) -> dict:
+        need = self.lib.zkhip_profile_dump(self.h, None, ctypes.c_size_t(0))
+        buf = ctypes.create_string_buffer(need + 16)
+        self.lib.zkhip_profile_dump(self.h, buf, ctypes.c_size_t(need + 16))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, ms, cnt = line.rsplit(" ", 2)
+            out[name] = (float(ms), int(cnt))
+        return out
+
+
+class Bases:
+    """Resident proving-key query / SRS (zkhip_bases)."""
+
+    def __init__(self, ctx: Context, h, curve, group, n):
+        self.ctx, self.h, self.curve, self.group, self.n = ctx, h, curve, group, n
+
+    def download(self, offset=0, n=None):
+        n = self.n - offset if n is None else n
+        out = np.zeros((n, 2 * coord_limbs(self.curve, self.group)), dtype=np.uint64)
+        inf = np.zeros(n, dtype=np.uint8)
+        self.ctx._check(self.ctx.lib.zkhip_bases_download(self.ctx.h, self.h, ctypes.c_size_t(offset), ctypes.c_size_t(n), _p(out), _p(inf)),
+                        "zkhip_bases_download")
+        return out, inf
+
+    def free(self):
+        if self.h is not None and self.ctx.h:
+            self.ctx.lib.zkhip_bases_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

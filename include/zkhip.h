@@ -1,0 +1,118 @@
+/* zkhip -- C ABI of the MI355X-native MSM / NTT proving backend for NilFoundation/crypto3-zk.
+ *
+ * The reference is a header-only C++ template library with no FFI; its hot path leaves the repository at
+ * the calls listed below (all into crypto3-algebra / crypto3-math).  Every entry point here states the
+ * reference interface it replaces; INTEGRATION.md shows the C++ shim a crypto3-zk maintainer adds on top.
+ *
+ * Conventions
+ *   - Plain C, caller owns every host buffer, nothing throws; return 0 on success, negative zkhip_status
+ *     otherwise (the reference asserts, compiled out in release: prover.hpp:77,88-89; kzg.hpp:145,413).
+ *   - Field elements cross the boundary as CANONICAL (non-Montgomery) little-endian 64-bit limbs:
+ *       Fr (both curves) 4 limbs; BLS12-381 Fq 6 limbs; BN254 Fq 4 limbs; Fq2 = c0 limbs then c1 limbs.
+ *     G1 affine = x | y; G2 affine = x.c0 | x.c1 | y.c0 | y.c1.  Infinity travels as a separate flag.
+ *     The reference's in-memory representation lives in crypto3-multiprecision (not observable from the
+ *     zk tree), so the shim converts through canonical integers and never memcpy's reference objects.
+ *   - Group results are returned as Jacobian (X, Y, Z) with x = X/Z^2, y = Y/Z^3 and Z = 0 for infinity,
+ *     the 3-coordinate shape of the reference's G::value_type; compare in affine.
+ *   - omega and the coset generator are ARGUMENTS (arithmetic_params<F> lives in crypto3-algebra).
+ *   - One context per GPU per process (one process per GPU); a context is not thread-safe.
+ *   - The library has no CPU fallback: without a usable HIP device every call fails with
+ *     ZKHIP_ERR_NO_DEVICE.
+ */
+#ifndef ZKHIP_H
+#define ZKHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zkhip_ctx zkhip_ctx;
+typedef struct zkhip_bases zkhip_bases;
+
+enum zkhip_curve { ZKHIP_BLS12_381 = 0, ZKHIP_BN254 = 1 };
+enum zkhip_group { ZKHIP_G1 = 1, ZKHIP_G2 = 2 };
+enum zkhip_status {
+    ZKHIP_OK = 0,
+    ZKHIP_ERR_NO_DEVICE = -1,
+    ZKHIP_ERR_INVALID = -2,
+    ZKHIP_ERR_HIP = -3,
+    ZKHIP_ERR_OOM = -4,
+    ZKHIP_ERR_RANGE = -5
+};
+
+/* ---- context -------------------------------------------------------------------------------- */
+int zkhip_init(int device_id, zkhip_ctx **out);
+void zkhip_destroy(zkhip_ctx *ctx);
+const char *zkhip_strerror(int status);
+const char *zkhip_last_error(const zkhip_ctx *ctx); /* HIP error text of the last ZKHIP_ERR_HIP */
+/* All work is enqueued on this stream (default: a stream the context creates). */
+int zkhip_set_stream(zkhip_ctx *ctx, void *hip_stream);
+int zkhip_sync(zkhip_ctx *ctx);
+/* Tunables: "msm_window_bits" (0 = auto), "msm_segment_log" , "ntt_radix_log", "ntt_tile_log". */
+int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value);
+
+/* ---- device memory (plumbing for callers that keep vectors resident) -------------------------- */
+int zkhip_malloc(zkhip_ctx *ctx, size_t bytes, void **dptr);
+int zkhip_free(zkhip_ctx *ctx, void *dptr);
+int zkhip_memcpy_h2d(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes);
+int zkhip_memcpy_d2h(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes);
+
+/* ---- resident bases: proving-key queries / SRS ------------------------------------------------
+ * Replaces the `bases_begin, bases_end` iterator pair of algebra::multiexp at
+ *   r1cs_gg_ppzksnark/prover.hpp:108-139 (A_query, B_query, H_query, L_query; layout proving_key.hpp:43-56)
+ *   commitments/polynomial/kzg.hpp:143-148, 409-435 (params.commitment_key)
+ * Upload once, reuse for every proof. */
+int zkhip_bases_upload(zkhip_ctx *ctx, int curve, int group, const uint64_t *affine_xy, const uint8_t *is_infinity /* nullable */,
+                       size_t n, zkhip_bases **out);
+/* out[i] = scalars[i] * base (base == NULL: the standard generator), computed on the device and left
+ * resident.  Replaces algebra::batch_exp / kc_batch_exp (generator.hpp:187-214,
+ * knowledge_commitment_multiexp.hpp:143-208) and structured_generators_scalar_power (ipp2/srs.hpp:44-56). */
+int zkhip_bases_from_scalars(zkhip_ctx *ctx, int curve, int group, const uint64_t *base_affine_xy /* nullable */,
+                             const uint64_t *scalars, size_t n, zkhip_bases **out);
+int zkhip_bases_download(zkhip_ctx *ctx, const zkhip_bases *b, size_t offset, size_t n, uint64_t *affine_xy, uint8_t *is_infinity);
+size_t zkhip_bases_size(const zkhip_bases *b);
+void zkhip_bases_free(zkhip_ctx *ctx, zkhip_bases *b);
+
+/* ---- MSM ---------------------------------------------------------------------------------------
+ * sum_{i<n} scalars[i] * bases[offset + i].
+ * Replaces algebra::multiexp<multiexp_method_BDLO12>(b0, b1, s0, s1, chunks) and
+ * multiexp_with_mixed_addition (prover.hpp:108-139, kzg.hpp:143-148,409-435,505-508,
+ * knowledge_commitment_multiexp.hpp:107).  `chunks` has no counterpart: the device splits the work itself.
+ * out_jacobian: 3 * (coordinate limbs) u64. */
+int zkhip_msm(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint64_t *scalars /* host, n x 4 */,
+              uint64_t *out_jacobian /* host */);
+/* Same, scalars and result resident in device memory; asynchronous on the context's stream. */
+int zkhip_msm_dev(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const void *d_scalars, void *d_out_jacobian);
+/* d_out = sum of `count` Jacobian points (canonical, 3 coordinates each) resident in device memory: the
+ * fold of per-GPU partial MSM results after the all-gather (RCCL has no elliptic-curve reduction). */
+int zkhip_jacobian_sum_dev(zkhip_ctx *ctx, int curve, int group, const void *d_points, size_t count, void *d_out_jacobian);
+/* Jacobian -> affine on the device (one inversion); is_infinity receives 0/1. */
+int zkhip_jacobian_to_affine(zkhip_ctx *ctx, int curve, int group, const uint64_t *jacobian, uint64_t *affine_xy, uint8_t *is_infinity);
+
+/* ---- NTT ---------------------------------------------------------------------------------------
+ * In-place radix-2 transform of `batch` vectors of m = 2^log_m Fr elements, natural order in and out:
+ *   forward:  [coset != NULL: v[j] *= coset^j;]  out[i] = sum_j v[j] omega^(ij)
+ *   inverse:  out[j] = (1/m) sum_i v[i] omega^(-ij);  [coset != NULL: out[j] *= coset^(-j)]
+ * Replaces evaluation_domain<F>::fft / inverse_fft and math::multiply_by_coset
+ * (reductions/r1cs_to_qap.hpp:250-315; column_polynomial.hpp:53; the polynomial_dfs::coefficients /
+ * resize calls of kzg.hpp:431 and basic_fri.hpp:452-455). */
+int zkhip_ntt(zkhip_ctx *ctx, int curve, uint64_t *data /* host, batch x m x 4 */, size_t log_m, size_t batch,
+              const uint64_t *omega /* 4 limbs */, int inverse, const uint64_t *coset_gen /* nullable, 4 limbs */);
+int zkhip_ntt_dev(zkhip_ctx *ctx, int curve, void *d_data, size_t log_m, size_t batch, const uint64_t *omega, int inverse,
+                  const uint64_t *coset_gen);
+
+/* ---- profiling (HIP events on the context's stream around every kernel launch) ------------------ */
+int zkhip_profile_enable(zkhip_ctx *ctx, int on);
+int zkhip_profile_reset(zkhip_ctx *ctx);
+/* Total milliseconds and launch count recorded for kernels whose name starts with `prefix`. */
+int zkhip_profile_get(zkhip_ctx *ctx, const char *prefix, double *total_ms, uint64_t *launches);
+/* Writes "name total_ms launches\n" lines; returns bytes needed. */
+size_t zkhip_profile_dump(zkhip_ctx *ctx, char *buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKHIP_H */

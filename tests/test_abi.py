@@ -1,0 +1,51 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/zkhip.h
+declares, and refuses to run without a GPU (no CPU fallback).  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "zkhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(zkhip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(zk):
+    lib = zk.load_library()
+    names = _declared()
+    assert len(names) >= 25
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/zkhip.h but not exported by libzkhip.so"
+    assert sorted(zk.zkhip.EXPORTS) == names
+
+
+def test_no_cpu_fallback(zk):
+    """Without a HIP device zkhip_init must fail loudly; with one it must succeed."""
+    lib = zk.load_library()
+    h = ctypes.c_void_p()
+    rc = lib.zkhip_init(0, ctypes.byref(h))
+    if rc == 0:
+        lib.zkhip_destroy(h)
+        pytest.skip("a GPU is present: covered by the -m gpu tests")
+    assert rc == -1  # ZKHIP_ERR_NO_DEVICE
+    assert b"no CPU fallback" in lib.zkhip_strerror(rc)
+    with pytest.raises(zk.ZkhipError):
+        zk.Context(0)
+
+
+def test_product_does_not_reference_oracle():
+    """The product path must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "crypto3-zk_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liboracle" not in text and "pyoracle" not in text and "cport" not in text, os.path.join(dirpath, f)
+    import subprocess
+    out = subprocess.run(["ldd", os.path.join(pkg, "libzkhip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out

@@ -1,0 +1,153 @@
+"""Parity of the HIP Pippenger path (through the C ABI) against the oracle, the reference's own
+known-answer vectors, and size-independent properties at the full BASELINE size.  Bit-exact (integer)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cport as cp
+import pyoracle as po
+from util import CURVES, fr_arr, fr_ints, jac_to_affine_py, limbs, pt_from_limbs, pt_limbs, pts_arr
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+h = lambda s: int(s, 16)
+
+
+def gpu_affine(ctx, bases, scalars, **kw):
+    """MSM on the GPU -> affine limbs via the checker's big-int inversion (and the device conversion)."""
+    jac = ctx.msm(bases, scalars, **kw)
+    P = jac_to_affine_py(bases.curve, bases.group, jac)
+    dev_aff, dev_inf = ctx.jacobian_to_affine(bases.curve, bases.group, jac)
+    assert pt_from_limbs(bases.curve, bases.group, dev_aff, dev_inf) == P
+    return P
+
+
+def test_reference_kat_vectors(ctx):
+    """AGG:864-930 (bellperson): 2 x G2 MSM (n=8), 2 x G1 MSM (n=16); kzg.cpp:75-103 commit identity."""
+    q = json.load(open(os.path.join(HERE, "golden", "ref_kat.json")))["prove_commitment_test"]
+    C = po.BLS12_381
+    tr = [h(x) for x in q["tr"]]
+    qv, ha, hb = po.ipp2_prove_commitment_v(C, q["n"], h(q["alpha"]), h(q["beta"]), tr, h(q["kzg_challenge"]))
+    qw, ga, gb = po.ipp2_prove_commitment_w(C, q["n"], h(q["alpha"]), h(q["beta"]), tr, h(q["r_shift"]), h(q["kzg_challenge"]))
+    g2 = lambda e: ((h(e[0][0]), h(e[0][1])), (h(e[1][0]), h(e[1][1])))
+    g1 = lambda e: (h(e[0]), h(e[1]))
+    for group, pts, sc, exp in ((2, ha, qv, g2(q["comm_v"][0])), (2, hb, qv, g2(q["comm_v"][1])),
+                                (1, ga, qw, g1(q["comm_w"][0])), (1, gb, qw, g1(q["comm_w"][1]))):
+        b = ctx.upload_bases(0, group, pts_arr(0, group, pts))
+        assert gpu_affine(ctx, b, fr_arr(sc)) == exp
+        b.free()
+    for curve in (0, 1):
+        Cc = CURVES[curve]
+        ck = po.structured_generators(Cc.g1, 4, 10)
+        b = ctx.upload_bases(curve, 1, pts_arr(curve, 1, ck))
+        assert gpu_affine(ctx, b, fr_arr([Cc.r - 1, 1, 2, 3])) == Cc.g1.mul(Cc.g1.gen, 3209)
+        b.free()
+
+
+@pytest.mark.parametrize("curve,group,sizes", [(0, 1, (1, 2, 17, 256, 4096)), (1, 1, (1, 17, 300, 2048)),
+                                               (0, 2, (1, 2, 17, 200)), (1, 2, (1, 17, 200))])
+def test_msm_matches_oracle(ctx, curve, group, sizes):
+    C = CURVES[curve]
+    nmax = max(sizes)
+    ks = cp.random_fr(curve, 100 + curve * 10 + group, nmax)
+    pts, inf = cp.batch_mul(curve, group, ks)
+    bases = ctx.upload_bases(curve, group, pts)
+    dl, dinf = bases.download()
+    assert (dl == pts).all() and not dinf.any()
+    for n in sizes:
+        sc = cp.random_fr(curve, 200 + n, n)
+        exp, einf = cp.msm(curve, group, pts[:n], sc, chunks=4)
+        got = gpu_affine(ctx, bases, sc, n=n)
+        assert got == pt_from_limbs(curve, group, exp, einf), (curve, group, n)
+    bases.free()
+
+
+@pytest.mark.parametrize("curve,group", [(0, 1), (1, 1), (0, 2)])
+def test_msm_edge_cases(ctx, curve, group):
+    """scalars {0, 1, r-1}, duplicate / negated / infinity bases, all-zero scalars, empty input, offsets."""
+    C = CURVES[curve]
+    G = C.g1 if group == 1 else C.g2
+    n = 64
+    ks = cp.random_fr(curve, 5, n)
+    pts, _ = cp.batch_mul(curve, group, ks)
+    P = [pt_from_limbs(curve, group, pts[i]) for i in range(n)]
+    P[1] = P[0]                 # duplicate
+    P[2] = G.neg(P[0])          # negation of a base that is also present
+    P[3] = None                 # infinity base
+    P[10] = P[11]
+    arr = pts_arr(curve, group, P)
+    infs = np.array([1 if p is None else 0 for p in P], dtype=np.uint8)
+    bases = ctx.upload_bases(curve, group, arr, infs)
+    sc = fr_ints(cp.random_fr(curve, 6, n))
+    sc[0] = sc[1] = sc[2] = 12345  # P0*k + P0*k - P0*k
+    sc[4] = 0
+    sc[5] = 1
+    sc[6] = C.r - 1
+    sc[7] = 1
+    sc[10] = 77
+    sc[11] = C.r - 77            # cancels with the duplicate base
+    exp = po.msm_naive(G, P, sc)
+    assert gpu_affine(ctx, bases, fr_arr(sc)) == exp
+    for c in (2, 3, 7, 12, 16):
+        ctx.set_option("msm_window_bits", c)
+        assert gpu_affine(ctx, bases, fr_arr(sc)) == exp, c
+    ctx.set_option("msm_window_bits", 0)
+    zero = np.zeros((n, 4), dtype=np.uint64)
+    assert gpu_affine(ctx, bases, zero) is None
+    assert gpu_affine(ctx, bases, zero[:0], n=0) is None
+    one = zero.copy()
+    one[:, 0] = 1
+    assert gpu_affine(ctx, bases, one) == po.msm_naive(G, P, [1] * n)
+    # offset / sub-range (the reference passes iterator sub-ranges: prover.hpp:133-139)
+    assert gpu_affine(ctx, bases, fr_arr(sc[20:50]), offset=20, n=30) == po.msm_naive(G, P[20:50], sc[20:50])
+    with pytest.raises(Exception):
+        ctx.msm(bases, fr_arr(sc), offset=10, n=n)
+    bases.free()
+
+
+@pytest.mark.parametrize("curve,group,n", [(0, 1, 500), (1, 2, 60)])
+def test_bases_from_scalars(ctx, curve, group, n):
+    """device-side fixed-base batch exponentiation (generator.hpp:187-214) against the oracle"""
+    ks = cp.random_fr(curve, 42, n)
+    ks[0] = 0
+    ks[1] = [1, 0, 0, 0]
+    exp, einf = cp.batch_mul(curve, group, ks)
+    b = ctx.bases_from_scalars(curve, group, ks)
+    got, ginf = b.download()
+    assert (ginf == einf).all() and (got == exp).all()
+    b.free()
+
+
+def test_msm_full_size_bls12_381_g1(ctx):
+    """BASELINE config 2: 2^20 points, bit-exact against the oracle, plus linearity at full size."""
+    n = 1 << 20
+    ks = cp.random_fr(0, 1, n)
+    bases = ctx.bases_from_scalars(0, 1, ks)
+    # spot-check the device-generated bases against the oracle
+    sample = np.array([0, 1, 77777, n - 1])
+    exp_pts, _ = cp.batch_mul(0, 1, ks[sample])
+    for j, i in enumerate(sample):
+        got, _ = bases.download(int(i), 1)
+        assert (got[0] == exp_pts[j]).all()
+    s1 = cp.random_fr(0, 2, n)
+    s2 = cp.random_fr(0, 3, n)
+    G = po.BLS12_381.g1
+    r1 = gpu_affine(ctx, bases, s1)
+    # oracle on the same inputs (all host cores)
+    allpts, _ = bases.download()
+    exp, einf = cp.msm(0, 1, allpts, s1, chunks=cp.num_threads())
+    assert r1 == pt_from_limbs(0, 1, exp, einf)
+    # linearity: MSM(s1) + MSM(s2) == MSM(s1 + s2 mod r)
+    r2 = gpu_affine(ctx, bases, s2)
+    r = po.BLS12_381.r
+    ssum = fr_arr([(a + b) % r for a, b in zip(fr_ints(s1), fr_ints(s2))])
+    assert gpu_affine(ctx, bases, ssum) == G.add(r1, r2)
+    # Groth16-like scalar distribution: half of the scalars in {0, 1}
+    s3 = s1.copy()
+    s3[::4] = 0
+    s3[1::4] = [1, 0, 0, 0]
+    exp, einf = cp.msm(0, 1, allpts, s3, chunks=cp.num_threads())
+    assert gpu_affine(ctx, bases, s3) == pt_from_limbs(0, 1, exp, einf)
+    bases.free()

@@ -1,0 +1,89 @@
+"""Parity of the HIP NTT (through the C ABI) against the oracle: every size 2^0..2^13, batches,
+forward / inverse / coset, the tunables that change the pass structure, and BASELINE config 3 (2^22 x 8)
+through a bit-exact comparison plus round-trip and random-point (Horner) properties."""
+import numpy as np
+import pytest
+
+import cport as cp
+import pyoracle as po
+from util import CURVES, fr_ints, limbs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_ntt_all_small_sizes(ctx, curve):
+    C = CURVES[curve]
+    g = limbs(C.fr_generator, 4)
+    for log_m in range(0, 14):
+        m = 1 << log_m
+        batch = 3 if log_m < 12 else 1
+        w = limbs(C.root_of_unity(log_m), 4)
+        a = cp.random_fr(curve, 1000 + log_m, batch * m).reshape(batch, m, 4)
+        exp = cp.ntt(curve, a, log_m, w)
+        got = ctx.ntt(curve, a, log_m, w)
+        assert (got == exp).all(), (curve, log_m)
+        if log_m <= 6:
+            assert fr_ints(got[0]) == po.dft_naive(fr_ints(a[0]), C.root_of_unity(log_m), C.r)
+        assert (ctx.ntt(curve, got, log_m, w, inverse=True) == a).all()
+        expc = cp.ntt(curve, a, log_m, w, coset=g)
+        gotc = ctx.ntt(curve, a, log_m, w, coset=g)
+        assert (gotc == expc).all()
+        assert (ctx.ntt(curve, gotc, log_m, w, inverse=True, coset=g) == a).all()
+        assert (ctx.ntt(curve, a, log_m, w, inverse=True, coset=g) == cp.ntt(curve, a, log_m, w, inverse=True, coset=g)).all()
+
+
+def test_ntt_pass_structure_options(ctx):
+    C = po.BLS12_381
+    log_m = 11
+    m = 1 << log_m
+    w = limbs(C.root_of_unity(log_m), 4)
+    a = cp.random_fr(0, 9, 2 * m).reshape(2, m, 4)
+    exp = cp.ntt(0, a, log_m, w)
+    try:
+        for radix in (1, 2, 3, 4, 5, 6, 8, 10):
+            for tile in (0, 1, 3, 4):
+                ctx.set_option("ntt_radix_log", radix)
+                ctx.set_option("ntt_tile_log", tile)
+                assert (ctx.ntt(0, a, log_m, w) == exp).all(), (radix, tile)
+    finally:
+        ctx.set_option("ntt_radix_log", 8)
+        ctx.set_option("ntt_tile_log", 3)
+
+
+def test_ntt_edge_values(ctx):
+    """all-zero, all-(r-1), delta and constant vectors; non-standard omega (another primitive root)."""
+    C = po.BLS12_381
+    log_m = 9
+    m = 1 << log_m
+    w0 = C.root_of_unity(log_m)
+    w = limbs(pow(w0, 5, C.r), 4)  # any odd power is again a primitive m-th root: omega is an argument
+    vecs = np.zeros((4, m, 4), dtype=np.uint64)
+    vecs[1, :] = limbs(C.r - 1, 4)
+    vecs[2, 0] = limbs(C.r - 1, 4)
+    vecs[3, :] = limbs(7, 4)
+    exp = cp.ntt(0, vecs, log_m, w)
+    assert (ctx.ntt(0, vecs, log_m, w) == exp).all()
+    assert fr_ints(exp[3])[0] == 7 * m % C.r and all(v == 0 for v in fr_ints(exp[3])[1:])
+
+
+def test_ntt_full_size_2_22_batch_8(ctx):
+    """BASELINE config 3.  Bit-exact against the oracle on every polynomial; round trip on the batch;
+    out[i] = f(omega^i) checked by Horner evaluation at sampled points."""
+    C = po.BLS12_381
+    log_m, batch = 22, 8
+    m = 1 << log_m
+    w_int = C.root_of_unity(log_m)
+    w = limbs(w_int, 4)
+    a = cp.random_fr(0, 1, batch * m).reshape(batch, m, 4)
+    got = ctx.ntt(0, a, log_m, w)
+    exp = cp.ntt(0, a, log_m, w)
+    assert (got == exp).all()
+    for b, i in ((0, 0), (0, 1), (3, 123456), (7, m - 1), (5, m // 2)):
+        x = limbs(pow(w_int, i, C.r), 4)
+        assert (cp.fr_horner(0, a[b], x) == got[b, i]).all()
+    assert (ctx.ntt(0, got, log_m, w, inverse=True) == a).all()
+    g = limbs(C.fr_generator, 4)
+    gotc = ctx.ntt(0, a[:2], log_m, w, coset=g)
+    assert (gotc == cp.ntt(0, a[:2], log_m, w, coset=g)).all()
+    assert (ctx.ntt(0, gotc, log_m, w, inverse=True, coset=g) == a[:2]).all()

@@ -1,0 +1,152 @@
+"""The __host__ __device__ field / curve / recoding code of crypto3-zk_amd/csrc (fp.hpp, curve.hpp,
+msm_recode.hpp), compiled for the CPU into libzkhip_hosttest.so, against the big-integer oracle.
+This checks the exact arithmetic the GPU kernels run, without a GPU.  (The shim is test-only.)"""
+import ctypes
+import os
+import random
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+from util import CURVES, FQ_LIMBS, pt_from_limbs, pts_arr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "crypto3-zk_amd", "libzkhip_hosttest.so")
+
+
+@pytest.fixture(scope="module")
+def shim():
+    if not os.path.exists(SO):
+        pytest.fail(f"{SO} missing: run __graft_entry__.build()")
+    return ctypes.CDLL(SO)
+
+
+def _u32(v, n32):
+    return np.array([(v >> (32 * i)) & 0xFFFFFFFF for i in range(n32)], dtype=np.uint32)
+
+
+def _int(a):
+    return sum(int(x) << (32 * i) for i, x in enumerate(a))
+
+
+FIELDS = {0: (po.BLS12_381.p, 12), 1: (po.BLS12_381.r, 8), 2: (po.BN254.p, 8), 3: (po.BN254.r, 8)}
+
+
+@pytest.mark.parametrize("field", [0, 1, 2, 3])
+def test_prime_field_ops(shim, field):
+    p, nl = FIELDS[field]
+    random.seed(field)
+    edge = [0, 1, 2, p - 1, p - 2, (1 << (32 * nl - 1)) % p, (p + 1) // 2]
+    vals = edge + [random.randrange(p) for _ in range(40)]
+    out = np.zeros(nl, dtype=np.uint32)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for i, a in enumerate(vals):
+        b = vals[(i * 7 + 3) % len(vals)]
+        A, B = _u32(a, nl), _u32(b, nl)
+        for op, fn in ((0, lambda: a * b % p), (1, lambda: (a + b) % p), (2, lambda: (a - b) % p), (4, lambda: a * a % p),
+                       (5, lambda: (-a) % p), (6, lambda: 2 * a % p)):
+            assert shim.zkt_field_op(field, op, P(A), P(B), P(out)) == 0
+            assert _int(out) == fn(), (field, op, hex(a), hex(b))
+        if a and i < 12:
+            assert shim.zkt_field_op(field, 3, P(A), None, P(out)) == 0
+            assert _int(out) == pow(a, -1, p)
+
+
+@pytest.mark.parametrize("field,curve", [(4, 0), (5, 1)])
+def test_fq2_ops(shim, field, curve):
+    C = CURVES[curve]
+    p, F = C.p, po.Fq2(C.p)
+    nl = FQ_LIMBS[curve] * 2
+    random.seed(11)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    out = np.zeros(2 * nl, dtype=np.uint32)
+    pack = lambda x: np.concatenate([_u32(x[0], nl), _u32(x[1], nl)])
+    unpack = lambda o: (_int(o[:nl]), _int(o[nl:]))
+    vals = [(0, 0), (1, 0), (0, 1), (p - 1, p - 1)] + [(random.randrange(p), random.randrange(p)) for _ in range(12)]
+    for i, a in enumerate(vals):
+        b = vals[(i * 5 + 2) % len(vals)]
+        for op, fn in ((0, lambda: F.mul(a, b)), (1, lambda: F.add(a, b)), (2, lambda: F.sub(a, b)), (4, lambda: F.sqr(a)),
+                       (5, lambda: F.neg(a)), (6, lambda: F.add(a, a))):
+            assert shim.zkt_field_op(field, op, P(pack(a)), P(pack(b)), P(out)) == 0
+            assert unpack(out) == fn(), (op, a, b)
+        if not F.is_zero(a) and i < 8:
+            assert shim.zkt_field_op(field, 3, P(pack(a)), None, P(out)) == 0
+            assert unpack(out) == F.inv(a)
+
+
+def _chain(shim, curve, group, pts, infs, negs, mode, k=0):
+    arr = pts_arr(curve, group, pts).view(np.uint32).reshape(len(pts), -1) if len(pts) else np.zeros((0, 1), dtype=np.uint32)
+    arr = np.ascontiguousarray(arr)
+    ncoord = 3 if mode == 3 else 2
+    out = np.zeros(ncoord * FQ_LIMBS[curve] * group * 2, dtype=np.uint32)
+    oinf = np.zeros(1, dtype=np.uint8)
+    infa = np.array(infs, dtype=np.uint8)
+    nega = np.array(negs, dtype=np.uint8)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert shim.zkt_point_chain(curve, group, P(arr), P(infa), P(nega), ctypes.c_size_t(len(pts)), mode, ctypes.c_uint32(k), P(out), P(oinf)) == 0
+    return out.view(np.uint64), int(oinf[0])
+
+
+@pytest.mark.parametrize("curve,group", [(0, 1), (0, 2), (1, 1), (1, 2)])
+def test_xyzz_group_law(shim, curve, group):
+    """madd chains incl. the special cases the bucket method meets: P+P, P+(-P), infinity operands."""
+    C = CURVES[curve]
+    G = C.g1 if group == 1 else C.g2
+    rng = po.SplitMix64(curve * 10 + group)
+    ks = [rng.next_mod(C.r) for _ in range(6)]
+    base = G.batch_mul_gen(ks)
+    P0, P1, P2 = base[0], base[1], base[2]
+    cases = [
+        ([P0, P1, P2, base[3], base[4], base[5]], [0] * 6, [0, 1, 0, 1, 1, 0]),
+        ([P0, P0], [0, 0], [0, 0]),            # doubling inside madd
+        ([P0, P0, P0, P0], [0] * 4, [0] * 4),  # 4P via dbl then adds
+        ([P0, P0], [0, 0], [0, 1]),            # P + (-P) = infinity
+        ([P0, P0, P1], [0, 0, 0], [0, 1, 0]),  # infinity then restart
+        ([P0, P1], [1, 0], [0, 0]),            # infinity operand
+        ([], [], []),
+    ]
+    sgn = lambda P, n: G.neg(P) if n else P
+    for pts, infs, negs in cases:
+        exp = None
+        for Pt, i, n in zip(pts, infs, negs):
+            if not i:
+                exp = G.add(exp, sgn(Pt, n))
+        out, oinf = _chain(shim, curve, group, pts, infs, negs, 0)
+        assert pt_from_limbs(curve, group, out, oinf) == exp
+        if len(pts) >= 2:
+            out, oinf = _chain(shim, curve, group, pts, infs, negs, 1)  # xyzz_add of the two halves
+            assert pt_from_limbs(curve, group, out, oinf) == exp
+            for k in (0, 1, 2, 37, 32768, 65535):
+                out, oinf = _chain(shim, curve, group, pts, infs, negs, 2, k)
+                assert pt_from_limbs(curve, group, out, oinf) == G.mul(exp, k)
+        out, oinf = _chain(shim, curve, group, pts, infs, negs, 3)  # XYZZ -> Jacobian
+        L = FQ_LIMBS[curve] * group
+        if exp is None:
+            assert oinf == 1 and po.from_limbs(out[2 * L:3 * L]) == 0
+        else:
+            from util import jac_to_affine_py
+            assert jac_to_affine_py(curve, group, out.reshape(3, L)) == exp
+    # xyzz_add doubling branch: same chain in both halves
+    pts = [P0, P1, P0, P1]
+    out, oinf = _chain(shim, curve, group, pts, [0] * 4, [0] * 4, 1)
+    assert pt_from_limbs(curve, group, out, oinf) == G.mul(G.add(P0, P1), 2)
+    # and the cancelling branch
+    out, oinf = _chain(shim, curve, group, pts, [0] * 4, [0, 0, 1, 1], 1)
+    assert oinf == 1
+
+
+@pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 13, 16])
+def test_signed_digit_recoding(shim, c):
+    r = po.BLS12_381.r
+    random.seed(c)
+    W = (256 + c - 1) // c
+    B = 1 << (c - 1)
+    vals = [0, 1, 2, B, B + 1, (1 << c) - 1, 1 << c, r - 1, r - 2, (1 << 255) - 1] + [random.randrange(r) for _ in range(50)]
+    dig = np.zeros(W, dtype=np.int32)
+    for v in vals:
+        s = _u32(v, 8)
+        carry = shim.zkt_recode(s.ctypes.data_as(ctypes.c_void_p), c, W, dig.ctypes.data_as(ctypes.c_void_p))
+        assert carry == 0
+        assert all(-B < int(d) <= B for d in dig)
+        assert sum(int(d) << (c * w) for w, d in enumerate(dig)) == v

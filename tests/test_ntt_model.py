@@ -1,0 +1,139 @@
+"""Line-by-line CPU replay of the index arithmetic of crypto3-zk_amd/csrc/ntt.hip (pass planning, tile
+load with inter-pass twiddles, in-LDS DIF stages, bit-reversed read-out with both store decodings,
+ping-pong buffer choice) on Python integers, checked against the O(n^2) DFT.  Catches indexing mistakes
+without a GPU; the arithmetic itself is covered by test_host_arith.py."""
+import random
+
+import pytest
+
+import pyoracle as po
+
+
+def plan(log_m, smax=8, tile_log=3):
+    np_ = (log_m + smax - 1) // smax
+    sv = [log_m // np_ + (1 if i < log_m % np_ else 0) for i in range(np_)]
+    passes = []
+    log_ns = 0
+    for s in sv:
+        log_cols = log_m - s
+        log_t = min(tile_log, log_cols)
+        while s + log_t > 12 and log_t > 0:
+            log_t -= 1
+        passes.append((s, log_ns, log_t))
+        log_ns += s
+    return passes
+
+
+def bitrev(v, bits):
+    return int(bin(v)[2:].zfill(bits)[::-1], 2) if bits else 0
+
+
+def kernel_pass(x, log_m, s, log_ns, log_t, w, r, nth=4, pre=None, post=None, scale=None):
+    m = 1 << log_m
+    R, T = 1 << s, 1 << log_t
+    nelem = R * T
+    log_stride = log_m - s
+    ns_mask = (1 << log_ns) - 1
+    tw_shift = log_m - log_ns - s
+    y = [None] * m
+    for tile in range(1 << (log_m - s - log_t)):
+        j0 = tile << log_t
+        twr = [pow(w, q << log_stride, r) for q in range(R // 2)]
+        lds = [0] * nelem
+        for e in range(nelem):
+            t, c = e >> log_t, e & (T - 1)
+            j = j0 + c
+            gi = j + (t << log_stride)
+            v = x[gi]
+            if pre is not None:
+                v = v * pow(pre, gi, r) % r
+            if log_ns:
+                k = j & ns_mask
+                ex = (k * t) << tw_shift
+                assert ex < m
+                v = v * pow(w, ex, r) % r
+            lds[e] = v
+        for st in range(s):
+            h = R >> (st + 1)
+            for bf in range(nelem >> 1):
+                c, q = bf & (T - 1), bf >> log_t
+                qq = q & (h - 1)
+                t_lo = ((q - qq) << 1) + qq
+                e0, e1 = (t_lo << log_t) + c, ((t_lo + h) << log_t) + c
+                a, b = lds[e0], lds[e1]
+                u, v = (a + b) % r, (a - b) % r
+                if h != 1:
+                    v = v * twr[qq << st] % r
+                lds[e0], lds[e1] = u, v
+        for e in range(nelem):
+            if log_ns >= log_t:
+                tp, c = e >> log_t, e & (T - 1)
+            else:
+                k_lo = e & ns_mask
+                tp = (e >> log_ns) & (R - 1)
+                c_hi = e >> (log_ns + s)
+                c = (c_hi << log_ns) + k_lo
+            j = j0 + c
+            k = j & ns_mask
+            oi = ((j - k) << s) + k + (tp << log_ns)
+            v = lds[(bitrev(tp, s) << log_t) + c]
+            if scale is not None:
+                v = v * scale % r
+            if post is not None:
+                v = v * pow(post, oi, r) % r
+            assert y[oi] is None
+            y[oi] = v
+    assert all(v is not None for v in y)
+    return y
+
+
+def model_ntt(a, log_m, w, r, inverse=False, coset=None, smax=8, tile_log=3):
+    if log_m == 0:
+        return list(a)
+    weff = pow(w, -1, r) if inverse else w
+    geff = None if coset is None else (pow(coset, -1, r) if inverse else coset)
+    passes = plan(log_m, smax, tile_log)
+    x = list(a)
+    for i, (s, log_ns, log_t) in enumerate(passes):
+        last = i == len(passes) - 1
+        x = kernel_pass(x, log_m, s, log_ns, log_t, weff, r,
+                        pre=geff if (not inverse and coset is not None and i == 0) else None,
+                        post=geff if (inverse and coset is not None and last) else None,
+                        scale=pow(1 << log_m, -1, r) if (inverse and last) else None)
+    return x
+
+
+@pytest.mark.parametrize("log_m,smax,tile_log", [(1, 8, 3), (2, 8, 3), (3, 2, 1), (4, 2, 3), (5, 2, 1), (5, 3, 3), (6, 2, 2),
+                                                 (6, 3, 0), (7, 3, 2), (7, 4, 3), (8, 3, 1), (9, 4, 2)])
+def test_kernel_index_model(log_m, smax, tile_log):
+    C = po.BLS12_381
+    r = C.r
+    random.seed(log_m * 100 + smax)
+    m = 1 << log_m
+    w = C.root_of_unity(log_m)
+    a = [random.randrange(r) for _ in range(m)]
+    d = po.ntt(a, w, r)
+    if m <= 64:
+        assert d == po.dft_naive(a, w, r)
+    assert model_ntt(a, log_m, w, r, smax=smax, tile_log=tile_log) == d
+    assert model_ntt(d, log_m, w, r, inverse=True, smax=smax, tile_log=tile_log) == a
+    g = C.fr_generator
+    dc = po.ntt(po.multiply_by_coset(a, g, r), w, r)
+    assert model_ntt(a, log_m, w, r, coset=g, smax=smax, tile_log=tile_log) == dc
+    assert model_ntt(dc, log_m, w, r, inverse=True, coset=g, smax=smax, tile_log=tile_log) == a
+
+
+def test_buffer_schedule():
+    """Mirror of the ping-pong choice in ntt_run_t: the last pass writes `data`, no pass reads what it writes."""
+    for np_ in range(1, 9):
+        src = "data"
+        for i in range(np_):
+            if np_ == 1:
+                dst = "data"
+            else:
+                dst = "data" if (np_ - 1 - i) % 2 == 0 else "A"
+                if i == 0 and dst == "data":
+                    dst = "B"
+                assert dst != src
+            src = dst
+        assert src == "data"

@@ -1,0 +1,139 @@
+"""The oracle is pinned before it is trusted: pyoracle against the reference's own known-answer vectors
+(tests/golden/ref_kat.json, literals extracted by tests/golden/make_ref_kat.py), then the C++ restatement
+(oracle/zk_oracle.cpp) against pyoracle.  CPU only."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import cport as cp
+import pyoracle as po
+from util import CURVES, fr_arr, fr_ints, limbs, pt_limbs, pts_arr
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "ref_kat.json")))
+h = lambda s: int(s, 16)
+
+
+def test_ref_polynomial_kat():
+    """AGG:578-862 bls381_polynomial_test: 256 Fr coefficients + 1 evaluation."""
+    p = KAT["polynomial_test"]
+    r = po.BLS12_381.r
+    tr = [h(x) for x in p["tr"]]
+    assert po.ipp2_poly_coeffs(tr, h(p["r_shift"]), r) == [h(x) for x in p["coeffs"]]
+    assert po.ipp2_poly_eval(tr, h(p["kzg_challenge"]), h(p["r_shift"]), r) == h(p["eval"])
+
+
+def _kat_msm_inputs():
+    q = KAT["prove_commitment_test"]
+    C = po.BLS12_381
+    tr = [h(x) for x in q["tr"]]
+    qv, ha, hb = po.ipp2_prove_commitment_v(C, q["n"], h(q["alpha"]), h(q["beta"]), tr, h(q["kzg_challenge"]))
+    qw, ga, gb = po.ipp2_prove_commitment_w(C, q["n"], h(q["alpha"]), h(q["beta"]), tr, h(q["r_shift"]), h(q["kzg_challenge"]))
+    g2 = lambda e: ((h(e[0][0]), h(e[0][1])), (h(e[1][0]), h(e[1][1])))
+    g1 = lambda e: (h(e[0]), h(e[1]))
+    return [
+        (2, ha, qv, g2(q["comm_v"][0])),
+        (2, hb, qv, g2(q["comm_v"][1])),
+        (1, ga, qw, g1(q["comm_w"][0])),
+        (1, gb, qw, g1(q["comm_w"][1])),
+    ]
+
+
+def test_ref_msm_kat_python():
+    """AGG:864-930 bls381_prove_commitment_test: 2 x G2 (n=8) and 2 x G1 (n=16) MSM through multiexp."""
+    C = po.BLS12_381
+    for group, bases, scalars, expected in _kat_msm_inputs():
+        G = C.g1 if group == 1 else C.g2
+        assert po.msm_naive(G, bases, scalars) == expected
+        assert po.msm_pippenger(G, bases, scalars, c=3) == expected
+
+
+def test_ref_msm_kat_cport():
+    for group, bases, scalars, expected in _kat_msm_inputs():
+        out, inf = cp.msm(0, group, pts_arr(0, group, bases), fr_arr(scalars), chunks=2)
+        assert inf == 0 and (out == pt_limbs(0, group, expected)).all()
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_ref_kzg_basic_identity(curve):
+    """kzg.cpp:75-103: commit({-1,1,2,3}; alpha=10) = 3209 * G (curve independent)."""
+    C = CURVES[curve]
+    k = KAT["kzg_basic_test"]
+    ck = po.structured_generators(C.g1, 4, k["alpha"])
+    f = [x % C.r for x in k["f"]]
+    exp = C.g1.mul(C.g1.gen, k["commit_scalar"])
+    assert po.msm_naive(C.g1, ck, f) == exp
+    out, inf = cp.msm(curve, 1, pts_arr(curve, 1, ck), fr_arr(f))
+    assert (out == pt_limbs(curve, 1, exp)).all()
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_cport_matches_python(curve):
+    C = CURVES[curve]
+    one = np.array([[1, 0, 0, 0]], dtype=np.uint64)
+    assert (cp.batch_mul(curve, 1, one)[0][0] == pt_limbs(curve, 1, C.g1.gen)).all()
+    assert (cp.batch_mul(curve, 2, one)[0][0] == pt_limbs(curve, 2, C.g2.gen)).all()
+    sc = cp.random_fr(curve, 7, 24)
+    rng = po.SplitMix64(7)
+    ks = [rng.next_mod(C.r) for _ in range(24)]
+    assert fr_ints(sc) == ks
+    for group in (1, 2):
+        G = C.g1 if group == 1 else C.g2
+        pts, inf = cp.batch_mul(curve, group, sc[:12])
+        exp = G.batch_mul_gen(ks[:12])
+        assert (pts == pts_arr(curve, group, exp)).all()
+        s2 = cp.random_fr(curve, 8, 12)
+        s2[0] = 0
+        s2[1] = [1, 0, 0, 0]
+        s2[2] = limbs(C.r - 1, 4)
+        e = po.msm_naive(G, exp, fr_ints(s2))
+        for kw in (dict(chunks=1), dict(chunks=3), dict(naive=True)):
+            out, oinf = cp.msm(curve, group, pts, s2, **kw)
+            assert oinf == 0 and (out == pt_limbs(curve, group, e)).all()
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_ntt_oracles(curve):
+    C = CURVES[curve]
+    random.seed(5)
+    for lg, rad in ((3, [8]), (4, [4, 4]), (5, [2, 4, 4]), (6, [4, 2, 8]), (6, [8, 8])):
+        m = 1 << lg
+        w = C.root_of_unity(lg)
+        a = [random.randrange(C.r) for _ in range(m)]
+        d = po.dft_naive(a, w, C.r)
+        assert po.ntt(a, w, C.r) == d
+        assert po.stockham_model(a, w, C.r, rad) == d
+        assert po.intt(d, w, C.r) == a
+        arr = fr_arr(a).reshape(1, m, 4)
+        assert fr_ints(cp.ntt(curve, arr, lg, limbs(w, 4))[0]) == d
+        g = C.fr_generator
+        e = po.ntt(po.multiply_by_coset(a, g, C.r), w, C.r)
+        oc = cp.ntt(curve, arr, lg, limbs(w, 4), coset=limbs(g, 4))
+        assert fr_ints(oc[0]) == e
+        assert (cp.ntt(curve, oc, lg, limbs(w, 4), inverse=True, coset=limbs(g, 4)) == arr).all()
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_groth16_oracles_in_exponent(curve):
+    """Whole proofs are unpinned in the reference (random r, s); pin both oracles to the trapdoor identity."""
+    C = CURVES[curve]
+    M, n = 16, 3
+    cs, prim, aux = po.r1cs_example_field_input(C.r, M, n, seed=1)
+    assert po.r1cs_is_satisfied(cs, prim, aux, C.r)
+    g = cp.Groth16(curve, M, n, seed=1)
+    assert g.is_satisfied() and fr_ints(g.assignment()) == prim + aux
+    w = C.root_of_unity(g.log_m)
+    rng = po.SplitMix64(99)
+    trap = [rng.next_mod(C.r) for _ in range(5)]
+    rr, ss = rng.next_mod(C.r), rng.next_mod(C.r)
+    g.keygen(fr_arr(trap), limbs(w, 4))
+    H = g.witness_map(limbs(w, 4), limbs(C.fr_generator, 4))
+    assert fr_ints(H) == po.witness_map(po.swap_AB_if_beneficial(cs), prim, aux, w, C.fr_generator, C.r)
+    proof = g.prove(limbs(rr, 4), limbs(ss, 4), limbs(w, 4), limbs(C.fr_generator, 4), chunks=2)
+    eA, eB, eC = po.groth16_expected_in_exponent(C, cs, prim, aux, trap, rr, ss, w)
+    assert (proof == np.concatenate([pt_limbs(curve, 1, eA), pt_limbs(curve, 2, eB), pt_limbs(curve, 1, eC)])).all()
+    pk = po.groth16_keygen(C, cs, trap, w)
+    assert po.groth16_prove(C, pk, prim, aux, rr, ss, w) == (eA, eB, eC)

@@ -1,0 +1,63 @@
+"""Shared helpers for the tests: canonical-limb conversions between Python ints and numpy arrays."""
+import numpy as np
+import pyoracle as po
+
+CURVES = {0: po.BLS12_381, 1: po.BN254}
+FQ_LIMBS = {0: 6, 1: 4}
+
+
+def limbs(v, n):
+    return np.array(po.to_limbs(v, n), dtype=np.uint64)
+
+
+def fr_arr(vals):
+    return np.array([po.to_limbs(v, 4) for v in vals], dtype=np.uint64).reshape(len(vals), 4)
+
+
+def fr_ints(arr):
+    return [po.from_limbs(x) for x in np.asarray(arr).reshape(-1, 4)]
+
+
+def pt_limbs(curve, group, P):
+    """affine point (python) -> flat canonical limbs; None -> zeros"""
+    L = FQ_LIMBS[curve]
+    if P is None:
+        return np.zeros(2 * L * group, dtype=np.uint64)
+    if group == 1:
+        return np.concatenate([limbs(P[0], L), limbs(P[1], L)])
+    return np.concatenate([limbs(P[0][0], L), limbs(P[0][1], L), limbs(P[1][0], L), limbs(P[1][1], L)])
+
+
+def pts_arr(curve, group, pts):
+    return np.stack([pt_limbs(curve, group, P) for P in pts]) if len(pts) else np.zeros((0, 2 * FQ_LIMBS[curve] * group), dtype=np.uint64)
+
+
+def pt_from_limbs(curve, group, a, inf=0):
+    if inf:
+        return None
+    L = FQ_LIMBS[curve]
+    a = np.asarray(a).reshape(-1)
+    f = lambda i: po.from_limbs(a[i * L:(i + 1) * L])
+    if group == 1:
+        return (f(0), f(1))
+    return ((f(0), f(1)), (f(2), f(3)))
+
+
+def jac_to_affine_py(curve, group, jac):
+    """Jacobian canonical limbs (3, coord) -> python affine point via big-int inversion (checker side)."""
+    C = CURVES[curve]
+    G = C.g1 if group == 1 else C.g2
+    L = FQ_LIMBS[curve]
+    jac = np.asarray(jac).reshape(3, -1)
+
+    def coord(row):
+        if group == 1:
+            return po.from_limbs(row[:L])
+        return (po.from_limbs(row[:L]), po.from_limbs(row[L:2 * L]))
+
+    return G.to_affine((coord(jac[0]), coord(jac[1]), coord(jac[2])))
+
+
+def group_of(curve, group):
+    C = CURVES[curve]
+    return C.g1 if group == 1 else C.g2
