@@ -141,7 +141,8 @@ struct zkhip_ctx {
 // implemented in msm.hip / ntt.hip
 int zk_msm_run(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac);
 size_t zk_coord_limbs64(int curve, int group);  // u64 limbs per coordinate (Fq: 6/4, Fq2: 12/8)
-int zk_bases_to_mont(zkhip_ctx *ctx, zkhip_bases *b, const uint8_t *d_inf);
+int zk_bases_to_mont(zkhip_ctx *ctx, zkhip_bases *b, const uint32_t *d_canonical, const uint8_t *d_inf);
+size_t zk_point_words(int curve, int group);  // u32 words per affine point in device buffers
 int zk_bases_from_mont(zkhip_ctx *ctx, const zkhip_bases *b, size_t offset, size_t n, uint32_t *d_out, uint8_t *d_inf);
 int zk_bases_mul(zkhip_ctx *ctx, zkhip_bases *b, const uint32_t *d_base_canonical /* nullable: generator */, const uint32_t *d_scalars);
 int zk_jac_sum(zkhip_ctx *ctx, int curve, int group, const uint32_t *d_pts, size_t count, uint32_t *d_out);

@@ -1,30 +1,37 @@
 // Short-Weierstrass y^2 = x^3 + b (a = 0) group law in extended Jacobian ("XYZZ") coordinates,
-// generic over the coordinate field F (Fq for G1, Fq2 for G2).
+// generic over the coordinate field F through FieldOps<F> (fu.hpp): the lazy 29-bit-limb types Fu / Fu2
+// that the kernels compute in, or the exactly-reduced saturated types Fp / Fp2 (reference path).
 //
-//   x = X / ZZ,  y = Y / ZZZ,  ZZ^3 = ZZZ^2;   infinity <=> ZZ == 0
+//   x = X / ZZ,  y = Y / ZZZ,  ZZ^3 = ZZZ^2;   infinity <=> ZZ is the exact zero
 //
 // XYZZ mixed addition costs 8M + 2S (vs 7M + 4S for Jacobian) and needs no special-casing of Z = 1,
 // which is why the bucket accumulators of the Pippenger kernels (msm.hip) use it.  All formulas are
 // complete for the cases the bucket method meets: P + P (doubling), P + (-P) (infinity), and either
-// operand at infinity.  The reference reaches the group law through crypto3-algebra
-// (`G::value_type` operator+, `mixed_add`: knowledge_commitment_multiexp.hpp:91-97); the result of a
-// sum is coordinate-system independent once normalised to affine, which is what parity is asserted on.
+// operand at infinity.  (Points of order 2 do not exist: all four groups have odd order.)
+// The reference reaches the group law through crypto3-algebra (`G::value_type` operator+, `mixed_add`:
+// knowledge_commitment_multiexp.hpp:91-97); a sum is coordinate-system independent once normalised to
+// affine, which is what parity is asserted on.
+//
+// Lazy-reduction bounds (units of p; MULB = bound of a product: 2 for Fu, 10 for Fu2):
+//   stored X, Y < MULB + K1;  stored ZZ, ZZZ < MULB;  affine inputs < MULB
+//   sub<K1>: subtrahend is a sum of at most three products (< 3 MULB <= K1 - 1)
+//   sub<K2>: subtrahend is a stored X / Y or another K1-difference (< MULB + K1 <= K2 - 1)
 #pragma once
-#include "fp.hpp"
+#include "fu.hpp"
 
 namespace zkhip {
 
 template <class F>
 struct Affine {  // (0, 0) encodes infinity: it is never on y^2 = x^3 + b with b != 0
     F x, y;
-    ZK_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+    ZK_HD bool is_inf() const { return FieldOps<F>::is_exact_zero(x) && FieldOps<F>::is_exact_zero(y); }
     ZK_HD static Affine infinity() { return {F::zero(), F::zero()}; }
 };
 
 template <class F>
 struct XYZZ {
     F X, Y, ZZ, ZZZ;
-    ZK_HD bool is_inf() const { return ZZ.is_zero(); }
+    ZK_HD bool is_inf() const { return FieldOps<F>::is_exact_zero(ZZ); }
     ZK_HD static XYZZ infinity() { return {F::zero(), F::zero(), F::zero(), F::zero()}; }
     ZK_HD static XYZZ from_affine(const Affine<F> &p) {
         if (p.is_inf()) return infinity();
@@ -40,82 +47,81 @@ struct Jacobian {
 // 2 * (affine p)
 template <class F>
 ZK_HD XYZZ<F> xyzz_dbl_affine(const Affine<F> &p) {
-    if (p.is_inf() || p.y.is_zero()) return XYZZ<F>::infinity();
-    F U = fp_dbl(p.y);
-    F V = fp_sqr(U);
-    F W = U * V;
-    F S = p.x * V;
-    F xx = fp_sqr(p.x);
-    F M = fp_dbl(xx) + xx;
-    F X3 = fp_sqr(M) - fp_dbl(S);
-    F Y3 = M * (S - X3) - W * p.y;
+    typedef FieldOps<F> O;
+    if (p.is_inf()) return XYZZ<F>::infinity();
+    F U = O::add(p.y, p.y);
+    F V = O::sqr(U);
+    F W = O::mul(U, V);
+    F S = O::mul(p.x, V);
+    F xx = O::sqr(p.x);
+    F M = O::add(O::add(xx, xx), xx);
+    F X3 = O::template sub<O::K1>(O::sqr(M), O::add(S, S));
+    F Y3 = O::template sub<O::K1>(O::mul(M, O::template sub<O::K2>(S, X3)), O::mul(W, p.y));
     return {X3, Y3, V, W};
 }
 
 // 2 * a
 template <class F>
 ZK_HD XYZZ<F> xyzz_dbl(const XYZZ<F> &a) {
-    if (a.is_inf() || a.Y.is_zero()) return XYZZ<F>::infinity();
-    F U = fp_dbl(a.Y);
-    F V = fp_sqr(U);
-    F W = U * V;
-    F S = a.X * V;
-    F xx = fp_sqr(a.X);
-    F M = fp_dbl(xx) + xx;
-    F X3 = fp_sqr(M) - fp_dbl(S);
-    F Y3 = M * (S - X3) - W * a.Y;
-    return {X3, Y3, V * a.ZZ, W * a.ZZZ};
+    typedef FieldOps<F> O;
+    if (a.is_inf()) return XYZZ<F>::infinity();
+    F U = O::add(a.Y, a.Y);
+    F V = O::sqr(U);
+    F W = O::mul(U, V);
+    F S = O::mul(a.X, V);
+    F xx = O::sqr(a.X);
+    F M = O::add(O::add(xx, xx), xx);
+    F X3 = O::template sub<O::K1>(O::sqr(M), O::add(S, S));
+    F Y3 = O::template sub<O::K1>(O::mul(M, O::template sub<O::K2>(S, X3)), O::mul(W, a.Y));
+    return {X3, Y3, O::mul(V, a.ZZ), O::mul(W, a.ZZZ)};
 }
 
 // a + (affine p); `negate` adds -p (signed-digit buckets)
 template <class F>
 ZK_HD XYZZ<F> xyzz_madd(const XYZZ<F> &a, const Affine<F> &p_in, bool negate = false) {
+    typedef FieldOps<F> O;
     if (p_in.is_inf()) return a;
     Affine<F> p = p_in;
-    if (negate) p.y = fp_neg(p.y);
+    if (negate) p.y = O::template sub<O::K1>(F::zero(), p.y);
     if (a.is_inf()) return {p.x, p.y, F::one(), F::one()};
-    F U2 = p.x * a.ZZ;
-    F S2 = p.y * a.ZZZ;
-    F Pd = U2 - a.X;
-    F R = S2 - a.Y;
-    if (Pd.is_zero()) {
-        if (R.is_zero()) return xyzz_dbl_affine(p);
+    F U2 = O::mul(p.x, a.ZZ);
+    F S2 = O::mul(p.y, a.ZZZ);
+    F Pd = O::template sub<O::K2>(U2, a.X);
+    F R = O::template sub<O::K2>(S2, a.Y);
+    F PP = O::sqr(Pd);
+    if (O::is_zero_product(PP)) {  // Pd = 0 mod p  <=>  same x: doubling or cancellation (rare)
+        if (O::is_zero(R)) return xyzz_dbl_affine(p);
         return XYZZ<F>::infinity();
     }
-    F PP = fp_sqr(Pd);
-    F PPP = Pd * PP;
-    F Q = a.X * PP;
-    F X3 = fp_sqr(R) - PPP - fp_dbl(Q);
-    F Y3 = R * (Q - X3) - a.Y * PPP;
-    return {X3, Y3, a.ZZ * PP, a.ZZZ * PPP};
+    F PPP = O::mul(Pd, PP);
+    F Q = O::mul(a.X, PP);
+    F X3 = O::template sub<O::K1>(O::sqr(R), O::add(PPP, O::add(Q, Q)));
+    F Y3 = O::template sub<O::K1>(O::mul(R, O::template sub<O::K2>(Q, X3)), O::mul(a.Y, PPP));
+    return {X3, Y3, O::mul(a.ZZ, PP), O::mul(a.ZZZ, PPP)};
 }
 
 // a + b
 template <class F>
 ZK_HD XYZZ<F> xyzz_add(const XYZZ<F> &a, const XYZZ<F> &b) {
+    typedef FieldOps<F> O;
     if (a.is_inf()) return b;
     if (b.is_inf()) return a;
-    F U1 = a.X * b.ZZ;
-    F U2 = b.X * a.ZZ;
-    F S1 = a.Y * b.ZZZ;
-    F S2 = b.Y * a.ZZZ;
-    F Pd = U2 - U1;
-    F R = S2 - S1;
-    if (Pd.is_zero()) {
-        if (R.is_zero()) return xyzz_dbl(a);
+    F U1 = O::mul(a.X, b.ZZ);
+    F U2 = O::mul(b.X, a.ZZ);
+    F S1 = O::mul(a.Y, b.ZZZ);
+    F S2 = O::mul(b.Y, a.ZZZ);
+    F Pd = O::template sub<O::K1>(U2, U1);
+    F R = O::template sub<O::K1>(S2, S1);
+    F PP = O::sqr(Pd);
+    if (O::is_zero_product(PP)) {
+        if (O::is_zero(R)) return xyzz_dbl(a);
         return XYZZ<F>::infinity();
     }
-    F PP = fp_sqr(Pd);
-    F PPP = Pd * PP;
-    F Q = U1 * PP;
-    F X3 = fp_sqr(R) - PPP - fp_dbl(Q);
-    F Y3 = R * (Q - X3) - S1 * PPP;
-    return {X3, Y3, a.ZZ * b.ZZ * PP, a.ZZZ * b.ZZZ * PPP};
-}
-
-template <class F>
-ZK_HD XYZZ<F> xyzz_neg(const XYZZ<F> &a) {
-    return {a.X, fp_neg(a.Y), a.ZZ, a.ZZZ};
+    F PPP = O::mul(Pd, PP);
+    F Q = O::mul(U1, PP);
+    F X3 = O::template sub<O::K1>(O::sqr(R), O::add(PPP, O::add(Q, Q)));
+    F Y3 = O::template sub<O::K1>(O::mul(R, O::template sub<O::K2>(Q, X3)), O::mul(S1, PPP));
+    return {X3, Y3, O::mul(O::mul(a.ZZ, b.ZZ), PP), O::mul(O::mul(a.ZZZ, b.ZZZ), PPP)};
 }
 
 // k * a for a small unsigned k (bucket-segment offsets, k < 2^32)
@@ -133,65 +139,76 @@ ZK_HD XYZZ<F> xyzz_mul_small(const XYZZ<F> &a, uint32_t k) {
 // (Z^2 = ZZ^5 = ZZ * ZZ^4, Z^3 = ZZZ^5 = ZZZ * ZZZ^4, using ZZ^3 = ZZZ^2)
 template <class F>
 ZK_HD Jacobian<F> xyzz_to_jacobian(const XYZZ<F> &a) {
+    typedef FieldOps<F> O;
     if (a.is_inf()) return {F::one(), F::one(), F::zero()};
-    F z2 = fp_sqr(a.ZZ);
-    F z3 = fp_sqr(a.ZZZ);
-    return {a.X * fp_sqr(z2), a.Y * fp_sqr(z3), a.ZZ * a.ZZZ};
+    F z2 = O::sqr(a.ZZ);
+    F z3 = O::sqr(a.ZZZ);
+    return {O::mul(a.X, O::sqr(z2)), O::mul(a.Y, O::sqr(z3)), O::mul(a.ZZ, a.ZZZ)};
+}
+
+// Jacobian (X, Y, Z) is XYZZ (X, Y, Z^2, Z^3)
+template <class F>
+ZK_HD XYZZ<F> xyzz_from_jacobian(const Jacobian<F> &j) {
+    typedef FieldOps<F> O;
+    if (O::is_zero(j.Z)) return XYZZ<F>::infinity();
+    F zz = O::sqr(j.Z);
+    return {j.X, j.Y, zz, O::mul(zz, j.Z)};
 }
 
 template <class F>
 ZK_HD Affine<F> xyzz_to_affine(const XYZZ<F> &a) {
+    typedef FieldOps<F> O;
     if (a.is_inf()) return Affine<F>::infinity();
-    F i = fp_inv(a.ZZ * a.ZZZ);
-    return {a.X * (i * a.ZZZ), a.Y * (i * a.ZZ)};
+    F i = O::inv(O::mul(a.ZZ, a.ZZZ));
+    return {O::mul(a.X, O::mul(i, a.ZZZ)), O::mul(a.Y, O::mul(i, a.ZZ))};
 }
 
-// memory layout helpers: Affine = x | y, XYZZ = X | Y | ZZ | ZZZ, each FieldIO<F>::NL u32 limbs
+// device-buffer layout: Affine = x | y, XYZZ = X | Y | ZZ | ZZZ, each FieldOps<F>::WORDS u32 words
 template <class F>
 ZK_HD Affine<F> affine_load(const uint32_t *p) {
-    return {FieldIO<F>::load(p), FieldIO<F>::load(p + FieldIO<F>::NL)};
+    typedef FieldOps<F> O;
+    return {O::load(p), O::load(p + O::WORDS)};
 }
 template <class F>
 ZK_HD void affine_store(uint32_t *p, const Affine<F> &a) {
-    FieldIO<F>::store(p, a.x);
-    FieldIO<F>::store(p + FieldIO<F>::NL, a.y);
+    typedef FieldOps<F> O;
+    O::store(p, a.x);
+    O::store(p + O::WORDS, a.y);
 }
 template <class F>
 ZK_HD XYZZ<F> xyzz_load(const uint32_t *p) {
-    constexpr int NL = FieldIO<F>::NL;
-    return {FieldIO<F>::load(p), FieldIO<F>::load(p + NL), FieldIO<F>::load(p + 2 * NL), FieldIO<F>::load(p + 3 * NL)};
+    typedef FieldOps<F> O;
+    constexpr int W = O::WORDS;
+    return {O::load(p), O::load(p + W), O::load(p + 2 * W), O::load(p + 3 * W)};
 }
 template <class F>
 ZK_HD void xyzz_store(uint32_t *p, const XYZZ<F> &a) {
-    constexpr int NL = FieldIO<F>::NL;
-    FieldIO<F>::store(p, a.X);
-    FieldIO<F>::store(p + NL, a.Y);
-    FieldIO<F>::store(p + 2 * NL, a.ZZ);
-    FieldIO<F>::store(p + 3 * NL, a.ZZZ);
+    typedef FieldOps<F> O;
+    constexpr int W = O::WORDS;
+    O::store(p, a.X);
+    O::store(p + W, a.Y);
+    O::store(p + 2 * W, a.ZZ);
+    O::store(p + 3 * W, a.ZZZ);
 }
 
-// (curve, group) -> coordinate field / scalar field
+// (curve, group) -> coordinate field the kernels compute in
 template <int CURVE, int GROUP>
 struct CurveTraits;
 template <>
 struct CurveTraits<CURVE_BLS12_381, GROUP_G1> {
-    typedef bls_fq F;
-    typedef bls_fr S;
+    typedef bls_fqu F;
 };
 template <>
 struct CurveTraits<CURVE_BLS12_381, GROUP_G2> {
-    typedef bls_fq2 F;
-    typedef bls_fr S;
+    typedef bls_fqu2 F;
 };
 template <>
 struct CurveTraits<CURVE_BN254, GROUP_G1> {
-    typedef bn_fq F;
-    typedef bn_fr S;
+    typedef bn_fqu F;
 };
 template <>
 struct CurveTraits<CURVE_BN254, GROUP_G2> {
-    typedef bn_fq2 F;
-    typedef bn_fr S;
+    typedef bn_fqu2 F;
 };
 
 }  // namespace zkhip

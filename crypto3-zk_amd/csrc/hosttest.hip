@@ -1,6 +1,6 @@
 // TEST SHIM (never loaded by the product path): runs the __host__ __device__ field / curve / recoding
-// code of fp.hpp, curve.hpp and msm_recode.hpp on the CPU so the no-GPU test-suite can compare the exact
-// device arithmetic against the oracle.  Built with --offload-host-only into libzkhip_hosttest.so.
+// code of fp.hpp, fu.hpp, curve.hpp and msm_recode.hpp on the CPU so the no-GPU test-suite can compare the
+// exact device arithmetic against the oracle.  Built with --offload-host-only into libzkhip_hosttest.so.
 #include <cstring>
 #include <vector>
 
@@ -12,66 +12,81 @@ using namespace zkhip;
 
 namespace {
 
-template <class F>
-F load_canon(const uint32_t *p) {
-    return fp_to_mont(FieldIO<F>::load(p));
-}
-template <class F>
-void store_canon(uint32_t *p, const F &a) {
-    FieldIO<F>::store(p, fp_from_mont(a));
-}
-
-// op: 0 mul, 1 add, 2 sub, 3 inv(a), 4 sqr(a), 5 neg(a), 6 dbl(a)
+// op: 0 mul, 1 add, 2 sub<K1>, 3 inv(a), 4 sqr(a), 5 neg(a) = sub<K1>(0, a), 6 dbl(a), 7 sub<K2>,
+//     8 bound stress: mul(sub<K2>(mul(a,b), X), sub<K2>(sqr(b), X)),  X = sub<K1>(sqr(a), ab + 2 b^2)
+//       -- the deepest lazy chain of the group law, with every operand at its contract bound
 template <class F>
 int field_op(int op, const uint32_t *a, const uint32_t *b, uint32_t *out) {
-    F x = load_canon<F>(a), y = b ? load_canon<F>(b) : F::zero(), r;
+    typedef FieldOps<F> O;
+    F x = O::from_canonical(a), y = b ? O::from_canonical(b) : F::zero(), r;
     switch (op) {
-        case 0: r = x * y; break;
-        case 1: r = x + y; break;
-        case 2: r = x - y; break;
-        case 3: r = fp_inv(x); break;
-        case 4: r = fp_sqr(x); break;
-        case 5: r = fp_neg(x); break;
-        case 6: r = fp_dbl(x); break;
+        case 0: r = O::mul(x, y); break;
+        case 1: r = O::add(x, y); break;
+        case 2: r = O::template sub<O::K1>(x, y); break;
+        case 3: r = O::inv(x); break;
+        case 4: r = O::sqr(x); break;
+        case 5: r = O::template sub<O::K1>(F::zero(), x); break;
+        case 6: r = O::add(x, x); break;
+        case 7: r = O::template sub<O::K2>(x, y); break;
+        case 8: {
+            F ab = O::mul(x, y), bb = O::sqr(y);
+            F X = O::template sub<O::K1>(O::sqr(x), O::add(ab, O::add(bb, bb)));
+            r = O::mul(O::template sub<O::K2>(ab, X), O::template sub<O::K2>(bb, X));
+            break;
+        }
         default: return -1;
     }
-    store_canon<F>(out, r);
+    O::to_canonical(out, r);
     return 0;
 }
 
 template <class F>
 Affine<F> load_aff(const uint32_t *p, int inf) {
+    typedef FieldOps<F> O;
     if (inf) return Affine<F>::infinity();
-    constexpr int NL = FieldIO<F>::NL;
-    return {load_canon<F>(p), load_canon<F>(p + NL)};
+    return {O::from_canonical(p), O::from_canonical(p + O::CANON_WORDS)};
 }
 template <class F>
 void store_aff(uint32_t *p, uint8_t *inf, const XYZZ<F> &a) {
-    constexpr int NL = FieldIO<F>::NL;
+    typedef FieldOps<F> O;
     Affine<F> r = xyzz_to_affine(a);
     *inf = a.is_inf() ? 1 : 0;
-    store_canon<F>(p, r.x);
-    store_canon<F>(p + NL, r.y);
+    O::to_canonical(p, r.x);
+    O::to_canonical(p + O::CANON_WORDS, r.y);
 }
 
-// sum_i (+/-) pts[i] accumulated with xyzz_madd in order, then optionally doubled `dbls` times,
-// multiplied by `k` (xyzz_mul_small) and added to itself via xyzz_add; result affine canonical.
-// mode: 0 = madd chain; 1 = chain then xyzz_add(acc, acc2) where acc2 = chain over the second half;
-//       2 = chain then xyzz_mul_small(acc, k); 3 = chain, via xyzz_to_jacobian -> canonical Jacobian out (3 coords)
+// sum_i (+/-) pts[i] accumulated with xyzz_madd in order; result affine canonical.
+// mode: 0 = madd chain; 1 = xyzz_add of the chains over the two halves; 2 = chain then xyzz_mul_small(acc, k);
+//       3 = chain, xyzz_to_jacobian -> canonical Jacobian out (3 coords); 4 = like 0 but every partial sum goes
+//       through the device-buffer store/load round trip (xyzz_store / xyzz_load, affine_store / affine_load)
 template <class F>
 int point_chain(const uint32_t *pts, const uint8_t *inf, const uint8_t *neg, size_t n, int mode, uint32_t k, uint32_t *out, uint8_t *out_inf) {
-    constexpr int NL = FieldIO<F>::NL;
+    typedef FieldOps<F> O;
+    constexpr int CW = O::CANON_WORDS;
     size_t split = mode == 1 ? n / 2 : n;
     XYZZ<F> acc = XYZZ<F>::infinity(), acc2 = XYZZ<F>::infinity();
-    for (size_t i = 0; i < split; ++i) acc = xyzz_madd(acc, load_aff<F>(pts + i * 2 * NL, inf ? inf[i] : 0), neg ? neg[i] != 0 : false);
-    for (size_t i = split; i < n; ++i) acc2 = xyzz_madd(acc2, load_aff<F>(pts + i * 2 * NL, inf ? inf[i] : 0), neg ? neg[i] != 0 : false);
+    std::vector<uint32_t> buf(4 * O::WORDS + 2 * O::WORDS + 8);
+    uint32_t *b16 = (uint32_t *)(((uintptr_t)buf.data() + 15) & ~(uintptr_t)15);
+    for (size_t i = 0; i < split; ++i) {
+        Affine<F> p = load_aff<F>(pts + i * 2 * CW, inf ? inf[i] : 0);
+        if (mode == 4) {
+            affine_store<F>(b16, p);
+            p = affine_load<F>(b16);
+        }
+        acc = xyzz_madd(acc, p, neg ? neg[i] != 0 : false);
+        if (mode == 4) {
+            xyzz_store<F>(b16, acc);
+            acc = xyzz_load<F>(b16);
+        }
+    }
+    for (size_t i = split; i < n; ++i) acc2 = xyzz_madd(acc2, load_aff<F>(pts + i * 2 * CW, inf ? inf[i] : 0), neg ? neg[i] != 0 : false);
     if (mode == 1) acc = xyzz_add(acc, acc2);
     if (mode == 2) acc = xyzz_mul_small(acc, k);
     if (mode == 3) {
         Jacobian<F> j = xyzz_to_jacobian(acc);
-        store_canon<F>(out, j.X);
-        store_canon<F>(out + NL, j.Y);
-        store_canon<F>(out + 2 * NL, j.Z);
+        O::to_canonical(out, j.X);
+        O::to_canonical(out + CW, j.Y);
+        O::to_canonical(out + 2 * CW, j.Z);
         *out_inf = acc.is_inf() ? 1 : 0;
         return 0;
     }
@@ -81,29 +96,37 @@ int point_chain(const uint32_t *pts, const uint8_t *inf, const uint8_t *neg, siz
 
 }  // namespace
 
-#define FIELD_SWITCH(field, ...)                      \
-    switch (field) {                                  \
-        case 0: { typedef bls_fq F; __VA_ARGS__; } break;  \
-        case 1: { typedef bls_fr F; __VA_ARGS__; } break;  \
-        case 2: { typedef bn_fq F; __VA_ARGS__; } break;   \
-        case 3: { typedef bn_fr F; __VA_ARGS__; } break;   \
-        case 4: { typedef bls_fq2 F; __VA_ARGS__; } break; \
-        case 5: { typedef bn_fq2 F; __VA_ARGS__; } break;  \
-        default: return -1;                           \
+#define FIELD_SWITCH(field, ...)                             \
+    switch (field) {                                         \
+        case 0: { typedef bls_fq F; __VA_ARGS__; } break;    \
+        case 1: { typedef bls_fr F; __VA_ARGS__; } break;    \
+        case 2: { typedef bn_fq F; __VA_ARGS__; } break;     \
+        case 3: { typedef bn_fr F; __VA_ARGS__; } break;     \
+        case 4: { typedef bls_fq2 F; __VA_ARGS__; } break;   \
+        case 5: { typedef bn_fq2 F; __VA_ARGS__; } break;    \
+        case 6: { typedef bls_fqu F; __VA_ARGS__; } break;   \
+        case 7: { typedef bn_fqu F; __VA_ARGS__; } break;    \
+        case 8: { typedef bls_fru F; __VA_ARGS__; } break;   \
+        case 9: { typedef bn_fru F; __VA_ARGS__; } break;    \
+        case 10: { typedef bls_fqu2 F; __VA_ARGS__; } break; \
+        case 11: { typedef bn_fqu2 F; __VA_ARGS__; } break;  \
+        default: return -1;                                  \
     }
 
 extern "C" {
 
-// field: 0 BLS Fq, 1 BLS Fr, 2 BN Fq, 3 BN Fr, 4 BLS Fq2, 5 BN Fq2; canonical u32 limbs in and out
+// field: 0 BLS Fq, 1 BLS Fr, 2 BN Fq, 3 BN Fr, 4 BLS Fq2, 5 BN Fq2 (saturated reference types);
+//        6 BLS Fq, 7 BN Fq, 8 BLS Fr, 9 BN Fr, 10 BLS Fq2, 11 BN Fq2 (lazy 29-bit-limb compute types).
+// canonical u32 limbs in and out
 int zkt_field_op(int field, int op, const uint32_t *a, const uint32_t *b, uint32_t *out) {
     FIELD_SWITCH(field, return field_op<F>(op, a, b, out));
     return -1;
 }
 
-// curve 0/1, group 1/2
-int zkt_point_chain(int curve, int group, const uint32_t *pts, const uint8_t *inf, const uint8_t *neg, size_t n, int mode, uint32_t k,
+// coordinate field id as above (0/2/4/5 saturated, 6/7/10/11 lazy)
+int zkt_point_chain(int field, const uint32_t *pts, const uint8_t *inf, const uint8_t *neg, size_t n, int mode, uint32_t k,
                     uint32_t *out, uint8_t *out_inf) {
-    int field = curve == 0 ? (group == 1 ? 0 : 4) : (group == 1 ? 2 : 5);
+    if (field == 1 || field == 3 || field == 8 || field == 9) return -1;
     FIELD_SWITCH(field, return point_chain<F>(pts, inf, neg, n, mode, k, out, out_inf));
     return -1;
 }

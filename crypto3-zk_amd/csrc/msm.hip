@@ -27,7 +27,7 @@
 // (compared in affine) does not.
 #include <algorithm>
 
-#define ZK_NOINLINE_MUL 1
+#define ZK_NOINLINE_MUL2 1  // G2 (Fq2) products stay out of line; G1 products are inlined
 #include "ctx.hpp"
 #include "curve.hpp"
 
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void msm_scatter(const uint32_t *__restrict__ 
 template <class F>
 __global__ __launch_bounds__(256) void msm_bucket_acc(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ offs,
                                                       const uint32_t *__restrict__ idx, uint32_t nbuckets, uint32_t *__restrict__ buckets) {
-    constexpr int NL = FieldIO<F>::NL;
+    constexpr int NL = FieldOps<F>::WORDS;
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nbuckets) return;
     uint32_t lo = offs[g], hi = offs[g + 1];
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void msm_bucket_acc(const uint32_t *__restrict
 template <class F>
 __global__ __launch_bounds__(64) void msm_bucket_red(const uint32_t *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t nseg,
                                                      uint32_t total, uint32_t *__restrict__ segsum) {
-    constexpr int NL = FieldIO<F>::NL;
+    constexpr int NL = FieldOps<F>::WORDS;
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;  // = w * nseg + seg
     if (g >= total) return;
     uint32_t w = g / nseg, seg = g % nseg;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64) void msm_bucket_red(const uint32_t *__restrict_
 // one workgroup per window: winsum[w] = sum_seg segsum[w][seg]
 template <class F>
 __global__ __launch_bounds__(128) void msm_window_sum(const uint32_t *__restrict__ segsum, uint32_t nseg, uint32_t *__restrict__ winsum) {
-    constexpr int NL = FieldIO<F>::NL;
+    constexpr int NL = FieldOps<F>::WORDS;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t w = blockIdx.x, t = threadIdx.x;
     XYZZ<F> acc = XYZZ<F>::infinity();
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(128) void msm_window_sum(const uint32_t *__restrict
 // result = sum_w 2^(c w) winsum[w]  (Horner from the top window), emitted as canonical Jacobian
 template <class F>
 __global__ void msm_final(const uint32_t *__restrict__ winsum, int W, int c, uint32_t *__restrict__ out_jac) {
-    constexpr int NL = FieldIO<F>::NL;
+    constexpr int NL = FieldOps<F>::WORDS;
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     XYZZ<F> acc = XYZZ<F>::infinity();
     for (int w = W - 1; w >= 0; --w) {
@@ -155,51 +155,48 @@ __global__ void msm_final(const uint32_t *__restrict__ winsum, int W, int c, uin
         acc = xyzz_add(acc, xyzz_load<F>(winsum + (size_t)w * (4 * NL)));
     }
     Jacobian<F> j = xyzz_to_jacobian(acc);
-    FieldIO<F>::store(out_jac, fp_from_mont(j.X));
-    FieldIO<F>::store(out_jac + NL, fp_from_mont(j.Y));
-    FieldIO<F>::store(out_jac + 2 * NL, fp_from_mont(j.Z));
+    constexpr int CW = FieldOps<F>::CANON_WORDS;
+    FieldOps<F>::to_canonical(out_jac, j.X);
+    FieldOps<F>::to_canonical(out_jac + CW, j.Y);
+    FieldOps<F>::to_canonical(out_jac + 2 * CW, j.Z);
 }
 
 // ---- bases maintenance ----------------------------------------------------------------------------
+// canonical affine (x | y, CANON_WORDS each) -> device form (Montgomery, WORDS each); flagged points -> (0, 0)
 template <class F>
-__global__ __launch_bounds__(256) void bases_to_mont(uint32_t *__restrict__ pts, const uint8_t *__restrict__ inf, uint32_t n) {
-    constexpr int NL = FieldIO<F>::NL;
+__global__ __launch_bounds__(256) void bases_to_mont(const uint32_t *__restrict__ canon, const uint8_t *__restrict__ inf, uint32_t n,
+                                                     uint32_t *__restrict__ pts) {
+    typedef FieldOps<F> O;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t *p = pts + (size_t)i * (2 * NL);
+    const uint32_t *c = canon + (size_t)i * (2 * O::CANON_WORDS);
     Affine<F> a;
     if (inf != nullptr && inf[i]) a = Affine<F>::infinity();
-    else {
-        a = affine_load<F>(p);
-        a.x = fp_to_mont(a.x);
-        a.y = fp_to_mont(a.y);
-    }
-    affine_store<F>(p, a);
+    else a = {O::from_canonical(c), O::from_canonical(c + O::CANON_WORDS)};
+    affine_store<F>(pts + (size_t)i * (2 * O::WORDS), a);
 }
 
 template <class F>
 __global__ __launch_bounds__(256) void bases_from_mont(const uint32_t *__restrict__ pts, uint32_t n, uint32_t *__restrict__ out,
                                                        uint8_t *__restrict__ inf) {
-    constexpr int NL = FieldIO<F>::NL;
+    typedef FieldOps<F> O;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Affine<F> a = affine_load<F>(pts + (size_t)i * (2 * NL));
+    Affine<F> a = affine_load<F>(pts + (size_t)i * (2 * O::WORDS));
     inf[i] = a.is_inf() ? 1 : 0;
-    a.x = fp_from_mont(a.x);
-    a.y = fp_from_mont(a.y);
-    affine_store<F>(out + (size_t)i * (2 * NL), a);
+    uint32_t *o = out + (size_t)i * (2 * O::CANON_WORDS);
+    O::to_canonical(o, a.x);
+    O::to_canonical(o + O::CANON_WORDS, a.y);
 }
 
 // pts[i] = scalars[i] * base, double-and-add from the top bit, then one inversion per point
 template <class F>
 __global__ __launch_bounds__(64) void bases_mul(uint32_t *__restrict__ pts, const uint32_t *__restrict__ base_canonical,
                                                 const uint32_t *__restrict__ scalars, uint32_t n) {
-    constexpr int NL = FieldIO<F>::NL;
+    constexpr int NL = FieldOps<F>::WORDS;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Affine<F> g = affine_load<F>(base_canonical);
-    g.x = fp_to_mont(g.x);
-    g.y = fp_to_mont(g.y);
+    Affine<F> g = {FieldOps<F>::from_canonical(base_canonical), FieldOps<F>::from_canonical(base_canonical + FieldOps<F>::CANON_WORDS)};
     const uint32_t *s = scalars + (size_t)i * 8;
     XYZZ<F> acc = XYZZ<F>::infinity();
     for (int b = 255; b >= 0; --b) {
@@ -211,39 +208,33 @@ __global__ __launch_bounds__(64) void bases_mul(uint32_t *__restrict__ pts, cons
 
 template <class F>
 __global__ void jac_to_affine_k(const uint32_t *__restrict__ jac, uint32_t *__restrict__ aff, uint8_t *__restrict__ inf) {
-    constexpr int NL = FieldIO<F>::NL;
+    typedef FieldOps<F> O;
+    constexpr int CW = O::CANON_WORDS;
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    F X = fp_to_mont(FieldIO<F>::load(jac)), Y = fp_to_mont(FieldIO<F>::load(jac + NL)), Z = fp_to_mont(FieldIO<F>::load(jac + 2 * NL));
-    if (Z.is_zero()) {
-        inf[0] = 1;
-        affine_store<F>(aff, Affine<F>::infinity());
-        return;
-    }
-    F zi = fp_inv(Z);
-    F zi2 = fp_sqr(zi);
-    inf[0] = 0;
-    Affine<F> a = {fp_from_mont(X * zi2), fp_from_mont(Y * zi2 * zi)};
-    affine_store<F>(aff, a);
+    Jacobian<F> j = {O::from_canonical(jac), O::from_canonical(jac + CW), O::from_canonical(jac + 2 * CW)};
+    XYZZ<F> q = xyzz_from_jacobian(j);
+    inf[0] = q.is_inf() ? 1 : 0;
+    Affine<F> a = xyzz_to_affine(q);
+    O::to_canonical(aff, a.x);
+    O::to_canonical(aff + CW, a.y);
 }
 
 // out = sum_i jac[i] (canonical Jacobian in and out); one lane, `count` is the number of GPUs
 template <class F>
 __global__ void jac_sum_k(const uint32_t *__restrict__ jac, uint32_t count, uint32_t *__restrict__ out) {
-    constexpr int NL = FieldIO<F>::NL;
+    typedef FieldOps<F> O;
+    constexpr int CW = O::CANON_WORDS;
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     XYZZ<F> acc = XYZZ<F>::infinity();
     for (uint32_t i = 0; i < count; ++i) {
-        const uint32_t *p = jac + (size_t)i * 3 * NL;
-        F X = fp_to_mont(FieldIO<F>::load(p)), Y = fp_to_mont(FieldIO<F>::load(p + NL)), Z = fp_to_mont(FieldIO<F>::load(p + 2 * NL));
-        if (Z.is_zero()) continue;
-        F zz = fp_sqr(Z);
-        XYZZ<F> q = {X, Y, zz, zz * Z};  // Jacobian (X, Y, Z) is XYZZ (X, Y, Z^2, Z^3)
-        acc = xyzz_add(acc, q);
+        const uint32_t *p = jac + (size_t)i * 3 * CW;
+        Jacobian<F> j = {O::from_canonical(p), O::from_canonical(p + CW), O::from_canonical(p + 2 * CW)};
+        acc = xyzz_add(acc, xyzz_from_jacobian(j));
     }
-    Jacobian<F> j = xyzz_to_jacobian(acc);
-    FieldIO<F>::store(out, fp_from_mont(j.X));
-    FieldIO<F>::store(out + NL, fp_from_mont(j.Y));
-    FieldIO<F>::store(out + 2 * NL, fp_from_mont(j.Z));
+    Jacobian<F> r = xyzz_to_jacobian(acc);
+    O::to_canonical(out, r.X);
+    O::to_canonical(out + CW, r.Y);
+    O::to_canonical(out + 2 * CW, r.Z);
 }
 
 // ---- host side ------------------------------------------------------------------------------------
@@ -270,11 +261,22 @@ size_t zk_coord_limbs64(int curve, int group) {
             return ZKHIP_ERR_INVALID;                                   \
     } while (0)
 
-int zk_bases_to_mont(zkhip_ctx *ctx, zkhip_bases *b, const uint8_t *d_inf) {
+int zk_bases_to_mont(zkhip_ctx *ctx, zkhip_bases *b, const uint32_t *d_canonical, const uint8_t *d_inf) {
     if (b->n == 0) return 0;
     dim3 grid((unsigned)((b->n + 255) / 256)), block(256);
-    ZK_DISPATCH_CG(b->curve, b->group, ZK_LAUNCH(ctx, "bases_to_mont", bases_to_mont<F>, grid, block, 0, b->d, d_inf, (uint32_t)b->n));
+    ZK_DISPATCH_CG(b->curve, b->group, ZK_LAUNCH(ctx, "bases_to_mont", bases_to_mont<F>, grid, block, 0, d_canonical, d_inf, (uint32_t)b->n, b->d));
     return 0;
+}
+
+// u32 words per affine point in device buffers
+size_t zk_point_words(int curve, int group) {
+    size_t w = 0;
+    auto f = [&]() -> int {
+        ZK_DISPATCH_CG(curve, group, w = 2 * FieldOps<F>::WORDS);
+        return 0;
+    };
+    (void)f();
+    return w;
 }
 
 int zk_bases_from_mont(zkhip_ctx *ctx, const zkhip_bases *b, size_t offset, size_t n, uint32_t *d_out, uint8_t *d_inf) {
@@ -310,7 +312,7 @@ static int ilog2(size_t v) {
 
 template <class F>
 static int msm_run_t(zkhip_ctx *ctx, const uint32_t *d_bases, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac) {
-    constexpr int NL = FieldIO<F>::NL;
+    constexpr int NL = FieldOps<F>::WORDS;
     // window size: 2^(c-1) buckets per window, about n / 2^(c-1) * ... points per bucket
     int c = ctx->opt_msm_window_bits;
     if (c <= 0) c = std::max(2, std::min(16, ilog2(n) - 4));
@@ -359,12 +361,11 @@ static int msm_run_t(zkhip_ctx *ctx, const uint32_t *d_bases, size_t n, const ui
 
 template <class F>
 __global__ void msm_write_infinity(uint32_t *out_jac) {
-    constexpr int NL = FieldIO<F>::NL;
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    F one = fp_from_mont(F::one());
-    FieldIO<F>::store(out_jac, one);
-    FieldIO<F>::store(out_jac + NL, one);
-    FieldIO<F>::store(out_jac + 2 * NL, F::zero());
+    constexpr int CW = FieldOps<F>::CANON_WORDS;
+    FieldOps<F>::to_canonical(out_jac, F::one());
+    FieldOps<F>::to_canonical(out_jac + CW, F::one());
+    FieldOps<F>::to_canonical(out_jac + 2 * CW, F::zero());
 }
 
 int zk_msm_run(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac) {

@@ -124,7 +124,7 @@ static int bases_alloc(zkhip_ctx *ctx, int curve, int group, size_t n, zkhip_bas
     b->curve = curve;
     b->group = group;
     b->n = n;
-    b->stride_u32 = 2 * 2 * zk_coord_limbs64(curve, group);
+    b->stride_u32 = zk_point_words(curve, group);
     b->d = nullptr;
     hipError_t e = hipMalloc((void **)&b->d, std::max<size_t>(1, n) * b->stride_u32 * 4);
     if (e != hipSuccess) {
@@ -143,10 +143,16 @@ int zkhip_bases_upload(zkhip_ctx *ctx, int curve, int group, const uint64_t *aff
     zkhip_bases *b = nullptr;
     ZK_TRY(bases_alloc(ctx, curve, group, n, &b));
     uint8_t *d_inf = nullptr;
+    uint32_t *d_canon = nullptr;
+    const size_t cbytes = n * 2 * zk_coord_limbs64(curve, group) * 8;
     int rc = 0;
     do {
         if (n == 0) break;
-        if (hipMemcpyAsync(b->d, affine_xy, n * b->stride_u32 * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        if (hipMalloc((void **)&d_canon, cbytes) != hipSuccess) {
+            rc = ZKHIP_ERR_OOM;
+            break;
+        }
+        if (hipMemcpyAsync(d_canon, affine_xy, cbytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
             rc = ZKHIP_ERR_HIP;
             break;
         }
@@ -160,11 +166,12 @@ int zkhip_bases_upload(zkhip_ctx *ctx, int curve, int group, const uint64_t *aff
                 break;
             }
         }
-        rc = zk_bases_to_mont(ctx, b, d_inf);
+        rc = zk_bases_to_mont(ctx, b, d_canon, d_inf);
         if (rc) break;
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
     } while (0);
     if (d_inf) (void)hipFree(d_inf);
+    if (d_canon) (void)hipFree(d_canon);
     if (rc) {
         (void)hipFree(b->d);
         delete b;
@@ -201,12 +208,12 @@ int zkhip_bases_from_scalars(zkhip_ctx *ctx, int curve, int group, const uint64_
     int rc = 0;
     do {
         if (n == 0) break;
-        if (hipMalloc((void **)&d_s, n * 32) != hipSuccess || hipMalloc((void **)&d_g, b->stride_u32 * 4) != hipSuccess) {
+        if (hipMalloc((void **)&d_s, n * 32) != hipSuccess || hipMalloc((void **)&d_g, 2 * zk_coord_limbs64(curve, group) * 8) != hipSuccess) {
             rc = ZKHIP_ERR_OOM;
             break;
         }
         if (hipMemcpyAsync(d_s, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(d_g, gen, b->stride_u32 * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            hipMemcpyAsync(d_g, gen, 2 * zk_coord_limbs64(curve, group) * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
             rc = ZKHIP_ERR_HIP;
             break;
         }
@@ -230,7 +237,7 @@ int zkhip_bases_download(zkhip_ctx *ctx, const zkhip_bases *b, size_t offset, si
     if (offset + n > b->n) return ZKHIP_ERR_RANGE;
     if (n == 0) return ZKHIP_OK;
     ZK_TRY(check_device(ctx));
-    size_t pbytes = n * b->stride_u32 * 4;
+    size_t pbytes = n * 2 * zk_coord_limbs64(b->curve, b->group) * 8;
     ZK_TRY(ctx->ws_reserve(zkhip_ctx::ws_round(pbytes) + zkhip_ctx::ws_round(n)));
     ctx->ws_reset();
     uint32_t *d_out = ctx->ws_take<uint32_t>(pbytes / 4);

@@ -30,22 +30,26 @@ def _int(a):
     return sum(int(x) << (32 * i) for i, x in enumerate(a))
 
 
-FIELDS = {0: (po.BLS12_381.p, 12), 1: (po.BLS12_381.r, 8), 2: (po.BN254.p, 8), 3: (po.BN254.r, 8)}
+# saturated reference types 0-3, lazy 29-bit-limb compute types 6-9 (same boundary form: canonical u32 limbs)
+FIELDS = {0: (po.BLS12_381.p, 12), 1: (po.BLS12_381.r, 8), 2: (po.BN254.p, 8), 3: (po.BN254.r, 8),
+          6: (po.BLS12_381.p, 12), 7: (po.BN254.p, 8), 8: (po.BLS12_381.r, 8), 9: (po.BN254.r, 8)}
 
 
-@pytest.mark.parametrize("field", [0, 1, 2, 3])
+@pytest.mark.parametrize("field", [0, 1, 2, 3, 6, 7, 8, 9])
 def test_prime_field_ops(shim, field):
     p, nl = FIELDS[field]
     random.seed(field)
     edge = [0, 1, 2, p - 1, p - 2, (1 << (32 * nl - 1)) % p, (p + 1) // 2]
-    vals = edge + [random.randrange(p) for _ in range(40)]
+    vals = edge + [random.randrange(p) for _ in range(60)]
     out = np.zeros(nl, dtype=np.uint32)
     P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     for i, a in enumerate(vals):
         b = vals[(i * 7 + 3) % len(vals)]
         A, B = _u32(a, nl), _u32(b, nl)
+        X = (a * a - a * b - 2 * b * b) % p
         for op, fn in ((0, lambda: a * b % p), (1, lambda: (a + b) % p), (2, lambda: (a - b) % p), (4, lambda: a * a % p),
-                       (5, lambda: (-a) % p), (6, lambda: 2 * a % p)):
+                       (5, lambda: (-a) % p), (6, lambda: 2 * a % p), (7, lambda: (a - b) % p),
+                       (8, lambda: (a * b - X) * (b * b - X) % p)):
             assert shim.zkt_field_op(field, op, P(A), P(B), P(out)) == 0
             assert _int(out) == fn(), (field, op, hex(a), hex(b))
         if a and i < 12:
@@ -53,7 +57,7 @@ def test_prime_field_ops(shim, field):
             assert _int(out) == pow(a, -1, p)
 
 
-@pytest.mark.parametrize("field,curve", [(4, 0), (5, 1)])
+@pytest.mark.parametrize("field,curve", [(4, 0), (5, 1), (10, 0), (11, 1)])
 def test_fq2_ops(shim, field, curve):
     C = CURVES[curve]
     p, F = C.p, po.Fq2(C.p)
@@ -66,8 +70,10 @@ def test_fq2_ops(shim, field, curve):
     vals = [(0, 0), (1, 0), (0, 1), (p - 1, p - 1)] + [(random.randrange(p), random.randrange(p)) for _ in range(12)]
     for i, a in enumerate(vals):
         b = vals[(i * 5 + 2) % len(vals)]
+        X = F.sub(F.sqr(a), F.add(F.mul(a, b), F.add(F.sqr(b), F.sqr(b))))
         for op, fn in ((0, lambda: F.mul(a, b)), (1, lambda: F.add(a, b)), (2, lambda: F.sub(a, b)), (4, lambda: F.sqr(a)),
-                       (5, lambda: F.neg(a)), (6, lambda: F.add(a, a))):
+                       (5, lambda: F.neg(a)), (6, lambda: F.add(a, a)), (7, lambda: F.sub(a, b)),
+                       (8, lambda: F.mul(F.sub(F.mul(a, b), X), F.sub(F.sqr(b), X)))):
             assert shim.zkt_field_op(field, op, P(pack(a)), P(pack(b)), P(out)) == 0
             assert unpack(out) == fn(), (op, a, b)
         if not F.is_zero(a) and i < 8:
@@ -75,7 +81,7 @@ def test_fq2_ops(shim, field, curve):
             assert unpack(out) == F.inv(a)
 
 
-def _chain(shim, curve, group, pts, infs, negs, mode, k=0):
+def _chain(shim, field, curve, group, pts, infs, negs, mode, k=0):
     arr = pts_arr(curve, group, pts).view(np.uint32).reshape(len(pts), -1) if len(pts) else np.zeros((0, 1), dtype=np.uint32)
     arr = np.ascontiguousarray(arr)
     ncoord = 3 if mode == 3 else 2
@@ -84,12 +90,17 @@ def _chain(shim, curve, group, pts, infs, negs, mode, k=0):
     infa = np.array(infs, dtype=np.uint8)
     nega = np.array(negs, dtype=np.uint8)
     P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    assert shim.zkt_point_chain(curve, group, P(arr), P(infa), P(nega), ctypes.c_size_t(len(pts)), mode, ctypes.c_uint32(k), P(out), P(oinf)) == 0
+    assert shim.zkt_point_chain(field, P(arr), P(infa), P(nega), ctypes.c_size_t(len(pts)), mode, ctypes.c_uint32(k), P(out), P(oinf)) == 0
     return out.view(np.uint64), int(oinf[0])
 
 
+COORD_FIELDS = {(0, 1): (0, 6), (0, 2): (4, 10), (1, 1): (2, 7), (1, 2): (5, 11)}  # (saturated, lazy) ids
+
+
+@pytest.mark.parametrize("lazy", [0, 1])
 @pytest.mark.parametrize("curve,group", [(0, 1), (0, 2), (1, 1), (1, 2)])
-def test_xyzz_group_law(shim, curve, group):
+def test_xyzz_group_law(shim, curve, group, lazy):
+    field = COORD_FIELDS[(curve, group)][lazy]
     """madd chains incl. the special cases the bucket method meets: P+P, P+(-P), infinity operands."""
     C = CURVES[curve]
     G = C.g1 if group == 1 else C.g2
@@ -112,15 +123,17 @@ def test_xyzz_group_law(shim, curve, group):
         for Pt, i, n in zip(pts, infs, negs):
             if not i:
                 exp = G.add(exp, sgn(Pt, n))
-        out, oinf = _chain(shim, curve, group, pts, infs, negs, 0)
+        out, oinf = _chain(shim, field, curve, group, pts, infs, negs, 0)
+        assert pt_from_limbs(curve, group, out, oinf) == exp
+        out, oinf = _chain(shim, field, curve, group, pts, infs, negs, 4)  # through the device-buffer layout
         assert pt_from_limbs(curve, group, out, oinf) == exp
         if len(pts) >= 2:
-            out, oinf = _chain(shim, curve, group, pts, infs, negs, 1)  # xyzz_add of the two halves
+            out, oinf = _chain(shim, field, curve, group, pts, infs, negs, 1)  # xyzz_add of the two halves
             assert pt_from_limbs(curve, group, out, oinf) == exp
             for k in (0, 1, 2, 37, 32768, 65535):
-                out, oinf = _chain(shim, curve, group, pts, infs, negs, 2, k)
+                out, oinf = _chain(shim, field, curve, group, pts, infs, negs, 2, k)
                 assert pt_from_limbs(curve, group, out, oinf) == G.mul(exp, k)
-        out, oinf = _chain(shim, curve, group, pts, infs, negs, 3)  # XYZZ -> Jacobian
+        out, oinf = _chain(shim, field, curve, group, pts, infs, negs, 3)  # XYZZ -> Jacobian
         L = FQ_LIMBS[curve] * group
         if exp is None:
             assert oinf == 1 and po.from_limbs(out[2 * L:3 * L]) == 0
@@ -129,10 +142,10 @@ def test_xyzz_group_law(shim, curve, group):
             assert jac_to_affine_py(curve, group, out.reshape(3, L)) == exp
     # xyzz_add doubling branch: same chain in both halves
     pts = [P0, P1, P0, P1]
-    out, oinf = _chain(shim, curve, group, pts, [0] * 4, [0] * 4, 1)
+    out, oinf = _chain(shim, field, curve, group, pts, [0] * 4, [0] * 4, 1)
     assert pt_from_limbs(curve, group, out, oinf) == G.mul(G.add(P0, P1), 2)
     # and the cancelling branch
-    out, oinf = _chain(shim, curve, group, pts, [0] * 4, [0, 0, 1, 1], 1)
+    out, oinf = _chain(shim, field, curve, group, pts, [0] * 4, [0, 0, 1, 1], 1)
     assert oinf == 1
 
 
