@@ -30,7 +30,9 @@ struct zkhip_bases {
     int curve, group;
     size_t n;
     size_t stride_u32;  // u32 words per affine point (2 * coordinate limbs)
-    uint32_t *d;        // Montgomery-form affine points, (0,0) = infinity
+    uint32_t *d;        // ntab tables of n Montgomery-form affine points each, (0,0) = infinity;
+                        // table w holds 2^(c_tab w) P_i ("window tables": no Horner pass over the windows)
+    int c_tab = 0, ntab = 1;
 };
 
 struct ZkEventPair {
@@ -62,6 +64,8 @@ struct zkhip_ctx {
     int opt_msm_segment_log = 5;
     int opt_ntt_radix_log = 8;
     int opt_ntt_tile_log = 3;
+    int opt_msm_precompute = 1;       // build window tables at upload for bases of >= opt_msm_precompute_min points
+    int opt_msm_precompute_min = 1024;
     ZkProfile prof;
     std::vector<NttTables *> ntt_tables;
 
@@ -142,7 +146,9 @@ struct zkhip_ctx {
 int zk_msm_run(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac);
 size_t zk_coord_limbs64(int curve, int group);  // u64 limbs per coordinate (Fq: 6/4, Fq2: 12/8)
 int zk_bases_to_mont(zkhip_ctx *ctx, zkhip_bases *b, const uint32_t *d_canonical, const uint8_t *d_inf);
-size_t zk_point_words(int curve, int group);  // u32 words per affine point in device buffers
+size_t zk_point_words(int curve, int group);
+int zk_msm_auto_window(size_t n);
+int zk_bases_precompute(zkhip_ctx *ctx, zkhip_bases *b);  // u32 words per affine point in device buffers
 int zk_bases_from_mont(zkhip_ctx *ctx, const zkhip_bases *b, size_t offset, size_t n, uint32_t *d_out, uint8_t *d_inf);
 int zk_bases_mul(zkhip_ctx *ctx, zkhip_bases *b, const uint32_t *d_base_canonical /* nullable: generator */, const uint32_t *d_scalars);
 int zk_jac_sum(zkhip_ctx *ctx, int curve, int group, const uint32_t *d_pts, size_t count, uint32_t *d_out);

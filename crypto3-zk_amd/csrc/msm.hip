@@ -17,9 +17,10 @@
 //
 // Kernels (all integer VALU; no MFMA -- this is modular arithmetic, not a dense contraction):
 //   msm_digits      scalar -> signed digits + bucket histogram      (streams 32 B/scalar, coalesced)
-//   msm_scan        exclusive prefix over W*B counters
+//   msm_scan        exclusive prefix over W*B counters (local scan, top scan, add-back)
 //   msm_scatter     counting-sort scatter of point indices by (window, bucket)
 //   msm_bucket_acc  one lane per bucket: gather affine points, XYZZ mixed additions     <- dominant
+//   msm_bucket_merge  with window tables: fold the W equal-weight windows bucket by bucket (log2 W launches)
 //   msm_bucket_red  running-sum reduction of L-bucket segments, weighted by segment offset
 //   msm_window_sum  LDS tree reduction of segment sums, one workgroup per window
 //   msm_final       Horner over the windows, XYZZ -> Jacobian, Montgomery -> canonical
@@ -49,30 +50,71 @@ __global__ __launch_bounds__(256) void msm_digits(const uint32_t *__restrict__ s
     }
 }
 
-// exclusive scan of `count` u32 counters by one 1024-thread workgroup; offs[count] = total; cursor = copy
-__global__ __launch_bounds__(1024) void msm_scan(const uint32_t *__restrict__ hist, uint32_t count, uint32_t *__restrict__ offs,
-                                                 uint32_t *__restrict__ cursor) {
+// exclusive scan of `count` u32 counters in three launches: per-block (1024 counters) local scan + block
+// totals, scan of the totals by one workgroup, add-back.  offs[count] = total; cursor = copy of offs.
+__global__ __launch_bounds__(256) void msm_scan_local(const uint32_t *__restrict__ hist, uint32_t count, uint32_t *__restrict__ offs,
+                                                      uint32_t *__restrict__ block_sums) {
+    __shared__ uint32_t part[256];
+    const uint32_t t = threadIdx.x, base = blockIdx.x * 1024 + t * 4;
+    uint32_t v[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[k] = base + k < count ? hist[base + k] : 0;
+        s += v[k];
+    }
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        uint32_t x = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < count) offs[base + k] = run;
+        run += v[k];
+    }
+    if (t == 255) block_sums[blockIdx.x] = part[255];
+}
+
+__global__ __launch_bounds__(1024) void msm_scan_top(uint32_t *__restrict__ block_sums, uint32_t nblocks, uint32_t *__restrict__ total) {
     __shared__ uint32_t part[1024];
-    uint32_t t = threadIdx.x;
-    uint32_t per = (count + 1023) / 1024;
-    uint32_t lo = min(count, t * per), hi = min(count, lo + per);
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (nblocks + 1023) / 1024;
+    const uint32_t lo = min(nblocks, t * per), hi = min(nblocks, lo + per);
     uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; ++i) s += hist[i];
+    for (uint32_t i = lo; i < hi; ++i) s += block_sums[i];
     part[t] = s;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t v = t >= d ? part[t - d] : 0;
+        uint32_t x = t >= d ? part[t - d] : 0;
         __syncthreads();
-        part[t] += v;
+        part[t] += x;
         __syncthreads();
     }
     uint32_t run = part[t] - s;
     for (uint32_t i = lo; i < hi; ++i) {
-        offs[i] = run;
-        cursor[i] = run;
-        run += hist[i];
+        uint32_t x = block_sums[i];
+        block_sums[i] = run;
+        run += x;
     }
-    if (t == 1023) offs[count] = part[1023];
+    if (t == 1023) *total = part[1023];
+}
+
+__global__ __launch_bounds__(256) void msm_scan_add(uint32_t *__restrict__ offs, uint32_t count, const uint32_t *__restrict__ block_sums,
+                                                    uint32_t *__restrict__ cursor) {
+    const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
+    const uint32_t add = block_sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < count) {
+            uint32_t x = offs[base + k] + add;
+            offs[base + k] = x;
+            cursor[base + k] = x;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void msm_scatter(const uint32_t *__restrict__ dig, uint32_t n, int c, uint32_t *__restrict__ cursor,
@@ -87,20 +129,35 @@ __global__ __launch_bounds__(256) void msm_scatter(const uint32_t *__restrict__ 
     idx[pos] = i | (d & 0x80000000u);
 }
 
+// One lane per (window, bucket).  With precomputed window tables (tab_stride != 0) window w gathers from
+// table w, whose entry i is 2^(c w) P_i, so that all windows feed buckets of equal weight.
 template <class F>
-__global__ __launch_bounds__(256) void msm_bucket_acc(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ offs,
-                                                      const uint32_t *__restrict__ idx, uint32_t nbuckets, uint32_t *__restrict__ buckets) {
+__global__ __launch_bounds__(256) void msm_bucket_acc(const uint32_t *__restrict__ bases, size_t tab_stride_words, uint32_t B,
+                                                      const uint32_t *__restrict__ offs, const uint32_t *__restrict__ idx, uint32_t nbuckets,
+                                                      uint32_t *__restrict__ buckets) {
     constexpr int NL = FieldOps<F>::WORDS;
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nbuckets) return;
+    const uint32_t *tab = bases + (size_t)(g / B) * tab_stride_words;
     uint32_t lo = offs[g], hi = offs[g + 1];
     XYZZ<F> acc = XYZZ<F>::infinity();
     for (uint32_t k = lo; k < hi; ++k) {
         uint32_t e = idx[k];
-        Affine<F> p = affine_load<F>(bases + (size_t)(e & 0x7FFFFFFFu) * (2 * NL));
+        Affine<F> p = affine_load<F>(tab + (size_t)(e & 0x7FFFFFFFu) * (2 * NL));
         acc = xyzz_madd(acc, p, (e >> 31) != 0);
     }
     xyzz_store<F>(buckets + (size_t)g * (4 * NL), acc);
+}
+
+// buckets[w][b] += buckets[w + half][b] for w < cnt (one level of the tree that folds equal-weight windows)
+template <class F>
+__global__ __launch_bounds__(256) void msm_bucket_merge(uint32_t *__restrict__ buckets, uint32_t B, uint32_t half, uint32_t cnt) {
+    constexpr int NL = FieldOps<F>::WORDS;
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= cnt * B) return;
+    uint32_t *dst = buckets + (size_t)g * (4 * NL);
+    const uint32_t *src = buckets + ((size_t)g + (size_t)half * B) * (4 * NL);
+    xyzz_store<F>(dst, xyzz_add(xyzz_load<F>(dst), xyzz_load<F>(src)));
 }
 
 // segment `seg` of window `w` covers buckets [seg*L, seg*L + L) (bucket b holds digit value b + 1):
@@ -204,6 +261,46 @@ __global__ __launch_bounds__(64) void bases_mul(uint32_t *__restrict__ pts, cons
         if ((s[b >> 5] >> (b & 31)) & 1) acc = xyzz_madd(acc, g);
     }
     affine_store<F>(pts + (size_t)i * (2 * NL), xyzz_to_affine(acc));
+}
+
+// Window tables: table w holds 2^(c w) P_i in affine form.  One lane per point: c doublings per table in
+// XYZZ, the W-1 intermediate points parked in `tmp`, one shared inversion (Montgomery's trick over the
+// lane's own W-1 denominators ZZ*ZZZ), then the affine results are written to their tables.
+// tmp: (W-1) x n entries of 5 field elements (X, Y, ZZ, ZZZ, prefix product).
+template <class F>
+__global__ __launch_bounds__(64) void bases_precompute_range(uint32_t *__restrict__ pts, uint32_t n, uint32_t lo, uint32_t cnt, int c, int W,
+                                                             uint32_t *__restrict__ tmp_base) {
+    typedef FieldOps<F> O;
+    constexpr int NL = O::WORDS;
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;  // index inside the chunk
+    if (j >= cnt) return;
+    const uint32_t i = lo + j;
+    // tmp is laid out [w-1][j] over the chunk: shift so that the expressions below can use (w-1) * n + i
+    uint32_t *tmp = tmp_base;
+    Affine<F> p = affine_load<F>(pts + (size_t)i * (2 * NL));
+    if (p.is_inf()) {
+        for (int w = 1; w < W; ++w) affine_store<F>(pts + ((size_t)w * n + i) * (2 * NL), Affine<F>::infinity());
+        return;
+    }
+    XYZZ<F> acc = XYZZ<F>::from_affine(p);
+    F pre = F::one();
+    for (int w = 1; w < W; ++w) {
+        for (int k = 0; k < c; ++k) acc = xyzz_dbl(acc);
+        uint32_t *slot = tmp + ((size_t)(w - 1) * cnt + j) * (5 * NL);
+        xyzz_store<F>(slot, acc);
+        pre = O::mul(pre, O::mul(acc.ZZ, acc.ZZZ));
+        O::store(slot + 4 * NL, pre);
+    }
+    F inv = O::inv(pre);  // 1 / prod_w (ZZ_w ZZZ_w)
+    for (int w = W - 1; w >= 1; --w) {
+        const uint32_t *slot = tmp + ((size_t)(w - 1) * cnt + j) * (5 * NL);
+        XYZZ<F> q = xyzz_load<F>(slot);
+        F before = w > 1 ? O::load(tmp + ((size_t)(w - 2) * cnt + j) * (5 * NL) + 4 * NL) : F::one();
+        F dinv = O::mul(inv, before);            // 1 / (ZZ_w ZZZ_w)
+        inv = O::mul(inv, O::mul(q.ZZ, q.ZZZ));  // drop this factor
+        Affine<F> a = {O::mul(q.X, O::mul(dinv, q.ZZZ)), O::mul(q.Y, O::mul(dinv, q.ZZ))};
+        affine_store<F>(pts + ((size_t)w * n + i) * (2 * NL), a);
+    }
 }
 
 template <class F>
@@ -310,25 +407,31 @@ static int ilog2(size_t v) {
     return l;
 }
 
+int zk_msm_auto_window(size_t n) { return std::max(2, std::min(16, ilog2(n) - 4)); }
+
 template <class F>
-static int msm_run_t(zkhip_ctx *ctx, const uint32_t *d_bases, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac) {
+static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac) {
     constexpr int NL = FieldOps<F>::WORDS;
-    // window size: 2^(c-1) buckets per window, about n / 2^(c-1) * ... points per bucket
-    int c = ctx->opt_msm_window_bits;
-    if (c <= 0) c = std::max(2, std::min(16, ilog2(n) - 4));
+    const bool tables = bases->ntab > 1;
+    // window size: 2^(c-1) buckets per window.  With window tables c is fixed by the tables.
+    int c = tables ? bases->c_tab : ctx->opt_msm_window_bits;
+    if (c <= 0) c = zk_msm_auto_window(n);
     c = std::max(2, std::min(16, c));
     const int scalar_bits_total = 256;  // Fr < 2^255: one spare bit absorbs the signed-digit carry
     const int W = (scalar_bits_total + c - 1) / c;
     const uint32_t B = 1u << (c - 1);
     const uint32_t nb = (uint32_t)W * B;
+    const int Wr = tables ? 1 : W;  // windows left after the equal-weight merge
     uint32_t L = std::min<uint32_t>(B, 1u << std::max(0, ctx->opt_msm_segment_log));
     const uint32_t nseg = B / L;
+    const uint32_t nblk = (nb + 1023) / 1024;
 
     size_t need = 0;
     need += zkhip_ctx::ws_round((size_t)W * n * 4);        // dig
     need += zkhip_ctx::ws_round((size_t)nb * 4);           // hist
     need += zkhip_ctx::ws_round(((size_t)nb + 1) * 4);     // offs
     need += zkhip_ctx::ws_round((size_t)nb * 4);           // cursor
+    need += zkhip_ctx::ws_round((size_t)nblk * 4);         // block sums
     need += zkhip_ctx::ws_round((size_t)W * n * 4);        // idx
     need += zkhip_ctx::ws_round((size_t)nb * 4 * NL * 4);  // buckets
     need += zkhip_ctx::ws_round((size_t)W * nseg * 4 * NL * 4);
@@ -339,23 +442,60 @@ static int msm_run_t(zkhip_ctx *ctx, const uint32_t *d_bases, size_t n, const ui
     uint32_t *hist = ctx->ws_take<uint32_t>(nb);
     uint32_t *offs = ctx->ws_take<uint32_t>((size_t)nb + 1);
     uint32_t *cursor = ctx->ws_take<uint32_t>(nb);
+    uint32_t *bsums = ctx->ws_take<uint32_t>(nblk);
     uint32_t *idx = ctx->ws_take<uint32_t>((size_t)W * n);
     uint32_t *buckets = ctx->ws_take<uint32_t>((size_t)nb * 4 * NL);
     uint32_t *segsum = ctx->ws_take<uint32_t>((size_t)W * nseg * 4 * NL);
     uint32_t *winsum = ctx->ws_take<uint32_t>((size_t)W * 4 * NL);
 
+    const uint32_t *d_b = bases->d + offset * bases->stride_u32;
+    const size_t tab_stride_words = tables ? bases->n * bases->stride_u32 : 0;
+
     ZK_HIP_CHECK(ctx, hipMemsetAsync(hist, 0, (size_t)nb * 4, ctx->stream));
     unsigned gn = (unsigned)((n + 255) / 256);
     ZK_LAUNCH(ctx, "msm_digits", msm_digits, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, c, W, dig, hist);
-    ZK_LAUNCH(ctx, "msm_scan", msm_scan, dim3(1), dim3(1024), 0, hist, nb, offs, cursor);
+    ZK_LAUNCH(ctx, "msm_scan", msm_scan_local, dim3(nblk), dim3(256), 0, hist, nb, offs, bsums);
+    ZK_LAUNCH(ctx, "msm_scan", msm_scan_top, dim3(1), dim3(1024), 0, bsums, nblk, offs + nb);
+    ZK_LAUNCH(ctx, "msm_scan", msm_scan_add, dim3(nblk), dim3(256), 0, offs, nb, bsums, cursor);
     ZK_LAUNCH(ctx, "msm_scatter", msm_scatter, dim3(gn, W), dim3(256), 0, dig, (uint32_t)n, c, cursor, idx);
-    ZK_LAUNCH(ctx, "msm_bucket_acc", msm_bucket_acc<F>, dim3((nb + 255) / 256), dim3(256), 0, d_bases, offs, idx, nb, buckets);
-    uint32_t tot = (uint32_t)W * nseg;
+    ZK_LAUNCH(ctx, "msm_bucket_acc", msm_bucket_acc<F>, dim3((nb + 255) / 256), dim3(256), 0, d_b, tab_stride_words, B, offs, idx, nb, buckets);
+    if (tables) {
+        for (uint32_t cur = (uint32_t)W; cur > 1;) {
+            uint32_t half = (cur + 1) / 2, cnt = cur - half;
+            ZK_LAUNCH(ctx, "msm_bucket_merge", msm_bucket_merge<F>, dim3((cnt * B + 255) / 256), dim3(256), 0, buckets, B, half, cnt);
+            cur = half;
+        }
+    }
+    uint32_t tot = (uint32_t)Wr * nseg;
     ZK_LAUNCH(ctx, "msm_bucket_red", msm_bucket_red<F>, dim3((tot + 63) / 64), dim3(64), 0, buckets, B, L, nseg, tot, segsum);
     unsigned wthreads = 128;
     size_t lds = (size_t)wthreads * 4 * NL * 4;
-    ZK_LAUNCH(ctx, "msm_window_sum", msm_window_sum<F>, dim3(W), dim3(wthreads), lds, segsum, nseg, winsum);
-    ZK_LAUNCH(ctx, "msm_final", msm_final<F>, dim3(1), dim3(64), 0, winsum, W, c, d_out_jac);
+    ZK_LAUNCH(ctx, "msm_window_sum", msm_window_sum<F>, dim3(Wr), dim3(wthreads), lds, segsum, nseg, winsum);
+    ZK_LAUNCH(ctx, "msm_final", msm_final<F>, dim3(1), dim3(64), 0, winsum, Wr, c, d_out_jac);
+    return 0;
+}
+
+// Build tables 1..ntab-1 of a bases object whose table 0 is filled (called once at upload).
+template <class F>
+static int bases_precompute_t(zkhip_ctx *ctx, zkhip_bases *b) {
+    constexpr int NL = FieldOps<F>::WORDS;
+    const size_t chunk = 1u << 18;  // bounds the temporary to (ntab-1) * 2^18 * 5 field elements
+    size_t per = (size_t)(b->ntab - 1) * 5 * NL * 4;
+    ZK_TRY(ctx->ws_reserve(per * std::min(chunk, b->n) + 4096));
+    for (size_t lo = 0; lo < b->n; lo += chunk) {
+        size_t cnt = std::min(chunk, b->n - lo);
+        ctx->ws_reset();
+        uint32_t *tmp = ctx->ws_take<uint32_t>(per / 4 * cnt);
+        // the kernel indexes tables with stride n: hand it the sub-range through a shifted base pointer
+        ZK_LAUNCH(ctx, "bases_precompute", bases_precompute_range<F>, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, b->d, (uint32_t)b->n,
+                  (uint32_t)lo, (uint32_t)cnt, b->c_tab, b->ntab, tmp);
+    }
+    return 0;
+}
+
+int zk_bases_precompute(zkhip_ctx *ctx, zkhip_bases *b) {
+    if (b->ntab <= 1 || b->n == 0) return 0;
+    ZK_DISPATCH_CG(b->curve, b->group, return bases_precompute_t<F>(ctx, b));
     return 0;
 }
 
@@ -371,11 +511,10 @@ __global__ void msm_write_infinity(uint32_t *out_jac) {
 int zk_msm_run(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac) {
     if (offset + n > bases->n) return ZKHIP_ERR_RANGE;
     if (n >= (1ull << 31)) return ZKHIP_ERR_RANGE;
-    const uint32_t *d_b = bases->d + offset * bases->stride_u32;
     if (n == 0) {
         ZK_DISPATCH_CG(bases->curve, bases->group, ZK_LAUNCH(ctx, "msm_write_infinity", msm_write_infinity<F>, dim3(1), dim3(64), 0, d_out_jac));
         return 0;
     }
-    ZK_DISPATCH_CG(bases->curve, bases->group, return msm_run_t<F>(ctx, d_b, n, d_scalars, d_out_jac));
+    ZK_DISPATCH_CG(bases->curve, bases->group, return msm_run_t<F>(ctx, bases, offset, n, d_scalars, d_out_jac));
     return 0;
 }

@@ -88,6 +88,8 @@ int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value) {
     else if (n == "msm_segment_log") ctx->opt_msm_segment_log = (int)value;
     else if (n == "ntt_radix_log") ctx->opt_ntt_radix_log = (int)value;
     else if (n == "ntt_tile_log") ctx->opt_ntt_tile_log = (int)value;
+    else if (n == "msm_precompute") ctx->opt_msm_precompute = (int)value;
+    else if (n == "msm_precompute_min") ctx->opt_msm_precompute_min = (int)value;
     else return ZKHIP_ERR_INVALID;
     return ZKHIP_OK;
 }
@@ -126,7 +128,13 @@ static int bases_alloc(zkhip_ctx *ctx, int curve, int group, size_t n, zkhip_bas
     b->n = n;
     b->stride_u32 = zk_point_words(curve, group);
     b->d = nullptr;
-    hipError_t e = hipMalloc((void **)&b->d, std::max<size_t>(1, n) * b->stride_u32 * 4);
+    b->ntab = 1;
+    b->c_tab = 0;
+    if (ctx->opt_msm_precompute && n >= (size_t)ctx->opt_msm_precompute_min) {
+        b->c_tab = zk_msm_auto_window(n);
+        b->ntab = (256 + b->c_tab - 1) / b->c_tab;
+    }
+    hipError_t e = hipMalloc((void **)&b->d, std::max<size_t>(1, n) * b->ntab * b->stride_u32 * 4);
     if (e != hipSuccess) {
         ctx->last_error = std::string("hipMalloc(bases): ") + hipGetErrorString(e);
         delete b;
@@ -167,6 +175,8 @@ int zkhip_bases_upload(zkhip_ctx *ctx, int curve, int group, const uint64_t *aff
             }
         }
         rc = zk_bases_to_mont(ctx, b, d_canon, d_inf);
+        if (rc) break;
+        rc = zk_bases_precompute(ctx, b);
         if (rc) break;
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
     } while (0);
@@ -218,6 +228,8 @@ int zkhip_bases_from_scalars(zkhip_ctx *ctx, int curve, int group, const uint64_
             break;
         }
         rc = zk_bases_mul(ctx, b, d_g, d_s);
+        if (rc) break;
+        rc = zk_bases_precompute(ctx, b);
         if (rc) break;
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
     } while (0);
