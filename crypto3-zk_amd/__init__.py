@@ -12,6 +12,7 @@ from .zkhip import (  # noqa: F401
     G2,
     Bases,
     Context,
+    R1CS,
     ZkhipError,
     build,
     coord_limbs,

@@ -1,0 +1,266 @@
+// Device side of the R1CS -> QAP witness map that feeds the Groth16 H-query MSM.
+//
+// Replaces reductions::r1cs_to_qap<F>::witness_map (zk/snark/reductions/r1cs_to_qap.hpp:219-325, with
+// d1 = d2 = d3 = 0 as r1cs_gg_ppzksnark_prover::process calls it, prover.hpp:79-83):
+//     aA[i] = <A_i, z>, aB[i] = <B_i, z>, aC[i] = <C_i, z>          (:245-248, :288-291)  sparse mat-vec
+//     aA[M + i] = z_i for i <= n (input-consistency rows)             (:240-243)
+//     inverse_fft; multiply_by_coset(g); fft    on aA, aB, aC         (:250-276, :293-299)  6 NTTs, batched x3
+//     H_tmp = (aA o aB - aC) / Z(g w^i),  Z on the coset = g^m - 1    (:283-308)            one pointwise pass
+//     inverse_fft; multiply_by_coset(g^-1)                            (:310-315)            1 NTT
+//     coefficients_for_H = H_tmp | 0                                  (m + 1 entries)
+// z = (1, primary, auxiliary) and all vectors stay in HBM; the result is consumed in place by zkhip_msm_dev.
+#include <algorithm>
+
+#include "ctx.hpp"
+#include "fu.hpp"
+
+using namespace zkhip;
+
+struct zkhip_r1cs {
+    int curve;
+    size_t M, n, N, m, log_m;
+    // CSR, three matrices; coefficients in Montgomery form of the lazy Fr type (SL words each)
+    uint32_t *rowptr[3] = {nullptr, nullptr, nullptr};
+    uint32_t *col[3] = {nullptr, nullptr, nullptr};
+    uint32_t *coeff[3] = {nullptr, nullptr, nullptr};
+    uint32_t *long_rows[3] = {nullptr, nullptr, nullptr};  // rows with more than LONG_ROW terms
+    uint32_t n_long[3] = {0, 0, 0};
+    size_t nnz[3] = {0, 0, 0};
+};
+
+static constexpr uint32_t LONG_ROW = 64;
+
+// value < 2p (product output) -> [0, p)
+template <class U>
+ZK_D Fu<U> fr_reduce(const Fu<U> &a) { return fu_cond_sub_p(a); }
+// a, b in [0, p) -> a + b in [0, p)
+template <class U>
+ZK_D Fu<U> fr_add_mod(const Fu<U> &a, const Fu<U> &b) { return fu_cond_sub_p(fu_add(a, b)); }
+
+template <class U>
+__global__ __launch_bounds__(256) void r1cs_coeff_to_mont(const uint32_t *__restrict__ canon, size_t nnz, uint32_t *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nnz) return;
+    fu_store<U>(out + i * U::SL, fu_cond_sub_p(fu_from_canonical<U>(canon + i * U::NL)));
+}
+
+// out[row] = <row, z> for short rows (one lane per row); long rows are left to r1cs_eval_long.
+// z is canonical (NL words per element); coefficients are Montgomery, so mul(unpack(z), c) = z*c canonical.
+template <class U>
+__global__ __launch_bounds__(256) void r1cs_eval_rows(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
+                                                      const uint32_t *__restrict__ coeff, const uint32_t *__restrict__ z, uint32_t M,
+                                                      uint32_t *__restrict__ out) {
+    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= M) return;
+    uint32_t lo = rowptr[row], hi = rowptr[row + 1];
+    if (hi - lo > LONG_ROW) return;
+    Fu<U> acc = Fu<U>::zero();
+    for (uint32_t k = lo; k < hi; ++k) {
+        Fu<U> t = fu_mul(fu_unpack<U>(z + (size_t)col[k] * U::NL), fu_load<U>(coeff + (size_t)k * U::SL));
+        acc = fr_add_mod(acc, fr_reduce(t));
+    }
+    fu_pack<U>(out + (size_t)row * U::NL, acc);
+}
+
+// one workgroup per long row: strided partial sums, LDS tree
+template <class U>
+__global__ __launch_bounds__(256) void r1cs_eval_long(const uint32_t *__restrict__ long_rows, const uint32_t *__restrict__ rowptr,
+                                                      const uint32_t *__restrict__ col, const uint32_t *__restrict__ coeff,
+                                                      const uint32_t *__restrict__ z, uint32_t *__restrict__ out) {
+    __shared__ uint32_t part[256 * U::L];
+    const uint32_t row = long_rows[blockIdx.x], t = threadIdx.x;
+    const uint32_t lo = rowptr[row], hi = rowptr[row + 1];
+    Fu<U> acc = Fu<U>::zero();
+    for (uint32_t k = lo + t; k < hi; k += 256) {
+        Fu<U> x = fu_mul(fu_unpack<U>(z + (size_t)col[k] * U::NL), fu_load<U>(coeff + (size_t)k * U::SL));
+        acc = fr_add_mod(acc, fr_reduce(x));
+    }
+#pragma unroll
+    for (int i = 0; i < U::L; ++i) part[i * 256 + t] = acc.v[i];
+    __syncthreads();
+    for (uint32_t d = 128; d >= 1; d >>= 1) {
+        if (t < d) {
+            Fu<U> o;
+#pragma unroll
+            for (int i = 0; i < U::L; ++i) o.v[i] = part[i * 256 + t + d];
+            acc = fr_add_mod(acc, o);
+#pragma unroll
+            for (int i = 0; i < U::L; ++i) part[i * 256 + t] = acc.v[i];
+        }
+        __syncthreads();
+    }
+    if (t == 0) fu_pack<U>(out + (size_t)row * U::NL, acc);
+}
+
+// rows M .. m-1 of the three vectors: aA[M + i] = z_i (i <= n), everything else zero
+template <class U>
+__global__ __launch_bounds__(256) void r1cs_fill_tail(uint32_t *__restrict__ abc, const uint32_t *__restrict__ z, uint32_t M, uint32_t n,
+                                                      uint32_t m) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // index in [M, m) x 3
+    uint32_t tail = m - M;
+    if (i >= 3 * tail) return;
+    uint32_t mat = i / tail, r = M + i % tail;
+    uint4 *dst = reinterpret_cast<uint4 *>(abc + ((size_t)mat * m + r) * U::NL);
+    uint4 a = make_uint4(0, 0, 0, 0), b = a;
+    if (mat == 0 && r - M <= n) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(z + (size_t)(r - M) * U::NL);
+        a = src[0];
+        b = src[1];
+    }
+    dst[0] = a;
+    dst[1] = b;
+}
+
+// consts[0] = zinv = 1/(g^m - 1) in Montgomery form, consts[1] = zinv * R (so that mul(mul(a, b), consts[1]) = a b zinv)
+template <class U>
+__global__ void groth16_h_setup(const uint32_t *__restrict__ coset_c, uint32_t log_m, uint32_t *__restrict__ consts) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Fu<U> g = fu_from_canonical<U>(coset_c);
+    Fu<U> gm = g;
+    for (uint32_t i = 0; i < log_m; ++i) gm = fu_mul_call(gm, gm);
+    Fu<U> zinv = fu_inv(fu_sub<4>(gm, Fu<U>::one()));
+    fu_store<U>(consts, fu_cond_sub_p(zinv));
+    fu_store<U>(consts + U::SL, fu_cond_sub_p(fu_mul_call(zinv, Fu<U>::r2())));
+}
+
+// h[i] = (a[i] b[i] - c[i]) * zinv, canonical in and out
+template <class U>
+__global__ __launch_bounds__(256) void groth16_h_pointwise(const uint32_t *__restrict__ abc, uint32_t m, const uint32_t *__restrict__ consts,
+                                                           uint32_t *__restrict__ h) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    Fu<U> a = fu_unpack<U>(abc + (size_t)i * U::NL), b = fu_unpack<U>(abc + ((size_t)m + i) * U::NL),
+          c = fu_unpack<U>(abc + ((size_t)2 * m + i) * U::NL);
+    Fu<U> k1 = fu_load<U>(consts), k2 = fu_load<U>(consts + U::SL);
+    Fu<U> ab = fu_mul(fu_mul(a, b), k2);  // a b zinv        (< 2p)
+    Fu<U> cz = fu_mul(c, k1);             // c zinv          (< 2p)
+    Fu<U> r = fu_sub<4>(ab, cz);          // < 6p
+    fu_pack<U>(h + (size_t)i * U::NL, fu_canon(r));  // canonical Montgomery form of r, i.e. r itself as an integer mod p
+}
+
+template <class U>
+__global__ void fr_zero_one(uint32_t *__restrict__ p) {
+    if (blockIdx.x != 0 || threadIdx.x >= U::NL) return;
+    p[threadIdx.x] = 0;
+}
+
+// ---- host side ------------------------------------------------------------------------------------
+template <class U>
+static int r1cs_upload_t(zkhip_ctx *ctx, zkhip_r1cs *r, const uint32_t *const rowptr[3], const uint32_t *const col[3],
+                         const uint64_t *const coeff[3]) {
+    for (int k = 0; k < 3; ++k) {
+        size_t nnz = rowptr[k][r->M];
+        r->nnz[k] = nnz;
+        ZK_HIP_CHECK(ctx, hipMalloc((void **)&r->rowptr[k], (r->M + 1) * 4));
+        ZK_HIP_CHECK(ctx, hipMalloc((void **)&r->col[k], std::max<size_t>(1, nnz) * 4));
+        ZK_HIP_CHECK(ctx, hipMalloc((void **)&r->coeff[k], std::max<size_t>(1, nnz) * U::SL * 4));
+        ZK_HIP_CHECK(ctx, hipMemcpyAsync(r->rowptr[k], rowptr[k], (r->M + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        std::vector<uint32_t> lr;
+        for (size_t i = 0; i < r->M; ++i) {
+            if (rowptr[k][i + 1] - rowptr[k][i] > LONG_ROW) lr.push_back((uint32_t)i);
+            if (rowptr[k][i + 1] < rowptr[k][i]) return ZKHIP_ERR_INVALID;
+        }
+        for (size_t j = 0; j < nnz; ++j)
+            if (col[k][j] > r->N) return ZKHIP_ERR_RANGE;
+        r->n_long[k] = (uint32_t)lr.size();
+        if (!lr.empty()) {
+            ZK_HIP_CHECK(ctx, hipMalloc((void **)&r->long_rows[k], lr.size() * 4));
+            ZK_HIP_CHECK(ctx, hipMemcpyAsync(r->long_rows[k], lr.data(), lr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        }
+        if (nnz) {
+            uint32_t *d_c = nullptr;
+            ZK_HIP_CHECK(ctx, hipMalloc((void **)&d_c, nnz * 32));
+            ZK_HIP_CHECK(ctx, hipMemcpyAsync(r->col[k], col[k], nnz * 4, hipMemcpyHostToDevice, ctx->stream));
+            ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_c, coeff[k], nnz * 32, hipMemcpyHostToDevice, ctx->stream));
+            ZK_LAUNCH(ctx, "r1cs_coeff_to_mont", r1cs_coeff_to_mont<U>, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, d_c, nnz, r->coeff[k]);
+            ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(d_c);
+        }
+        ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+template <class U>
+static int witness_h_t(zkhip_ctx *ctx, const zkhip_r1cs *r, const uint32_t *d_z, const uint64_t *omega, const uint64_t *coset, uint32_t *d_h,
+                       uint32_t *d_abc) {
+    const uint32_t M = (uint32_t)r->M, m = (uint32_t)r->m;
+    for (int k = 0; k < 3; ++k) {
+        uint32_t *out = d_abc + (size_t)k * m * U::NL;
+        ZK_LAUNCH(ctx, "r1cs_eval_rows", r1cs_eval_rows<U>, dim3((M + 255) / 256), dim3(256), 0, r->rowptr[k], r->col[k], r->coeff[k], d_z, M, out);
+        if (r->n_long[k])
+            ZK_LAUNCH(ctx, "r1cs_eval_long", r1cs_eval_long<U>, dim3(r->n_long[k]), dim3(256), 0, r->long_rows[k], r->rowptr[k], r->col[k],
+                      r->coeff[k], d_z, out);
+    }
+    if (m > M) ZK_LAUNCH(ctx, "r1cs_fill_tail", r1cs_fill_tail<U>, dim3((3 * (m - M) + 255) / 256), dim3(256), 0, d_abc, d_z, M, (uint32_t)r->n, m);
+    // coefficients, then evaluations on the coset g<omega>
+    ZK_TRY(zk_ntt_run(ctx, r->curve, d_abc, r->log_m, 3, omega, 1, nullptr));
+    ZK_TRY(zk_ntt_run(ctx, r->curve, d_abc, r->log_m, 3, omega, 0, coset));
+    // constants live at the tail of the caller-provided scratch (after the three vectors)
+    uint32_t *consts = d_abc + (size_t)3 * m * U::NL;
+    uint32_t *d_g = consts + 2 * U::SL;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_g, coset, 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_LAUNCH(ctx, "groth16_h_setup", groth16_h_setup<U>, dim3(1), dim3(64), 0, d_g, (uint32_t)r->log_m, consts);
+    ZK_LAUNCH(ctx, "groth16_h_pointwise", groth16_h_pointwise<U>, dim3((m + 255) / 256), dim3(256), 0, d_abc, m, consts, d_h);
+    ZK_TRY(zk_ntt_run(ctx, r->curve, d_h, r->log_m, 1, omega, 1, coset));
+    ZK_LAUNCH(ctx, "fr_zero_one", fr_zero_one<U>, dim3(1), dim3(64), 0, d_h + (size_t)m * U::NL);
+    return 0;
+}
+
+extern "C" {
+
+int zkhip_r1cs_upload(zkhip_ctx *ctx, int curve, size_t num_constraints, size_t num_inputs, size_t num_variables, const uint32_t *rowptr_a,
+                      const uint32_t *col_a, const uint64_t *coeff_a, const uint32_t *rowptr_b, const uint32_t *col_b, const uint64_t *coeff_b,
+                      const uint32_t *rowptr_c, const uint32_t *col_c, const uint64_t *coeff_c, zkhip_r1cs **out) {
+    if (!ctx || !out || !rowptr_a || !rowptr_b || !rowptr_c) return ZKHIP_ERR_INVALID;
+    if (curve != CURVE_BLS12_381 && curve != CURVE_BN254) return ZKHIP_ERR_INVALID;
+    if (num_inputs > num_variables || num_constraints == 0 || num_constraints >= (1ull << 31)) return ZKHIP_ERR_RANGE;
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    zkhip_r1cs *r = new zkhip_r1cs();
+    r->curve = curve;
+    r->M = num_constraints;
+    r->n = num_inputs;
+    r->N = num_variables;
+    r->m = 1;
+    r->log_m = 0;
+    while (r->m < r->M + r->n + 1) {  // make_evaluation_domain(num_constraints + num_inputs + 1), r1cs_to_qap.hpp:229-230
+        r->m <<= 1;
+        ++r->log_m;
+    }
+    const uint32_t *rp[3] = {rowptr_a, rowptr_b, rowptr_c}, *cl[3] = {col_a, col_b, col_c};
+    const uint64_t *cf[3] = {coeff_a, coeff_b, coeff_c};
+    int rc = curve == CURVE_BLS12_381 ? r1cs_upload_t<BlsFrU>(ctx, r, rp, cl, cf) : r1cs_upload_t<BnFrU>(ctx, r, rp, cl, cf);
+    if (rc) {
+        zkhip_r1cs_free(ctx, r);
+        return rc;
+    }
+    *out = r;
+    return ZKHIP_OK;
+}
+
+void zkhip_r1cs_free(zkhip_ctx *ctx, zkhip_r1cs *r) {
+    if (!r) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    for (int k = 0; k < 3; ++k) {
+        (void)hipFree(r->rowptr[k]);
+        (void)hipFree(r->col[k]);
+        (void)hipFree(r->coeff[k]);
+        (void)hipFree(r->long_rows[k]);
+    }
+    delete r;
+}
+
+size_t zkhip_r1cs_domain_size(const zkhip_r1cs *r) { return r ? r->m : 0; }
+
+size_t zkhip_groth16_scratch_bytes(const zkhip_r1cs *r) { return r ? (size_t)3 * r->m * 32 + 4096 : 0; }
+
+int zkhip_groth16_witness_h_dev(zkhip_ctx *ctx, const zkhip_r1cs *r, const void *d_assignment, const uint64_t *omega, const uint64_t *coset_gen,
+                                void *d_h, void *d_scratch) {
+    if (!ctx || !r || !d_assignment || !omega || !coset_gen || !d_h || !d_scratch) return ZKHIP_ERR_INVALID;
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (r->curve == CURVE_BLS12_381)
+        return witness_h_t<BlsFrU>(ctx, r, (const uint32_t *)d_assignment, omega, coset_gen, (uint32_t *)d_h, (uint32_t *)d_scratch);
+    return witness_h_t<BnFrU>(ctx, r, (const uint32_t *)d_assignment, omega, coset_gen, (uint32_t *)d_h, (uint32_t *)d_scratch);
+}
+
+}  // extern "C"

@@ -17,6 +17,7 @@ EXPORTS = [
     "zkhip_set_option", "zkhip_malloc", "zkhip_free", "zkhip_memcpy_h2d", "zkhip_memcpy_d2h",
     "zkhip_bases_upload", "zkhip_bases_from_scalars", "zkhip_bases_download", "zkhip_bases_size",
     "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
+    "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_domain_size", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev",
     "zkhip_profile_enable", "zkhip_profile_reset", "zkhip_profile_get", "zkhip_profile_dump",
 ]
 
@@ -62,6 +63,11 @@ def load_library() -> ctypes.CDLL:
     lib.zkhip_bases_size.restype = ctypes.c_size_t
     lib.zkhip_bases_size.argtypes = [ctypes.c_void_p]
     lib.zkhip_profile_dump.restype = ctypes.c_size_t
+    lib.zkhip_r1cs_domain_size.restype = ctypes.c_size_t
+    lib.zkhip_r1cs_domain_size.argtypes = [ctypes.c_void_p]
+    lib.zkhip_groth16_scratch_bytes.restype = ctypes.c_size_t
+    lib.zkhip_groth16_scratch_bytes.argtypes = [ctypes.c_void_p]
+    lib.zkhip_r1cs_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.zkhip_destroy.argtypes = [ctypes.c_void_p]
     lib.zkhip_bases_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     _LIB = lib
@@ -193,6 +199,44 @@ class Context:
                                            _p(_u64(omega)), 1 if inverse else 0, _p(_u64(coset)) if coset is not None else None),
                     "zkhip_ntt_dev")
 
+    # ---- Groth16 witness map
+    def upload_r1cs(self, curve: int, M: int, n: int, N: int, csr_a, csr_b, csr_c) -> "R1CS":
+        """csr_x = (rowptr u32 (M+1), col u32 (nnz), coeff u64 (nnz, 4))"""
+        args = []
+        keep = []
+        for rp, cl, cf in (csr_a, csr_b, csr_c):
+            rp = np.ascontiguousarray(rp, dtype=np.uint32)
+            cl = np.ascontiguousarray(cl, dtype=np.uint32)
+            cf = _u64(cf)
+            keep += [rp, cl, cf]
+            args += [_p(rp), _p(cl), _p(cf)]
+        h = ctypes.c_void_p()
+        self._check(self.lib.zkhip_r1cs_upload(self.h, curve, ctypes.c_size_t(M), ctypes.c_size_t(n), ctypes.c_size_t(N), *args, ctypes.byref(h)),
+                    "zkhip_r1cs_upload")
+        return R1CS(self, h, curve, M, n, N)
+
+    def groth16_witness_h_dev(self, r1cs: "R1CS", d_assignment: int, omega, coset, d_h: int, d_scratch: int):
+        self._check(self.lib.zkhip_groth16_witness_h_dev(self.h, r1cs.h, ctypes.c_void_p(d_assignment), _p(_u64(omega)), _p(_u64(coset)),
+                                                         ctypes.c_void_p(d_h), ctypes.c_void_p(d_scratch)), "zkhip_groth16_witness_h_dev")
+
+    def groth16_witness_h(self, r1cs: "R1CS", assignment_with_one: np.ndarray, omega, coset) -> np.ndarray:
+        """host convenience: (N+1, 4) canonical assignment (1 | primary | auxiliary) -> (m+1, 4) coefficients of H"""
+        z = _u64(assignment_with_one)
+        m = r1cs.m
+        d_z = self.malloc(z.nbytes)
+        d_h = self.malloc((m + 1) * 32)
+        d_s = self.malloc(self.lib.zkhip_groth16_scratch_bytes(r1cs.h))
+        try:
+            self.h2d(d_z, z)
+            self.groth16_witness_h_dev(r1cs, d_z, omega, coset, d_h, d_s)
+            out = np.zeros((m + 1, 4), dtype=np.uint64)
+            self.d2h(out, d_h)
+        finally:
+            self.free(d_z)
+            self.free(d_h)
+            self.free(d_s)
+        return out
+
     # ---- profiling
     def profile(self, on: bool):
         self._check(self.lib.zkhip_profile_enable(self.h, 1 if on else 0), "zkhip_profile_enable")
@@ -215,6 +259,26 @@ class Context:
             name, ms, cnt = line.rsplit(" ", 2)
             out[name] = (float(ms), int(cnt))
         return out
+
+
+class R1CS:
+    """Resident constraint system (zkhip_r1cs)."""
+
+    def __init__(self, ctx: "Context", h, curve, M, n, N):
+        self.ctx, self.h, self.curve, self.M, self.n, self.N = ctx, h, curve, M, n, N
+        self.m = ctx.lib.zkhip_r1cs_domain_size(h)
+        self.log_m = self.m.bit_length() - 1
+
+    def free(self):
+        if self.h is not None and self.ctx.h:
+            self.ctx.lib.zkhip_r1cs_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Bases:

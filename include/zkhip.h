@@ -104,6 +104,27 @@ int zkhip_ntt(zkhip_ctx *ctx, int curve, uint64_t *data /* host, batch x m x 4 *
 int zkhip_ntt_dev(zkhip_ctx *ctx, int curve, void *d_data, size_t log_m, size_t batch, const uint64_t *omega, int inverse,
                   const uint64_t *coset_gen);
 
+/* ---- Groth16 witness map ------------------------------------------------------------------------
+ * Resident R1CS in CSR form (three matrices A, B, C; column 0 is the constant 1, column j >= 1 is variable
+ * j - 1; coefficients canonical Fr, 4 limbs each).  Replaces the constraint_system member of the proving key
+ * (r1cs_gg_ppzksnark/proving_key.hpp:56; r1cs.hpp:61-64,125-133) as consumed by
+ * reductions::r1cs_to_qap<F>::witness_map (reductions/r1cs_to_qap.hpp:219-325). */
+typedef struct zkhip_r1cs zkhip_r1cs;
+int zkhip_r1cs_upload(zkhip_ctx *ctx, int curve, size_t num_constraints, size_t num_inputs, size_t num_variables, const uint32_t *rowptr_a,
+                      const uint32_t *col_a, const uint64_t *coeff_a, const uint32_t *rowptr_b, const uint32_t *col_b, const uint64_t *coeff_b,
+                      const uint32_t *rowptr_c, const uint32_t *col_c, const uint64_t *coeff_c, zkhip_r1cs **out);
+void zkhip_r1cs_free(zkhip_ctx *ctx, zkhip_r1cs *r);
+/* m = the radix-2 domain size make_evaluation_domain(num_constraints + num_inputs + 1) picks (r1cs_to_qap.hpp:229-230) */
+size_t zkhip_r1cs_domain_size(const zkhip_r1cs *r);
+size_t zkhip_groth16_scratch_bytes(const zkhip_r1cs *r);
+/* coefficients_for_H of witness_map with d1 = d2 = d3 = 0 (as prover.hpp:79-83 calls it): m + 1 Fr elements
+ * written to d_h.  d_assignment = (1, primary_input, auxiliary_input), num_variables + 1 elements, device
+ * resident; omega = the primitive m-th root of the caller's evaluation domain; coset_gen = the field's
+ * multiplicative generator (arithmetic_params<F>::multiplicative_generator).  3 sparse mat-vecs, 7 NTTs and
+ * one fused pointwise pass, all on the context's stream; the result feeds zkhip_msm_dev directly. */
+int zkhip_groth16_witness_h_dev(zkhip_ctx *ctx, const zkhip_r1cs *r, const void *d_assignment, const uint64_t *omega,
+                                const uint64_t *coset_gen, void *d_h, void *d_scratch);
+
 /* ---- profiling (HIP events on the context's stream around every kernel launch) ------------------ */
 int zkhip_profile_enable(zkhip_ctx *ctx, int on);
 int zkhip_profile_reset(zkhip_ctx *ctx);

@@ -151,3 +151,22 @@ def test_msm_full_size_bls12_381_g1(ctx):
     exp, einf = cp.msm(0, 1, allpts, s3, chunks=cp.num_threads())
     assert gpu_affine(ctx, bases, s3) == pt_from_limbs(0, 1, exp, einf)
     bases.free()
+
+
+@pytest.mark.parametrize("curve,M,n", [(1, 1024, 10), (0, 1024, 10), (0, 50, 3), (0, 4085, 10)])
+def test_groth16_witness_map(ctx, curve, M, n):
+    """r1cs_to_qap::witness_map on the device (sparse mat-vec, 7 NTTs, pointwise) against the oracle; the
+    example system has two rows of ~M terms (long-row path) and M short rows."""
+    C = CURVES[curve]
+    g16 = cp.Groth16(curve, M, n, seed=3)
+    assert g16.is_satisfied()
+    w = limbs(C.root_of_unity(g16.log_m), 4)
+    gen = limbs(C.fr_generator, 4)
+    exp = g16.witness_map(w, gen)
+    r1cs = ctx.upload_r1cs(curve, g16.M, g16.n, g16.N, g16.csr(0), g16.csr(1), g16.csr(2))
+    assert r1cs.m == g16.m
+    z = np.concatenate([np.array([[1, 0, 0, 0]], dtype=np.uint64), g16.assignment()])
+    got = ctx.groth16_witness_h(r1cs, z, w, gen)
+    assert (got == exp).all()
+    assert not got[g16.m - 1].any() and not got[g16.m].any()  # prover.hpp:88-89
+    r1cs.free()
