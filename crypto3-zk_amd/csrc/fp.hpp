@@ -153,7 +153,7 @@ ZK_HD Fp<P> fp_mul_inline(const Fp<P> &a, const Fp<P> &b) {
 // instruction cache and take hipcc tens of minutes to schedule).  Translation units that want the
 // product inlined (the NTT butterflies) leave ZK_NOINLINE_MUL undefined.
 template <class P>
-__host__ __device__ __noinline__ Fp<P> fp_mul_call(const Fp<P> &a, const Fp<P> &b) {
+ZK_NOINLINE_HD Fp<P> fp_mul_call(const Fp<P> &a, const Fp<P> &b) {
     return fp_mul_inline(a, b);
 }
 

@@ -136,7 +136,7 @@ ZK_HD Fu<U> fu_mul(const Fu<U> &a, const Fu<U> &b) {
 
 // out-of-line copy; operands by value so that they travel in VGPRs, not through scratch
 template <class U>
-__host__ __device__ __noinline__ Fu<U> fu_mul_call(Fu<U> a, Fu<U> b) {
+ZK_NOINLINE_HD Fu<U> fu_mul_call(Fu<U> a, Fu<U> b) {
     return fu_mul(a, b);
 }
 

@@ -138,6 +138,16 @@ __global__ __launch_bounds__(256) void groth16_h_pointwise(const uint32_t *__res
     fu_pack<U>(h + (size_t)i * U::NL, fu_canon(r));  // canonical Montgomery form of r, i.e. r itself as an integer mod p
 }
 
+// dst[j] = src[idx[j]] on 32-byte elements: the scalar side of a sparse query (B_query.indices)
+__global__ __launch_bounds__(256) void fr_gather(const uint4 *__restrict__ src, const uint32_t *__restrict__ idx, size_t count,
+                                                 uint4 *__restrict__ dst) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    size_t s = idx[j];
+    dst[2 * j] = src[2 * s];
+    dst[2 * j + 1] = src[2 * s + 1];
+}
+
 template <class U>
 __global__ void fr_zero_one(uint32_t *__restrict__ p) {
     if (blockIdx.x != 0 || threadIdx.x >= U::NL) return;
@@ -248,6 +258,15 @@ void zkhip_r1cs_free(zkhip_ctx *ctx, zkhip_r1cs *r) {
         (void)hipFree(r->long_rows[k]);
     }
     delete r;
+}
+
+int zkhip_fr_gather_dev(zkhip_ctx *ctx, const void *d_src, const void *d_indices, size_t count, void *d_dst) {
+    if (!ctx || (count && (!d_src || !d_indices || !d_dst))) return ZKHIP_ERR_INVALID;
+    if (count == 0) return ZKHIP_OK;
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ZK_LAUNCH(ctx, "fr_gather", fr_gather, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (const uint4 *)d_src, (const uint32_t *)d_indices,
+              count, (uint4 *)d_dst);
+    return ZKHIP_OK;
 }
 
 size_t zkhip_r1cs_domain_size(const zkhip_r1cs *r) { return r ? r->m : 0; }

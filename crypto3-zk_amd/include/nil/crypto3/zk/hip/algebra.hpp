@@ -1,0 +1,200 @@
+//---------------------------------------------------------------------------//
+// zkhip host-side value types for the header-only shim.
+//
+// In a crypto3 tree the curve / field value types come from crypto3-algebra
+// (`CurveType::scalar_field_type::value_type`, `CurveType::template g1_type<>::value_type`, ...).  That library
+// is not part of crypto3-zk, so the shim is written against the small `curve_adapter` concept below and ships a
+// self-contained implementation of it (`native_curve<ZKHIP_BLS12_381>`, `native_curve<ZKHIP_BN254>`), built on
+// the same field / group-law headers the HIP kernels are compiled from (csrc/fu.hpp, csrc/curve.hpp).  A
+// crypto3 maintainer specialises `curve_adapter<nil::crypto3::algebra::curves::bls12<381>>` with the four
+// conversion functions instead (INTEGRATION.md shows it).
+//
+// Everything that crosses into the C ABI is CANONICAL little-endian 64-bit limbs.
+//---------------------------------------------------------------------------//
+#ifndef ZKHIP_SHIM_ALGEBRA_HPP
+#define ZKHIP_SHIM_ALGEBRA_HPP
+
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#define ZK_NOINLINE_MUL 1
+#include "../../../../../csrc/curve.hpp"
+#include "../../../../../../include/zkhip.h"
+
+namespace nil {
+namespace crypto3 {
+namespace zk {
+namespace hip {
+
+namespace detail {
+    template <int Curve>
+    struct native_fields;
+    template <>
+    struct native_fields<ZKHIP_BLS12_381> {
+        typedef zkhip::bls_fru fr;
+        typedef zkhip::bls_fqu fq;
+        typedef zkhip::bls_fqu2 fq2;
+    };
+    template <>
+    struct native_fields<ZKHIP_BN254> {
+        typedef zkhip::bn_fru fr;
+        typedef zkhip::bn_fqu fq;
+        typedef zkhip::bn_fqu2 fq2;
+    };
+}    // namespace detail
+
+/// Scalar-field element: canonical integer in 4 x u64 limbs; the operators the prover's host glue needs
+/// (`r * s` at prover.hpp:153, comparisons with zero / one at knowledge_commitment_multiexp.hpp:88-90).
+template <int Curve>
+struct fr_value {
+    typedef typename detail::native_fields<Curve>::fr F;
+    std::array<std::uint64_t, 4> limbs {};
+
+    fr_value() = default;
+    fr_value(std::uint64_t v) { limbs[0] = v; }
+    static fr_value zero() { return fr_value(); }
+    static fr_value one() { return fr_value(1); }
+    bool is_zero() const { return (limbs[0] | limbs[1] | limbs[2] | limbs[3]) == 0; }
+    bool operator==(const fr_value &o) const { return limbs == o.limbs; }
+    bool operator!=(const fr_value &o) const { return !(*this == o); }
+
+    // u64 <-> u32 limb views go through memcpy (no type punning through pointers)
+    F mont() const {
+        alignas(16) std::uint32_t w[8];
+        std::memcpy(w, limbs.data(), 32);
+        return zkhip::FieldOps<F>::from_canonical(w);
+    }
+    static fr_value from_mont(const F &m) {
+        alignas(16) std::uint32_t w[8];
+        zkhip::FieldOps<F>::to_canonical(w, m);
+        fr_value r;
+        std::memcpy(r.limbs.data(), w, 32);
+        return r;
+    }
+    fr_value operator*(const fr_value &o) const { return from_mont(zkhip::FieldOps<F>::mul(mont(), o.mont())); }
+    fr_value operator+(const fr_value &o) const { return from_mont(zkhip::FieldOps<F>::add(mont(), o.mont())); }
+    fr_value operator-(const fr_value &o) const { return from_mont(zkhip::FieldOps<F>::template sub<zkhip::FieldOps<F>::K1>(mont(), o.mont())); }
+    fr_value inversed() const { return from_mont(zkhip::FieldOps<F>::inv(mont())); }
+};
+
+/// Group element in the 3-coordinate shape of the reference's `G::value_type` (held as XYZZ internally).
+/// `Coord` is the coordinate field (Fq for G1, Fq2 for G2), `Words64` the canonical u64 limbs per coordinate.
+template <int Curve, int Group>
+struct group_value {
+    typedef typename std::conditional<Group == ZKHIP_G1, typename detail::native_fields<Curve>::fq,
+                                      typename detail::native_fields<Curve>::fq2>::type F;
+    typedef zkhip::FieldOps<F> O;
+    static constexpr std::size_t coord_limbs = O::CANON_WORDS / 2;    // u64 limbs per coordinate
+    zkhip::XYZZ<F> p = zkhip::XYZZ<F>::infinity();
+
+    static group_value zero() { return group_value(); }
+    bool is_zero() const { return p.is_inf(); }
+
+    /// from canonical affine limbs (x | y) and an infinity flag
+    static group_value from_affine(const std::uint64_t *xy, bool infinity = false) {
+        group_value r;
+        if (!infinity) {
+            alignas(16) std::uint32_t w[2 * O::CANON_WORDS];
+            std::memcpy(w, xy, sizeof(w));
+            zkhip::Affine<F> a = {O::from_canonical(w), O::from_canonical(w + O::CANON_WORDS)};
+            r.p = zkhip::XYZZ<F>::from_affine(a);
+        }
+        return r;
+    }
+    /// from the C ABI's Jacobian result (X | Y | Z canonical)
+    static group_value from_jacobian(const std::uint64_t *xyz) {
+        alignas(16) std::uint32_t w[3 * O::CANON_WORDS];
+        std::memcpy(w, xyz, sizeof(w));
+        zkhip::Jacobian<F> j = {O::from_canonical(w), O::from_canonical(w + O::CANON_WORDS), O::from_canonical(w + 2 * O::CANON_WORDS)};
+        group_value r;
+        r.p = zkhip::xyzz_from_jacobian(j);
+        return r;
+    }
+    /// canonical affine limbs (x | y); returns false for the point at infinity (limbs zeroed)
+    bool to_affine(std::uint64_t *xy) const {
+        if (p.is_inf()) {
+            std::memset(xy, 0, 2 * coord_limbs * 8);
+            return false;
+        }
+        alignas(16) std::uint32_t w[2 * O::CANON_WORDS];
+        zkhip::Affine<F> a = zkhip::xyzz_to_affine(p);
+        O::to_canonical(w, a.x);
+        O::to_canonical(w + O::CANON_WORDS, a.y);
+        std::memcpy(xy, w, sizeof(w));
+        return true;
+    }
+    group_value operator+(const group_value &o) const {
+        group_value r;
+        r.p = zkhip::xyzz_add(p, o.p);
+        return r;
+    }
+    group_value operator-() const {
+        group_value r = *this;
+        if (!r.p.is_inf()) r.p.Y = O::template sub<O::K2>(F::zero(), r.p.Y);
+        return r;
+    }
+    group_value operator-(const group_value &o) const { return *this + (-o); }
+    /// scalar multiplication, double-and-add from the top bit (the handful of products at prover.hpp:142-155)
+    group_value operator*(const fr_value<Curve> &k) const {
+        group_value r;
+        for (int b = 255; b >= 0; --b) {
+            r.p = zkhip::xyzz_dbl(r.p);
+            if ((k.limbs[b >> 6] >> (b & 63)) & 1) r.p = zkhip::xyzz_add(r.p, p);
+        }
+        return r;
+    }
+    friend group_value operator*(const fr_value<Curve> &k, const group_value &g) { return g * k; }
+    bool operator==(const group_value &o) const {
+        std::vector<std::uint64_t> a(2 * coord_limbs), b(2 * coord_limbs);
+        bool ia = to_affine(a.data()), ib = o.to_affine(b.data());
+        return ia == ib && a == b;
+    }
+};
+
+/// The concept the shim is written against.  `native_curve<C>` is the self-contained model.
+template <int Curve>
+struct native_curve {
+    static constexpr int id = Curve;
+    typedef fr_value<Curve> scalar_value_type;
+    typedef group_value<Curve, ZKHIP_G1> g1_value_type;
+    typedef group_value<Curve, ZKHIP_G2> g2_value_type;
+};
+
+/// Adapter: how the shim reads canonical limbs out of / builds values of a curve's types.
+template <typename CurveType>
+struct curve_adapter;
+
+template <int Curve>
+struct curve_adapter<native_curve<Curve>> {
+    typedef native_curve<Curve> curve_type;
+    static constexpr int id = Curve;
+    typedef typename curve_type::scalar_value_type scalar_value_type;
+    typedef typename curve_type::g1_value_type g1_value_type;
+    typedef typename curve_type::g2_value_type g2_value_type;
+    static constexpr std::size_t g1_coord_limbs = g1_value_type::coord_limbs;
+    static constexpr std::size_t g2_coord_limbs = g2_value_type::coord_limbs;
+
+    static void scalar_to_limbs(const scalar_value_type &s, std::uint64_t *out) { std::memcpy(out, s.limbs.data(), 32); }
+    static scalar_value_type scalar_from_limbs(const std::uint64_t *in) {
+        scalar_value_type s;
+        std::memcpy(s.limbs.data(), in, 32);
+        return s;
+    }
+    template <typename G>
+    static bool point_to_affine_limbs(const G &p, std::uint64_t *out) { return p.to_affine(out); }
+    static g1_value_type g1_from_jacobian(const std::uint64_t *xyz) { return g1_value_type::from_jacobian(xyz); }
+    static g2_value_type g2_from_jacobian(const std::uint64_t *xyz) { return g2_value_type::from_jacobian(xyz); }
+};
+
+typedef native_curve<ZKHIP_BLS12_381> bls12_381;
+typedef native_curve<ZKHIP_BN254> alt_bn128_254;
+
+}    // namespace hip
+}    // namespace zk
+}    // namespace crypto3
+}    // namespace nil
+
+#endif    // ZKHIP_SHIM_ALGEBRA_HPP

@@ -1,0 +1,106 @@
+//---------------------------------------------------------------------------//
+// zkhip shim: RAII view of the C ABI (include/zkhip.h) for the header-only C++ classes that mirror the
+// reference's call sites.  Errors become std::runtime_error here, on the C++ side of the boundary (the ABI
+// itself never throws); the reference's own failure mode at these call sites is BOOST_ASSERT / one
+// std::runtime_error (kzg.hpp:167).
+//---------------------------------------------------------------------------//
+#ifndef ZKHIP_SHIM_BACKEND_HPP
+#define ZKHIP_SHIM_BACKEND_HPP
+
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "algebra.hpp"
+
+namespace nil {
+namespace crypto3 {
+namespace zk {
+namespace hip {
+
+inline void check(int rc, const char *what, const zkhip_ctx *ctx = nullptr) {
+    if (rc != ZKHIP_OK) {
+        std::string msg = std::string(what) + ": " + zkhip_strerror(rc);
+        if (ctx) msg += std::string(" [") + zkhip_last_error(ctx) + "]";
+        throw std::runtime_error(msg);
+    }
+}
+
+/// One context per GPU per process.  There is no CPU fallback: construction throws without a GPU.
+class context {
+public:
+    explicit context(int device = 0) {
+        check(zkhip_init(device, &ctx_), "zkhip_init");
+    }
+    ~context() { zkhip_destroy(ctx_); }
+    context(const context &) = delete;
+    context &operator=(const context &) = delete;
+    zkhip_ctx *get() const { return ctx_; }
+    void sync() const { check(zkhip_sync(ctx_), "zkhip_sync", ctx_); }
+
+    /// device buffer of `bytes` bytes, freed with the returned handle
+    std::shared_ptr<void> alloc(std::size_t bytes) const {
+        void *p = nullptr;
+        check(zkhip_malloc(ctx_, bytes, &p), "zkhip_malloc", ctx_);
+        zkhip_ctx *c = ctx_;
+        return std::shared_ptr<void>(p, [c](void *q) { zkhip_free(c, q); });
+    }
+    void h2d(void *dst, const void *src, std::size_t bytes) const { check(zkhip_memcpy_h2d(ctx_, dst, src, bytes), "zkhip_memcpy_h2d", ctx_); }
+    void d2h(void *dst, const void *src, std::size_t bytes) const { check(zkhip_memcpy_d2h(ctx_, dst, src, bytes), "zkhip_memcpy_d2h", ctx_); }
+
+private:
+    zkhip_ctx *ctx_ = nullptr;
+};
+
+/// Resident bases (a proving-key query or an SRS): uploaded once, reused for every proof / commitment.
+template <typename CurveType, int Group>
+class device_bases {
+public:
+    typedef curve_adapter<CurveType> adapter;
+    device_bases() = default;
+    /// from a range of group values (G::value_type of the reference; here adapter point types)
+    template <typename InputIt>
+    device_bases(const context &ctx, InputIt first, InputIt last) : ctx_(&ctx) {
+        const std::size_t cl = Group == ZKHIP_G1 ? adapter::g1_coord_limbs : adapter::g2_coord_limbs;
+        std::vector<std::uint64_t> xy;
+        std::vector<std::uint8_t> inf;
+        for (InputIt it = first; it != last; ++it) {
+            xy.resize(xy.size() + 2 * cl);
+            inf.push_back(adapter::point_to_affine_limbs(*it, xy.data() + xy.size() - 2 * cl) ? 0 : 1);
+        }
+        size_ = inf.size();
+        check(zkhip_bases_upload(ctx.get(), adapter::id, Group, xy.data(), inf.data(), size_, &b_), "zkhip_bases_upload", ctx.get());
+    }
+    ~device_bases() {
+        if (b_) zkhip_bases_free(ctx_ ? ctx_->get() : nullptr, b_);
+    }
+    device_bases(device_bases &&o) noexcept : ctx_(o.ctx_), b_(o.b_), size_(o.size_) { o.b_ = nullptr; }
+    device_bases &operator=(device_bases &&o) noexcept {
+        if (this != &o) {
+            if (b_) zkhip_bases_free(ctx_ ? ctx_->get() : nullptr, b_);
+            ctx_ = o.ctx_;
+            b_ = o.b_;
+            size_ = o.size_;
+            o.b_ = nullptr;
+        }
+        return *this;
+    }
+    device_bases(const device_bases &) = delete;
+    device_bases &operator=(const device_bases &) = delete;
+    const zkhip_bases *get() const { return b_; }
+    std::size_t size() const { return size_; }
+
+private:
+    const context *ctx_ = nullptr;
+    zkhip_bases *b_ = nullptr;
+    std::size_t size_ = 0;
+};
+
+}    // namespace hip
+}    // namespace zk
+}    // namespace crypto3
+}    // namespace nil
+
+#endif    // ZKHIP_SHIM_BACKEND_HPP

@@ -1,0 +1,83 @@
+//---------------------------------------------------------------------------//
+// zkhip shim: KZG commitment of polynomials given in evaluation (DFS) form, on the MI355X.
+//
+// Mirrors zk/commitments/polynomial/kzg.hpp:
+//   params_type { commitment_key = { alpha^i * G1 } }                      (:262-290)
+//   commit_one<KZG>(params, polynomial_dfs)  = multiexp(ck, p.coefficients()) (:427-435: iNTT then MSM, chunks = 1)
+//   kzg_commitment_scheme[_v2]::commit(batch) loops commit_one over the batch (:748-765, kzg_v2.hpp:208-226)
+// Here the whole batch is transformed by ONE batched inverse NTT and the coefficient vectors never leave HBM:
+// each column's MSM reads them in place against the resident SRS.
+//---------------------------------------------------------------------------//
+#ifndef ZKHIP_SHIM_KZG_HPP
+#define ZKHIP_SHIM_KZG_HPP
+
+#include <vector>
+
+#include "multiexp.hpp"
+
+namespace nil {
+namespace crypto3 {
+namespace zk {
+namespace hip {
+
+/// math::polynomial_dfs as far as the commitment layer reads it: evaluations over the size()-point domain.
+template <typename CurveType>
+struct polynomial_dfs {
+    std::vector<typename curve_adapter<CurveType>::scalar_value_type> values;
+    std::size_t size() const { return values.size(); }
+};
+
+/// kzg::params_type with the commitment key resident on the device.
+template <typename CurveType>
+struct kzg_params_hip {
+    typedef multiexp_method_hip multiexp_method;    // shadows kzg.hpp:82's BDLO12 typedef
+    template <typename InputIt>
+    kzg_params_hip(const context &ctx, InputIt ck_first, InputIt ck_last) : ctx(ctx), commitment_key(ctx, ck_first, ck_last) { }
+    const context &ctx;
+    device_bases<CurveType, ZKHIP_G1> commitment_key;
+};
+
+/// commit(batch): one commitment per polynomial; all polynomials must have the same power-of-two size
+/// n <= commitment_key.size().  `omega` is the primitive n-th root of the polynomials' evaluation domain.
+template <typename CurveType>
+std::vector<typename curve_adapter<CurveType>::g1_value_type>
+    kzg_commit_batch(const kzg_params_hip<CurveType> &params, const std::vector<polynomial_dfs<CurveType>> &polys,
+                     const typename curve_adapter<CurveType>::scalar_value_type &omega) {
+    typedef curve_adapter<CurveType> adapter;
+    std::vector<typename adapter::g1_value_type> out;
+    if (polys.empty()) return out;
+    const context &ctx = params.ctx;
+    const std::size_t n = polys[0].size(), batch = polys.size();
+    std::size_t log_n = 0;
+    while (((std::size_t)1 << log_n) < n) ++log_n;
+    if (((std::size_t)1 << log_n) != n || n > params.commitment_key.size()) throw std::runtime_error("kzg_commit_batch: bad polynomial size");
+    std::vector<std::uint64_t> host(4 * n * batch);
+    for (std::size_t b = 0; b < batch; ++b) {
+        if (polys[b].size() != n) throw std::runtime_error("kzg_commit_batch: ragged batch");
+        for (std::size_t i = 0; i < n; ++i) adapter::scalar_to_limbs(polys[b].values[i], &host[4 * (b * n + i)]);
+    }
+    auto d = ctx.alloc(host.size() * 8);
+    ctx.h2d(d.get(), host.data(), host.size() * 8);
+    std::uint64_t w[4];
+    adapter::scalar_to_limbs(omega, w);
+    /* p.coefficients() for every polynomial of the batch (kzg.hpp:431) */
+    check(zkhip_ntt_dev(ctx.get(), adapter::id, d.get(), log_n, batch, w, 1, nullptr), "zkhip_ntt_dev", ctx.get());
+    /* multiexp<multiexp_method>(commitment_key[0 .. n), coefficients, 1) (kzg.hpp:433-434) */
+    for (std::size_t b = 0; b < batch; ++b)
+        out.push_back(multiexp_dev<CurveType, ZKHIP_G1>(ctx, params.commitment_key, 0, n, static_cast<const char *>(d.get()) + 32 * b * n));
+    return out;
+}
+
+/// commit_one<KZG>(params, polynomial_dfs)
+template <typename CurveType>
+typename curve_adapter<CurveType>::g1_value_type commit_one(const kzg_params_hip<CurveType> &params, const polynomial_dfs<CurveType> &poly,
+                                                            const typename curve_adapter<CurveType>::scalar_value_type &omega) {
+    return kzg_commit_batch<CurveType>(params, std::vector<polynomial_dfs<CurveType>> {poly}, omega)[0];
+}
+
+}    // namespace hip
+}    // namespace zk
+}    // namespace crypto3
+}    // namespace nil
+
+#endif    // ZKHIP_SHIM_KZG_HPP

@@ -1,0 +1,97 @@
+//---------------------------------------------------------------------------//
+// zkhip shim: drop-in for algebra::multiexp<Method>(bases_begin, bases_end, scalars_begin, scalars_end, chunks)
+// and algebra::multiexp_with_mixed_addition<Method>(...) as the reference calls them at
+//   zk/snark/systems/ppzksnark/r1cs_gg_ppzksnark/prover.hpp:108-139
+//   zk/commitments/polynomial/kzg.hpp:143-148, 409-435, 505-508
+//   zk/commitments/polynomial/knowledge_commitment_multiexp.hpp:107
+// Same argument order and meaning; `chunks` is accepted and ignored (the device splits the work itself).
+// `multiexp_method_hip` is the policy tag a KZG parameter struct shadows `multiexp_method` with
+// (kzg.hpp:82,231 declare `using multiexp_method = ...BDLO12` and use it as `typename KZG::multiexp_method`).
+//---------------------------------------------------------------------------//
+#ifndef ZKHIP_SHIM_MULTIEXP_HPP
+#define ZKHIP_SHIM_MULTIEXP_HPP
+
+#include <iterator>
+#include <vector>
+
+#include "backend.hpp"
+
+namespace nil {
+namespace crypto3 {
+namespace zk {
+namespace hip {
+
+struct multiexp_method_hip { };
+
+namespace detail {
+    template <typename CurveType, typename ScalarIt>
+    std::vector<std::uint64_t> pack_scalars(ScalarIt first, ScalarIt last) {
+        std::vector<std::uint64_t> out;
+        for (ScalarIt it = first; it != last; ++it) {
+            out.resize(out.size() + 4);
+            curve_adapter<CurveType>::scalar_to_limbs(*it, out.data() + out.size() - 4);
+        }
+        return out;
+    }
+    template <typename CurveType, int Group>
+    struct jac_result;
+    template <typename CurveType>
+    struct jac_result<CurveType, ZKHIP_G1> {
+        typedef typename curve_adapter<CurveType>::g1_value_type type;
+        static constexpr std::size_t limbs = 3 * curve_adapter<CurveType>::g1_coord_limbs;
+        static type make(const std::uint64_t *j) { return curve_adapter<CurveType>::g1_from_jacobian(j); }
+    };
+    template <typename CurveType>
+    struct jac_result<CurveType, ZKHIP_G2> {
+        typedef typename curve_adapter<CurveType>::g2_value_type type;
+        static constexpr std::size_t limbs = 3 * curve_adapter<CurveType>::g2_coord_limbs;
+        static type make(const std::uint64_t *j) { return curve_adapter<CurveType>::g2_from_jacobian(j); }
+    };
+}    // namespace detail
+
+/// sum scalars[i] * bases[offset + i] over resident bases, scalars on the host.
+template <typename CurveType, int Group, typename ScalarIt>
+typename detail::jac_result<CurveType, Group>::type multiexp(const context &ctx, const device_bases<CurveType, Group> &bases, std::size_t offset,
+                                                             ScalarIt scalars_begin, ScalarIt scalars_end, std::size_t /*chunks*/ = 1) {
+    typedef detail::jac_result<CurveType, Group> R;
+    std::vector<std::uint64_t> s = detail::pack_scalars<CurveType>(scalars_begin, scalars_end);
+    std::uint64_t jac[R::limbs];
+    check(zkhip_msm(ctx.get(), bases.get(), offset, s.size() / 4, s.data(), jac), "zkhip_msm", ctx.get());
+    return R::make(jac);
+}
+
+/// Same over scalars already resident on the device (n elements at d_scalars).
+template <typename CurveType, int Group>
+typename detail::jac_result<CurveType, Group>::type multiexp_dev(const context &ctx, const device_bases<CurveType, Group> &bases, std::size_t offset,
+                                                                 std::size_t n, const void *d_scalars) {
+    typedef detail::jac_result<CurveType, Group> R;
+    auto d_out = ctx.alloc(R::limbs * 8);
+    check(zkhip_msm_dev(ctx.get(), bases.get(), offset, n, d_scalars, d_out.get()), "zkhip_msm_dev", ctx.get());
+    std::uint64_t jac[R::limbs];
+    ctx.d2h(jac, d_out.get(), sizeof(jac));
+    return R::make(jac);
+}
+
+/// The reference's one-shot signature: bases given as an iterator range of group values (uploaded for this call).
+template <typename Method, typename CurveType, int Group, typename BaseIt, typename ScalarIt>
+typename detail::jac_result<CurveType, Group>::type multiexp(const context &ctx, BaseIt bases_begin, BaseIt bases_end, ScalarIt scalars_begin,
+                                                             ScalarIt scalars_end, std::size_t chunks = 1) {
+    device_bases<CurveType, Group> b(ctx, bases_begin, bases_end);
+    return multiexp<CurveType, Group>(ctx, b, 0, scalars_begin, scalars_end, chunks);
+}
+
+/// multiexp_with_mixed_addition peels scalars 0 and 1 before the bucket method (prover.hpp:108-114); the device
+/// path needs no peeling (0 -> no digit, 1 -> one bucket hit), so this is the same call.
+template <typename Method, typename CurveType, int Group, typename BaseIt, typename ScalarIt>
+typename detail::jac_result<CurveType, Group>::type multiexp_with_mixed_addition(const context &ctx, BaseIt bases_begin, BaseIt bases_end,
+                                                                                 ScalarIt scalars_begin, ScalarIt scalars_end,
+                                                                                 std::size_t chunks = 1) {
+    return multiexp<Method, CurveType, Group>(ctx, bases_begin, bases_end, scalars_begin, scalars_end, chunks);
+}
+
+}    // namespace hip
+}    // namespace zk
+}    // namespace crypto3
+}    // namespace nil
+
+#endif    // ZKHIP_SHIM_MULTIEXP_HPP

@@ -1,0 +1,310 @@
+//---------------------------------------------------------------------------//
+// zkhip shim: Groth16 prover with the reference's interface, MSM and NTT on the MI355X.
+//
+// Mirrors (same member names, same argument meaning):
+//   r1cs_constraint_system / r1cs_constraint / linear_combination
+//        zk/snark/arithmetization/constraint_satisfaction_problems/r1cs.hpp:61-64, 125-133
+//   r1cs_gg_ppzksnark_proving_key         .../r1cs_gg_ppzksnark/proving_key.hpp:43-56
+//   r1cs_gg_ppzksnark_proof               .../r1cs_gg_ppzksnark/proof.hpp:41-46
+//   reductions::r1cs_to_qap::witness_map  zk/snark/reductions/r1cs_to_qap.hpp:219-325
+//   r1cs_gg_ppzksnark_prover::process     .../r1cs_gg_ppzksnark/prover.hpp:73-158
+// `r1cs_gg_ppzksnark_prover_hip<CurveType>::process(pk, primary_input, auxiliary_input)` has the reference's
+// static signature; the facade `r1cs_gg_ppzksnark<...>` insists on the exact reference prover type
+// (r1cs_gg_ppzksnark.hpp:50-59, 112-115), so the sibling class is called directly.
+// The overload taking (r, s) makes proofs reproducible; the three-argument form draws them at random exactly
+// like prover.hpp:92-93.
+//---------------------------------------------------------------------------//
+#ifndef ZKHIP_SHIM_R1CS_GG_PPZKSNARK_HPP
+#define ZKHIP_SHIM_R1CS_GG_PPZKSNARK_HPP
+
+#include <algorithm>
+#include <random>
+#include <utility>
+#include <vector>
+
+#include "multiexp.hpp"
+
+namespace nil {
+namespace crypto3 {
+namespace zk {
+namespace hip {
+
+// ---- arithmetization (r1cs.hpp) --------------------------------------------------------------------------
+template <typename CurveType>
+struct linear_term {
+    std::size_t index;    // 0 = the constant one, j >= 1 = variable j - 1
+    typename curve_adapter<CurveType>::scalar_value_type coeff;
+};
+
+template <typename CurveType>
+struct linear_combination {
+    typedef typename curve_adapter<CurveType>::scalar_value_type value_type;
+    std::vector<linear_term<CurveType>> terms;
+    void add_term(std::size_t index, const value_type &coeff) { terms.push_back({index, coeff}); }
+    void add_term(std::size_t index, std::uint64_t coeff) { terms.push_back({index, value_type(coeff)}); }
+    /// sum_j coeff_j * assignment[index_j - 1]  (r1cs.hpp `evaluate`; host reference path, used by is_satisfied)
+    value_type evaluate(const std::vector<value_type> &assignment) const {
+        value_type acc = value_type::zero();
+        for (const auto &t : terms) acc = acc + t.coeff * (t.index == 0 ? value_type::one() : assignment[t.index - 1]);
+        return acc;
+    }
+};
+
+template <typename CurveType>
+struct r1cs_constraint {
+    linear_combination<CurveType> a, b, c;
+};
+
+template <typename CurveType>
+struct r1cs_constraint_system {
+    typedef typename curve_adapter<CurveType>::scalar_value_type value_type;
+    std::size_t primary_input_size = 0;
+    std::size_t auxiliary_input_size = 0;
+    std::vector<r1cs_constraint<CurveType>> constraints;
+
+    std::size_t num_inputs() const { return primary_input_size; }
+    std::size_t num_variables() const { return primary_input_size + auxiliary_input_size; }
+    std::size_t num_constraints() const { return constraints.size(); }
+    void add_constraint(const r1cs_constraint<CurveType> &c) { constraints.emplace_back(c); }
+    bool is_satisfied(const std::vector<value_type> &primary_input, const std::vector<value_type> &auxiliary_input) const {
+        std::vector<value_type> full(primary_input);
+        full.insert(full.end(), auxiliary_input.begin(), auxiliary_input.end());
+        for (const auto &c : constraints)
+            if (c.a.evaluate(full) * c.b.evaluate(full) != c.c.evaluate(full)) return false;
+        return true;
+    }
+};
+
+// ---- proving key / proof (proving_key.hpp, proof.hpp, knowledge_commitment.hpp) ---------------------------
+template <typename CurveType>
+struct element_kc {    // element_knowledge_commitment.hpp:54-59
+    typename curve_adapter<CurveType>::g2_value_type g;
+    typename curve_adapter<CurveType>::g1_value_type h;
+};
+
+template <typename CurveType>
+struct knowledge_commitment_vector {    // container::sparse_vector of (g, h) pairs
+    std::vector<std::size_t> indices;
+    std::vector<element_kc<CurveType>> values;
+    std::size_t domain_size_ = 0;
+};
+
+template <typename CurveType>
+struct r1cs_gg_ppzksnark_proving_key {
+    typedef curve_adapter<CurveType> adapter;
+    typename adapter::g1_value_type alpha_g1, beta_g1;
+    typename adapter::g2_value_type beta_g2;
+    typename adapter::g1_value_type delta_g1;
+    typename adapter::g2_value_type delta_g2;
+    std::vector<typename adapter::g1_value_type> A_query;
+    knowledge_commitment_vector<CurveType> B_query;
+    std::vector<typename adapter::g1_value_type> H_query;
+    std::vector<typename adapter::g1_value_type> L_query;
+    r1cs_constraint_system<CurveType> constraint_system;
+};
+
+template <typename CurveType>
+struct r1cs_gg_ppzksnark_proof {
+    typename curve_adapter<CurveType>::g1_value_type g_A;
+    typename curve_adapter<CurveType>::g2_value_type g_B;
+    typename curve_adapter<CurveType>::g1_value_type g_C;
+};
+
+// ---- device-resident constraint system -------------------------------------------------------------------
+template <typename CurveType>
+class device_r1cs {
+public:
+    typedef curve_adapter<CurveType> adapter;
+    device_r1cs(const context &ctx, const r1cs_constraint_system<CurveType> &cs) : ctx_(&ctx) {
+        std::vector<std::uint32_t> rp[3], cl[3];
+        std::vector<std::uint64_t> cf[3];
+        for (int k = 0; k < 3; ++k) rp[k].push_back(0);
+        for (const auto &c : cs.constraints) {
+            const linear_combination<CurveType> *lc[3] = {&c.a, &c.b, &c.c};
+            for (int k = 0; k < 3; ++k) {
+                for (const auto &t : lc[k]->terms) {
+                    cl[k].push_back((std::uint32_t)t.index);
+                    cf[k].resize(cf[k].size() + 4);
+                    adapter::scalar_to_limbs(t.coeff, cf[k].data() + cf[k].size() - 4);
+                }
+                rp[k].push_back((std::uint32_t)cl[k].size());
+            }
+        }
+        check(zkhip_r1cs_upload(ctx.get(), adapter::id, cs.num_constraints(), cs.num_inputs(), cs.num_variables(), rp[0].data(), cl[0].data(),
+                                cf[0].data(), rp[1].data(), cl[1].data(), cf[1].data(), rp[2].data(), cl[2].data(), cf[2].data(), &r_),
+              "zkhip_r1cs_upload", ctx.get());
+    }
+    ~device_r1cs() { zkhip_r1cs_free(ctx_->get(), r_); }
+    device_r1cs(const device_r1cs &) = delete;
+    device_r1cs &operator=(const device_r1cs &) = delete;
+    const zkhip_r1cs *get() const { return r_; }
+    std::size_t domain_size() const { return zkhip_r1cs_domain_size(r_); }
+
+private:
+    const context *ctx_;
+    zkhip_r1cs *r_ = nullptr;
+};
+
+/// The evaluation-domain constants the reference takes from crypto3-algebra / crypto3-math
+/// (`arithmetic_params<F>::multiplicative_generator`, the root of unity make_evaluation_domain picks).
+template <typename CurveType>
+struct domain_params {
+    typename curve_adapter<CurveType>::scalar_value_type omega;             // primitive m-th root of unity
+    typename curve_adapter<CurveType>::scalar_value_type coset_generator;    // multiplicative generator
+};
+
+// ---- reductions::r1cs_to_qap<F>::witness_map on the device ---------------------------------------------------
+template <typename CurveType>
+struct r1cs_to_qap_hip {
+    typedef curve_adapter<CurveType> adapter;
+    typedef typename adapter::scalar_value_type value_type;
+
+    /// coefficients_for_H (m + 1 elements) left RESIDENT on the device; `d_assignment` receives (1, x, w).
+    static std::shared_ptr<void> witness_map(const context &ctx, const device_r1cs<CurveType> &cs, const domain_params<CurveType> &dom,
+                                             const std::vector<value_type> &primary_input, const std::vector<value_type> &auxiliary_input,
+                                             std::shared_ptr<void> &d_assignment) {
+        const std::size_t N = primary_input.size() + auxiliary_input.size(), m = cs.domain_size();
+        std::vector<std::uint64_t> z(4 * (N + 1), 0);
+        z[0] = 1;
+        std::size_t k = 1;
+        for (const auto &v : primary_input) adapter::scalar_to_limbs(v, &z[4 * k++]);
+        for (const auto &v : auxiliary_input) adapter::scalar_to_limbs(v, &z[4 * k++]);
+        d_assignment = ctx.alloc(z.size() * 8);
+        ctx.h2d(d_assignment.get(), z.data(), z.size() * 8);
+        auto d_h = ctx.alloc((m + 1) * 32);
+        auto d_scratch = ctx.alloc(zkhip_groth16_scratch_bytes(cs.get()));
+        std::uint64_t w[4], g[4];
+        adapter::scalar_to_limbs(dom.omega, w);
+        adapter::scalar_to_limbs(dom.coset_generator, g);
+        check(zkhip_groth16_witness_h_dev(ctx.get(), cs.get(), d_assignment.get(), w, g, d_h.get(), d_scratch.get()),
+              "zkhip_groth16_witness_h_dev", ctx.get());
+        ctx.sync();    // d_scratch is released on return
+        return d_h;
+    }
+    /// host copy of the same (the reference's return value, qap_witness::coefficients_for_H)
+    static std::vector<value_type> witness_map_host(const context &ctx, const device_r1cs<CurveType> &cs, const domain_params<CurveType> &dom,
+                                                    const std::vector<value_type> &primary_input,
+                                                    const std::vector<value_type> &auxiliary_input) {
+        std::shared_ptr<void> d_z;
+        auto d_h = witness_map(ctx, cs, dom, primary_input, auxiliary_input, d_z);
+        const std::size_t m = cs.domain_size();
+        std::vector<std::uint64_t> raw(4 * (m + 1));
+        ctx.d2h(raw.data(), d_h.get(), raw.size() * 8);
+        std::vector<value_type> out;
+        for (std::size_t i = 0; i <= m; ++i) out.push_back(adapter::scalar_from_limbs(&raw[4 * i]));
+        return out;
+    }
+};
+
+// ---- proving key with its device-resident queries -------------------------------------------------------------
+template <typename CurveType>
+class r1cs_gg_ppzksnark_proving_key_hip {
+public:
+    typedef curve_adapter<CurveType> adapter;
+    typedef r1cs_gg_ppzksnark_proving_key<CurveType> host_key_type;
+
+    /// Uploads the four queries and the constraint system once; proofs then only move the assignment.
+    r1cs_gg_ppzksnark_proving_key_hip(const context &ctx, const host_key_type &pk, const domain_params<CurveType> &dom) :
+        ctx(ctx), host(pk), domain(dom), A_query(ctx, pk.A_query.begin(), pk.A_query.end()), H_query(ctx, pk.H_query.begin(), pk.H_query.end()),
+        L_query(ctx, pk.L_query.begin(), pk.L_query.end()), constraint_system(ctx, pk.constraint_system) {
+        std::vector<typename adapter::g2_value_type> g;
+        std::vector<typename adapter::g1_value_type> h;
+        std::vector<std::uint32_t> idx;
+        for (std::size_t i = 0; i < pk.B_query.values.size(); ++i) {
+            g.push_back(pk.B_query.values[i].g);
+            h.push_back(pk.B_query.values[i].h);
+            idx.push_back((std::uint32_t)pk.B_query.indices[i]);
+        }
+        B_query_g = device_bases<CurveType, ZKHIP_G2>(ctx, g.begin(), g.end());
+        B_query_h = device_bases<CurveType, ZKHIP_G1>(ctx, h.begin(), h.end());
+        d_B_indices = ctx.alloc(std::max<std::size_t>(1, idx.size()) * 4);
+        if (!idx.empty()) ctx.h2d(d_B_indices.get(), idx.data(), idx.size() * 4);
+        B_count = idx.size();
+    }
+
+    const context &ctx;
+    const host_key_type &host;
+    domain_params<CurveType> domain;
+    device_bases<CurveType, ZKHIP_G1> A_query, H_query, L_query, B_query_h;
+    device_bases<CurveType, ZKHIP_G2> B_query_g;
+    device_r1cs<CurveType> constraint_system;
+    std::shared_ptr<void> d_B_indices;
+    std::size_t B_count = 0;
+};
+
+// ---- r1cs_gg_ppzksnark_prover<CurveType, basic>::process -------------------------------------------------------
+template <typename CurveType>
+class r1cs_gg_ppzksnark_prover_hip {
+    typedef curve_adapter<CurveType> adapter;
+
+public:
+    typedef typename adapter::scalar_value_type scalar_value_type;
+    typedef std::vector<scalar_value_type> primary_input_type;
+    typedef std::vector<scalar_value_type> auxiliary_input_type;
+    typedef r1cs_gg_ppzksnark_proving_key_hip<CurveType> proving_key_type;
+    typedef r1cs_gg_ppzksnark_proof<CurveType> proof_type;
+
+    static proof_type process(const proving_key_type &proving_key, const primary_input_type &primary_input,
+                              const auxiliary_input_type &auxiliary_input) {
+        /* Choose two random field elements for prover zero-knowledge (prover.hpp:92-93). */
+        return process(proving_key, primary_input, auxiliary_input, random_scalar(), random_scalar());
+    }
+
+    static proof_type process(const proving_key_type &pk, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input,
+                              const scalar_value_type &r, const scalar_value_type &s) {
+        const context &ctx = pk.ctx;
+        const std::size_t num_inputs = primary_input.size();
+        const std::size_t num_variables = primary_input.size() + auxiliary_input.size();
+        const std::size_t degree = pk.constraint_system.domain_size();
+
+        /* qap_wit.coefficients_for_H, and const_padded_assignment = (1, x, w), both resident (prover.hpp:79-106) */
+        std::shared_ptr<void> d_cpa;
+        std::shared_ptr<void> d_h =
+            r1cs_to_qap_hip<CurveType>::witness_map(ctx, pk.constraint_system, pk.domain, primary_input, auxiliary_input, d_cpa);
+        const char *cpa = static_cast<const char *>(d_cpa.get());
+
+        /* evaluation_At (prover.hpp:108-114) */
+        auto evaluation_At = multiexp_dev<CurveType, ZKHIP_G1>(ctx, pk.A_query, 0, num_variables + 1, cpa);
+        /* evaluation_Bt: kc_multiexp_with_mixed_addition over the sparse (G2, G1) query (prover.hpp:116-123) */
+        auto d_bs = ctx.alloc(std::max<std::size_t>(1, pk.B_count) * 32);
+        check(zkhip_fr_gather_dev(ctx.get(), cpa, pk.d_B_indices.get(), pk.B_count, d_bs.get()), "zkhip_fr_gather_dev", ctx.get());
+        auto evaluation_Bt_g = multiexp_dev<CurveType, ZKHIP_G2>(ctx, pk.B_query_g, 0, pk.B_count, d_bs.get());
+        auto evaluation_Bt_h = multiexp_dev<CurveType, ZKHIP_G1>(ctx, pk.B_query_h, 0, pk.B_count, d_bs.get());
+        /* evaluation_Ht over H_query[0 .. degree - 1) (prover.hpp:125-131) */
+        auto evaluation_Ht = multiexp_dev<CurveType, ZKHIP_G1>(ctx, pk.H_query, 0, degree - 1, d_h.get());
+        /* evaluation_Lt over the auxiliary part of the assignment (prover.hpp:133-139) */
+        auto evaluation_Lt = multiexp_dev<CurveType, ZKHIP_G1>(ctx, pk.L_query, 0, num_variables - num_inputs, cpa + 32 * (num_inputs + 1));
+
+        const auto &k = pk.host;
+        /* A = alpha + sum_i(a_i*A_i(t)) + r*delta */
+        auto g1_A = k.alpha_g1 + evaluation_At + r * k.delta_g1;
+        /* B = beta + sum_i(a_i*B_i(t)) + s*delta */
+        auto g1_B = k.beta_g1 + evaluation_Bt_h + s * k.delta_g1;
+        auto g2_B = k.beta_g2 + evaluation_Bt_g + s * k.delta_g2;
+        /* C = sum_i(a_i*((beta*A_i(t) + alpha*B_i(t) + C_i(t)) + H(t)*Z(t))/delta) + A*s + r*b - r*s*delta */
+        auto g1_C = evaluation_Ht + evaluation_Lt + s * g1_A + r * g1_B - (r * s) * k.delta_g1;
+        return proof_type {g1_A, g2_B, g1_C};
+    }
+
+private:
+    static scalar_value_type random_scalar() {
+        static std::random_device rd;
+        static std::mt19937_64 gen(rd());
+        // uniform via two products: (a * b + c) of independent 255-bit draws reduced by the field arithmetic
+        std::uint64_t w[4];
+        auto draw = [&]() {
+            for (auto &x : w) x = gen();
+            w[3] &= 0x0fffffffffffffffULL;    // < 2^252 < r for both curves: already canonical
+            return adapter::scalar_from_limbs(w);
+        };
+        scalar_value_type a = draw(), b = draw(), c = draw();
+        return a * b + c;
+    }
+};
+
+}    // namespace hip
+}    // namespace zk
+}    // namespace crypto3
+}    // namespace nil
+
+#endif    // ZKHIP_SHIM_R1CS_GG_PPZKSNARK_HPP

@@ -125,6 +125,11 @@ size_t zkhip_groth16_scratch_bytes(const zkhip_r1cs *r);
 int zkhip_groth16_witness_h_dev(zkhip_ctx *ctx, const zkhip_r1cs *r, const void *d_assignment, const uint64_t *omega,
                                 const uint64_t *coset_gen, void *d_h, void *d_scratch);
 
+/* d_dst[j] = d_src[d_indices[j]] on Fr elements (u32 indices): gathers the scalars of a sparse query, i.e. the
+ * `*(scalar_start + scalar_position)` walk over vec.indices of kc_multiexp_with_mixed_addition
+ * (knowledge_commitment_multiexp.hpp:66-100).  Zero and one scalars need no peeling on the device. */
+int zkhip_fr_gather_dev(zkhip_ctx *ctx, const void *d_src, const void *d_indices, size_t count, void *d_dst);
+
 /* ---- profiling (HIP events on the context's stream around every kernel launch) ------------------ */
 int zkhip_profile_enable(zkhip_ctx *ctx, int on);
 int zkhip_profile_reset(zkhip_ctx *ctx);

@@ -1,0 +1,97 @@
+"""End-to-end through the header-only C++ shim that mirrors the reference's interfaces
+(crypto3-zk_amd/include/nil/crypto3/zk/hip/): r1cs_gg_ppzksnark_prover_hip::process and the batched KZG commit,
+driven with inputs from the oracle and compared bit-for-bit with the oracle's proof / commitments.
+BASELINE config 1 (Groth16 on alt_bn128, 2^10 constraints) runs here with the MSM / NTT on the GPU."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import cport as cp
+import pyoracle as po
+from util import CURVES, fr_arr, limbs, pt_limbs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def shim():
+    so = os.path.join(ROOT, "tests", "cpp", "libshimtest.so")
+    src = os.path.join(ROOT, "tests", "cpp", "shim_test.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")])
+    return ctypes.CDLL(so)
+
+
+_KEEP = []
+
+
+def P(a):
+    a = np.ascontiguousarray(a)
+    _KEEP.append(a)  # ctypes pointers do not own the array: keep temporaries alive for the call
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+@pytest.mark.parametrize("curve,M,n", [(1, 1024, 10), (0, 1024, 10), (0, 100, 10)])
+def test_groth16_prover_shim(shim, curve, M, n):
+    C = CURVES[curve]
+    g = cp.Groth16(curve, M, n, seed=1)
+    w = limbs(C.root_of_unity(g.log_m), 4)
+    gen = limbs(C.fr_generator, 4)
+    rng = po.SplitMix64(2024)
+    trap = fr_arr([rng.next_mod(C.r) for _ in range(5)])
+    r_, s_ = limbs(rng.next_mod(C.r), 4), limbs(rng.next_mod(C.r), 4)
+    g.keygen(trap, w)
+    expected = g.prove(r_, s_, w, gen, chunks=cp.num_threads())
+    csr = [g.csr(k) for k in range(3)]
+    aq, ainf = g.query(0)
+    bh, bhinf = g.query(1)
+    bg, bginf = g.query(2)
+    hq, _ = g.query(3)
+    lq, _ = g.query(4)
+    f1, _ = g.query(5)
+    f2, _ = g.query(6)
+    assert (bhinf == bginf).all()
+    proof = np.zeros_like(expected)
+    args = []
+    for rp, cl, cf in csr:
+        args += [P(rp), P(cl), P(cf)]
+    rc = shim.shim_groth16_prove(curve, ctypes.c_size_t(g.M), ctypes.c_size_t(g.n), ctypes.c_size_t(g.N), *args, P(aq), P(ainf), P(bg), P(bh),
+                                 P(bhinf), P(hq), ctypes.c_size_t(g.m - 1), P(lq), P(f1), P(f2), P(g.assignment()), P(w), P(gen), P(r_), P(s_),
+                                 P(proof))
+    assert rc == 0
+    assert (proof == expected).all()
+    if M == 100:
+        # and against the trapdoor identity, independently of both implementations' MSM / NTT
+        cs, prim, aux = po.r1cs_example_field_input(C.r, M, n, seed=1)
+        rng = po.SplitMix64(2024)
+        tr = [rng.next_mod(C.r) for _ in range(5)]
+        rr, ss = rng.next_mod(C.r), rng.next_mod(C.r)
+        eA, eB, eC = po.groth16_expected_in_exponent(C, cs, prim, aux, tr, rr, ss, C.root_of_unity(g.log_m))
+        assert (proof == np.concatenate([pt_limbs(curve, 1, eA), pt_limbs(curve, 2, eB), pt_limbs(curve, 1, eC)])).all()
+
+
+@pytest.mark.parametrize("curve,log_n,batch", [(0, 10, 3), (1, 8, 2)])
+def test_kzg_commit_shim(shim, curve, log_n, batch):
+    """commit(batch) = per column iNTT + MSM against {alpha^i G} (kzg.hpp:427-435); alpha = 7 as placeholder.cpp:175"""
+    C = CURVES[curve]
+    n = 1 << log_n
+    alpha = 7
+    powers = fr_arr([pow(alpha, i, C.r) for i in range(n)])
+    srs, _ = cp.batch_mul(curve, 1, powers)
+    w = limbs(C.root_of_unity(log_n), 4)
+    evals = cp.random_fr(curve, 5, batch * n).reshape(batch, n, 4)
+    coeffs = cp.ntt(curve, evals, log_n, w, inverse=True)
+    out = np.zeros((batch, srs.shape[1]), dtype=np.uint64)
+    oinf = np.zeros(batch, dtype=np.uint8)
+    assert shim.shim_kzg_commit(curve, P(srs), ctypes.c_size_t(n), P(evals), ctypes.c_size_t(log_n), ctypes.c_size_t(batch), P(w), P(out), P(oinf)) == 0
+    for b in range(batch):
+        exp, einf = cp.msm(curve, 1, srs, coeffs[b], chunks=4)
+        assert oinf[b] == einf and (out[b] == exp).all()
+        # the commitment is f(alpha) * G: Horner on the coefficients
+        fa = cp.fr_horner(curve, coeffs[b], limbs(alpha, 4))
+        pt, _ = cp.batch_mul(curve, 1, fa.reshape(1, 4))
+        assert (out[b] == pt[0]).all()
