@@ -36,6 +36,9 @@ using namespace zkhip;
 
 #include "msm_recode.hpp"
 
+static constexpr uint32_t MSM_LARGE_BUCKET = 128;  // buckets above this many entries are split across workgroups
+static constexpr uint32_t MSM_LARGE_CHUNK = 4096;  // entries per task of a split bucket
+
 __global__ __launch_bounds__(256) void msm_digits(const uint32_t *__restrict__ scalars, uint32_t n, int c, int W,
                                                   uint32_t *__restrict__ dig, uint32_t *__restrict__ hist) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -140,6 +143,7 @@ __global__ __launch_bounds__(256) void msm_bucket_acc(const uint32_t *__restrict
     if (g >= nbuckets) return;
     const uint32_t *tab = bases + (size_t)(g / B) * tab_stride_words;
     uint32_t lo = offs[g], hi = offs[g + 1];
+    if (hi - lo > MSM_LARGE_BUCKET) return;  // split across workgroups by msm_bucket_large
     XYZZ<F> acc = XYZZ<F>::infinity();
     for (uint32_t k = lo; k < hi; ++k) {
         uint32_t e = idx[k];
@@ -147,6 +151,77 @@ __global__ __launch_bounds__(256) void msm_bucket_acc(const uint32_t *__restrict
         acc = xyzz_madd(acc, p, (e >> 31) != 0);
     }
     xyzz_store<F>(buckets + (size_t)g * (4 * NL), acc);
+}
+
+// ---- large buckets ---------------------------------------------------------------------------------------
+// Skewed scalars (Groth16 witnesses full of 0/1 values, a top window with only a few significant bits)
+// put thousands of points into single buckets; one lane per bucket would serialise them.  Buckets above
+// MSM_LARGE_BUCKET entries are cut into tasks of MSM_LARGE_CHUNK entries, one workgroup per task
+// (strided mixed additions + LDS tree), and the per-task partial sums of a bucket are folded afterwards.
+// plan[0] = number of tasks, plan[1] = number of large buckets; tasks[t] = {bucket, lo, hi};
+// large[j] = {bucket, first task, task count}.
+__global__ __launch_bounds__(256) void msm_plan_large(const uint32_t *__restrict__ offs, uint32_t nbuckets, uint32_t *__restrict__ plan,
+                                                      uint32_t *__restrict__ tasks, uint32_t *__restrict__ large, uint32_t task_cap,
+                                                      uint32_t large_cap) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nbuckets) return;
+    uint32_t lo = offs[g], hi = offs[g + 1], size = hi - lo;
+    if (size <= MSM_LARGE_BUCKET) return;
+    uint32_t nt = (size + MSM_LARGE_CHUNK - 1) / MSM_LARGE_CHUNK;
+    uint32_t first = atomicAdd(&plan[0], nt);
+    uint32_t slot = atomicAdd(&plan[1], 1u);
+    if (first + nt > task_cap || slot >= large_cap) return;  // cannot happen: capacities are worst-case (see host)
+    for (uint32_t t = 0; t < nt; ++t) {
+        tasks[3 * (first + t)] = g;
+        tasks[3 * (first + t) + 1] = lo + t * MSM_LARGE_CHUNK;
+        tasks[3 * (first + t) + 2] = min(hi, lo + (t + 1) * MSM_LARGE_CHUNK);
+    }
+    large[3 * slot] = g;
+    large[3 * slot + 1] = first;
+    large[3 * slot + 2] = nt;
+}
+
+template <class F>
+__global__ __launch_bounds__(128) void msm_bucket_large(const uint32_t *__restrict__ bases, size_t tab_stride_words, uint32_t B,
+                                                        const uint32_t *__restrict__ idx, const uint32_t *__restrict__ plan,
+                                                        const uint32_t *__restrict__ tasks, uint32_t *__restrict__ partials) {
+    constexpr int NL = FieldOps<F>::WORDS;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t ntasks = plan[0];
+    for (uint32_t task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        const uint32_t g = tasks[3 * task], lo = tasks[3 * task + 1], hi = tasks[3 * task + 2], t = threadIdx.x;
+        const uint32_t *tab = bases + (size_t)(g / B) * tab_stride_words;
+        XYZZ<F> acc = XYZZ<F>::infinity();
+        for (uint32_t k = lo + t; k < hi; k += blockDim.x) {
+            uint32_t e = idx[k];
+            Affine<F> p = affine_load<F>(tab + (size_t)(e & 0x7FFFFFFFu) * (2 * NL));
+            acc = xyzz_madd(acc, p, (e >> 31) != 0);
+        }
+        xyzz_store<F>(lds + (size_t)t * (4 * NL), acc);
+        __syncthreads();
+        for (uint32_t d = blockDim.x / 2; d >= 1; d >>= 1) {
+            if (t < d) {
+                acc = xyzz_add(xyzz_load<F>(lds + (size_t)t * (4 * NL)), xyzz_load<F>(lds + (size_t)(t + d) * (4 * NL)));
+                xyzz_store<F>(lds + (size_t)t * (4 * NL), acc);
+            }
+            __syncthreads();
+        }
+        if (t == 0) xyzz_store<F>(partials + (size_t)task * (4 * NL), acc);
+        __syncthreads();
+    }
+}
+
+template <class F>
+__global__ __launch_bounds__(64) void msm_large_combine(const uint32_t *__restrict__ plan, const uint32_t *__restrict__ large,
+                                                        const uint32_t *__restrict__ partials, uint32_t *__restrict__ buckets) {
+    constexpr int NL = FieldOps<F>::WORDS;
+    const uint32_t nlarge = plan[1];
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nlarge; j += gridDim.x * blockDim.x) {
+        const uint32_t g = large[3 * j], first = large[3 * j + 1], nt = large[3 * j + 2];
+        XYZZ<F> acc = XYZZ<F>::infinity();
+        for (uint32_t t = 0; t < nt; ++t) acc = xyzz_add(acc, xyzz_load<F>(partials + (size_t)(first + t) * (4 * NL)));
+        xyzz_store<F>(buckets + (size_t)g * (4 * NL), acc);
+    }
 }
 
 // buckets[w][b] += buckets[w + half][b] for w < cnt (one level of the tree that folds equal-weight windows)
@@ -436,6 +511,12 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     need += zkhip_ctx::ws_round((size_t)nb * 4 * NL * 4);  // buckets
     need += zkhip_ctx::ws_round((size_t)W * nseg * 4 * NL * 4);
     need += zkhip_ctx::ws_round((size_t)W * 4 * NL * 4);
+    // worst-case plan of the large-bucket path: every entry in a large bucket
+    const size_t entries = (size_t)W * n;
+    const uint32_t large_cap = (uint32_t)(entries / MSM_LARGE_BUCKET + 1);
+    const uint32_t task_cap = (uint32_t)(entries / MSM_LARGE_CHUNK + large_cap + 1);
+    need += zkhip_ctx::ws_round(16) + zkhip_ctx::ws_round((size_t)task_cap * 12) + zkhip_ctx::ws_round((size_t)large_cap * 12);
+    need += zkhip_ctx::ws_round((size_t)task_cap * 4 * NL * 4);
     ZK_TRY(ctx->ws_reserve(need));
     ctx->ws_reset();
     uint32_t *dig = ctx->ws_take<uint32_t>((size_t)W * n);
@@ -447,6 +528,10 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     uint32_t *buckets = ctx->ws_take<uint32_t>((size_t)nb * 4 * NL);
     uint32_t *segsum = ctx->ws_take<uint32_t>((size_t)W * nseg * 4 * NL);
     uint32_t *winsum = ctx->ws_take<uint32_t>((size_t)W * 4 * NL);
+    uint32_t *plan = ctx->ws_take<uint32_t>(4);
+    uint32_t *tasks = ctx->ws_take<uint32_t>((size_t)task_cap * 3);
+    uint32_t *large = ctx->ws_take<uint32_t>((size_t)large_cap * 3);
+    uint32_t *partials = ctx->ws_take<uint32_t>((size_t)task_cap * 4 * NL);
 
     const uint32_t *d_b = bases->d + offset * bases->stride_u32;
     const size_t tab_stride_words = tables ? bases->n * bases->stride_u32 : 0;
@@ -459,6 +544,22 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     ZK_LAUNCH(ctx, "msm_scan", msm_scan_add, dim3(nblk), dim3(256), 0, offs, nb, bsums, cursor);
     ZK_LAUNCH(ctx, "msm_scatter", msm_scatter, dim3(gn, W), dim3(256), 0, dig, (uint32_t)n, c, cursor, idx);
     ZK_LAUNCH(ctx, "msm_bucket_acc", msm_bucket_acc<F>, dim3((nb + 255) / 256), dim3(256), 0, d_b, tab_stride_words, B, offs, idx, nb, buckets);
+    // large buckets: plan on the device (no host round trip), then fixed-size grids that read the plan
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(plan, 0, 16, ctx->stream));
+    ZK_LAUNCH(ctx, "msm_plan_large", msm_plan_large, dim3((nb + 255) / 256), dim3(256), 0, offs, nb, plan, tasks, large, task_cap, large_cap);
+    {
+        static bool attr_set = false;
+        size_t lds_large = (size_t)128 * 4 * NL * 4;
+        if (!attr_set && lds_large > 48 * 1024) {
+            ZK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&msm_bucket_large<F>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)lds_large));
+            attr_set = true;
+        }
+        unsigned grid_large = (unsigned)std::min<size_t>(task_cap, 2048);
+        ZK_LAUNCH(ctx, "msm_bucket_large", msm_bucket_large<F>, dim3(grid_large), dim3(128), lds_large, d_b, tab_stride_words, B, idx, plan, tasks,
+                  partials);
+        ZK_LAUNCH(ctx, "msm_bucket_large", msm_large_combine<F>, dim3(64), dim3(64), 0, plan, large, partials, buckets);
+    }
     if (tables) {
         for (uint32_t cur = (uint32_t)W; cur > 1;) {
             uint32_t half = (cur + 1) / 2, cnt = cur - half;

@@ -73,6 +73,29 @@ public:
         size_ = inf.size();
         check(zkhip_bases_upload(ctx.get(), adapter::id, Group, xy.data(), inf.data(), size_, &b_), "zkhip_bases_upload", ctx.get());
     }
+    /// bases[i] = scalars[i] * G computed on the device (fixed-base batch exponentiation, generator.hpp:187-214)
+    template <typename ScalarIt>
+    static device_bases from_scalars(const context &ctx, ScalarIt first, ScalarIt last) {
+        std::vector<std::uint64_t> s;
+        for (ScalarIt it = first; it != last; ++it) {
+            s.resize(s.size() + 4);
+            adapter::scalar_to_limbs(*it, s.data() + s.size() - 4);
+        }
+        device_bases r;
+        r.ctx_ = &ctx;
+        r.size_ = s.size() / 4;
+        check(zkhip_bases_from_scalars(ctx.get(), adapter::id, Group, nullptr, s.data(), r.size_, &r.b_), "zkhip_bases_from_scalars", ctx.get());
+        return r;
+    }
+    /// host copy of entry i as a group value
+    typename std::conditional<Group == ZKHIP_G1, typename adapter::g1_value_type, typename adapter::g2_value_type>::type at(std::size_t i) const {
+        typedef typename std::conditional<Group == ZKHIP_G1, typename adapter::g1_value_type, typename adapter::g2_value_type>::type G;
+        const std::size_t cl = Group == ZKHIP_G1 ? adapter::g1_coord_limbs : adapter::g2_coord_limbs;
+        std::vector<std::uint64_t> xy(2 * cl);
+        std::uint8_t inf = 0;
+        check(zkhip_bases_download(ctx_->get(), b_, i, 1, xy.data(), &inf), "zkhip_bases_download", ctx_->get());
+        return G::from_affine(xy.data(), inf != 0);
+    }
     ~device_bases() {
         if (b_) zkhip_bases_free(ctx_ ? ctx_->get() : nullptr, b_);
     }

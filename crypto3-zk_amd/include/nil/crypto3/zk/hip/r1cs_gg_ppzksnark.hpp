@@ -222,6 +222,19 @@ public:
         B_count = idx.size();
     }
 
+    /// Adopts queries that already live on the device (e.g. produced by device_bases::from_scalars); `pk` supplies
+    /// the five single group elements and the constraint system, its query vectors are not read.
+    r1cs_gg_ppzksnark_proving_key_hip(const context &ctx, const host_key_type &pk, const domain_params<CurveType> &dom,
+                                      device_bases<CurveType, ZKHIP_G1> &&a_query, device_bases<CurveType, ZKHIP_G2> &&b_query_g,
+                                      device_bases<CurveType, ZKHIP_G1> &&b_query_h, const std::vector<std::uint32_t> &b_indices,
+                                      device_bases<CurveType, ZKHIP_G1> &&h_query, device_bases<CurveType, ZKHIP_G1> &&l_query) :
+        ctx(ctx), host(pk), domain(dom), A_query(std::move(a_query)), H_query(std::move(h_query)), L_query(std::move(l_query)),
+        B_query_h(std::move(b_query_h)), B_query_g(std::move(b_query_g)), constraint_system(ctx, pk.constraint_system) {
+        d_B_indices = ctx.alloc(std::max<std::size_t>(1, b_indices.size()) * 4);
+        if (!b_indices.empty()) ctx.h2d(d_B_indices.get(), b_indices.data(), b_indices.size() * 4);
+        B_count = b_indices.size();
+    }
+
     const context &ctx;
     const host_key_type &host;
     domain_params<CurveType> domain;

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Groth16 prover throughput through the C++ shim (r1cs_gg_ppzksnark_prover_hip::process): constraints/s on one GPU.
+BASELINE config 4's single-GPU leg (M = 2^20, n = 10 -> m = 2^21)."""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = {0: (0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001, 7),
+     1: (21888242871839275222246405745257275088548364400416034343698204186575808495617, 5)}
+
+
+def limbs(v):
+    return np.array([(v >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log-constraints", type=int, default=20)
+    ap.add_argument("--inputs", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--curve", type=int, default=0)
+    a = ap.parse_args()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(os.path.join(ROOT, "tests", "cpp", "libshimtest.so"))
+    M = 1 << a.log_constraints
+    m = 1
+    while m < M + a.inputs + 1:
+        m <<= 1
+    r, g = R[a.curve]
+    omega = limbs(pow(g, (r - 1) // m, r))
+    coset = limbs(g)
+    times = np.zeros(a.steps, dtype=np.float64)
+    setup = ctypes.c_double()
+    rc = lib.shim_groth16_bench(a.curve, ctypes.c_size_t(M), ctypes.c_size_t(a.inputs), ctypes.c_uint64(1), a.steps,
+                                omega.ctypes.data_as(ctypes.c_void_p), coset.ctypes.data_as(ctypes.c_void_p),
+                                times.ctypes.data_as(ctypes.c_void_p), ctypes.byref(setup))
+    assert rc == 0, rc
+    best = float(times[1:].min() if a.steps > 1 else times.min())
+    print(json.dumps({"workload": "Groth16 prove, curve %d, 2^%d constraints, %d inputs, domain 2^%d, 1 GPU, via C++ shim (H2D of the assignment and D2H of the 5 MSM results included)"
+                      % (a.curve, a.log_constraints, a.inputs, m.bit_length() - 1),
+                      "ms_per_proof": [round(float(t), 3) for t in times], "constraints_per_s": round(M / best * 1e3, 1),
+                      "setup_ms": round(setup.value, 1)}))
+
+
+if __name__ == "__main__":
+    main()
