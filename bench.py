@@ -90,11 +90,16 @@ def main():
     d_gather = torch.zeros(world * 3 * 6, dtype=torch.int64, device=f"cuda:{local_rank}") if world > 1 else None
     d_total = torch.zeros(3 * 6, dtype=torch.int64, device=f"cuda:{local_rank}")
 
+    from crypto3_zk_amd import dist as zd
+
+    def fold(gathered, w):
+        ctx.jacobian_sum_dev(zk.BLS12_381, zk.G1, gathered.data_ptr(), w, d_total.data_ptr())
+        return d_total
+
     def step():
         ctx.msm_dev(bases, d_scalars.data_ptr(), d_out.data_ptr(), 0, n)
-        if world > 1:
-            dist.all_gather_into_tensor(d_gather, d_out)
-            ctx.jacobian_sum_dev(zk.BLS12_381, zk.G1, d_gather.data_ptr(), world, d_total.data_ptr())
+        # N > 1: one all-gather of the 144-byte partial sums over RCCL, then the on-device fold
+        zd.allgather_fold(d_out, world, lambda o, i: dist.all_gather_into_tensor(o, i), fold)
 
     def fence():
         if world > 1:

@@ -26,6 +26,7 @@ struct zkhip_r1cs {
     uint32_t *long_rows[3] = {nullptr, nullptr, nullptr};  // rows with more than LONG_ROW terms
     uint32_t n_long[3] = {0, 0, 0};
     size_t nnz[3] = {0, 0, 0};
+    size_t long_terms[3] = {0, 0, 0};  // total terms in long rows
 };
 
 static constexpr uint32_t LONG_ROW = 64;
@@ -69,7 +70,10 @@ __global__ __launch_bounds__(256) void r1cs_eval_long(const uint32_t *__restrict
                                                       const uint32_t *__restrict__ z, uint32_t *__restrict__ out) {
     __shared__ uint32_t part[256 * U::L];
     const uint32_t row = long_rows[blockIdx.x], t = threadIdx.x;
-    const uint32_t lo = rowptr[row], hi = rowptr[row + 1];
+    // blockIdx.y selects one of gridDim.y equal slices of the row; `out` then holds per-slice partial sums
+    const uint32_t rlo = rowptr[row], rhi = rowptr[row + 1];
+    const uint32_t per = (rhi - rlo + gridDim.y - 1) / gridDim.y;
+    const uint32_t lo = min(rhi, rlo + blockIdx.y * per), hi = min(rhi, lo + per);
     Fu<U> acc = Fu<U>::zero();
     for (uint32_t k = lo + t; k < hi; k += 256) {
         Fu<U> x = fu_mul(fu_unpack<U>(z + (size_t)col[k] * U::NL), fu_load<U>(coeff + (size_t)k * U::SL));
@@ -89,7 +93,18 @@ __global__ __launch_bounds__(256) void r1cs_eval_long(const uint32_t *__restrict
         }
         __syncthreads();
     }
-    if (t == 0) fu_pack<U>(out + (size_t)row * U::NL, acc);
+    if (t == 0) fu_store<U>(out + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * U::SL, acc);
+}
+
+// out[row] = sum of the row's `nslice` partial sums
+template <class U>
+__global__ __launch_bounds__(64) void r1cs_long_combine(const uint32_t *__restrict__ long_rows, uint32_t n_long, uint32_t nslice,
+                                                        const uint32_t *__restrict__ partial, uint32_t *__restrict__ out) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_long) return;
+    Fu<U> acc = Fu<U>::zero();
+    for (uint32_t s = 0; s < nslice; ++s) acc = fr_add_mod(acc, fu_load<U>(partial + ((size_t)j * nslice + s) * U::SL));
+    fu_pack<U>(out + (size_t)long_rows[j] * U::NL, acc);
 }
 
 // rows M .. m-1 of the three vectors: aA[M + i] = z_i (i <= n), everything else zero
@@ -167,7 +182,10 @@ static int r1cs_upload_t(zkhip_ctx *ctx, zkhip_r1cs *r, const uint32_t *const ro
         ZK_HIP_CHECK(ctx, hipMemcpyAsync(r->rowptr[k], rowptr[k], (r->M + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
         std::vector<uint32_t> lr;
         for (size_t i = 0; i < r->M; ++i) {
-            if (rowptr[k][i + 1] - rowptr[k][i] > LONG_ROW) lr.push_back((uint32_t)i);
+            if (rowptr[k][i + 1] - rowptr[k][i] > LONG_ROW) {
+                lr.push_back((uint32_t)i);
+                r->long_terms[k] += rowptr[k][i + 1] - rowptr[k][i];
+            }
             if (rowptr[k][i + 1] < rowptr[k][i]) return ZKHIP_ERR_INVALID;
         }
         for (size_t j = 0; j < nnz; ++j)
@@ -198,9 +216,17 @@ static int witness_h_t(zkhip_ctx *ctx, const zkhip_r1cs *r, const uint32_t *d_z,
     for (int k = 0; k < 3; ++k) {
         uint32_t *out = d_abc + (size_t)k * m * U::NL;
         ZK_LAUNCH(ctx, "r1cs_eval_rows", r1cs_eval_rows<U>, dim3((M + 255) / 256), dim3(256), 0, r->rowptr[k], r->col[k], r->coeff[k], d_z, M, out);
-        if (r->n_long[k])
-            ZK_LAUNCH(ctx, "r1cs_eval_long", r1cs_eval_long<U>, dim3(r->n_long[k]), dim3(256), 0, r->long_rows[k], r->rowptr[k], r->col[k],
-                      r->coeff[k], d_z, out);
+        if (r->n_long[k]) {
+            // slices of ~4096 terms, at most 64 per row; per-slice partial sums live in the context workspace
+            uint32_t nslice = (uint32_t)std::max<size_t>(1, std::min<size_t>(64, r->long_terms[k] / ((size_t)r->n_long[k] * 4096)));
+            ZK_TRY(ctx->ws_reserve((size_t)r->n_long[k] * nslice * U::SL * 4 + 256));
+            ctx->ws_reset();
+            uint32_t *partial = ctx->ws_take<uint32_t>((size_t)r->n_long[k] * nslice * U::SL);
+            ZK_LAUNCH(ctx, "r1cs_eval_long", r1cs_eval_long<U>, dim3(r->n_long[k], nslice), dim3(256), 0, r->long_rows[k], r->rowptr[k], r->col[k],
+                      r->coeff[k], d_z, partial);
+            ZK_LAUNCH(ctx, "r1cs_eval_long", r1cs_long_combine<U>, dim3((r->n_long[k] + 63) / 64), dim3(64), 0, r->long_rows[k], r->n_long[k], nslice,
+                      partial, out);
+        }
     }
     if (m > M) ZK_LAUNCH(ctx, "r1cs_fill_tail", r1cs_fill_tail<U>, dim3((3 * (m - M) + 255) / 256), dim3(256), 0, d_abc, d_z, M, (uint32_t)r->n, m);
     // coefficients, then evaluations on the coset g<omega>

@@ -1,0 +1,39 @@
+"""Multi-GPU sharding of the MSM path: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).
+
+The path shards by POINT RANGE: rank g owns bases / scalars [lo_g, hi_g), computes one partial sum with the
+full single-GPU pipeline, and the only exchange is one all-gather of the Jacobian partial results
+(3 coordinates x 48 B for BLS12-381 G1).  RCCL has no elliptic-curve reduction operator, so the "reduce" is
+all-gather + a fold of `world` points on every rank (zkhip_jacobian_sum_dev).  The message is latency-bound
+(about a microsecond class transfer over xGMI), nothing here is bandwidth-bound.
+
+Independent NTT batches (KZG columns, the three witness vectors of Groth16) shard by polynomial with no
+collective at all.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Tuple
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced split of [0, n): the first n % world ranks get one extra element."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_polys(batch: int, rank: int, world: int) -> List[int]:
+    """Polynomial indices of an NTT batch owned by `rank` (round-robin: equal work, no collective)."""
+    return list(range(rank, batch, world))
+
+
+def allgather_fold(partial, world: int, all_gather: Callable, fold: Callable):
+    """partial: this rank's Jacobian result as a flat tensor (device or host).
+    all_gather(out, inp): the collective (torch.distributed.all_gather_into_tensor or a test double);
+    fold(gathered, world): sums `world` Jacobian points (zkhip_jacobian_sum_dev on the GPU)."""
+    if world == 1:
+        return partial
+    gathered = partial.new_zeros(world * partial.numel())
+    all_gather(gathered, partial)
+    return fold(gathered, world)

@@ -1,0 +1,85 @@
+"""The N > 1 path on CPU: world_size 2 over the gloo backend.  The sharding and the all-gather + fold logic of
+crypto3-zk_amd/dist.py run for real; the per-rank partial MSM (a GPU kernel in production) is supplied by the
+oracle here, so this checks the distributed plumbing, not the kernels (those are covered by -m gpu)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n, out_q):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conftest
+    import cport as cp
+
+    zk = conftest.load_pkg()
+    from crypto3_zk_amd import dist as zd
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    ks = cp.random_fr(0, 11, n)
+    pts, _ = cp.batch_mul(0, 1, ks)
+    sc = cp.random_fr(0, 12, n)
+    lo, hi = zd.shard_range(n, rank, world)
+    part, pinf = cp.msm(0, 1, pts[lo:hi], sc[lo:hi])  # stand-in for the rank's GPU MSM
+    # Jacobian (X, Y, Z) with Z = 1 (or 0 for infinity), as the C ABI returns it
+    jac = np.concatenate([part, np.array([0 if pinf else 1, 0, 0, 0, 0, 0], dtype=np.uint64)])
+    t = torch.from_numpy(jac.view(np.int64).copy())
+
+    def fold(gathered, w):
+        acc, ainf = None, 1
+        g = gathered.numpy().view(np.uint64).reshape(w, 18)
+        for j in range(w):
+            p, pi = cp.jac_to_affine(0, 1, g[j].reshape(3, 6))
+            acc, ainf = (p, pi) if acc is None else cp.point_add(0, 1, acc, ainf, p, pi)
+        return acc, ainf
+
+    total, tinf = zd.allgather_fold(t, world, lambda o, i: dist.all_gather_into_tensor(o, i), fold)
+    exp, einf = cp.msm(0, 1, pts, sc, chunks=2)
+    ok = bool(tinf == einf and (total == exp).all())
+    # NTT batches shard by polynomial without any collective
+    polys = zd.shard_polys(8, rank, world)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, polys)
+    ok = ok and sorted(sum(gathered, [])) == list(range(8))
+    dist.barrier()
+    dist.destroy_process_group()
+    out_q.put((rank, ok))
+
+
+def test_shard_range():
+    conf = __import__("conftest")
+    conf.load_pkg()
+    from crypto3_zk_amd import dist as zd
+
+    for n in (0, 1, 7, 8, 1 << 20, (1 << 20) + 3):
+        for world in (1, 2, 3, 4, 8):
+            ranges = [zd.shard_range(n, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in ranges]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        zd.shard_range(10, 2, 2)
+
+
+def test_point_range_sharding_world2_gloo():
+    world, n = 2, 301
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(0, True), (1, True)]
