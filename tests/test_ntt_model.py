@@ -1,5 +1,5 @@
 """Line-by-line CPU replay of the index arithmetic of crypto3-zk_amd/csrc/ntt.hip (pass planning, tile
-load with inter-pass twiddles, in-LDS DIF stages, bit-reversed read-out with both store decodings,
+bit-reversed tile load, in-LDS DIT stages, store with the next pass's twiddle and both store decodings,
 ping-pong buffer choice) on Python integers, checked against the O(n^2) DFT.  Catches indexing mistakes
 without a GPU; the arithmetic itself is covered by test_host_arith.py."""
 import random
@@ -28,13 +28,17 @@ def bitrev(v, bits):
     return int(bin(v)[2:].zfill(bits)[::-1], 2) if bits else 0
 
 
-def kernel_pass(x, log_m, s, log_ns, log_t, w, r, nth=4, pre=None, post=None, scale=None):
+def kernel_pass(x, log_m, s, log_ns, log_t, next_s, w, r, pre=None, post=None, scale=1):
     m = 1 << log_m
     R, T = 1 << s, 1 << log_t
     nelem = R * T
     log_stride = log_m - s
     ns_mask = (1 << log_ns) - 1
-    tw_shift = log_m - log_ns - s
+    last = next_s == 0
+    n_log_ns = log_ns + s
+    n_log_stride = log_m - next_s
+    n_ns_mask = (1 << n_log_ns) - 1
+    n_tw_shift = log_m - n_log_ns - next_s
     y = [None] * m
     for tile in range(1 << (log_m - s - log_t)):
         j0 = tile << log_t
@@ -42,29 +46,22 @@ def kernel_pass(x, log_m, s, log_ns, log_t, w, r, nth=4, pre=None, post=None, sc
         lds = [0] * nelem
         for e in range(nelem):
             t, c = e >> log_t, e & (T - 1)
-            j = j0 + c
-            gi = j + (t << log_stride)
+            gi = j0 + c + (t << log_stride)
             v = x[gi]
             if pre is not None:
                 v = v * pow(pre, gi, r) % r
-            if log_ns:
-                k = j & ns_mask
-                ex = (k * t) << tw_shift
-                assert ex < m
-                v = v * pow(w, ex, r) % r
-            lds[e] = v
+            lds[(bitrev(t, s) << log_t) + c] = v
         for st in range(s):
-            h = R >> (st + 1)
+            h = 1 << st
             for bf in range(nelem >> 1):
                 c, q = bf & (T - 1), bf >> log_t
                 qq = q & (h - 1)
-                t_lo = ((q - qq) << 1) + qq
-                e0, e1 = (t_lo << log_t) + c, ((t_lo + h) << log_t) + c
+                i0 = ((q - qq) << 1) + qq
+                e0, e1 = (i0 << log_t) + c, ((i0 + h) << log_t) + c
                 a, b = lds[e0], lds[e1]
-                u, v = (a + b) % r, (a - b) % r
-                if h != 1:
-                    v = v * twr[qq << st] % r
-                lds[e0], lds[e1] = u, v
+                if st != 0:
+                    b = b * twr[qq << (s - 1 - st)] % r
+                lds[e0], lds[e1] = (a + b) % r, (a - b) % r
         for e in range(nelem):
             if log_ns >= log_t:
                 tp, c = e >> log_t, e & (T - 1)
@@ -76,13 +73,18 @@ def kernel_pass(x, log_m, s, log_ns, log_t, w, r, nth=4, pre=None, post=None, sc
             j = j0 + c
             k = j & ns_mask
             oi = ((j - k) << s) + k + (tp << log_ns)
-            v = lds[(bitrev(tp, s) << log_t) + c]
-            if scale is not None:
-                v = v * scale % r
-            if post is not None:
-                v = v * pow(post, oi, r) % r
+            v = lds[(tp << log_t) + c]
+            if not last:
+                jn, tn = oi & ((1 << n_log_stride) - 1), oi >> n_log_stride
+                ex = ((jn & n_ns_mask) * tn) << n_tw_shift
+                assert ex < m
+                f = pow(w, ex, r)
+            else:
+                f = scale
+                if post is not None:
+                    f = f * pow(post, oi, r) % r
             assert y[oi] is None
-            y[oi] = v
+            y[oi] = v * f % r
     assert all(v is not None for v in y)
     return y
 
@@ -96,10 +98,11 @@ def model_ntt(a, log_m, w, r, inverse=False, coset=None, smax=8, tile_log=3):
     x = list(a)
     for i, (s, log_ns, log_t) in enumerate(passes):
         last = i == len(passes) - 1
-        x = kernel_pass(x, log_m, s, log_ns, log_t, weff, r,
+        next_s = 0 if last else passes[i + 1][0]
+        x = kernel_pass(x, log_m, s, log_ns, log_t, next_s, weff, r,
                         pre=geff if (not inverse and coset is not None and i == 0) else None,
                         post=geff if (inverse and coset is not None and last) else None,
-                        scale=pow(1 << log_m, -1, r) if (inverse and last) else None)
+                        scale=pow(1 << log_m, -1, r) if inverse else 1)
     return x
 
 
