@@ -134,21 +134,58 @@ __global__ __launch_bounds__(256) void msm_scatter(const uint32_t *__restrict__ 
 
 // One lane per (window, bucket).  With precomputed window tables (tab_stride != 0) window w gathers from
 // table w, whose entry i is 2^(c w) P_i, so that all windows feed buckets of equal weight.
-template <class F>
-__global__ __launch_bounds__(256) void msm_bucket_acc(const uint32_t *__restrict__ bases, size_t tab_stride_words, uint32_t B,
+template <class F, int MSM_ACC_THREADS>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_bucket_acc(const uint32_t *__restrict__ bases, size_t tab_stride_words, uint32_t B,
                                                       const uint32_t *__restrict__ offs, const uint32_t *__restrict__ idx, uint32_t nbuckets,
                                                       uint32_t *__restrict__ buckets) {
     constexpr int NL = FieldOps<F>::WORDS;
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    // Lanes of a wave run in lockstep, so a wave costs max(bucket size) over its 64 buckets.  The workgroup's
+    // buckets are therefore handed out in descending order of size (counting sort over the sizes in LDS):
+    // waves see near-equal trip counts and the empty / large (skipped) buckets collect in the last waves.
+    __shared__ uint32_t bin_start[MSM_LARGE_BUCKET + 2];
+    __shared__ uint32_t order[MSM_ACC_THREADS];
+    const uint32_t tid = threadIdx.x, gbase = blockIdx.x * blockDim.x;
+    for (uint32_t i = tid; i < MSM_LARGE_BUCKET + 2; i += blockDim.x) bin_start[i] = 0;
+    __syncthreads();
+    uint32_t my_g = gbase + tid, my_bin = MSM_LARGE_BUCKET + 1;  // bins by descending size; last bin = nothing to do
+    if (my_g < nbuckets) {
+        uint32_t size = offs[my_g + 1] - offs[my_g];
+        if (size != 0 && size <= MSM_LARGE_BUCKET) my_bin = MSM_LARGE_BUCKET - size;
+    }
+    uint32_t rank = atomicAdd(&bin_start[my_bin], 1u);
+    __syncthreads();
+    if (tid == 0) {  // exclusive scan of 130 counters
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < MSM_LARGE_BUCKET + 2; ++i) {
+            uint32_t c = bin_start[i];
+            bin_start[i] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    order[bin_start[my_bin] + rank] = my_g;
+    __syncthreads();
+    const uint32_t g = order[tid];
     if (g >= nbuckets) return;
     const uint32_t *tab = bases + (size_t)(g / B) * tab_stride_words;
     uint32_t lo = offs[g], hi = offs[g + 1];
-    if (hi - lo > MSM_LARGE_BUCKET) return;  // split across workgroups by msm_bucket_large
+    if (hi - lo > MSM_LARGE_BUCKET) return;  // split across workgroups by msm_bucket_large (empty: written below)
     XYZZ<F> acc = XYZZ<F>::infinity();
-    for (uint32_t k = lo; k < hi; ++k) {
-        uint32_t e = idx[k];
+    if (lo < hi) {
+        // software pipeline: the next point's gather is in flight while the current mixed addition runs
+        uint32_t e = idx[lo];
         Affine<F> p = affine_load<F>(tab + (size_t)(e & 0x7FFFFFFFu) * (2 * NL));
-        acc = xyzz_madd(acc, p, (e >> 31) != 0);
+        for (uint32_t k = lo; k < hi; ++k) {
+            uint32_t e_next = e;
+            Affine<F> p_next = p;
+            if (k + 1 < hi) {
+                e_next = idx[k + 1];
+                p_next = affine_load<F>(tab + (size_t)(e_next & 0x7FFFFFFFu) * (2 * NL));
+            }
+            acc = xyzz_madd(acc, p, (e >> 31) != 0);
+            e = e_next;
+            p = p_next;
+        }
     }
     xyzz_store<F>(buckets + (size_t)g * (4 * NL), acc);
 }
@@ -257,7 +294,7 @@ __global__ __launch_bounds__(64) void msm_bucket_red(const uint32_t *__restrict_
 
 // one workgroup per window: winsum[w] = sum_seg segsum[w][seg]
 template <class F>
-__global__ __launch_bounds__(128) void msm_window_sum(const uint32_t *__restrict__ segsum, uint32_t nseg, uint32_t *__restrict__ winsum) {
+__global__ __launch_bounds__(256) void msm_window_sum(const uint32_t *__restrict__ segsum, uint32_t nseg, uint32_t *__restrict__ winsum) {
     constexpr int NL = FieldOps<F>::WORDS;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t w = blockIdx.x, t = threadIdx.x;
@@ -497,7 +534,7 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     const uint32_t B = 1u << (c - 1);
     const uint32_t nb = (uint32_t)W * B;
     const int Wr = tables ? 1 : W;  // windows left after the equal-weight merge
-    uint32_t L = std::min<uint32_t>(B, 1u << std::max(0, ctx->opt_msm_segment_log));
+    uint32_t L = std::min<uint32_t>(B, 1u << std::max(0, ctx->opt_msm_segment_log));  // 8 buckets per segment by default
     const uint32_t nseg = B / L;
     const uint32_t nblk = (nb + 1023) / 1024;
 
@@ -543,7 +580,12 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     ZK_LAUNCH(ctx, "msm_scan", msm_scan_top, dim3(1), dim3(1024), 0, bsums, nblk, offs + nb);
     ZK_LAUNCH(ctx, "msm_scan", msm_scan_add, dim3(nblk), dim3(256), 0, offs, nb, bsums, cursor);
     ZK_LAUNCH(ctx, "msm_scatter", msm_scatter, dim3(gn, W), dim3(256), 0, dig, (uint32_t)n, c, cursor, idx);
-    ZK_LAUNCH(ctx, "msm_bucket_acc", msm_bucket_acc<F>, dim3((nb + 255) / 256), dim3(256), 0, d_b, tab_stride_words, B, offs, idx, nb, buckets);
+    {
+        // G1 kernels fit two waves per SIMD: 512-lane workgroups sort 512 buckets by size; the Fq2 kernels need 256
+        constexpr int AT = FieldOps<F>::WORDS <= 16 ? 512 : 256;
+        ZK_LAUNCH(ctx, "msm_bucket_acc", (msm_bucket_acc<F, AT>), dim3((nb + AT - 1) / AT), dim3(AT), 0, d_b, tab_stride_words, B, offs, idx, nb,
+                  buckets);
+    }
     // large buckets: plan on the device (no host round trip), then fixed-size grids that read the plan
     ZK_HIP_CHECK(ctx, hipMemsetAsync(plan, 0, 16, ctx->stream));
     ZK_LAUNCH(ctx, "msm_plan_large", msm_plan_large, dim3((nb + 255) / 256), dim3(256), 0, offs, nb, plan, tasks, large, task_cap, large_cap);
@@ -569,7 +611,7 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     }
     uint32_t tot = (uint32_t)Wr * nseg;
     ZK_LAUNCH(ctx, "msm_bucket_red", msm_bucket_red<F>, dim3((tot + 63) / 64), dim3(64), 0, buckets, B, L, nseg, tot, segsum);
-    unsigned wthreads = 128;
+    unsigned wthreads = (4 * NL * 4 <= 256) ? 256 : 128;  // 64 KiB of LDS either way
     size_t lds = (size_t)wthreads * 4 * NL * 4;
     ZK_LAUNCH(ctx, "msm_window_sum", msm_window_sum<F>, dim3(Wr), dim3(wthreads), lds, segsum, nseg, winsum);
     ZK_LAUNCH(ctx, "msm_final", msm_final<F>, dim3(1), dim3(64), 0, winsum, Wr, c, d_out_jac);
