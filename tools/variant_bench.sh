@@ -1,0 +1,9 @@
+#!/bin/bash
+# A/B of libzkhip.so builds on one GPU box: swaps the library in place, runs the MSM bench, restores it
+cd "$(dirname "$0")/.."
+cp crypto3-zk_amd/libzkhip.so /tmp/libzkhip_base.so
+for v in base "$@"; do
+  if [ "$v" != base ]; then cp crypto3-zk_amd/variants/libzkhip_$v.so crypto3-zk_amd/libzkhip.so; fi
+  echo "== $v"; timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['kernel_ms_per_step'])"
+done
+cp /tmp/libzkhip_base.so crypto3-zk_amd/libzkhip.so
