@@ -18,7 +18,7 @@
 // Kernels (all integer VALU; no MFMA -- this is modular arithmetic, not a dense contraction):
 //   msm_digits      scalar -> signed digits + bucket histogram      (streams 32 B/scalar, coalesced)
 //   msm_scan        exclusive prefix over W*B counters (local scan, top scan, add-back)
-//   msm_scatter     counting-sort scatter of point indices by (window, bucket)
+//   msm_sort_*      two-level counting sort of point indices by (window, bucket), counters in LDS only
 //   msm_bucket_acc  one lane per bucket: gather affine points, XYZZ mixed additions     <- dominant
 //   msm_bucket_merge  with window tables: fold the W equal-weight windows bucket by bucket (log2 W launches)
 //   msm_bucket_red  running-sum reduction of L-bucket segments, weighted by segment offset
@@ -134,6 +134,95 @@ __global__ __launch_bounds__(256) void msm_scatter(const uint32_t *__restrict__ 
     if (d == DIG_NONE) return;
     uint32_t pos = atomicAdd(&cursor[(size_t)w * B + (d & 0x7FFFFFFFu)], 1u);
     idx[pos] = i | (d & 0x80000000u);
+}
+
+// ---- bucket sort without global atomics ------------------------------------------------------------------
+// Random global atomics top out near 11 G/s on this chip (1.5 ms for the 16.8 M digits of a 2^20 MSM), so the
+// (window, bucket) counting sort is done as a two-level partition whose counters all live in LDS:
+//   pass 1  split every window into 2^hb "super-buckets" by the high bits of the bucket id: per-tile LDS
+//           histogram -> global exclusive scan over (window, super-bucket, tile) -> per-tile LDS ranks;
+//   pass 2  one workgroup per (window, super-bucket): LDS counting sort over the low 8 bits, which also
+//           yields the final bucket offsets.
+// The digit array is read twice per pass, no thread ever waits on a global atomic.
+static constexpr uint32_t SORT_TILE = 4096;  // digits per pass-1 tile (256 lanes x 16)
+
+__global__ __launch_bounds__(256) void msm_digits_only(const uint32_t *__restrict__ scalars, uint32_t n, int c, int W,
+                                                       uint32_t *__restrict__ dig) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *s = scalars + (size_t)i * 8;
+    uint32_t carry = 0;
+    for (int w = 0; w < W; ++w) dig[(size_t)w * n + i] = msm_recode(s, w, c, carry);
+}
+
+// bh[(w * nsuper + sb) * ntile + tile] = number of digits of window w, tile `tile`, in super-bucket sb
+__global__ __launch_bounds__(256) void msm_sort_hist(const uint32_t *__restrict__ dig, uint32_t n, uint32_t lowb, uint32_t nsuper, uint32_t ntile,
+                                                     uint32_t *__restrict__ bh) {
+    __shared__ uint32_t lh[128];
+    const uint32_t tile = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
+    if (t < 128) lh[t] = 0;
+    __syncthreads();
+    const uint32_t lo = tile * SORT_TILE, hi = min(n, lo + SORT_TILE);
+    for (uint32_t i = lo + t; i < hi; i += 256) {
+        uint32_t d = dig[(size_t)w * n + i];
+        if (d != DIG_NONE) atomicAdd(&lh[(d & 0x7FFFFFFFu) >> lowb], 1u);
+    }
+    __syncthreads();
+    if (t < nsuper) bh[((size_t)w * nsuper + t) * ntile + tile] = lh[t];
+}
+
+// tmp_idx / tmp_key: digits grouped by (window, super-bucket); order inside a group is arbitrary
+__global__ __launch_bounds__(256) void msm_sort_split(const uint32_t *__restrict__ dig, uint32_t n, uint32_t lowb, uint32_t nsuper, uint32_t ntile,
+                                                      const uint32_t *__restrict__ bo, uint32_t *__restrict__ tmp_idx,
+                                                      uint8_t *__restrict__ tmp_key) {
+    __shared__ uint32_t cur[128];
+    const uint32_t tile = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
+    if (t < nsuper) cur[t] = bo[((size_t)w * nsuper + t) * ntile + tile];
+    __syncthreads();
+    const uint32_t lo = tile * SORT_TILE, hi = min(n, lo + SORT_TILE);
+    const uint32_t lmask = (1u << lowb) - 1;
+    for (uint32_t i = lo + t; i < hi; i += 256) {
+        uint32_t d = dig[(size_t)w * n + i];
+        if (d == DIG_NONE) continue;
+        uint32_t key = d & 0x7FFFFFFFu;
+        uint32_t pos = atomicAdd(&cur[key >> lowb], 1u);
+        tmp_idx[pos] = i | (d & 0x80000000u);
+        tmp_key[pos] = (uint8_t)(key & lmask);
+    }
+}
+
+// one workgroup per (window, super-bucket): final order + bucket offsets.  offs[w * B + sb * 2^lowb + lo].
+__global__ __launch_bounds__(256) void msm_sort_final(const uint32_t *__restrict__ tmp_idx, const uint8_t *__restrict__ tmp_key, uint32_t lowb,
+                                                      uint32_t nsuper, uint32_t ntile, uint32_t ngroups, const uint32_t *__restrict__ bo,
+                                                      uint32_t *__restrict__ offs, uint32_t *__restrict__ idx) {
+    __shared__ uint32_t cnt[256];
+    __shared__ uint32_t scan[256];
+    const uint32_t grp = blockIdx.x, t = threadIdx.x;  // grp = w * nsuper + sb
+    const uint32_t start = bo[(size_t)grp * ntile];
+    const uint32_t end = bo[(size_t)(grp + 1) * ntile];  // bo has one trailing entry = total (grp + 1 == ngroups)
+    const uint32_t nlow = 1u << lowb;
+    cnt[t] = 0;
+    __syncthreads();
+    for (uint32_t k = start + t; k < end; k += 256) atomicAdd(&cnt[tmp_key[k]], 1u);
+    __syncthreads();
+    uint32_t mine = cnt[t];
+    scan[t] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        uint32_t x = t >= d ? scan[t - d] : 0;
+        __syncthreads();
+        scan[t] += x;
+        __syncthreads();
+    }
+    uint32_t excl = start + scan[t] - mine;
+    if (t < nlow) offs[(size_t)grp * nlow + t] = excl;
+    if (grp + 1 == ngroups && t == 0) offs[(size_t)ngroups * nlow] = end;
+    cnt[t] = excl;  // running cursor
+    __syncthreads();
+    for (uint32_t k = start + t; k < end; k += 256) {
+        uint32_t pos = atomicAdd(&cnt[tmp_key[k]], 1u);
+        idx[pos] = tmp_idx[k];
+    }
 }
 
 // One lane per (window, bucket).  With precomputed window tables (tab_stride != 0) window w gathers from
@@ -540,14 +629,19 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     const int Wr = tables ? 1 : W;  // windows left after the equal-weight merge
     uint32_t L = std::min<uint32_t>(B, 1u << std::max(0, ctx->opt_msm_segment_log));  // 8 buckets per segment by default
     const uint32_t nseg = B / L;
-    const uint32_t nblk = (nb + 1023) / 1024;
+    // two-level LDS counting sort (see msm_sort_*): low 8 bits inside a super-bucket, the rest across super-buckets
+    const uint32_t lowb = (uint32_t)std::min(8, c - 1), nsuper = 1u << ((c - 1) - lowb);
+    const uint32_t ntile = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE), ngroups = (uint32_t)W * nsuper;
+    const uint32_t nbh = ngroups * ntile, nblk = (nbh + 1023) / 1024;
 
     size_t need = 0;
     need += zkhip_ctx::ws_round((size_t)W * n * 4);        // dig
-    need += zkhip_ctx::ws_round((size_t)nb * 4);           // hist
-    need += zkhip_ctx::ws_round(((size_t)nb + 1) * 4);     // offs
-    need += zkhip_ctx::ws_round((size_t)nb * 4);           // cursor
+    need += zkhip_ctx::ws_round((size_t)nbh * 4);          // per-tile super-bucket histogram
+    need += zkhip_ctx::ws_round(((size_t)nbh + 1) * 4);    // its exclusive scan
     need += zkhip_ctx::ws_round((size_t)nblk * 4);         // block sums
+    need += zkhip_ctx::ws_round((size_t)W * n * 4);        // tmp_idx
+    need += zkhip_ctx::ws_round((size_t)W * n);            // tmp_key
+    need += zkhip_ctx::ws_round(((size_t)nb + 1) * 4);     // offs
     need += zkhip_ctx::ws_round((size_t)W * n * 4);        // idx
     need += zkhip_ctx::ws_round((size_t)nb * 4 * NL * 4);  // buckets
     need += zkhip_ctx::ws_round((size_t)W * nseg * 4 * NL * 4);
@@ -561,10 +655,12 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     ZK_TRY(ctx->ws_reserve(need));
     ctx->ws_reset();
     uint32_t *dig = ctx->ws_take<uint32_t>((size_t)W * n);
-    uint32_t *hist = ctx->ws_take<uint32_t>(nb);
-    uint32_t *offs = ctx->ws_take<uint32_t>((size_t)nb + 1);
-    uint32_t *cursor = ctx->ws_take<uint32_t>(nb);
+    uint32_t *bh = ctx->ws_take<uint32_t>(nbh);
+    uint32_t *bo = ctx->ws_take<uint32_t>((size_t)nbh + 1);
     uint32_t *bsums = ctx->ws_take<uint32_t>(nblk);
+    uint32_t *tmp_idx = ctx->ws_take<uint32_t>((size_t)W * n);
+    uint8_t *tmp_key = ctx->ws_take<uint8_t>((size_t)W * n);
+    uint32_t *offs = ctx->ws_take<uint32_t>((size_t)nb + 1);
     uint32_t *idx = ctx->ws_take<uint32_t>((size_t)W * n);
     uint32_t *buckets = ctx->ws_take<uint32_t>((size_t)nb * 4 * NL);
     uint32_t *segsum = ctx->ws_take<uint32_t>((size_t)W * nseg * 4 * NL);
@@ -577,13 +673,14 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     const uint32_t *d_b = bases->d + offset * bases->stride_u32;
     const size_t tab_stride_words = tables ? bases->n * bases->stride_u32 : 0;
 
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(hist, 0, (size_t)nb * 4, ctx->stream));
     unsigned gn = (unsigned)((n + 255) / 256);
-    ZK_LAUNCH(ctx, "msm_digits", msm_digits, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, c, W, dig, hist);
-    ZK_LAUNCH(ctx, "msm_scan", msm_scan_local, dim3(nblk), dim3(256), 0, hist, nb, offs, bsums);
-    ZK_LAUNCH(ctx, "msm_scan", msm_scan_top, dim3(1), dim3(1024), 0, bsums, nblk, offs + nb);
-    ZK_LAUNCH(ctx, "msm_scan", msm_scan_add, dim3(nblk), dim3(256), 0, offs, nb, bsums, cursor);
-    ZK_LAUNCH(ctx, "msm_scatter", msm_scatter, dim3(gn, W), dim3(256), 0, dig, (uint32_t)n, c, cursor, idx);
+    ZK_LAUNCH(ctx, "msm_digits", msm_digits_only, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, c, W, dig);
+    ZK_LAUNCH(ctx, "msm_sort_hist", msm_sort_hist, dim3(ntile, W), dim3(256), 0, dig, (uint32_t)n, lowb, nsuper, ntile, bh);
+    ZK_LAUNCH(ctx, "msm_scan", msm_scan_local, dim3(nblk), dim3(256), 0, bh, nbh, bo, bsums);
+    ZK_LAUNCH(ctx, "msm_scan", msm_scan_top, dim3(1), dim3(1024), 0, bsums, nblk, bo + nbh);
+    ZK_LAUNCH(ctx, "msm_scan", msm_scan_add, dim3(nblk), dim3(256), 0, bo, nbh, bsums, bo);
+    ZK_LAUNCH(ctx, "msm_sort_split", msm_sort_split, dim3(ntile, W), dim3(256), 0, dig, (uint32_t)n, lowb, nsuper, ntile, bo, tmp_idx, tmp_key);
+    ZK_LAUNCH(ctx, "msm_sort_final", msm_sort_final, dim3(ngroups), dim3(256), 0, tmp_idx, tmp_key, lowb, nsuper, ntile, ngroups, bo, offs, idx);
     {
         // G1 kernels fit two waves per SIMD: 512-lane workgroups sort 512 buckets by size; the Fq2 kernels need 256
         constexpr int AT = FieldOps<F>::WORDS <= 16 ? MSM_G1_THREADS : 256;
