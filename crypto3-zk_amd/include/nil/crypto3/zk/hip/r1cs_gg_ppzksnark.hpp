@@ -243,6 +243,23 @@ public:
     device_r1cs<CurveType> constraint_system;
     std::shared_ptr<void> d_B_indices;
     std::size_t B_count = 0;
+
+    /// per-proof device buffers, kept across proofs: (1, x, w), coefficients_for_H, witness-map scratch, gathered B
+    /// scalars, the five Jacobian MSM results
+    mutable std::shared_ptr<void> d_cpa, d_h, d_scratch, d_bs, d_results;
+    mutable std::vector<std::uint64_t> h_cpa;
+    void reserve_work(std::size_t cpa_elems, std::size_t degree, std::size_t result_bytes) const {
+        if (d_cpa && work_cpa_ >= cpa_elems) return;
+        d_cpa = ctx.alloc(cpa_elems * 32);
+        d_h = ctx.alloc((degree + 1) * 32);
+        d_scratch = ctx.alloc(zkhip_groth16_scratch_bytes(constraint_system.get()));
+        d_bs = ctx.alloc(std::max<std::size_t>(1, B_count) * 32);
+        d_results = ctx.alloc(result_bytes);
+        work_cpa_ = cpa_elems;
+    }
+
+private:
+    mutable std::size_t work_cpa_ = 0;
 };
 
 // ---- r1cs_gg_ppzksnark_prover<CurveType, basic>::process -------------------------------------------------------
@@ -270,23 +287,45 @@ public:
         const std::size_t num_variables = primary_input.size() + auxiliary_input.size();
         const std::size_t degree = pk.constraint_system.domain_size();
 
-        /* qap_wit.coefficients_for_H, and const_padded_assignment = (1, x, w), both resident (prover.hpp:79-106) */
-        std::shared_ptr<void> d_cpa;
-        std::shared_ptr<void> d_h =
-            r1cs_to_qap_hip<CurveType>::witness_map(ctx, pk.constraint_system, pk.domain, primary_input, auxiliary_input, d_cpa);
-        const char *cpa = static_cast<const char *>(d_cpa.get());
+        /* Everything below is enqueued on the context's stream without intermediate synchronisation; the device
+           buffers live in the key object (allocated on first use) so a proof costs no hipMalloc. */
+        const std::size_t jl1 = 3 * adapter::g1_coord_limbs, jl2 = 3 * adapter::g2_coord_limbs;
+        pk.reserve_work(num_variables + 1, degree, (4 * jl1 + jl2) * 8);
+        char *cpa = static_cast<char *>(pk.d_cpa.get());
+        std::uint64_t *d_res = static_cast<std::uint64_t *>(pk.d_results.get());
 
+        /* const_padded_assignment = (1, x, w) (prover.hpp:102-106) */
+        std::vector<std::uint64_t> &z = pk.h_cpa;
+        z.assign(4 * (num_variables + 1), 0);
+        z[0] = 1;
+        std::size_t zi = 1;
+        for (const auto &v : primary_input) adapter::scalar_to_limbs(v, &z[4 * zi++]);
+        for (const auto &v : auxiliary_input) adapter::scalar_to_limbs(v, &z[4 * zi++]);
+        ctx.h2d(cpa, z.data(), z.size() * 8);
+        /* qap_wit.coefficients_for_H, resident (prover.hpp:79-83) */
+        std::uint64_t w[4], g[4];
+        adapter::scalar_to_limbs(pk.domain.omega, w);
+        adapter::scalar_to_limbs(pk.domain.coset_generator, g);
+        check(zkhip_groth16_witness_h_dev(ctx.get(), pk.constraint_system.get(), cpa, w, g, pk.d_h.get(), pk.d_scratch.get()),
+              "zkhip_groth16_witness_h_dev", ctx.get());
         /* evaluation_At (prover.hpp:108-114) */
-        auto evaluation_At = multiexp_dev<CurveType, ZKHIP_G1>(ctx, pk.A_query, 0, num_variables + 1, cpa);
+        check(zkhip_msm_dev(ctx.get(), pk.A_query.get(), 0, num_variables + 1, cpa, d_res), "zkhip_msm_dev(A)", ctx.get());
         /* evaluation_Bt: kc_multiexp_with_mixed_addition over the sparse (G2, G1) query (prover.hpp:116-123) */
-        auto d_bs = ctx.alloc(std::max<std::size_t>(1, pk.B_count) * 32);
-        check(zkhip_fr_gather_dev(ctx.get(), cpa, pk.d_B_indices.get(), pk.B_count, d_bs.get()), "zkhip_fr_gather_dev", ctx.get());
-        auto evaluation_Bt_g = multiexp_dev<CurveType, ZKHIP_G2>(ctx, pk.B_query_g, 0, pk.B_count, d_bs.get());
-        auto evaluation_Bt_h = multiexp_dev<CurveType, ZKHIP_G1>(ctx, pk.B_query_h, 0, pk.B_count, d_bs.get());
+        check(zkhip_fr_gather_dev(ctx.get(), cpa, pk.d_B_indices.get(), pk.B_count, pk.d_bs.get()), "zkhip_fr_gather_dev", ctx.get());
+        check(zkhip_msm_dev(ctx.get(), pk.B_query_h.get(), 0, pk.B_count, pk.d_bs.get(), d_res + jl1), "zkhip_msm_dev(B.h)", ctx.get());
+        check(zkhip_msm_dev(ctx.get(), pk.B_query_g.get(), 0, pk.B_count, pk.d_bs.get(), d_res + 4 * jl1), "zkhip_msm_dev(B.g)", ctx.get());
         /* evaluation_Ht over H_query[0 .. degree - 1) (prover.hpp:125-131) */
-        auto evaluation_Ht = multiexp_dev<CurveType, ZKHIP_G1>(ctx, pk.H_query, 0, degree - 1, d_h.get());
+        check(zkhip_msm_dev(ctx.get(), pk.H_query.get(), 0, degree - 1, pk.d_h.get(), d_res + 2 * jl1), "zkhip_msm_dev(H)", ctx.get());
         /* evaluation_Lt over the auxiliary part of the assignment (prover.hpp:133-139) */
-        auto evaluation_Lt = multiexp_dev<CurveType, ZKHIP_G1>(ctx, pk.L_query, 0, num_variables - num_inputs, cpa + 32 * (num_inputs + 1));
+        check(zkhip_msm_dev(ctx.get(), pk.L_query.get(), 0, num_variables - num_inputs, cpa + 32 * (num_inputs + 1), d_res + 3 * jl1),
+              "zkhip_msm_dev(L)", ctx.get());
+        std::vector<std::uint64_t> res(4 * jl1 + jl2);
+        ctx.d2h(res.data(), d_res, res.size() * 8);    // the one synchronisation of the proof
+        auto evaluation_At = adapter::g1_from_jacobian(&res[0]);
+        auto evaluation_Bt_h = adapter::g1_from_jacobian(&res[jl1]);
+        auto evaluation_Ht = adapter::g1_from_jacobian(&res[2 * jl1]);
+        auto evaluation_Lt = adapter::g1_from_jacobian(&res[3 * jl1]);
+        auto evaluation_Bt_g = adapter::g2_from_jacobian(&res[4 * jl1]);
 
         const auto &k = pk.host;
         /* A = alpha + sum_i(a_i*A_i(t)) + r*delta */
