@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=LOG_N, help="points per GPU = 2^log_n (default: the BASELINE size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-groth16", action="store_true", help="skip the Groth16 constraints/s leg (N = 1 only)")
     args = ap.parse_args()
 
     import numpy as np
@@ -149,6 +150,9 @@ def main():
                          "avg_launch_ms": round(dom_avg_ms, 4), "algorithmic_bytes_per_launch": ALG_BYTES_PER_POINT * n},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
         }
+        line["roofline"]["traffic"] = pmc_traffic()
+        if world == 1 and not args.no_groth16:
+            line["groth16"] = groth16_leg(np)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(np, bases)
         print(json.dumps(line), flush=True)
@@ -157,6 +161,50 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc_msm_bench.json): 2 x FETCH_SIZE (gfx950 reports half the bytes of 16-B-per-lane reads; the
+    factor reproduces the expected 16 x 2^20 x 128 B of point gathers + index reads to within 15 %) + WRITE_SIZE."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_msm_bench.json")
+    try:
+        k = json.load(open(path))["kernels"]
+        name = next(n for n in k if n.startswith("msm_bucket_acc"))
+        return int((2 * k[name]["FETCH_SIZE"]["mean_per_launch"] + k[name]["WRITE_SIZE"]["mean_per_launch"]) * 1024)
+    except Exception:
+        return None
+
+
+def groth16_leg(np, log_constraints=20, inputs=10, steps=3):
+    """The other half of BASELINE.json's metric: Groth16 prove constraints/s on one GPU (config 4's single-GPU leg:
+    M = 2^20, n = 10, domain 2^21) through the header-only shim, assignment H2D and result D2H included."""
+    import ctypes
+    import subprocess
+
+    so = os.path.join(ROOT, "crypto3-zk_amd", "libzkhip_bench.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "crypto3-zk_amd"), "libzkhip_bench.so"], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(so)
+    r, g = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001, 7
+    M = 1 << log_constraints
+    m = 1
+    while m < M + inputs + 1:
+        m <<= 1
+    lim = lambda v: np.array([(v >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+    omega, coset = lim(pow(g, (r - 1) // m, r)), lim(g)
+    times = np.zeros(steps, dtype=np.float64)
+    setup = ctypes.c_double()
+    prof = ctypes.create_string_buffer(16384)
+    rc = lib.zkhip_bench_groth16(0, ctypes.c_size_t(M), ctypes.c_size_t(inputs), ctypes.c_uint64(1), steps, omega.ctypes.data_as(ctypes.c_void_p),
+                                 coset.ctypes.data_as(ctypes.c_void_p), times.ctypes.data_as(ctypes.c_void_p), ctypes.byref(setup), prof,
+                                 ctypes.c_size_t(16384))
+    if rc != 0:
+        return {"error": rc}
+    best = float(times[1:].min())
+    return {"metric": "Groth16 prove constraints/sec, BLS12-381, 2^%d constraints, 1 GPU" % log_constraints, "value": round(M / best * 1e3, 1),
+            "unit": "constraints/s", "ms_per_proof": [round(float(x), 2) for x in times], "domain": m,
+            "key": "synthetic (random multiples of the generators, resident)", "key_setup_ms": round(setup.value, 1)}
 
 
 def cpu_baseline(np, bases):
