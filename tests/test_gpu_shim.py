@@ -35,7 +35,7 @@ def P(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-@pytest.mark.parametrize("curve,M,n", [(1, 1024, 10), (0, 1024, 10), (0, 100, 10)])
+@pytest.mark.parametrize("curve,M,n", [(1, 1024, 10), (0, 1024, 10), (0, 100, 10), (0, 1 << 15, 10)])
 def test_groth16_prover_shim(shim, curve, M, n):
     C = CURVES[curve]
     g = cp.Groth16(curve, M, n, seed=1)

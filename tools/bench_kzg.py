@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""BASELINE config 5's commitment leg on one GPU: KZG commit of `cols` witness columns of 2^log_n rows
+(placeholder's commit(VARIABLE_VALUES_BATCH): per column one inverse NTT + one G1 MSM against the resident SRS,
+kzg.hpp:427-435 / kzg_v2.hpp:208-226).  Columns and SRS resident; one batched iNTT, then one MSM per column."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--cols", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=2)
+    a = ap.parse_args()
+    zk = bench.load_pkg()
+    ctx = zk.Context(0)
+    n = 1 << a.log_n
+    r = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    lim = lambda v: np.array([(v >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+    omega = lim(pow(7, (r - 1) >> a.log_n, r))
+    # SRS alpha^i G with alpha = 7 (placeholder.cpp:175): powers by repeated multiplication in Python ints
+    alpha, x, pw = 7, 1, np.empty((n, 4), dtype=np.uint64)
+    for i in range(n):
+        pw[i] = lim(x)
+        x = x * alpha % r
+    t0 = time.time()
+    srs = ctx.bases_from_scalars(zk.BLS12_381, zk.G1, pw)
+    t_srs = time.time() - t0
+    cols = bench.random_scalars(np, n * a.cols, 5).reshape(a.cols, n, 4)
+    d = ctx.malloc(cols.nbytes)
+    d_out = ctx.malloc(a.cols * 144)
+    times = []
+    for s in range(a.steps + 1):
+        ctx.h2d(d, cols)
+        if s == a.steps:
+            ctx.profile_reset()
+            ctx.profile(True)
+        t0 = time.perf_counter()
+        ctx.ntt_dev(zk.BLS12_381, d, a.log_n, a.cols, omega, inverse=True)
+        for c in range(a.cols):
+            ctx.msm_dev(srs, d + 32 * n * c, d_out + 144 * c, 0, n)
+        ctx.sync()
+        times.append((time.perf_counter() - t0) * 1e3)
+    ctx.profile(False)
+    prof = ctx.profile_dump()
+    best = min(times[1:])
+    print(json.dumps({"workload": "KZG commit of %d columns x 2^%d rows (BLS12-381), 1 GPU, columns and SRS resident" % (a.cols, a.log_n),
+                      "ms": [round(t, 2) for t in times], "columns_per_s": round(a.cols / best * 1e3, 2), "srs_setup_s": round(t_srs, 2),
+                      "kernel_ms": {k: round(v[0], 2) for k, v in sorted(prof.items())}}))
+
+
+if __name__ == "__main__":
+    main()
