@@ -39,8 +39,8 @@ using namespace zkhip;
 static constexpr uint32_t MSM_LARGE_BUCKET = 128;  // buckets above this many entries are split across workgroups
 static constexpr uint32_t MSM_LARGE_CHUNK = 4096;  // entries per task of a split bucket
 #ifndef MSM_G1_THREADS
-#define MSM_G1_THREADS 512
-#define MSM_G1_WAVES 2
+#define MSM_G1_THREADS 256
+#define MSM_G1_WAVES 3
 #endif
 
 __global__ __launch_bounds__(256) void msm_digits(const uint32_t *__restrict__ scalars, uint32_t n, int c, int W,
@@ -225,41 +225,49 @@ __global__ __launch_bounds__(256) void msm_sort_final(const uint32_t *__restrict
     }
 }
 
+// ---- order of buckets by descending size (counting sort, counters in LDS) --------------------------------------
+// Lanes of a wave run in lockstep (a wave costs the largest bucket among its 64) and a workgroup holds its
+// registers until its last wave retires, so buckets are handed out in globally sorted order: every wave and every
+// workgroup sees near-equal trip counts, long buckets start first, empty and large (split elsewhere) buckets
+// collect at the end.  bin = LARGE - size for 1 <= size <= LARGE, last bin otherwise.
+static constexpr uint32_t SIZE_BINS = MSM_LARGE_BUCKET + 1;
+
+ZK_D uint32_t size_bin(uint32_t size) { return (size != 0 && size <= MSM_LARGE_BUCKET) ? MSM_LARGE_BUCKET - size : MSM_LARGE_BUCKET; }
+
+__global__ __launch_bounds__(256) void msm_size_hist(const uint32_t *__restrict__ offs, uint32_t nbuckets, uint32_t nblocks,
+                                                     uint32_t *__restrict__ bh) {
+    __shared__ uint32_t lh[SIZE_BINS];
+    const uint32_t t = threadIdx.x;
+    if (t < SIZE_BINS) lh[t] = 0;
+    __syncthreads();
+    for (uint32_t g = blockIdx.x * 1024 + t; g < min(nbuckets, (blockIdx.x + 1) * 1024); g += 256)
+        atomicAdd(&lh[size_bin(offs[g + 1] - offs[g])], 1u);
+    __syncthreads();
+    if (t < SIZE_BINS) bh[(size_t)t * nblocks + blockIdx.x] = lh[t];
+}
+
+__global__ __launch_bounds__(256) void msm_size_scatter(const uint32_t *__restrict__ offs, uint32_t nbuckets, uint32_t nblocks,
+                                                        const uint32_t *__restrict__ bo, uint32_t *__restrict__ order) {
+    __shared__ uint32_t cur[SIZE_BINS];
+    const uint32_t t = threadIdx.x;
+    if (t < SIZE_BINS) cur[t] = bo[(size_t)t * nblocks + blockIdx.x];
+    __syncthreads();
+    for (uint32_t g = blockIdx.x * 1024 + t; g < min(nbuckets, (blockIdx.x + 1) * 1024); g += 256)
+        order[atomicAdd(&cur[size_bin(offs[g + 1] - offs[g])], 1u)] = g;
+}
+
 // One lane per (window, bucket).  With precomputed window tables (tab_stride != 0) window w gathers from
 // table w, whose entry i is 2^(c w) P_i, so that all windows feed buckets of equal weight.
 template <class F, int MSM_ACC_THREADS, int MSM_ACC_WAVES>
 __global__ __launch_bounds__(MSM_ACC_THREADS, MSM_ACC_WAVES) void msm_bucket_acc(const uint32_t *__restrict__ bases, size_t tab_stride_words, uint32_t B,
                                                       const uint32_t *__restrict__ offs, const uint32_t *__restrict__ idx, uint32_t nbuckets,
-                                                      uint32_t *__restrict__ buckets) {
+                                                      const uint32_t *__restrict__ order, uint32_t *__restrict__ buckets) {
     constexpr int NL = FieldOps<F>::WORDS;
-    // Lanes of a wave run in lockstep, so a wave costs max(bucket size) over its 64 buckets.  The workgroup's
-    // buckets are therefore handed out in descending order of size (counting sort over the sizes in LDS):
-    // waves see near-equal trip counts and the empty / large (skipped) buckets collect in the last waves.
-    __shared__ uint32_t bin_start[MSM_LARGE_BUCKET + 2];
-    __shared__ uint32_t order[MSM_ACC_THREADS];
-    const uint32_t tid = threadIdx.x, gbase = blockIdx.x * blockDim.x;
-    for (uint32_t i = tid; i < MSM_LARGE_BUCKET + 2; i += blockDim.x) bin_start[i] = 0;
-    __syncthreads();
-    uint32_t my_g = gbase + tid, my_bin = MSM_LARGE_BUCKET + 1;  // bins by descending size; last bin = nothing to do
-    if (my_g < nbuckets) {
-        uint32_t size = offs[my_g + 1] - offs[my_g];
-        if (size != 0 && size <= MSM_LARGE_BUCKET) my_bin = MSM_LARGE_BUCKET - size;
-    }
-    uint32_t rank = atomicAdd(&bin_start[my_bin], 1u);
-    __syncthreads();
-    if (tid == 0) {  // exclusive scan of 130 counters
-        uint32_t run = 0;
-        for (uint32_t i = 0; i < MSM_LARGE_BUCKET + 2; ++i) {
-            uint32_t c = bin_start[i];
-            bin_start[i] = run;
-            run += c;
-        }
-    }
-    __syncthreads();
-    order[bin_start[my_bin] + rank] = my_g;
-    __syncthreads();
-    const uint32_t g = order[tid];
-    if (g >= nbuckets) return;
+    // `order` lists the buckets by descending size (msm_size_*): lanes of a wave, and waves of a workgroup, get
+    // near-equal trip counts, and the long buckets are dispatched first.
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nbuckets) return;
+    const uint32_t g = order[slot];
     const uint32_t *tab = bases + (size_t)(g / B) * tab_stride_words;
     uint32_t lo = offs[g], hi = offs[g + 1];
     if (hi - lo > MSM_LARGE_BUCKET) return;  // split across workgroups by msm_bucket_large (empty: written below)
@@ -352,6 +360,101 @@ __global__ __launch_bounds__(64) void msm_large_combine(const uint32_t *__restri
         for (uint32_t t = 0; t < nt; ++t) acc = xyzz_add(acc, xyzz_load<F>(partials + (size_t)(first + t) * (4 * NL)));
         xyzz_store<F>(buckets + (size_t)g * (4 * NL), acc);
     }
+}
+
+// ---- bucket accumulation with the accumulator in LDS (G1) ------------------------------------------------------
+// A wave issues one VALU instruction per ~4 cycles, so throughput scales with waves per SIMD (measured linear up to
+// 4, tools/mulbench).  Holding X, Y, ZZ of the running sum in LDS (conflict-free [coord][quad][lane] uint4 planes)
+// instead of VGPRs brings the kernel under 168 registers: three waves per SIMD instead of two.  ZZZ stays in
+// registers; the mixed addition reads the LDS coordinates where it uses them and writes the results back.
+template <class F, int NT>
+struct LdsAcc {
+    static constexpr int Q = FieldOps<F>::WORDS / 4;  // uint4 per coordinate
+    uint4 *base;                                      // [3][Q][NT]
+    uint32_t t;
+    ZK_D F get(int coord) const {
+        uint32_t w[FieldOps<F>::WORDS];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            uint4 v = base[(coord * Q + q) * NT + t];
+            w[4 * q] = v.x, w[4 * q + 1] = v.y, w[4 * q + 2] = v.z, w[4 * q + 3] = v.w;
+        }
+        F r;
+#pragma unroll
+        for (int i = 0; i < F::L; ++i) r.v[i] = w[i];
+        return r;
+    }
+    ZK_D void put(int coord, const F &x) const {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            uint4 v;
+            v.x = 4 * q + 0 < F::L ? x.v[4 * q + 0] : 0u;
+            v.y = 4 * q + 1 < F::L ? x.v[4 * q + 1] : 0u;
+            v.z = 4 * q + 2 < F::L ? x.v[4 * q + 2] : 0u;
+            v.w = 4 * q + 3 < F::L ? x.v[4 * q + 3] : 0u;
+            base[(coord * Q + q) * NT + t] = v;
+        }
+    }
+};
+
+template <class F, int NT>
+__global__ __launch_bounds__(NT, 3) void msm_bucket_acc_lds(const uint32_t *__restrict__ bases, size_t tab_stride_words, uint32_t B,
+                                                           const uint32_t *__restrict__ offs, const uint32_t *__restrict__ idx, uint32_t nbuckets,
+                                                           const uint32_t *__restrict__ order, uint32_t *__restrict__ buckets) {
+    typedef FieldOps<F> O;
+    constexpr int NL = O::WORDS;
+    extern __shared__ __attribute__((aligned(16))) uint4 acc_lds[];
+    const uint32_t tid = threadIdx.x, slot = blockIdx.x * NT + tid;
+    if (slot >= nbuckets) return;
+    const uint32_t g = order[slot];  // buckets by descending size (msm_size_*)
+    const uint32_t *tab = bases + (size_t)(g / B) * tab_stride_words;
+    const uint32_t lo = offs[g], hi = offs[g + 1];
+    if (hi - lo > MSM_LARGE_BUCKET) return;
+    LdsAcc<F, NT> A = {acc_lds, tid};
+    enum { CX = 0, CY = 1, CZZ = 2 };
+    F ZZZ = F::zero();
+    bool inf = true;
+    for (uint32_t k = lo; k < hi; ++k) {
+        const uint32_t e = idx[k];
+        Affine<F> p = affine_load<F>(tab + (size_t)(e & 0x7FFFFFFFu) * (2 * NL));
+        if (p.is_inf()) continue;
+        if (e >> 31) p.y = O::template sub<O::K1>(F::zero(), p.y);
+        if (inf) {
+            A.put(CX, p.x);
+            A.put(CY, p.y);
+            A.put(CZZ, F::one());
+            ZZZ = F::one();
+            inf = false;
+            continue;
+        }
+        // xyzz_madd (curve.hpp) with X, Y, ZZ fetched from LDS at their points of use
+        F Pd = O::template sub<O::K2>(O::mul(p.x, A.get(CZZ)), A.get(CX));
+        F R = O::template sub<O::K2>(O::mul(p.y, ZZZ), A.get(CY));
+        F PP = O::sqr(Pd);
+        if (O::is_zero_product(PP)) {  // same x: doubling or cancellation (rare)
+            if (O::is_zero(R)) {
+                XYZZ<F> d = xyzz_dbl_affine(p);
+                A.put(CX, d.X);
+                A.put(CY, d.Y);
+                A.put(CZZ, d.ZZ);
+                ZZZ = d.ZZZ;
+            } else {
+                inf = true;
+            }
+            continue;
+        }
+        F PPP = O::mul(Pd, PP);
+        F Q = O::mul(A.get(CX), PP);
+        F X3 = O::template sub<O::K1>(O::sqr(R), O::add(PPP, O::add(Q, Q)));
+        F Y3 = O::template sub<O::K1>(O::mul(R, O::template sub<O::K2>(Q, X3)), O::mul(A.get(CY), PPP));
+        A.put(CX, X3);
+        A.put(CY, Y3);
+        A.put(CZZ, O::mul(A.get(CZZ), PP));
+        ZZZ = O::mul(ZZZ, PPP);
+    }
+    XYZZ<F> out = XYZZ<F>::infinity();
+    if (!inf) out = {A.get(CX), A.get(CY), A.get(CZZ), ZZZ};
+    xyzz_store<F>(buckets + (size_t)g * (4 * NL), out);
 }
 
 // buckets[w][b] += buckets[w + half][b] for w < cnt (one level of the tree that folds equal-weight windows)
@@ -644,6 +747,8 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     need += zkhip_ctx::ws_round(((size_t)nb + 1) * 4);     // offs
     need += zkhip_ctx::ws_round((size_t)W * n * 4);        // idx
     need += zkhip_ctx::ws_round((size_t)nb * 4 * NL * 4);  // buckets
+    const uint32_t sblk = (nb + 1023) / 1024, nsh = SIZE_BINS * sblk, sblk2 = (nsh + 1023) / 1024;
+    need += 2 * zkhip_ctx::ws_round(((size_t)nsh + 1) * 4) + zkhip_ctx::ws_round((size_t)sblk2 * 4) + zkhip_ctx::ws_round((size_t)nb * 4);  // size sort
     need += zkhip_ctx::ws_round((size_t)W * nseg * 4 * NL * 4);
     need += zkhip_ctx::ws_round((size_t)W * 4 * NL * 4);
     // worst-case plan of the large-bucket path: every entry in a large bucket
@@ -663,6 +768,10 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     uint32_t *offs = ctx->ws_take<uint32_t>((size_t)nb + 1);
     uint32_t *idx = ctx->ws_take<uint32_t>((size_t)W * n);
     uint32_t *buckets = ctx->ws_take<uint32_t>((size_t)nb * 4 * NL);
+    uint32_t *sh = ctx->ws_take<uint32_t>((size_t)nsh + 1);
+    uint32_t *so = ctx->ws_take<uint32_t>((size_t)nsh + 1);
+    uint32_t *ssums = ctx->ws_take<uint32_t>(sblk2);
+    uint32_t *order = ctx->ws_take<uint32_t>(nb);
     uint32_t *segsum = ctx->ws_take<uint32_t>((size_t)W * nseg * 4 * NL);
     uint32_t *winsum = ctx->ws_take<uint32_t>((size_t)W * 4 * NL);
     uint32_t *plan = ctx->ws_take<uint32_t>(4);
@@ -681,12 +790,27 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     ZK_LAUNCH(ctx, "msm_scan", msm_scan_add, dim3(nblk), dim3(256), 0, bo, nbh, bsums, bo);
     ZK_LAUNCH(ctx, "msm_sort_split", msm_sort_split, dim3(ntile, W), dim3(256), 0, dig, (uint32_t)n, lowb, nsuper, ntile, bo, tmp_idx, tmp_key);
     ZK_LAUNCH(ctx, "msm_sort_final", msm_sort_final, dim3(ngroups), dim3(256), 0, tmp_idx, tmp_key, lowb, nsuper, ntile, ngroups, bo, offs, idx);
-    {
-        // G1 kernels fit two waves per SIMD: 512-lane workgroups sort 512 buckets by size; the Fq2 kernels need 256
-        constexpr int AT = FieldOps<F>::WORDS <= 16 ? MSM_G1_THREADS : 256;
-        constexpr int AW = FieldOps<F>::WORDS <= 16 ? MSM_G1_WAVES : 1;
-        ZK_LAUNCH(ctx, "msm_bucket_acc", (msm_bucket_acc<F, AT, AW>), dim3((nb + AT - 1) / AT), dim3(AT), 0, d_b, tab_stride_words, B, offs, idx, nb,
-                  buckets);
+    // buckets by descending size
+    ZK_LAUNCH(ctx, "msm_size_sort", msm_size_hist, dim3(sblk), dim3(256), 0, offs, nb, sblk, sh);
+    ZK_LAUNCH(ctx, "msm_size_sort", msm_scan_local, dim3(sblk2), dim3(256), 0, sh, nsh, so, ssums);
+    ZK_LAUNCH(ctx, "msm_size_sort", msm_scan_top, dim3(1), dim3(1024), 0, ssums, sblk2, so + nsh);
+    ZK_LAUNCH(ctx, "msm_size_sort", msm_scan_add, dim3(sblk2), dim3(256), 0, so, nsh, ssums, so);
+    ZK_LAUNCH(ctx, "msm_size_sort", msm_size_scatter, dim3(sblk), dim3(256), 0, offs, nb, sblk, so, order);
+    if constexpr (FieldOps<F>::WORDS <= 16) {
+        // G1: accumulator in LDS, three waves per SIMD (256-lane workgroups, three per CU)
+        constexpr int NT = MSM_G1_THREADS;
+        size_t lds_acc = (size_t)3 * (NL / 4) * NT * 16;
+        static bool attr_acc = false;
+        if (!attr_acc) {
+            ZK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&msm_bucket_acc_lds<F, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)lds_acc));
+            attr_acc = true;
+        }
+        ZK_LAUNCH(ctx, "msm_bucket_acc", (msm_bucket_acc_lds<F, NT>), dim3((nb + NT - 1) / NT), dim3(NT), lds_acc, d_b, tab_stride_words, B, offs, idx,
+                  nb, order, buckets);
+    } else {
+        ZK_LAUNCH(ctx, "msm_bucket_acc", (msm_bucket_acc<F, 256, 1>), dim3((nb + 255) / 256), dim3(256), 0, d_b, tab_stride_words, B, offs, idx, nb,
+                  order, buckets);
     }
     // large buckets: plan on the device (no host round trip), then fixed-size grids that read the plan
     ZK_HIP_CHECK(ctx, hipMemsetAsync(plan, 0, 16, ctx->stream));
