@@ -17,7 +17,7 @@ EXPORTS = [
     "zkhip_set_option", "zkhip_malloc", "zkhip_free", "zkhip_memcpy_h2d", "zkhip_memcpy_d2h",
     "zkhip_bases_upload", "zkhip_bases_from_scalars", "zkhip_bases_download", "zkhip_bases_size",
     "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
-    "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_domain_size", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev", "zkhip_fr_gather_dev",
+    "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_domain_size", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev", "zkhip_fr_gather_dev", "zkhip_poly_resize_dev", "zkhip_fri_fold_dev",
     "zkhip_profile_enable", "zkhip_profile_reset", "zkhip_profile_get", "zkhip_profile_dump",
 ]
 

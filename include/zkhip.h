@@ -130,6 +130,17 @@ int zkhip_groth16_witness_h_dev(zkhip_ctx *ctx, const zkhip_r1cs *r, const void 
  * (knowledge_commitment_multiexp.hpp:66-100).  Zero and one scalars need no peeling on the device. */
 int zkhip_fr_gather_dev(zkhip_ctx *ctx, const void *d_src, const void *d_indices, size_t count, void *d_dst);
 
+/* ---- LPC / FRI polynomial helpers on top of the NTT -------------------------------------------------
+ * polynomial_dfs::resize as precommit<FRI> applies it to every committed polynomial
+ * (commitments/detail/polynomial/basic_fri.hpp:452-455): `batch` vectors of 2^log_n evaluations at d_in
+ * (CONSUMED: left holding the coefficients) -> 2^log_out evaluations each at d_out.  omega_n / omega_out are the
+ * primitive roots of the two domains. */
+int zkhip_poly_resize_dev(zkhip_ctx *ctx, int curve, void *d_in, size_t log_n, size_t batch, const uint64_t *omega_n, void *d_out,
+                          size_t log_out, const uint64_t *omega_out);
+/* detail::fold_polynomial, DFS form (commitments/detail/polynomial/fold_polynomial.hpp:68-93):
+ * d_out[i] = 1/2 [(1 + alpha omega^-i) d_f[i] + (1 - alpha omega^-i) d_f[i + size/2]], i < size/2 = 2^(log_size-1). */
+int zkhip_fri_fold_dev(zkhip_ctx *ctx, int curve, const void *d_f, size_t log_size, const uint64_t *alpha, const uint64_t *omega, void *d_out);
+
 /* ---- profiling (HIP events on the context's stream around every kernel launch) ------------------ */
 int zkhip_profile_enable(zkhip_ctx *ctx, int on);
 int zkhip_profile_reset(zkhip_ctx *ctx);

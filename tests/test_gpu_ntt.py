@@ -87,3 +87,47 @@ def test_ntt_full_size_2_22_batch_8(ctx):
     gotc = ctx.ntt(0, a[:2], log_m, w, coset=g)
     assert (gotc == cp.ntt(0, a[:2], log_m, w, coset=g)).all()
     assert (ctx.ntt(0, gotc, log_m, w, inverse=True, coset=g) == a[:2]).all()
+
+
+@pytest.mark.parametrize("curve,log_n,expand", [(0, 8, 2), (1, 6, 1), (0, 12, 3)])
+def test_lpc_resize_and_fold(ctx, zk, curve, log_n, expand):
+    """polynomial_dfs::resize as precommit<FRI> uses it (basic_fri.hpp:452-455) and the DFS fold_polynomial
+    (fold_polynomial.hpp:68-93), against the oracle / the formula on big integers."""
+    import ctypes
+
+    C = CURVES[curve]
+    n, batch = 1 << log_n, 3
+    log_out = log_n + expand
+    m = 1 << log_out
+    wn, wm = limbs(C.root_of_unity(log_n), 4), limbs(C.root_of_unity(log_out), 4)
+    evals = cp.random_fr(curve, 77, batch * n).reshape(batch, n, 4)
+    coeffs = cp.ntt(curve, evals, log_n, wn, inverse=True)
+    padded = np.zeros((batch, m, 4), dtype=np.uint64)
+    padded[:, :n] = coeffs
+    exp = cp.ntt(curve, padded, log_out, wm)
+    d_in, d_out = ctx.malloc(evals.nbytes), ctx.malloc(exp.nbytes)
+    ctx.h2d(d_in, evals)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = ctx.lib.zkhip_poly_resize_dev(ctx.h, curve, ctypes.c_void_p(d_in), ctypes.c_size_t(log_n), ctypes.c_size_t(batch), P(wn),
+                                       ctypes.c_void_p(d_out), ctypes.c_size_t(log_out), P(wm))
+    assert rc == 0
+    got = np.zeros_like(exp)
+    ctx.d2h(got, d_out)
+    assert (got == exp).all()
+    # the extension agrees with the original evaluations on the sub-domain (omega_m^(2^expand) = omega_n)
+    assert (got[:, :: 1 << expand] == evals).all()
+    # fold the first extended polynomial with a random alpha
+    r = C.r
+    alpha = po.SplitMix64(5).next_mod(r)
+    f = fr_ints(got[0])
+    winv = pow(C.root_of_unity(log_out), -1, r)
+    half, inv2 = m // 2, pow(2, -1, r)
+    expf = [inv2 * ((1 + alpha * pow(winv, i, r)) * f[i] + (1 - alpha * pow(winv, i, r)) * f[half + i]) % r for i in range(half)]
+    d_f = ctx.malloc(half * 32)
+    al = limbs(alpha, 4)
+    assert ctx.lib.zkhip_fri_fold_dev(ctx.h, curve, ctypes.c_void_p(d_out), ctypes.c_size_t(log_out), P(al), P(wm), ctypes.c_void_p(d_f)) == 0
+    gotf = np.zeros((half, 4), dtype=np.uint64)
+    ctx.d2h(gotf, d_f)
+    assert fr_ints(gotf) == expf
+    for p in (d_in, d_out, d_f):
+        ctx.free(p)
