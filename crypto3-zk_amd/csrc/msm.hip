@@ -823,7 +823,7 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
                                                   (int)lds_large));
             attr_set = true;
         }
-        unsigned grid_large = (unsigned)std::min<size_t>(task_cap, 2048);
+        unsigned grid_large = (unsigned)std::min<size_t>(task_cap, 512);  // persistent: workgroups loop over the task list
         ZK_LAUNCH(ctx, "msm_bucket_large", msm_bucket_large<F>, dim3(grid_large), dim3(128), lds_large, d_b, tab_stride_words, B, idx, plan, tasks,
                   partials);
         ZK_LAUNCH(ctx, "msm_bucket_large", msm_large_combine<F>, dim3(64), dim3(64), 0, plan, large, partials, buckets);

@@ -112,6 +112,23 @@ int zkhip_memcpy_h2d(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes) {
     ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return ZKHIP_OK;
 }
+int zkhip_memcpy_h2d_async(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return ZKHIP_OK;
+}
+int zkhip_host_alloc(zkhip_ctx *ctx, size_t bytes, void **hptr) {
+    if (!ctx || !hptr) return ZKHIP_ERR_INVALID;
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ZK_HIP_CHECK(ctx, hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return ZKHIP_OK;
+}
+int zkhip_host_free(zkhip_ctx *ctx, void *hptr) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP_CHECK(ctx, hipHostFree(hptr));
+    return ZKHIP_OK;
+}
 int zkhip_memcpy_d2h(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx) return ZKHIP_ERR_INVALID;
     ZK_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));

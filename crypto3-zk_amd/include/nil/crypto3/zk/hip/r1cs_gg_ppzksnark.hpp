@@ -247,10 +247,16 @@ public:
     /// per-proof device buffers, kept across proofs: (1, x, w), coefficients_for_H, witness-map scratch, gathered B
     /// scalars, the five Jacobian MSM results
     mutable std::shared_ptr<void> d_cpa, d_h, d_scratch, d_bs, d_results;
-    mutable std::vector<std::uint64_t> h_cpa;
+    mutable std::shared_ptr<void> h_cpa;    // page-locked staging for (1, x, w): H2D at link speed, asynchronous
     void reserve_work(std::size_t cpa_elems, std::size_t degree, std::size_t result_bytes) const {
         if (d_cpa && work_cpa_ >= cpa_elems) return;
         d_cpa = ctx.alloc(cpa_elems * 32);
+        {
+            void *hp = nullptr;
+            check(zkhip_host_alloc(ctx.get(), cpa_elems * 32, &hp), "zkhip_host_alloc", ctx.get());
+            zkhip_ctx *c = ctx.get();
+            h_cpa = std::shared_ptr<void>(hp, [c](void *p) { zkhip_host_free(c, p); });
+        }
         d_h = ctx.alloc((degree + 1) * 32);
         d_scratch = ctx.alloc(zkhip_groth16_scratch_bytes(constraint_system.get()));
         d_bs = ctx.alloc(std::max<std::size_t>(1, B_count) * 32);
@@ -295,13 +301,13 @@ public:
         std::uint64_t *d_res = static_cast<std::uint64_t *>(pk.d_results.get());
 
         /* const_padded_assignment = (1, x, w) (prover.hpp:102-106) */
-        std::vector<std::uint64_t> &z = pk.h_cpa;
-        z.assign(4 * (num_variables + 1), 0);
+        std::uint64_t *z = static_cast<std::uint64_t *>(pk.h_cpa.get());
         z[0] = 1;
+        z[1] = z[2] = z[3] = 0;
         std::size_t zi = 1;
         for (const auto &v : primary_input) adapter::scalar_to_limbs(v, &z[4 * zi++]);
         for (const auto &v : auxiliary_input) adapter::scalar_to_limbs(v, &z[4 * zi++]);
-        ctx.h2d(cpa, z.data(), z.size() * 8);
+        check(zkhip_memcpy_h2d_async(ctx.get(), cpa, z, 32 * (num_variables + 1)), "zkhip_memcpy_h2d_async", ctx.get());
         /* qap_wit.coefficients_for_H, resident (prover.hpp:79-83) */
         std::uint64_t w[4], g[4];
         adapter::scalar_to_limbs(pk.domain.omega, w);
@@ -319,6 +325,10 @@ public:
         /* evaluation_Lt over the auxiliary part of the assignment (prover.hpp:133-139) */
         check(zkhip_msm_dev(ctx.get(), pk.L_query.get(), 0, num_variables - num_inputs, cpa + 32 * (num_inputs + 1), d_res + 3 * jl1),
               "zkhip_msm_dev(L)", ctx.get());
+        /* host products that do not depend on the MSM results, computed while the GPU works (prover.hpp:142-155) */
+        const auto &k = pk.host;
+        const auto r_delta = r * k.delta_g1, s_delta = s * k.delta_g1, rs_delta = (r * s) * k.delta_g1;
+        const auto s_delta2 = s * k.delta_g2;
         std::vector<std::uint64_t> res(4 * jl1 + jl2);
         ctx.d2h(res.data(), d_res, res.size() * 8);    // the one synchronisation of the proof
         auto evaluation_At = adapter::g1_from_jacobian(&res[0]);
@@ -327,14 +337,13 @@ public:
         auto evaluation_Lt = adapter::g1_from_jacobian(&res[3 * jl1]);
         auto evaluation_Bt_g = adapter::g2_from_jacobian(&res[4 * jl1]);
 
-        const auto &k = pk.host;
         /* A = alpha + sum_i(a_i*A_i(t)) + r*delta */
-        auto g1_A = k.alpha_g1 + evaluation_At + r * k.delta_g1;
+        auto g1_A = k.alpha_g1 + evaluation_At + r_delta;
         /* B = beta + sum_i(a_i*B_i(t)) + s*delta */
-        auto g1_B = k.beta_g1 + evaluation_Bt_h + s * k.delta_g1;
-        auto g2_B = k.beta_g2 + evaluation_Bt_g + s * k.delta_g2;
+        auto g1_B = k.beta_g1 + evaluation_Bt_h + s_delta;
+        auto g2_B = k.beta_g2 + evaluation_Bt_g + s_delta2;
         /* C = sum_i(a_i*((beta*A_i(t) + alpha*B_i(t) + C_i(t)) + H(t)*Z(t))/delta) + A*s + r*b - r*s*delta */
-        auto g1_C = evaluation_Ht + evaluation_Lt + s * g1_A + r * g1_B - (r * s) * k.delta_g1;
+        auto g1_C = evaluation_Ht + evaluation_Lt + s * g1_A + r * g1_B - rs_delta;
         return proof_type {g1_A, g2_B, g1_C};
     }
 

@@ -59,6 +59,11 @@ int zkhip_malloc(zkhip_ctx *ctx, size_t bytes, void **dptr);
 int zkhip_free(zkhip_ctx *ctx, void *dptr);
 int zkhip_memcpy_h2d(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes);
 int zkhip_memcpy_d2h(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* enqueue only (no synchronisation): for pinned host buffers, ordered with the kernels on the context's stream */
+int zkhip_memcpy_h2d_async(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* page-locked host memory: H2D / D2H at link speed instead of through a staging copy */
+int zkhip_host_alloc(zkhip_ctx *ctx, size_t bytes, void **hptr);
+int zkhip_host_free(zkhip_ctx *ctx, void *hptr);
 
 /* ---- resident bases: proving-key queries / SRS ------------------------------------------------
  * Replaces the `bases_begin, bases_end` iterator pair of algebra::multiexp at
