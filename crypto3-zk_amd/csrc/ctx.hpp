@@ -55,7 +55,8 @@ struct zkhip_ctx {
     std::string last_error;
     // bump-allocated workspace, grown on demand, reused across calls
     char *ws = nullptr;
-    size_t ws_cap = 0, ws_off = 0;
+    size_t ws_cap = 0, ws_off = 0, ws_floor = 0;  // ws_floor: start of the per-call region (a batch parks data below it)
+    std::vector<uint32_t *> batch_ptrs;            // host copy of a batch's output pointers (alive until the copy ran)
     // pinned staging for small results
     void *pinned = nullptr;
     size_t pinned_cap = 0;
@@ -90,7 +91,7 @@ struct zkhip_ctx {
         ws_cap = cap;
         return 0;
     }
-    void ws_reset() { ws_off = 0; }
+    void ws_reset() { ws_off = ws_floor; }
     template <class T>
     T *ws_take(size_t count) {
         size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
@@ -144,6 +145,8 @@ struct zkhip_ctx {
 
 // implemented in msm.hip / ntt.hip
 int zk_msm_run(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac);
+int zk_msm_run_batch(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases, const size_t *offsets, const size_t *ns,
+                     const uint32_t *const *d_scalars, uint32_t *const *d_outs);
 size_t zk_coord_limbs64(int curve, int group);  // u64 limbs per coordinate (Fq: 6/4, Fq2: 12/8)
 int zk_bases_to_mont(zkhip_ctx *ctx, zkhip_bases *b, const uint32_t *d_canonical, const uint8_t *d_inf);
 size_t zk_point_words(int curve, int group);

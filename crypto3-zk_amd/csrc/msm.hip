@@ -6,27 +6,32 @@
 //   zk/commitments/polynomial/knowledge_commitment_multiexp.hpp:107     (sparse (G2,G1) query)
 //
 // Data layout in HBM
-//   bases    : n x {x, y}            Montgomery form, u32 limbs, AoS, (0,0) = infinity   (resident)
+//   bases    : ntab tables x n x {x, y}   lazy Montgomery limbs (fu.hpp), 16 words per coordinate, AoS, (0,0) = infinity;
+//                                         table w holds 2^(c w) P_i (built once at upload)                    (resident)
 //   scalars  : n x 8 u32             canonical little-endian
 //   dig      : W x n u32             signed c-bit digit of scalar i in window w: (|d|-1) | sign<<31, NONE if d = 0
-//   hist/offs: W*B (+1) u32          bucket sizes / exclusive prefix (B = 2^(c-1) buckets per window)
+//   offs     : W*B + 1 u32           exclusive prefix of the bucket sizes (B = 2^(c-1) buckets per window)
 //   idx      : (#non-zero digits) u32  point index | sign<<31, grouped by (window, bucket)
+//   order    : W*B u32               bucket ids by descending size
 //   buckets  : W*B XYZZ              bucket sums
-//   segsum   : W*nseg XYZZ           per-segment weighted sums of the bucket reduction
-//   winsum   : W XYZZ                per-window sums
+//   segsum / winsum                  per-segment weighted sums of the bucket reduction / per-window sums
 //
 // Kernels (all integer VALU; no MFMA -- this is modular arithmetic, not a dense contraction):
-//   msm_digits      scalar -> signed digits + bucket histogram      (streams 32 B/scalar, coalesced)
-//   msm_scan        exclusive prefix over W*B counters (local scan, top scan, add-back)
-//   msm_sort_*      two-level counting sort of point indices by (window, bucket), counters in LDS only
-//   msm_bucket_acc  one lane per bucket: gather affine points, XYZZ mixed additions     <- dominant
+//   msm_digits_only   scalar -> signed digits                           (streams 32 B/scalar, coalesced)
+//   msm_sort_*        two-level counting sort of point indices by (window, bucket), counters in LDS only
+//   msm_scan_*        exclusive prefix (local scan, top scan, add-back), shared by both sorts
+//   msm_size_*        order of the buckets by descending size
+//   msm_bucket_acc_lds  one lane per bucket: gather affine points, XYZZ mixed additions, accumulator in LDS   <- dominant
+//   msm_bucket_acc    same with the accumulator in registers (Fq2: G2)
+//   msm_plan_large / msm_bucket_large / msm_large_combine   buckets above 128 entries, one workgroup per 4096-entry task
 //   msm_bucket_merge  with window tables: fold the W equal-weight windows bucket by bucket (log2 W launches)
-//   msm_bucket_red  running-sum reduction of L-bucket segments, weighted by segment offset
-//   msm_window_sum  LDS tree reduction of segment sums, one workgroup per window
-//   msm_final       Horner over the windows, XYZZ -> Jacobian, Montgomery -> canonical
-// Point order inside a bucket depends on atomic arrival order; the group law is exact, so the sum
+//   msm_bucket_red    running-sum reduction of 8-bucket segments, weighted by segment offset
+//   msm_window_sum    LDS tree reduction of segment sums, one workgroup per window
+//   msm_final         (Horner over the windows when there are no tables,) XYZZ -> Jacobian, Montgomery -> canonical
+// Point order inside a bucket depends on LDS-atomic arrival order; the group law is exact, so the sum
 // (compared in affine) does not.
 #include <algorithm>
+#include <vector>
 
 #define ZK_NOINLINE_MUL2 1  // G2 (Fq2) products stay out of line; G1 products are inlined (out of line measured 27 % slower)
 #include "ctx.hpp"
@@ -42,20 +47,6 @@ static constexpr uint32_t MSM_LARGE_CHUNK = 4096;  // entries per task of a spli
 #define MSM_G1_THREADS 256
 #define MSM_G1_WAVES 3
 #endif
-
-__global__ __launch_bounds__(256) void msm_digits(const uint32_t *__restrict__ scalars, uint32_t n, int c, int W,
-                                                  uint32_t *__restrict__ dig, uint32_t *__restrict__ hist) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t *s = scalars + (size_t)i * 8;
-    const uint32_t B = 1u << (c - 1);
-    uint32_t carry = 0;
-    for (int w = 0; w < W; ++w) {
-        uint32_t out = msm_recode(s, w, c, carry);
-        if (out != DIG_NONE) atomicAdd(&hist[(size_t)w * B + (out & 0x7FFFFFFFu)], 1u);
-        dig[(size_t)w * n + i] = out;
-    }
-}
 
 // exclusive scan of `count` u32 counters in three launches: per-block (1024 counters) local scan + block
 // totals, scan of the totals by one workgroup, add-back.  offs[count] = total; cursor = copy of offs.
@@ -122,18 +113,6 @@ __global__ __launch_bounds__(256) void msm_scan_add(uint32_t *__restrict__ offs,
             cursor[base + k] = x;
         }
     }
-}
-
-__global__ __launch_bounds__(256) void msm_scatter(const uint32_t *__restrict__ dig, uint32_t n, int c, uint32_t *__restrict__ cursor,
-                                                   uint32_t *__restrict__ idx) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t w = blockIdx.y;
-    if (i >= n) return;
-    const uint32_t B = 1u << (c - 1);
-    uint32_t d = dig[(size_t)w * n + i];
-    if (d == DIG_NONE) return;
-    uint32_t pos = atomicAdd(&cursor[(size_t)w * B + (d & 0x7FFFFFFFu)], 1u);
-    idx[pos] = i | (d & 0x80000000u);
 }
 
 // ---- bucket sort without global atomics ------------------------------------------------------------------
@@ -718,7 +697,8 @@ static int ilog2(size_t v) {
 int zk_msm_auto_window(size_t n) { return std::max(2, std::min(16, ilog2(n) - 4)); }
 
 template <class F>
-static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac) {
+static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac,
+                     uint32_t *batch_slot = nullptr, size_t *need_out = nullptr) {
     constexpr int NL = FieldOps<F>::WORDS;
     const bool tables = bases->ntab > 1;
     // window size: 2^(c-1) buckets per window.  With window tables c is fixed by the tables.
@@ -757,7 +737,11 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     const uint32_t task_cap = (uint32_t)(entries / MSM_LARGE_CHUNK + large_cap + 1);
     need += zkhip_ctx::ws_round(16) + zkhip_ctx::ws_round((size_t)task_cap * 12) + zkhip_ctx::ws_round((size_t)large_cap * 12);
     need += zkhip_ctx::ws_round((size_t)task_cap * 4 * NL * 4);
-    ZK_TRY(ctx->ws_reserve(need));
+    if (need_out) {  // dry run: workspace size only
+        *need_out = need;
+        return 0;
+    }
+    ZK_TRY(ctx->ws_reserve(ctx->ws_floor + need));
     ctx->ws_reset();
     uint32_t *dig = ctx->ws_take<uint32_t>((size_t)W * n);
     uint32_t *bh = ctx->ws_take<uint32_t>(nbh);
@@ -835,6 +819,10 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
             cur = half;
         }
     }
+    if (batch_slot) {  // batched call: hand the merged buckets over, the reduction runs once for the whole batch
+        ZK_HIP_CHECK(ctx, hipMemcpyAsync(batch_slot, buckets, (size_t)B * 4 * NL * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        return 0;
+    }
     uint32_t tot = (uint32_t)Wr * nseg;
     ZK_LAUNCH(ctx, "msm_bucket_red", msm_bucket_red<F>, dim3((tot + 63) / 64), dim3(64), 0, buckets, B, L, nseg, tot, segsum);
     unsigned wthreads = (4 * NL * 4 <= 256) ? 256 : 128;  // 64 KiB of LDS either way
@@ -875,6 +863,102 @@ __global__ void msm_write_infinity(uint32_t *out_jac) {
     FieldOps<F>::to_canonical(out_jac, F::one());
     FieldOps<F>::to_canonical(out_jac + CW, F::one());
     FieldOps<F>::to_canonical(out_jac + 2 * CW, F::zero());
+}
+
+// one workgroup per MSM of a batch: window sum -> canonical Jacobian at that MSM's output pointer
+template <class F>
+__global__ void msm_final_batch(const uint32_t *__restrict__ winsum, uint32_t count, uint32_t *const *__restrict__ outs) {
+    constexpr int NL = FieldOps<F>::WORDS;
+    constexpr int CW = FieldOps<F>::CANON_WORDS;
+    if (blockIdx.x >= count || threadIdx.x != 0) return;
+    Jacobian<F> j = xyzz_to_jacobian(xyzz_load<F>(winsum + (size_t)blockIdx.x * (4 * NL)));
+    uint32_t *out = outs[blockIdx.x];
+    FieldOps<F>::to_canonical(out, j.X);
+    FieldOps<F>::to_canonical(out + CW, j.Y);
+    FieldOps<F>::to_canonical(out + 2 * CW, j.Z);
+}
+
+// Several MSMs over table-backed bases of one group with one window size: per MSM digits / sort / accumulate /
+// merge as usual, then ONE bucket reduction, window sum and output conversion for the whole batch (those
+// stages are latency-bound chains of a few thousand lanes; batching them costs the same as doing one).
+template <class F>
+static int msm_batch_t(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases, const size_t *offsets, const size_t *ns,
+                       const uint32_t *const *d_scalars, uint32_t *const *d_outs) {
+    constexpr int NL = FieldOps<F>::WORDS;
+    const int c = bases[0]->c_tab;
+    const uint32_t B = 1u << (c - 1);
+    uint32_t L = std::min<uint32_t>(B, 1u << std::max(0, ctx->opt_msm_segment_log));
+    const uint32_t nseg = B / L;
+    size_t max_need = 0;
+    for (size_t i = 0; i < count; ++i) {
+        size_t need = 0;
+        ZK_TRY(msm_run_t<F>(ctx, bases[i], offsets[i], ns[i], nullptr, nullptr, nullptr, &need));
+        max_need = std::max(max_need, need);
+    }
+    const size_t slot_words = (size_t)B * 4 * NL;
+    size_t fixed = zkhip_ctx::ws_round(count * slot_words * 4) + zkhip_ctx::ws_round(count * nseg * 4 * NL * 4) +
+                   zkhip_ctx::ws_round(count * 4 * NL * 4) + zkhip_ctx::ws_round(count * sizeof(void *));
+    ctx->ws_floor = 0;
+    ZK_TRY(ctx->ws_reserve(fixed + max_need));
+    ctx->ws_reset();
+    uint32_t *slots = ctx->ws_take<uint32_t>(count * slot_words);
+    uint32_t *segsum = ctx->ws_take<uint32_t>(count * nseg * 4 * NL);
+    uint32_t *winsum = ctx->ws_take<uint32_t>(count * 4 * NL);
+    uint32_t **d_ptrs = ctx->ws_take<uint32_t *>(count);
+    ctx->ws_floor = ctx->ws_off;  // the per-MSM stages bump-allocate above the batch area
+    int rc = 0;
+    for (size_t i = 0; i < count && rc == 0; ++i) {
+        if (ns[i] == 0) {
+            hipError_t e = hipMemsetAsync(slots + i * slot_words, 0, slot_words * 4, ctx->stream);  // all buckets at infinity
+            if (e != hipSuccess) rc = ZKHIP_ERR_HIP;
+        } else {
+            rc = msm_run_t<F>(ctx, bases[i], offsets[i], ns[i], d_scalars[i], nullptr, slots + i * slot_words, nullptr);
+        }
+    }
+    ctx->ws_floor = 0;
+    if (rc) return rc;
+    ctx->batch_ptrs.assign(d_outs, d_outs + count);
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_ptrs, ctx->batch_ptrs.data(), count * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+    uint32_t tot = (uint32_t)count * nseg;
+    ZK_LAUNCH(ctx, "msm_bucket_red", msm_bucket_red<F>, dim3((tot + 63) / 64), dim3(64), 0, slots, B, L, nseg, tot, segsum);
+    unsigned wthreads = (4 * NL * 4 <= 256) ? 256 : 128;
+    ZK_LAUNCH(ctx, "msm_window_sum", msm_window_sum<F>, dim3((unsigned)count), dim3(wthreads), (size_t)wthreads * 4 * NL * 4, segsum, nseg, winsum);
+    ZK_LAUNCH(ctx, "msm_final", msm_final_batch<F>, dim3((unsigned)count), dim3(64), 0, winsum, (uint32_t)count, d_ptrs);
+    return 0;
+}
+
+int zk_msm_run_batch(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases, const size_t *offsets, const size_t *ns,
+                     const uint32_t *const *d_scalars, uint32_t *const *d_outs) {
+    if (count == 0) return 0;
+    for (size_t i = 0; i < count; ++i)
+        if (offsets[i] + ns[i] > bases[i]->n || ns[i] >= (1ull << 31)) return ZKHIP_ERR_RANGE;
+    // members that share (curve, group, window size) and have window tables form a batch; the rest run alone
+    std::vector<char> done(count, 0);
+    for (size_t i = 0; i < count; ++i) {
+        if (done[i]) continue;
+        std::vector<const zkhip_bases *> gb;
+        std::vector<size_t> go, gn;
+        std::vector<const uint32_t *> gs;
+        std::vector<uint32_t *> gd;
+        for (size_t j = i; j < count; ++j) {
+            if (done[j] || bases[j]->ntab <= 1 || bases[i]->ntab <= 1 || bases[j]->curve != bases[i]->curve || bases[j]->group != bases[i]->group ||
+                bases[j]->c_tab != bases[i]->c_tab)
+                continue;
+            done[j] = 1;
+            gb.push_back(bases[j]);
+            go.push_back(offsets[j]);
+            gn.push_back(ns[j]);
+            gs.push_back(d_scalars[j]);
+            gd.push_back(d_outs[j]);
+        }
+        if (gb.size() >= 2) {
+            ZK_DISPATCH_CG(gb[0]->curve, gb[0]->group, ZK_TRY(msm_batch_t<F>(ctx, gb.size(), gb.data(), go.data(), gn.data(), gs.data(), gd.data())));
+        } else {
+            done[i] = 1;
+            ZK_TRY(zk_msm_run(ctx, bases[i], offsets[i], ns[i], d_scalars[i], d_outs[i]));
+        }
+    }
+    return 0;
 }
 
 int zk_msm_run(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac) {

@@ -294,6 +294,15 @@ int zkhip_msm_dev(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_
     return zk_msm_run(ctx, bases, offset, n, (const uint32_t *)d_scalars, (uint32_t *)d_out_jacobian);
 }
 
+int zkhip_msm_batch_dev(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases, const size_t *offsets, const size_t *ns,
+                        const void *const *d_scalars, void *const *d_out_jacobian) {
+    if (!ctx || (count && (!bases || !offsets || !ns || !d_scalars || !d_out_jacobian))) return ZKHIP_ERR_INVALID;
+    for (size_t i = 0; i < count; ++i)
+        if (!bases[i] || !d_out_jacobian[i] || (ns[i] && !d_scalars[i])) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
+    return zk_msm_run_batch(ctx, count, bases, offsets, ns, (const uint32_t *const *)d_scalars, (uint32_t *const *)d_out_jacobian);
+}
+
 int zkhip_msm(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint64_t *scalars, uint64_t *out_jacobian) {
     if (!ctx || !bases || !out_jacobian || (n && !scalars)) return ZKHIP_ERR_INVALID;
     ZK_TRY(check_device(ctx));

@@ -62,9 +62,22 @@ std::vector<typename curve_adapter<CurveType>::g1_value_type>
     adapter::scalar_to_limbs(omega, w);
     /* p.coefficients() for every polynomial of the batch (kzg.hpp:431) */
     check(zkhip_ntt_dev(ctx.get(), adapter::id, d.get(), log_n, batch, w, 1, nullptr), "zkhip_ntt_dev", ctx.get());
-    /* multiexp<multiexp_method>(commitment_key[0 .. n), coefficients, 1) (kzg.hpp:433-434) */
-    for (std::size_t b = 0; b < batch; ++b)
-        out.push_back(multiexp_dev<CurveType, ZKHIP_G1>(ctx, params.commitment_key, 0, n, static_cast<const char *>(d.get()) + 32 * b * n));
+    /* multiexp<multiexp_method>(commitment_key[0 .. n), coefficients, 1) for every column (kzg.hpp:433-434), as one
+       batch: the columns' bucket reductions share one launch */
+    const std::size_t jl = 3 * adapter::g1_coord_limbs;
+    auto d_res = ctx.alloc(batch * jl * 8);
+    std::vector<const zkhip_bases *> qb(batch, params.commitment_key.get());
+    std::vector<std::size_t> qo(batch, 0), qn(batch, n);
+    std::vector<const void *> qs(batch);
+    std::vector<void *> qr(batch);
+    for (std::size_t b = 0; b < batch; ++b) {
+        qs[b] = static_cast<const char *>(d.get()) + 32 * b * n;
+        qr[b] = static_cast<std::uint64_t *>(d_res.get()) + b * jl;
+    }
+    check(zkhip_msm_batch_dev(ctx.get(), batch, qb.data(), qo.data(), qn.data(), qs.data(), qr.data()), "zkhip_msm_batch_dev", ctx.get());
+    std::vector<std::uint64_t> res(batch * jl);
+    ctx.d2h(res.data(), d_res.get(), res.size() * 8);
+    for (std::size_t b = 0; b < batch; ++b) out.push_back(adapter::g1_from_jacobian(&res[b * jl]));
     return out;
 }
 

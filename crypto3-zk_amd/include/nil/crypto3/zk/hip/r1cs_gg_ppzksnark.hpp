@@ -314,17 +314,17 @@ public:
         adapter::scalar_to_limbs(pk.domain.coset_generator, g);
         check(zkhip_groth16_witness_h_dev(ctx.get(), pk.constraint_system.get(), cpa, w, g, pk.d_h.get(), pk.d_scratch.get()),
               "zkhip_groth16_witness_h_dev", ctx.get());
-        /* evaluation_At (prover.hpp:108-114) */
-        check(zkhip_msm_dev(ctx.get(), pk.A_query.get(), 0, num_variables + 1, cpa, d_res), "zkhip_msm_dev(A)", ctx.get());
         /* evaluation_Bt: kc_multiexp_with_mixed_addition over the sparse (G2, G1) query (prover.hpp:116-123) */
         check(zkhip_fr_gather_dev(ctx.get(), cpa, pk.d_B_indices.get(), pk.B_count, pk.d_bs.get()), "zkhip_fr_gather_dev", ctx.get());
-        check(zkhip_msm_dev(ctx.get(), pk.B_query_h.get(), 0, pk.B_count, pk.d_bs.get(), d_res + jl1), "zkhip_msm_dev(B.h)", ctx.get());
         check(zkhip_msm_dev(ctx.get(), pk.B_query_g.get(), 0, pk.B_count, pk.d_bs.get(), d_res + 4 * jl1), "zkhip_msm_dev(B.g)", ctx.get());
-        /* evaluation_Ht over H_query[0 .. degree - 1) (prover.hpp:125-131) */
-        check(zkhip_msm_dev(ctx.get(), pk.H_query.get(), 0, degree - 1, pk.d_h.get(), d_res + 2 * jl1), "zkhip_msm_dev(H)", ctx.get());
-        /* evaluation_Lt over the auxiliary part of the assignment (prover.hpp:133-139) */
-        check(zkhip_msm_dev(ctx.get(), pk.L_query.get(), 0, num_variables - num_inputs, cpa + 32 * (num_inputs + 1), d_res + 3 * jl1),
-              "zkhip_msm_dev(L)", ctx.get());
+        /* the four G1 multiexps as one batch (their bucket reductions share one launch):
+           evaluation_At (prover.hpp:108-114), evaluation_Bt.h (:116-123), evaluation_Ht over H_query[0 .. degree - 1)
+           (:125-131), evaluation_Lt over the auxiliary part of the assignment (:133-139) */
+        const zkhip_bases *qb[4] = {pk.A_query.get(), pk.B_query_h.get(), pk.H_query.get(), pk.L_query.get()};
+        const std::size_t qo[4] = {0, 0, 0, 0}, qn[4] = {num_variables + 1, pk.B_count, degree - 1, num_variables - num_inputs};
+        const void *qs[4] = {cpa, pk.d_bs.get(), pk.d_h.get(), cpa + 32 * (num_inputs + 1)};
+        void *qr[4] = {d_res, d_res + jl1, d_res + 2 * jl1, d_res + 3 * jl1};
+        check(zkhip_msm_batch_dev(ctx.get(), 4, qb, qo, qn, qs, qr), "zkhip_msm_batch_dev", ctx.get());
         /* host products that do not depend on the MSM results, computed while the GPU works (prover.hpp:142-155) */
         const auto &k = pk.host;
         const auto r_delta = r * k.delta_g1, s_delta = s * k.delta_g1, rs_delta = (r * s) * k.delta_g1;

@@ -16,7 +16,7 @@ EXPORTS = [
     "zkhip_init", "zkhip_destroy", "zkhip_strerror", "zkhip_last_error", "zkhip_set_stream", "zkhip_sync",
     "zkhip_set_option", "zkhip_malloc", "zkhip_free", "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_memcpy_h2d_async", "zkhip_host_alloc", "zkhip_host_free",
     "zkhip_bases_upload", "zkhip_bases_from_scalars", "zkhip_bases_download", "zkhip_bases_size",
-    "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
+    "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_batch_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_domain_size", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev", "zkhip_fr_gather_dev", "zkhip_poly_resize_dev", "zkhip_fri_fold_dev",
     "zkhip_profile_enable", "zkhip_profile_reset", "zkhip_profile_get", "zkhip_profile_dump",
 ]
@@ -169,6 +169,17 @@ class Context:
         n = bases.n - offset if n is None else n
         self._check(self.lib.zkhip_msm_dev(self.h, bases.h, ctypes.c_size_t(offset), ctypes.c_size_t(n), ctypes.c_void_p(d_scalars),
                                            ctypes.c_void_p(d_out)), "zkhip_msm_dev")
+
+    def msm_batch_dev(self, bases_list, d_scalars_list, d_out_list, offsets=None, ns=None):
+        cnt = len(bases_list)
+        offsets = offsets or [0] * cnt
+        ns = ns or [b.n - o for b, o in zip(bases_list, offsets)]
+        B = (ctypes.c_void_p * cnt)(*[b.h for b in bases_list])
+        O = (ctypes.c_size_t * cnt)(*offsets)
+        N = (ctypes.c_size_t * cnt)(*ns)
+        S = (ctypes.c_void_p * cnt)(*d_scalars_list)
+        D = (ctypes.c_void_p * cnt)(*d_out_list)
+        self._check(self.lib.zkhip_msm_batch_dev(self.h, ctypes.c_size_t(cnt), B, O, N, S, D), "zkhip_msm_batch_dev")
 
     def jacobian_sum_dev(self, curve: int, group: int, d_points: int, count: int, d_out: int):
         self._check(self.lib.zkhip_jacobian_sum_dev(self.h, curve, group, ctypes.c_void_p(d_points), ctypes.c_size_t(count),

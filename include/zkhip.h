@@ -91,6 +91,11 @@ int zkhip_msm(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
               uint64_t *out_jacobian /* host */);
 /* Same, scalars and result resident in device memory; asynchronous on the context's stream. */
 int zkhip_msm_dev(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const void *d_scalars, void *d_out_jacobian);
+/* `count` MSMs whose results are needed together (the queries of one Groth16 proof, the columns of a KZG batch):
+ * same semantics as `count` calls of zkhip_msm_dev, but the latency-bound bucket reductions of all of them run as
+ * one launch when the bases share group and window size (otherwise the calls simply run one after the other). */
+int zkhip_msm_batch_dev(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases, const size_t *offsets, const size_t *ns,
+                        const void *const *d_scalars, void *const *d_out_jacobian);
 /* d_out = sum of `count` Jacobian points (canonical, 3 coordinates each) resident in device memory: the
  * fold of per-GPU partial MSM results after the all-gather (RCCL has no elliptic-curve reduction). */
 int zkhip_jacobian_sum_dev(zkhip_ctx *ctx, int curve, int group, const void *d_points, size_t count, void *d_out_jacobian);

@@ -170,3 +170,35 @@ def test_groth16_witness_map(ctx, curve, M, n):
     assert (got == exp).all()
     assert not got[g16.m - 1].any() and not got[g16.m].any()  # prover.hpp:88-89
     r1cs.free()
+
+
+def test_msm_batch(ctx, zk):
+    """zkhip_msm_batch_dev: several MSMs with one shared bucket reduction == the same MSMs one by one;
+    covers an empty member, a sub-range member and the mixed (fallback) case."""
+    n = 3000
+    ks = cp.random_fr(0, 31, n)
+    b1 = ctx.bases_from_scalars(0, 1, ks)
+    b2 = ctx.bases_from_scalars(0, 1, cp.random_fr(0, 32, n))
+    small = ctx.bases_from_scalars(0, 1, cp.random_fr(0, 33, 40))  # no window tables: forces the fallback when mixed in
+    scs = [cp.random_fr(0, 40 + i, n) for i in range(3)]
+    scs[2][::3] = 0
+    d_s = [ctx.malloc(s.nbytes) for s in scs]
+    for d, s in zip(d_s, scs):
+        ctx.h2d(d, s)
+    d_o = [ctx.malloc(144) for _ in range(4)]
+    singles = [jac_to_affine_py(0, 1, ctx.msm(b, s)) for b, s in ((b1, scs[0]), (b2, scs[1]), (b1, scs[2]))]
+    sub = jac_to_affine_py(0, 1, ctx.msm(b2, scs[0][:1000], offset=500, n=1000))
+
+    def fetch(k):
+        out = np.zeros((3, 6), dtype=np.uint64)
+        ctx.d2h(out, d_o[k])
+        return jac_to_affine_py(0, 1, out)
+
+    ctx.msm_batch_dev([b1, b2, b1, b2], [d_s[0], d_s[1], d_s[2], d_s[0]], d_o, offsets=[0, 0, 0, 500], ns=[n, n, n, 1000])
+    assert [fetch(k) for k in range(4)] == singles + [sub]
+    ctx.msm_batch_dev([b1, b2, b1], [d_s[0], d_s[1], d_s[2]], d_o[:3], ns=[n, 0, n])
+    assert fetch(0) == singles[0] and fetch(1) is None and fetch(2) == singles[2]
+    ctx.msm_batch_dev([b1, small], [d_s[0], d_s[1]], d_o[:2], ns=[n, 40])  # mixed: sequential fallback
+    assert fetch(0) == singles[0] and fetch(1) == jac_to_affine_py(0, 1, ctx.msm(small, scs[1][:40]))
+    for d in d_s + d_o:
+        ctx.free(d)

@@ -45,8 +45,7 @@ def main():
             ctx.profile(True)
         t0 = time.perf_counter()
         ctx.ntt_dev(zk.BLS12_381, d, a.log_n, a.cols, omega, inverse=True)
-        for c in range(a.cols):
-            ctx.msm_dev(srs, d + 32 * n * c, d_out + 144 * c, 0, n)
+        ctx.msm_batch_dev([srs] * a.cols, [d + 32 * n * c for c in range(a.cols)], [d_out + 144 * c for c in range(a.cols)], ns=[n] * a.cols)
         ctx.sync()
         times.append((time.perf_counter() - t0) * 1e3)
     ctx.profile(False)
