@@ -49,7 +49,7 @@ def test_prime_field_ops(shim, field):
         X = (a * a - a * b - 2 * b * b) % p
         for op, fn in ((0, lambda: a * b % p), (1, lambda: (a + b) % p), (2, lambda: (a - b) % p), (4, lambda: a * a % p),
                        (5, lambda: (-a) % p), (6, lambda: 2 * a % p), (7, lambda: (a - b) % p),
-                       (8, lambda: (a * b - X) * (b * b - X) % p)):
+                       (8, lambda: (a * b - X) * (b * b - X) % p), (9, lambda: (a + b) * (a + b) % p)):
             assert shim.zkt_field_op(field, op, P(A), P(B), P(out)) == 0
             assert _int(out) == fn(), (field, op, hex(a), hex(b))
         if a and i < 12:
