@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=LOG_N, help="points per GPU = 2^log_n (default: the BASELINE size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-groth16", action="store_true", help="skip the Groth16 constraints/s leg (N = 1 only)")
+    ap.add_argument("--no-ntt", action="store_true", help="skip the NTT leg (BASELINE config 3, N = 1 only)")
     args = ap.parse_args()
 
     import numpy as np
@@ -151,6 +152,8 @@ def main():
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
         }
         line["roofline"]["traffic"] = pmc_traffic()
+        if world == 1 and not args.no_ntt:
+            line["ntt"] = ntt_leg(np, zk, ctx)
         if world == 1 and not args.no_groth16:
             line["groth16"] = groth16_leg(np)
         if world == 1 and not args.no_cpu_baseline:
@@ -174,6 +177,35 @@ def pmc_traffic():
         return int((2 * k[name]["FETCH_SIZE"]["mean_per_launch"] + k[name]["WRITE_SIZE"]["mean_per_launch"]) * 1024)
     except Exception:
         return None
+
+
+def ntt_leg(np, zk, ctx, log_m=22, batch=8, steps=5):
+    """BASELINE config 3: radix-2 NTT over BLS12-381 Fr, domain 2^22, batch of 8, device resident, in place."""
+    r = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    lim = lambda v: np.array([(v >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+    omega = lim(pow(7, (r - 1) >> log_m, r))
+    m = 1 << log_m
+    data = random_scalars(np, batch * m, 3)
+    d = ctx.malloc(data.nbytes)
+    ctx.h2d(d, data)
+    ctx.ntt_dev(zk.BLS12_381, d, log_m, batch, omega)  # warm-up: builds the twiddle tables
+    ctx.sync()
+    ctx.profile_reset()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.ntt_dev(zk.BLS12_381, d, log_m, batch, omega)
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / steps
+    ctx.profile(False)
+    k_ms, k_cnt = ctx.profile_get("ntt_pass")
+    ctx.free(d)
+    alg = batch * m * 64  # one read + one write of every element per transform (SURVEY 8d)
+    achieved = alg / (k_ms / steps * 1e-3) / 1e9
+    return {"metric": "NTT elements/sec, BLS12-381 Fr, 2^%d x %d" % (log_m, batch), "value": round(batch * m / dt / 1e6, 2), "unit": "Melements/s",
+            "ms_per_transform_batch": round(dt * 1e3, 4),
+            "roofline": {"bound": "hbm", "kernel": "ntt_pass (x%d per transform)" % (k_cnt // steps), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_transform_batch": alg}}
 
 
 def groth16_leg(np, log_constraints=20, inputs=10, steps=3):

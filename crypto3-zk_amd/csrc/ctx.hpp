@@ -151,6 +151,7 @@ size_t zk_coord_limbs64(int curve, int group);  // u64 limbs per coordinate (Fq:
 int zk_bases_to_mont(zkhip_ctx *ctx, zkhip_bases *b, const uint32_t *d_canonical, const uint8_t *d_inf);
 size_t zk_point_words(int curve, int group);
 int zk_msm_auto_window(size_t n);
+int zk_scalar_bits(int curve);  // bit length of the scalar-field modulus
 int zk_bases_precompute(zkhip_ctx *ctx, zkhip_bases *b);  // u32 words per affine point in device buffers
 int zk_bases_from_mont(zkhip_ctx *ctx, const zkhip_bases *b, size_t offset, size_t n, uint32_t *d_out, uint8_t *d_inf);
 int zk_bases_mul(zkhip_ctx *ctx, zkhip_bases *b, const uint32_t *d_base_canonical /* nullable: generator */, const uint32_t *d_scalars);

@@ -152,4 +152,16 @@ int zkt_recode(const uint32_t *scalar, int c, int W, int32_t *digits) {
     return (int)carry;
 }
 
+// the recoding msm_digits_only performs: fold to |s| <= (r - 1) / 2, then signed digits over msm_windows() windows.
+// Returns the window count, or -1 if a carry left the top window (must not happen).  curve: 0 BLS12-381, 1 BN254.
+int zkt_recode_folded(int curve, const uint32_t *scalar, int c, int32_t *digits) {
+    uint32_t s[8];
+    const bool flip = curve == 0 ? msm_fold_scalar<BlsFr>(scalar, s) : msm_fold_scalar<BnFr>(scalar, s);
+    const int W = msm_windows(curve == 0 ? 255 : 254, c);
+    if (zkt_recode(s, c, W, digits) != 0) return -1;
+    if (flip)
+        for (int w = 0; w < W; ++w) digits[w] = -digits[w];
+    return W;
+}
+
 }  // extern "C"

@@ -125,13 +125,18 @@ __global__ __launch_bounds__(256) void msm_scan_add(uint32_t *__restrict__ offs,
 // The digit array is read twice per pass, no thread ever waits on a global atomic.
 static constexpr uint32_t SORT_TILE = 4096;  // digits per pass-1 tile (256 lanes x 16)
 
+template <class FR>
 __global__ __launch_bounds__(256) void msm_digits_only(const uint32_t *__restrict__ scalars, uint32_t n, int c, int W,
                                                        uint32_t *__restrict__ dig) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t *s = scalars + (size_t)i * 8;
+    uint32_t s[8];
+    const uint32_t flip = msm_fold_scalar<FR>(scalars + (size_t)i * 8, s) ? 0x80000000u : 0u;  // |s| <= (r - 1) / 2
     uint32_t carry = 0;
-    for (int w = 0; w < W; ++w) dig[(size_t)w * n + i] = msm_recode(s, w, c, carry);
+    for (int w = 0; w < W; ++w) {
+        uint32_t d = msm_recode(s, w, c, carry);
+        dig[(size_t)w * n + i] = d == DIG_NONE ? d : d ^ flip;
+    }
 }
 
 // bh[(w * nsuper + sb) * ntile + tile] = number of digits of window w, tile `tile`, in super-bucket sb
@@ -208,31 +213,36 @@ __global__ __launch_bounds__(256) void msm_sort_final(const uint32_t *__restrict
 // Lanes of a wave run in lockstep (a wave costs the largest bucket among its 64) and a workgroup holds its
 // registers until its last wave retires, so buckets are handed out in globally sorted order: every wave and every
 // workgroup sees near-equal trip counts, long buckets start first, empty and large (split elsewhere) buckets
-// collect at the end.  bin = LARGE - size for 1 <= size <= LARGE, last bin otherwise.
-static constexpr uint32_t SIZE_BINS = MSM_LARGE_BUCKET + 1;
+// collect at the end.  `large` is the split threshold of this MSM (max(MSM_LARGE_BUCKET, 4 x mean bucket size): at
+// 2^22 points and more the mean itself passes 128).  bin 0: MSM_LARGE_BUCKET < size <= large;
+// bin 1 + MSM_LARGE_BUCKET - size for 1 <= size <= MSM_LARGE_BUCKET; last bin: empty or split.
+static constexpr uint32_t SIZE_BINS = MSM_LARGE_BUCKET + 2;
 
-ZK_D uint32_t size_bin(uint32_t size) { return (size != 0 && size <= MSM_LARGE_BUCKET) ? MSM_LARGE_BUCKET - size : MSM_LARGE_BUCKET; }
+ZK_D uint32_t size_bin(uint32_t size, uint32_t large) {
+    if (size == 0 || size > large) return SIZE_BINS - 1;
+    return size > MSM_LARGE_BUCKET ? 0 : 1 + MSM_LARGE_BUCKET - size;
+}
 
 __global__ __launch_bounds__(256) void msm_size_hist(const uint32_t *__restrict__ offs, uint32_t nbuckets, uint32_t nblocks,
-                                                     uint32_t *__restrict__ bh) {
+                                                     uint32_t large, uint32_t *__restrict__ bh) {
     __shared__ uint32_t lh[SIZE_BINS];
     const uint32_t t = threadIdx.x;
     if (t < SIZE_BINS) lh[t] = 0;
     __syncthreads();
     for (uint32_t g = blockIdx.x * 1024 + t; g < min(nbuckets, (blockIdx.x + 1) * 1024); g += 256)
-        atomicAdd(&lh[size_bin(offs[g + 1] - offs[g])], 1u);
+        atomicAdd(&lh[size_bin(offs[g + 1] - offs[g], large)], 1u);
     __syncthreads();
     if (t < SIZE_BINS) bh[(size_t)t * nblocks + blockIdx.x] = lh[t];
 }
 
 __global__ __launch_bounds__(256) void msm_size_scatter(const uint32_t *__restrict__ offs, uint32_t nbuckets, uint32_t nblocks,
-                                                        const uint32_t *__restrict__ bo, uint32_t *__restrict__ order) {
+                                                        uint32_t large, const uint32_t *__restrict__ bo, uint32_t *__restrict__ order) {
     __shared__ uint32_t cur[SIZE_BINS];
     const uint32_t t = threadIdx.x;
     if (t < SIZE_BINS) cur[t] = bo[(size_t)t * nblocks + blockIdx.x];
     __syncthreads();
     for (uint32_t g = blockIdx.x * 1024 + t; g < min(nbuckets, (blockIdx.x + 1) * 1024); g += 256)
-        order[atomicAdd(&cur[size_bin(offs[g + 1] - offs[g])], 1u)] = g;
+        order[atomicAdd(&cur[size_bin(offs[g + 1] - offs[g], large)], 1u)] = g;
 }
 
 // One lane per (window, bucket).  With precomputed window tables (tab_stride != 0) window w gathers from
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(256) void msm_size_scatter(const uint32_t *__restri
 template <class F, int MSM_ACC_THREADS, int MSM_ACC_WAVES>
 __global__ __launch_bounds__(MSM_ACC_THREADS, MSM_ACC_WAVES) void msm_bucket_acc(const uint32_t *__restrict__ bases, size_t tab_stride_words, uint32_t B,
                                                       const uint32_t *__restrict__ offs, const uint32_t *__restrict__ idx, uint32_t nbuckets,
-                                                      const uint32_t *__restrict__ order, uint32_t *__restrict__ buckets) {
+                                                      uint32_t large, const uint32_t *__restrict__ order, uint32_t *__restrict__ buckets) {
     constexpr int NL = FieldOps<F>::WORDS;
     // `order` lists the buckets by descending size (msm_size_*): lanes of a wave, and waves of a workgroup, get
     // near-equal trip counts, and the long buckets are dispatched first.
@@ -249,7 +259,7 @@ __global__ __launch_bounds__(MSM_ACC_THREADS, MSM_ACC_WAVES) void msm_bucket_acc
     const uint32_t g = order[slot];
     const uint32_t *tab = bases + (size_t)(g / B) * tab_stride_words;
     uint32_t lo = offs[g], hi = offs[g + 1];
-    if (hi - lo > MSM_LARGE_BUCKET) return;  // split across workgroups by msm_bucket_large (empty: written below)
+    if (hi - lo > large) return;  // split across workgroups by msm_bucket_large (empty: written below)
     XYZZ<F> acc = XYZZ<F>::infinity();
     if (lo < hi) {
         // software pipeline: the next point's gather is in flight while the current mixed addition runs
@@ -279,11 +289,11 @@ __global__ __launch_bounds__(MSM_ACC_THREADS, MSM_ACC_WAVES) void msm_bucket_acc
 // large[j] = {bucket, first task, task count}.
 __global__ __launch_bounds__(256) void msm_plan_large(const uint32_t *__restrict__ offs, uint32_t nbuckets, uint32_t *__restrict__ plan,
                                                       uint32_t *__restrict__ tasks, uint32_t *__restrict__ large, uint32_t task_cap,
-                                                      uint32_t large_cap) {
+                                                      uint32_t large_cap, uint32_t thresh) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nbuckets) return;
     uint32_t lo = offs[g], hi = offs[g + 1], size = hi - lo;
-    if (size <= MSM_LARGE_BUCKET) return;
+    if (size <= thresh) return;
     uint32_t nt = (size + MSM_LARGE_CHUNK - 1) / MSM_LARGE_CHUNK;
     uint32_t first = atomicAdd(&plan[0], nt);
     uint32_t slot = atomicAdd(&plan[1], 1u);
@@ -328,16 +338,30 @@ __global__ __launch_bounds__(128) void msm_bucket_large(const uint32_t *__restri
     }
 }
 
+// one wave per large bucket: lanes fold the bucket's task partials in strides, then an LDS tree
 template <class F>
 __global__ __launch_bounds__(64) void msm_large_combine(const uint32_t *__restrict__ plan, const uint32_t *__restrict__ large,
                                                         const uint32_t *__restrict__ partials, uint32_t *__restrict__ buckets) {
     constexpr int NL = FieldOps<F>::WORDS;
-    const uint32_t nlarge = plan[1];
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nlarge; j += gridDim.x * blockDim.x) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t nlarge = plan[1], t = threadIdx.x;
+    for (uint32_t j = blockIdx.x; j < nlarge; j += gridDim.x) {
         const uint32_t g = large[3 * j], first = large[3 * j + 1], nt = large[3 * j + 2];
         XYZZ<F> acc = XYZZ<F>::infinity();
-        for (uint32_t t = 0; t < nt; ++t) acc = xyzz_add(acc, xyzz_load<F>(partials + (size_t)(first + t) * (4 * NL)));
-        xyzz_store<F>(buckets + (size_t)g * (4 * NL), acc);
+        for (uint32_t k = t; k < nt; k += 64) acc = xyzz_add(acc, xyzz_load<F>(partials + (size_t)(first + k) * (4 * NL)));
+        if (nt > 1) {  // uniform over the wave
+            xyzz_store<F>(lds + (size_t)t * (4 * NL), acc);
+            __syncthreads();
+            for (uint32_t d = 32; d >= 1; d >>= 1) {
+                if (t < d && t + d < nt) {
+                    acc = xyzz_add(xyzz_load<F>(lds + (size_t)t * (4 * NL)), xyzz_load<F>(lds + (size_t)(t + d) * (4 * NL)));
+                    xyzz_store<F>(lds + (size_t)t * (4 * NL), acc);
+                }
+                __syncthreads();
+            }
+        }
+        if (t == 0) xyzz_store<F>(buckets + (size_t)g * (4 * NL), acc);
+        __syncthreads();
     }
 }
 
@@ -379,7 +403,7 @@ struct LdsAcc {
 template <class F, int NT>
 __global__ __launch_bounds__(NT, 3) void msm_bucket_acc_lds(const uint32_t *__restrict__ bases, size_t tab_stride_words, uint32_t B,
                                                            const uint32_t *__restrict__ offs, const uint32_t *__restrict__ idx, uint32_t nbuckets,
-                                                           const uint32_t *__restrict__ order, uint32_t *__restrict__ buckets) {
+                                                           uint32_t large, const uint32_t *__restrict__ order, uint32_t *__restrict__ buckets) {
     typedef FieldOps<F> O;
     constexpr int NL = O::WORDS;
     extern __shared__ __attribute__((aligned(16))) uint4 acc_lds[];
@@ -388,7 +412,7 @@ __global__ __launch_bounds__(NT, 3) void msm_bucket_acc_lds(const uint32_t *__re
     const uint32_t g = order[slot];  // buckets by descending size (msm_size_*)
     const uint32_t *tab = bases + (size_t)(g / B) * tab_stride_words;
     const uint32_t lo = offs[g], hi = offs[g + 1];
-    if (hi - lo > MSM_LARGE_BUCKET) return;
+    if (hi - lo > large) return;
     LdsAcc<F, NT> A = {acc_lds, tid};
     enum { CX = 0, CY = 1, CZZ = 2 };
     F ZZZ = F::zero();
@@ -694,6 +718,8 @@ static int ilog2(size_t v) {
     return l;
 }
 
+int zk_scalar_bits(int curve) { return curve == CURVE_BLS12_381 ? 255 : 254; }  // bit length of r
+
 int zk_msm_auto_window(size_t n) { return std::max(2, std::min(16, ilog2(n) - 4)); }
 
 template <class F>
@@ -705,8 +731,7 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     int c = tables ? bases->c_tab : ctx->opt_msm_window_bits;
     if (c <= 0) c = zk_msm_auto_window(n);
     c = std::max(2, std::min(16, c));
-    const int scalar_bits_total = 256;  // Fr < 2^255: one spare bit absorbs the signed-digit carry
-    const int W = (scalar_bits_total + c - 1) / c;
+    const int W = msm_windows(zk_scalar_bits(bases->curve), c);  // scalars are folded to |s| <= (r - 1) / 2: no carry out of window W - 1
     const uint32_t B = 1u << (c - 1);
     const uint32_t nb = (uint32_t)W * B;
     const int Wr = tables ? 1 : W;  // windows left after the equal-weight merge
@@ -733,7 +758,8 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     need += zkhip_ctx::ws_round((size_t)W * 4 * NL * 4);
     // worst-case plan of the large-bucket path: every entry in a large bucket
     const size_t entries = (size_t)W * n;
-    const uint32_t large_cap = (uint32_t)(entries / MSM_LARGE_BUCKET + 1);
+    const uint32_t large_thresh = (uint32_t)std::max<size_t>(MSM_LARGE_BUCKET, 4 * ((n + B - 1) / B));
+    const uint32_t large_cap = (uint32_t)(entries / large_thresh + 1);
     const uint32_t task_cap = (uint32_t)(entries / MSM_LARGE_CHUNK + large_cap + 1);
     need += zkhip_ctx::ws_round(16) + zkhip_ctx::ws_round((size_t)task_cap * 12) + zkhip_ctx::ws_round((size_t)large_cap * 12);
     need += zkhip_ctx::ws_round((size_t)task_cap * 4 * NL * 4);
@@ -767,7 +793,8 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     const size_t tab_stride_words = tables ? bases->n * bases->stride_u32 : 0;
 
     unsigned gn = (unsigned)((n + 255) / 256);
-    ZK_LAUNCH(ctx, "msm_digits", msm_digits_only, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, c, W, dig);
+    if (bases->curve == CURVE_BLS12_381) ZK_LAUNCH(ctx, "msm_digits", msm_digits_only<BlsFr>, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, c, W, dig);
+    else ZK_LAUNCH(ctx, "msm_digits", msm_digits_only<BnFr>, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, c, W, dig);
     ZK_LAUNCH(ctx, "msm_sort_hist", msm_sort_hist, dim3(ntile, W), dim3(256), 0, dig, (uint32_t)n, lowb, nsuper, ntile, bh);
     ZK_LAUNCH(ctx, "msm_scan", msm_scan_local, dim3(nblk), dim3(256), 0, bh, nbh, bo, bsums);
     ZK_LAUNCH(ctx, "msm_scan", msm_scan_top, dim3(1), dim3(1024), 0, bsums, nblk, bo + nbh);
@@ -775,11 +802,11 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     ZK_LAUNCH(ctx, "msm_sort_split", msm_sort_split, dim3(ntile, W), dim3(256), 0, dig, (uint32_t)n, lowb, nsuper, ntile, bo, tmp_idx, tmp_key);
     ZK_LAUNCH(ctx, "msm_sort_final", msm_sort_final, dim3(ngroups), dim3(256), 0, tmp_idx, tmp_key, lowb, nsuper, ntile, ngroups, bo, offs, idx);
     // buckets by descending size
-    ZK_LAUNCH(ctx, "msm_size_sort", msm_size_hist, dim3(sblk), dim3(256), 0, offs, nb, sblk, sh);
+    ZK_LAUNCH(ctx, "msm_size_sort", msm_size_hist, dim3(sblk), dim3(256), 0, offs, nb, sblk, large_thresh, sh);
     ZK_LAUNCH(ctx, "msm_size_sort", msm_scan_local, dim3(sblk2), dim3(256), 0, sh, nsh, so, ssums);
     ZK_LAUNCH(ctx, "msm_size_sort", msm_scan_top, dim3(1), dim3(1024), 0, ssums, sblk2, so + nsh);
     ZK_LAUNCH(ctx, "msm_size_sort", msm_scan_add, dim3(sblk2), dim3(256), 0, so, nsh, ssums, so);
-    ZK_LAUNCH(ctx, "msm_size_sort", msm_size_scatter, dim3(sblk), dim3(256), 0, offs, nb, sblk, so, order);
+    ZK_LAUNCH(ctx, "msm_size_sort", msm_size_scatter, dim3(sblk), dim3(256), 0, offs, nb, sblk, large_thresh, so, order);
     if constexpr (FieldOps<F>::WORDS <= 16) {
         // G1: accumulator in LDS, three waves per SIMD (256-lane workgroups, three per CU)
         constexpr int NT = MSM_G1_THREADS;
@@ -791,14 +818,14 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
             attr_acc = true;
         }
         ZK_LAUNCH(ctx, "msm_bucket_acc", (msm_bucket_acc_lds<F, NT>), dim3((nb + NT - 1) / NT), dim3(NT), lds_acc, d_b, tab_stride_words, B, offs, idx,
-                  nb, order, buckets);
+                  nb, large_thresh, order, buckets);
     } else {
         ZK_LAUNCH(ctx, "msm_bucket_acc", (msm_bucket_acc<F, 256, 1>), dim3((nb + 255) / 256), dim3(256), 0, d_b, tab_stride_words, B, offs, idx, nb,
-                  order, buckets);
+                  large_thresh, order, buckets);
     }
     // large buckets: plan on the device (no host round trip), then fixed-size grids that read the plan
     ZK_HIP_CHECK(ctx, hipMemsetAsync(plan, 0, 16, ctx->stream));
-    ZK_LAUNCH(ctx, "msm_plan_large", msm_plan_large, dim3((nb + 255) / 256), dim3(256), 0, offs, nb, plan, tasks, large, task_cap, large_cap);
+    ZK_LAUNCH(ctx, "msm_plan_large", msm_plan_large, dim3((nb + 255) / 256), dim3(256), 0, offs, nb, plan, tasks, large, task_cap, large_cap, large_thresh);
     {
         static bool attr_set = false;
         size_t lds_large = (size_t)128 * 4 * NL * 4;
@@ -810,7 +837,8 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
         unsigned grid_large = (unsigned)std::min<size_t>(task_cap, 512);  // persistent: workgroups loop over the task list
         ZK_LAUNCH(ctx, "msm_bucket_large", msm_bucket_large<F>, dim3(grid_large), dim3(128), lds_large, d_b, tab_stride_words, B, idx, plan, tasks,
                   partials);
-        ZK_LAUNCH(ctx, "msm_bucket_large", msm_large_combine<F>, dim3(64), dim3(64), 0, plan, large, partials, buckets);
+        ZK_LAUNCH(ctx, "msm_bucket_large", msm_large_combine<F>, dim3((unsigned)std::min<uint32_t>(large_cap, 256)), dim3(64), (size_t)64 * 4 * NL * 4, plan,
+                  large, partials, buckets);
     }
     if (tables) {
         for (uint32_t cur = (uint32_t)W; cur > 1;) {

@@ -31,5 +31,50 @@ ZK_HD uint32_t msm_recode(const uint32_t *s, int w, int c, uint32_t &carry) {
     return d == 0 ? DIG_NONE : ((d - 1) | (neg << 31));
 }
 
+// Fold a scalar s (reduced mod r first when it is not canonical) into the symmetric range: when 2 s > r it is replaced by r - s and the caller
+// flips the sign of every digit (s P = (r - s)(-P)).  |s| <= (r - 1) / 2 < 2^(bitlen(r) - 1), so the recoding over
+// msm_windows(bitlen(r), c) windows never carries out of the top window -- without the fold a window size that
+// divides bitlen(r) (c = 15 for the 255-bit BLS12-381 r) leaves a carry-only top window whose single bucket
+// receives ~45 % of all points.  FR: saturated scalar-field constants (mod(i), 8 u32 limbs).
+template <class FR>
+ZK_HD bool msm_fold_scalar(const uint32_t *s, uint32_t out[8]) {
+    uint32_t v[8], t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = s[i];
+    for (int it = 0; it < 6; ++it) {  // input that is not canonical is reduced first (2^256 < 6 r for both fields)
+        uint64_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint64_t d = (uint64_t)v[i] - FR::mod(i) - borrow;
+            t[i] = (uint32_t)d;
+            borrow = (d >> 32) & 1;
+        }
+        if (borrow) break;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = t[i];
+    }
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t d = (uint64_t)FR::mod(i) - v[i] - borrow;
+        t[i] = (uint32_t)d;
+        borrow = (d >> 32) & 1;
+    }
+    bool fold = false, decided = false;  // fold iff v > r - v
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+        if (!decided && v[i] != t[i]) {
+            fold = v[i] > t[i];
+            decided = true;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = fold ? t[i] : v[i];
+    return fold;
+}
+
+// windows needed for folded scalars of a field with `rbits`-bit modulus
+ZK_HD int msm_windows(int rbits, int c) { return (rbits + c - 1) / c; }
+
 
 }  // namespace zkhip

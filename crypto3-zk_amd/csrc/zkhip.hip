@@ -3,6 +3,7 @@
 #include <cstdlib>
 
 #include "ctx.hpp"
+#include "msm_recode.hpp"
 #include "zk_defs.hpp"
 
 using namespace zkhip;
@@ -149,7 +150,7 @@ static int bases_alloc(zkhip_ctx *ctx, int curve, int group, size_t n, zkhip_bas
     b->c_tab = 0;
     if (ctx->opt_msm_precompute && n >= (size_t)ctx->opt_msm_precompute_min) {
         b->c_tab = zk_msm_auto_window(n);
-        b->ntab = (256 + b->c_tab - 1) / b->c_tab;
+        b->ntab = msm_windows(zk_scalar_bits(curve), b->c_tab);
     }
     hipError_t e = hipMalloc((void **)&b->d, std::max<size_t>(1, n) * b->ntab * b->stride_u32 * 4);
     if (e != hipSuccess) {

@@ -90,9 +90,18 @@ def test_msm_edge_cases(ctx, curve, group):
     sc[11] = C.r - 77            # cancels with the duplicate base
     exp = po.msm_naive(G, P, sc)
     assert gpu_affine(ctx, bases, fr_arr(sc)) == exp
-    for c in (2, 3, 7, 12, 16):
+    for c in (2, 3, 5, 7, 12, 15, 16):  # 3, 5, 15 divide 255: the top window is full
         ctx.set_option("msm_window_bits", c)
         assert gpu_affine(ctx, bases, fr_arr(sc)) == exp, c
+    # scalars that are not canonical are taken mod r (the reference's field type cannot hold them)
+    nc = list(sc)
+    nc[8] = sc[8] + C.r if sc[8] + C.r < (1 << 256) else sc[8]
+    nc[9] = (1 << 256) - 1
+    sc9 = list(sc)
+    sc9[9] = ((1 << 256) - 1) % C.r
+    for c in (0, 15):
+        ctx.set_option("msm_window_bits", c)
+        assert gpu_affine(ctx, bases, fr_arr(nc)) == po.msm_naive(G, P, sc9)
     ctx.set_option("msm_window_bits", 0)
     zero = np.zeros((n, 4), dtype=np.uint64)
     assert gpu_affine(ctx, bases, zero) is None
@@ -104,6 +113,20 @@ def test_msm_edge_cases(ctx, curve, group):
     assert gpu_affine(ctx, bases, fr_arr(sc[20:50]), offset=20, n=30) == po.msm_naive(G, P[20:50], sc[20:50])
     with pytest.raises(Exception):
         ctx.msm(bases, fr_arr(sc), offset=10, n=n)
+    bases.free()
+
+
+@pytest.mark.parametrize("curve,group,n", [(0, 1, 20000), (1, 1, 9000), (0, 2, 9000)])
+def test_msm_skewed_scalars(ctx, curve, group, n):
+    """most scalars identical: every window has one bucket with thousands of entries, which is cut into several
+    tasks (msm_bucket_large) whose partial sums are folded by msm_large_combine."""
+    ks = cp.random_fr(curve, 21, n)
+    bases = ctx.bases_from_scalars(curve, group, ks)
+    pts, infs = bases.download()
+    sc = cp.random_fr(curve, 22, n)
+    sc[: (3 * n) // 4] = sc[0]
+    exp, einf = cp.msm(curve, group, pts, sc, chunks=cp.num_threads())
+    assert gpu_affine(ctx, bases, sc) == pt_from_limbs(curve, group, exp, einf)
     bases.free()
 
 

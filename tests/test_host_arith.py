@@ -163,3 +163,21 @@ def test_signed_digit_recoding(shim, c):
         assert carry == 0
         assert all(-B < int(d) <= B for d in dig)
         assert sum(int(d) << (c * w) for w, d in enumerate(dig)) == v
+
+
+@pytest.mark.parametrize("curve_id,curve", [(0, po.BLS12_381), (1, po.BN254)])
+@pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 13, 14, 15, 16])
+def test_folded_recoding(shim, curve_id, curve, c):
+    """msm_digits_only: scalars folded to |s| <= (r-1)/2 so no window size leaves a carry-only top window."""
+    r = curve.r
+    random.seed(100 + c)
+    B = 1 << (c - 1)
+    vals = [0, 1, 2, B, B + 1, (r - 1) // 2, (r + 1) // 2, r - 1, r - 2, r, r + 5, (1 << 256) - 1] + [random.randrange(r) for _ in range(60)]
+    dig = np.zeros(140, dtype=np.int32)
+    for v in vals:
+        s = _u32(v, 8)
+        W = shim.zkt_recode_folded(curve_id, s.ctypes.data_as(ctypes.c_void_p), c, dig.ctypes.data_as(ctypes.c_void_p))
+        assert W == (r.bit_length() + c - 1) // c
+        assert all(-B <= int(d) <= B for d in dig[:W])
+        got = sum(int(d) << (c * w) for w, d in enumerate(dig[:W]))
+        assert got % r == v % r and abs(got) <= (r - 1) // 2
