@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=LOG_N, help="points per GPU = 2^log_n (default: the BASELINE size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-groth16", action="store_true", help="skip the Groth16 constraints/s leg (N = 1 only)")
+    ap.add_argument("--force-dist", action="store_true", help="run the RCCL all-gather + fold at N = 1 too (checks the N > 1 path on one GPU)")
     ap.add_argument("--no-ntt", action="store_true", help="skip the NTT leg (BASELINE config 3, N = 1 only)")
     args = ap.parse_args()
 
@@ -72,10 +73,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X: zkhip has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)  # nccl == RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,  # nccl == RCCL on ROCm
+                                device_id=torch.device("cuda", local_rank))
 
     zk = load_pkg()
     ctx = zk.Context(local_rank)
@@ -89,7 +93,6 @@ def main():
     scalars = random_scalars(np, n, 2000 + rank)
     d_scalars = torch.from_numpy(scalars.view(np.int64)).to(f"cuda:{local_rank}")
     d_out = torch.zeros(3 * 6, dtype=torch.int64, device=f"cuda:{local_rank}")
-    d_gather = torch.zeros(world * 3 * 6, dtype=torch.int64, device=f"cuda:{local_rank}") if world > 1 else None
     d_total = torch.zeros(3 * 6, dtype=torch.int64, device=f"cuda:{local_rank}")
 
     from crypto3_zk_amd import dist as zd
@@ -101,11 +104,11 @@ def main():
     def step():
         ctx.msm_dev(bases, d_scalars.data_ptr(), d_out.data_ptr(), 0, n)
         # N > 1: one all-gather of the 144-byte partial sums over RCCL, then the on-device fold
-        zd.allgather_fold(d_out, world, lambda o, i: dist.all_gather_into_tensor(o, i), fold)
+        zd.allgather_fold(d_out, world, lambda o, i: dist.all_gather_into_tensor(o, i), fold, always=use_dist)
 
     def fence():
-        if world > 1:
-            dist.barrier()
+        if use_dist:
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -119,7 +122,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     ctx.profile(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -162,7 +165,7 @@ def main():
     fence()
     bases.free()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -246,15 +249,18 @@ def cpu_baseline(np, bases):
     import cport as cp
 
     cores = cp.num_threads()
-    sample = min(bases.n, 1 << 19)
+    sample = bases.n
     pts, inf = bases.download(0, sample)
     hb = cp.Bases(0, 1, pts, inf)
     sc = random_scalars(np, sample, 77)
-    t0 = time.perf_counter()
-    hb.msm(sc, chunks=cores)
+    hb.msm(sc[: 1 << 16], chunks=cores)  # spin the thread pool up
+    reps, t0 = 0, time.perf_counter()
+    while reps < 2 or time.perf_counter() - t0 < 10.0:  # ~10 s of wall time on all host cores
+        hb.msm(sc, chunks=cores)
+        reps += 1
     dt = time.perf_counter() - t0
-    return {"value": round(sample / dt / 1e6, 5), "unit": "Mpoints/s", "cores": cores, "kind": "port",
-            "sample": "2^%d of the 2^20 points, one MSM, chunks = %d OpenMP threads, %.1f s" % (sample.bit_length() - 1, cores, dt)}
+    return {"value": round(reps * sample / dt / 1e6, 5), "unit": "Mpoints/s", "cores": cores, "kind": "port",
+            "sample": "%d MSMs over all 2^%d points, chunks = %d OpenMP threads, %.1f s wall" % (reps, sample.bit_length() - 1, cores, dt)}
 
 
 if __name__ == "__main__":

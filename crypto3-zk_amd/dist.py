@@ -28,11 +28,12 @@ def shard_polys(batch: int, rank: int, world: int) -> List[int]:
     return list(range(rank, batch, world))
 
 
-def allgather_fold(partial, world: int, all_gather: Callable, fold: Callable):
+def allgather_fold(partial, world: int, all_gather: Callable, fold: Callable, always: bool = False):
     """partial: this rank's Jacobian result as a flat tensor (device or host).
     all_gather(out, inp): the collective (torch.distributed.all_gather_into_tensor or a test double);
-    fold(gathered, world): sums `world` Jacobian points (zkhip_jacobian_sum_dev on the GPU)."""
-    if world == 1:
+    fold(gathered, world): sums `world` Jacobian points (zkhip_jacobian_sum_dev on the GPU).
+    always: run the collective and the fold at world == 1 too (exercises the N > 1 code path on one GPU)."""
+    if world == 1 and not always:
         return partial
     gathered = partial.new_zeros(world * partial.numel())
     all_gather(gathered, partial)
