@@ -124,11 +124,15 @@ ZK_HD XYZZ<F> xyzz_add(const XYZZ<F> &a, const XYZZ<F> &b) {
     return {X3, Y3, O::mul(O::mul(a.ZZ, b.ZZ), PP), O::mul(O::mul(a.ZZZ, b.ZZZ), PPP)};
 }
 
-// k * a for a small unsigned k (bucket-segment offsets, k < 2^32)
+// k * a for a small unsigned k (bucket weights / segment offsets, k < 2^32): left-to-right double-and-add
 template <class F>
 ZK_HD XYZZ<F> xyzz_mul_small(const XYZZ<F> &a, uint32_t k) {
     XYZZ<F> r = XYZZ<F>::infinity();
-    for (int i = 31; i >= 0; --i) {
+    if (k == 0 || a.is_inf()) return r;
+    int top = 31;
+    while (!((k >> top) & 1)) --top;
+    r = a;
+    for (int i = top - 1; i >= 0; --i) {
         r = xyzz_dbl(r);
         if ((k >> i) & 1) r = xyzz_add(r, a);
     }

@@ -25,8 +25,8 @@
 //   msm_bucket_acc    same with the accumulator in registers (Fq2: G2)
 //   msm_plan_large / msm_bucket_large / msm_large_combine   buckets above 128 entries, one workgroup per 4096-entry task
 //   msm_bucket_merge  with window tables: fold the W equal-weight windows bucket by bucket (log2 W launches)
-//   msm_bucket_red    running-sum reduction of 8-bucket segments, weighted by segment offset
-//   msm_window_sum    LDS tree reduction of segment sums, one workgroup per window
+//   msm_bucket_red    (b + 1) * bucket[b] per lane, LDS tree over the 256 lanes of a workgroup
+//   msm_window_sum    LDS tree over the per-workgroup partials of a window
 //   msm_final         (Horner over the windows when there are no tables,) XYZZ -> Jacobian, Montgomery -> canonical
 // Point order inside a bucket depends on LDS-atomic arrival order; the group law is exact, so the sum
 // (compared in affine) does not.
@@ -471,43 +471,66 @@ __global__ __launch_bounds__(256) void msm_bucket_merge(uint32_t *__restrict__ b
     xyzz_store<F>(dst, xyzz_add(xyzz_load<F>(dst), xyzz_load<F>(src)));
 }
 
+// ---- tail: sum_b (b + 1) * bucket[b] per window -----------------------------------------------------------
+// Every operation here is a full (projective) addition or doubling, a few thousand dependent instructions that a
+// lone wave issues at one per ~4 cycles: the tail is bound by the LENGTH of its dependency chain, not by work.
+// Stage 1 gives every lane one segment of L buckets (L = 1 by default: just the scalar multiple
+// (b + 1) * bucket[b], ~15 doublings + ~10 additions) and folds the 256 lanes of a workgroup in an LDS tree
+// (8 additions deep); stage 2 folds the per-workgroup partials of a window (one more tree).
 // segment `seg` of window `w` covers buckets [seg*L, seg*L + L) (bucket b holds digit value b + 1):
-//   out = sum_b (b + 1) * bucket[b]  restricted to the segment
+//   sum_b (b + 1) * bucket[b]  restricted to the segment
 //       = sum_b (b - seg*L + 1) * bucket[b]  +  (seg*L) * sum_b bucket[b]
-template <class F>
-__global__ __launch_bounds__(64) void msm_bucket_red(const uint32_t *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t nseg,
-                                                     uint32_t total, uint32_t *__restrict__ segsum) {
-    constexpr int NL = FieldOps<F>::WORDS;
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;  // = w * nseg + seg
-    if (g >= total) return;
-    uint32_t w = g / nseg, seg = g % nseg;
-    const uint32_t *base = buckets + ((size_t)w * B + (size_t)seg * L) * (4 * NL);
-    XYZZ<F> run = XYZZ<F>::infinity(), sum = XYZZ<F>::infinity();
-    for (int b = (int)L - 1; b >= 0; --b) {
-        run = xyzz_add(run, xyzz_load<F>(base + (size_t)b * (4 * NL)));
-        sum = xyzz_add(sum, run);
-    }
-    if (seg != 0) sum = xyzz_add(sum, xyzz_mul_small(run, seg * L));
-    xyzz_store<F>(segsum + (size_t)g * (4 * NL), sum);
-}
+static constexpr int MSM_TAIL_THREADS = 256;
 
-// one workgroup per window: winsum[w] = sum_seg segsum[w][seg]
 template <class F>
-__global__ __launch_bounds__(256) void msm_window_sum(const uint32_t *__restrict__ segsum, uint32_t nseg, uint32_t *__restrict__ winsum) {
+ZK_D XYZZ<F> block_tree_sum(uint32_t *lds, XYZZ<F> acc, uint32_t t, uint32_t nthreads) {
     constexpr int NL = FieldOps<F>::WORDS;
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t w = blockIdx.x, t = threadIdx.x;
-    XYZZ<F> acc = XYZZ<F>::infinity();
-    for (uint32_t s = t; s < nseg; s += blockDim.x) acc = xyzz_add(acc, xyzz_load<F>(segsum + ((size_t)w * nseg + s) * (4 * NL)));
     xyzz_store<F>(lds + (size_t)t * (4 * NL), acc);
     __syncthreads();
-    for (uint32_t d = blockDim.x / 2; d >= 1; d >>= 1) {
+    for (uint32_t d = nthreads / 2; d >= 1; d >>= 1) {
         if (t < d) {
             acc = xyzz_add(xyzz_load<F>(lds + (size_t)t * (4 * NL)), xyzz_load<F>(lds + (size_t)(t + d) * (4 * NL)));
             xyzz_store<F>(lds + (size_t)t * (4 * NL), acc);
         }
         __syncthreads();
     }
+    return acc;  // lane 0: the sum
+}
+
+// grid = windows x nblk workgroups; partial[w * nblk + j] = weighted sum of segments [256 j, 256 j + 256) of window w
+template <class F>
+__global__ __launch_bounds__(MSM_TAIL_THREADS) void msm_bucket_red(const uint32_t *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t nseg,
+                                                                   uint32_t nblk, uint32_t *__restrict__ partial) {
+    constexpr int NL = FieldOps<F>::WORDS;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t t = threadIdx.x, w = blockIdx.x / nblk, seg = (blockIdx.x % nblk) * MSM_TAIL_THREADS + t;
+    XYZZ<F> sum = XYZZ<F>::infinity();
+    if (seg < nseg) {
+        const uint32_t *base = buckets + ((size_t)w * B + (size_t)seg * L) * (4 * NL);
+        if (L == 1) {
+            sum = xyzz_mul_small(xyzz_load<F>(base), seg + 1);
+        } else {
+            XYZZ<F> run = XYZZ<F>::infinity();
+            for (int b = (int)L - 1; b >= 0; --b) {
+                run = xyzz_add(run, xyzz_load<F>(base + (size_t)b * (4 * NL)));
+                sum = xyzz_add(sum, run);
+            }
+            if (seg != 0) sum = xyzz_add(sum, xyzz_mul_small(run, seg * L));
+        }
+    }
+    sum = block_tree_sum<F>(lds, sum, t, MSM_TAIL_THREADS);
+    if (t == 0) xyzz_store<F>(partial + (size_t)blockIdx.x * (4 * NL), sum);
+}
+
+// one 64-lane workgroup per window: winsum[w] = sum_j partial[w][j]
+template <class F>
+__global__ __launch_bounds__(64) void msm_window_sum(const uint32_t *__restrict__ partial, uint32_t nblk, uint32_t *__restrict__ winsum) {
+    constexpr int NL = FieldOps<F>::WORDS;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t w = blockIdx.x, t = threadIdx.x;
+    XYZZ<F> acc = XYZZ<F>::infinity();
+    for (uint32_t j = t; j < nblk; j += 64) acc = xyzz_add(acc, xyzz_load<F>(partial + ((size_t)w * nblk + j) * (4 * NL)));
+    if (nblk > 1) acc = block_tree_sum<F>(lds, acc, t, 64);
     if (t == 0) xyzz_store<F>(winsum + (size_t)w * (4 * NL), acc);
 }
 
@@ -722,6 +745,18 @@ int zk_scalar_bits(int curve) { return curve == CURVE_BLS12_381 ? 255 : 254; }  
 
 int zk_msm_auto_window(size_t n) { return std::max(2, std::min(16, ilog2(n) - 4)); }
 
+// the tail workgroups keep 256 XYZZ points in LDS (56 KiB for G1, 128 KiB for BLS12-381 G2)
+template <class F>
+static int msm_tail_attr(zkhip_ctx *ctx) {
+    static bool done = false;
+    if (!done) {
+        ZK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&msm_bucket_red<F>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              MSM_TAIL_THREADS * 4 * FieldOps<F>::WORDS * 4));
+        done = true;
+    }
+    return 0;
+}
+
 template <class F>
 static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac,
                      uint32_t *batch_slot = nullptr, size_t *need_out = nullptr) {
@@ -735,8 +770,8 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     const uint32_t B = 1u << (c - 1);
     const uint32_t nb = (uint32_t)W * B;
     const int Wr = tables ? 1 : W;  // windows left after the equal-weight merge
-    uint32_t L = std::min<uint32_t>(B, 1u << std::max(0, ctx->opt_msm_segment_log));  // 8 buckets per segment by default
-    const uint32_t nseg = B / L;
+    uint32_t L = std::min<uint32_t>(B, 1u << std::max(0, ctx->opt_msm_segment_log));  // buckets per tail segment
+    const uint32_t nseg = B / L, nblk_tail = (nseg + MSM_TAIL_THREADS - 1) / MSM_TAIL_THREADS;
     // two-level LDS counting sort (see msm_sort_*): low 8 bits inside a super-bucket, the rest across super-buckets
     const uint32_t lowb = (uint32_t)std::min(8, c - 1), nsuper = 1u << ((c - 1) - lowb);
     const uint32_t ntile = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE), ngroups = (uint32_t)W * nsuper;
@@ -754,7 +789,7 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     need += zkhip_ctx::ws_round((size_t)nb * 4 * NL * 4);  // buckets
     const uint32_t sblk = (nb + 1023) / 1024, nsh = SIZE_BINS * sblk, sblk2 = (nsh + 1023) / 1024;
     need += 2 * zkhip_ctx::ws_round(((size_t)nsh + 1) * 4) + zkhip_ctx::ws_round((size_t)sblk2 * 4) + zkhip_ctx::ws_round((size_t)nb * 4);  // size sort
-    need += zkhip_ctx::ws_round((size_t)W * nseg * 4 * NL * 4);
+    need += zkhip_ctx::ws_round((size_t)W * nblk_tail * 4 * NL * 4);
     need += zkhip_ctx::ws_round((size_t)W * 4 * NL * 4);
     // worst-case plan of the large-bucket path: every entry in a large bucket
     const size_t entries = (size_t)W * n;
@@ -782,7 +817,7 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     uint32_t *so = ctx->ws_take<uint32_t>((size_t)nsh + 1);
     uint32_t *ssums = ctx->ws_take<uint32_t>(sblk2);
     uint32_t *order = ctx->ws_take<uint32_t>(nb);
-    uint32_t *segsum = ctx->ws_take<uint32_t>((size_t)W * nseg * 4 * NL);
+    uint32_t *segsum = ctx->ws_take<uint32_t>((size_t)W * nblk_tail * 4 * NL);
     uint32_t *winsum = ctx->ws_take<uint32_t>((size_t)W * 4 * NL);
     uint32_t *plan = ctx->ws_take<uint32_t>(4);
     uint32_t *tasks = ctx->ws_take<uint32_t>((size_t)task_cap * 3);
@@ -851,11 +886,10 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
         ZK_HIP_CHECK(ctx, hipMemcpyAsync(batch_slot, buckets, (size_t)B * 4 * NL * 4, hipMemcpyDeviceToDevice, ctx->stream));
         return 0;
     }
-    uint32_t tot = (uint32_t)Wr * nseg;
-    ZK_LAUNCH(ctx, "msm_bucket_red", msm_bucket_red<F>, dim3((tot + 63) / 64), dim3(64), 0, buckets, B, L, nseg, tot, segsum);
-    unsigned wthreads = (4 * NL * 4 <= 256) ? 256 : 128;  // 64 KiB of LDS either way
-    size_t lds = (size_t)wthreads * 4 * NL * 4;
-    ZK_LAUNCH(ctx, "msm_window_sum", msm_window_sum<F>, dim3(Wr), dim3(wthreads), lds, segsum, nseg, winsum);
+    ZK_TRY(msm_tail_attr<F>(ctx));
+    ZK_LAUNCH(ctx, "msm_bucket_red", msm_bucket_red<F>, dim3((unsigned)Wr * nblk_tail), dim3(MSM_TAIL_THREADS), (size_t)MSM_TAIL_THREADS * 4 * NL * 4, buckets, B, L,
+              nseg, nblk_tail, segsum);
+    ZK_LAUNCH(ctx, "msm_window_sum", msm_window_sum<F>, dim3(Wr), dim3(64), (size_t)64 * 4 * NL * 4, segsum, nblk_tail, winsum);
     ZK_LAUNCH(ctx, "msm_final", msm_final<F>, dim3(1), dim3(64), 0, winsum, Wr, c, d_out_jac);
     return 0;
 }
@@ -916,7 +950,7 @@ static int msm_batch_t(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *b
     const int c = bases[0]->c_tab;
     const uint32_t B = 1u << (c - 1);
     uint32_t L = std::min<uint32_t>(B, 1u << std::max(0, ctx->opt_msm_segment_log));
-    const uint32_t nseg = B / L;
+    const uint32_t nseg = B / L, nblk_tail = (nseg + MSM_TAIL_THREADS - 1) / MSM_TAIL_THREADS;
     size_t max_need = 0;
     for (size_t i = 0; i < count; ++i) {
         size_t need = 0;
@@ -924,13 +958,13 @@ static int msm_batch_t(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *b
         max_need = std::max(max_need, need);
     }
     const size_t slot_words = (size_t)B * 4 * NL;
-    size_t fixed = zkhip_ctx::ws_round(count * slot_words * 4) + zkhip_ctx::ws_round(count * nseg * 4 * NL * 4) +
+    size_t fixed = zkhip_ctx::ws_round(count * slot_words * 4) + zkhip_ctx::ws_round(count * nblk_tail * 4 * NL * 4) +
                    zkhip_ctx::ws_round(count * 4 * NL * 4) + zkhip_ctx::ws_round(count * sizeof(void *));
     ctx->ws_floor = 0;
     ZK_TRY(ctx->ws_reserve(fixed + max_need));
     ctx->ws_reset();
     uint32_t *slots = ctx->ws_take<uint32_t>(count * slot_words);
-    uint32_t *segsum = ctx->ws_take<uint32_t>(count * nseg * 4 * NL);
+    uint32_t *segsum = ctx->ws_take<uint32_t>(count * nblk_tail * 4 * NL);
     uint32_t *winsum = ctx->ws_take<uint32_t>(count * 4 * NL);
     uint32_t **d_ptrs = ctx->ws_take<uint32_t *>(count);
     ctx->ws_floor = ctx->ws_off;  // the per-MSM stages bump-allocate above the batch area
@@ -947,10 +981,10 @@ static int msm_batch_t(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *b
     if (rc) return rc;
     ctx->batch_ptrs.assign(d_outs, d_outs + count);
     ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_ptrs, ctx->batch_ptrs.data(), count * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
-    uint32_t tot = (uint32_t)count * nseg;
-    ZK_LAUNCH(ctx, "msm_bucket_red", msm_bucket_red<F>, dim3((tot + 63) / 64), dim3(64), 0, slots, B, L, nseg, tot, segsum);
-    unsigned wthreads = (4 * NL * 4 <= 256) ? 256 : 128;
-    ZK_LAUNCH(ctx, "msm_window_sum", msm_window_sum<F>, dim3((unsigned)count), dim3(wthreads), (size_t)wthreads * 4 * NL * 4, segsum, nseg, winsum);
+    ZK_TRY(msm_tail_attr<F>(ctx));
+    ZK_LAUNCH(ctx, "msm_bucket_red", msm_bucket_red<F>, dim3((unsigned)count * nblk_tail), dim3(MSM_TAIL_THREADS), (size_t)MSM_TAIL_THREADS * 4 * NL * 4, slots, B,
+              L, nseg, nblk_tail, segsum);
+    ZK_LAUNCH(ctx, "msm_window_sum", msm_window_sum<F>, dim3((unsigned)count), dim3(64), (size_t)64 * 4 * NL * 4, segsum, nblk_tail, winsum);
     ZK_LAUNCH(ctx, "msm_final", msm_final_batch<F>, dim3((unsigned)count), dim3(64), 0, winsum, (uint32_t)count, d_ptrs);
     return 0;
 }

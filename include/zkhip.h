@@ -51,7 +51,7 @@ const char *zkhip_last_error(const zkhip_ctx *ctx); /* HIP error text of the las
 /* All work is enqueued on this stream (default: a stream the context creates). */
 int zkhip_set_stream(zkhip_ctx *ctx, void *hip_stream);
 int zkhip_sync(zkhip_ctx *ctx);
-/* Tunables: "msm_window_bits" (0 = auto), "msm_segment_log" , "ntt_radix_log", "ntt_tile_log". */
+/* Tunables: "msm_window_bits" (0 = auto), "msm_segment_log" (tail: 2^k buckets per lane), "ntt_radix_log", "ntt_tile_log". */
 int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value);
 
 /* ---- device memory (plumbing for callers that keep vectors resident) -------------------------- */

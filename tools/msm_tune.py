@@ -10,7 +10,7 @@ b = ctx.bases_from_scalars(0, 1, ks)
 sc = bench.random_scalars(np, n, 2)
 d_s = ctx.malloc(sc.nbytes); ctx.h2d(d_s, sc)
 d_o = ctx.malloc(144)
-for seg in (5, 4, 3, 2):
+for seg in (0, 1, 2, 3):
     ctx.set_option("msm_segment_log", seg)
     ctx.msm_dev(b, d_s, d_o); ctx.sync()
     ctx.profile_reset(); ctx.profile(True)
