@@ -56,6 +56,7 @@ struct zkhip_ctx {
     // bump-allocated workspace, grown on demand, reused across calls
     char *ws = nullptr;
     size_t ws_cap = 0, ws_off = 0, ws_floor = 0;  // ws_floor: start of the per-call region (a batch parks data below it)
+    std::vector<uint64_t> lincomb_stage, lincomb_coeffs;  // host staging of zkhip_poly_lincomb_dev's tables
     std::vector<uint32_t *> batch_ptrs;            // host copy of a batch's output pointers (alive until the copy ran)
     // pinned staging for small results
     void *pinned = nullptr;

@@ -40,12 +40,12 @@
 using namespace zkhip;
 
 #include "msm_recode.hpp"
+#include "msm_bucket_acc.hpp"
 
 static constexpr uint32_t MSM_LARGE_BUCKET = 128;  // buckets above this many entries are split across workgroups
 static constexpr uint32_t MSM_LARGE_CHUNK = 4096;  // entries per task of a split bucket
 #ifndef MSM_G1_THREADS
 #define MSM_G1_THREADS 256
-#define MSM_G1_WAVES 3
 #endif
 
 // exclusive scan of `count` u32 counters in three launches: per-block (1024 counters) local scan + block
@@ -363,101 +363,6 @@ __global__ __launch_bounds__(64) void msm_large_combine(const uint32_t *__restri
         if (t == 0) xyzz_store<F>(buckets + (size_t)g * (4 * NL), acc);
         __syncthreads();
     }
-}
-
-// ---- bucket accumulation with the accumulator in LDS (G1) ------------------------------------------------------
-// A wave issues one VALU instruction per ~4 cycles, so throughput scales with waves per SIMD (measured linear up to
-// 4, tools/mulbench).  Holding X, Y, ZZ of the running sum in LDS (conflict-free [coord][quad][lane] uint4 planes)
-// instead of VGPRs brings the kernel under 168 registers: three waves per SIMD instead of two.  ZZZ stays in
-// registers; the mixed addition reads the LDS coordinates where it uses them and writes the results back.
-template <class F, int NT>
-struct LdsAcc {
-    static constexpr int Q = FieldOps<F>::WORDS / 4;  // uint4 per coordinate
-    uint4 *base;                                      // [3][Q][NT]
-    uint32_t t;
-    ZK_D F get(int coord) const {
-        uint32_t w[FieldOps<F>::WORDS];
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            uint4 v = base[(coord * Q + q) * NT + t];
-            w[4 * q] = v.x, w[4 * q + 1] = v.y, w[4 * q + 2] = v.z, w[4 * q + 3] = v.w;
-        }
-        F r;
-#pragma unroll
-        for (int i = 0; i < F::L; ++i) r.v[i] = w[i];
-        return r;
-    }
-    ZK_D void put(int coord, const F &x) const {
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            uint4 v;
-            v.x = 4 * q + 0 < F::L ? x.v[4 * q + 0] : 0u;
-            v.y = 4 * q + 1 < F::L ? x.v[4 * q + 1] : 0u;
-            v.z = 4 * q + 2 < F::L ? x.v[4 * q + 2] : 0u;
-            v.w = 4 * q + 3 < F::L ? x.v[4 * q + 3] : 0u;
-            base[(coord * Q + q) * NT + t] = v;
-        }
-    }
-};
-
-template <class F, int NT>
-__global__ __launch_bounds__(NT, 3) void msm_bucket_acc_lds(const uint32_t *__restrict__ bases, size_t tab_stride_words, uint32_t B,
-                                                           const uint32_t *__restrict__ offs, const uint32_t *__restrict__ idx, uint32_t nbuckets,
-                                                           uint32_t large, const uint32_t *__restrict__ order, uint32_t *__restrict__ buckets) {
-    typedef FieldOps<F> O;
-    constexpr int NL = O::WORDS;
-    extern __shared__ __attribute__((aligned(16))) uint4 acc_lds[];
-    const uint32_t tid = threadIdx.x, slot = blockIdx.x * NT + tid;
-    if (slot >= nbuckets) return;
-    const uint32_t g = order[slot];  // buckets by descending size (msm_size_*)
-    const uint32_t *tab = bases + (size_t)(g / B) * tab_stride_words;
-    const uint32_t lo = offs[g], hi = offs[g + 1];
-    if (hi - lo > large) return;
-    LdsAcc<F, NT> A = {acc_lds, tid};
-    enum { CX = 0, CY = 1, CZZ = 2 };
-    F ZZZ = F::zero();
-    bool inf = true;
-    for (uint32_t k = lo; k < hi; ++k) {
-        const uint32_t e = idx[k];
-        Affine<F> p = affine_load<F>(tab + (size_t)(e & 0x7FFFFFFFu) * (2 * NL));
-        if (p.is_inf()) continue;
-        if (e >> 31) p.y = O::template sub<O::K1>(F::zero(), p.y);
-        if (inf) {
-            A.put(CX, p.x);
-            A.put(CY, p.y);
-            A.put(CZZ, F::one());
-            ZZZ = F::one();
-            inf = false;
-            continue;
-        }
-        // xyzz_madd (curve.hpp) with X, Y, ZZ fetched from LDS at their points of use
-        F Pd = O::template sub<O::K2>(O::mul(p.x, A.get(CZZ)), A.get(CX));
-        F R = O::template sub<O::K2>(O::mul(p.y, ZZZ), A.get(CY));
-        F PP = O::sqr(Pd);
-        if (O::is_zero_product(PP)) {  // same x: doubling or cancellation (rare)
-            if (O::is_zero(R)) {
-                XYZZ<F> d = xyzz_dbl_affine(p);
-                A.put(CX, d.X);
-                A.put(CY, d.Y);
-                A.put(CZZ, d.ZZ);
-                ZZZ = d.ZZZ;
-            } else {
-                inf = true;
-            }
-            continue;
-        }
-        F PPP = O::mul(Pd, PP);
-        F Q = O::mul(A.get(CX), PP);
-        F X3 = O::template sub<O::K1>(O::sqr(R), O::add(PPP, O::add(Q, Q)));
-        F Y3 = O::template sub<O::K1>(O::mul(R, O::template sub<O::K2>(Q, X3)), O::mul(A.get(CY), PPP));
-        A.put(CX, X3);
-        A.put(CY, Y3);
-        A.put(CZZ, O::mul(A.get(CZZ), PP));
-        ZZZ = O::mul(ZZZ, PPP);
-    }
-    XYZZ<F> out = XYZZ<F>::infinity();
-    if (!inf) out = {A.get(CX), A.get(CY), A.get(CZZ), ZZZ};
-    xyzz_store<F>(buckets + (size_t)g * (4 * NL), out);
 }
 
 // buckets[w][b] += buckets[w + half][b] for w < cnt (one level of the tree that folds equal-weight windows)
@@ -843,18 +748,20 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     ZK_LAUNCH(ctx, "msm_size_sort", msm_scan_add, dim3(sblk2), dim3(256), 0, so, nsh, ssums, so);
     ZK_LAUNCH(ctx, "msm_size_sort", msm_size_scatter, dim3(sblk), dim3(256), 0, offs, nb, sblk, large_thresh, so, order);
     if constexpr (FieldOps<F>::WORDS <= 16) {
-        // G1: accumulator in LDS, three waves per SIMD (256-lane workgroups, three per CU)
+        // G1: accumulator coordinates in LDS, three waves per SIMD (256-lane workgroups, three per CU)
         constexpr int NT = MSM_G1_THREADS;
-        size_t lds_acc = (size_t)3 * (NL / 4) * NT * 16;
+        size_t lds_acc = LdsAcc<F, NT>::BYTES;
         static bool attr_acc = false;
         if (!attr_acc) {
-            ZK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&msm_bucket_acc_lds<F, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            ZK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&msm_bucket_acc_lds<F, NT, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                   (int)lds_acc));
             attr_acc = true;
         }
-        ZK_LAUNCH(ctx, "msm_bucket_acc", (msm_bucket_acc_lds<F, NT>), dim3((nb + NT - 1) / NT), dim3(NT), lds_acc, d_b, tab_stride_words, B, offs, idx,
+        ZK_LAUNCH(ctx, "msm_bucket_acc", (msm_bucket_acc_lds<F, NT, 3>), dim3((nb + NT - 1) / NT), dim3(NT), lds_acc, d_b, tab_stride_words, B, offs, idx,
                   nb, large_thresh, order, buckets);
     } else {
+        // G2: everything in registers at one wave per SIMD.  The LDS variant (msm_bucket_acc_lds<F, 64, 2>: 256 VGPRs,
+        // ~200 spilled dwords, 7 waves per CU) measured 14.8 ms against 14.2 ms for this kernel at 2^20 points.
         ZK_LAUNCH(ctx, "msm_bucket_acc", (msm_bucket_acc<F, 256, 1>), dim3((nb + 255) / 256), dim3(256), 0, d_b, tab_stride_words, B, offs, idx, nb,
                   large_thresh, order, buckets);
     }

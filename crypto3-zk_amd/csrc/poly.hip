@@ -65,6 +65,198 @@ __global__ __launch_bounds__(256) void fri_fold(const uint32_t *__restrict__ f, 
     }
 }
 
+
+// ---- coefficient-form arithmetic of the KZG opening proof (kzg_v2.hpp:236-305) --------------------------------
+// Elements are canonical integers in HBM; constants (evaluation points, linear-combination coefficients) are
+// converted to Montgomery form once, so `fu_mul(canonical, montgomery)` yields the canonical-domain product < 2p.
+
+// out[i] = a[i] op b[i]   (op 0: +, 1: -, 2: *)   polynomial_dfs::operator+=, -=, *= on equal domains
+template <class U>
+__global__ __launch_bounds__(256) void fr_vec_op(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, size_t count, int op,
+                                                 uint32_t *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Fu<U> x = fu_unpack<U>(a + i * U::NL), y = fu_unpack<U>(b + i * U::NL), r;
+    if (op == 0) r = fu_cond_sub_p(fu_add(x, y));
+    else if (op == 1) r = fu_cond_sub_p(fu_cond_sub_p(fu_sub<2>(x, y)));  // x + 2p - y in (p, 3p)
+    else r = fu_cond_sub_p(fu_mul(fu_mul(x, y), Fu<U>::r2()));  // (x y / R) R^2 / R
+    fu_pack<U>(out + i * U::NL, r);
+}
+
+// canonical -> Montgomery (canonical representative) for a short table of constants
+template <class U>
+__global__ void fr_table_to_mont(const uint32_t *__restrict__ canon, uint32_t count, uint32_t *__restrict__ mont) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    fu_store<U>(mont + (size_t)i * U::SL, fu_cond_sub_p(fu_from_canonical<U>(canon + (size_t)i * U::NL)));
+}
+
+// Horner machinery shared by evaluation and division by (X - z).  A lane owns HORNER_CHUNK consecutive
+// coefficients, a workgroup of 256 lanes owns HORNER_BLOCK = 8192.
+//   S_t   = sum_{j in chunk t} f[j] z^(j - chunk start)                      (local Horner)
+//   V_t   = sum_{u >= t} S_u z^(C (u - t))  within the workgroup             (suffix scan, log steps, z^(C 2^k))
+//   P_b   = V_0 of workgroup b; G over workgroups by a short sequential pass  (poly_block_carry)
+static constexpr uint32_t HORNER_CHUNK = 32, HORNER_BLOCK = 256 * HORNER_CHUNK;
+
+// zpow[p][k] = z_p^(C 2^k) for k = 0..8 (k = 8: z^HORNER_BLOCK), zpow[p][9] = z_p; Montgomery form
+template <class U>
+__global__ void horner_setup(const uint32_t *__restrict__ points_c, uint32_t npoints, uint32_t *__restrict__ zpow) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npoints) return;
+    Fu<U> z = fu_cond_sub_p(fu_from_canonical<U>(points_c + (size_t)p * U::NL));
+    fu_store<U>(zpow + ((size_t)p * 10 + 9) * U::SL, z);
+    Fu<U> w = z;
+    for (int i = 0; i < 5; ++i) w = fu_mul(w, w);  // z^32
+    for (int k = 0; k <= 8; ++k) {
+        w = fu_cond_sub_p(w);
+        fu_store<U>(zpow + ((size_t)p * 10 + k) * U::SL, w);
+        w = fu_mul(w, w);
+    }
+}
+
+template <class U>
+ZK_D Fu<U> horner_chunk(const uint32_t *__restrict__ f, size_t n, size_t start, const Fu<U> &z) {
+    Fu<U> acc = Fu<U>::zero();
+    for (int j = HORNER_CHUNK - 1; j >= 0; --j) {
+        size_t e = start + j;
+        acc = fu_mul(acc, z);
+        if (e < n) acc = fu_add(acc, fu_unpack<U>(f + e * U::NL));
+    }
+    return acc;  // < 3p
+}
+
+// suffix scan over the 256 lanes of a workgroup: returns V_t (and leaves all V in lds)
+template <class U>
+ZK_D Fu<U> horner_block_scan(uint32_t *lds, Fu<U> v, uint32_t t, const uint32_t *__restrict__ zp) {
+    fu_store<U>(lds + (size_t)t * U::SL, v);
+    __syncthreads();
+    for (uint32_t k = 0, d = 1; d < 256; ++k, d <<= 1) {
+        Fu<U> add = Fu<U>::zero();
+        const bool has = t + d < 256;
+        if (has) add = fu_mul(fu_load<U>(lds + (size_t)(t + d) * U::SL), fu_load<U>(zp + (size_t)k * U::SL));
+        __syncthreads();
+        if (has) {
+            v = fu_cond_sub_p(fu_mul(fu_add(v, add), Fu<U>::one()));  // back under p: the next level adds again
+            fu_store<U>(lds + (size_t)t * U::SL, v);
+        }
+        __syncthreads();
+    }
+    return v;
+}
+
+// grid (blocks per polynomial, batch, npoints): part[(poly * npoints + p) * nblk + b] = P_b
+template <class U>
+__global__ __launch_bounds__(256) void poly_block_horner(const uint32_t *__restrict__ polys, size_t n, size_t stride, uint32_t nblk, uint32_t npoints,
+                                                         const uint32_t *__restrict__ zpow, uint32_t *__restrict__ part) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[256 * U::SL];
+    const uint32_t t = threadIdx.x, b = blockIdx.x, poly = blockIdx.y, p = blockIdx.z;
+    const uint32_t *f = polys + (size_t)poly * stride * U::NL;
+    const uint32_t *zp = zpow + (size_t)p * 10 * U::SL;
+    Fu<U> s = horner_chunk<U>(f, n, (size_t)b * HORNER_BLOCK + (size_t)t * HORNER_CHUNK, fu_load<U>(zp + 9 * U::SL));
+    Fu<U> v = horner_block_scan<U>(lds, fu_cond_sub_p(fu_mul(s, Fu<U>::one())), t, zp);
+    if (t == 0) fu_store<U>(part + (((size_t)poly * npoints + p) * nblk + b) * U::SL, v);
+}
+
+// one lane per (polynomial, point): carry[b] = G at the start of workgroup b + 1 (0 for the last), value = G_0 = f(z)
+template <class U>
+__global__ void poly_block_carry(const uint32_t *__restrict__ part, uint32_t nblk, uint32_t npoints, uint32_t total, const uint32_t *__restrict__ zpow,
+                                 uint32_t *__restrict__ carry, uint32_t *__restrict__ values) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;  // = poly * npoints + p
+    if (g >= total) return;
+    const uint32_t p = g % npoints;
+    const Fu<U> zb = fu_load<U>(zpow + ((size_t)p * 10 + 8) * U::SL);
+    Fu<U> acc = Fu<U>::zero();
+    for (int b = (int)nblk - 1; b >= 0; --b) {
+        if (carry) fu_store<U>(carry + ((size_t)g * nblk + b) * U::SL, acc);
+        acc = fu_cond_sub_p(fu_mul(fu_add(fu_mul(acc, zb), fu_load<U>(part + ((size_t)g * nblk + b) * U::SL)), Fu<U>::one()));
+    }
+    fu_pack<U>(values + (size_t)g * U::NL, acc);
+}
+
+// division by (X - z): out[j] = G_j = sum_{t >= j} f[t] z^(t - j);  out[0] = f(z), out[1..n) = quotient.  In place allowed.
+template <class U>
+__global__ __launch_bounds__(256) void poly_div_finish(const uint32_t *f, size_t n, uint32_t nblk, const uint32_t *__restrict__ zpow,
+                                                       const uint32_t *__restrict__ carry, uint32_t *out) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[256 * U::SL];
+    const uint32_t t = threadIdx.x, b = blockIdx.x;
+    const size_t start = (size_t)b * HORNER_BLOCK + (size_t)t * HORNER_CHUNK;
+    const Fu<U> z = fu_load<U>(zpow + 9 * U::SL);
+    Fu<U> s = horner_chunk<U>(f, n, start, z);
+    horner_block_scan<U>(lds, fu_cond_sub_p(fu_mul(s, Fu<U>::one())), t, zpow);
+    // G at the end of this lane's chunk: V_{t+1} + z^(C (255 - t)) * carry-in of the workgroup
+    Fu<U> cin = fu_load<U>(carry + (size_t)b * U::SL);
+    Fu<U> pw = fu_cond_sub_p(Fu<U>::one());
+    for (uint32_t e = 255 - t, k = 0; e; e >>= 1, ++k)
+        if (e & 1) pw = fu_mul(pw, fu_load<U>(zpow + (size_t)k * U::SL));
+    Fu<U> g = fu_mul(cin, pw);
+    if (t + 1 < 256) g = fu_add(g, fu_load<U>(lds + (size_t)(t + 1) * U::SL));
+    for (int j = HORNER_CHUNK - 1; j >= 0; --j) {
+        size_t e = start + j;
+        if (e >= n) continue;  // beyond the top coefficient: G = 0 there, g is still 0
+        g = fu_cond_sub_p(fu_mul(fu_add(fu_mul(g, z), fu_unpack<U>(f + e * U::NL)), Fu<U>::one()));
+        fu_pack<U>(out + e * U::NL, g);
+    }
+}
+
+// acc[j] (+)= sum_i sum_{t < taps} c[i][t] * poly_i[j - t]   (poly_i = 0 outside [0, len_i)); c in Montgomery form
+template <class U>
+__global__ __launch_bounds__(256) void poly_lincomb(const uint32_t *const *__restrict__ polys, const uint64_t *__restrict__ lens, uint32_t count,
+                                                    uint32_t taps, const uint32_t *__restrict__ coeff, size_t acc_len, int accumulate,
+                                                    uint32_t *__restrict__ acc_out) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= acc_len) return;
+    Fu<U> acc = Fu<U>::zero();
+    uint32_t pending = 0;
+    if (accumulate) acc = fu_unpack<U>(acc_out + j * U::NL), pending = 1;
+    for (uint32_t i = 0; i < count; ++i) {
+        const uint32_t *f = polys[i];
+        const size_t len = lens[i];
+        for (uint32_t t = 0; t < taps; ++t) {
+            if (j < t || j - t >= len) continue;
+            acc = fu_add(acc, fu_mul(fu_unpack<U>(f + (j - t) * U::NL), fu_load<U>(coeff + ((size_t)i * taps + t) * U::SL)));
+            if (++pending == 16) {  // each term is < 2p and the limbs hold ~64p: fold back under 2p
+                acc = fu_mul(acc, Fu<U>::one());
+                pending = 1;
+            }
+        }
+    }
+    fu_pack<U>(acc_out + j * U::NL, fu_cond_sub_p(fu_mul(acc, Fu<U>::one())));
+}
+
+#define ZK_FR_DISPATCH(curve, ...)                 \
+    if ((curve) == CURVE_BLS12_381) {           \
+        typedef BlsFrU U;                       \
+        __VA_ARGS__;                            \
+    } else {                                    \
+        typedef BnFrU U;                        \
+        __VA_ARGS__;                            \
+    }
+
+// shared front half of evaluation and division: per-(polynomial, point) workgroup partials and the pass over them
+template <class U>
+static int horner_run(zkhip_ctx *ctx, const uint32_t *d_polys, size_t n, size_t stride, size_t batch, const uint64_t *points, size_t npoints,
+                      uint32_t **zpow_out, uint32_t **carry_out, uint32_t **values_out, bool want_carry) {
+    const uint32_t nblk = (uint32_t)((n + HORNER_BLOCK - 1) / HORNER_BLOCK);
+    const size_t total = batch * npoints;
+    size_t need = zkhip_ctx::ws_round(npoints * 32) + zkhip_ctx::ws_round(npoints * 10 * U::SL * 4) + zkhip_ctx::ws_round(total * nblk * U::SL * 4) +
+                  zkhip_ctx::ws_round(total * nblk * U::SL * 4) + zkhip_ctx::ws_round(total * 32);
+    ZK_TRY(ctx->ws_reserve(need));
+    ctx->ws_reset();
+    uint32_t *d_pts = ctx->ws_take<uint32_t>(npoints * 8);
+    uint32_t *zpow = ctx->ws_take<uint32_t>(npoints * 10 * U::SL);
+    uint32_t *part = ctx->ws_take<uint32_t>(total * nblk * U::SL);
+    uint32_t *carry = ctx->ws_take<uint32_t>(total * nblk * U::SL);
+    uint32_t *values = ctx->ws_take<uint32_t>(total * 8);
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_pts, points, npoints * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_LAUNCH(ctx, "poly_horner_setup", horner_setup<U>, dim3((unsigned)((npoints + 63) / 64)), dim3(64), 0, d_pts, (uint32_t)npoints, zpow);
+    ZK_LAUNCH(ctx, "poly_block_horner", poly_block_horner<U>, dim3(nblk, (unsigned)batch, (unsigned)npoints), dim3(256), 0, d_polys, n, stride, nblk,
+              (uint32_t)npoints, zpow, part);
+    ZK_LAUNCH(ctx, "poly_block_carry", poly_block_carry<U>, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, part, nblk, (uint32_t)npoints, (uint32_t)total,
+              zpow, want_carry ? carry : nullptr, values);
+    *zpow_out = zpow, *carry_out = carry, *values_out = values;
+    return ZKHIP_OK;
+}
+
 extern "C" {
 
 int zkhip_poly_resize_dev(zkhip_ctx *ctx, int curve, void *d_in, size_t log_n, size_t batch, const uint64_t *omega_n, void *d_out, size_t log_out,
@@ -102,6 +294,84 @@ int zkhip_fri_fold_dev(zkhip_ctx *ctx, int curve, const void *d_f, size_t log_si
         ZK_LAUNCH(ctx, "fri_fold_setup", fri_fold_setup<BnFrU>, dim3(1), dim3(64), 0, d_c, d_c + 8, consts);
         ZK_LAUNCH(ctx, "fri_fold", fri_fold<BnFrU>, grid, block, 0, (const uint32_t *)d_f, (uint32_t)log_size, consts, (uint32_t *)d_out);
     }
+    return ZKHIP_OK;
+}
+
+int zkhip_fr_vec_op_dev(zkhip_ctx *ctx, int curve, int op, const void *d_a, const void *d_b, void *d_out, size_t count) {
+    if (!ctx || (count && (!d_a || !d_b || !d_out)) || op < 0 || op > 2) return ZKHIP_ERR_INVALID;
+    if (curve != CURVE_BLS12_381 && curve != CURVE_BN254) return ZKHIP_ERR_INVALID;
+    if (count == 0) return ZKHIP_OK;
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ZK_FR_DISPATCH(curve, ZK_LAUNCH(ctx, "fr_vec_op", fr_vec_op<U>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (const uint32_t *)d_a,
+                                    (const uint32_t *)d_b, count, op, (uint32_t *)d_out));
+    return ZKHIP_OK;
+}
+
+int zkhip_poly_eval_dev(zkhip_ctx *ctx, int curve, const void *d_polys, size_t n, size_t stride, size_t batch, const uint64_t *points, size_t npoints,
+                        uint64_t *out) {
+    if (!ctx || !out || (batch && npoints && (!d_polys || !points))) return ZKHIP_ERR_INVALID;
+    if (curve != CURVE_BLS12_381 && curve != CURVE_BN254) return ZKHIP_ERR_INVALID;
+    if (stride < n || batch >= 65536 || npoints >= 65536 || n >= ((size_t)1 << 40)) return ZKHIP_ERR_RANGE;
+    if (batch == 0 || npoints == 0) return ZKHIP_OK;
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    uint32_t *zpow, *carry, *values;
+    ZK_FR_DISPATCH(curve, ZK_TRY(horner_run<U>(ctx, (const uint32_t *)d_polys, n, stride, batch, points, npoints, &zpow, &carry, &values, false)));
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(out, values, batch * npoints * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+
+int zkhip_poly_div_linear_dev(zkhip_ctx *ctx, int curve, const void *d_f, size_t n, const uint64_t *z, void *d_out, uint64_t *remainder) {
+    if (!ctx || !z || (n && (!d_f || !d_out))) return ZKHIP_ERR_INVALID;
+    if (curve != CURVE_BLS12_381 && curve != CURVE_BN254) return ZKHIP_ERR_INVALID;
+    if (n >= ((size_t)1 << 40)) return ZKHIP_ERR_RANGE;
+    if (n == 0) {
+        if (remainder) remainder[0] = remainder[1] = remainder[2] = remainder[3] = 0;
+        return ZKHIP_OK;
+    }
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    uint32_t *zpow, *carry, *values;
+    const uint32_t nblk = (uint32_t)((n + HORNER_BLOCK - 1) / HORNER_BLOCK);
+    ZK_FR_DISPATCH(curve, ZK_TRY(horner_run<U>(ctx, (const uint32_t *)d_f, n, n, 1, z, 1, &zpow, &carry, &values, true));
+                   ZK_LAUNCH(ctx, "poly_div_finish", poly_div_finish<U>, dim3(nblk), dim3(256), 0, (const uint32_t *)d_f, n, nblk, zpow, carry,
+                             (uint32_t *)d_out));
+    if (remainder) {
+        ZK_HIP_CHECK(ctx, hipMemcpyAsync(remainder, values, 32, hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return ZKHIP_OK;
+}
+
+int zkhip_poly_lincomb_dev(zkhip_ctx *ctx, int curve, size_t count, const void *const *d_polys, const size_t *lens, const uint64_t *coeffs, size_t taps,
+                           void *d_acc, size_t acc_len, int accumulate) {
+    if (!ctx || (acc_len && !d_acc) || (count && (!d_polys || !lens || !coeffs || taps == 0))) return ZKHIP_ERR_INVALID;
+    if (curve != CURVE_BLS12_381 && curve != CURVE_BN254) return ZKHIP_ERR_INVALID;
+    if (count >= ((size_t)1 << 24) || taps >= 4096) return ZKHIP_ERR_RANGE;
+    if (acc_len == 0) return ZKHIP_OK;
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t nc = std::max<size_t>(1, count * taps);
+    size_t need = zkhip_ctx::ws_round(nc * 32) + zkhip_ctx::ws_round(nc * 16 * 4) + zkhip_ctx::ws_round((count + 1) * 8) * 2;
+    ZK_TRY(ctx->ws_reserve(need));
+    ctx->ws_reset();
+    uint32_t *d_c = ctx->ws_take<uint32_t>(nc * 8);
+    uint32_t *d_m = ctx->ws_take<uint32_t>(nc * 16);
+    const uint32_t **d_p = ctx->ws_take<const uint32_t *>(count + 1);
+    uint64_t *d_l = ctx->ws_take<uint64_t>(count + 1);
+    if (count) {
+        // the pointer / length / coefficient tables are staged through the context so the caller's arrays may die on return
+        ctx->lincomb_stage.resize(count * 2);
+        for (size_t i = 0; i < count; ++i) ctx->lincomb_stage[i] = (uint64_t)(uintptr_t)d_polys[i], ctx->lincomb_stage[count + i] = lens[i];
+        ctx->lincomb_coeffs.assign(coeffs, coeffs + count * taps * 4);
+        ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_p, ctx->lincomb_stage.data(), count * 8, hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_l, ctx->lincomb_stage.data() + count, count * 8, hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_c, ctx->lincomb_coeffs.data(), count * taps * 32, hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // pageable sources: the copies above must not outlive the staging vectors' next reuse
+    }
+    ZK_FR_DISPATCH(curve, static_assert(U::SL <= 16, "coefficient slot");
+                   if (count) ZK_LAUNCH(ctx, "poly_lincomb_setup", fr_table_to_mont<U>, dim3((unsigned)((count * taps + 63) / 64)), dim3(64), 0, d_c,
+                                        (uint32_t)(count * taps), d_m);
+                   ZK_LAUNCH(ctx, "poly_lincomb", poly_lincomb<U>, dim3((unsigned)((acc_len + 255) / 256)), dim3(256), 0, d_p, d_l, (uint32_t)count,
+                             (uint32_t)taps, d_m, acc_len, accumulate, (uint32_t *)d_acc));
     return ZKHIP_OK;
 }
 

@@ -18,6 +18,7 @@ EXPORTS = [
     "zkhip_bases_upload", "zkhip_bases_from_scalars", "zkhip_bases_download", "zkhip_bases_size",
     "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_batch_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_domain_size", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev", "zkhip_fr_gather_dev", "zkhip_poly_resize_dev", "zkhip_fri_fold_dev",
+    "zkhip_fr_vec_op_dev", "zkhip_poly_eval_dev", "zkhip_poly_div_linear_dev", "zkhip_poly_lincomb_dev",
     "zkhip_profile_enable", "zkhip_profile_reset", "zkhip_profile_get", "zkhip_profile_dump",
 ]
 
@@ -249,6 +250,36 @@ class Context:
         return out
 
     # ---- profiling
+    # ---- coefficient-form polynomial arithmetic (KZG opening proofs) ----
+    def fr_vec_op_dev(self, curve: int, op: int, d_a: int, d_b: int, d_out: int, count: int):
+        self._check(self.lib.zkhip_fr_vec_op_dev(self.h, curve, op, ctypes.c_void_p(d_a), ctypes.c_void_p(d_b), ctypes.c_void_p(d_out),
+                                                 ctypes.c_size_t(count)), "fr_vec_op_dev")
+
+    def poly_eval_dev(self, curve: int, d_polys: int, n: int, batch: int, points: np.ndarray, stride=None) -> np.ndarray:
+        """out[b, p] = poly_b(points[p]) for `batch` coefficient vectors of n elements, `stride` elements apart"""
+        pts = _u64(points).reshape(-1, 4)
+        out = np.zeros((batch, len(pts), 4), dtype=np.uint64)
+        self._check(self.lib.zkhip_poly_eval_dev(self.h, curve, ctypes.c_void_p(d_polys), ctypes.c_size_t(n), ctypes.c_size_t(n if stride is None else stride),
+                                                 ctypes.c_size_t(batch), _p(pts), ctypes.c_size_t(len(pts)), _p(out)), "poly_eval_dev")
+        return out
+
+    def poly_div_linear_dev(self, curve: int, d_f: int, n: int, z, d_out: int) -> np.ndarray:
+        """d_out[0] = f(z), d_out[1:] = f / (X - z); returns f(z)"""
+        zz = _u64(z).reshape(4)
+        rem = np.zeros(4, dtype=np.uint64)
+        self._check(self.lib.zkhip_poly_div_linear_dev(self.h, curve, ctypes.c_void_p(d_f), ctypes.c_size_t(n), _p(zz), ctypes.c_void_p(d_out), _p(rem)),
+                    "poly_div_linear_dev")
+        return rem
+
+    def poly_lincomb_dev(self, curve: int, d_polys, lens, coeffs: np.ndarray, taps: int, d_acc: int, acc_len: int, accumulate: bool):
+        count = len(d_polys)
+        ptrs = (ctypes.c_void_p * max(1, count))(*d_polys)
+        ls = (ctypes.c_size_t * max(1, count))(*lens)
+        cf = _u64(coeffs).reshape(-1, 4)
+        assert len(cf) == count * taps
+        self._check(self.lib.zkhip_poly_lincomb_dev(self.h, curve, ctypes.c_size_t(count), ptrs, ls, _p(cf), ctypes.c_size_t(taps), ctypes.c_void_p(d_acc),
+                                                    ctypes.c_size_t(acc_len), 1 if accumulate else 0), "poly_lincomb_dev")
+
     def profile(self, on: bool):
         self._check(self.lib.zkhip_profile_enable(self.h, 1 if on else 0), "zkhip_profile_enable")
 

@@ -151,6 +151,28 @@ int zkhip_poly_resize_dev(zkhip_ctx *ctx, int curve, void *d_in, size_t log_n, s
  * d_out[i] = 1/2 [(1 + alpha omega^-i) d_f[i] + (1 - alpha omega^-i) d_f[i + size/2]], i < size/2 = 2^(log_size-1). */
 int zkhip_fri_fold_dev(zkhip_ctx *ctx, int curve, const void *d_f, size_t log_size, const uint64_t *alpha, const uint64_t *omega, void *d_out);
 
+/* ---- coefficient-form polynomial arithmetic (KZG opening proofs, polynomial_dfs pointwise operators) -------
+ * All vectors are canonical Fr elements (4 limbs) resident on the device.
+ *
+ * polynomial_dfs::operator+= / -= / *= on equal domains (ph/gates_argument.hpp:119-121,
+ * ph/permutation_argument.hpp:148-167): d_out[i] = d_a[i] op d_b[i], op 0 add, 1 sub, 2 mul; in place allowed. */
+int zkhip_fr_vec_op_dev(zkhip_ctx *ctx, int curve, int op, const void *d_a, const void *d_b, void *d_out, size_t count);
+/* polynomial::evaluate for `batch` polynomials (n coefficients each, `stride` elements apart) at `npoints` points
+ * given on the host (eval_polys, batched_commitment.hpp:168-183): out[b * npoints + p] = poly_b(points[p]), host. */
+int zkhip_poly_eval_dev(zkhip_ctx *ctx, int curve, const void *d_polys, size_t n, size_t stride, size_t batch, const uint64_t *points,
+                        size_t npoints, uint64_t *out);
+/* Division by (X - z), the step `f /= V`, `L /= theta_2_vanish` of kzg_v2.hpp:267, 289 performs once per root:
+ * d_out[0] = f(z) (the remainder), d_out[1 .. n) = the quotient's n - 1 coefficients.  d_out may equal d_f.
+ * `remainder` (nullable, host) receives f(z); passing it synchronises the stream. */
+int zkhip_poly_div_linear_dev(zkhip_ctx *ctx, int curve, const void *d_f, size_t n, const uint64_t *z, void *d_out, uint64_t *remainder);
+/* d_acc[j] (+)= sum_i sum_{t < taps} coeffs[i * taps + t] * poly_i[j - t] for j < acc_len (poly_i is zero outside
+ * [0, lens[i])): the accumulation `f += theta_i * (f_i - U) * diffpoly` (kzg_v2.hpp:258-263) for every committed
+ * polynomial in ONE pass (coeffs[i] = theta_i * diffpoly_i, a few taps), and `L += ...` (:281-288) with taps = 1.
+ * d_polys / lens / coeffs are host arrays (device pointers, element counts, canonical Fr); accumulate = 0
+ * overwrites d_acc. */
+int zkhip_poly_lincomb_dev(zkhip_ctx *ctx, int curve, size_t count, const void *const *d_polys, const size_t *lens, const uint64_t *coeffs,
+                           size_t taps, void *d_acc, size_t acc_len, int accumulate);
+
 /* ---- profiling (HIP events on the context's stream around every kernel launch) ------------------ */
 int zkhip_profile_enable(zkhip_ctx *ctx, int on);
 int zkhip_profile_reset(zkhip_ctx *ctx);

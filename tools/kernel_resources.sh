@@ -1,7 +1,7 @@
 #!/bin/bash
 # Print per-kernel VGPR/SGPR/LDS/scratch usage of a HIP shared object (reads the code-object notes).
 set -e
-so=$(readlink -f "$1"); tmp=$(mktemp -d); cd "$tmp"
+tmp=$(mktemp -d); cp "$(readlink -f "$1")" "$tmp/lib.so"; so="$tmp/lib.so"; cd "$tmp"  # the extractor writes next to its input
 /opt/rocm/lib/llvm/bin/llvm-objdump --offloading "$so" >/dev/null 2>&1 || true
 for f in "$(dirname "$so")"/"$(basename "$so")".*gfx950 ./*gfx950; do
   [ -f "$f" ] || continue
