@@ -1,0 +1,461 @@
+//---------------------------------------------------------------------------//
+// zkhip shim: the batched KZG commitment scheme placeholder plugs in as `commitment_scheme_type`, on the MI355X.
+//
+// Mirrors zk/commitments/polynomial/kzg_v2.hpp (class kzg_commitment_scheme_v2, :56-360) on top of
+// zk/commitments/batched_commitment.hpp (class polys_evaluator, :58-249) and
+// zk/commitments/detail/polynomial/eval_storage.hpp:36-95 -- same member names, same call order:
+//   append_to_batch / commit(batch) / append_eval_point[s] / set_batch_size / mark_batch_as_fixed /
+//   preprocess / setup / proof_eval(transcript), public `_z`.
+// What changes: every committed polynomial is transformed to coefficient form ONCE (commit: one batched inverse
+// NTT, kzg.hpp:431) and stays resident; proof_eval's `_polys[k][i].coefficients()` (kzg_v2.hpp:253, 287, an
+// inverse NTT per polynomial per use in the reference) reads those buffers; the two accumulations, the divisions
+// by V and by (X - theta_2) and the two commitments run on the device.
+//
+// Transcript: the reference packs commitments and scalars to bytes (nil::marshalling, outside this tree) and
+// hashes them.  Here TranscriptType is duck-typed on VALUES, the caller's adapter does the packing:
+//   transcript(const single_commitment_type &), transcript(const scalar_value_type &),
+//   scalar_value_type transcript.challenge().
+// commit() returns the vector of single commitments (the reference returns their concatenated byte blob,
+// kzg_v2.hpp:208-226).  verify_eval needs pairings and is not part of this path.
+//---------------------------------------------------------------------------//
+#ifndef ZKHIP_SHIM_KZG_V2_HPP
+#define ZKHIP_SHIM_KZG_V2_HPP
+
+#include <algorithm>
+#include <functional>
+#include <map>
+#include <set>
+#include <vector>
+
+#include "kzg.hpp"
+
+namespace nil {
+namespace crypto3 {
+namespace zk {
+namespace hip {
+
+/// eval_storage (eval_storage.hpp:36-95)
+template <typename CurveType>
+class eval_storage_hip {
+    typedef typename curve_adapter<CurveType>::scalar_value_type value_type;
+    std::map<std::size_t, std::vector<std::vector<value_type>>> z;
+
+public:
+    bool operator==(const eval_storage_hip &other) const { return z == other.z; }
+    std::vector<std::size_t> get_batches() const {
+        std::vector<std::size_t> b;
+        for (const auto &it : z) b.push_back(it.first);
+        return b;
+    }
+    std::size_t get_batches_num() const { return z.size(); }
+    std::size_t get_batch_size(std::size_t batch_id) const { return z.at(batch_id).size(); }
+    std::size_t get_poly_points_number(std::size_t batch_id, std::size_t poly_id) const { return z.at(batch_id)[poly_id].size(); }
+    const std::vector<std::vector<value_type>> &get(std::size_t batch_id) const { return z.at(batch_id); }
+    const std::vector<value_type> &get(std::size_t batch_id, std::size_t poly_id) const { return z.at(batch_id)[poly_id]; }
+    const value_type &get(std::size_t batch_id, std::size_t poly_id, std::size_t point_id) const { return z.at(batch_id)[poly_id][point_id]; }
+    void set_batch_size(std::size_t batch_id, std::size_t batch_size) { z[batch_id].assign(batch_size, {}); }
+    void set_poly_points_number(std::size_t batch_id, std::size_t poly_id, std::size_t n) { z[batch_id][poly_id].assign(n, value_type::zero()); }
+    void set(std::size_t batch_id, std::size_t poly_id, std::size_t point_id, const value_type &v) { z[batch_id][poly_id][point_id] = v; }
+};
+
+namespace detail {
+    /// dense host polynomials of a few coefficients (U, V, diffpoly): math::polynomial as far as proof_eval uses it
+    template <typename S>
+    struct small_poly {
+        typedef std::vector<S> P;
+        static P mul(const P &a, const P &b) {
+            if (a.empty() || b.empty()) return {};
+            P out(a.size() + b.size() - 1, S::zero());
+            for (std::size_t i = 0; i < a.size(); ++i)
+                for (std::size_t j = 0; j < b.size(); ++j) out[i + j] = out[i + j] + a[i] * b[j];
+            return out;
+        }
+        static P add(const P &a, const P &b) {
+            P out(std::max(a.size(), b.size()), S::zero());
+            for (std::size_t i = 0; i < a.size(); ++i) out[i] = out[i] + a[i];
+            for (std::size_t i = 0; i < b.size(); ++i) out[i] = out[i] + b[i];
+            return out;
+        }
+        static P scale(const P &a, const S &c) {
+            P out(a);
+            for (auto &x : out) x = x * c;
+            return out;
+        }
+        static S evaluate(const P &a, const S &x) {
+            S acc = S::zero();
+            for (std::size_t i = a.size(); i-- > 0;) acc = acc * x + a[i];
+            return acc;
+        }
+        /// get_V (batched_commitment.hpp:79-87)
+        static P vanishing(const std::vector<S> &points) {
+            P v {S::one()};
+            for (const auto &x : points) v = mul(v, P {S::zero() - x, S::one()});
+            return v;
+        }
+        /// math::lagrange_interpolation as get_U uses it (batched_commitment.hpp:100-111)
+        static P lagrange(const std::vector<S> &xs, const std::vector<S> &ys) {
+            P out;
+            for (std::size_t k = 0; k < xs.size(); ++k) {
+                P num {S::one()};
+                S den = S::one();
+                for (std::size_t j = 0; j < xs.size(); ++j) {
+                    if (j == k) continue;
+                    num = mul(num, P {S::zero() - xs[j], S::one()});
+                    den = den * (xs[k] - xs[j]);
+                }
+                out = add(out, scale(num, ys[k] * den.inversed()));
+            }
+            return out;
+        }
+    };
+    template <typename S>
+    bool limbs_less(const S &a, const S &b) {
+        for (int i = 3; i >= 0; --i)
+            if (a.limbs[i] != b.limbs[i]) return a.limbs[i] < b.limbs[i];
+        return false;
+    }
+}    // namespace detail
+
+/// algorithms::proof_eval<KZG>(params, f, z) of the basic scheme (kzg.hpp:155-172): commit((f - f(z)) / (X - z)),
+/// f given by its coefficients.
+template <typename CurveType>
+typename curve_adapter<CurveType>::g1_value_type kzg_proof_eval(const kzg_params_hip<CurveType> &params,
+                                                                const std::vector<typename curve_adapter<CurveType>::scalar_value_type> &f,
+                                                                const typename curve_adapter<CurveType>::scalar_value_type &z) {
+    typedef curve_adapter<CurveType> adapter;
+    const context &ctx = params.ctx;
+    if (f.size() > params.commitment_key.size() + 1) throw std::runtime_error("kzg_proof_eval: polynomial longer than the commitment key");
+    if (f.size() <= 1) return adapter::g1_value_type::zero();
+    std::vector<std::uint64_t> host(4 * f.size());
+    for (std::size_t i = 0; i < f.size(); ++i) adapter::scalar_to_limbs(f[i], &host[4 * i]);
+    auto d = ctx.alloc(host.size() * 8);
+    ctx.h2d(d.get(), host.data(), host.size() * 8);
+    std::uint64_t zl[4];
+    adapter::scalar_to_limbs(z, zl);
+    /* q[0] -= f(z); q /= (X - z): the synthetic division drops the remainder f(z) by itself (kzg.hpp:163-169) */
+    check(zkhip_poly_div_linear_dev(ctx.get(), adapter::id, d.get(), f.size(), zl, d.get(), nullptr), "zkhip_poly_div_linear_dev", ctx.get());
+    return multiexp_dev<CurveType, ZKHIP_G1>(ctx, params.commitment_key, 0, f.size() - 1, static_cast<const char *>(d.get()) + 32);
+}
+
+template <typename CurveType, typename TranscriptType>
+class kzg_commitment_scheme_v2_hip {
+public:
+    typedef curve_adapter<CurveType> adapter;
+    typedef CurveType curve_type;
+    typedef typename adapter::scalar_value_type scalar_value_type;
+    typedef typename adapter::g1_value_type single_commitment_type;
+    typedef std::vector<single_commitment_type> commitment_type;
+    typedef TranscriptType transcript_type;
+    typedef kzg_params_hip<CurveType> params_type;
+    typedef polynomial_dfs<CurveType> poly_type;
+    typedef eval_storage_hip<CurveType> eval_storage_type;
+    typedef bool preprocessed_data_type;
+    struct proof_type {
+        eval_storage_type z;
+        single_commitment_type pi_1, pi_2;
+    };
+    /// primitive 2^log_n-th root of unity of the evaluation domains (math::make_evaluation_domain's choice)
+    typedef std::function<scalar_value_type(std::size_t log_n)> root_of_unity_type;
+
+    eval_storage_type _z;
+
+    kzg_commitment_scheme_v2_hip(const params_type &kzg_params, root_of_unity_type root_of_unity) :
+        _params(kzg_params), _root_of_unity(std::move(root_of_unity)) { }
+
+    const params_type &get_commitment_params() const { return _params; }
+    preprocessed_data_type preprocess(transcript_type &) const { return true; }
+    void setup(transcript_type &, preprocessed_data_type = true) { }
+    void mark_batch_as_fixed(std::size_t) { }
+
+    // ---- polys_evaluator (batched_commitment.hpp:197-247) ----
+    void append_to_batch(std::size_t index, const poly_type &poly) {
+        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
+        _polys[index].push_back(poly);
+    }
+    template <typename ContainerType>
+    void append_to_batch(std::size_t index, const ContainerType &polys) {
+        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
+        _polys[index].insert(_polys[index].end(), std::begin(polys), std::end(polys));
+    }
+    void append_eval_point(std::size_t batch_id, const scalar_value_type &point) {
+        for (auto &pts : _points.at(batch_id)) pts.push_back(point);
+    }
+    void append_eval_point(std::size_t batch_id, std::size_t poly_id, const scalar_value_type &point) { _points.at(batch_id).at(poly_id).push_back(point); }
+    void append_eval_points(std::size_t batch_id, const std::vector<scalar_value_type> &points) {
+        for (auto &pts : _points.at(batch_id)) pts.insert(pts.end(), points.begin(), points.end());
+    }
+    void append_eval_points(std::size_t batch_id, std::size_t poly_id, const std::vector<scalar_value_type> &points) {
+        auto &pts = _points.at(batch_id).at(poly_id);
+        pts.insert(pts.end(), points.begin(), points.end());
+    }
+    void set_batch_size(std::size_t batch_id, std::size_t batch_size) {
+        _points[batch_id].resize(batch_size);
+        _locked[batch_id] = true;
+    }
+
+    /// commit(index) (kzg_v2.hpp:208-226): one commitment per polynomial of the batch; the coefficient forms stay
+    /// on the device for proof_eval.
+    commitment_type commit(std::size_t index) {
+        const context &ctx = _params.ctx;
+        const auto &polys = _polys[index];
+        device_batch db;
+        std::size_t total = 0;
+        for (const auto &p : polys) {
+            if (p.size() == 0 || (p.size() & (p.size() - 1))) throw std::runtime_error("commit: polynomial_dfs size must be a power of two");
+            if (p.size() > _params.commitment_key.size()) throw std::runtime_error("commit: polynomial longer than the commitment key");
+            db.offset.push_back(total);
+            db.len.push_back(p.size());
+            total += p.size();
+        }
+        db.data = ctx.alloc(std::max<std::size_t>(1, total) * 32);
+        std::vector<std::uint64_t> host(4 * total);
+        std::size_t at = 0;
+        for (const auto &p : polys)
+            for (const auto &v : p.values) adapter::scalar_to_limbs(v, &host[4 * at++]);
+        if (total) ctx.h2d(db.data.get(), host.data(), host.size() * 8);
+        /* p.coefficients() (kzg.hpp:431): one batched inverse NTT per run of equally sized polynomials */
+        for (std::size_t i = 0; i < polys.size();) {
+            std::size_t j = i;
+            while (j < polys.size() && db.len[j] == db.len[i]) ++j;
+            std::size_t log_n = 0;
+            while (((std::size_t)1 << log_n) < db.len[i]) ++log_n;
+            std::uint64_t w[4];
+            adapter::scalar_to_limbs(_root_of_unity(log_n), w);
+            check(zkhip_ntt_dev(ctx.get(), adapter::id, db.at(i), log_n, j - i, w, 1, nullptr), "zkhip_ntt_dev", ctx.get());
+            i = j;
+        }
+        _ind_commitments[index] = commit_resident(db);
+        _dev[index] = std::move(db);
+        /* state_commited (batched_commitment.hpp:163-166) */
+        _locked[index] = true;
+        _points[index].resize(polys.size());
+        return _ind_commitments[index];
+    }
+
+    /// proof_eval (kzg_v2.hpp:236-305)
+    proof_type proof_eval(transcript_type &transcript) {
+        typedef detail::small_poly<scalar_value_type> SP;
+        const context &ctx = _params.ctx;
+        eval_polys();
+        merge_eval_points();
+        for (const auto &it : _ind_commitments) update_transcript(it.first, transcript);
+
+        auto theta = transcript.challenge();
+        const std::vector<scalar_value_type> V = SP::vanishing(_merged_points);
+
+        /* every committed polynomial in the reference's iteration order (batches ascending, then index) */
+        struct item {
+            std::size_t k, i;
+            const void *d;
+            std::size_t len;
+            std::vector<scalar_value_type> U, diff;
+        };
+        std::vector<item> items;
+        std::size_t max_len = 0, taps = 1;
+        for (const auto &it : _dev) {
+            const std::size_t k = it.first;
+            for (std::size_t i = 0; i < it.second.len.size(); ++i) {
+                item e {k, i, it.second.at(i), it.second.len[i], get_U(k, i), set_difference_polynom(_points.at(k)[i])};
+                max_len = std::max(max_len, e.len);
+                taps = std::max(taps, e.diff.size());
+                items.push_back(std::move(e));
+            }
+        }
+        single_commitment_type pi_1 = single_commitment_type::zero(), pi_2 = single_commitment_type::zero();
+        if (!items.empty()) {
+            /* f = sum_i theta^i (f_i - U_i) diffpoly_i (kzg_v2.hpp:251-263): the f_i part in one pass over the resident
+               coefficients, the U_i part (a few coefficients) on the host */
+            const std::size_t acc_len = max_len + taps - 1;
+            std::vector<const void *> ptrs;
+            std::vector<std::size_t> lens;
+            std::vector<std::uint64_t> coeffs(items.size() * taps * 4, 0);
+            std::vector<scalar_value_type> corr;
+            scalar_value_type theta_i = scalar_value_type::one();
+            for (std::size_t n = 0; n < items.size(); ++n) {
+                ptrs.push_back(items[n].d);
+                lens.push_back(items[n].len);
+                auto c = SP::scale(items[n].diff, theta_i);
+                for (std::size_t t = 0; t < c.size(); ++t) adapter::scalar_to_limbs(c[t], &coeffs[4 * (n * taps + t)]);
+                corr = SP::add(corr, SP::scale(SP::mul(items[n].U, c), scalar_value_type::zero() - scalar_value_type::one()));
+                theta_i = theta_i * theta;
+            }
+            auto d_f = ctx.alloc(acc_len * 32);
+            check(zkhip_poly_lincomb_dev(ctx.get(), adapter::id, items.size(), ptrs.data(), lens.data(), coeffs.data(), taps, d_f.get(), acc_len, 0),
+                  "zkhip_poly_lincomb_dev", ctx.get());
+            add_low_coefficients(d_f.get(), corr, acc_len);
+            /* f /= V, one root at a time (kzg_v2.hpp:266-267); the remainders are the BOOST_ASSERT */
+            char *f_ptr = static_cast<char *>(d_f.get());
+            std::size_t f_len = acc_len;
+            for (const auto &root : _merged_points) divide_in_place(f_ptr, f_len, root, "proof_eval: f is not divisible by V");
+            pi_1 = commit_range(f_ptr, f_len);
+            transcript(pi_1);
+
+            auto theta_2 = transcript.challenge();
+            /* L = sum_i theta^i Z_{T\S_i}(theta_2) (f_i - U_i(theta_2)) - V(theta_2) f (kzg_v2.hpp:281-289) */
+            ptrs.push_back(f_ptr);
+            lens.push_back(f_len);
+            std::vector<std::uint64_t> c1((items.size() + 1) * 4, 0);
+            scalar_value_type l0 = scalar_value_type::zero();
+            theta_i = scalar_value_type::one();
+            for (std::size_t n = 0; n < items.size(); ++n) {
+                auto s = theta_i * SP::evaluate(items[n].diff, theta_2);
+                adapter::scalar_to_limbs(s, &c1[4 * n]);
+                l0 = l0 - s * SP::evaluate(items[n].U, theta_2);
+                theta_i = theta_i * theta;
+            }
+            adapter::scalar_to_limbs(scalar_value_type::zero() - SP::evaluate(V, theta_2), &c1[4 * items.size()]);
+            const std::size_t l_len = std::max(max_len, f_len);
+            auto d_l = ctx.alloc(std::max<std::size_t>(1, l_len) * 32);
+            check(zkhip_poly_lincomb_dev(ctx.get(), adapter::id, ptrs.size(), ptrs.data(), lens.data(), c1.data(), 1, d_l.get(), l_len, 0),
+                  "zkhip_poly_lincomb_dev", ctx.get());
+            add_low_coefficients(d_l.get(), {l0}, l_len);
+            /* L /= (X - theta_2) (kzg_v2.hpp:290-291) */
+            char *l_ptr = static_cast<char *>(d_l.get());
+            std::size_t ll = l_len;
+            divide_in_place(l_ptr, ll, theta_2, "proof_eval: L(theta_2) != 0");
+            pi_2 = commit_range(l_ptr, ll);
+            ctx.sync();    // d_f / d_l are released on return
+        } else {
+            transcript(pi_1);
+            (void)transcript.challenge();
+        }
+        /* TODO in the reference: "Review the necessity of sending pi_2 to transcript" (kzg_v2.hpp:295) -- kept */
+        transcript(pi_2);
+        return proof_type {_z, pi_1, pi_2};
+    }
+
+    const std::map<std::size_t, commitment_type> &commitments() const { return _ind_commitments; }
+
+protected:
+    struct device_batch {
+        std::shared_ptr<void> data;
+        std::vector<std::size_t> offset, len;    // in elements
+        void *at(std::size_t i) const { return static_cast<char *>(data.get()) + 32 * offset[i]; }
+    };
+
+    /// multiexp(commitment_key[0 .. len), coefficients) for every polynomial of a resident batch, as one device batch
+    commitment_type commit_resident(const device_batch &db) const {
+        const context &ctx = _params.ctx;
+        const std::size_t count = db.len.size(), jl = 3 * adapter::g1_coord_limbs;
+        commitment_type out;
+        if (count == 0) return out;
+        auto d_res = ctx.alloc(count * jl * 8);
+        std::vector<const zkhip_bases *> qb(count, _params.commitment_key.get());
+        std::vector<std::size_t> qo(count, 0);
+        std::vector<const void *> qs(count);
+        std::vector<void *> qr(count);
+        for (std::size_t i = 0; i < count; ++i) {
+            qs[i] = db.at(i);
+            qr[i] = static_cast<std::uint64_t *>(d_res.get()) + i * jl;
+        }
+        check(zkhip_msm_batch_dev(ctx.get(), count, qb.data(), qo.data(), db.len.data(), qs.data(), qr.data()), "zkhip_msm_batch_dev", ctx.get());
+        std::vector<std::uint64_t> res(count * jl);
+        ctx.d2h(res.data(), d_res.get(), res.size() * 8);
+        for (std::size_t i = 0; i < count; ++i) out.push_back(adapter::g1_from_jacobian(&res[i * jl]));
+        return out;
+    }
+    single_commitment_type commit_range(const void *d_coeffs, std::size_t len) const {
+        if (len == 0) return single_commitment_type::zero();
+        if (len > _params.commitment_key.size()) throw std::runtime_error("proof_eval: quotient longer than the commitment key");
+        return multiexp_dev<CurveType, ZKHIP_G1>(_params.ctx, _params.commitment_key, 0, len, d_coeffs);
+    }
+    /// d[0 .. small.size()) += small
+    void add_low_coefficients(void *d, const std::vector<scalar_value_type> &small, std::size_t len) const {
+        const context &ctx = _params.ctx;
+        const std::size_t n = std::min(small.size(), len);
+        if (n == 0) return;
+        std::vector<std::uint64_t> h(4 * n);
+        for (std::size_t i = 0; i < n; ++i) adapter::scalar_to_limbs(small[i], &h[4 * i]);
+        auto tmp = ctx.alloc(n * 32);
+        ctx.h2d(tmp.get(), h.data(), h.size() * 8);
+        check(zkhip_fr_vec_op_dev(ctx.get(), adapter::id, 0, d, tmp.get(), d, n), "zkhip_fr_vec_op_dev", ctx.get());
+        ctx.sync();
+    }
+    /// (ptr, len) <- quotient by (X - root); throws when the remainder is not zero
+    void divide_in_place(char *&ptr, std::size_t &len, const scalar_value_type &root, const char *what) const {
+        if (len == 0) return;
+        std::uint64_t zl[4], rem[4];
+        adapter::scalar_to_limbs(root, zl);
+        check(zkhip_poly_div_linear_dev(_params.ctx.get(), adapter::id, ptr, len, zl, ptr, rem), "zkhip_poly_div_linear_dev", _params.ctx.get());
+        if (rem[0] | rem[1] | rem[2] | rem[3]) throw std::runtime_error(what);
+        ptr += 32;
+        len -= 1;
+    }
+
+    /// eval_polys (batched_commitment.hpp:168-183): every polynomial of a batch at the union of the batch's points
+    void eval_polys() {
+        const context &ctx = _params.ctx;
+        for (const auto &it : _dev) {
+            const std::size_t k = it.first;
+            const device_batch &db = it.second;
+            const auto &point = _points.at(k);
+            _z.set_batch_size(k, db.len.size());
+            std::vector<scalar_value_type> uni;
+            for (const auto &pl : point)
+                for (const auto &x : pl)
+                    if (std::find(uni.begin(), uni.end(), x) == uni.end()) uni.push_back(x);
+            std::vector<std::uint64_t> pts(4 * uni.size());
+            for (std::size_t j = 0; j < uni.size(); ++j) adapter::scalar_to_limbs(uni[j], &pts[4 * j]);
+            for (std::size_t i = 0; i < db.len.size();) {
+                std::size_t j = i;
+                while (j < db.len.size() && db.len[j] == db.len[i]) ++j;
+                std::vector<std::uint64_t> vals(4 * (j - i) * uni.size());
+                if (!uni.empty())
+                    check(zkhip_poly_eval_dev(ctx.get(), adapter::id, db.at(i), db.len[i], db.len[i], j - i, pts.data(), uni.size(), vals.data()),
+                          "zkhip_poly_eval_dev", ctx.get());
+                for (std::size_t p = i; p < j; ++p) {
+                    _z.set_poly_points_number(k, p, point[p].size());
+                    for (std::size_t q = 0; q < point[p].size(); ++q) {
+                        const std::size_t u = std::find(uni.begin(), uni.end(), point[p][q]) - uni.begin();
+                        _z.set(k, p, q, adapter::scalar_from_limbs(&vals[4 * ((p - i) * uni.size() + u)]));
+                    }
+                }
+                i = j;
+            }
+        }
+    }
+    /// merge_eval_points (kzg_v2.hpp:121-130)
+    void merge_eval_points() {
+        _merged_points.clear();
+        for (const auto &it : _points)
+            for (const auto &pl : it.second)
+                for (const auto &x : pl)
+                    if (std::find(_merged_points.begin(), _merged_points.end(), x) == _merged_points.end()) _merged_points.push_back(x);
+        std::sort(_merged_points.begin(), _merged_points.end(), detail::limbs_less<scalar_value_type>);
+    }
+    /// set_difference_polynom (kzg_v2.hpp:132-148)
+    std::vector<scalar_value_type> set_difference_polynom(const std::vector<scalar_value_type> &points) const {
+        std::vector<scalar_value_type> rest;
+        for (const auto &x : _merged_points)
+            if (std::find(points.begin(), points.end(), x) == points.end()) rest.push_back(x);
+        return detail::small_poly<scalar_value_type>::vanishing(rest);
+    }
+    /// get_U (batched_commitment.hpp:100-111)
+    std::vector<scalar_value_type> get_U(std::size_t b_ind, std::size_t poly_ind) const {
+        return detail::small_poly<scalar_value_type>::lagrange(_points.at(b_ind)[poly_ind], _z.get(b_ind, poly_ind));
+    }
+    /// update_transcript (kzg_v2.hpp:150-190): commitments, evaluations, U polynomials
+    void update_transcript(std::size_t batch_ind, transcript_type &transcript) {
+        for (const auto &c : _ind_commitments.at(batch_ind)) transcript(c);
+        for (std::size_t i = 0; i < _z.get_batch_size(batch_ind); ++i)
+            for (std::size_t j = 0; j < _z.get_poly_points_number(batch_ind, i); ++j) transcript(_z.get(batch_ind, i, j));
+        for (std::size_t i = 0; i < _points.at(batch_ind).size(); ++i)
+            for (const auto &c : get_U(batch_ind, i)) transcript(c);
+    }
+
+    const params_type &_params;
+    root_of_unity_type _root_of_unity;
+    std::map<std::size_t, std::vector<poly_type>> _polys;
+    std::map<std::size_t, bool> _locked;
+    std::map<std::size_t, std::vector<std::vector<scalar_value_type>>> _points;
+    std::map<std::size_t, device_batch> _dev;
+    std::map<std::size_t, commitment_type> _ind_commitments;
+    std::vector<scalar_value_type> _merged_points;
+};
+
+}    // namespace hip
+}    // namespace zk
+}    // namespace crypto3
+}    // namespace nil
+
+#endif    // ZKHIP_SHIM_KZG_V2_HPP

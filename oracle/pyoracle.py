@@ -828,6 +828,121 @@ def ipp2_prove_commitment_w(curve: Curve, n, alpha, beta, tr, r_shift, z):
 # --------------------------------------------------------------------------------------
 # limb helpers shared by the tests (canonical little-endian u64 limbs at the C ABI)
 # --------------------------------------------------------------------------------------
+# ---------------------------------------------------------------------------------------------------------
+# KZG v2 batched opening proof (zk/commitments/polynomial/kzg_v2.hpp:236-305 on top of
+# zk/commitments/batched_commitment.hpp:73-183).  Coefficient lists are low degree first.
+def poly_trim(a: Sequence[int]) -> List[int]:
+    a = list(a)
+    while a and a[-1] == 0:
+        a.pop()
+    return a
+
+
+def poly_add(a, b, r):
+    n = max(len(a), len(b))
+    return [((a[i] if i < len(a) else 0) + (b[i] if i < len(b) else 0)) % r for i in range(n)]
+
+
+def poly_sub(a, b, r):
+    n = max(len(a), len(b))
+    return [((a[i] if i < len(a) else 0) - (b[i] if i < len(b) else 0)) % r for i in range(n)]
+
+
+def poly_scale(a, c, r):
+    return [x * c % r for x in a]
+
+
+def poly_mul(a, b, r):
+    if not a or not b:
+        return []
+    out = [0] * (len(a) + len(b) - 1)
+    for i, x in enumerate(a):
+        if x:
+            for j, y in enumerate(b):
+                out[i + j] = (out[i + j] + x * y) % r
+    return out
+
+
+def poly_eval(a, z, r):
+    acc = 0
+    for x in reversed(a):
+        acc = (acc * z + x) % r
+    return acc
+
+
+def poly_divmod(a, b, r):
+    """long division: returns (quotient, remainder); b's leading coefficient must be invertible"""
+    a, b = poly_trim(a), poly_trim(b)
+    if len(a) < len(b):
+        return [], a
+    inv = pow(b[-1], -1, r)
+    q = [0] * (len(a) - len(b) + 1)
+    rem = list(a)
+    for i in range(len(q) - 1, -1, -1):
+        c = rem[i + len(b) - 1] * inv % r
+        q[i] = c
+        if c:
+            for j, y in enumerate(b):
+                rem[i + j] = (rem[i + j] - c * y) % r
+    return q, poly_trim(rem[: len(b) - 1])
+
+
+def vanishing_poly(points, r):
+    """get_V (batched_commitment.hpp:79-87): prod (X - x_i)"""
+    v = [1]
+    for x in points:
+        v = poly_mul(v, [(-x) % r, 1], r)
+    return v
+
+
+def lagrange_interpolation(pairs, r):
+    """math::lagrange_interpolation as get_U uses it (batched_commitment.hpp:100-111): the unique polynomial of
+    degree < len(pairs) through (x_k, y_k)"""
+    out = []
+    for k, (xk, yk) in enumerate(pairs):
+        num, den = [1], 1
+        for j, (xj, _) in enumerate(pairs):
+            if j != k:
+                num = poly_mul(num, [(-xj) % r, 1], r)
+                den = den * (xk - xj) % r
+        out = poly_add(out, poly_scale(num, yk * pow(den, -1, r) % r, r), r)
+    return out
+
+
+def kzg_v2_proof_eval(r: int, polys: dict, points: dict, theta: int, theta2: int):
+    """polys[k][i]: coefficient list of polynomial i of batch k; points[k][i]: its evaluation points.
+    Returns (z, f, L): z[k][i][j] = poly(point) (eval_polys), f = the quotient committed as pi_1
+    (kzg_v2.hpp:253-269), L = the quotient committed as pi_2 (:281-292).  The challenges are inputs: the
+    transcript (hashing, byte packing) is outside this path."""
+    z = {k: [[poly_eval(p, x, r) for x in points[k][i]] for i, p in enumerate(ps)] for k, ps in polys.items()}
+    merged = sorted({x for k in points for pl in points[k] for x in pl})          # merge_eval_points (:121-130)
+    V = vanishing_poly(merged, r)
+
+    def diffpoly(pts):                                                             # set_difference_polynom (:132-148)
+        return vanishing_poly([x for x in merged if x not in pts], r)
+
+    theta_i, f = 1, []
+    for k in sorted(polys):
+        for i, p in enumerate(polys[k]):
+            U = lagrange_interpolation(list(zip(points[k][i], z[k][i])), r)
+            f = poly_add(f, poly_scale(poly_mul(poly_sub(p, U, r), diffpoly(points[k][i]), r), theta_i, r), r)
+            theta_i = theta_i * theta % r
+    f, rem = poly_divmod(f, V, r)
+    assert not rem                                                                 # BOOST_ASSERT(f % V == 0) (:266)
+    theta_i, L = 1, []
+    for k in sorted(polys):
+        for i, p in enumerate(polys[k]):
+            U = lagrange_interpolation(list(zip(points[k][i], z[k][i])), r)
+            zts = poly_eval(diffpoly(points[k][i]), theta2, r)
+            L = poly_add(L, poly_scale(poly_sub(p, [poly_eval(U, theta2, r)], r), theta_i * zts % r, r), r)
+            theta_i = theta_i * theta % r
+    L = poly_sub(L, poly_scale(f, poly_eval(V, theta2, r), r), r)
+    assert poly_eval(L, theta2, r) == 0                                            # (:290)
+    L, rem = poly_divmod(L, [(-theta2) % r, 1], r)
+    assert not rem
+    return z, f, L
+
+
 def to_limbs(v: int, n: int) -> List[int]:
     return [(v >> (64 * i)) & MASK64 for i in range(n)]
 

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include <nil/crypto3/zk/hip/kzg.hpp>
+#include <nil/crypto3/zk/hip/kzg_v2.hpp>
 #include <nil/crypto3/zk/hip/r1cs_gg_ppzksnark.hpp>
 
 using namespace nil::crypto3::zk::hip;
@@ -87,6 +88,80 @@ int kzg_commit_t(const uint64_t *srs, size_t n, const uint64_t *evals, size_t lo
     return 0;
 }
 
+/// transcript double: hands out the caller's challenges in order and counts what it absorbed
+template <typename Curve>
+struct scripted_transcript {
+    typedef curve_adapter<Curve> A;
+    std::vector<typename A::scalar_value_type> challenges;
+    std::size_t next = 0, absorbed_points = 0, absorbed_scalars = 0;
+    void operator()(const typename A::g1_value_type &) { ++absorbed_points; }
+    void operator()(const typename A::scalar_value_type &) { ++absorbed_scalars; }
+    typename A::scalar_value_type challenge() { return challenges.at(next++); }
+};
+
+template <typename Curve>
+int kzg_v2_t(const uint64_t *srs, size_t n_srs, size_t npolys, const uint64_t *batch_id, const uint64_t *log_n, const uint64_t *evals,
+             const uint64_t *npts, const uint64_t *points, const uint64_t *roots, const uint64_t *theta, const uint64_t *theta2, uint64_t *commits,
+             uint64_t *zvals, uint64_t *pi, uint64_t *absorbed) {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::g1_value_type G1;
+    typedef typename A::scalar_value_type Fr;
+    const size_t L1 = 2 * A::g1_coord_limbs;
+    context ctx(0);
+    std::vector<G1> ck;
+    for (size_t i = 0; i < n_srs; ++i) ck.push_back(G1::from_affine(srs + i * L1));
+    kzg_params_hip<Curve> params(ctx, ck.begin(), ck.end());
+    typedef kzg_commitment_scheme_v2_hip<Curve, scripted_transcript<Curve>> scheme_type;
+    scheme_type scheme(params, [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); });
+    std::vector<size_t> batches;
+    size_t at = 0;
+    for (size_t p = 0; p < npolys; ++p) {
+        polynomial_dfs<Curve> poly;
+        for (size_t i = 0; i < ((size_t)1 << log_n[p]); ++i) poly.values.push_back(A::scalar_from_limbs(evals + 4 * at++));
+        scheme.append_to_batch(batch_id[p], poly);
+        if (batches.empty() || batches.back() != batch_id[p]) batches.push_back(batch_id[p]);
+    }
+    size_t ci = 0;
+    for (size_t b : batches)
+        for (const auto &c : scheme.commit(b)) {
+            c.to_affine(commits + ci * L1);
+            ++ci;
+        }
+    size_t pt = 0;
+    std::vector<size_t> idx_in_batch(npolys, 0);
+    for (size_t p = 0, i = 0; p < npolys; ++p) {
+        if (p && batch_id[p] != batch_id[p - 1]) i = 0;
+        for (size_t q = 0; q < npts[p]; ++q) scheme.append_eval_point(batch_id[p], i, A::scalar_from_limbs(points + 4 * pt++));
+        idx_in_batch[p] = i++;
+    }
+    scripted_transcript<Curve> tr;
+    tr.challenges = {A::scalar_from_limbs(theta), A::scalar_from_limbs(theta2)};
+    auto proof = scheme.proof_eval(tr);
+    size_t zi = 0;
+    for (size_t p = 0; p < npolys; ++p)
+        for (size_t q = 0; q < npts[p]; ++q) A::scalar_to_limbs(proof.z.get(batch_id[p], idx_in_batch[p], q), zvals + 4 * zi++);
+    proof.pi_1.to_affine(pi);
+    proof.pi_2.to_affine(pi + L1);
+    absorbed[0] = tr.absorbed_points;
+    absorbed[1] = tr.absorbed_scalars;
+    return 0;
+}
+
+template <typename Curve>
+int kzg_basic_proof_t(const uint64_t *srs, size_t n_srs, const uint64_t *coeffs, size_t n, const uint64_t *z, uint64_t *out) {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::g1_value_type G1;
+    const size_t L1 = 2 * A::g1_coord_limbs;
+    context ctx(0);
+    std::vector<G1> ck;
+    for (size_t i = 0; i < n_srs; ++i) ck.push_back(G1::from_affine(srs + i * L1));
+    kzg_params_hip<Curve> params(ctx, ck.begin(), ck.end());
+    std::vector<typename A::scalar_value_type> f;
+    for (size_t i = 0; i < n; ++i) f.push_back(A::scalar_from_limbs(coeffs + 4 * i));
+    kzg_proof_eval<Curve>(params, f, A::scalar_from_limbs(z)).to_affine(out);
+    return 0;
+}
+
 }    // namespace
 
 extern "C" {
@@ -118,6 +193,29 @@ int shim_kzg_commit(int curve, const uint64_t *srs, size_t n, const uint64_t *ev
         return kzg_commit_t<alt_bn128_254>(srs, n, evals, log_n, batch, omega, out, out_inf);
     } catch (const std::exception &e) {
         fprintf(stderr, "shim_kzg_commit: %s\n", e.what());
+        return -1;
+    }
+}
+
+int shim_kzg_v2_proof_eval(int curve, const uint64_t *srs, size_t n_srs, size_t npolys, const uint64_t *batch_id, const uint64_t *log_n,
+                           const uint64_t *evals, const uint64_t *npts, const uint64_t *points, const uint64_t *roots, const uint64_t *theta,
+                           const uint64_t *theta2, uint64_t *commits, uint64_t *zvals, uint64_t *pi, uint64_t *absorbed) {
+    try {
+        if (curve == ZKHIP_BLS12_381)
+            return kzg_v2_t<bls12_381>(srs, n_srs, npolys, batch_id, log_n, evals, npts, points, roots, theta, theta2, commits, zvals, pi, absorbed);
+        return kzg_v2_t<alt_bn128_254>(srs, n_srs, npolys, batch_id, log_n, evals, npts, points, roots, theta, theta2, commits, zvals, pi, absorbed);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "shim_kzg_v2_proof_eval: %s\n", e.what());
+        return -1;
+    }
+}
+
+int shim_kzg_basic_proof(int curve, const uint64_t *srs, size_t n_srs, const uint64_t *coeffs, size_t n, const uint64_t *z, uint64_t *out) {
+    try {
+        if (curve == ZKHIP_BLS12_381) return kzg_basic_proof_t<bls12_381>(srs, n_srs, coeffs, n, z, out);
+        return kzg_basic_proof_t<alt_bn128_254>(srs, n_srs, coeffs, n, z, out);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "shim_kzg_basic_proof: %s\n", e.what());
         return -1;
     }
 }

@@ -95,3 +95,98 @@ def test_kzg_commit_shim(shim, curve, log_n, batch):
         fa = cp.fr_horner(curve, coeffs[b], limbs(alpha, 4))
         pt, _ = cp.batch_mul(curve, 1, fa.reshape(1, 4))
         assert (out[b] == pt[0]).all()
+
+
+def _srs(curve, alpha, n):
+    C = CURVES[curve]
+    pts, _ = cp.batch_mul(curve, 1, fr_arr([pow(alpha, i, C.r) for i in range(n)]))
+    return pts
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_kzg_basic_proof_eval_shim(shim, curve):
+    """kzg_basic_test (t/commitment/kzg.cpp:75-103) on this curve: f = {-1, 1, 2, 3}, alpha = 10, z = 2.
+    commit = 3209 G (the literal of :97); proof = commit((f - f(2)) / (X - 2)) = commit(3X^2 + 8X + 17) = 397 G."""
+    C = CURVES[curve]
+    srs = _srs(curve, 10, 16)
+    f = fr_arr([C.r - 1, 1, 2, 3])
+    out = np.zeros(srs.shape[1], dtype=np.uint64)
+    assert shim.shim_kzg_basic_proof(curve, P(srs), ctypes.c_size_t(16), P(f), ctypes.c_size_t(4), P(limbs(2, 4)), P(out)) == 0
+    exp, _ = cp.batch_mul(curve, 1, fr_arr([397]))
+    assert (out == exp[0]).all()
+    # a random polynomial longer than one Horner workgroup chunk, random point
+    n = 300
+    coeffs = cp.random_fr(curve, 9, n)
+    z = po.SplitMix64(4).next_mod(C.r)
+    srs = _srs(curve, 10, n)
+    assert shim.shim_kzg_basic_proof(curve, P(srs), ctypes.c_size_t(n), P(coeffs), ctypes.c_size_t(n), P(limbs(z, 4)), P(out)) == 0
+    fi = [po.from_limbs(x) for x in coeffs]
+    q, rem = po.poly_divmod(po.poly_sub(fi, [po.poly_eval(fi, z, C.r)], C.r), [(-z) % C.r, 1], C.r)
+    assert not rem
+    exp, _ = cp.batch_mul(curve, 1, fr_arr([po.poly_eval(q, 10, C.r)]))
+    assert (out == exp[0]).all()
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_kzg_v2_proof_eval_shim(shim, curve):
+    """kzg_commitment_scheme_v2::commit + proof_eval (kzg_v2.hpp:208-305) through the shim class against the oracle's
+    restatement: evaluations z, both quotient commitments, and the verifier's equation in the exponent (alpha known)."""
+    C = CURVES[curve]
+    r = C.r
+    alpha = 7  # placeholder.cpp:175
+    rng = po.SplitMix64(77 + curve)
+    x1, x2, x3 = (rng.next_mod(r) for _ in range(3))
+    # batch 0: three polynomials of 64 evaluations opened at {x1, x2}; batch 2: sizes 64 and 128 with ragged point sets
+    layout = [(0, 6, [x1, x2]), (0, 6, [x1, x2]), (0, 6, [x1, x2]), (2, 6, [x2]), (2, 7, [x1, x3])]
+    npolys = len(layout)
+    evals, coeffs = [], []
+    for p, (_, log_n, _) in enumerate(layout):
+        e = cp.random_fr(curve, 500 + p, 1 << log_n)
+        evals.append(e)
+        c = cp.ntt(curve, e.reshape(1, -1, 4), log_n, limbs(C.root_of_unity(log_n), 4), inverse=True)[0]
+        coeffs.append([po.from_limbs(x) for x in c])
+    n_srs = 128
+    srs = _srs(curve, alpha, n_srs)
+    theta, theta2 = rng.next_mod(r), rng.next_mod(r)
+    polys, points = {}, {}
+    for p, (k, _, pts) in enumerate(layout):
+        polys.setdefault(k, []).append(coeffs[p])
+        points.setdefault(k, []).append(pts)
+    z, f, L = po.kzg_v2_proof_eval(r, polys, points, theta, theta2)
+
+    u64 = lambda v: np.array(v, dtype=np.uint64)
+    roots = np.stack([limbs(C.root_of_unity(l), 4) for l in range(8)])
+    allpts = fr_arr([x for _, _, pts in layout for x in pts])
+    commits = np.zeros((npolys, srs.shape[1]), dtype=np.uint64)
+    zvals = np.zeros((len(allpts), 4), dtype=np.uint64)
+    pi = np.zeros((2, srs.shape[1]), dtype=np.uint64)
+    absorbed = np.zeros(2, dtype=np.uint64)
+    rc = shim.shim_kzg_v2_proof_eval(curve, P(srs), ctypes.c_size_t(n_srs), ctypes.c_size_t(npolys), P(u64([k for k, _, _ in layout])),
+                                     P(u64([l for _, l, _ in layout])), P(np.concatenate(evals)), P(u64([len(p) for _, _, p in layout])), P(allpts),
+                                     P(roots), P(limbs(theta, 4)), P(limbs(theta2, 4)), P(commits), P(zvals), P(pi), P(absorbed))
+    assert rc == 0
+    g = lambda v: cp.batch_mul(curve, 1, fr_arr([v % r]))[0][0]
+    # commitments: f_i(alpha) G
+    for p in range(npolys):
+        assert (commits[p] == g(po.poly_eval(coeffs[p], alpha, r))).all(), p
+    # evaluations in the reference's order (batch, polynomial, point)
+    exp_z = [v for k in sorted(z) for zl in z[k] for v in zl]
+    assert [po.from_limbs(x) for x in zvals] == exp_z
+    # pi_1, pi_2 against the oracle's quotients, once through the MSM oracle and once in the exponent
+    e1, i1 = cp.msm(curve, 1, srs[: len(f)], fr_arr(f), chunks=2)
+    assert i1 == 0 and (pi[0] == e1).all()
+    assert (pi[0] == g(po.poly_eval(f, alpha, r))).all() and (pi[1] == g(po.poly_eval(L, alpha, r))).all()
+    # the verifier's equation (kzg_v2.hpp verify_eval) with alpha in the clear:
+    #   sum_i theta^i Z_{T\S_i}(theta2) (f_i(alpha) - U_i(theta2)) - V(theta2) f(alpha) == (alpha - theta2) L(alpha)
+    merged = sorted({x for _, _, pts in layout for x in pts})
+    lhs, th = 0, 1
+    for k in sorted(polys):
+        for i, c in enumerate(polys[k]):
+            U = po.lagrange_interpolation(list(zip(points[k][i], z[k][i])), r)
+            zts = po.poly_eval(po.vanishing_poly([x for x in merged if x not in points[k][i]], r), theta2, r)
+            lhs = (lhs + th * zts * (po.poly_eval(c, alpha, r) - po.poly_eval(U, theta2, r))) % r
+            th = th * theta % r
+    lhs = (lhs - po.poly_eval(po.vanishing_poly(merged, r), theta2, r) * po.poly_eval(f, alpha, r)) % r
+    assert lhs == (alpha - theta2) * po.poly_eval(L, alpha, r) % r
+    # transcript traffic: 5 commitments + pi_1 + pi_2; 8 evaluations + 8 U coefficients
+    assert list(absorbed) == [npolys + 2, 2 * len(allpts)]
