@@ -63,7 +63,7 @@ struct zkhip_ctx {
     size_t pinned_cap = 0;
     // options
     int opt_msm_window_bits = 0;
-    int opt_msm_segment_log = 0;  // tail segments of 2^k buckets per lane
+    int opt_msm_segment_log = -1;  // tail segments of 2^k buckets per lane; < 0: chosen from the lane count
     int opt_ntt_radix_log = 8;
     int opt_ntt_tile_log = 3;
     int opt_msm_precompute = 1;       // build window tables at upload for bases of >= opt_msm_precompute_min points

@@ -650,6 +650,18 @@ int zk_scalar_bits(int curve) { return curve == CURVE_BLS12_381 ? 255 : 254; }  
 
 int zk_msm_auto_window(size_t n) { return std::max(2, std::min(16, ilog2(n) - 4)); }
 
+// Buckets per tail lane.  One bucket per lane gives the shortest dependency chain (~20 additions for the scalar
+// multiple) and is right while the lanes fit the chip once (a single MSM: 2^15 lanes, half a wave per SIMD).  A
+// batch multiplies the lanes: past ~2 waves per SIMD the tail is bound by work, and a segment of L buckets costs
+// 2 + 20/L additions per bucket instead of 20.
+static uint32_t msm_tail_segment(const zkhip_ctx *ctx, uint32_t B, size_t windows) {
+    uint32_t L = 1;
+    if (ctx->opt_msm_segment_log >= 0) L = 1u << std::min(ctx->opt_msm_segment_log, 8);
+    else
+        while (L < 16 && windows * B / L > 131072) L <<= 1;
+    return std::min(B, L);
+}
+
 // the tail workgroups keep 256 XYZZ points in LDS (56 KiB for G1, 128 KiB for BLS12-381 G2)
 template <class F>
 static int msm_tail_attr(zkhip_ctx *ctx) {
@@ -675,7 +687,7 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     const uint32_t B = 1u << (c - 1);
     const uint32_t nb = (uint32_t)W * B;
     const int Wr = tables ? 1 : W;  // windows left after the equal-weight merge
-    uint32_t L = std::min<uint32_t>(B, 1u << std::max(0, ctx->opt_msm_segment_log));  // buckets per tail segment
+    const uint32_t L = msm_tail_segment(ctx, B, tables ? 1 : W);  // buckets per tail segment
     const uint32_t nseg = B / L, nblk_tail = (nseg + MSM_TAIL_THREADS - 1) / MSM_TAIL_THREADS;
     // two-level LDS counting sort (see msm_sort_*): low 8 bits inside a super-bucket, the rest across super-buckets
     const uint32_t lowb = (uint32_t)std::min(8, c - 1), nsuper = 1u << ((c - 1) - lowb);
@@ -856,7 +868,7 @@ static int msm_batch_t(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *b
     constexpr int NL = FieldOps<F>::WORDS;
     const int c = bases[0]->c_tab;
     const uint32_t B = 1u << (c - 1);
-    uint32_t L = std::min<uint32_t>(B, 1u << std::max(0, ctx->opt_msm_segment_log));
+    const uint32_t L = msm_tail_segment(ctx, B, count);
     const uint32_t nseg = B / L, nblk_tail = (nseg + MSM_TAIL_THREADS - 1) / MSM_TAIL_THREADS;
     size_t max_need = 0;
     for (size_t i = 0; i < count; ++i) {

@@ -29,6 +29,29 @@ __global__ __launch_bounds__(256) void poly_pad_copy(const uint4 *__restrict__ i
     out[2 * e + 1] = hi;
 }
 
+
+// precommit<FRI>'s leaf layout (basic_fri.hpp:456-492, m = 2): leaf x (< D / 2^step) holds, for every polynomial in
+// turn, the pairs (f[s_i], f[s_i + D/2 mod D]) for i < 2^step / 2, with s_0 = x and
+// s_(2^l + j) = s_j + D / (4 * 2^l) mod D.  out[((x * batch + p) * half + i) * 2 + {0, 1}], 32-byte elements.
+__global__ __launch_bounds__(256) void fri_leaf_gather(const uint4 *__restrict__ polys, uint32_t log_d, uint32_t batch, uint32_t step, size_t total,
+                                                       uint4 *__restrict__ out) {
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index: (x * batch + p) * half + i
+    if (e >= total) return;
+    const uint32_t half_log = step - 1;  // log2(coset_size / 2)
+    const size_t i = e & (((size_t)1 << half_log) - 1), xp = e >> half_log;
+    const size_t p = xp % batch, x = xp / batch, D = (size_t)1 << log_d;
+    size_t s = x;
+    for (uint32_t l = 0; l < half_log; ++l)
+        if ((i >> l) & 1) s += D >> (2 + l);
+    s &= D - 1;
+    const size_t s2 = (s + (D >> 1)) & (D - 1);
+    const uint4 *f = polys + 2 * (p << log_d);
+    out[4 * e] = f[2 * s];
+    out[4 * e + 1] = f[2 * s + 1];
+    out[4 * e + 2] = f[2 * s2];
+    out[4 * e + 3] = f[2 * s2 + 1];
+}
+
 static constexpr uint32_t FOLD_CHUNK = 128;  // consecutive i per lane: one power, then a running product
 
 // consts = [alpha, w^-1, 1/2] in Montgomery form, canonical representatives
@@ -294,6 +317,17 @@ int zkhip_fri_fold_dev(zkhip_ctx *ctx, int curve, const void *d_f, size_t log_si
         ZK_LAUNCH(ctx, "fri_fold_setup", fri_fold_setup<BnFrU>, dim3(1), dim3(64), 0, d_c, d_c + 8, consts);
         ZK_LAUNCH(ctx, "fri_fold", fri_fold<BnFrU>, grid, block, 0, (const uint32_t *)d_f, (uint32_t)log_size, consts, (uint32_t *)d_out);
     }
+    return ZKHIP_OK;
+}
+
+int zkhip_fri_leaves_dev(zkhip_ctx *ctx, const void *d_polys, size_t log_domain, size_t batch, size_t fri_step, void *d_out) {
+    if (!ctx || (batch && (!d_polys || !d_out))) return ZKHIP_ERR_INVALID;
+    if (fri_step < 1 || fri_step > log_domain || log_domain > 32 || batch >= ((size_t)1 << 31)) return ZKHIP_ERR_RANGE;
+    if (batch == 0) return ZKHIP_OK;
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t total = (batch << log_domain) >> 1;  // pairs
+    ZK_LAUNCH(ctx, "fri_leaf_gather", fri_leaf_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (const uint4 *)d_polys, (uint32_t)log_domain,
+              (uint32_t)batch, (uint32_t)fri_step, total, (uint4 *)d_out);
     return ZKHIP_OK;
 }
 

@@ -137,6 +137,12 @@ int zkhip_memcpy_d2h(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes) {
     return ZKHIP_OK;
 }
 
+int zkhip_memcpy_d2d_async(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return ZKHIP_OK;
+}
+
 // ---- bases ------------------------------------------------------------------------------------------
 static int bases_alloc(zkhip_ctx *ctx, int curve, int group, size_t n, zkhip_bases **out) {
     if ((curve != CURVE_BLS12_381 && curve != CURVE_BN254) || (group != GROUP_G1 && group != GROUP_G2)) return ZKHIP_ERR_INVALID;

@@ -1,0 +1,174 @@
+//---------------------------------------------------------------------------//
+// zkhip shim: the NTT side of the LPC / FRI commitment layer and polynomial_dfs arithmetic, on the MI355X.
+//
+// Mirrors (same names, same argument meaning):
+//   math::polynomial_dfs::{resize, coefficients, from_coefficients, operator+=, -=, *=}   (crypto3-math; used at
+//        zk/snark/systems/plonk/placeholder/prover.hpp:255,277, gates_argument.hpp:119-121,
+//        permutation_argument.hpp:148-167, zk/commitments/detail/polynomial/basic_fri.hpp:452-455)
+//   detail::fold_polynomial, DFS form        zk/commitments/detail/polynomial/fold_polynomial.hpp:68-93
+//   algorithms::precommit<FRI>               zk/commitments/detail/polynomial/basic_fri.hpp:433-496, up to the
+//        Merkle tree: domain extension of every polynomial + the coset-ordered leaf data; hashing is the caller's.
+// The roots of unity come from the caller (math::make_evaluation_domain's choice).
+//---------------------------------------------------------------------------//
+#ifndef ZKHIP_SHIM_FRI_HPP
+#define ZKHIP_SHIM_FRI_HPP
+
+#include <functional>
+#include <vector>
+
+#include "kzg.hpp"
+
+namespace nil {
+namespace crypto3 {
+namespace zk {
+namespace hip {
+
+/// math::polynomial_dfs with its evaluations resident on the device
+template <typename CurveType>
+class device_polynomial_dfs {
+public:
+    typedef curve_adapter<CurveType> adapter;
+    typedef typename adapter::scalar_value_type value_type;
+    typedef std::function<value_type(std::size_t log_n)> root_of_unity_type;
+
+    device_polynomial_dfs(const context &ctx, std::size_t size) : ctx_(&ctx), size_(size), d_(ctx.alloc(std::max<std::size_t>(1, size) * 32)) { }
+    device_polynomial_dfs(const context &ctx, const polynomial_dfs<CurveType> &p) : device_polynomial_dfs(ctx, p.size()) {
+        std::vector<std::uint64_t> h(4 * size_);
+        for (std::size_t i = 0; i < size_; ++i) adapter::scalar_to_limbs(p.values[i], &h[4 * i]);
+        if (size_) ctx.h2d(d_.get(), h.data(), h.size() * 8);
+    }
+    std::size_t size() const { return size_; }
+    void *data() const { return d_.get(); }
+    const context &ctx() const { return *ctx_; }
+
+    polynomial_dfs<CurveType> to_host() const {
+        std::vector<std::uint64_t> h(4 * size_);
+        if (size_) ctx_->d2h(h.data(), d_.get(), h.size() * 8);
+        polynomial_dfs<CurveType> out;
+        for (std::size_t i = 0; i < size_; ++i) out.values.push_back(adapter::scalar_from_limbs(&h[4 * i]));
+        return out;
+    }
+
+    /// resize(new_size): evaluations on the size()-point domain -> evaluations of the same polynomial on the
+    /// new_size-point domain (new_size >= size(), both powers of two)
+    void resize(std::size_t new_size, const root_of_unity_type &root) {
+        if (new_size == size_) return;
+        const std::size_t lo = log2_exact(size_), ln = log2_exact(new_size);
+        if (ln < lo) throw std::runtime_error("device_polynomial_dfs::resize: shrinking is not supported");
+        auto d_new = ctx_->alloc(new_size * 32);
+        std::uint64_t wo[4], wn[4];
+        adapter::scalar_to_limbs(root(lo), wo);
+        adapter::scalar_to_limbs(root(ln), wn);
+        check(zkhip_poly_resize_dev(ctx_->get(), adapter::id, d_.get(), lo, 1, wo, d_new.get(), ln, wn), "zkhip_poly_resize_dev", ctx_->get());
+        ctx_->sync();    // the old buffer is released below
+        d_ = d_new;
+        size_ = new_size;
+    }
+    /// coefficients(): inverse NTT into a new device buffer of size() elements
+    std::shared_ptr<void> coefficients(const root_of_unity_type &root) const {
+        auto d_c = ctx_->alloc(std::max<std::size_t>(1, size_) * 32);
+        check(zkhip_memcpy_d2d_async(ctx_->get(), d_c.get(), d_.get(), size_ * 32), "zkhip_memcpy_d2d_async", ctx_->get());
+        std::uint64_t w[4];
+        adapter::scalar_to_limbs(root(log2_exact(size_)), w);
+        check(zkhip_ntt_dev(ctx_->get(), adapter::id, d_c.get(), log2_exact(size_), 1, w, 1, nullptr), "zkhip_ntt_dev", ctx_->get());
+        return d_c;
+    }
+    /// from_coefficients(): the evaluations of the polynomial whose size() coefficients are at d_coeffs
+    void from_coefficients(const void *d_coeffs, const root_of_unity_type &root) {
+        check(zkhip_memcpy_d2d_async(ctx_->get(), d_.get(), d_coeffs, size_ * 32), "zkhip_memcpy_d2d_async", ctx_->get());
+        std::uint64_t w[4];
+        adapter::scalar_to_limbs(root(log2_exact(size_)), w);
+        check(zkhip_ntt_dev(ctx_->get(), adapter::id, d_.get(), log2_exact(size_), 1, w, 0, nullptr), "zkhip_ntt_dev", ctx_->get());
+        ctx_->sync();
+    }
+    device_polynomial_dfs &operator+=(const device_polynomial_dfs &o) { return pointwise(0, o); }
+    device_polynomial_dfs &operator-=(const device_polynomial_dfs &o) { return pointwise(1, o); }
+    device_polynomial_dfs &operator*=(const device_polynomial_dfs &o) { return pointwise(2, o); }
+
+private:
+    static std::size_t log2_exact(std::size_t n) {
+        std::size_t l = 0;
+        while (((std::size_t)1 << l) < n) ++l;
+        if (n == 0 || ((std::size_t)1 << l) != n) throw std::runtime_error("device_polynomial_dfs: size must be a power of two");
+        return l;
+    }
+    device_polynomial_dfs &pointwise(int op, const device_polynomial_dfs &o) {
+        if (o.size_ != size_) throw std::runtime_error("device_polynomial_dfs: operands must share the domain (resize first)");
+        check(zkhip_fr_vec_op_dev(ctx_->get(), adapter::id, op, d_.get(), o.d_.get(), d_.get(), size_), "zkhip_fr_vec_op_dev", ctx_->get());
+        return *this;
+    }
+
+    const context *ctx_;
+    std::size_t size_;
+    std::shared_ptr<void> d_;
+};
+
+/// detail::fold_polynomial, DFS form (fold_polynomial.hpp:68-93): f over the size()-point domain with generator
+/// `omega` -> the folded polynomial over the half-size domain.
+template <typename CurveType>
+device_polynomial_dfs<CurveType> fold_polynomial(const device_polynomial_dfs<CurveType> &f, const typename curve_adapter<CurveType>::scalar_value_type &alpha,
+                                                 const typename curve_adapter<CurveType>::scalar_value_type &omega) {
+    typedef curve_adapter<CurveType> adapter;
+    std::size_t log_size = 0;
+    while (((std::size_t)1 << log_size) < f.size()) ++log_size;
+    device_polynomial_dfs<CurveType> out(f.ctx(), f.size() / 2);
+    std::uint64_t a[4], w[4];
+    adapter::scalar_to_limbs(alpha, a);
+    adapter::scalar_to_limbs(omega, w);
+    check(zkhip_fri_fold_dev(f.ctx().get(), adapter::id, f.data(), log_size, a, w, out.data()), "zkhip_fri_fold_dev", f.ctx().get());
+    return out;
+}
+
+/// The device part of algorithms::precommit<FRI>(poly, D, fri_step) (basic_fri.hpp:433-496): every polynomial is
+/// extended to the 2^log_domain-point domain D (`poly[i].resize(D->size())`, :452-455) and the leaves are laid out
+/// in the reference's coset order; returns the leaf data (2^log_domain / 2^fri_step leaves of
+/// polys.size() * 2^fri_step canonical elements each) on the host for the caller's Merkle tree.
+template <typename CurveType>
+std::vector<typename curve_adapter<CurveType>::scalar_value_type>
+    precommit_leaves(const context &ctx, const std::vector<polynomial_dfs<CurveType>> &polys, std::size_t log_domain, std::size_t fri_step,
+                     const typename device_polynomial_dfs<CurveType>::root_of_unity_type &root) {
+    typedef curve_adapter<CurveType> adapter;
+    const std::size_t D = (std::size_t)1 << log_domain, batch = polys.size();
+    std::vector<typename adapter::scalar_value_type> out;
+    if (batch == 0) return out;
+    auto d_ext = ctx.alloc(batch * D * 32);
+    std::uint64_t wd[4];
+    adapter::scalar_to_limbs(root(log_domain), wd);
+    /* runs of equally sized polynomials are extended by one batched call */
+    for (std::size_t i = 0; i < batch;) {
+        std::size_t j = i;
+        while (j < batch && polys[j].size() == polys[i].size()) ++j;
+        const std::size_t n = polys[i].size();
+        std::size_t log_n = 0;
+        while (((std::size_t)1 << log_n) < n) ++log_n;
+        if (n == 0 || ((std::size_t)1 << log_n) != n || log_n > log_domain) throw std::runtime_error("precommit: bad polynomial size");
+        std::vector<std::uint64_t> h(4 * n * (j - i));
+        for (std::size_t p = i; p < j; ++p)
+            for (std::size_t e = 0; e < n; ++e) adapter::scalar_to_limbs(polys[p].values[e], &h[4 * ((p - i) * n + e)]);
+        char *dst = static_cast<char *>(d_ext.get()) + 32 * i * D;
+        if (log_n == log_domain) {
+            ctx.h2d(dst, h.data(), h.size() * 8);
+        } else {
+            auto d_in = ctx.alloc(h.size() * 8);
+            ctx.h2d(d_in.get(), h.data(), h.size() * 8);
+            std::uint64_t wn[4];
+            adapter::scalar_to_limbs(root(log_n), wn);
+            check(zkhip_poly_resize_dev(ctx.get(), adapter::id, d_in.get(), log_n, j - i, wn, dst, log_domain, wd), "zkhip_poly_resize_dev", ctx.get());
+            ctx.sync();
+        }
+        i = j;
+    }
+    auto d_leaves = ctx.alloc(batch * D * 32);
+    check(zkhip_fri_leaves_dev(ctx.get(), d_ext.get(), log_domain, batch, fri_step, d_leaves.get()), "zkhip_fri_leaves_dev", ctx.get());
+    std::vector<std::uint64_t> h(4 * batch * D);
+    ctx.d2h(h.data(), d_leaves.get(), h.size() * 8);
+    for (std::size_t e = 0; e < batch * D; ++e) out.push_back(adapter::scalar_from_limbs(&h[4 * e]));
+    return out;
+}
+
+}    // namespace hip
+}    // namespace zk
+}    // namespace crypto3
+}    // namespace nil
+
+#endif    // ZKHIP_SHIM_FRI_HPP

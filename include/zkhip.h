@@ -51,7 +51,7 @@ const char *zkhip_last_error(const zkhip_ctx *ctx); /* HIP error text of the las
 /* All work is enqueued on this stream (default: a stream the context creates). */
 int zkhip_set_stream(zkhip_ctx *ctx, void *hip_stream);
 int zkhip_sync(zkhip_ctx *ctx);
-/* Tunables: "msm_window_bits" (0 = auto), "msm_segment_log" (tail: 2^k buckets per lane), "ntt_radix_log", "ntt_tile_log". */
+/* Tunables: "msm_window_bits" (0 = auto), "msm_segment_log" (tail: 2^k buckets per lane, < 0 = auto), "ntt_radix_log", "ntt_tile_log". */
 int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value);
 
 /* ---- device memory (plumbing for callers that keep vectors resident) -------------------------- */
@@ -62,6 +62,8 @@ int zkhip_memcpy_d2h(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes);
 /* enqueue only (no synchronisation): for pinned host buffers, ordered with the kernels on the context's stream */
 int zkhip_memcpy_h2d_async(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes);
 /* page-locked host memory: H2D / D2H at link speed instead of through a staging copy */
+/* device-to-device copy in stream order (no synchronisation) */
+int zkhip_memcpy_d2d_async(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes);
 int zkhip_host_alloc(zkhip_ctx *ctx, size_t bytes, void **hptr);
 int zkhip_host_free(zkhip_ctx *ctx, void *hptr);
 
@@ -150,6 +152,12 @@ int zkhip_poly_resize_dev(zkhip_ctx *ctx, int curve, void *d_in, size_t log_n, s
 /* detail::fold_polynomial, DFS form (commitments/detail/polynomial/fold_polynomial.hpp:68-93):
  * d_out[i] = 1/2 [(1 + alpha omega^-i) d_f[i] + (1 - alpha omega^-i) d_f[i + size/2]], i < size/2 = 2^(log_size-1). */
 int zkhip_fri_fold_dev(zkhip_ctx *ctx, int curve, const void *d_f, size_t log_size, const uint64_t *alpha, const uint64_t *omega, void *d_out);
+
+/* The leaf layout precommit<FRI> feeds to the Merkle tree (basic_fri.hpp:456-492, FRI::m = 2): `batch` vectors of
+ * 2^log_domain evaluations at d_polys -> d_out, 2^log_domain / 2^fri_step leaves of batch * 2^fri_step elements each:
+ * leaf x = for every polynomial, the pairs (f[s_i], f[s_i + D/2]) in the reference's coset order.  Hashing is
+ * the caller's. */
+int zkhip_fri_leaves_dev(zkhip_ctx *ctx, const void *d_polys, size_t log_domain, size_t batch, size_t fri_step, void *d_out);
 
 /* ---- coefficient-form polynomial arithmetic (KZG opening proofs, polynomial_dfs pointwise operators) -------
  * All vectors are canonical Fr elements (4 limbs) resident on the device.

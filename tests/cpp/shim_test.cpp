@@ -9,6 +9,8 @@
 #include <vector>
 
 #include <nil/crypto3/zk/hip/kzg.hpp>
+#include <nil/crypto3/zk/hip/fri.hpp>
+#include <nil/crypto3/zk/hip/knowledge_commitment_multiexp.hpp>
 #include <nil/crypto3/zk/hip/kzg_v2.hpp>
 #include <nil/crypto3/zk/hip/r1cs_gg_ppzksnark.hpp>
 
@@ -162,6 +164,75 @@ int kzg_basic_proof_t(const uint64_t *srs, size_t n_srs, const uint64_t *coeffs,
     return 0;
 }
 
+template <typename Curve>
+int precommit_leaves_t(const uint64_t *evals, size_t npolys, const uint64_t *log_n, size_t log_domain, size_t fri_step, const uint64_t *roots,
+                       uint64_t *out) {
+    typedef curve_adapter<Curve> A;
+    context ctx(0);
+    std::vector<polynomial_dfs<Curve>> polys(npolys);
+    size_t at = 0;
+    for (size_t p = 0; p < npolys; ++p)
+        for (size_t i = 0; i < ((size_t)1 << log_n[p]); ++i) polys[p].values.push_back(A::scalar_from_limbs(evals + 4 * at++));
+    auto leaves = precommit_leaves<Curve>(ctx, polys, log_domain, fri_step, [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); });
+    for (size_t i = 0; i < leaves.size(); ++i) A::scalar_to_limbs(leaves[i], out + 4 * i);
+    return 0;
+}
+
+/// a.resize(big); b.resize(big); a *= b (out_prod); then a -> coefficients -> from_coefficients (out_round), a += b, a -= b (out_addsub);
+/// fold of the product with alpha (out_fold, big / 2 elements)
+template <typename Curve>
+int dfs_ops_t(const uint64_t *a_evals, const uint64_t *b_evals, size_t log_n, size_t log_big, const uint64_t *roots, const uint64_t *alpha,
+              uint64_t *out_prod, uint64_t *out_round, uint64_t *out_addsub, uint64_t *out_fold) {
+    typedef curve_adapter<Curve> A;
+    context ctx(0);
+    auto root = [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); };
+    polynomial_dfs<Curve> ha, hb;
+    for (size_t i = 0; i < ((size_t)1 << log_n); ++i) {
+        ha.values.push_back(A::scalar_from_limbs(a_evals + 4 * i));
+        hb.values.push_back(A::scalar_from_limbs(b_evals + 4 * i));
+    }
+    device_polynomial_dfs<Curve> a(ctx, ha), b(ctx, hb);
+    const size_t big = (size_t)1 << log_big;
+    a.resize(big, root);
+    b.resize(big, root);
+    a *= b;
+    auto dump = [&](const device_polynomial_dfs<Curve> &p, uint64_t *out) {
+        auto h = p.to_host();
+        for (size_t i = 0; i < h.size(); ++i) A::scalar_to_limbs(h.values[i], out + 4 * i);
+    };
+    dump(a, out_prod);
+    auto coeffs = a.coefficients(root);
+    device_polynomial_dfs<Curve> c(ctx, big);
+    c.from_coefficients(coeffs.get(), root);
+    dump(c, out_round);
+    c += b;
+    c -= b;
+    dump(c, out_addsub);
+    dump(fold_polynomial<Curve>(a, A::scalar_from_limbs(alpha), root(log_big)), out_fold);
+    return 0;
+}
+
+template <typename Curve>
+int kc_multiexp_t(const uint64_t *g_pts, const uint64_t *h_pts, const uint64_t *indices, size_t count, size_t domain_size, size_t min_idx, size_t max_idx,
+                  const uint64_t *scalars, size_t nscalars, uint64_t *out_g, uint64_t *out_h, uint8_t *out_inf) {
+    typedef curve_adapter<Curve> A;
+    const size_t L1 = 2 * A::g1_coord_limbs, L2 = 2 * A::g2_coord_limbs;
+    context ctx(0);
+    knowledge_commitment_vector<Curve> vec;
+    vec.domain_size_ = domain_size;
+    for (size_t i = 0; i < count; ++i) {
+        vec.indices.push_back(indices[i]);
+        vec.values.push_back({A::g2_value_type::from_affine(g_pts + i * L2), A::g1_value_type::from_affine(h_pts + i * L1)});
+    }
+    device_kc_vector<Curve> dv(ctx, vec);
+    std::vector<typename A::scalar_value_type> sc;
+    for (size_t i = 0; i < nscalars; ++i) sc.push_back(A::scalar_from_limbs(scalars + 4 * i));
+    auto r = kc_multiexp_with_mixed_addition<multiexp_method_hip>(dv, min_idx, max_idx, sc.begin(), sc.end(), 1);
+    out_inf[0] = r.g.to_affine(out_g) ? 0 : 1;
+    out_inf[1] = r.h.to_affine(out_h) ? 0 : 1;
+    return 0;
+}
+
 }    // namespace
 
 extern "C" {
@@ -208,6 +279,30 @@ int shim_kzg_v2_proof_eval(int curve, const uint64_t *srs, size_t n_srs, size_t 
         fprintf(stderr, "shim_kzg_v2_proof_eval: %s\n", e.what());
         return -1;
     }
+}
+
+#define CURVE_CALL(name, fn, ...)                                   \
+    try {                                                           \
+        if (curve == ZKHIP_BLS12_381) return fn<bls12_381>(__VA_ARGS__); \
+        return fn<alt_bn128_254>(__VA_ARGS__);                      \
+    } catch (const std::exception &e) {                             \
+        fprintf(stderr, name ": %s\n", e.what());                   \
+        return -1;                                                  \
+    }
+
+int shim_precommit_leaves(int curve, const uint64_t *evals, size_t npolys, const uint64_t *log_n, size_t log_domain, size_t fri_step,
+                          const uint64_t *roots, uint64_t *out) {
+    CURVE_CALL("shim_precommit_leaves", precommit_leaves_t, evals, npolys, log_n, log_domain, fri_step, roots, out)
+}
+
+int shim_dfs_ops(int curve, const uint64_t *a_evals, const uint64_t *b_evals, size_t log_n, size_t log_big, const uint64_t *roots, const uint64_t *alpha,
+                 uint64_t *out_prod, uint64_t *out_round, uint64_t *out_addsub, uint64_t *out_fold) {
+    CURVE_CALL("shim_dfs_ops", dfs_ops_t, a_evals, b_evals, log_n, log_big, roots, alpha, out_prod, out_round, out_addsub, out_fold)
+}
+
+int shim_kc_multiexp(int curve, const uint64_t *g_pts, const uint64_t *h_pts, const uint64_t *indices, size_t count, size_t domain_size, size_t min_idx,
+                     size_t max_idx, const uint64_t *scalars, size_t nscalars, uint64_t *out_g, uint64_t *out_h, uint8_t *out_inf) {
+    CURVE_CALL("shim_kc_multiexp", kc_multiexp_t, g_pts, h_pts, indices, count, domain_size, min_idx, max_idx, scalars, nscalars, out_g, out_h, out_inf)
 }
 
 int shim_kzg_basic_proof(int curve, const uint64_t *srs, size_t n_srs, const uint64_t *coeffs, size_t n, const uint64_t *z, uint64_t *out) {

@@ -190,3 +190,99 @@ def test_kzg_v2_proof_eval_shim(shim, curve):
     assert lhs == (alpha - theta2) * po.poly_eval(L, alpha, r) % r
     # transcript traffic: 5 commitments + pi_1 + pi_2; 8 evaluations + 8 U coefficients
     assert list(absorbed) == [npolys + 2, 2 * len(allpts)]
+
+
+def _extend(curve, evals, log_n, log_big):
+    """polynomial_dfs::resize on the oracle: coefficients, zero-extend, evaluate on the larger domain"""
+    C = CURVES[curve]
+    c = cp.ntt(curve, evals.reshape(1, -1, 4), log_n, limbs(C.root_of_unity(log_n), 4), inverse=True)[0]
+    big = np.zeros((1 << log_big, 4), dtype=np.uint64)
+    big[: 1 << log_n] = c
+    return cp.ntt(curve, big.reshape(1, -1, 4), log_big, limbs(C.root_of_unity(log_big), 4))[0]
+
+
+@pytest.mark.parametrize("curve,log_domain,fri_step", [(0, 8, 1), (0, 8, 3), (1, 7, 2)])
+def test_precommit_leaves_shim(shim, curve, log_domain, fri_step):
+    """precommit<FRI> up to the Merkle tree (basic_fri.hpp:433-496): resize to D, then the coset-ordered leaves.
+    The expected layout replays the reference's s_indices loop (:456-492) on the oracle's extended polynomials."""
+    C = CURVES[curve]
+    logs = [log_domain - 2, log_domain - 2, log_domain, log_domain - 1]
+    evals = [cp.random_fr(curve, 900 + i, 1 << l) for i, l in enumerate(logs)]
+    ext = [e if l == log_domain else _extend(curve, e, l, log_domain) for e, l in zip(evals, logs)]
+    D, m = 1 << log_domain, 2
+    coset = 1 << fri_step
+    exp = []
+    for x in range(D // coset):
+        for f in ext:
+            s = [[0, 0] for _ in range(coset // m)]
+            s[0] = [x, (x + D // 2) % D]
+            exp += [f[s[0][0]], f[s[0][1]]]
+            base, prev_half, i = D // (m * m), 1, 1
+            while i < coset // m:
+                for j in range(prev_half):
+                    s[i][0] = (base + s[j][0]) % D
+                    s[i][1] = (s[i][0] + D // 2) % D
+                    exp += [f[s[i][0]], f[s[i][1]]]
+                    i += 1
+                base //= m
+                prev_half <<= 1
+    exp = np.array(exp, dtype=np.uint64)
+    roots = np.stack([limbs(C.root_of_unity(l), 4) for l in range(log_domain + 1)])
+    out = np.zeros((len(logs) * D, 4), dtype=np.uint64)
+    rc = shim.shim_precommit_leaves(curve, P(np.concatenate(evals)), ctypes.c_size_t(len(logs)), P(np.array(logs, dtype=np.uint64)),
+                                    ctypes.c_size_t(log_domain), ctypes.c_size_t(fri_step), P(roots), P(out))
+    assert rc == 0
+    assert (out == exp).all()
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_polynomial_dfs_ops_shim(shim, curve):
+    """device polynomial_dfs: resize, *=, coefficients / from_coefficients, +=, -=, and fold_polynomial of the product"""
+    C = CURVES[curve]
+    r = C.r
+    log_n, log_big = 6, 8
+    a, b = cp.random_fr(curve, 950, 1 << log_n), cp.random_fr(curve, 951, 1 << log_n)
+    ea, eb = _extend(curve, a, log_n, log_big), _extend(curve, b, log_n, log_big)
+    prod = [x * y % r for x, y in zip((po.from_limbs(v) for v in ea), (po.from_limbs(v) for v in eb))]
+    alpha = po.SplitMix64(12).next_mod(r)
+    roots = np.stack([limbs(C.root_of_unity(l), 4) for l in range(log_big + 1)])
+    big = 1 << log_big
+    o_prod, o_round, o_as = (np.zeros((big, 4), dtype=np.uint64) for _ in range(3))
+    o_fold = np.zeros((big // 2, 4), dtype=np.uint64)
+    rc = shim.shim_dfs_ops(curve, P(a), P(b), ctypes.c_size_t(log_n), ctypes.c_size_t(log_big), P(roots), P(limbs(alpha, 4)), P(o_prod), P(o_round),
+                           P(o_as), P(o_fold))
+    assert rc == 0
+    assert [po.from_limbs(v) for v in o_prod] == prod
+    assert (o_round == o_prod).all() and (o_as == o_prod).all()
+    winv, inv2, half = pow(C.root_of_unity(log_big), -1, r), pow(2, -1, r), big // 2
+    assert [po.from_limbs(v) for v in o_fold] == [
+        inv2 * ((1 + alpha * pow(winv, i, r)) * prod[i] + (1 - alpha * pow(winv, i, r)) * prod[half + i]) % r for i in range(half)]
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_kc_multiexp_shim(shim, curve):
+    """kc_multiexp_with_mixed_addition (knowledge_commitment_multiexp.hpp:57-108): sparse (G2, G1) pairs, index window,
+    zero / one scalars, against the oracle's restatement."""
+    C = CURVES[curve]
+    domain = 60
+    indices = [0, 1, 3, 4, 7, 10, 11, 20, 21, 22, 35, 36, 50, 59]
+    ks = cp.random_fr(curve, 970, len(indices))
+    g_pts, _ = cp.batch_mul(curve, 2, ks)
+    h_pts, _ = cp.batch_mul(curve, 1, ks)
+    from util import pt_from_limbs
+    values = [(pt_from_limbs(curve, 2, g_pts[i]), pt_from_limbs(curve, 1, h_pts[i])) for i in range(len(indices))]
+    for min_idx, max_idx in ((0, 60), (3, 36), (5, 6), (11, 51)):
+        n = max_idx - min_idx
+        sc = [po.from_limbs(v) for v in cp.random_fr(curve, 980 + min_idx, n)]
+        for j in range(0, n, 3):
+            sc[j] = 0
+        for j in range(1, n, 5):
+            sc[j] = 1
+        eg, eh = po.kc_multiexp(C.g2, C.g1, indices, values, min_idx, max_idx, sc)
+        og, oh = np.zeros(g_pts.shape[1], dtype=np.uint64), np.zeros(h_pts.shape[1], dtype=np.uint64)
+        oinf = np.zeros(2, dtype=np.uint8)
+        rc = shim.shim_kc_multiexp(curve, P(g_pts), P(h_pts), P(np.array(indices, dtype=np.uint64)), ctypes.c_size_t(len(indices)),
+                                   ctypes.c_size_t(domain), ctypes.c_size_t(min_idx), ctypes.c_size_t(max_idx), P(fr_arr(sc)), ctypes.c_size_t(n),
+                                   P(og), P(oh), P(oinf))
+        assert rc == 0
+        assert pt_from_limbs(curve, 2, og, oinf[0]) == eg and pt_from_limbs(curve, 1, oh, oinf[1]) == eh, (min_idx, max_idx)
