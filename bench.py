@@ -169,14 +169,15 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_pmc_msm_bench.json): 2 x FETCH_SIZE (gfx950 reports half the bytes of 16-B-per-lane reads; the
-    factor reproduces the expected 16 x 2^20 x 128 B of point gathers + index reads to within 15 %) + WRITE_SIZE."""
+def pmc_traffic(prefix="msm_bucket_acc"):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc_msm_bench.json, collected by tools/pmc_collect.sh): 2 x FETCH_SIZE (gfx950 reports half the
+    bytes of 16-B-per-lane reads; the factor reproduces the expected 16 x 2^20 x 128 B of point gathers + index reads
+    to within 15 %) + WRITE_SIZE."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_msm_bench.json")
     try:
         k = json.load(open(path))["kernels"]
-        name = next(n for n in k if n.startswith("msm_bucket_acc"))
+        name = next(n for n in k if n.startswith(prefix))
         return int((2 * k[name]["FETCH_SIZE"]["mean_per_launch"] + k[name]["WRITE_SIZE"]["mean_per_launch"]) * 1024)
     except Exception:
         return None
@@ -208,7 +209,9 @@ def ntt_leg(np, zk, ctx, log_m=22, batch=8, steps=5):
     return {"metric": "NTT elements/sec, BLS12-381 Fr, 2^%d x %d" % (log_m, batch), "value": round(batch * m / dt / 1e6, 2), "unit": "Melements/s",
             "ms_per_transform_batch": round(dt * 1e3, 4),
             "roofline": {"bound": "hbm", "kernel": "ntt_pass (x%d per transform)" % (k_cnt // steps), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_transform_batch": alg}}
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": (lambda t: None if t is None else t * (k_cnt // steps))(pmc_traffic("ntt_pass")),  # per transform batch, like `achieved`
+                         "algorithmic_bytes_per_transform_batch": alg}}
 
 
 def groth16_leg(np, log_constraints=20, inputs=10, steps=3):
