@@ -16,6 +16,8 @@
 //   stored X, Y < MULB + K1;  stored ZZ, ZZZ < MULB;  affine inputs < MULB
 //   sub<K1>: subtrahend is a sum of at most three products (< 3 MULB <= K1 - 1)
 //   sub<K2>: subtrahend is a stored X / Y or another K1-difference (< MULB + K1 <= K2 - 1)
+//   mul_sub<K>(a, b, c, d) = a b - c d with c <= (K - 1) p: for Fu both products share ONE Montgomery reduction
+//       (fu_mul2) and the result is < 2p; the other field types compute sub<K1>(a b, c d)
 #pragma once
 #include "fu.hpp"
 
@@ -56,7 +58,7 @@ ZK_HD XYZZ<F> xyzz_dbl_affine(const Affine<F> &p) {
     F xx = O::sqr(p.x);
     F M = O::add(O::add(xx, xx), xx);
     F X3 = O::template sub<O::K1>(O::sqr(M), O::add(S, S));
-    F Y3 = O::template sub<O::K1>(O::mul(M, O::template sub<O::K2>(S, X3)), O::mul(W, p.y));
+    F Y3 = O::template mul_sub<O::K2>(M, O::template sub<O::K2>(S, X3), W, p.y);
     return {X3, Y3, V, W};
 }
 
@@ -72,7 +74,7 @@ ZK_HD XYZZ<F> xyzz_dbl(const XYZZ<F> &a) {
     F xx = O::sqr(a.X);
     F M = O::add(O::add(xx, xx), xx);
     F X3 = O::template sub<O::K1>(O::sqr(M), O::add(S, S));
-    F Y3 = O::template sub<O::K1>(O::mul(M, O::template sub<O::K2>(S, X3)), O::mul(W, a.Y));
+    F Y3 = O::template mul_sub<O::K2>(M, O::template sub<O::K2>(S, X3), W, a.Y);
     return {X3, Y3, O::mul(V, a.ZZ), O::mul(W, a.ZZZ)};
 }
 
@@ -96,7 +98,7 @@ ZK_HD XYZZ<F> xyzz_madd(const XYZZ<F> &a, const Affine<F> &p_in, bool negate = f
     F PPP = O::mul(Pd, PP);
     F Q = O::mul(a.X, PP);
     F X3 = O::template sub<O::K1>(O::sqr(R), O::add(PPP, O::add(Q, Q)));
-    F Y3 = O::template sub<O::K1>(O::mul(R, O::template sub<O::K2>(Q, X3)), O::mul(a.Y, PPP));
+    F Y3 = O::template mul_sub<O::K2>(R, O::template sub<O::K2>(Q, X3), a.Y, PPP);
     return {X3, Y3, O::mul(a.ZZ, PP), O::mul(a.ZZZ, PPP)};
 }
 
@@ -120,7 +122,7 @@ ZK_HD XYZZ<F> xyzz_add(const XYZZ<F> &a, const XYZZ<F> &b) {
     F PPP = O::mul(Pd, PP);
     F Q = O::mul(U1, PP);
     F X3 = O::template sub<O::K1>(O::sqr(R), O::add(PPP, O::add(Q, Q)));
-    F Y3 = O::template sub<O::K1>(O::mul(R, O::template sub<O::K2>(Q, X3)), O::mul(S1, PPP));
+    F Y3 = O::template mul_sub<O::K1>(R, O::template sub<O::K2>(Q, X3), S1, PPP);
     return {X3, Y3, O::mul(O::mul(a.ZZ, b.ZZ), PP), O::mul(O::mul(a.ZZZ, b.ZZZ), PPP)};
 }
 

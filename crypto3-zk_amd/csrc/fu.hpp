@@ -134,6 +134,45 @@ ZK_HD Fu<U> fu_mul(const Fu<U> &a, const Fu<U> &b) {
     return r;
 }
 
+// REDC(a b + c d): the two products share the column accumulators and ONE Montgomery reduction (3 L^2 mads
+// instead of the 4 L^2 of two separate products).  Limbs normalised (< 2^B): a column holds at most 2L products
+// < 2^58 plus L reduction terms, 3L 2^58 < 2^64 for L <= 21.
+// a b + c d < R p  =>  result < 2p.
+template <class U>
+ZK_HD Fu<U> fu_mul2(const Fu<U> &a, const Fu<U> &b, const Fu<U> &c, const Fu<U> &d) {
+    constexpr int L = U::L, B = U::B;
+    constexpr uint32_t MASK = Fu<U>::MASK;
+    static_assert(3 * L <= 63, "column accumulator would overflow");
+    uint32_t m[L];
+    Fu<U> r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc += (uint64_t)c.v[i] * d.v[k - i];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * U::mod(k - i);
+        m[k] = ((uint32_t)acc * U::QINV) & MASK;
+        acc += (uint64_t)m[k] * U::mod(0);
+        acc >>= B;
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L - 1; ++k) {
+#pragma unroll
+        for (int i = k - L + 1; i < L; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = k - L + 1; i < L; ++i) acc += (uint64_t)c.v[i] * d.v[k - i];
+#pragma unroll
+        for (int i = k - L + 1; i < L; ++i) acc += (uint64_t)m[i] * U::mod(k - i);
+        r.v[k - L] = (uint32_t)acc & MASK;
+        acc >>= B;
+    }
+    r.v[L - 1] = (uint32_t)acc;
+    return r;
+}
+
 // Montgomery square: the cross products a_i a_j (i != j) are taken once against the doubled operand, which
 // saves L(L-1)/2 of the 2 L^2 mads.  Same contract as fu_mul, with normalised input limbs (< 2^B).
 template <class U>
@@ -171,6 +210,10 @@ ZK_HD Fu<U> fu_sqr(const Fu<U> &a) {
 template <class U>
 ZK_NOINLINE_HD Fu<U> fu_mul_call(Fu<U> a, Fu<U> b) {
     return fu_mul(a, b);
+}
+template <class U>
+ZK_NOINLINE_HD Fu<U> fu_mul2_call(Fu<U> a, Fu<U> b, Fu<U> c, Fu<U> d) {
+    return fu_mul2(a, b, c, d);
 }
 
 // value < 2p with normalised limbs: is it 0 mod p?
@@ -319,6 +362,8 @@ struct FieldOps<Fp<P>> {
     ZK_HD static F add(const F &a, const F &b) { return a + b; }
     template <int K>
     ZK_HD static F sub(const F &a, const F &b) { return a - b; }
+    template <int K>
+    ZK_HD static F mul_sub(const F &a, const F &b, const F &c, const F &d) { return mul(a, b) - mul(c, d); }
     ZK_HD static bool is_zero(const F &a) { return a.is_zero(); }           // exact
     ZK_HD static bool is_zero_product(const F &a) { return a.is_zero(); }   // a is a mul/sqr output
     ZK_HD static bool is_exact_zero(const F &a) { return a.is_zero(); }     // representation of the constant 0
@@ -340,6 +385,8 @@ struct FieldOps<Fp2<P>> {
     ZK_HD static F add(const F &a, const F &b) { return a + b; }
     template <int K>
     ZK_HD static F sub(const F &a, const F &b) { return a - b; }
+    template <int K>
+    ZK_HD static F mul_sub(const F &a, const F &b, const F &c, const F &d) { return mul(a, b) - mul(c, d); }
     ZK_HD static bool is_zero(const F &a) { return a.is_zero(); }
     ZK_HD static bool is_zero_product(const F &a) { return a.is_zero(); }
     ZK_HD static bool is_exact_zero(const F &a) { return a.is_zero(); }
@@ -377,6 +424,14 @@ ZK_HD Fu<U> fu_mul_sel2(const Fu<U> &a, const Fu<U> &b) {
 #endif
 }
 
+template <class U>
+ZK_HD Fu<U> fu_mul2_sel(const Fu<U> &a, const Fu<U> &b, const Fu<U> &c, const Fu<U> &d) {
+#ifdef ZK_NOINLINE_MUL
+    return fu_mul2_call(a, b, c, d);
+#else
+    return fu_mul2(a, b, c, d);
+#endif
+}
 // a^(p-2): serial, never on a per-element path
 template <class U>
 ZK_HD Fu<U> fu_inv(const Fu<U> &a) {
@@ -413,6 +468,11 @@ struct FieldOps<Fu<U>> {
     ZK_HD static F add(const F &a, const F &b) { return fu_add(a, b); }
     template <int K>
     ZK_HD static F sub(const F &a, const F &b) { return fu_sub<K>(a, b); }
+    // a b - c d with c <= (K - 1) p: one reduction for both products, result < 2p
+    template <int K>
+    ZK_HD static F mul_sub(const F &a, const F &b, const F &c, const F &d) {
+        return fu_mul2_sel(a, b, fu_sub<K>(F::zero(), c), d);
+    }
     ZK_HD static bool is_zero(const F &a) { return fu_canon(a).limbs_zero(); }
     ZK_HD static bool is_zero_product(const F &a) { return fu_is_zero_lt2p(a); }
     ZK_HD static bool is_exact_zero(const F &a) { return a.limbs_zero(); }
@@ -431,7 +491,12 @@ struct FieldOps<Fu2<U>> {
     // products are < 10p per component, so the levels sit a factor ~5 above the base field's
     static constexpr int K1 = 32, K2 = 64, K3 = 128;
     static constexpr int WORDS = 2 * U::SL;
-    ZK_HD static F mul(const F &a, const F &b) {  // Karatsuba: v0, v1, s < 2p; c0 < 6p, c1 < 10p
+    // Karatsuba: v0, v1, s < 2p; c0 < 6p, c1 < 10p.  Measured and rejected for the G2 bucket kernel (14.2 ms): schoolbook
+    // over fu_mul2 (four products, two reductions: the same 6 L^2 mads; 16.0 ms) and Karatsuba with lazy reduction
+    // (three products formed column-wise feeding two reductions, 5 L^2 mads; 15.9 ms) -- both need 56 argument
+    // registers per out-of-line call, 24 of which the calling convention passes through scratch, and inlining the
+    // products overflows the instruction cache.
+    ZK_HD static F mul(const F &a, const F &b) {
         Fu<U> v0 = fu_mul_sel2(a.c0, b.c0), v1 = fu_mul_sel2(a.c1, b.c1);
         Fu<U> s = fu_mul_sel2(fu_add(a.c0, a.c1), fu_add(b.c0, b.c1));
         return {fu_sub<4>(v0, v1), fu_sub<8>(s, fu_add(v0, v1))};
@@ -444,6 +509,8 @@ struct FieldOps<Fu2<U>> {
     ZK_HD static F add(const F &a, const F &b) { return {fu_add(a.c0, b.c0), fu_add(a.c1, b.c1)}; }
     template <int K>
     ZK_HD static F sub(const F &a, const F &b) { return {fu_sub<K>(a.c0, b.c0), fu_sub<K>(a.c1, b.c1)}; }
+    template <int K>
+    ZK_HD static F mul_sub(const F &a, const F &b, const F &c, const F &d) { return sub<K1>(mul(a, b), mul(c, d)); }
     ZK_HD static bool is_zero(const F &a) { return fu_canon(a.c0).limbs_zero() && fu_canon(a.c1).limbs_zero(); }
     ZK_HD static bool is_zero_product(const F &a) { return is_zero(a); }
     ZK_HD static bool is_exact_zero(const F &a) { return a.limbs_zero(); }

@@ -13,6 +13,7 @@ using namespace zkhip;
 namespace {
 
 // op: 0 mul, 1 add, 2 sub<K1>, 3 inv(a), 4 sqr(a), 5 neg(a) = sub<K1>(0, a), 6 dbl(a), 7 sub<K2>, 9 fu_sqr(a + b),
+//     10 mul_sub<K2>(a, a + b, sub<K1>(0, b), b) = a (a + b) + b^2  (one shared reduction for the lazy base field),
 //     8 bound stress: mul(sub<K2>(mul(a,b), X), sub<K2>(sqr(b), X)),  X = sub<K1>(sqr(a), ab + 2 b^2)
 //       -- the deepest lazy chain of the group law, with every operand at its contract bound
 // the dedicated Montgomery square the kernels inline (FieldOps::sqr routes to the out-of-line product in this build)
@@ -35,6 +36,7 @@ int field_op(int op, const uint32_t *a, const uint32_t *b, uint32_t *out) {
         case 6: r = O::add(x, x); break;
         case 7: r = O::template sub<O::K2>(x, y); break;
         case 9: r = sqr_direct(O::add(x, y)); break;  // (a + b)^2 through fu_sqr, operand not reduced
+        case 10: r = O::template mul_sub<O::K2>(x, O::add(x, y), O::template sub<O::K1>(F::zero(), y), y); break;
         case 8: {
             F ab = O::mul(x, y), bb = O::sqr(y);
             F X = O::template sub<O::K1>(O::sqr(x), O::add(ab, O::add(bb, bb)));

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(NT, WAVES) void msm_bucket_acc_lds(const uint32_t *
         F PPP = O::mul(Pd, PP);
         F Q = O::mul(A.get(CX), PP);
         F X3 = O::template sub<O::K1>(O::sqr(R), O::add(PPP, O::add(Q, Q)));
-        F Y3 = O::template sub<O::K1>(O::mul(R, O::template sub<O::K2>(Q, X3)), O::mul(A.get(CY), PPP));
+        F Y3 = O::template mul_sub<O::K2>(R, O::template sub<O::K2>(Q, X3), A.get(CY), PPP);
         A.put(CX, X3);
         A.put(CY, Y3);
         A.put(CZZ, O::mul(A.get(CZZ), PP));

@@ -49,7 +49,8 @@ def test_prime_field_ops(shim, field):
         X = (a * a - a * b - 2 * b * b) % p
         for op, fn in ((0, lambda: a * b % p), (1, lambda: (a + b) % p), (2, lambda: (a - b) % p), (4, lambda: a * a % p),
                        (5, lambda: (-a) % p), (6, lambda: 2 * a % p), (7, lambda: (a - b) % p),
-                       (8, lambda: (a * b - X) * (b * b - X) % p), (9, lambda: (a + b) * (a + b) % p)):
+                       (8, lambda: (a * b - X) * (b * b - X) % p), (9, lambda: (a + b) * (a + b) % p),
+                       (10, lambda: (a * (a + b) + b * b) % p)):
             assert shim.zkt_field_op(field, op, P(A), P(B), P(out)) == 0
             assert _int(out) == fn(), (field, op, hex(a), hex(b))
         if a and i < 12:
@@ -73,7 +74,8 @@ def test_fq2_ops(shim, field, curve):
         X = F.sub(F.sqr(a), F.add(F.mul(a, b), F.add(F.sqr(b), F.sqr(b))))
         for op, fn in ((0, lambda: F.mul(a, b)), (1, lambda: F.add(a, b)), (2, lambda: F.sub(a, b)), (4, lambda: F.sqr(a)),
                        (5, lambda: F.neg(a)), (6, lambda: F.add(a, a)), (7, lambda: F.sub(a, b)),
-                       (8, lambda: F.mul(F.sub(F.mul(a, b), X), F.sub(F.sqr(b), X)))):
+                       (8, lambda: F.mul(F.sub(F.mul(a, b), X), F.sub(F.sqr(b), X))),
+                       (10, lambda: F.add(F.mul(a, F.add(a, b)), F.sqr(b)))):
             assert shim.zkt_field_op(field, op, P(pack(a)), P(pack(b)), P(out)) == 0
             assert unpack(out) == fn(), (op, a, b)
         if not F.is_zero(a) and i < 8:
