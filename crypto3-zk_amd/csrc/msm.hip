@@ -648,7 +648,14 @@ static int ilog2(size_t v) {
 
 int zk_scalar_bits(int curve) { return curve == CURVE_BLS12_381 ? 255 : 254; }  // bit length of r
 
-int zk_msm_auto_window(size_t n) { return std::max(2, std::min(16, ilog2(n) - 4)); }
+// c = round(log2 n) - 4: between 2^(k + 1/2) and 2^(k + 1) points the wider window already wins (one window fewer
+// per point against twice the buckets), and keys of 2^20 - k points land on the same c as their 2^20 / 2^21-point
+// neighbours, so that zkhip_msm_batch_dev can share one bucket reduction among them (Groth16's L query).
+int zk_msm_auto_window(size_t n) {
+    int l = ilog2(n);
+    if ((double)n >= 1.41421356237 * (double)((size_t)1 << l)) ++l;
+    return std::max(2, std::min(16, l - 4));
+}
 
 // Buckets per tail lane.  One bucket per lane gives the shortest dependency chain (~20 additions for the scalar
 // multiple) and is right while the lanes fit the chip once (a single MSM: 2^15 lanes, half a wave per SIMD).  A
