@@ -47,6 +47,9 @@ static constexpr uint32_t MSM_LARGE_CHUNK = 4096;  // entries per task of a spli
 #ifndef MSM_G1_THREADS
 #define MSM_G1_THREADS 256
 #endif
+#ifndef MSM_G2_WAVES
+#define MSM_G2_WAVES 2
+#endif
 
 // exclusive scan of `count` u32 counters in three launches: per-block (1024 counters) local scan + block
 // totals, scan of the totals by one workgroup, add-back.  offs[count] = total; cursor = copy of offs.
@@ -779,10 +782,19 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
         ZK_LAUNCH(ctx, "msm_bucket_acc", (msm_bucket_acc_lds<F, NT, 3>), dim3((nb + NT - 1) / NT), dim3(NT), lds_acc, d_b, tab_stride_words, B, offs, idx,
                   nb, large_thresh, order, buckets);
     } else {
-        // G2: everything in registers at one wave per SIMD.  The LDS variant (msm_bucket_acc_lds<F, 64, 2>: 256 VGPRs,
-        // ~200 spilled dwords, 7 waves per CU) measured 14.8 ms against 14.2 ms for this kernel at 2^20 points.
-        ZK_LAUNCH(ctx, "msm_bucket_acc", (msm_bucket_acc<F, 256, 1>), dim3((nb + 255) / 256), dim3(256), 0, d_b, tab_stride_words, B, offs, idx, nb,
-                  large_thresh, order, buckets);
+        // G2: every bucket is an even / odd lane pair, each lane holding one component of the Fq2 coordinates
+        // (fu2_pair.hpp): a lane then carries what a G1 lane carries -- two waves per SIMD instead of one.
+        typedef typename BucketLane<F>::type FL;
+        constexpr int NT = 256, WAVES = MSM_G2_WAVES, LPB = BucketLane<F>::LANES;
+        size_t lds_acc = LdsAcc<FL, NT>::BYTES;
+        static bool attr_acc2 = false;
+        if (!attr_acc2) {
+            ZK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&msm_bucket_acc_lds<FL, NT, WAVES, LPB>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
+            attr_acc2 = true;
+        }
+        ZK_LAUNCH(ctx, "msm_bucket_acc", (msm_bucket_acc_lds<FL, NT, WAVES, LPB>), dim3((unsigned)(((size_t)nb * LPB + NT - 1) / NT)), dim3(NT), lds_acc, d_b,
+                  tab_stride_words, B, offs, idx, nb, large_thresh, order, buckets);
     }
     // large buckets: plan on the device (no host round trip), then fixed-size grids that read the plan
     ZK_HIP_CHECK(ctx, hipMemsetAsync(plan, 0, 16, ctx->stream));

@@ -1,6 +1,7 @@
 // Bucket accumulation with the running sum's coordinates in LDS (included by msm.hip).
 #pragma once
 #include "curve.hpp"
+#include "fu2_pair.hpp"
 
 namespace zkhip {
 
@@ -26,6 +27,13 @@ struct LimbView<Fu2<U>> {
         if (i < U::L) x.c0.v[i] = v;
         else x.c1.v[i - U::L] = v;
     }
+};
+
+template <class U>
+struct LimbView<Fu2h<U>> {
+    static constexpr int N = U::L;
+    ZK_D static uint32_t get(const Fu2h<U> &x, int i) { return x.v.v[i]; }
+    ZK_D static void set(Fu2h<U> &x, int i, uint32_t v) { x.v.v[i] = v; }
 };
 
 template <class F, int NT>
@@ -60,14 +68,16 @@ struct LdsAcc {
     }
 };
 
-template <class F, int NT, int WAVES>
+// F is the type a LANE holds: the coordinate field itself (LPB = 1 lane per bucket), or one half of an Fq2
+// coordinate (Fu2h, LPB = 2: an even / odd lane pair per bucket, fu2_pair.hpp).
+template <class F, int NT, int WAVES, int LPB = 1>
 __global__ __launch_bounds__(NT, WAVES) void msm_bucket_acc_lds(const uint32_t *__restrict__ bases, size_t tab_stride_words, uint32_t B,
                                                            const uint32_t *__restrict__ offs, const uint32_t *__restrict__ idx, uint32_t nbuckets,
                                                            uint32_t large, const uint32_t *__restrict__ order, uint32_t *__restrict__ buckets) {
     typedef FieldOps<F> O;
     constexpr int NL = O::WORDS;
     extern __shared__ __attribute__((aligned(16))) uint4 acc_lds[];
-    const uint32_t tid = threadIdx.x, slot = blockIdx.x * NT + tid;
+    const uint32_t tid = threadIdx.x, slot = (blockIdx.x * NT + tid) / LPB;
     if (slot >= nbuckets) return;
     const uint32_t g = order[slot];  // buckets by descending size (msm_size_*)
     const uint32_t *tab = bases + (size_t)(g / B) * tab_stride_words;

@@ -13,10 +13,12 @@
 #define ZK_HD __host__ __device__ __forceinline__
 #define ZK_D __device__ __forceinline__
 #define ZK_NOINLINE_HD __host__ __device__ __noinline__
+#define ZK_NOINLINE_D __device__ __noinline__
 #else
 #define ZK_HD inline
 #define ZK_D inline
 #define ZK_NOINLINE_HD __attribute__((noinline))
+#define ZK_NOINLINE_D __attribute__((noinline))
 struct alignas(16) uint4 {
     uint32_t x, y, z, w;
 };

@@ -130,6 +130,21 @@ def test_msm_skewed_scalars(ctx, curve, group, n):
     bases.free()
 
 
+@pytest.mark.parametrize("curve,group,n", [(0, 2, 300), (1, 2, 1500), (0, 1, 1500)])
+def test_msm_over_device_generated_bases(ctx, curve, group, n):
+    """bases built on the device (zkhip_bases_from_scalars, and the window tables above 1024 points) hold lazily reduced
+    coordinates -- for G2 up to 10p -- unlike uploaded ones (< 2p): the bucket kernels must accept both."""
+    b = ctx.bases_from_scalars(curve, group, cp.random_fr(curve, 21, n))
+    pts, infs = b.download()
+    sc = cp.random_fr(curve, 22, n)
+    exp, einf = cp.msm(curve, group, pts, sc, chunks=cp.num_threads())
+    for c in (0, 2, 6, 10):
+        ctx.set_option("msm_window_bits", c)
+        assert gpu_affine(ctx, b, sc) == pt_from_limbs(curve, group, exp, einf), c
+    ctx.set_option("msm_window_bits", 0)
+    b.free()
+
+
 @pytest.mark.parametrize("curve,group,n", [(0, 1, 500), (1, 2, 60)])
 def test_bases_from_scalars(ctx, curve, group, n):
     """device-side fixed-base batch exponentiation (generator.hpp:187-214) against the oracle"""
