@@ -101,6 +101,8 @@ struct FieldOps<Fu2h<U>> {
     ZK_D static bool is_zero(const F &a) { return both(fu_canon(a.v).limbs_zero()); }
     ZK_D static bool is_zero_product(const F &a) { return both(fu_is_zero_lt2p(a.v)); }
     ZK_D static bool is_exact_zero(const F &a) { return both(a.v.limbs_zero()); }
+    static constexpr int CANON_WORDS = 2 * U::NL;  // canonical Fq2 at the boundary: c0 | c1
+    ZK_D static void to_canonical(uint32_t *sat, const F &a) { fu_to_canonical<U>(sat + (F::odd() ? U::NL : 0), a.v); }
     ZK_D static F load(const uint32_t *p) { return {fu_load<U>(p + (F::odd() ? U::SL : 0))}; }
     ZK_D static void store(uint32_t *p, const F &a) { fu_store<U>(p + (F::odd() ? U::SL : 0), a.v); }
 };

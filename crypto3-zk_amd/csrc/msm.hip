@@ -311,7 +311,8 @@ __global__ __launch_bounds__(256) void msm_plan_large(const uint32_t *__restrict
     large[3 * slot + 2] = nt;
 }
 
-template <class F>
+// (all kernels below: F is the type a lane holds, LPB lanes share one point -- fu2_pair.hpp; `t` is the point slot)
+template <class F, int LPB>
 __global__ __launch_bounds__(128) void msm_bucket_large(const uint32_t *__restrict__ bases, size_t tab_stride_words, uint32_t B,
                                                         const uint32_t *__restrict__ idx, const uint32_t *__restrict__ plan,
                                                         const uint32_t *__restrict__ tasks, uint32_t *__restrict__ partials) {
@@ -319,17 +320,17 @@ __global__ __launch_bounds__(128) void msm_bucket_large(const uint32_t *__restri
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t ntasks = plan[0];
     for (uint32_t task = blockIdx.x; task < ntasks; task += gridDim.x) {
-        const uint32_t g = tasks[3 * task], lo = tasks[3 * task + 1], hi = tasks[3 * task + 2], t = threadIdx.x;
+        const uint32_t g = tasks[3 * task], lo = tasks[3 * task + 1], hi = tasks[3 * task + 2], t = threadIdx.x / LPB;
         const uint32_t *tab = bases + (size_t)(g / B) * tab_stride_words;
         XYZZ<F> acc = XYZZ<F>::infinity();
-        for (uint32_t k = lo + t; k < hi; k += blockDim.x) {
+        for (uint32_t k = lo + t; k < hi; k += blockDim.x / LPB) {
             uint32_t e = idx[k];
             Affine<F> p = affine_load<F>(tab + (size_t)(e & 0x7FFFFFFFu) * (2 * NL));
             acc = xyzz_madd(acc, p, (e >> 31) != 0);
         }
         xyzz_store<F>(lds + (size_t)t * (4 * NL), acc);
         __syncthreads();
-        for (uint32_t d = blockDim.x / 2; d >= 1; d >>= 1) {
+        for (uint32_t d = blockDim.x / LPB / 2; d >= 1; d >>= 1) {
             if (t < d) {
                 acc = xyzz_add(xyzz_load<F>(lds + (size_t)t * (4 * NL)), xyzz_load<F>(lds + (size_t)(t + d) * (4 * NL)));
                 xyzz_store<F>(lds + (size_t)t * (4 * NL), acc);
@@ -342,20 +343,20 @@ __global__ __launch_bounds__(128) void msm_bucket_large(const uint32_t *__restri
 }
 
 // one wave per large bucket: lanes fold the bucket's task partials in strides, then an LDS tree
-template <class F>
+template <class F, int LPB>
 __global__ __launch_bounds__(64) void msm_large_combine(const uint32_t *__restrict__ plan, const uint32_t *__restrict__ large,
                                                         const uint32_t *__restrict__ partials, uint32_t *__restrict__ buckets) {
     constexpr int NL = FieldOps<F>::WORDS;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t nlarge = plan[1], t = threadIdx.x;
+    const uint32_t nlarge = plan[1], t = threadIdx.x / LPB;
     for (uint32_t j = blockIdx.x; j < nlarge; j += gridDim.x) {
         const uint32_t g = large[3 * j], first = large[3 * j + 1], nt = large[3 * j + 2];
         XYZZ<F> acc = XYZZ<F>::infinity();
-        for (uint32_t k = t; k < nt; k += 64) acc = xyzz_add(acc, xyzz_load<F>(partials + (size_t)(first + k) * (4 * NL)));
+        for (uint32_t k = t; k < nt; k += 64 / LPB) acc = xyzz_add(acc, xyzz_load<F>(partials + (size_t)(first + k) * (4 * NL)));
         if (nt > 1) {  // uniform over the wave
             xyzz_store<F>(lds + (size_t)t * (4 * NL), acc);
             __syncthreads();
-            for (uint32_t d = 32; d >= 1; d >>= 1) {
+            for (uint32_t d = 32 / LPB; d >= 1; d >>= 1) {
                 if (t < d && t + d < nt) {
                     acc = xyzz_add(xyzz_load<F>(lds + (size_t)t * (4 * NL)), xyzz_load<F>(lds + (size_t)(t + d) * (4 * NL)));
                     xyzz_store<F>(lds + (size_t)t * (4 * NL), acc);
@@ -369,10 +370,10 @@ __global__ __launch_bounds__(64) void msm_large_combine(const uint32_t *__restri
 }
 
 // buckets[w][b] += buckets[w + half][b] for w < cnt (one level of the tree that folds equal-weight windows)
-template <class F>
+template <class F, int LPB>
 __global__ __launch_bounds__(256) void msm_bucket_merge(uint32_t *__restrict__ buckets, uint32_t B, uint32_t half, uint32_t cnt) {
     constexpr int NL = FieldOps<F>::WORDS;
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) / LPB;
     if (g >= cnt * B) return;
     uint32_t *dst = buckets + (size_t)g * (4 * NL);
     const uint32_t *src = buckets + ((size_t)g + (size_t)half * B) * (4 * NL);
@@ -406,12 +407,13 @@ ZK_D XYZZ<F> block_tree_sum(uint32_t *lds, XYZZ<F> acc, uint32_t t, uint32_t nth
 }
 
 // grid = windows x nblk workgroups; partial[w * nblk + j] = weighted sum of segments [256 j, 256 j + 256) of window w
-template <class F>
+template <class F, int LPB>
 __global__ __launch_bounds__(MSM_TAIL_THREADS) void msm_bucket_red(const uint32_t *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t nseg,
                                                                    uint32_t nblk, uint32_t *__restrict__ partial) {
     constexpr int NL = FieldOps<F>::WORDS;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t t = threadIdx.x, w = blockIdx.x / nblk, seg = (blockIdx.x % nblk) * MSM_TAIL_THREADS + t;
+    constexpr uint32_t SLOTS = MSM_TAIL_THREADS / LPB;
+    const uint32_t t = threadIdx.x / LPB, w = blockIdx.x / nblk, seg = (blockIdx.x % nblk) * SLOTS + t;
     XYZZ<F> sum = XYZZ<F>::infinity();
     if (seg < nseg) {
         const uint32_t *base = buckets + ((size_t)w * B + (size_t)seg * L) * (4 * NL);
@@ -426,27 +428,27 @@ __global__ __launch_bounds__(MSM_TAIL_THREADS) void msm_bucket_red(const uint32_
             if (seg != 0) sum = xyzz_add(sum, xyzz_mul_small(run, seg * L));
         }
     }
-    sum = block_tree_sum<F>(lds, sum, t, MSM_TAIL_THREADS);
+    sum = block_tree_sum<F>(lds, sum, t, SLOTS);
     if (t == 0) xyzz_store<F>(partial + (size_t)blockIdx.x * (4 * NL), sum);
 }
 
 // one 64-lane workgroup per window: winsum[w] = sum_j partial[w][j]
-template <class F>
+template <class F, int LPB>
 __global__ __launch_bounds__(64) void msm_window_sum(const uint32_t *__restrict__ partial, uint32_t nblk, uint32_t *__restrict__ winsum) {
     constexpr int NL = FieldOps<F>::WORDS;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t w = blockIdx.x, t = threadIdx.x;
+    const uint32_t w = blockIdx.x, t = threadIdx.x / LPB;
     XYZZ<F> acc = XYZZ<F>::infinity();
-    for (uint32_t j = t; j < nblk; j += 64) acc = xyzz_add(acc, xyzz_load<F>(partial + ((size_t)w * nblk + j) * (4 * NL)));
-    if (nblk > 1) acc = block_tree_sum<F>(lds, acc, t, 64);
+    for (uint32_t j = t; j < nblk; j += 64 / LPB) acc = xyzz_add(acc, xyzz_load<F>(partial + ((size_t)w * nblk + j) * (4 * NL)));
+    if (nblk > 1) acc = block_tree_sum<F>(lds, acc, t, 64 / LPB);
     if (t == 0) xyzz_store<F>(winsum + (size_t)w * (4 * NL), acc);
 }
 
 // result = sum_w 2^(c w) winsum[w]  (Horner from the top window), emitted as canonical Jacobian
-template <class F>
-__global__ void msm_final(const uint32_t *__restrict__ winsum, int W, int c, uint32_t *__restrict__ out_jac) {
+template <class F, int LPB>
+__global__ __launch_bounds__(64) void msm_final(const uint32_t *__restrict__ winsum, int W, int c, uint32_t *__restrict__ out_jac) {
     constexpr int NL = FieldOps<F>::WORDS;
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x >= LPB) return;
     XYZZ<F> acc = XYZZ<F>::infinity();
     for (int w = W - 1; w >= 0; --w) {
         if (!acc.is_inf())
@@ -675,10 +677,12 @@ static uint32_t msm_tail_segment(const zkhip_ctx *ctx, uint32_t B, size_t window
 // the tail workgroups keep 256 XYZZ points in LDS (56 KiB for G1, 128 KiB for BLS12-381 G2)
 template <class F>
 static int msm_tail_attr(zkhip_ctx *ctx) {
+    typedef typename BucketLane<F>::type FL;
+    constexpr int LPB = BucketLane<F>::LANES;
     static bool done = false;
     if (!done) {
-        ZK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&msm_bucket_red<F>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              MSM_TAIL_THREADS * 4 * FieldOps<F>::WORDS * 4));
+        ZK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&msm_bucket_red<FL, LPB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              MSM_TAIL_THREADS / LPB * 4 * FieldOps<F>::WORDS * 4));
         done = true;
     }
     return 0;
@@ -688,6 +692,8 @@ template <class F>
 static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac,
                      uint32_t *batch_slot = nullptr, size_t *need_out = nullptr) {
     constexpr int NL = FieldOps<F>::WORDS;
+    typedef typename BucketLane<F>::type FL;           // what a lane holds in the bucket / tail kernels
+    constexpr int LPB = BucketLane<F>::LANES;          // lanes per point (2 for G2: fu2_pair.hpp)
     const bool tables = bases->ntab > 1;
     // window size: 2^(c-1) buckets per window.  With window tables c is fixed by the tables.
     int c = tables ? bases->c_tab : ctx->opt_msm_window_bits;
@@ -698,7 +704,8 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     const uint32_t nb = (uint32_t)W * B;
     const int Wr = tables ? 1 : W;  // windows left after the equal-weight merge
     const uint32_t L = msm_tail_segment(ctx, B, tables ? 1 : W);  // buckets per tail segment
-    const uint32_t nseg = B / L, nblk_tail = (nseg + MSM_TAIL_THREADS - 1) / MSM_TAIL_THREADS;
+    const uint32_t tail_slots = MSM_TAIL_THREADS / BucketLane<F>::LANES;  // points per tail workgroup
+    const uint32_t nseg = B / L, nblk_tail = (nseg + tail_slots - 1) / tail_slots;
     // two-level LDS counting sort (see msm_sort_*): low 8 bits inside a super-bucket, the rest across super-buckets
     const uint32_t lowb = (uint32_t)std::min(8, c - 1), nsuper = 1u << ((c - 1) - lowb);
     const uint32_t ntile = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE), ngroups = (uint32_t)W * nsuper;
@@ -784,8 +791,7 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     } else {
         // G2: every bucket is an even / odd lane pair, each lane holding one component of the Fq2 coordinates
         // (fu2_pair.hpp): a lane then carries what a G1 lane carries -- two waves per SIMD instead of one.
-        typedef typename BucketLane<F>::type FL;
-        constexpr int NT = 256, WAVES = MSM_G2_WAVES, LPB = BucketLane<F>::LANES;
+        constexpr int NT = 256, WAVES = MSM_G2_WAVES;
         size_t lds_acc = LdsAcc<FL, NT>::BYTES;
         static bool attr_acc2 = false;
         if (!attr_acc2) {
@@ -801,22 +807,23 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     ZK_LAUNCH(ctx, "msm_plan_large", msm_plan_large, dim3((nb + 255) / 256), dim3(256), 0, offs, nb, plan, tasks, large, task_cap, large_cap, large_thresh);
     {
         static bool attr_set = false;
-        size_t lds_large = (size_t)128 * 4 * NL * 4;
+        size_t lds_large = (size_t)128 / LPB * 4 * NL * 4;
         if (!attr_set && lds_large > 48 * 1024) {
-            ZK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&msm_bucket_large<F>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            ZK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&msm_bucket_large<FL, LPB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                   (int)lds_large));
             attr_set = true;
         }
         unsigned grid_large = (unsigned)std::min<size_t>(task_cap, 512);  // persistent: workgroups loop over the task list
-        ZK_LAUNCH(ctx, "msm_bucket_large", msm_bucket_large<F>, dim3(grid_large), dim3(128), lds_large, d_b, tab_stride_words, B, idx, plan, tasks,
-                  partials);
-        ZK_LAUNCH(ctx, "msm_bucket_large", msm_large_combine<F>, dim3((unsigned)std::min<uint32_t>(large_cap, 256)), dim3(64), (size_t)64 * 4 * NL * 4, plan,
-                  large, partials, buckets);
+        ZK_LAUNCH(ctx, "msm_bucket_large", (msm_bucket_large<FL, LPB>), dim3(grid_large), dim3(128), lds_large, d_b, tab_stride_words, B, idx, plan,
+                  tasks, partials);
+        ZK_LAUNCH(ctx, "msm_bucket_large", (msm_large_combine<FL, LPB>), dim3((unsigned)std::min<uint32_t>(large_cap, 256)), dim3(64),
+                  (size_t)64 / LPB * 4 * NL * 4, plan, large, partials, buckets);
     }
     if (tables) {
         for (uint32_t cur = (uint32_t)W; cur > 1;) {
             uint32_t half = (cur + 1) / 2, cnt = cur - half;
-            ZK_LAUNCH(ctx, "msm_bucket_merge", msm_bucket_merge<F>, dim3((cnt * B + 255) / 256), dim3(256), 0, buckets, B, half, cnt);
+            ZK_LAUNCH(ctx, "msm_bucket_merge", (msm_bucket_merge<FL, LPB>), dim3((unsigned)(((size_t)cnt * B * LPB + 255) / 256)), dim3(256), 0, buckets, B,
+                      half, cnt);
             cur = half;
         }
     }
@@ -825,10 +832,10 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
         return 0;
     }
     ZK_TRY(msm_tail_attr<F>(ctx));
-    ZK_LAUNCH(ctx, "msm_bucket_red", msm_bucket_red<F>, dim3((unsigned)Wr * nblk_tail), dim3(MSM_TAIL_THREADS), (size_t)MSM_TAIL_THREADS * 4 * NL * 4, buckets, B, L,
-              nseg, nblk_tail, segsum);
-    ZK_LAUNCH(ctx, "msm_window_sum", msm_window_sum<F>, dim3(Wr), dim3(64), (size_t)64 * 4 * NL * 4, segsum, nblk_tail, winsum);
-    ZK_LAUNCH(ctx, "msm_final", msm_final<F>, dim3(1), dim3(64), 0, winsum, Wr, c, d_out_jac);
+    ZK_LAUNCH(ctx, "msm_bucket_red", (msm_bucket_red<FL, LPB>), dim3((unsigned)Wr * nblk_tail), dim3(MSM_TAIL_THREADS), (size_t)tail_slots * 4 * NL * 4, buckets, B,
+              L, nseg, nblk_tail, segsum);
+    ZK_LAUNCH(ctx, "msm_window_sum", (msm_window_sum<FL, LPB>), dim3(Wr), dim3(64), (size_t)64 / LPB * 4 * NL * 4, segsum, nblk_tail, winsum);
+    ZK_LAUNCH(ctx, "msm_final", (msm_final<FL, LPB>), dim3(1), dim3(64), 0, winsum, Wr, c, d_out_jac);
     return 0;
 }
 
@@ -866,11 +873,11 @@ __global__ void msm_write_infinity(uint32_t *out_jac) {
 }
 
 // one workgroup per MSM of a batch: window sum -> canonical Jacobian at that MSM's output pointer
-template <class F>
-__global__ void msm_final_batch(const uint32_t *__restrict__ winsum, uint32_t count, uint32_t *const *__restrict__ outs) {
+template <class F, int LPB>
+__global__ __launch_bounds__(64) void msm_final_batch(const uint32_t *__restrict__ winsum, uint32_t count, uint32_t *const *__restrict__ outs) {
     constexpr int NL = FieldOps<F>::WORDS;
     constexpr int CW = FieldOps<F>::CANON_WORDS;
-    if (blockIdx.x >= count || threadIdx.x != 0) return;
+    if (blockIdx.x >= count || threadIdx.x >= LPB) return;
     Jacobian<F> j = xyzz_to_jacobian(xyzz_load<F>(winsum + (size_t)blockIdx.x * (4 * NL)));
     uint32_t *out = outs[blockIdx.x];
     FieldOps<F>::to_canonical(out, j.X);
@@ -885,10 +892,13 @@ template <class F>
 static int msm_batch_t(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases, const size_t *offsets, const size_t *ns,
                        const uint32_t *const *d_scalars, uint32_t *const *d_outs) {
     constexpr int NL = FieldOps<F>::WORDS;
+    typedef typename BucketLane<F>::type FL;
+    constexpr int LPB = BucketLane<F>::LANES;
     const int c = bases[0]->c_tab;
     const uint32_t B = 1u << (c - 1);
     const uint32_t L = msm_tail_segment(ctx, B, count);
-    const uint32_t nseg = B / L, nblk_tail = (nseg + MSM_TAIL_THREADS - 1) / MSM_TAIL_THREADS;
+    const uint32_t tail_slots = MSM_TAIL_THREADS / BucketLane<F>::LANES;  // points per tail workgroup
+    const uint32_t nseg = B / L, nblk_tail = (nseg + tail_slots - 1) / tail_slots;
     size_t max_need = 0;
     for (size_t i = 0; i < count; ++i) {
         size_t need = 0;
@@ -920,10 +930,10 @@ static int msm_batch_t(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *b
     ctx->batch_ptrs.assign(d_outs, d_outs + count);
     ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_ptrs, ctx->batch_ptrs.data(), count * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
     ZK_TRY(msm_tail_attr<F>(ctx));
-    ZK_LAUNCH(ctx, "msm_bucket_red", msm_bucket_red<F>, dim3((unsigned)count * nblk_tail), dim3(MSM_TAIL_THREADS), (size_t)MSM_TAIL_THREADS * 4 * NL * 4, slots, B,
-              L, nseg, nblk_tail, segsum);
-    ZK_LAUNCH(ctx, "msm_window_sum", msm_window_sum<F>, dim3((unsigned)count), dim3(64), (size_t)64 * 4 * NL * 4, segsum, nblk_tail, winsum);
-    ZK_LAUNCH(ctx, "msm_final", msm_final_batch<F>, dim3((unsigned)count), dim3(64), 0, winsum, (uint32_t)count, d_ptrs);
+    ZK_LAUNCH(ctx, "msm_bucket_red", (msm_bucket_red<FL, LPB>), dim3((unsigned)count * nblk_tail), dim3(MSM_TAIL_THREADS), (size_t)tail_slots * 4 * NL * 4, slots,
+              B, L, nseg, nblk_tail, segsum);
+    ZK_LAUNCH(ctx, "msm_window_sum", (msm_window_sum<FL, LPB>), dim3((unsigned)count), dim3(64), (size_t)64 / LPB * 4 * NL * 4, segsum, nblk_tail, winsum);
+    ZK_LAUNCH(ctx, "msm_final", (msm_final_batch<FL, LPB>), dim3((unsigned)count), dim3(64), 0, winsum, (uint32_t)count, d_ptrs);
     return 0;
 }
 
