@@ -18,6 +18,7 @@
 #define ZKHIP_SHIM_R1CS_GG_PPZKSNARK_HPP
 
 #include <algorithm>
+#include <future>
 #include <random>
 #include <utility>
 #include <vector>
@@ -304,10 +305,28 @@ public:
         std::uint64_t *z = static_cast<std::uint64_t *>(pk.h_cpa.get());
         z[0] = 1;
         z[1] = z[2] = z[3] = 0;
-        std::size_t zi = 1;
-        for (const auto &v : primary_input) adapter::scalar_to_limbs(v, &z[4 * zi++]);
-        for (const auto &v : auxiliary_input) adapter::scalar_to_limbs(v, &z[4 * zi++]);
-        check(zkhip_memcpy_h2d_async(ctx.get(), cpa, z, 32 * (num_variables + 1)), "zkhip_memcpy_h2d_async", ctx.get());
+        for (std::size_t i = 0; i < num_inputs; ++i) adapter::scalar_to_limbs(primary_input[i], &z[4 * (1 + i)]);
+        /* the auxiliary input (almost all of the assignment) is converted into the page-locked staging buffer in
+           slices by a few host threads, and every slice is sent as soon as it is ready: the conversion of slice k + 1
+           overlaps the PCIe copy of slice k */
+        {
+            const std::size_t aux = auxiliary_input.size(), slices = aux >= (std::size_t)1 << 16 ? 8 : 1, per = (aux + slices - 1) / slices;
+            std::uint64_t *za = z + 4 * (1 + num_inputs);
+            std::vector<std::future<void>> ready;
+            for (std::size_t k = 1; k < slices; ++k)
+                ready.push_back(std::async(std::launch::async, [&, k]() {
+                    for (std::size_t i = k * per; i < std::min(aux, (k + 1) * per); ++i) adapter::scalar_to_limbs(auxiliary_input[i], &za[4 * i]);
+                }));
+            for (std::size_t i = 0; i < std::min(aux, per); ++i) adapter::scalar_to_limbs(auxiliary_input[i], &za[4 * i]);
+            check(zkhip_memcpy_h2d_async(ctx.get(), cpa, z, 32 * (1 + num_inputs + std::min(aux, per))), "zkhip_memcpy_h2d_async", ctx.get());
+            for (std::size_t k = 1; k < slices; ++k) {
+                ready[k - 1].get();
+                const std::size_t lo = k * per, hi = std::min(aux, (k + 1) * per);
+                if (hi > lo)
+                    check(zkhip_memcpy_h2d_async(ctx.get(), cpa + 32 * (1 + num_inputs + lo), za + 4 * lo, 32 * (hi - lo)), "zkhip_memcpy_h2d_async",
+                          ctx.get());
+            }
+        }
         /* qap_wit.coefficients_for_H, resident (prover.hpp:79-83) */
         std::uint64_t w[4], g[4];
         adapter::scalar_to_limbs(pk.domain.omega, w);
