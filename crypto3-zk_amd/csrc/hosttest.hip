@@ -140,11 +140,12 @@ int zkt_point_chain(int field, const uint32_t *pts, const uint8_t *inf, const ui
     return -1;
 }
 
-// digits[w] for one scalar: value = sum_w digit_w * 2^(c w), digit as signed int32 (0 when none)
-int zkt_recode(const uint32_t *scalar, int c, int W, int32_t *digits) {
+// digits[w] for one scalar: value = sum_w digit_w * 2^off(w), digit as signed int32 (0 when none); returns the carry
+// out of the top window
+static int recode_windows(const uint32_t *scalar, MsmWindows win, int32_t *digits) {
     uint32_t carry = 0;
-    for (int w = 0; w < W; ++w) {
-        uint32_t d = msm_recode(scalar, w, c, carry);
+    for (int w = 0; w < win.W; ++w) {
+        uint32_t d = msm_recode(scalar, win.off(w), win.width(w), carry);
         if (d == DIG_NONE) digits[w] = 0;
         else {
             int32_t mag = (int32_t)(d & 0x7FFFFFFFu) + 1;
@@ -154,13 +155,17 @@ int zkt_recode(const uint32_t *scalar, int c, int W, int32_t *digits) {
     return (int)carry;
 }
 
-// the recoding msm_digits_only performs: fold to |s| <= (r - 1) / 2, then signed digits over msm_windows() windows.
+// W uniform windows of c bits (off(w) = c w)
+int zkt_recode(const uint32_t *scalar, int c, int W, int32_t *digits) { return recode_windows(scalar, MsmWindows {c * W, W}, digits); }
+
+// the recoding msm_digits_only performs: fold to |s| <= (r - 1) / 2, then signed digits over the balanced windows
+// MsmWindows{bitlen(r), ceil(bitlen(r) / c)}: value = sum_w digit_w * 2^floor(w * bitlen(r) / W).
 // Returns the window count, or -1 if a carry left the top window (must not happen).  curve: 0 BLS12-381, 1 BN254.
 int zkt_recode_folded(int curve, const uint32_t *scalar, int c, int32_t *digits) {
     uint32_t s[8];
     const bool flip = curve == 0 ? msm_fold_scalar<BlsFr>(scalar, s) : msm_fold_scalar<BnFr>(scalar, s);
-    const int W = msm_windows(curve == 0 ? 255 : 254, c);
-    if (zkt_recode(s, c, W, digits) != 0) return -1;
+    const int tb = curve == 0 ? 255 : 254, W = msm_windows(tb, c);
+    if (recode_windows(s, MsmWindows {tb, W}, digits) != 0) return -1;
     if (flip)
         for (int w = 0; w < W; ++w) digits[w] = -digits[w];
     return W;

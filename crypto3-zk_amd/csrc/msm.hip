@@ -129,15 +129,15 @@ __global__ __launch_bounds__(256) void msm_scan_add(uint32_t *__restrict__ offs,
 static constexpr uint32_t SORT_TILE = 4096;  // digits per pass-1 tile (256 lanes x 16)
 
 template <class FR>
-__global__ __launch_bounds__(256) void msm_digits_only(const uint32_t *__restrict__ scalars, uint32_t n, int c, int W,
+__global__ __launch_bounds__(256) void msm_digits_only(const uint32_t *__restrict__ scalars, uint32_t n, MsmWindows win,
                                                        uint32_t *__restrict__ dig) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t s[8];
     const uint32_t flip = msm_fold_scalar<FR>(scalars + (size_t)i * 8, s) ? 0x80000000u : 0u;  // |s| <= (r - 1) / 2
     uint32_t carry = 0;
-    for (int w = 0; w < W; ++w) {
-        uint32_t d = msm_recode(s, w, c, carry);
+    for (int w = 0; w < win.W; ++w) {
+        uint32_t d = msm_recode(s, win.off(w), win.width(w), carry);
         dig[(size_t)w * n + i] = d == DIG_NONE ? d : d ^ flip;
     }
 }
@@ -446,13 +446,13 @@ __global__ __launch_bounds__(64) void msm_window_sum(const uint32_t *__restrict_
 
 // result = sum_w 2^(c w) winsum[w]  (Horner from the top window), emitted as canonical Jacobian
 template <class F, int LPB>
-__global__ __launch_bounds__(64) void msm_final(const uint32_t *__restrict__ winsum, int W, int c, uint32_t *__restrict__ out_jac) {
+__global__ __launch_bounds__(64) void msm_final(const uint32_t *__restrict__ winsum, int W, MsmWindows win, uint32_t *__restrict__ out_jac) {
     constexpr int NL = FieldOps<F>::WORDS;
     if (blockIdx.x != 0 || threadIdx.x >= LPB) return;
     XYZZ<F> acc = XYZZ<F>::infinity();
     for (int w = W - 1; w >= 0; --w) {
         if (!acc.is_inf())
-            for (int i = 0; i < c; ++i) acc = xyzz_dbl(acc);
+            for (int i = 0; i < win.width(w); ++i) acc = xyzz_dbl(acc);
         acc = xyzz_add(acc, xyzz_load<F>(winsum + (size_t)w * (4 * NL)));
     }
     Jacobian<F> j = xyzz_to_jacobian(acc);
@@ -512,8 +512,9 @@ __global__ __launch_bounds__(64) void bases_mul(uint32_t *__restrict__ pts, cons
 // lane's own W-1 denominators ZZ*ZZZ), then the affine results are written to their tables.
 // tmp: (W-1) x n entries of 5 field elements (X, Y, ZZ, ZZZ, prefix product).
 template <class F>
-__global__ __launch_bounds__(64) void bases_precompute_range(uint32_t *__restrict__ pts, uint32_t n, uint32_t lo, uint32_t cnt, int c, int W,
+__global__ __launch_bounds__(64) void bases_precompute_range(uint32_t *__restrict__ pts, uint32_t n, uint32_t lo, uint32_t cnt, MsmWindows win,
                                                              uint32_t *__restrict__ tmp_base) {
+    const int W = win.W;
     typedef FieldOps<F> O;
     constexpr int NL = O::WORDS;
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;  // index inside the chunk
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(64) void bases_precompute_range(uint32_t *__restric
     XYZZ<F> acc = XYZZ<F>::from_affine(p);
     F pre = F::one();
     for (int w = 1; w < W; ++w) {
-        for (int k = 0; k < c; ++k) acc = xyzz_dbl(acc);
+        for (int k = 0; k < win.width(w - 1); ++k) acc = xyzz_dbl(acc);  // table w holds 2^off(w) P
         uint32_t *slot = tmp + ((size_t)(w - 1) * cnt + j) * (5 * NL);
         xyzz_store<F>(slot, acc);
         pre = O::mul(pre, O::mul(acc.ZZ, acc.ZZZ));
@@ -700,6 +701,7 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     if (c <= 0) c = zk_msm_auto_window(n);
     c = std::max(2, std::min(16, c));
     const int W = msm_windows(zk_scalar_bits(bases->curve), c);  // scalars are folded to |s| <= (r - 1) / 2: no carry out of window W - 1
+    const MsmWindows win = {zk_scalar_bits(bases->curve), W};
     const uint32_t B = 1u << (c - 1);
     const uint32_t nb = (uint32_t)W * B;
     const int Wr = tables ? 1 : W;  // windows left after the equal-weight merge
@@ -762,8 +764,8 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     const size_t tab_stride_words = tables ? bases->n * bases->stride_u32 : 0;
 
     unsigned gn = (unsigned)((n + 255) / 256);
-    if (bases->curve == CURVE_BLS12_381) ZK_LAUNCH(ctx, "msm_digits", msm_digits_only<BlsFr>, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, c, W, dig);
-    else ZK_LAUNCH(ctx, "msm_digits", msm_digits_only<BnFr>, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, c, W, dig);
+    if (bases->curve == CURVE_BLS12_381) ZK_LAUNCH(ctx, "msm_digits", msm_digits_only<BlsFr>, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, win, dig);
+    else ZK_LAUNCH(ctx, "msm_digits", msm_digits_only<BnFr>, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, win, dig);
     ZK_LAUNCH(ctx, "msm_sort_hist", msm_sort_hist, dim3(ntile, W), dim3(256), 0, dig, (uint32_t)n, lowb, nsuper, ntile, bh);
     ZK_LAUNCH(ctx, "msm_scan", msm_scan_local, dim3(nblk), dim3(256), 0, bh, nbh, bo, bsums);
     ZK_LAUNCH(ctx, "msm_scan", msm_scan_top, dim3(1), dim3(1024), 0, bsums, nblk, bo + nbh);
@@ -835,7 +837,7 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     ZK_LAUNCH(ctx, "msm_bucket_red", (msm_bucket_red<FL, LPB>), dim3((unsigned)Wr * nblk_tail), dim3(MSM_TAIL_THREADS), (size_t)tail_slots * 4 * NL * 4, buckets, B,
               L, nseg, nblk_tail, segsum);
     ZK_LAUNCH(ctx, "msm_window_sum", (msm_window_sum<FL, LPB>), dim3(Wr), dim3(64), (size_t)64 / LPB * 4 * NL * 4, segsum, nblk_tail, winsum);
-    ZK_LAUNCH(ctx, "msm_final", (msm_final<FL, LPB>), dim3(1), dim3(64), 0, winsum, Wr, c, d_out_jac);
+    ZK_LAUNCH(ctx, "msm_final", (msm_final<FL, LPB>), dim3(1), dim3(64), 0, winsum, Wr, win, d_out_jac);
     return 0;
 }
 
@@ -852,7 +854,7 @@ static int bases_precompute_t(zkhip_ctx *ctx, zkhip_bases *b) {
         uint32_t *tmp = ctx->ws_take<uint32_t>(per / 4 * cnt);
         // the kernel indexes tables with stride n: hand it the sub-range through a shifted base pointer
         ZK_LAUNCH(ctx, "bases_precompute", bases_precompute_range<F>, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, b->d, (uint32_t)b->n,
-                  (uint32_t)lo, (uint32_t)cnt, b->c_tab, b->ntab, tmp);
+                  (uint32_t)lo, (uint32_t)cnt, MsmWindows {zk_scalar_bits(b->curve), b->ntab}, tmp);
     }
     return 0;
 }

@@ -15,16 +15,26 @@ ZK_HD uint32_t scalar_bits(const uint32_t *s, int lo, int c) {
     return (uint32_t)(v >> off) & ((1u << c) - 1);
 }
 
-// Signed c-bit digit of window w: returns (|d| - 1) | sign << 31, or DIG_NONE for d = 0; `carry` threads
-// through the windows from w = 0 upwards.  d = bits + carry in [0, 2^c]; values above B = 2^(c-1) are
-// replaced by d - 2^c (carry 1), so every non-zero digit has magnitude in [1, B].
-ZK_HD uint32_t msm_recode(const uint32_t *s, int w, int c, uint32_t &carry) {
-    const uint32_t B = 1u << (c - 1);
-    uint32_t d = scalar_bits(s, w * c, c) + carry;
+// Window geometry: the tb = bitlen(r) scalar bits are cut into W = ceil(tb / c) windows of NEARLY EQUAL width
+// (floor or ceil of tb / W, never more than c): window w covers bits [off(w), off(w + 1)).  Cutting at multiples of c
+// instead leaves a top window with whatever remains -- 2 bits for c = 12 or 14 -- whose handful of buckets each
+// receive a quarter of all points.
+struct MsmWindows {
+    int tb, W;
+    ZK_HD int off(int w) const { return (int)(((long long)w * tb) / W); }
+    ZK_HD int width(int w) const { return off(w + 1) - off(w); }
+};
+
+// Signed digit of a window of `width` bits at bit offset `off`: returns (|d| - 1) | sign << 31, or DIG_NONE for
+// d = 0; `carry` threads through the windows from the lowest upwards.  d = bits + carry in [0, 2^width]; values
+// above 2^(width-1) are replaced by d - 2^width (carry 1), so every non-zero digit has magnitude in [1, 2^(width-1)].
+ZK_HD uint32_t msm_recode(const uint32_t *s, int off, int width, uint32_t &carry) {
+    const uint32_t B = 1u << (width - 1);
+    uint32_t d = scalar_bits(s, off, width) + carry;
     uint32_t neg = 0;
     carry = 0;
     if (d > B) {
-        d = (1u << c) - d;
+        d = (1u << width) - d;
         neg = d != 0 ? 1u : 0u;
         carry = 1;
     }
@@ -33,7 +43,7 @@ ZK_HD uint32_t msm_recode(const uint32_t *s, int w, int c, uint32_t &carry) {
 
 // Fold a scalar s (reduced mod r first when it is not canonical) into the symmetric range: when 2 s > r it is replaced by r - s and the caller
 // flips the sign of every digit (s P = (r - s)(-P)).  |s| <= (r - 1) / 2 < 2^(bitlen(r) - 1), so the recoding over
-// msm_windows(bitlen(r), c) windows never carries out of the top window -- without the fold a window size that
+// MsmWindows{bitlen(r), msm_windows(bitlen(r), c)} never carries out of the top window -- without the fold a window size that
 // divides bitlen(r) (c = 15 for the 255-bit BLS12-381 r) leaves a carry-only top window whose single bucket
 // receives ~45 % of all points.  FR: saturated scalar-field constants (mod(i), 8 u32 limbs).
 template <class FR>

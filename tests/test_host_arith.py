@@ -179,7 +179,10 @@ def test_folded_recoding(shim, curve_id, curve, c):
     for v in vals:
         s = _u32(v, 8)
         W = shim.zkt_recode_folded(curve_id, s.ctypes.data_as(ctypes.c_void_p), c, dig.ctypes.data_as(ctypes.c_void_p))
-        assert W == (r.bit_length() + c - 1) // c
-        assert all(-B <= int(d) <= B for d in dig[:W])
-        got = sum(int(d) << (c * w) for w, d in enumerate(dig[:W]))
+        tb = r.bit_length()
+        assert W == (tb + c - 1) // c
+        off = [w * tb // W for w in range(W + 1)]  # balanced windows: widths floor / ceil of tb / W, never above c
+        assert all(1 <= off[w + 1] - off[w] <= c for w in range(W))
+        assert all(abs(int(d)) <= (1 << (off[w + 1] - off[w] - 1)) for w, d in enumerate(dig[:W]))
+        got = sum(int(d) << off[w] for w, d in enumerate(dig[:W]))
         assert got % r == v % r and abs(got) <= (r - 1) // 2
