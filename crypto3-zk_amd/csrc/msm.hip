@@ -654,13 +654,16 @@ static int ilog2(size_t v) {
 
 int zk_scalar_bits(int curve) { return curve == CURVE_BLS12_381 ? 255 : 254; }  // bit length of r
 
-// c = round(log2 n) - 4: between 2^(k + 1/2) and 2^(k + 1) points the wider window already wins (one window fewer
-// per point against twice the buckets), and keys of 2^20 - k points land on the same c as their 2^20 / 2^21-point
-// neighbours, so that zkhip_msm_batch_dev can share one bucket reduction among them (Groth16's L query).
+// Window size from the number of points (tools/msm_window_sweep.py, 2^10 .. 2^19 points, window tables built for every
+// c): the time falls with c almost until c = log2 n -- buckets of a few entries keep the per-lane chains short and
+// the tables make extra buckets cheap -- so c = round(log2 n), held at 15 for 2^16 / 2^17 points (the 2^15-lane tail
+// of c = 16 costs more than the one window it saves there) and capped at 16.  Keys of 2^20 - k and 2^21 - 1 points
+// get the same c as 2^20, so zkhip_msm_batch_dev shares one bucket reduction among Groth16's G1 queries.
 int zk_msm_auto_window(size_t n) {
     int l = ilog2(n);
     if ((double)n >= 1.41421356237 * (double)((size_t)1 << l)) ++l;
-    return std::max(2, std::min(16, l - 4));
+    int c = l >= 18 ? 16 : (l >= 16 ? 15 : l);
+    return std::max(2, std::min(16, c));
 }
 
 // Buckets per tail lane.  One bucket per lane gives the shortest dependency chain (~20 additions for the scalar

@@ -155,7 +155,7 @@ static int bases_alloc(zkhip_ctx *ctx, int curve, int group, size_t n, zkhip_bas
     b->ntab = 1;
     b->c_tab = 0;
     if (ctx->opt_msm_precompute && n >= (size_t)ctx->opt_msm_precompute_min) {
-        b->c_tab = zk_msm_auto_window(n);
+        b->c_tab = ctx->opt_msm_window_bits > 0 ? std::max(2, std::min(16, ctx->opt_msm_window_bits)) : zk_msm_auto_window(n);
         b->ntab = msm_windows(zk_scalar_bits(curve), b->c_tab);
     }
     hipError_t e = hipMalloc((void **)&b->d, std::max<size_t>(1, n) * b->ntab * b->stride_u32 * 4);
