@@ -7,9 +7,10 @@
 //
 // Data layout in HBM
 //   bases    : ntab tables x n x {x, y}   lazy Montgomery limbs (fu.hpp), 16 words per coordinate, AoS, (0,0) = infinity;
-//                                         table w holds 2^(c w) P_i (built once at upload)                    (resident)
+//                                         table w holds 2^off(w) P_i (built once at upload)                   (resident)
 //   scalars  : n x 8 u32             canonical little-endian
-//   dig      : W x n u32             signed c-bit digit of scalar i in window w: (|d|-1) | sign<<31, NONE if d = 0
+//   dig      : W x n u32             signed digit of scalar i in window w (balanced widths <= c, msm_recode.hpp):
+//                                    (|d|-1) | sign<<31, NONE if d = 0; scalars are folded to |s| <= (r-1)/2 first
 //   offs     : W*B + 1 u32           exclusive prefix of the bucket sizes (B = 2^(c-1) buckets per window)
 //   idx      : (#non-zero digits) u32  point index | sign<<31, grouped by (window, bucket)
 //   order    : W*B u32               bucket ids by descending size
@@ -21,8 +22,8 @@
 //   msm_sort_*        two-level counting sort of point indices by (window, bucket), counters in LDS only
 //   msm_scan_*        exclusive prefix (local scan, top scan, add-back), shared by both sorts
 //   msm_size_*        order of the buckets by descending size
-//   msm_bucket_acc_lds  one lane per bucket: gather affine points, XYZZ mixed additions, accumulator in LDS   <- dominant
-//   msm_bucket_acc    same with the accumulator in registers (Fq2: G2)
+//   msm_bucket_acc_lds  one lane per bucket (G1) or one even / odd lane pair per bucket (G2, fu2_pair.hpp): gather affine
+//                     points, XYZZ mixed additions, accumulator coordinates in LDS                          <- dominant
 //   msm_plan_large / msm_bucket_large / msm_large_combine   buckets above 128 entries, one workgroup per 4096-entry task
 //   msm_bucket_merge  with window tables: fold the W equal-weight windows bucket by bucket (log2 W launches)
 //   msm_bucket_red    (b + 1) * bucket[b] per lane, LDS tree over the 256 lanes of a workgroup
@@ -246,41 +247,6 @@ __global__ __launch_bounds__(256) void msm_size_scatter(const uint32_t *__restri
     __syncthreads();
     for (uint32_t g = blockIdx.x * 1024 + t; g < min(nbuckets, (blockIdx.x + 1) * 1024); g += 256)
         order[atomicAdd(&cur[size_bin(offs[g + 1] - offs[g], large)], 1u)] = g;
-}
-
-// One lane per (window, bucket).  With precomputed window tables (tab_stride != 0) window w gathers from
-// table w, whose entry i is 2^(c w) P_i, so that all windows feed buckets of equal weight.
-template <class F, int MSM_ACC_THREADS, int MSM_ACC_WAVES>
-__global__ __launch_bounds__(MSM_ACC_THREADS, MSM_ACC_WAVES) void msm_bucket_acc(const uint32_t *__restrict__ bases, size_t tab_stride_words, uint32_t B,
-                                                      const uint32_t *__restrict__ offs, const uint32_t *__restrict__ idx, uint32_t nbuckets,
-                                                      uint32_t large, const uint32_t *__restrict__ order, uint32_t *__restrict__ buckets) {
-    constexpr int NL = FieldOps<F>::WORDS;
-    // `order` lists the buckets by descending size (msm_size_*): lanes of a wave, and waves of a workgroup, get
-    // near-equal trip counts, and the long buckets are dispatched first.
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= nbuckets) return;
-    const uint32_t g = order[slot];
-    const uint32_t *tab = bases + (size_t)(g / B) * tab_stride_words;
-    uint32_t lo = offs[g], hi = offs[g + 1];
-    if (hi - lo > large) return;  // split across workgroups by msm_bucket_large (empty: written below)
-    XYZZ<F> acc = XYZZ<F>::infinity();
-    if (lo < hi) {
-        // software pipeline: the next point's gather is in flight while the current mixed addition runs
-        uint32_t e = idx[lo];
-        Affine<F> p = affine_load<F>(tab + (size_t)(e & 0x7FFFFFFFu) * (2 * NL));
-        for (uint32_t k = lo; k < hi; ++k) {
-            uint32_t e_next = e;
-            Affine<F> p_next = p;
-            if (k + 1 < hi) {
-                e_next = idx[k + 1];
-                p_next = affine_load<F>(tab + (size_t)(e_next & 0x7FFFFFFFu) * (2 * NL));
-            }
-            acc = xyzz_madd(acc, p, (e >> 31) != 0);
-            e = e_next;
-            p = p_next;
-        }
-    }
-    xyzz_store<F>(buckets + (size_t)g * (4 * NL), acc);
 }
 
 // ---- large buckets ---------------------------------------------------------------------------------------

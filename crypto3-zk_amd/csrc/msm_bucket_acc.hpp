@@ -8,9 +8,9 @@ namespace zkhip {
 // ---- bucket accumulation with the accumulator in LDS ----------------------------------------------------------
 // A wave issues one VALU instruction per ~4 cycles, so throughput scales with waves per SIMD (measured linear up to
 // 4, tools/mulbench).  Holding X, Y, ZZ of the running sum in LDS (conflict-free [coord][quad][lane] uint4 planes)
-// instead of VGPRs brings the G1 kernel under 168 registers (three waves per SIMD instead of two) and the G2
-// kernel under 256 (two instead of one).  ZZZ stays in registers; the mixed addition reads the LDS coordinates
-// where it uses them and writes the results back.
+// instead of VGPRs brings the G1 kernel under 168 registers (three waves per SIMD instead of two); the G2 kernel
+// runs on lane pairs (fu2_pair.hpp) that each hold half of every Fq2 coordinate, at two waves per SIMD.  ZZZ stays
+// in registers; the mixed addition reads the LDS coordinates where it uses them and writes the results back.
 template <class F>
 struct LimbView;  // the 29-bit limbs of a coordinate as one flat sequence
 template <class U>
@@ -19,16 +19,6 @@ struct LimbView<Fu<U>> {
     ZK_D static uint32_t get(const Fu<U> &x, int i) { return x.v[i]; }
     ZK_D static void set(Fu<U> &x, int i, uint32_t v) { x.v[i] = v; }
 };
-template <class U>
-struct LimbView<Fu2<U>> {
-    static constexpr int N = 2 * U::L;
-    ZK_D static uint32_t get(const Fu2<U> &x, int i) { return i < U::L ? x.c0.v[i] : x.c1.v[i - U::L]; }
-    ZK_D static void set(Fu2<U> &x, int i, uint32_t v) {
-        if (i < U::L) x.c0.v[i] = v;
-        else x.c1.v[i - U::L] = v;
-    }
-};
-
 template <class U>
 struct LimbView<Fu2h<U>> {
     static constexpr int N = U::L;
