@@ -7,6 +7,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/zkhip.h"
@@ -56,6 +57,7 @@ struct zkhip_ctx {
     // bump-allocated workspace, grown on demand, reused across calls
     char *ws = nullptr;
     size_t ws_cap = 0, ws_off = 0, ws_floor = 0;  // ws_floor: start of the per-call region (a batch parks data below it)
+    std::unordered_set<const void *> lds_configured;  // kernels whose dynamic-LDS limit was raised on this context's device
     std::vector<uint64_t> lincomb_stage, lincomb_coeffs;  // host staging of zkhip_poly_lincomb_dev's tables
     std::vector<uint32_t *> batch_ptrs;            // host copy of a batch's output pointers (alive until the copy ran)
     // pinned staging for small results
@@ -134,6 +136,15 @@ struct zkhip_ctx {
         prof.pending.clear();
     }
 };
+
+// raise a kernel's dynamic-LDS limit once per context (the attribute is per device: a process may hold contexts on
+// several GPUs, so a process-wide flag would skip it on the second device)
+#define ZK_MAX_LDS(ctx, kernel, bytes)                                                                                              \
+    do {                                                                                                                            \
+        const void *fn__ = reinterpret_cast<const void *>(&kernel);                                                                 \
+        if ((ctx)->lds_configured.insert(fn__).second)                                                                              \
+            ZK_HIP_CHECK(ctx, hipFuncSetAttribute(fn__, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)));                 \
+    } while (0)
 
 // launch + profile wrapper: ZK_LAUNCH(ctx, "name", kernel, grid, block, lds, args...)
 #define ZK_LAUNCH(ctx, name, kernel, grid, block, lds, ...)                        \

@@ -339,11 +339,7 @@ static int ntt_run_t(zkhip_ctx *ctx, int curve, uint32_t *d_data, size_t log_m, 
         p.post_coset = (inverse && coset != nullptr && i == np - 1) ? 1u : 0u;
         size_t nelem = (size_t)1 << (p.s + p.log_t), nhalf = std::max<size_t>(1, ((size_t)1 << p.s) / 2);
         size_t lds = (2 * nelem + (nelem + 3) / 4 + 2 * nhalf + (nhalf + 3) / 4) * 16;
-        static bool attr_set = false;
-        if (!attr_set) {
-            ZK_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass<U>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+        ZK_MAX_LDS(ctx, ntt_pass<U>, 160 * 1024);
         size_t grid = batch * p.tiles_per_poly;
         if (grid >= (1ull << 31)) return ZKHIP_ERR_RANGE;
         unsigned threads = (unsigned)std::min<size_t>(256, std::max<size_t>(64, nelem / 2));
