@@ -156,7 +156,7 @@ static int recode_windows(const uint32_t *scalar, MsmWindows win, int32_t *digit
 }
 
 // W uniform windows of c bits (off(w) = c w)
-int zkt_recode(const uint32_t *scalar, int c, int W, int32_t *digits) { return recode_windows(scalar, MsmWindows {c * W, W}, digits); }
+int zkt_recode(const uint32_t *scalar, int c, int W, int32_t *digits) { return recode_windows(scalar, msm_make_windows(c * W, W), digits); }
 
 // the recoding msm_digits_only performs: fold to |s| <= (r - 1) / 2, then signed digits over the balanced windows
 // MsmWindows{bitlen(r), ceil(bitlen(r) / c)}: value = sum_w digit_w * 2^floor(w * bitlen(r) / W).
@@ -165,7 +165,7 @@ int zkt_recode_folded(int curve, const uint32_t *scalar, int c, int32_t *digits)
     uint32_t s[8];
     const bool flip = curve == 0 ? msm_fold_scalar<BlsFr>(scalar, s) : msm_fold_scalar<BnFr>(scalar, s);
     const int tb = curve == 0 ? 255 : 254, W = msm_windows(tb, c);
-    if (recode_windows(s, MsmWindows {tb, W}, digits) != 0) return -1;
+    if (recode_windows(s, msm_make_windows(tb, W), digits) != 0) return -1;
     if (flip)
         for (int w = 0; w < W; ++w) digits[w] = -digits[w];
     return W;

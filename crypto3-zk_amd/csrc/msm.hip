@@ -734,7 +734,7 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     if (c <= 0) c = zk_msm_auto_window(n);
     c = std::max(2, std::min(16, c));
     const int W = msm_windows(zk_scalar_bits(bases->curve), c);  // scalars are folded to |s| <= (r - 1) / 2: no carry out of window W - 1
-    const MsmWindows win = {zk_scalar_bits(bases->curve), W};
+    const MsmWindows win = msm_make_windows(zk_scalar_bits(bases->curve), W);
     const uint32_t B = 1u << (c - 1);
     const uint32_t nb = (uint32_t)W * B;
     const int Wr = tables ? 1 : W;  // windows left after the equal-weight merge
@@ -872,7 +872,7 @@ static int bases_precompute_t(zkhip_ctx *ctx, zkhip_bases *b) {
         uint32_t *tmp = ctx->ws_take<uint32_t>(per / 4 * cnt);
         // the kernel indexes tables with stride n: hand it the sub-range through a shifted base pointer
         ZK_LAUNCH(ctx, "bases_precompute", bases_precompute_range<F>, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, b->d, (uint32_t)b->n,
-                  (uint32_t)lo, (uint32_t)cnt, MsmWindows {zk_scalar_bits(b->curve), b->ntab}, tmp);
+                  (uint32_t)lo, (uint32_t)cnt, msm_make_windows(zk_scalar_bits(b->curve), b->ntab), tmp);
     }
     return 0;
 }

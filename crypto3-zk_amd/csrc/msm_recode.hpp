@@ -21,9 +21,17 @@ ZK_HD uint32_t scalar_bits(const uint32_t *s, int lo, int c) {
 // receive a quarter of all points.
 struct MsmWindows {
     int tb, W;
-    ZK_HD int off(int w) const { return (int)(((long long)w * tb) / W); }
+    uint8_t offs[64];  // offs[w] = floor(w * tb / W), w = 0..W (tb <= 255, W <= 64 for c >= 4; smaller c: computed)
+    ZK_HD int off(int w) const { return W < 64 ? (int)offs[w] : (int)(((long long)w * tb) / W); }
     ZK_HD int width(int w) const { return off(w + 1) - off(w); }
 };
+inline MsmWindows msm_make_windows(int tb, int W) {
+    MsmWindows m;
+    m.tb = tb;
+    m.W = W;
+    for (int w = 0; w < 64; ++w) m.offs[w] = (uint8_t)(w <= W ? ((long long)w * tb) / W : 0);
+    return m;
+}
 
 // Signed digit of a window of `width` bits at bit offset `off`: returns (|d| - 1) | sign << 31, or DIG_NONE for
 // d = 0; `carry` threads through the windows from the lowest upwards.  d = bits + carry in [0, 2^width]; values
