@@ -197,12 +197,64 @@ struct r1cs_to_qap_hip {
     }
 };
 
+/// Contiguous, balanced split of [0, n) over `world` ranks (the first n % world ranks get one extra element).
+inline std::pair<std::size_t, std::size_t> shard_range(std::size_t n, std::size_t rank, std::size_t world) {
+    const std::size_t base = n / world, extra = n % world, lo = rank * base + std::min(rank, extra);
+    return {lo, lo + base + (rank < extra ? 1 : 0)};
+}
+
+/// Which slice of every query a proving-key object holds when a proof is sharded over several GPUs (SURVEY 8e:
+/// point-range partition, one process per GPU).  Offsets are positions in the FULL query; *_n the slice length.
+/// B counts entries of the sparse query (its index list is sliced, not the variable range).
+struct query_shard {
+    std::size_t rank = 0, world = 1;
+    std::size_t A_lo = 0, A_n = 0, B_lo = 0, B_n = 0, H_lo = 0, H_n = 0, L_lo = 0, L_n = 0;
+    /// slices for `rank` of `world` given the sizes a proof uses: A: N + 1, B: entries, H: degree - 1, L: N - n
+    static query_shard make(std::size_t rank, std::size_t world, std::size_t a, std::size_t b, std::size_t h, std::size_t l) {
+        query_shard q;
+        q.rank = rank;
+        q.world = world;
+        auto ra = shard_range(a, rank, world), rb = shard_range(b, rank, world), rh = shard_range(h, rank, world), rl = shard_range(l, rank, world);
+        q.A_lo = ra.first, q.A_n = ra.second - ra.first;
+        q.B_lo = rb.first, q.B_n = rb.second - rb.first;
+        q.H_lo = rh.first, q.H_n = rh.second - rh.first;
+        q.L_lo = rl.first, q.L_n = rl.second - rl.first;
+        return q;
+    }
+};
+
 // ---- proving key with its device-resident queries -------------------------------------------------------------
 template <typename CurveType>
 class r1cs_gg_ppzksnark_proving_key_hip {
 public:
     typedef curve_adapter<CurveType> adapter;
     typedef r1cs_gg_ppzksnark_proving_key<CurveType> host_key_type;
+
+    /// Rank `rank` of `world`: uploads only this rank's slice of the four queries (and the whole constraint system:
+    /// the witness map is replicated).  Proofs then go through prover::process_partial + an all-gather of the partial
+    /// sums + prover::finish.
+    r1cs_gg_ppzksnark_proving_key_hip(const context &ctx, const host_key_type &pk, const domain_params<CurveType> &dom, std::size_t rank,
+                                      std::size_t world) :
+        ctx(ctx), host(pk), domain(dom), constraint_system(ctx, pk.constraint_system) {
+        const std::size_t N = pk.constraint_system.num_variables(), n = pk.constraint_system.num_inputs();
+        shard = query_shard::make(rank, world, N + 1, pk.B_query.values.size(), constraint_system.domain_size() - 1, N - n);
+        A_query = device_bases<CurveType, ZKHIP_G1>(ctx, pk.A_query.begin() + shard.A_lo, pk.A_query.begin() + shard.A_lo + shard.A_n);
+        H_query = device_bases<CurveType, ZKHIP_G1>(ctx, pk.H_query.begin() + shard.H_lo, pk.H_query.begin() + shard.H_lo + shard.H_n);
+        L_query = device_bases<CurveType, ZKHIP_G1>(ctx, pk.L_query.begin() + shard.L_lo, pk.L_query.begin() + shard.L_lo + shard.L_n);
+        std::vector<typename adapter::g2_value_type> g;
+        std::vector<typename adapter::g1_value_type> h;
+        std::vector<std::uint32_t> idx;
+        for (std::size_t i = shard.B_lo; i < shard.B_lo + shard.B_n; ++i) {
+            g.push_back(pk.B_query.values[i].g);
+            h.push_back(pk.B_query.values[i].h);
+            idx.push_back((std::uint32_t)pk.B_query.indices[i]);
+        }
+        B_query_g = device_bases<CurveType, ZKHIP_G2>(ctx, g.begin(), g.end());
+        B_query_h = device_bases<CurveType, ZKHIP_G1>(ctx, h.begin(), h.end());
+        d_B_indices = ctx.alloc(std::max<std::size_t>(1, idx.size()) * 4);
+        if (!idx.empty()) ctx.h2d(d_B_indices.get(), idx.data(), idx.size() * 4);
+        B_count = idx.size();
+    }
 
     /// Uploads the four queries and the constraint system once; proofs then only move the assignment.
     r1cs_gg_ppzksnark_proving_key_hip(const context &ctx, const host_key_type &pk, const domain_params<CurveType> &dom) :
@@ -221,6 +273,7 @@ public:
         d_B_indices = ctx.alloc(std::max<std::size_t>(1, idx.size()) * 4);
         if (!idx.empty()) ctx.h2d(d_B_indices.get(), idx.data(), idx.size() * 4);
         B_count = idx.size();
+        set_full_shard();
     }
 
     /// Adopts queries that already live on the device (e.g. produced by device_bases::from_scalars); `pk` supplies
@@ -228,12 +281,15 @@ public:
     r1cs_gg_ppzksnark_proving_key_hip(const context &ctx, const host_key_type &pk, const domain_params<CurveType> &dom,
                                       device_bases<CurveType, ZKHIP_G1> &&a_query, device_bases<CurveType, ZKHIP_G2> &&b_query_g,
                                       device_bases<CurveType, ZKHIP_G1> &&b_query_h, const std::vector<std::uint32_t> &b_indices,
-                                      device_bases<CurveType, ZKHIP_G1> &&h_query, device_bases<CurveType, ZKHIP_G1> &&l_query) :
+                                      device_bases<CurveType, ZKHIP_G1> &&h_query, device_bases<CurveType, ZKHIP_G1> &&l_query,
+                                      const query_shard *slice = nullptr) :
         ctx(ctx), host(pk), domain(dom), A_query(std::move(a_query)), H_query(std::move(h_query)), L_query(std::move(l_query)),
         B_query_h(std::move(b_query_h)), B_query_g(std::move(b_query_g)), constraint_system(ctx, pk.constraint_system) {
         d_B_indices = ctx.alloc(std::max<std::size_t>(1, b_indices.size()) * 4);
         if (!b_indices.empty()) ctx.h2d(d_B_indices.get(), b_indices.data(), b_indices.size() * 4);
         B_count = b_indices.size();
+        if (slice) shard = *slice;    // the adopted bases are this rank's slices
+        else set_full_shard();
     }
 
     const context &ctx;
@@ -244,6 +300,7 @@ public:
     device_r1cs<CurveType> constraint_system;
     std::shared_ptr<void> d_B_indices;
     std::size_t B_count = 0;
+    query_shard shard;
 
     /// per-proof device buffers, kept across proofs: (1, x, w), coefficients_for_H, witness-map scratch, gathered B
     /// scalars, the five Jacobian MSM results
@@ -266,6 +323,10 @@ public:
     }
 
 private:
+    void set_full_shard() {
+        const std::size_t N = host.constraint_system.num_variables(), n = host.constraint_system.num_inputs();
+        shard = query_shard::make(0, 1, N + 1, B_count, constraint_system.domain_size() - 1, N - n);
+    }
     mutable std::size_t work_cpa_ = 0;
 };
 
@@ -289,15 +350,69 @@ public:
 
     static proof_type process(const proving_key_type &pk, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input,
                               const scalar_value_type &r, const scalar_value_type &s) {
+        if (pk.shard.world != 1) throw std::runtime_error("process: sharded key -- use process_partial / finish (or the all-gather overload)");
+        enqueue(pk, primary_input, auxiliary_input);
+        /* host products that do not depend on the MSM results, computed while the GPU works (prover.hpp:142-155) */
+        const host_terms t = host_products(pk, r, s);
+        return assemble(pk, collect(pk), 1, r, s, t);    // collect(): the one synchronisation of the proof
+    }
+
+    // ---- one proof sharded over several GPUs (one process per GPU) ---------------------------------------
+    // Every rank holds a slice of each query (proving_key_type(ctx, pk, dom, rank, world)), runs the witness map in
+    // full (replicated: 7 NTTs, no exchange) and the five MSMs over its slices; the only exchange is one all-gather
+    // of partial_limbs() u64 words per rank (4 G1 + 1 G2 Jacobian points, 864 bytes for BLS12-381), after which
+    // every rank can assemble the proof.
+
+    /// u64 words of one rank's partial sums: A, B.h, H, L (G1) then B.g (G2), Jacobian
+    static constexpr std::size_t partial_limbs() { return 4 * 3 * adapter::g1_coord_limbs + 3 * adapter::g2_coord_limbs; }
+
+    /// this rank's partial sums (synchronises)
+    static std::vector<std::uint64_t> process_partial(const proving_key_type &pk, const primary_input_type &primary_input,
+                                                      const auxiliary_input_type &auxiliary_input) {
+        enqueue(pk, primary_input, auxiliary_input);
+        return collect(pk);
+    }
+    /// `gathered`: world x partial_limbs() words, rank-major (what an all-gather of process_partial's result yields)
+    static proof_type finish(const proving_key_type &pk, const std::vector<std::uint64_t> &gathered, const scalar_value_type &r,
+                             const scalar_value_type &s) {
+        if (gathered.size() != pk.shard.world * partial_limbs()) throw std::runtime_error("finish: gathered partial sums have the wrong size");
+        return assemble(pk, gathered, pk.shard.world, r, s, host_products(pk, r, s));
+    }
+    /// process with the exchange supplied by the caller: all_gather(mine, words, all) fills `all` with world x words
+    /// (RCCL through torch.distributed, MPI, ...)
+    template <typename AllGather>
+    static proof_type process(const proving_key_type &pk, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input,
+                              const scalar_value_type &r, const scalar_value_type &s, AllGather all_gather) {
+        enqueue(pk, primary_input, auxiliary_input);
+        const host_terms t = host_products(pk, r, s);
+        const std::vector<std::uint64_t> mine = collect(pk);
+        std::vector<std::uint64_t> all(pk.shard.world * partial_limbs());
+        all_gather(mine.data(), mine.size(), all.data());
+        return assemble(pk, all, pk.shard.world, r, s, t);
+    }
+
+private:
+    struct host_terms {
+        typename adapter::g1_value_type r_delta, s_delta, rs_delta;
+        typename adapter::g2_value_type s_delta2;
+    };
+    static host_terms host_products(const proving_key_type &pk, const scalar_value_type &r, const scalar_value_type &s) {
+        const auto &k = pk.host;
+        return {r * k.delta_g1, s * k.delta_g1, (r * s) * k.delta_g1, s * k.delta_g2};
+    }
+
+    /// enqueue the whole device side of a proof on the context's stream (no synchronisation)
+    static void enqueue(const proving_key_type &pk, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input) {
         const context &ctx = pk.ctx;
+        const query_shard &sh = pk.shard;
         const std::size_t num_inputs = primary_input.size();
         const std::size_t num_variables = primary_input.size() + auxiliary_input.size();
         const std::size_t degree = pk.constraint_system.domain_size();
 
         /* Everything below is enqueued on the context's stream without intermediate synchronisation; the device
            buffers live in the key object (allocated on first use) so a proof costs no hipMalloc. */
-        const std::size_t jl1 = 3 * adapter::g1_coord_limbs, jl2 = 3 * adapter::g2_coord_limbs;
-        pk.reserve_work(num_variables + 1, degree, (4 * jl1 + jl2) * 8);
+        const std::size_t jl1 = 3 * adapter::g1_coord_limbs;
+        pk.reserve_work(num_variables + 1, degree, partial_limbs() * 8);
         char *cpa = static_cast<char *>(pk.d_cpa.get());
         std::uint64_t *d_res = static_cast<std::uint64_t *>(pk.d_results.get());
 
@@ -333,40 +448,53 @@ public:
         adapter::scalar_to_limbs(pk.domain.coset_generator, g);
         check(zkhip_groth16_witness_h_dev(ctx.get(), pk.constraint_system.get(), cpa, w, g, pk.d_h.get(), pk.d_scratch.get()),
               "zkhip_groth16_witness_h_dev", ctx.get());
-        /* evaluation_Bt: kc_multiexp_with_mixed_addition over the sparse (G2, G1) query (prover.hpp:116-123) */
+        /* evaluation_Bt: kc_multiexp_with_mixed_addition over the sparse (G2, G1) query (prover.hpp:116-123); a sharded key
+           holds a slice of the index list */
         check(zkhip_fr_gather_dev(ctx.get(), cpa, pk.d_B_indices.get(), pk.B_count, pk.d_bs.get()), "zkhip_fr_gather_dev", ctx.get());
         check(zkhip_msm_dev(ctx.get(), pk.B_query_g.get(), 0, pk.B_count, pk.d_bs.get(), d_res + 4 * jl1), "zkhip_msm_dev(B.g)", ctx.get());
         /* the four G1 multiexps as one batch (their bucket reductions share one launch):
            evaluation_At (prover.hpp:108-114), evaluation_Bt.h (:116-123), evaluation_Ht over H_query[0 .. degree - 1)
-           (:125-131), evaluation_Lt over the auxiliary part of the assignment (:133-139) */
+           (:125-131), evaluation_Lt over the auxiliary part of the assignment (:133-139) -- each over this key's slice */
+        if (sh.A_n > num_variables + 1 - sh.A_lo || sh.H_n > degree - 1 - sh.H_lo || sh.L_n > num_variables - num_inputs - sh.L_lo)
+            throw std::runtime_error("prover: the key's query slices do not fit this assignment");
         const zkhip_bases *qb[4] = {pk.A_query.get(), pk.B_query_h.get(), pk.H_query.get(), pk.L_query.get()};
-        const std::size_t qo[4] = {0, 0, 0, 0}, qn[4] = {num_variables + 1, pk.B_count, degree - 1, num_variables - num_inputs};
-        const void *qs[4] = {cpa, pk.d_bs.get(), pk.d_h.get(), cpa + 32 * (num_inputs + 1)};
+        const std::size_t qo[4] = {0, 0, 0, 0}, qn[4] = {sh.A_n, pk.B_count, sh.H_n, sh.L_n};
+        const void *qs[4] = {cpa + 32 * sh.A_lo, pk.d_bs.get(), static_cast<const char *>(pk.d_h.get()) + 32 * sh.H_lo,
+                             cpa + 32 * (num_inputs + 1 + sh.L_lo)};
         void *qr[4] = {d_res, d_res + jl1, d_res + 2 * jl1, d_res + 3 * jl1};
         check(zkhip_msm_batch_dev(ctx.get(), 4, qb, qo, qn, qs, qr), "zkhip_msm_batch_dev", ctx.get());
-        /* host products that do not depend on the MSM results, computed while the GPU works (prover.hpp:142-155) */
+    }
+    /// the five partial sums of this rank, after the stream has drained
+    static std::vector<std::uint64_t> collect(const proving_key_type &pk) {
+        std::vector<std::uint64_t> res(partial_limbs());
+        pk.ctx.d2h(res.data(), pk.d_results.get(), res.size() * 8);
+        return res;
+    }
+    /// fold the ranks' partial sums and build the proof (prover.hpp:141-157)
+    static proof_type assemble(const proving_key_type &pk, const std::vector<std::uint64_t> &gathered, std::size_t world, const scalar_value_type &r,
+                               const scalar_value_type &s, const host_terms &t) {
+        const std::size_t jl1 = 3 * adapter::g1_coord_limbs, pl = partial_limbs();
+        auto evaluation_At = adapter::g1_value_type::zero(), evaluation_Bt_h = evaluation_At, evaluation_Ht = evaluation_At, evaluation_Lt = evaluation_At;
+        auto evaluation_Bt_g = adapter::g2_value_type::zero();
+        for (std::size_t k = 0; k < world; ++k) {
+            const std::uint64_t *res = gathered.data() + k * pl;
+            evaluation_At = evaluation_At + adapter::g1_from_jacobian(&res[0]);
+            evaluation_Bt_h = evaluation_Bt_h + adapter::g1_from_jacobian(&res[jl1]);
+            evaluation_Ht = evaluation_Ht + adapter::g1_from_jacobian(&res[2 * jl1]);
+            evaluation_Lt = evaluation_Lt + adapter::g1_from_jacobian(&res[3 * jl1]);
+            evaluation_Bt_g = evaluation_Bt_g + adapter::g2_from_jacobian(&res[4 * jl1]);
+        }
         const auto &k = pk.host;
-        const auto r_delta = r * k.delta_g1, s_delta = s * k.delta_g1, rs_delta = (r * s) * k.delta_g1;
-        const auto s_delta2 = s * k.delta_g2;
-        std::vector<std::uint64_t> res(4 * jl1 + jl2);
-        ctx.d2h(res.data(), d_res, res.size() * 8);    // the one synchronisation of the proof
-        auto evaluation_At = adapter::g1_from_jacobian(&res[0]);
-        auto evaluation_Bt_h = adapter::g1_from_jacobian(&res[jl1]);
-        auto evaluation_Ht = adapter::g1_from_jacobian(&res[2 * jl1]);
-        auto evaluation_Lt = adapter::g1_from_jacobian(&res[3 * jl1]);
-        auto evaluation_Bt_g = adapter::g2_from_jacobian(&res[4 * jl1]);
-
         /* A = alpha + sum_i(a_i*A_i(t)) + r*delta */
-        auto g1_A = k.alpha_g1 + evaluation_At + r_delta;
+        auto g1_A = k.alpha_g1 + evaluation_At + t.r_delta;
         /* B = beta + sum_i(a_i*B_i(t)) + s*delta */
-        auto g1_B = k.beta_g1 + evaluation_Bt_h + s_delta;
-        auto g2_B = k.beta_g2 + evaluation_Bt_g + s_delta2;
+        auto g1_B = k.beta_g1 + evaluation_Bt_h + t.s_delta;
+        auto g2_B = k.beta_g2 + evaluation_Bt_g + t.s_delta2;
         /* C = sum_i(a_i*((beta*A_i(t) + alpha*B_i(t) + C_i(t)) + H(t)*Z(t))/delta) + A*s + r*b - r*s*delta */
-        auto g1_C = evaluation_Ht + evaluation_Lt + s * g1_A + r * g1_B - rs_delta;
+        auto g1_C = evaluation_Ht + evaluation_Lt + s * g1_A + r * g1_B - t.rs_delta;
         return proof_type {g1_A, g2_B, g1_C};
     }
 
-private:
     static scalar_value_type random_scalar() {
         static std::random_device rd;
         static std::mt19937_64 gen(rd());

@@ -18,6 +18,8 @@ using namespace nil::crypto3::zk::hip;
 
 namespace {
 
+int g_world = 1;    // > 1: shim_groth16_prove emulates that many ranks one after the other on this GPU
+
 template <typename Curve>
 int groth16_prove_t(size_t M, size_t n, size_t N, const uint32_t *const rowptr[3], const uint32_t *const col[3], const uint64_t *const coeff[3],
                     const uint64_t *a_query, const uint8_t *a_inf, const uint64_t *b_g, const uint64_t *b_h, const uint8_t *b_inf,
@@ -62,6 +64,31 @@ int groth16_prove_t(size_t M, size_t n, size_t N, const uint32_t *const rowptr[3
 
     context ctx(0);
     domain_params<Curve> dom {A::scalar_from_limbs(omega), A::scalar_from_limbs(coset)};
+    if (g_world > 1) {
+        /* one proof sharded over g_world ranks: every rank holds a slice of each query and contributes its partial sums;
+           the all-gather is the concatenation below */
+        typedef r1cs_gg_ppzksnark_prover_hip<Curve> prover;
+        std::vector<uint64_t> gathered;
+        for (int rank = 0; rank < g_world; ++rank) {
+            r1cs_gg_ppzksnark_proving_key_hip<Curve> shard_key(ctx, pk, dom, rank, g_world);
+            auto part = prover::process_partial(shard_key, primary, auxiliary);
+            gathered.insert(gathered.end(), part.begin(), part.end());
+        }
+        r1cs_gg_ppzksnark_proving_key_hip<Curve> last(ctx, pk, dom, g_world - 1, g_world);
+        auto pv = prover::finish(last, gathered, A::scalar_from_limbs(r), A::scalar_from_limbs(s));
+        /* and the all-gather overload on rank 0, fed with the other ranks' partial sums */
+        r1cs_gg_ppzksnark_proving_key_hip<Curve> first(ctx, pk, dom, 0, g_world);
+        auto pv2 = prover::process(first, primary, auxiliary, A::scalar_from_limbs(r), A::scalar_from_limbs(s),
+                                   [&](const uint64_t *mine, size_t words, uint64_t *all) {
+                                       std::memcpy(all, gathered.data(), gathered.size() * 8);
+                                       std::memcpy(all, mine, words * 8);
+                                   });
+        if (!(pv2.g_A == pv.g_A) || !(pv2.g_B == pv.g_B) || !(pv2.g_C == pv.g_C)) return -102;
+        pv.g_A.to_affine(proof);
+        pv.g_B.to_affine(proof + L1);
+        pv.g_C.to_affine(proof + L1 + L2);
+        return 0;
+    }
     r1cs_gg_ppzksnark_proving_key_hip<Curve> dpk(ctx, pk, dom);
     auto proof_v = r1cs_gg_ppzksnark_prover_hip<Curve>::process(dpk, primary, auxiliary, A::scalar_from_limbs(r), A::scalar_from_limbs(s));
     proof_v.g_A.to_affine(proof);
@@ -236,6 +263,8 @@ int kc_multiexp_t(const uint64_t *g_pts, const uint64_t *h_pts, const uint64_t *
 }    // namespace
 
 extern "C" {
+
+void shim_set_world(int world) { g_world = world < 1 ? 1 : world; }
 
 int shim_groth16_prove(int curve, size_t M, size_t n, size_t N, const uint32_t *rpa, const uint32_t *cla, const uint64_t *cfa, const uint32_t *rpb,
                        const uint32_t *clb, const uint64_t *cfb, const uint32_t *rpc, const uint32_t *clc, const uint64_t *cfc,

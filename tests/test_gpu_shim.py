@@ -35,8 +35,19 @@ def P(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-@pytest.mark.parametrize("curve,M,n", [(1, 1024, 10), (0, 1024, 10), (0, 100, 10), (0, 1 << 15, 10)])
-def test_groth16_prover_shim(shim, curve, M, n):
+@pytest.mark.parametrize("curve,M,n,world", [(1, 1024, 10, 1), (0, 1024, 10, 1), (0, 100, 10, 1), (0, 1 << 15, 10, 1),
+                                             (0, 1024, 10, 2), (1, 1024, 10, 3), (0, 100, 10, 8)])
+def test_groth16_prover_shim(shim, curve, M, n, world):
+    """world > 1: the same proof sharded over `world` ranks (each holding a slice of every query; process_partial, the
+    all-gather emulated by concatenation, finish) must equal the single-GPU proof -- SURVEY 8e's point-range partition."""
+    shim.shim_set_world(world)
+    try:
+        _groth16_prover_shim(shim, curve, M, n)
+    finally:
+        shim.shim_set_world(1)
+
+
+def _groth16_prover_shim(shim, curve, M, n):
     C = CURVES[curve]
     g = cp.Groth16(curve, M, n, seed=1)
     w = limbs(C.root_of_unity(g.log_m), 4)
