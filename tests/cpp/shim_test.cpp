@@ -262,7 +262,56 @@ int kc_multiexp_t(const uint64_t *g_pts, const uint64_t *h_pts, const uint64_t *
 
 }    // namespace
 
+// ---- host-only logic of the shim (no GPU needed: the CPU test-suite calls these) -----------------------------------
+template <typename Curve>
+int host_small_poly_t(const uint64_t *xs, const uint64_t *ys, size_t k, const uint64_t *at, uint64_t *u_at, uint64_t *u_coeffs, uint64_t *v_coeffs) {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::scalar_value_type Fr;
+    typedef detail::small_poly<Fr> SP;
+    std::vector<Fr> x, y;
+    for (size_t i = 0; i < k; ++i) {
+        x.push_back(A::scalar_from_limbs(xs + 4 * i));
+        y.push_back(A::scalar_from_limbs(ys + 4 * i));
+    }
+    auto U = SP::lagrange(x, y);      // get_U
+    auto V = SP::vanishing(x);        // get_V
+    A::scalar_to_limbs(SP::evaluate(U, A::scalar_from_limbs(at)), u_at);
+    for (size_t i = 0; i < k; ++i) A::scalar_to_limbs(i < U.size() ? U[i] : Fr::zero(), u_coeffs + 4 * i);
+    for (size_t i = 0; i <= k; ++i) A::scalar_to_limbs(V[i], v_coeffs + 4 * i);
+    return 0;
+}
+
+template <typename Curve>
+int host_group_t(const uint64_t *p_aff, const uint64_t *q_aff, const uint64_t *scalar, uint64_t *out_sum, uint64_t *out_mul) {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::g1_value_type G1;
+    G1 P = G1::from_affine(p_aff), Q = G1::from_affine(q_aff);
+    (P + Q - Q + Q).to_affine(out_sum);                      // P + Q through the operators the prover's last lines use
+    (A::scalar_from_limbs(scalar) * P).to_affine(out_mul);   // r * delta_g1 etc. (prover.hpp:142-155)
+    return 0;
+}
+
 extern "C" {
+
+int shim_host_small_poly(int curve, const uint64_t *xs, const uint64_t *ys, size_t k, const uint64_t *at, uint64_t *u_at, uint64_t *u_coeffs,
+                         uint64_t *v_coeffs) {
+    if (curve == ZKHIP_BLS12_381) return host_small_poly_t<bls12_381>(xs, ys, k, at, u_at, u_coeffs, v_coeffs);
+    return host_small_poly_t<alt_bn128_254>(xs, ys, k, at, u_at, u_coeffs, v_coeffs);
+}
+
+int shim_host_group(int curve, const uint64_t *p_aff, const uint64_t *q_aff, const uint64_t *scalar, uint64_t *out_sum, uint64_t *out_mul) {
+    if (curve == ZKHIP_BLS12_381) return host_group_t<bls12_381>(p_aff, q_aff, scalar, out_sum, out_mul);
+    return host_group_t<alt_bn128_254>(p_aff, q_aff, scalar, out_sum, out_mul);
+}
+
+/* out[8 * rank ..]: A_lo, A_n, B_lo, B_n, H_lo, H_n, L_lo, L_n of every rank */
+void shim_host_query_shards(size_t world, size_t a, size_t b, size_t h, size_t l, uint64_t *out) {
+    for (size_t r = 0; r < world; ++r) {
+        query_shard q = query_shard::make(r, world, a, b, h, l);
+        const uint64_t v[8] = {q.A_lo, q.A_n, q.B_lo, q.B_n, q.H_lo, q.H_n, q.L_lo, q.L_n};
+        std::memcpy(out + 8 * r, v, sizeof(v));
+    }
+}
 
 void shim_set_world(int world) { g_world = world < 1 ? 1 : world; }
 

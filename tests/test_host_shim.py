@@ -1,0 +1,71 @@
+"""Host-side logic of the header-only C++ shim that needs no GPU: the small-polynomial helpers of the KZG opening
+proof (get_U / get_V: Lagrange interpolation, vanishing polynomial), the group operators the Groth16 prover's last
+lines use on the host (prover.hpp:142-155), and the query slices of the sharded prover -- against the big-integer
+oracle.  (tests/cpp/libshimtest.so links libzkhip.so but these entry points never touch the device.)"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+from util import CURVES, fr_arr, limbs, pt_from_limbs, pt_limbs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def shim():
+    so = os.path.join(ROOT, "tests", "cpp", "libshimtest.so")
+    src = os.path.join(ROOT, "tests", "cpp", "shim_test.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")])
+    return ctypes.CDLL(so)
+
+
+def P(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("k", [1, 2, 5])
+def test_lagrange_and_vanishing(shim, curve, k):
+    r = CURVES[curve].r
+    rng = po.SplitMix64(31 * k + curve)
+    xs = [rng.next_mod(r) for _ in range(k)]
+    ys = [rng.next_mod(r) for _ in range(k)]
+    at = rng.next_mod(r)
+    U = po.lagrange_interpolation(list(zip(xs, ys)), r)
+    V = po.vanishing_poly(xs, r)
+    u_at, u_c, v_c = np.zeros(4, dtype=np.uint64), np.zeros((k, 4), dtype=np.uint64), np.zeros((k + 1, 4), dtype=np.uint64)
+    assert shim.shim_host_small_poly(curve, P(fr_arr(xs)), P(fr_arr(ys)), ctypes.c_size_t(k), P(limbs(at, 4)), P(u_at), P(u_c), P(v_c)) == 0
+    assert po.from_limbs(u_at) == po.poly_eval(U, at, r)
+    assert [po.from_limbs(c) for c in u_c] == (U + [0] * k)[:k]
+    assert [po.from_limbs(c) for c in v_c] == V
+    for x, y in zip(xs, ys):  # the defining property, independent of the oracle's construction
+        assert po.poly_eval([po.from_limbs(c) for c in u_c], x, r) == y
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_host_group_operators(shim, curve):
+    C = CURVES[curve]
+    G = C.g1
+    Pt, Qt = G.mul(G.gen, 123456789), G.mul(G.gen, 987654321)
+    k = po.SplitMix64(5).next_mod(C.r)
+    L = len(pt_limbs(curve, 1, Pt))
+    o_sum, o_mul = np.zeros(L, dtype=np.uint64), np.zeros(L, dtype=np.uint64)
+    assert shim.shim_host_group(curve, P(pt_limbs(curve, 1, Pt)), P(pt_limbs(curve, 1, Qt)), P(limbs(k, 4)), P(o_sum), P(o_mul)) == 0
+    assert pt_from_limbs(curve, 1, o_sum) == G.add(Pt, Qt)
+    assert pt_from_limbs(curve, 1, o_mul) == G.mul(Pt, k)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_query_shards_partition(shim, world):
+    a, b, h, l = 1048579, 1000003, 2097151, 1048568  # the query sizes of a 2^20-constraint proof (B sparse)
+    out = np.zeros((world, 8), dtype=np.uint64)
+    shim.shim_host_query_shards(ctypes.c_size_t(world), ctypes.c_size_t(a), ctypes.c_size_t(b), ctypes.c_size_t(h), ctypes.c_size_t(l), P(out))
+    for col, total in ((0, a), (2, b), (4, h), (6, l)):
+        lo, n = out[:, col].astype(int), out[:, col + 1].astype(int)
+        assert lo[0] == 0 and (lo[1:] == lo[:-1] + n[:-1]).all() and lo[-1] + n[-1] == total  # contiguous, complete
+        assert n.max() - n.min() <= 1                                                          # balanced
