@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-groth16", action="store_true", help="skip the Groth16 constraints/s leg (N = 1 only)")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL all-gather + fold at N = 1 too (checks the N > 1 path on one GPU)")
+    ap.add_argument("--no-kzg", action="store_true", help="skip the KZG commit / opening-proof leg (BASELINE config 5's commitment layer, N = 1 only)")
     ap.add_argument("--no-ntt", action="store_true", help="skip the NTT leg (BASELINE config 3, N = 1 only)")
     args = ap.parse_args()
 
@@ -165,6 +166,8 @@ def main():
             line["groth16"] = groth16_leg(np)
         if g16_sharded is not None:
             line["groth16_sharded"] = g16_sharded
+        if world == 1 and not args.no_kzg:
+            line["kzg"] = kzg_leg(np, zk, ctx)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(np, bases)
         print(json.dumps(line), flush=True)
@@ -297,6 +300,58 @@ def groth16_sharded_leg(np, torch, dist, rank, world, local_rank, log_constraint
             "value": round(M / best * 1e3, 1), "unit": "constraints/s", "scaling": "strong", "ms_per_proof": [round(float(x), 2) for x in t[:-1]],
             "domain": m, "exchange": "one RCCL all-gather of 864 B per rank per proof",
             "key": "synthetic (random multiples of the generators), each rank holds 1/%d of every query" % world}
+
+
+def kzg_leg(np, zk, ctx, log_n=20, cols=50, steps=2):
+    """BASELINE config 5's commitment layer on one GPU: KZG commit of 50 witness columns of 2^20 rows (per column one
+    inverse NTT + one G1 MSM against the resident SRS alpha^i G, alpha = 7 as placeholder.cpp:175; kzg_v2.hpp:208-226)
+    and the device part of the batched opening proof of the same columns at two points (kzg_v2.hpp:236-305), the
+    coefficient forms staying resident in between."""
+    n = 1 << log_n
+    r = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    lim = lambda v: np.array([(v >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+    omega = lim(pow(7, (r - 1) >> log_n, r))
+    x, pw = 1, np.empty((n, 4), dtype=np.uint64)
+    for i in range(n):  # alpha^i as canonical limbs
+        pw[i, 0], pw[i, 1], pw[i, 2], pw[i, 3] = x & 0xFFFFFFFFFFFFFFFF, (x >> 64) & 0xFFFFFFFFFFFFFFFF, (x >> 128) & 0xFFFFFFFFFFFFFFFF, x >> 192
+        x = x * 7 % r
+    srs = ctx.bases_from_scalars(zk.BLS12_381, zk.G1, pw)
+    data = random_scalars(np, n * cols, 5).reshape(cols, n, 4)
+    d = ctx.malloc(data.nbytes)
+    d_out = ctx.malloc(cols * 144)
+    ptrs = [d + 32 * n * c for c in range(cols)]
+    commit = []
+    for _ in range(steps + 1):
+        ctx.h2d(d, data)
+        t0 = time.perf_counter()
+        ctx.ntt_dev(zk.BLS12_381, d, log_n, cols, omega, inverse=True)
+        ctx.msm_batch_dev([srs] * cols, ptrs, [d_out + 144 * c for c in range(cols)], ns=[n] * cols)
+        ctx.sync()
+        commit.append((time.perf_counter() - t0) * 1e3)
+    pts = random_scalars(np, 2, 9)
+    th = random_scalars(np, cols + 1, 10)
+    d_f, d_l, d_pi = ctx.malloc(n * 32), ctx.malloc(n * 32), ctx.malloc(2 * 144)
+    opening = []
+    for _ in range(steps + 1):
+        t0 = time.perf_counter()
+        ctx.poly_eval_dev(zk.BLS12_381, d, n, cols, pts)
+        ctx.poly_lincomb_dev(zk.BLS12_381, ptrs, [n] * cols, th[:cols], 1, d_f, n, False)
+        ctx.poly_div_linear_dev(zk.BLS12_381, d_f, n, pts[0], d_f)
+        ctx.poly_div_linear_dev(zk.BLS12_381, d_f + 32, n - 1, pts[1], d_f + 32)
+        ctx.msm_dev(srs, d_f + 64, d_pi, 0, n - 2)
+        ctx.poly_lincomb_dev(zk.BLS12_381, ptrs + [d_f + 64], [n] * cols + [n - 2], th, 1, d_l, n, False)
+        ctx.poly_div_linear_dev(zk.BLS12_381, d_l, n, pts[0], d_l)
+        ctx.msm_dev(srs, d_l + 32, d_pi + 144, 0, n - 1)
+        ctx.sync()
+        opening.append((time.perf_counter() - t0) * 1e3)
+    for p in (d, d_out, d_f, d_l, d_pi):
+        ctx.free(p)
+    srs.free()
+    best = min(commit[1:])
+    return {"metric": "KZG commit columns/sec, BLS12-381, %d columns x 2^%d rows, 1 GPU (columns and SRS resident)" % (cols, log_n),
+            "value": round(cols / best * 1e3, 2), "unit": "columns/s", "ms_per_commit": [round(t, 2) for t in commit],
+            "opening_proof_ms": [round(t, 2) for t in opening],
+            "opening_proof": "device part of kzg_v2 proof_eval for the same %d columns at 2 points, coefficient forms resident" % cols}
 
 
 def cpu_baseline(np, bases):
