@@ -8,7 +8,9 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf /tmp/pmc_run && mkdir -p /tmp/pmc_run
 i=0
 # FETCH_SIZE (3 TCC slots) and WRITE_SIZE (2) do not fit one pass (MI355X_MICROARCH.md, counter-slot table)
-if [ -n "${PMC_ONLY_TRAFFIC:-}" ]; then
+if [ -n "${PMC_GROUPS:-}" ]; then
+  IFS=';' read -ra groups <<< "$PMC_GROUPS"   # e.g. PMC_GROUPS="GRBM_GUI_ACTIVE;FETCH_SIZE"
+elif [ -n "${PMC_ONLY_TRAFFIC:-}" ]; then
   groups=("FETCH_SIZE" "WRITE_SIZE")
 else
   groups=("SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
