@@ -22,13 +22,18 @@ CI ref NilFoundation/crypto3@1bd56b12f410f3f1a4891076705a9261a6b1efaa,
   * r1cs_gg_ppzksnark_prover::process       -> groth16_prove (prover.hpp:73-158)
   * ipp2 prove_commitment_{v,w} (the KAT carrier) -> ipp2_prove_commitment_{v,w}
       zk/snark/systems/ppzksnark/r1cs_gg_ppzksnark/ipp2/prover.hpp:99-290, ipp2/srs.hpp:44-56
+  * kzg_commitment_scheme_v2::proof_eval    -> kzg_v2_proof_eval (+ get_U / get_V / set_difference_polynom:
+      lagrange_interpolation, vanishing_poly)
+      zk/commitments/polynomial/kzg_v2.hpp:121-148, 236-305; zk/commitments/batched_commitment.hpp:79-111, 168-183
 
 Parity pin: the bellperson-derived known-answer vectors of
 test/systems/ppzksnark/r1cs_gg_ppzksnark/r1cs_gg_ppzksnark_aggregation_conformity.cpp
 (:578-862 Fr chains, :864-930 G1/G2 MSM) and test/commitment/kzg.cpp:75-103 are reproduced by
-tests/test_oracle_kat.py from tests/golden/ref_kat.json.  NTT outputs and full Groth16 proofs
-are NOT pinned by any reference test ("parity unpinned" there): the NTT is pinned to the
-mathematical DFT definition, Groth16 proofs to the trapdoor ("in the exponent") identities.
+tests/test_oracle_kat.py from tests/golden/ref_kat.json.  NTT outputs, full Groth16 proofs and KZG
+opening proofs are NOT pinned by any reference test ("parity unpinned" there): the NTT is pinned to
+the mathematical DFT definition, Groth16 proofs to the trapdoor ("in the exponent") identities, the
+opening proofs to the reference's own BOOST_ASSERTs (f divisible by V, L(theta_2) = 0), to the
+identities of kzg_basic_test and to the verifier's equation evaluated with alpha in the clear.
 """
 from __future__ import annotations
 
