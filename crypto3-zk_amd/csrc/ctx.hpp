@@ -69,7 +69,7 @@ struct zkhip_ctx {
     int opt_ntt_radix_log = 8;
     int opt_ntt_tile_log = 3;
     int opt_msm_precompute = 1;       // build window tables at upload for bases of >= opt_msm_precompute_min points
-    int opt_msm_precompute_min = 1024;
+    int opt_msm_precompute_min = 32;  // without tables the windows are combined by a serial Horner pass (~255 doublings on one lane: 3.8 ms)
     ZkProfile prof;
     std::vector<NttTables *> ntt_tables;
 

@@ -10,6 +10,7 @@
 //     coefficients_for_H = H_tmp | 0                                  (m + 1 entries)
 // z = (1, primary, auxiliary) and all vectors stay in HBM; the result is consumed in place by zkhip_msm_dev.
 #include <algorithm>
+#include <cstring>
 
 #include "ctx.hpp"
 #include "fu.hpp"
@@ -27,6 +28,10 @@ struct zkhip_r1cs {
     uint32_t n_long[3] = {0, 0, 0};
     size_t nnz[3] = {0, 0, 0};
     size_t long_terms[3] = {0, 0, 0};  // total terms in long rows
+    // 1 / Z on the coset (groth16_h_setup: a field inversion on one lane, 0.3 ms) cached per coset generator
+    mutable uint32_t *h_consts = nullptr;
+    mutable uint64_t h_consts_coset[4] = {0, 0, 0, 0};
+    mutable bool h_consts_valid = false;
 };
 
 static constexpr uint32_t LONG_ROW = 64;
@@ -232,11 +237,16 @@ static int witness_h_t(zkhip_ctx *ctx, const zkhip_r1cs *r, const uint32_t *d_z,
     // coefficients, then evaluations on the coset g<omega>
     ZK_TRY(zk_ntt_run(ctx, r->curve, d_abc, r->log_m, 3, omega, 1, nullptr));
     ZK_TRY(zk_ntt_run(ctx, r->curve, d_abc, r->log_m, 3, omega, 0, coset));
-    // constants live at the tail of the caller-provided scratch (after the three vectors)
-    uint32_t *consts = d_abc + (size_t)3 * m * U::NL;
-    uint32_t *d_g = consts + 2 * U::SL;
-    ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_g, coset, 32, hipMemcpyHostToDevice, ctx->stream));
-    ZK_LAUNCH(ctx, "groth16_h_setup", groth16_h_setup<U>, dim3(1), dim3(64), 0, d_g, (uint32_t)r->log_m, consts);
+    // 1 / Z(coset) constants: computed once per (constraint system, coset generator), kept with the constraint system
+    if (!r->h_consts) ZK_HIP_CHECK(ctx, hipMalloc((void **)&r->h_consts, (2 * U::SL + 8) * 4));
+    uint32_t *consts = r->h_consts;
+    if (!r->h_consts_valid || memcmp(r->h_consts_coset, coset, 32) != 0) {
+        uint32_t *d_g = consts + 2 * U::SL;
+        ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_g, coset, 32, hipMemcpyHostToDevice, ctx->stream));
+        ZK_LAUNCH(ctx, "groth16_h_setup", groth16_h_setup<U>, dim3(1), dim3(64), 0, d_g, (uint32_t)r->log_m, consts);
+        memcpy(r->h_consts_coset, coset, 32);
+        r->h_consts_valid = true;
+    }
     ZK_LAUNCH(ctx, "groth16_h_pointwise", groth16_h_pointwise<U>, dim3((m + 255) / 256), dim3(256), 0, d_abc, m, consts, d_h);
     ZK_TRY(zk_ntt_run(ctx, r->curve, d_h, r->log_m, 1, omega, 1, coset));
     ZK_LAUNCH(ctx, "fr_zero_one", fr_zero_one<U>, dim3(1), dim3(64), 0, d_h + (size_t)m * U::NL);
@@ -283,6 +293,7 @@ void zkhip_r1cs_free(zkhip_ctx *ctx, zkhip_r1cs *r) {
         (void)hipFree(r->coeff[k]);
         (void)hipFree(r->long_rows[k]);
     }
+    (void)hipFree(r->h_consts);
     delete r;
 }
 

@@ -90,7 +90,19 @@ def test_msm_edge_cases(ctx, curve, group):
     sc[11] = C.r - 77            # cancels with the duplicate base
     exp = po.msm_naive(G, P, sc)
     assert gpu_affine(ctx, bases, fr_arr(sc)) == exp
+    # every window size, with window tables (rebuilt for each c) ...
     for c in (2, 3, 5, 7, 12, 15, 16):  # 3, 5, 15 divide 255: the top window is full
+        ctx.set_option("msm_window_bits", c)
+        tb = ctx.upload_bases(curve, group, arr, infs)
+        assert gpu_affine(ctx, tb, fr_arr(sc)) == exp, c
+        tb.free()
+    # ... and without them (the per-window sums are combined by the Horner pass of msm_final)
+    ctx.set_option("msm_precompute", 0)
+    ctx.set_option("msm_window_bits", 0)
+    bases.free()
+    bases = ctx.upload_bases(curve, group, arr, infs)
+    ctx.set_option("msm_precompute", 1)
+    for c in (0, 2, 3, 5, 7, 12, 15, 16):
         ctx.set_option("msm_window_bits", c)
         assert gpu_affine(ctx, bases, fr_arr(sc)) == exp, c
     # scalars that are not canonical are taken mod r (the reference's field type cannot hold them)
@@ -217,7 +229,9 @@ def test_msm_batch(ctx, zk):
     ks = cp.random_fr(0, 31, n)
     b1 = ctx.bases_from_scalars(0, 1, ks)
     b2 = ctx.bases_from_scalars(0, 1, cp.random_fr(0, 32, n))
+    ctx.set_option("msm_precompute", 0)
     small = ctx.bases_from_scalars(0, 1, cp.random_fr(0, 33, 40))  # no window tables: forces the fallback when mixed in
+    ctx.set_option("msm_precompute", 1)
     scs = [cp.random_fr(0, 40 + i, n) for i in range(3)]
     scs[2][::3] = 0
     d_s = [ctx.malloc(s.nbytes) for s in scs]
