@@ -203,6 +203,39 @@ def test_msm_full_size_bls12_381_g1(ctx):
     bases.free()
 
 
+@pytest.mark.parametrize("curve,group,log_n", [(1, 1, 20), (0, 2, 18), (0, 1, 22)])
+def test_msm_large_other_configs(ctx, zk, curve, group, log_n):
+    """full-size MSMs outside the headline configuration (BN254 G1 2^20, BLS12-381 G2 2^18 on the lane-pair kernels,
+    BLS12-381 G1 2^22): bit-exact against the oracle where it finishes in seconds, and the size-independent property
+    MSM(s1) + MSM(s2) == MSM(s1 + s2 mod r) computed entirely on the device."""
+    n = 1 << log_n
+    b = ctx.bases_from_scalars(curve, group, cp.random_fr(curve, 11, n))
+    s1, s2 = cp.random_fr(curve, 12, n), cp.random_fr(curve, 13, n)
+    jac = 3 * zk.coord_limbs(curve, group) * 8
+    d1, d2, d3, d_out = ctx.malloc(n * 32), ctx.malloc(n * 32), ctx.malloc(n * 32), ctx.malloc(3 * jac)
+    ctx.h2d(d1, s1)
+    ctx.h2d(d2, s2)
+    ctx.fr_vec_op_dev(curve, 0, d1, d2, d3, n)
+    for i, d in enumerate((d1, d2, d3)):
+        ctx.msm_dev(b, d, d_out + i * jac)
+    res = np.zeros((3, jac // 8), dtype=np.uint64)
+    ctx.d2h(res, d_out)
+    ctx.jacobian_sum_dev(curve, group, d_out, 2, d_out)
+    tot = np.zeros(jac // 8, dtype=np.uint64)
+    ctx.d2h(tot, d_out)
+    a_sum, i_sum = ctx.jacobian_to_affine(curve, group, tot)
+    a_3, i_3 = ctx.jacobian_to_affine(curve, group, res[2])
+    assert i_sum == i_3 and (a_sum == a_3).all()
+    if log_n <= 20:
+        pts, _ = b.download()
+        exp, einf = cp.msm(curve, group, pts, s1, chunks=cp.num_threads())
+        a_1, i_1 = ctx.jacobian_to_affine(curve, group, res[0])
+        assert i_1 == einf and (a_1 == exp).all()
+    for d in (d1, d2, d3, d_out):
+        ctx.free(d)
+    b.free()
+
+
 @pytest.mark.parametrize("curve,M,n", [(1, 1024, 10), (0, 1024, 10), (0, 50, 3), (0, 4085, 10)])
 def test_groth16_witness_map(ctx, curve, M, n):
     """r1cs_to_qap::witness_map on the device (sparse mat-vec, 7 NTTs, pointwise) against the oracle; the

@@ -89,6 +89,24 @@ def test_ntt_full_size_2_22_batch_8(ctx):
     assert (ctx.ntt(0, gotc, log_m, w, inverse=True, coset=g) == a[:2]).all()
 
 
+@pytest.mark.parametrize("curve,log_m", [(0, 24), (1, 23), (0, 17)])
+def test_ntt_large_single_polynomial(ctx, curve, log_m):
+    """sizes beyond the BASELINE configs (four-pass structure at 2^24, BN254's 2^28-adic field): bit-exact against the
+    oracle, out[i] = f(omega^i) by Horner at sampled points, round trip, coset round trip"""
+    C = CURVES[curve]
+    m = 1 << log_m
+    w_int = C.root_of_unity(log_m)
+    w = limbs(w_int, 4)
+    a = cp.random_fr(curve, 7, m).reshape(1, m, 4)
+    got = ctx.ntt(curve, a, log_m, w)
+    assert (got == cp.ntt(curve, a, log_m, w)).all()
+    for i in (0, 1, 54321, m - 1, m // 2 + 3):
+        assert (cp.fr_horner(curve, a[0], limbs(pow(w_int, i, C.r), 4)) == got[0, i]).all()
+    assert (ctx.ntt(curve, got, log_m, w, inverse=True) == a).all()
+    g = limbs(C.fr_generator, 4)
+    assert (ctx.ntt(curve, ctx.ntt(curve, a, log_m, w, coset=g), log_m, w, inverse=True, coset=g) == a).all()
+
+
 @pytest.mark.parametrize("curve,log_n,expand", [(0, 8, 2), (1, 6, 1), (0, 12, 3)])
 def test_lpc_resize_and_fold(ctx, zk, curve, log_n, expand):
     """polynomial_dfs::resize as precommit<FRI> uses it (basic_fri.hpp:452-455) and the DFS fold_polynomial
