@@ -26,6 +26,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """The shared objects are build artefacts (git-ignored): a fresh checkout compiles them once, as
+    __graft_entry__.build() does (hipcc cross-compiles gfx950 without a GPU; a few minutes)."""
+    import subprocess
+
+    need = {os.path.join(ROOT, "crypto3-zk_amd"): ["libzkhip.so", "libzkhip_hosttest.so"],
+            os.path.join(ROOT, "oracle"): ["liboracle.so"],
+            os.path.join(ROOT, "tests", "cpp"): ["libshimtest.so"]}
+    for d, files in need.items():
+        if not all(os.path.exists(os.path.join(d, f)) for f in files):
+            subprocess.check_call(["make", "-C", d, "-j4"] + (["all"] if d.endswith("crypto3-zk_amd") else []))
+
+
 @pytest.fixture(scope="session")
 def zk():
     return load_pkg()
