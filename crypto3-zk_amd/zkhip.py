@@ -17,7 +17,7 @@ EXPORTS = [
     "zkhip_set_option", "zkhip_malloc", "zkhip_free", "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_memcpy_h2d_async", "zkhip_memcpy_d2d_async", "zkhip_host_alloc", "zkhip_host_free",
     "zkhip_bases_upload", "zkhip_bases_from_scalars", "zkhip_bases_download", "zkhip_bases_size",
     "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_batch_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
-    "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_domain_size", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev", "zkhip_fr_gather_dev", "zkhip_poly_resize_dev", "zkhip_fri_fold_dev", "zkhip_fri_leaves_dev",
+    "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_domain_size", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev", "zkhip_fr_gather_dev", "zkhip_poly_resize_dev", "zkhip_fri_fold_dev", "zkhip_fri_leaves_dev", "zkhip_ec_ntt_dev",
     "zkhip_fr_vec_op_dev", "zkhip_poly_eval_dev", "zkhip_poly_div_linear_dev", "zkhip_poly_lincomb_dev",
     "zkhip_profile_enable", "zkhip_profile_reset", "zkhip_profile_get", "zkhip_profile_dump",
 ]
@@ -250,6 +250,12 @@ class Context:
         return out
 
     # ---- profiling
+    def ec_ntt_dev(self, curve: int, group: int, d_jacobian: int, log_m: int, omega, inverse=False):
+        """DFT over group elements, in place on 2^log_m canonical Jacobian points (powers-of-tau Lagrange basis)"""
+        w = _u64(omega).reshape(4)
+        self._check(self.lib.zkhip_ec_ntt_dev(self.h, curve, group, ctypes.c_void_p(d_jacobian), ctypes.c_size_t(log_m), _p(w), 1 if inverse else 0),
+                    "ec_ntt_dev")
+
     # ---- coefficient-form polynomial arithmetic (KZG opening proofs) ----
     def fr_vec_op_dev(self, curve: int, op: int, d_a: int, d_b: int, d_out: int, count: int):
         self._check(self.lib.zkhip_fr_vec_op_dev(self.h, curve, op, ctypes.c_void_p(d_a), ctypes.c_void_p(d_b), ctypes.c_void_p(d_out),

@@ -159,6 +159,14 @@ int zkhip_fri_fold_dev(zkhip_ctx *ctx, int curve, const void *d_f, size_t log_si
  * the caller's. */
 int zkhip_fri_leaves_dev(zkhip_ctx *ctx, const void *d_polys, size_t log_domain, size_t batch, size_t fri_step, void *d_out);
 
+/* ---- DFT over group elements -------------------------------------------------------------------------------
+ * evaluation_domain<Fr, G>::evaluate_all_lagrange_polynomials(powers_begin, powers_end) as the powers-of-tau result uses
+ * it (commitments/detail/polynomial/powers_of_tau/result.hpp:81-94): with P_i = tau^i G the INVERSE transform gives
+ * L_j(tau) G for every Lagrange polynomial of the 2^log_m-point domain.  d_jacobian: 2^log_m canonical Jacobian points
+ * (3 coordinates each, Z = 0 for infinity -- the form zkhip_msm_dev writes), transformed in place:
+ * out[j] = sum_i omega^(i j) P_i, or with inverse != 0: (1/m) sum_i omega^(-i j) P_i. */
+int zkhip_ec_ntt_dev(zkhip_ctx *ctx, int curve, int group, void *d_jacobian, size_t log_m, const uint64_t *omega, int inverse);
+
 /* ---- coefficient-form polynomial arithmetic (KZG opening proofs, polynomial_dfs pointwise operators) -------
  * All vectors are canonical Fr elements (4 limbs) resident on the device.
  *

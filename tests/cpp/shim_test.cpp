@@ -12,6 +12,7 @@
 #include <nil/crypto3/zk/hip/fri.hpp>
 #include <nil/crypto3/zk/hip/knowledge_commitment_multiexp.hpp>
 #include <nil/crypto3/zk/hip/kzg_v2.hpp>
+#include <nil/crypto3/zk/hip/powers_of_tau.hpp>
 #include <nil/crypto3/zk/hip/r1cs_gg_ppzksnark.hpp>
 
 using namespace nil::crypto3::zk::hip;
@@ -262,6 +263,19 @@ int kc_multiexp_t(const uint64_t *g_pts, const uint64_t *h_pts, const uint64_t *
 
 }    // namespace
 
+template <typename Curve>
+int lagrange_g1_t(const uint64_t *powers, size_t m, const uint64_t *omega, uint64_t *out, uint8_t *out_inf) {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::g1_value_type G1;
+    const size_t L1 = 2 * A::g1_coord_limbs;
+    context ctx(0);
+    std::vector<G1> p;
+    for (size_t i = 0; i < m; ++i) p.push_back(G1::from_affine(powers + i * L1));
+    auto res = evaluate_all_lagrange_polynomials<Curve, ZKHIP_G1>(ctx, p.begin(), p.end(), A::scalar_from_limbs(omega));
+    for (size_t i = 0; i < m; ++i) out_inf[i] = res[i].to_affine(out + i * L1) ? 0 : 1;
+    return 0;
+}
+
 // ---- host-only logic of the shim (no GPU needed: the CPU test-suite calls these) -----------------------------------
 template <typename Curve>
 int host_small_poly_t(const uint64_t *xs, const uint64_t *ys, size_t k, const uint64_t *at, uint64_t *u_at, uint64_t *u_coeffs, uint64_t *v_coeffs) {
@@ -381,6 +395,10 @@ int shim_dfs_ops(int curve, const uint64_t *a_evals, const uint64_t *b_evals, si
 int shim_kc_multiexp(int curve, const uint64_t *g_pts, const uint64_t *h_pts, const uint64_t *indices, size_t count, size_t domain_size, size_t min_idx,
                      size_t max_idx, const uint64_t *scalars, size_t nscalars, uint64_t *out_g, uint64_t *out_h, uint8_t *out_inf) {
     CURVE_CALL("shim_kc_multiexp", kc_multiexp_t, g_pts, h_pts, indices, count, domain_size, min_idx, max_idx, scalars, nscalars, out_g, out_h, out_inf)
+}
+
+int shim_lagrange_g1(int curve, const uint64_t *powers, size_t m, const uint64_t *omega, uint64_t *out, uint8_t *out_inf) {
+    CURVE_CALL("shim_lagrange_g1", lagrange_g1_t, powers, m, omega, out, out_inf)
 }
 
 int shim_kzg_basic_proof(int curve, const uint64_t *srs, size_t n_srs, const uint64_t *coeffs, size_t n, const uint64_t *z, uint64_t *out) {

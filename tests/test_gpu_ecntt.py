@@ -1,0 +1,63 @@
+"""DFT over group elements (zkhip_ec_ntt_dev): evaluate_all_lagrange_polynomials on the powers [tau^i] G as the
+powers-of-tau result computes it (commitments/detail/polynomial/powers_of_tau/result.hpp:81-94).  The expected values
+come from the scalar side: the inverse transform of tau^i G is L_j(tau) G (closed form, pyoracle.lagrange_at), the
+forward transform is (sum_i omega^(ij) tau^i) G."""
+import numpy as np
+import pytest
+
+import cport as cp
+import pyoracle as po
+from util import CURVES, FQ_LIMBS, fr_arr, jac_to_affine_py, limbs, pt_from_limbs
+
+pytestmark = pytest.mark.gpu
+
+
+def _jac_of(curve, group, scalars):
+    """canonical Jacobian (x, y, 1) of scalar * generator; the zero scalar gives Z = 0"""
+    pts, inf = cp.batch_mul(curve, group, fr_arr(scalars))
+    L = FQ_LIMBS[curve] * group
+    out = np.zeros((len(scalars), 3 * L), dtype=np.uint64)
+    out[:, : 2 * L] = pts
+    out[:, 2 * L] = 1
+    out[inf != 0] = 0
+    return out
+
+
+@pytest.mark.parametrize("curve,group,log_m", [(0, 1, 0), (0, 1, 1), (0, 1, 4), (1, 1, 6), (0, 2, 3), (1, 2, 2), (0, 1, 8)])
+def test_ec_ntt_lagrange_basis(ctx, curve, group, log_m):
+    C = CURVES[curve]
+    r, m = C.r, 1 << log_m
+    w = C.root_of_unity(log_m)
+    tau = po.SplitMix64(100 + log_m).next_mod(r)
+    powers = [pow(tau, i, r) for i in range(m)]
+    if m >= 4:
+        powers[2] = 0  # a point at infinity among the inputs
+    jac = _jac_of(curve, group, powers)
+    d = ctx.malloc(jac.nbytes)
+    out = np.zeros_like(jac)
+
+    def run(inverse):
+        ctx.h2d(d, jac)
+        ctx.ec_ntt_dev(curve, group, d, log_m, limbs(w, 4), inverse=inverse)
+        ctx.d2h(out, d)
+        return [jac_to_affine_py(curve, group, out[j]) for j in range(m)]
+
+    def expect(scalars):
+        pts, inf = cp.batch_mul(curve, group, fr_arr(scalars))
+        return [pt_from_limbs(curve, group, pts[j], inf[j]) for j in range(m)]
+
+    fwd = [sum(pow(w, i * j, r) * powers[i] for i in range(m)) % r for j in range(m)]
+    assert run(False) == expect(fwd)
+    minv, winv = pow(m, -1, r), pow(w, -1, r)
+    inv = [minv * sum(pow(winv, i * j, r) * powers[i] for i in range(m)) % r for j in range(m)]
+    assert run(True) == expect(inv)
+    if m >= 4:
+        powers[2] = pow(tau, 2, r)
+        jac = _jac_of(curve, group, powers)
+    # with the genuine powers the inverse transform is the Lagrange basis at tau
+    assert run(True) == expect(po.lagrange_at(m, w, tau, r))
+    # round trip on the device
+    ctx.ec_ntt_dev(curve, group, d, log_m, limbs(w, 4), inverse=False)
+    ctx.d2h(out, d)
+    assert [jac_to_affine_py(curve, group, out[j]) for j in range(m)] == expect(powers)
+    ctx.free(d)

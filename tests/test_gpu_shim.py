@@ -297,3 +297,17 @@ def test_kc_multiexp_shim(shim, curve):
                                    P(og), P(oh), P(oinf))
         assert rc == 0
         assert pt_from_limbs(curve, 2, og, oinf[0]) == eg and pt_from_limbs(curve, 1, oh, oinf[1]) == eh, (min_idx, max_idx)
+
+
+@pytest.mark.parametrize("curve,log_m", [(0, 5), (1, 4)])
+def test_powers_of_tau_lagrange_shim(shim, curve, log_m):
+    """evaluate_all_lagrange_polynomials over group elements (powers_of_tau/result.hpp:81-94): [tau^i] G -> [L_j(tau)] G"""
+    C = CURVES[curve]
+    r, m = C.r, 1 << log_m
+    w, tau = C.root_of_unity(log_m), po.SplitMix64(55).next_mod(C.r)
+    powers, _ = cp.batch_mul(curve, 1, fr_arr([pow(tau, i, r) for i in range(m)]))
+    out = np.zeros_like(powers)
+    oinf = np.zeros(m, dtype=np.uint8)
+    assert shim.shim_lagrange_g1(curve, P(powers), ctypes.c_size_t(m), P(limbs(w, 4)), P(out), P(oinf)) == 0
+    exp, einf = cp.batch_mul(curve, 1, fr_arr(po.lagrange_at(m, w, tau, r)))
+    assert (oinf == einf).all() and (out == exp).all()
