@@ -7,6 +7,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -49,6 +50,13 @@ struct ZkProfile {
 
 struct NttTables;  // ntt.hip
 
+// a captured launch sequence (HIP graph) of one MSM / MSM batch, replayed when the same call comes again
+struct ZkGraph {
+    hipGraphExec_t exec = nullptr;
+    uint64_t ws_epoch = 0;   // the workspace allocation the graph's addresses refer to
+    void *d_ptrs = nullptr;  // batch: device array of the output pointers (kept with the graph)
+};
+
 struct zkhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -60,6 +68,13 @@ struct zkhip_ctx {
     std::unordered_set<const void *> lds_configured;  // kernels whose dynamic-LDS limit was raised on this context's device
     std::vector<uint64_t> lincomb_stage, lincomb_coeffs;  // host staging of zkhip_poly_lincomb_dev's tables
     std::vector<uint32_t *> batch_ptrs;            // host copy of a batch's output pointers (alive until the copy ran)
+    // HIP graphs of repeated MSM calls (msm.hip: zk_graph_run)
+    std::unordered_map<std::string, ZkGraph> graphs;
+    std::unordered_map<std::string, int> graph_seen;
+    uint64_t ws_epoch = 0;
+    bool capturing = false;
+    void *batch_dptrs_override = nullptr;  // during a batch capture: the graph-owned output-pointer array
+    int opt_msm_graphs = 0;  // off: replaying the captured launch sequence measured no faster than issuing it
     // pinned staging for small results
     void *pinned = nullptr;
     size_t pinned_cap = 0;
@@ -75,6 +90,11 @@ struct zkhip_ctx {
 
     int ws_reserve(size_t bytes) {
         if (bytes <= ws_cap) return 0;
+        if (capturing) {  // growing means a synchronisation and new addresses: not inside a stream capture
+            last_error = "workspace growth during graph capture";
+            return ZKHIP_ERR_HIP;
+        }
+        ++ws_epoch;
         if (ws) {
             hipError_t e = hipStreamSynchronize(stream);
             if (e != hipSuccess) {
@@ -164,6 +184,7 @@ int zk_bases_to_mont(zkhip_ctx *ctx, zkhip_bases *b, const uint32_t *d_canonical
 size_t zk_point_words(int curve, int group);
 int zk_msm_auto_window(size_t n);
 int zk_scalar_bits(int curve);  // bit length of the scalar-field modulus
+void zk_graphs_clear(zkhip_ctx *ctx);  // destroy the cached MSM graphs
 int zk_bases_precompute(zkhip_ctx *ctx, zkhip_bases *b);  // u32 words per affine point in device buffers
 int zk_bases_from_mont(zkhip_ctx *ctx, const zkhip_bases *b, size_t offset, size_t n, uint32_t *d_out, uint8_t *d_inf);
 int zk_bases_mul(zkhip_ctx *ctx, zkhip_bases *b, const uint32_t *d_base_canonical /* nullable: generator */, const uint32_t *d_scalars);

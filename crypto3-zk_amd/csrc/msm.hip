@@ -32,6 +32,7 @@
 // Point order inside a bucket depends on LDS-atomic arrival order; the group law is exact, so the sum
 // (compared in affine) does not.
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #define ZK_NOINLINE_MUL2 1  // G2 (Fq2) products stay out of line; G1 products are inlined (out of line measured 27 % slower)
@@ -952,8 +953,12 @@ static int msm_batch_t(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *b
     }
     ctx->ws_floor = 0;
     if (rc) return rc;
-    ctx->batch_ptrs.assign(d_outs, d_outs + count);
-    ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_ptrs, ctx->batch_ptrs.data(), count * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->batch_dptrs_override) {  // graph capture: the output pointers already sit in a device array owned by the graph
+        d_ptrs = static_cast<uint32_t **>(ctx->batch_dptrs_override);
+    } else {
+        ctx->batch_ptrs.assign(d_outs, d_outs + count);
+        ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_ptrs, ctx->batch_ptrs.data(), count * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+    }
     ZK_TRY(msm_tail_attr<F>(ctx));
     ZK_LAUNCH(ctx, "msm_bucket_red", (msm_bucket_red<FL, LPB>), dim3((unsigned)count * nblk_tail), dim3(MSM_TAIL_THREADS), (size_t)tail_slots * 4 * NL * 4, slots,
               B, L, nseg, nblk_tail, segsum);
@@ -962,8 +967,124 @@ static int msm_batch_t(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *b
     return 0;
 }
 
+static int zk_msm_run_direct(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac);
+
+// ---- HIP graphs of repeated calls ------------------------------------------------------------------------------
+// An MSM is ~30 dependent launches (a batch of four: ~100); a prover repeats the same call -- same bases, same
+// resident buffers -- for every proof.  The third identical call is captured into a HIP graph (the first two ran
+// directly, so every lazy allocation and attribute is settled) and later ones replay it: one graph launch instead
+// of the launch sequence.  A graph bakes the workspace addresses, so it is dropped when the workspace is
+// reallocated; profiling (per-kernel events) bypasses it.  MEASURED: no gain on ROCm 7.2 / MI355X -- 0.663 ms per
+// 2^10-point MSM replayed against 0.660 ms issued directly, the same at every size up to 2^18 (the gaps between
+// dependent kernels are on the device side, not in the host's launch path) -- so the option "msm_graphs" is OFF by
+// default; the path stays for runtimes where graph launches are cheaper, and is covered by the GPU tests.
+void zk_graphs_clear(zkhip_ctx *ctx) {
+    for (auto &g : ctx->graphs) {
+        if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
+        if (g.second.d_ptrs) (void)hipFree(g.second.d_ptrs);
+    }
+    ctx->graphs.clear();
+    ctx->graph_seen.clear();
+}
+
+template <class T>
+static void key_add(std::string &k, const T &v) {
+    k.append(reinterpret_cast<const char *>(&v), sizeof(T));
+}
+static void key_add_bases(std::string &k, const zkhip_bases *b) {
+    key_add(k, b);
+    key_add(k, b->d);
+    key_add(k, b->n);
+    key_add(k, b->c_tab);
+    key_add(k, b->ntab);
+    key_add(k, b->curve);
+    key_add(k, b->group);
+}
+static std::string key_begin(zkhip_ctx *ctx, char kind) {
+    std::string k(1, kind);
+    key_add(k, ctx->stream);
+    key_add(k, ctx->opt_msm_window_bits);
+    key_add(k, ctx->opt_msm_segment_log);
+    return k;
+}
+
+template <class Enqueue>
+static int zk_graph_run(zkhip_ctx *ctx, const std::string &key, Enqueue &&enqueue, size_t nptrs = 0, uint32_t *const *ptrs = nullptr) {
+    if (!ctx->opt_msm_graphs || ctx->prof.on || ctx->capturing) return enqueue();
+    auto it = ctx->graphs.find(key);
+    if (it != ctx->graphs.end()) {
+        if (it->second.ws_epoch == ctx->ws_epoch) {
+            ZK_HIP_CHECK(ctx, hipGraphLaunch(it->second.exec, ctx->stream));
+            return 0;
+        }
+        (void)hipGraphExecDestroy(it->second.exec);  // the workspace moved: recapture below
+        if (it->second.d_ptrs) (void)hipFree(it->second.d_ptrs);
+        ctx->graphs.erase(it);
+    }
+    int &seen = ctx->graph_seen[key];
+    if (seen < 0 || ++seen < 3) return enqueue();
+    if (ctx->graphs.size() >= 64) zk_graphs_clear(ctx);
+    ZkGraph g;
+    if (nptrs) {
+        if (hipMalloc(&g.d_ptrs, nptrs * sizeof(void *)) != hipSuccess) return enqueue();
+        if (hipMemcpy(g.d_ptrs, ptrs, nptrs * sizeof(void *), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(g.d_ptrs);
+            return enqueue();
+        }
+    }
+    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        if (g.d_ptrs) (void)hipFree(g.d_ptrs);
+        ctx->graph_seen[key] = -1;
+        return enqueue();
+    }
+    ctx->capturing = true;
+    ctx->batch_dptrs_override = g.d_ptrs;
+    const int rc = enqueue();
+    ctx->batch_dptrs_override = nullptr;
+    ctx->capturing = false;
+    hipGraph_t graph = nullptr;
+    const hipError_t e_end = hipStreamEndCapture(ctx->stream, &graph);
+    bool ok = rc == 0 && e_end == hipSuccess && graph != nullptr;
+    if (ok) ok = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) == hipSuccess;
+    if (graph) (void)hipGraphDestroy(graph);
+    if (!ok) {  // nothing ran during the capture: do it directly, and stop trying for this call shape
+        (void)hipGetLastError();
+        if (g.d_ptrs) (void)hipFree(g.d_ptrs);
+        ctx->graph_seen[key] = -1;
+        return enqueue();
+    }
+    g.ws_epoch = ctx->ws_epoch;
+    ctx->graphs[key] = g;
+    ZK_HIP_CHECK(ctx, hipGraphLaunch(g.exec, ctx->stream));
+    return 0;
+}
+
+static int zk_msm_run_batch_direct(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases, const size_t *offsets, const size_t *ns,
+                                   const uint32_t *const *d_scalars, uint32_t *const *d_outs);
+
 int zk_msm_run_batch(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases, const size_t *offsets, const size_t *ns,
                      const uint32_t *const *d_scalars, uint32_t *const *d_outs) {
+    if (count == 0) return 0;
+    for (size_t i = 0; i < count; ++i)
+        if (offsets[i] + ns[i] > bases[i]->n || ns[i] >= (1ull << 31)) return ZKHIP_ERR_RANGE;
+    std::string key = key_begin(ctx, 'B');
+    bool uniform = true;  // one tail group: the graph-owned pointer array then serves the single shared reduction
+    for (size_t i = 0; i < count; ++i) {
+        key_add_bases(key, bases[i]);
+        key_add(key, offsets[i]);
+        key_add(key, ns[i]);
+        key_add(key, d_scalars[i]);
+        key_add(key, d_outs[i]);
+        uniform = uniform && bases[i]->ntab > 1 && bases[i]->curve == bases[0]->curve && bases[i]->group == bases[0]->group &&
+                  bases[i]->c_tab == bases[0]->c_tab;
+    }
+    auto direct = [&]() { return zk_msm_run_batch_direct(ctx, count, bases, offsets, ns, d_scalars, d_outs); };
+    if (!uniform || count < 2) return direct();
+    return zk_graph_run(ctx, key, direct, count, d_outs);
+}
+
+static int zk_msm_run_batch_direct(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases, const size_t *offsets, const size_t *ns,
+                                   const uint32_t *const *d_scalars, uint32_t *const *d_outs) {
     if (count == 0) return 0;
     for (size_t i = 0; i < count; ++i)
         if (offsets[i] + ns[i] > bases[i]->n || ns[i] >= (1ull << 31)) return ZKHIP_ERR_RANGE;
@@ -990,13 +1111,25 @@ int zk_msm_run_batch(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bas
             ZK_DISPATCH_CG(gb[0]->curve, gb[0]->group, ZK_TRY(msm_batch_t<F>(ctx, gb.size(), gb.data(), go.data(), gn.data(), gs.data(), gd.data())));
         } else {
             done[i] = 1;
-            ZK_TRY(zk_msm_run(ctx, bases[i], offsets[i], ns[i], d_scalars[i], d_outs[i]));
+            ZK_TRY(zk_msm_run_direct(ctx, bases[i], offsets[i], ns[i], d_scalars[i], d_outs[i]));
         }
     }
     return 0;
 }
 
 int zk_msm_run(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac) {
+    if (offset + n > bases->n) return ZKHIP_ERR_RANGE;
+    if (n == 0 || n >= (1ull << 31)) return zk_msm_run_direct(ctx, bases, offset, n, d_scalars, d_out_jac);
+    std::string key = key_begin(ctx, 'S');
+    key_add_bases(key, bases);
+    key_add(key, offset);
+    key_add(key, n);
+    key_add(key, d_scalars);
+    key_add(key, d_out_jac);
+    return zk_graph_run(ctx, key, [&]() { return zk_msm_run_direct(ctx, bases, offset, n, d_scalars, d_out_jac); });
+}
+
+static int zk_msm_run_direct(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac) {
     if (offset + n > bases->n) return ZKHIP_ERR_RANGE;
     if (n >= (1ull << 31)) return ZKHIP_ERR_RANGE;
     if (n == 0) {

@@ -58,6 +58,7 @@ void zkhip_destroy(zkhip_ctx *ctx) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
+    zk_graphs_clear(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -91,6 +92,7 @@ int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value) {
     else if (n == "ntt_tile_log") ctx->opt_ntt_tile_log = (int)value;
     else if (n == "msm_precompute") ctx->opt_msm_precompute = (int)value;
     else if (n == "msm_precompute_min") ctx->opt_msm_precompute_min = (int)value;
+    else if (n == "msm_graphs") ctx->opt_msm_graphs = (int)value;
     else return ZKHIP_ERR_INVALID;
     return ZKHIP_OK;
 }

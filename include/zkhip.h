@@ -51,7 +51,8 @@ const char *zkhip_last_error(const zkhip_ctx *ctx); /* HIP error text of the las
 /* All work is enqueued on this stream (default: a stream the context creates). */
 int zkhip_set_stream(zkhip_ctx *ctx, void *hip_stream);
 int zkhip_sync(zkhip_ctx *ctx);
-/* Tunables: "msm_window_bits" (0 = auto), "msm_segment_log" (tail: 2^k buckets per lane, < 0 = auto), "ntt_radix_log", "ntt_tile_log". */
+/* Tunables: "msm_window_bits" (0 = auto), "msm_segment_log" (tail: 2^k buckets per lane, < 0 = auto), "ntt_radix_log", "ntt_tile_log",
+ * "msm_precompute" / "msm_precompute_min" (window tables at upload), "msm_graphs" (HIP-graph replay of repeated MSM calls; off). */
 int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value);
 
 /* ---- device memory (plumbing for callers that keep vectors resident) -------------------------- */

@@ -203,6 +203,52 @@ def test_msm_full_size_bls12_381_g1(ctx):
     bases.free()
 
 
+@pytest.mark.parametrize("curve,group,n", [(0, 1, 3000), (0, 2, 700)])
+def test_msm_repeated_calls_replay_graph(ctx, zk, curve, group, n):
+    """the third identical call (same bases, same device buffers) is captured into a HIP graph and later ones replay it:
+    the CONTENT of the scalar buffer changes between calls and every result must follow it; same through the batch
+    entry point; growing the workspace in between (a larger MSM) must invalidate the graphs, not corrupt them."""
+    ctx.set_option("msm_graphs", 1)  # off by default (no measured gain): exercised here
+    b = ctx.bases_from_scalars(curve, group, cp.random_fr(curve, 60, n))
+    b2 = ctx.bases_from_scalars(curve, group, cp.random_fr(curve, 61, n))
+    pts, _ = b.download()
+    pts2, _ = b2.download()
+    jac = 3 * zk.coord_limbs(curve, group) * 8
+    d_s, d_s2, d_o = ctx.malloc(n * 32), ctx.malloc(n * 32), ctx.malloc(2 * jac)
+    res = np.zeros((2, jac // 8), dtype=np.uint64)
+
+    def check(k, batch):
+        s1, s2 = cp.random_fr(curve, 600 + k, n), cp.random_fr(curve, 700 + k, n)
+        ctx.h2d(d_s, s1)
+        ctx.h2d(d_s2, s2)
+        if batch:
+            ctx.msm_batch_dev([b, b2], [d_s, d_s2], [d_o, d_o + jac])
+        else:
+            ctx.msm_dev(b, d_s, d_o)
+            ctx.msm_dev(b2, d_s2, d_o + jac)
+        ctx.d2h(res, d_o)
+        for r, p, s in ((res[0], pts, s1), (res[1], pts2, s2)):
+            exp, einf = cp.msm(curve, group, p, s, chunks=4)
+            assert jac_to_affine_py(curve, group, r) == pt_from_limbs(curve, group, exp, einf), (k, batch)
+
+    for k in range(6):
+        check(k, False)
+    for k in range(6):
+        check(10 + k, True)
+    big = ctx.bases_from_scalars(curve, 1, cp.random_fr(curve, 62, 1 << 17))  # forces a larger workspace
+    ctx.msm(big, cp.random_fr(curve, 63, 1 << 17))
+    big.free()
+    for k in range(4):
+        check(20 + k, False)
+        check(30 + k, True)
+    ctx.set_option("msm_graphs", 0)
+    check(40, False)
+    for p in (d_s, d_s2, d_o):
+        ctx.free(p)
+    b.free()
+    b2.free()
+
+
 @pytest.mark.parametrize("curve,group,log_n", [(1, 1, 20), (0, 2, 18), (0, 1, 22)])
 def test_msm_large_other_configs(ctx, zk, curve, group, log_n):
     """full-size MSMs outside the headline configuration (BN254 G1 2^20, BLS12-381 G2 2^18 on the lane-pair kernels,

@@ -16,5 +16,15 @@ for log_n in (10, 12, 14, 16, 18):
     for _ in range(5): ctx.msm_dev(b, d_s, d_o)
     ctx.sync(); dt = (time.perf_counter() - t) / 5
     ctx.profile(False)
-    print(log_n, "%.3f ms" % (dt * 1e3), {k: (round(v[0] / 5, 3), v[1] // 5) for k, v in ctx.profile_dump().items()}, flush=True)
+    for _ in range(3): ctx.msm_dev(b, d_s, d_o)   # identical calls: the third is captured into a graph
+    ctx.sync()
+    t = time.perf_counter()
+    for _ in range(10): ctx.msm_dev(b, d_s, d_o)
+    ctx.sync(); dg = (time.perf_counter() - t) / 10
+    ctx.set_option("msm_graphs", 0)
+    t = time.perf_counter()
+    for _ in range(10): ctx.msm_dev(b, d_s, d_o)
+    ctx.sync(); dn = (time.perf_counter() - t) / 10
+    ctx.set_option("msm_graphs", 1)
+    print(log_n, "graph %.3f ms, direct %.3f ms;" % (dg * 1e3, dn * 1e3), "profiled:", "%.3f ms" % (dt * 1e3), {k: (round(v[0] / 5, 3), v[1] // 5) for k, v in ctx.profile_dump().items()}, flush=True)
     b.free()
