@@ -61,6 +61,7 @@ struct zkhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipEvent_t order_event = nullptr;  // zkhip_stream_wait: marks this context's stream for another context to wait on
     std::string last_error;
     // bump-allocated workspace, grown on demand, reused across calls
     char *ws = nullptr;

@@ -59,10 +59,23 @@ void zkhip_destroy(zkhip_ctx *ctx) {
         (void)hipEventDestroy(e.b);
     }
     zk_graphs_clear(ctx);
+    if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+int zkhip_device(const zkhip_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+int zkhip_stream_wait(zkhip_ctx *waiter, zkhip_ctx *signal) {
+    if (!waiter || !signal || waiter->device != signal->device) return ZKHIP_ERR_INVALID;
+    if (waiter == signal) return ZKHIP_OK;
+    ZK_HIP_CHECK(waiter, hipSetDevice(waiter->device));
+    if (!signal->order_event) ZK_HIP_CHECK(waiter, hipEventCreateWithFlags(&signal->order_event, hipEventDisableTiming));
+    ZK_HIP_CHECK(waiter, hipEventRecord(signal->order_event, signal->stream));
+    ZK_HIP_CHECK(waiter, hipStreamWaitEvent(waiter->stream, signal->order_event, 0));
+    return ZKHIP_OK;
 }
 
 const char *zkhip_last_error(const zkhip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }

@@ -38,6 +38,9 @@ public:
     context(const context &) = delete;
     context &operator=(const context &) = delete;
     zkhip_ctx *get() const { return ctx_; }
+    int device() const { return zkhip_device(ctx_); }
+    /// work enqueued here from now on runs after what `other` has enqueued so far (both on the same GPU)
+    void wait_for(const context &other) const { check(zkhip_stream_wait(ctx_, other.ctx_), "zkhip_stream_wait", ctx_); }
     void sync() const { check(zkhip_sync(ctx_), "zkhip_sync", ctx_); }
 
     /// device buffer of `bytes` bytes, freed with the returned handle

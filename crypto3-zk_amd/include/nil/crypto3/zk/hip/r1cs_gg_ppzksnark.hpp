@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <future>
+#include <memory>
 #include <random>
 #include <utility>
 #include <vector>
@@ -306,6 +307,9 @@ public:
     /// scalars, the five Jacobian MSM results
     mutable std::shared_ptr<void> d_cpa, d_h, d_scratch, d_bs, d_results;
     mutable std::shared_ptr<void> h_cpa;    // page-locked staging for (1, x, w): H2D at link speed, asynchronous
+    /// second in-order stream on the same GPU for the G2 multiexp (its own workspace); false: everything on `ctx`
+    bool overlap_g2 = true;
+    mutable std::unique_ptr<context> side;
     void reserve_work(std::size_t cpa_elems, std::size_t degree, std::size_t result_bytes) const {
         if (d_cpa && work_cpa_ >= cpa_elems) return;
         d_cpa = ctx.alloc(cpa_elems * 32);
@@ -319,6 +323,7 @@ public:
         d_scratch = ctx.alloc(zkhip_groth16_scratch_bytes(constraint_system.get()));
         d_bs = ctx.alloc(std::max<std::size_t>(1, B_count) * 32);
         d_results = ctx.alloc(result_bytes);
+        if (overlap_g2 && !side && B_count >= ((std::size_t)1 << 14)) side.reset(new context(ctx.device()));    // pays off for large queries only
         work_cpa_ = cpa_elems;
     }
 
@@ -451,7 +456,13 @@ private:
         /* evaluation_Bt: kc_multiexp_with_mixed_addition over the sparse (G2, G1) query (prover.hpp:116-123); a sharded key
            holds a slice of the index list */
         check(zkhip_fr_gather_dev(ctx.get(), cpa, pk.d_B_indices.get(), pk.B_count, pk.d_bs.get()), "zkhip_fr_gather_dev", ctx.get());
-        check(zkhip_msm_dev(ctx.get(), pk.B_query_g.get(), 0, pk.B_count, pk.d_bs.get(), d_res + 4 * jl1), "zkhip_msm_dev(B.g)", ctx.get());
+        if (pk.side) {
+            /* the G2 part on the second stream, after the gather; the four G1 multiexps below do not depend on it */
+            pk.side->wait_for(ctx);
+            check(zkhip_msm_dev(pk.side->get(), pk.B_query_g.get(), 0, pk.B_count, pk.d_bs.get(), d_res + 4 * jl1), "zkhip_msm_dev(B.g)", pk.side->get());
+        } else {
+            check(zkhip_msm_dev(ctx.get(), pk.B_query_g.get(), 0, pk.B_count, pk.d_bs.get(), d_res + 4 * jl1), "zkhip_msm_dev(B.g)", ctx.get());
+        }
         /* the four G1 multiexps as one batch (their bucket reductions share one launch):
            evaluation_At (prover.hpp:108-114), evaluation_Bt.h (:116-123), evaluation_Ht over H_query[0 .. degree - 1)
            (:125-131), evaluation_Lt over the auxiliary part of the assignment (:133-139) -- each over this key's slice */
@@ -467,6 +478,7 @@ private:
     /// the five partial sums of this rank, after the stream has drained
     static std::vector<std::uint64_t> collect(const proving_key_type &pk) {
         std::vector<std::uint64_t> res(partial_limbs());
+        if (pk.side) pk.ctx.wait_for(*pk.side);
         pk.ctx.d2h(res.data(), pk.d_results.get(), res.size() * 8);
         return res;
     }

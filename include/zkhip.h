@@ -50,6 +50,12 @@ const char *zkhip_strerror(int status);
 const char *zkhip_last_error(const zkhip_ctx *ctx); /* HIP error text of the last ZKHIP_ERR_HIP */
 /* All work is enqueued on this stream (default: a stream the context creates). */
 int zkhip_set_stream(zkhip_ctx *ctx, void *hip_stream);
+/* Two contexts on one GPU are two in-order streams (each with its own workspace).  zkhip_stream_wait(waiter, signal):
+ * everything enqueued on `waiter` after this call runs after everything enqueued on `signal` before it (an event;
+ * the host does not block).  The Groth16 shim runs the G2 multiexp of the B query on a second context this way, so
+ * that its latency-bound reduction tail overlaps the G1 multiexps (prover.hpp:116-139 are independent). */
+int zkhip_stream_wait(zkhip_ctx *waiter, zkhip_ctx *signal);
+int zkhip_device(const zkhip_ctx *ctx);
 int zkhip_sync(zkhip_ctx *ctx);
 /* Tunables: "msm_window_bits" (0 = auto), "msm_segment_log" (tail: 2^k buckets per lane, < 0 = auto), "ntt_radix_log", "ntt_tile_log",
  * "msm_precompute" / "msm_precompute_min" (window tables at upload), "msm_graphs" (HIP-graph replay of repeated MSM calls; off). */
