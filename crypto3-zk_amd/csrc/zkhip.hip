@@ -174,6 +174,14 @@ static int bases_alloc(zkhip_ctx *ctx, int curve, int group, size_t n, zkhip_bas
         b->ntab = msm_windows(zk_scalar_bits(curve), b->c_tab);
     }
     hipError_t e = hipMalloc((void **)&b->d, std::max<size_t>(1, n) * b->ntab * b->stride_u32 * 4);
+    if (e != hipSuccess && b->ntab > 1) {
+        // the window tables do not fit (ntab x n points): keep the points alone; the MSM then folds the windows by the
+        // Horner pass of msm_final instead of bucket-wise
+        (void)hipGetLastError();
+        b->ntab = 1;
+        b->c_tab = 0;
+        e = hipMalloc((void **)&b->d, std::max<size_t>(1, n) * b->stride_u32 * 4);
+    }
     if (e != hipSuccess) {
         ctx->last_error = std::string("hipMalloc(bases): ") + hipGetErrorString(e);
         delete b;
