@@ -185,6 +185,7 @@ int zk_bases_to_mont(zkhip_ctx *ctx, zkhip_bases *b, const uint32_t *d_canonical
 size_t zk_point_words(int curve, int group);
 int zk_msm_auto_window(size_t n);
 int zk_scalar_bits(int curve);  // bit length of the scalar-field modulus
+int zk_bases_decompress(zkhip_ctx *ctx, zkhip_bases *b, const uint8_t *d_octets, uint32_t *d_err);  // wire.hip
 void zk_graphs_clear(zkhip_ctx *ctx);  // destroy the cached MSM graphs
 int zk_bases_precompute(zkhip_ctx *ctx, zkhip_bases *b);  // u32 words per affine point in device buffers
 int zk_bases_from_mont(zkhip_ctx *ctx, const zkhip_bases *b, size_t offset, size_t n, uint32_t *d_out, uint8_t *d_inf);

@@ -238,6 +238,53 @@ int zkhip_bases_upload(zkhip_ctx *ctx, int curve, int group, const uint64_t *aff
     return ZKHIP_OK;
 }
 
+int zkhip_bases_upload_compressed(zkhip_ctx *ctx, int curve, int group, const uint8_t *octets, size_t n, zkhip_bases **out) {
+    if (!ctx || !out || (n && !octets)) return ZKHIP_ERR_INVALID;
+    if (curve != CURVE_BLS12_381) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
+    zkhip_bases *b = nullptr;
+    ZK_TRY(bases_alloc(ctx, curve, group, n, &b));
+    const size_t bytes = n * (group == GROUP_G2 ? 96 : 48);
+    uint8_t *d_oct = nullptr;
+    uint32_t rejected = 0;
+    int rc = 0;
+    do {
+        if (n == 0) break;
+        if (hipMalloc((void **)&d_oct, bytes + 16) != hipSuccess) {
+            rc = ZKHIP_ERR_OOM;
+            break;
+        }
+        uint32_t *d_err = reinterpret_cast<uint32_t *>(d_oct + ((bytes + 3) & ~(size_t)3));
+        if (hipMemcpyAsync(d_oct, octets, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemsetAsync(d_err, 0, 4, ctx->stream) != hipSuccess) {
+            rc = ZKHIP_ERR_HIP;
+            break;
+        }
+        rc = zk_bases_decompress(ctx, b, d_oct, d_err);
+        if (rc) break;
+        if (hipMemcpyAsync(&rejected, d_err, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            rc = ZKHIP_ERR_HIP;
+            break;
+        }
+        if (rejected) {
+            ctx->last_error = std::to_string(rejected) + " point encoding(s) rejected (flags, x >= p, or x not on the curve)";
+            rc = ZKHIP_ERR_INVALID;
+            break;
+        }
+        rc = zk_bases_precompute(ctx, b);
+        if (rc) break;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
+    } while (0);
+    if (d_oct) (void)hipFree(d_oct);
+    if (rc) {
+        (void)hipFree(b->d);
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return ZKHIP_OK;
+}
+
 // standard generators, canonical u32 limbs (x | y)
 static const uint64_t GEN_BLS_G1[12] = {0xfb3af00adb22c6bbULL, 0x6c55e83ff97a1aefULL, 0xa14e3a3f171bac58ULL, 0xc3688c4f9774b905ULL,
                                         0x2695638c4fa9ac0fULL, 0x17f1d3a73197d794ULL, 0x0caa232946c5e7e1ULL, 0xd03cc744a2888ae4ULL,

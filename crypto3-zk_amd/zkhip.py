@@ -15,7 +15,7 @@ _FQ = {BLS12_381: 6, BN254: 4}
 EXPORTS = [
     "zkhip_init", "zkhip_destroy", "zkhip_strerror", "zkhip_last_error", "zkhip_set_stream", "zkhip_sync", "zkhip_stream_wait", "zkhip_device",
     "zkhip_set_option", "zkhip_malloc", "zkhip_free", "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_memcpy_h2d_async", "zkhip_memcpy_d2d_async", "zkhip_host_alloc", "zkhip_host_free",
-    "zkhip_bases_upload", "zkhip_bases_from_scalars", "zkhip_bases_download", "zkhip_bases_size",
+    "zkhip_bases_upload", "zkhip_bases_upload_compressed", "zkhip_bases_from_scalars", "zkhip_bases_download", "zkhip_bases_size",
     "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_batch_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_domain_size", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev", "zkhip_fr_gather_dev", "zkhip_poly_resize_dev", "zkhip_fri_fold_dev", "zkhip_fri_leaves_dev", "zkhip_ec_ntt_dev",
     "zkhip_fr_vec_op_dev", "zkhip_poly_eval_dev", "zkhip_poly_div_linear_dev", "zkhip_poly_lincomb_dev",
@@ -146,6 +146,15 @@ class Context:
         h = ctypes.c_void_p()
         self._check(self.lib.zkhip_bases_upload(self.h, curve, group, _p(affine), _p(infa), ctypes.c_size_t(n), ctypes.byref(h)),
                     "zkhip_bases_upload")
+        return Bases(self, h, curve, group, n)
+
+    def upload_bases_compressed(self, curve: int, group: int, octets: bytes, n: int) -> "Bases":
+        """bases from n compressed wire encodings (48 B per G1 point, 96 B per G2 point), decoded on the device"""
+        buf = np.frombuffer(octets, dtype=np.uint8)
+        assert len(buf) == n * 48 * group
+        h = ctypes.c_void_p()
+        self._check(self.lib.zkhip_bases_upload_compressed(self.h, curve, group, _p(np.ascontiguousarray(buf)), ctypes.c_size_t(n), ctypes.byref(h)),
+                    "bases_upload_compressed")
         return Bases(self, h, curve, group, n)
 
     def bases_from_scalars(self, curve: int, group: int, scalars: np.ndarray, base=None) -> "Bases":

@@ -84,6 +84,12 @@ int zkhip_bases_upload(zkhip_ctx *ctx, int curve, int group, const uint64_t *aff
 /* out[i] = scalars[i] * base (base == NULL: the standard generator), computed on the device and left
  * resident.  Replaces algebra::batch_exp / kc_batch_exp (generator.hpp:187-214,
  * knowledge_commitment_multiexp.hpp:143-208) and structured_generators_scalar_power (ipp2/srs.hpp:44-56). */
+/* The same from the WIRE form of a proving key (g16/marshalling.hpp:111-112, 178-201): n compressed
+ * BLS12-381 points, 48 bytes each for G1, 96 for G2 (big-endian x, G2: x.c1 then x.c0; byte 0 carries the flags
+ * 0x80 compressed, 0x40 infinity, 0x20 larger y) -- the encoding pinned by the vectors of
+ * r1cs_gg_ppzksnark_aggregation_conformity.cpp:932-1010.  Decoded on the device (one square root per point).
+ * ZKHIP_ERR_INVALID if any encoding is malformed or not on the curve (zkhip_last_error says how many). */
+int zkhip_bases_upload_compressed(zkhip_ctx *ctx, int curve, int group, const uint8_t *octets, size_t n, zkhip_bases **out);
 int zkhip_bases_from_scalars(zkhip_ctx *ctx, int curve, int group, const uint64_t *base_affine_xy /* nullable */,
                              const uint64_t *scalars, size_t n, zkhip_bases **out);
 int zkhip_bases_download(zkhip_ctx *ctx, const zkhip_bases *b, size_t offset, size_t n, uint64_t *affine_xy, uint8_t *is_infinity);

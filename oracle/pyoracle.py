@@ -948,6 +948,90 @@ def kzg_v2_proof_eval(r: int, polys: dict, points: dict, theta: int, theta2: int
     return z, f, L
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Compressed point encoding of BLS12-381 keys on the wire (the ZCash format; what
+# nil::marshalling::bincode::curve<bls12<381>>::point_to_bytes / g1_point_from_bytes produce and read -- pinned by the
+# literal vectors of AGG:932-1010 -- and what the proving-key serializer emits per point, g16/marshalling.hpp:111-112,
+# 178-201: G1 = one Fq, G2 = two).  Byte 0 carries three flags: 0x80 compressed, 0x40 infinity, 0x20 "y is the
+# lexicographically larger root"; the rest is x big-endian (G2: x.c1 then x.c0).
+def _sqrt_fq(a: int, p: int):
+    r = pow(a, (p + 1) // 4, p)  # p = 3 mod 4
+    return r if r * r % p == a % p else None
+
+
+def _sqrt_fq2(a, p: int):
+    """complex method: a = a0 + a1 u, u^2 = -1"""
+    a0, a1 = a[0] % p, a[1] % p
+    if a1 == 0:
+        r = _sqrt_fq(a0, p)
+        if r is not None:
+            return (r, 0)
+        r = _sqrt_fq((-a0) % p, p)
+        return None if r is None else (0, r)
+    s = _sqrt_fq((a0 * a0 + a1 * a1) % p, p)
+    if s is None:
+        return None
+    inv2 = pow(2, -1, p)
+    x0 = _sqrt_fq((a0 + s) * inv2 % p, p)
+    if x0 is None:
+        x0 = _sqrt_fq((a0 - s) * inv2 % p, p)
+    if x0 is None or x0 == 0:
+        return None
+    x1 = a1 * pow(2 * x0, -1, p) % p
+    return (x0, x1)
+
+
+def bls12_381_compress(group: int, P) -> bytes:
+    p = BLS12_381.p
+    n = 48 * group
+    if P is None:
+        return bytes([0xC0]) + bytes(n - 1)
+    if group == 1:
+        x, y = P
+        larger = y > (p - 1) // 2
+        body = x.to_bytes(48, "big")
+    else:
+        (x0, x1), (y0, y1) = P
+        larger = (y1 > (p - 1) // 2) if y1 != 0 else (y0 > (p - 1) // 2)
+        body = x1.to_bytes(48, "big") + x0.to_bytes(48, "big")
+    return bytes([body[0] | 0x80 | (0x20 if larger else 0)]) + body[1:]
+
+
+def bls12_381_decompress(group: int, data: bytes):
+    """returns the affine point (None for infinity); raises ValueError on a malformed or off-curve encoding"""
+    p = BLS12_381.p
+    n = 48 * group
+    if len(data) != n or not data[0] & 0x80:
+        raise ValueError("not a compressed point")
+    if data[0] & 0x40:
+        if data[0] & 0x3F or any(data[1:]):
+            raise ValueError("malformed infinity")
+        return None
+    larger = bool(data[0] & 0x20)
+    body = bytes([data[0] & 0x1F]) + data[1:]
+    if group == 1:
+        x = int.from_bytes(body, "big")
+        if x >= p:
+            raise ValueError("x not reduced")
+        y = _sqrt_fq((x * x * x + 4) % p, p)
+        if y is None:
+            raise ValueError("not on the curve")
+        if (y > (p - 1) // 2) != larger:
+            y = p - y
+        return (x, y)
+    x1, x0 = int.from_bytes(body[:48], "big"), int.from_bytes(body[48:], "big")
+    if x0 >= p or x1 >= p:
+        raise ValueError("x not reduced")
+    F = Fq2(p)
+    y = _sqrt_fq2(F.add(F.mul(F.sqr((x0, x1)), (x0, x1)), (4, 4)), p)
+    if y is None:
+        raise ValueError("not on the curve")
+    is_larger = (y[1] > (p - 1) // 2) if y[1] != 0 else (y[0] > (p - 1) // 2)
+    if is_larger != larger:
+        y = F.neg(y)
+    return ((x0, x1), y)
+
+
 def to_limbs(v: int, n: int) -> List[int]:
     return [(v >> (64 * i)) & MASK64 for i in range(n)]
 

@@ -8,6 +8,8 @@ that travels.  Sources (data literals, no code):
                                         kzg_challenge, expected evaluation)
     :864-930  bls381_prove_commitment_test (alpha, beta, kzg_challenge, 3 transcript scalars, r_shift,
                                         expected 2 x G2 and 2 x G1 affine points)
+    :932-1010 bls381_transcript_test, serialisation part (an Fr element with its 32 little-endian bytes, a G1 point with
+                                        its 48 compressed bytes, a G2 point with its 96 compressed bytes)
   test/commitment/kzg.cpp:75-103        kzg_basic_test  (alpha = 10, f = {-1, 1, 2, 3}, commit = 3209 * G)
 """
 import json
@@ -63,6 +65,23 @@ def main():
         "comm_w": [[hex(fq[8]), hex(fq[9])], [hex(fq[10]), hex(fq[11])]],
     }
     out["kzg_basic_test"] = {"alpha": 10, "f": [-1, 1, 2, 3], "commit_scalar": 3209}
+    # serialised forms (bincode::curve<bls12<381>>: the ZCash compressed encoding of points, little-endian scalars)
+    tr = block("BOOST_AUTO_TEST_CASE(bls381_transcript_test)")
+    tr = tr[: tr.index("fq12_value_type d(")]
+    fr = hexes(tr, "255")
+    fq = hexes(tr, "381")
+
+    def byte_list(name):
+        body = tr[tr.index(name + " = {") + len(name) + 4:]
+        return [int(x) for x in re.findall(r"\d+", body[: body.index("}")])]
+
+    assert len(fr) == 1 and len(fq) == 2 + 4, (len(fr), len(fq))
+    out["serialisation_test"] = {
+        "fr": hex(fr[0]), "fr_bytes": byte_list("et_a_ser"),
+        "g1": [hex(fq[0]), hex(fq[1])], "g1_bytes": byte_list("et_b_ser"),
+        # [[x.c0, x.c1], [y.c0, y.c1]]
+        "g2": [[hex(fq[2]), hex(fq[3])], [hex(fq[4]), hex(fq[5])]], "g2_bytes": byte_list("et_c_ser"),
+    }
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_kat.json")
     json.dump(out, open(dst, "w"), indent=1)
     print("wrote", dst)

@@ -137,3 +137,23 @@ def test_groth16_oracles_in_exponent(curve):
     assert (proof == np.concatenate([pt_limbs(curve, 1, eA), pt_limbs(curve, 2, eB), pt_limbs(curve, 1, eC)])).all()
     pk = po.groth16_keygen(C, cs, trap, w)
     assert po.groth16_prove(C, pk, prim, aux, rr, ss, w) == (eA, eB, eC)
+
+
+def test_reference_serialisation_vectors():
+    """AGG:932-1010: the byte encodings of an Fr element, a G1 and a G2 point (bincode::curve<bls12<381>>)"""
+    k = KAT["serialisation_test"]
+    assert list(int(k["fr"], 16).to_bytes(32, "little")) == k["fr_bytes"]
+    g1 = (int(k["g1"][0], 16), int(k["g1"][1], 16))
+    assert po.BLS12_381.g1.on_curve(g1)
+    assert list(po.bls12_381_compress(1, g1)) == k["g1_bytes"]
+    assert po.bls12_381_decompress(1, bytes(k["g1_bytes"])) == g1
+    g2 = tuple((int(c[0], 16), int(c[1], 16)) for c in k["g2"])
+    assert po.BLS12_381.g2.on_curve(g2)
+    assert list(po.bls12_381_compress(2, g2)) == k["g2_bytes"]
+    assert po.bls12_381_decompress(2, bytes(k["g2_bytes"])) == g2
+    # round trips on other points, both signs, infinity
+    for grp, G in ((1, po.BLS12_381.g1), (2, po.BLS12_381.g2)):
+        for s in (1, 2, 3, 12345, po.BLS12_381.r - 1):
+            P = G.mul(G.gen, s)
+            assert po.bls12_381_decompress(grp, po.bls12_381_compress(grp, P)) == P
+        assert po.bls12_381_decompress(grp, po.bls12_381_compress(grp, None)) is None
