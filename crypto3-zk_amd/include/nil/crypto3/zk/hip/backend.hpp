@@ -90,6 +90,14 @@ public:
         check(zkhip_bases_from_scalars(ctx.get(), adapter::id, Group, nullptr, s.data(), r.size_, &r.b_), "zkhip_bases_from_scalars", ctx.get());
         return r;
     }
+    /// from `n` compressed wire encodings (48 bytes per G1 point, 96 per G2 point), decoded on the device
+    static device_bases from_compressed(const context &ctx, const std::uint8_t *octets, std::size_t n) {
+        device_bases r;
+        r.ctx_ = &ctx;
+        r.size_ = n;
+        check(zkhip_bases_upload_compressed(ctx.get(), adapter::id, Group, octets, n, &r.b_), "zkhip_bases_upload_compressed", ctx.get());
+        return r;
+    }
     /// host copy of entry i as a group value
     typename std::conditional<Group == ZKHIP_G1, typename adapter::g1_value_type, typename adapter::g2_value_type>::type at(std::size_t i) const {
         typedef typename std::conditional<Group == ZKHIP_G1, typename adapter::g1_value_type, typename adapter::g2_value_type>::type G;

@@ -12,6 +12,7 @@
 #include <nil/crypto3/zk/hip/fri.hpp>
 #include <nil/crypto3/zk/hip/knowledge_commitment_multiexp.hpp>
 #include <nil/crypto3/zk/hip/kzg_v2.hpp>
+#include <nil/crypto3/zk/hip/marshalling.hpp>
 #include <nil/crypto3/zk/hip/powers_of_tau.hpp>
 #include <nil/crypto3/zk/hip/r1cs_gg_ppzksnark.hpp>
 
@@ -276,6 +277,27 @@ int lagrange_g1_t(const uint64_t *powers, size_t m, const uint64_t *omega, uint6
     return 0;
 }
 
+template <typename Curve>
+int groth16_prove_from_bytes_t(const uint8_t *blob, size_t size, const uint64_t *assignment, size_t n, size_t N, const uint64_t *omega, const uint64_t *coset,
+                               const uint64_t *r, const uint64_t *s, uint64_t *proof) {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::scalar_value_type Fr;
+    const size_t L1 = 2 * A::g1_coord_limbs, L2 = 2 * A::g2_coord_limbs;
+    context ctx(0);
+    domain_params<Curve> dom {A::scalar_from_limbs(omega), A::scalar_from_limbs(coset)};
+    auto key = proving_key_from_bytes<Curve>(ctx, blob, size, dom);
+    if (key->host.constraint_system.num_inputs() != n || key->host.constraint_system.num_variables() != N) return -103;
+    std::vector<Fr> primary, auxiliary;
+    for (size_t i = 0; i < n; ++i) primary.push_back(A::scalar_from_limbs(assignment + 4 * i));
+    for (size_t i = n; i < N; ++i) auxiliary.push_back(A::scalar_from_limbs(assignment + 4 * i));
+    if (!key->host.constraint_system.is_satisfied(primary, auxiliary)) return -100;
+    auto pv = r1cs_gg_ppzksnark_prover_hip<Curve>::process(*key->device, primary, auxiliary, A::scalar_from_limbs(r), A::scalar_from_limbs(s));
+    pv.g_A.to_affine(proof);
+    pv.g_B.to_affine(proof + L1);
+    pv.g_C.to_affine(proof + L1 + L2);
+    return 0;
+}
+
 // ---- host-only logic of the shim (no GPU needed: the CPU test-suite calls these) -----------------------------------
 template <typename Curve>
 int host_small_poly_t(const uint64_t *xs, const uint64_t *ys, size_t k, const uint64_t *at, uint64_t *u_at, uint64_t *u_coeffs, uint64_t *v_coeffs) {
@@ -399,6 +421,16 @@ int shim_kc_multiexp(int curve, const uint64_t *g_pts, const uint64_t *h_pts, co
 
 int shim_lagrange_g1(int curve, const uint64_t *powers, size_t m, const uint64_t *omega, uint64_t *out, uint8_t *out_inf) {
     CURVE_CALL("shim_lagrange_g1", lagrange_g1_t, powers, m, omega, out, out_inf)
+}
+
+int shim_groth16_prove_from_bytes(const uint8_t *blob, size_t size, const uint64_t *assignment, size_t n, size_t N, const uint64_t *omega,
+                                  const uint64_t *coset, const uint64_t *r, const uint64_t *s, uint64_t *proof) {
+    try {
+        return groth16_prove_from_bytes_t<bls12_381>(blob, size, assignment, n, N, omega, coset, r, s, proof);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "shim_groth16_prove_from_bytes: %s\n", e.what());
+        return -1;
+    }
 }
 
 int shim_kzg_basic_proof(int curve, const uint64_t *srs, size_t n_srs, const uint64_t *coeffs, size_t n, const uint64_t *z, uint64_t *out) {

@@ -311,3 +311,62 @@ def test_powers_of_tau_lagrange_shim(shim, curve, log_m):
     assert shim.shim_lagrange_g1(curve, P(powers), ctypes.c_size_t(m), P(limbs(w, 4)), P(out), P(oinf)) == 0
     exp, einf = cp.batch_mul(curve, 1, fr_arr(po.lagrange_at(m, w, tau, r)))
     assert (oinf == einf).all() and (out == exp).all()
+
+
+def _key_blob(g, C):
+    """serialise the oracle's proving key in the reference's wire format (g16/marshalling.hpp:203-492, 656-760):
+    4-byte big-endian counts, compressed points (po.bls12_381_compress, pinned to AGG:932-1010), little-endian Fr"""
+    u32 = lambda v: int(v).to_bytes(4, "big")
+    aq, ainf = g.query(0)
+    bh, bhinf = g.query(1)
+    bg, _ = g.query(2)
+    hq, hinf = g.query(3)
+    lq, linf = g.query(4)
+    f1, _ = g.query(5)
+    f2, _ = g.query(6)
+    pt = lambda grp, arr, inf=0: po.bls12_381_compress(grp, pt_from_limbs_(grp, arr, inf))
+    out = pt(1, f1[0]) + pt(1, f1[1]) + pt(2, f2[0]) + pt(1, f1[2]) + pt(2, f2[1])           # alpha_g1 beta_g1 beta_g2 delta_g1 delta_g2
+    out += u32(len(aq)) + b"".join(pt(1, aq[i], ainf[i]) for i in range(len(aq)))
+    idx = [i for i in range(len(bh)) if not bhinf[i]]                                          # sparse over the non-zero B_i(t)
+    body = u32(len(idx)) + b"".join(u32(i) for i in idx) + b"".join(pt(2, bg[i]) + pt(1, bh[i]) for i in idx) + u32(len(bh))
+    out += u32(len(body)) + body
+    out += u32(g.m - 1) + b"".join(pt(1, hq[i], hinf[i]) for i in range(g.m - 1))
+    out += u32(len(lq)) + b"".join(pt(1, lq[i], linf[i]) for i in range(len(lq)))
+    out += u32(g.n) + u32(g.N - g.n) + u32(g.M)
+    csr = [g.csr(k) for k in range(3)]
+    for row in range(g.M):
+        c = b""
+        for rp, cl, cf in csr:
+            lo, hi = int(rp[row]), int(rp[row + 1])
+            c += u32(hi - lo) + b"".join(u32(cl[j]) + po.from_limbs(cf[j]).to_bytes(32, "little") for j in range(lo, hi))
+        out += u32(len(c)) + c
+    return out
+
+
+def pt_from_limbs_(grp, arr, inf):
+    from util import pt_from_limbs
+    return pt_from_limbs(0, grp, arr, inf)
+
+
+def test_groth16_from_serialised_key(shim):
+    """the proving key arrives in the reference's wire format, its point blobs are decoded on the device,
+    and the proof equals the oracle's."""
+    C = CURVES[0]
+    M, n = 100, 10
+    g = cp.Groth16(0, M, n, seed=1)
+    w = limbs(C.root_of_unity(g.log_m), 4)
+    gen = limbs(C.fr_generator, 4)
+    rng = po.SplitMix64(2024)
+    trap = fr_arr([rng.next_mod(C.r) for _ in range(5)])
+    r_, s_ = limbs(rng.next_mod(C.r), 4), limbs(rng.next_mod(C.r), 4)
+    g.keygen(trap, w)
+    expected = g.prove(r_, s_, w, gen, chunks=4)
+    blob = np.frombuffer(_key_blob(g, C), dtype=np.uint8).copy()
+    proof = np.zeros_like(expected)
+    rc = shim.shim_groth16_prove_from_bytes(P(blob), ctypes.c_size_t(len(blob)), P(g.assignment()), ctypes.c_size_t(g.n), ctypes.c_size_t(g.N), P(w),
+                                            P(gen), P(r_), P(s_), P(proof))
+    assert rc == 0
+    assert (proof == expected).all()
+    # a truncated blob is reported, not read past
+    assert shim.shim_groth16_prove_from_bytes(P(blob), ctypes.c_size_t(len(blob) - 7), P(g.assignment()), ctypes.c_size_t(g.n),
+                                              ctypes.c_size_t(g.N), P(w), P(gen), P(r_), P(s_), P(proof)) == -1
