@@ -7,7 +7,7 @@
 #include <cstring>
 #include <vector>
 
-#include <nil/crypto3/zk/hip/r1cs_gg_ppzksnark.hpp>
+#include <nil/crypto3/zk/hip/r1cs_gg_ppzksnark_generator.hpp>
 
 using namespace nil::crypto3::zk::hip;
 
@@ -24,10 +24,12 @@ struct SplitMix {
     }
 };
 
-// Groth16 prover throughput on a synthetic instance of the reference's example family
-// (generate_r1cs_example_with_field_input, r1cs_examples.hpp:77-140): the constraint system and a satisfying
-// assignment are real; the proving-key queries are random multiples of the generators computed on the device
-// (the prover's work does not depend on the key being a valid setup).  times[]: wall ms per proof.
+// Groth16 prover throughput on an instance of the reference's example family
+// (generate_r1cs_example_with_field_input, r1cs_examples.hpp:77-140): constraint system, satisfying assignment and a
+// VALID proving key generated on the device from a fixed trapdoor (r1cs_gg_ppzksnark_generator_hip).  After the timed
+// proofs the last proof is held against the trapdoor identity (A = a G1, B = b G2, C = c G1, prover.hpp:141-153; the
+// exponents come from O(nnz + m) host field arithmetic, the three scalar multiplications run on the host): *verified.
+// times[]: wall ms per proof.
 // rank / world > 1: ONE proof sharded over `world` GPUs (one process each): this rank generates and holds only its
 // slice of every query, runs the replicated witness map and its five partial MSMs, and `all_gather` (supplied by the
 // caller: RCCL through torch.distributed in bench.py) exchanges the 864-byte partial sums.
@@ -35,23 +37,25 @@ typedef void (*all_gather_fn)(const uint64_t *mine, size_t words, uint64_t *all)
 
 template <typename Curve>
 int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gather, size_t M, size_t n, uint64_t seed, int steps, const uint64_t *omega,
-                    const uint64_t *coset, double *times, double *setup_ms, char *prof, size_t prof_cap) {
+                    const uint64_t *coset, double *times, double *setup_ms, int *verified, char *prof, size_t prof_cap) {
     typedef curve_adapter<Curve> A;
     typedef typename A::scalar_value_type Fr;
     auto t0 = std::chrono::steady_clock::now();
     SplitMix rng {seed};
-    auto rnd = [&]() {
+    std::uint64_t mod[4];
+    A::scalar_modulus(mod);
+    auto rnd = [&]() {    // < 2^252 < r for both curves: canonical
         uint64_t w[4] = {rng.next(), rng.next(), rng.next(), rng.next() & 0x0fffffffffffffffULL};
         return A::scalar_from_limbs(w);
     };
-    r1cs_gg_ppzksnark_proving_key<Curve> pk;
-    auto &cs = pk.constraint_system;
+    r1cs_constraint_system<Curve> cs;
     cs.primary_input_size = n;
     cs.auxiliary_input_size = 2 + M - n;
     std::vector<Fr> full;
     Fr a = rnd(), b = rnd();
     full.push_back(a);
     full.push_back(b);
+    cs.constraints.reserve(M);
     for (size_t i = 0; i + 1 < M; ++i) {
         r1cs_constraint<Curve> c;
         Fr tmp;
@@ -83,51 +87,39 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
         cs.add_constraint(c);
         full.push_back(fin * fin);
     }
-    const size_t N = cs.num_variables();
     std::vector<Fr> primary(full.begin(), full.begin() + n), auxiliary(full.begin() + n, full.end());
 
     context ctx(device);
-    size_t m = 1;
-    while (m < M + n + 1) m <<= 1;
-    const query_shard slice = query_shard::make(rank, world, N + 1, N + 1, m - 1, N - n);
-    SplitMix key_rng {seed * 1000003 + 17 * rank + 1};    // key material differs per rank (each rank owns other points)
+    domain_params<Curve> dom {A::scalar_from_limbs(omega), A::scalar_from_limbs(coset)};
+    /* the toxic waste: fixed by the seed (identical on every rank of a sharded proof) */
+    SplitMix key_rng {seed * 1000003 + 1};
     auto rnd_key = [&]() {
         uint64_t w[4] = {key_rng.next(), key_rng.next(), key_rng.next(), key_rng.next() & 0x0fffffffffffffffULL};
         return A::scalar_from_limbs(w);
     };
-    auto rand_bases_g1 = [&](size_t cnt) {
-        std::vector<Fr> s(cnt);
-        for (auto &x : s) x = rnd_key();
-        return device_bases<Curve, ZKHIP_G1>::from_scalars(ctx, s.begin(), s.end());
-    };
-    std::vector<Fr> sb(slice.B_n);
-    for (auto &x : sb) x = rnd_key();
-    std::vector<uint32_t> bidx(slice.B_n);
-    for (size_t i = 0; i < slice.B_n; ++i) bidx[i] = (uint32_t)(slice.B_lo + i);
-    std::vector<Fr> fx = {rnd(), rnd(), rnd()};
-    auto f1 = device_bases<Curve, ZKHIP_G1>::from_scalars(ctx, fx.begin(), fx.end());
-    auto f2 = device_bases<Curve, ZKHIP_G2>::from_scalars(ctx, fx.begin(), fx.end());
-    pk.alpha_g1 = f1.at(0);
-    pk.beta_g1 = f1.at(1);
-    pk.delta_g1 = f1.at(2);
-    pk.beta_g2 = f2.at(1);
-    pk.delta_g2 = f2.at(2);
-    domain_params<Curve> dom {A::scalar_from_limbs(omega), A::scalar_from_limbs(coset)};
-    r1cs_gg_ppzksnark_proving_key_hip<Curve> dpk(ctx, pk, dom, rand_bases_g1(slice.A_n), device_bases<Curve, ZKHIP_G2>::from_scalars(ctx, sb.begin(), sb.end()),
-                                                 device_bases<Curve, ZKHIP_G1>::from_scalars(ctx, sb.begin(), sb.end()), bidx, rand_bases_g1(slice.H_n),
-                                                 rand_bases_g1(slice.L_n), &slice);
+    const Fr t = rnd_key(), alpha = rnd_key(), beta = rnd_key(), gamma = rnd_key(), delta = rnd_key();
+    auto key = r1cs_gg_ppzksnark_generator_hip<Curve>::deterministic_basic_process(ctx, cs, dom, t, alpha, beta, gamma, delta, rank, world);
+    auto &dpk = *key->device;
     ctx.sync();
     *setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     Fr r = rnd(), s = rnd();
+    typedef r1cs_gg_ppzksnark_prover_hip<Curve> prover;
+    typename prover::proof_type proof;
     for (int k = 0; k < steps; ++k) {
         if (k == steps - 1) zkhip_profile_enable(ctx.get(), 1);    // per-kernel HIP-event times of the last proof
         auto t1 = std::chrono::steady_clock::now();
-        auto proof = all_gather ? r1cs_gg_ppzksnark_prover_hip<Curve>::process(dpk, primary, auxiliary, r, s, all_gather)
-                                : r1cs_gg_ppzksnark_prover_hip<Curve>::process(dpk, primary, auxiliary, r, s);
+        proof = all_gather ? prover::process(dpk, primary, auxiliary, r, s, all_gather) : prover::process(dpk, primary, auxiliary, r, s);
         times[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
-        if (proof.g_A.is_zero()) return -2;
     }
     if (prof && prof_cap) zkhip_profile_dump(ctx.get(), prof, prof_cap);    // per-kernel HIP-event ms of the last proof
+    /* the check, outside the timed region: the proof must be the one the trapdoor dictates */
+    if (verified) {
+        const auto e = groth16_proof_exponents<Curve>(key->host.constraint_system, dom, primary, auxiliary, t, alpha, beta, delta, r, s);
+        std::vector<Fr> one = {Fr::one()};
+        const auto g1 = device_bases<Curve, ZKHIP_G1>::from_scalars(ctx, one.begin(), one.end()).at(0);    // the standard generators
+        const auto g2 = device_bases<Curve, ZKHIP_G2>::from_scalars(ctx, one.begin(), one.end()).at(0);
+        *verified = (proof.g_A == e[0] * g1 && proof.g_B == e[1] * g2 && proof.g_C == e[2] * g1) ? 1 : 0;
+    }
     return 0;
 }
 
@@ -135,11 +127,12 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
 
 extern "C" {
 
-int zkhip_bench_groth16(int curve, size_t M, size_t n, uint64_t seed, int steps, const uint64_t *omega, const uint64_t *coset, double *times,
-                        double *setup_ms, char *prof, size_t prof_cap) {
+int zkhip_bench_groth16(int device, int curve, size_t M, size_t n, uint64_t seed, int steps, const uint64_t *omega, const uint64_t *coset, double *times,
+                        double *setup_ms, int *verified, char *prof, size_t prof_cap) {
     try {
-        if (curve == ZKHIP_BLS12_381) return groth16_bench_t<bls12_381>(0, 0, 1, nullptr, M, n, seed, steps, omega, coset, times, setup_ms, prof, prof_cap);
-        return groth16_bench_t<alt_bn128_254>(0, 0, 1, nullptr, M, n, seed, steps, omega, coset, times, setup_ms, prof, prof_cap);
+        if (curve == ZKHIP_BLS12_381)
+            return groth16_bench_t<bls12_381>(device, 0, 1, nullptr, M, n, seed, steps, omega, coset, times, setup_ms, verified, prof, prof_cap);
+        return groth16_bench_t<alt_bn128_254>(device, 0, 1, nullptr, M, n, seed, steps, omega, coset, times, setup_ms, verified, prof, prof_cap);
     } catch (const std::exception &e) {
         fprintf(stderr, "zkhip_bench_groth16: %s\n", e.what());
         return -1;
@@ -148,11 +141,11 @@ int zkhip_bench_groth16(int curve, size_t M, size_t n, uint64_t seed, int steps,
 
 /* one proof sharded over `world` processes / GPUs; every rank calls this with the same M, n, seed and steps */
 int zkhip_bench_groth16_sharded(int device, size_t rank, size_t world, all_gather_fn all_gather, int curve, size_t M, size_t n, uint64_t seed, int steps,
-                                const uint64_t *omega, const uint64_t *coset, double *times, double *setup_ms) {
+                                const uint64_t *omega, const uint64_t *coset, double *times, double *setup_ms, int *verified) {
     try {
         if (curve == ZKHIP_BLS12_381)
-            return groth16_bench_t<bls12_381>(device, rank, world, all_gather, M, n, seed, steps, omega, coset, times, setup_ms, nullptr, 0);
-        return groth16_bench_t<alt_bn128_254>(device, rank, world, all_gather, M, n, seed, steps, omega, coset, times, setup_ms, nullptr, 0);
+            return groth16_bench_t<bls12_381>(device, rank, world, all_gather, M, n, seed, steps, omega, coset, times, setup_ms, verified, nullptr, 0);
+        return groth16_bench_t<alt_bn128_254>(device, rank, world, all_gather, M, n, seed, steps, omega, coset, times, setup_ms, verified, nullptr, 0);
     } catch (const std::exception &e) {
         fprintf(stderr, "zkhip_bench_groth16_sharded: %s\n", e.what());
         return -1;

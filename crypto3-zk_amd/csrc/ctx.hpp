@@ -28,13 +28,26 @@
         if (rc__ != 0) return rc__; \
     } while (0)
 
+static constexpr int ZK_MSM_MAX_C = 16;  // largest Pippenger window (bits); 2^(c-1) buckets per window
+
+// bits of the sticky device status word (kernels atomicOr them in; zkhip_device_status reports and clears)
+enum : uint32_t { ZK_STATUS_GATHER_RANGE = 1u, ZK_STATUS_MSM_PLAN_OVERFLOW = 2u };
+
 struct zkhip_bases {
     int curve, group;
     size_t n;
     size_t stride_u32;  // u32 words per affine point (2 * coordinate limbs)
-    uint32_t *d;        // ntab tables of n Montgomery-form affine points each, (0,0) = infinity;
-                        // table w holds 2^(c_tab w) P_i ("window tables": no Horner pass over the windows)
-    int c_tab = 0, ntab = 1;
+    uint32_t *d;        // nslots tables of n Montgomery-form affine points each, (0,0) = infinity;
+                        // the table of window w holds 2^off(w) P_i ("window tables": no Horner pass over the windows)
+    int c_tab = 0, ntab = 1;  // window size the tables were built for (0: no tables) and the number of windows W
+    // Window partition over GPUs: this object holds the tables of windows {w : w mod win_world == win_rank}
+    // only, for ALL n points; an MSM over it yields the partial sum of those windows.  Slot 0 always holds the points
+    // themselves (window 0, which belongs to rank 0; other ranks keep it as the source of their doubling chains).
+    int win_rank = 0, win_world = 1;
+    int nslots = 1;
+    bool tables() const { return c_tab > 0; }
+    int local_windows() const { return win_rank < ntab ? (ntab - win_rank + win_world - 1) / win_world : 0; }
+    int slot_of_local(int lw) const { return lw + (win_rank != 0 ? 1 : 0); }  // local window lw = window win_rank + lw * win_world
 };
 
 struct ZkEventPair {
@@ -63,6 +76,7 @@ struct zkhip_ctx {
     bool own_stream = false;
     hipEvent_t order_event = nullptr;  // zkhip_stream_wait: marks this context's stream for another context to wait on
     std::string last_error;
+    uint32_t *d_status = nullptr;  // sticky device-side error flags (ZK_STATUS_*), read and cleared by zkhip_device_status
     // bump-allocated workspace, grown on demand, reused across calls
     char *ws = nullptr;
     size_t ws_cap = 0, ws_off = 0, ws_floor = 0;  // ws_floor: start of the per-call region (a batch parks data below it)
@@ -85,6 +99,7 @@ struct zkhip_ctx {
     int opt_ntt_radix_log = 8;
     int opt_ntt_tile_log = 3;
     int opt_msm_precompute = 1;       // build window tables at upload for bases of >= opt_msm_precompute_min points
+    int opt_msm_shard_rank = 0, opt_msm_shard_world = 1;  // window partition applied to bases uploaded from now on
     int opt_msm_precompute_min = 32;  // without tables the windows are combined by a serial Horner pass (~255 doublings on one lane: 3.8 ms)
     ZkProfile prof;
     std::vector<NttTables *> ntt_tables;

@@ -159,11 +159,17 @@ __global__ __launch_bounds__(256) void groth16_h_pointwise(const uint32_t *__res
 }
 
 // dst[j] = src[idx[j]] on 32-byte elements: the scalar side of a sparse query (B_query.indices)
-__global__ __launch_bounds__(256) void fr_gather(const uint4 *__restrict__ src, const uint32_t *__restrict__ idx, size_t count,
-                                                 uint4 *__restrict__ dst) {
+// An index >= src_count (a malformed key) yields the zero scalar and raises ZK_STATUS_GATHER_RANGE.
+__global__ __launch_bounds__(256) void fr_gather(const uint4 *__restrict__ src, size_t src_count, const uint32_t *__restrict__ idx, size_t count,
+                                                 uint4 *__restrict__ dst, uint32_t *__restrict__ status) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     size_t s = idx[j];
+    if (s >= src_count) {
+        dst[2 * j] = dst[2 * j + 1] = make_uint4(0, 0, 0, 0);
+        atomicOr(status, ZK_STATUS_GATHER_RANGE);
+        return;
+    }
     dst[2 * j] = src[2 * s];
     dst[2 * j + 1] = src[2 * s + 1];
 }
@@ -269,9 +275,17 @@ int zkhip_r1cs_upload(zkhip_ctx *ctx, int curve, size_t num_constraints, size_t 
     r->N = num_variables;
     r->m = 1;
     r->log_m = 0;
-    while (r->m < r->M + r->n + 1) {  // make_evaluation_domain(num_constraints + num_inputs + 1), r1cs_to_qap.hpp:229-230
+    // make_evaluation_domain(num_constraints + num_inputs + 1), r1cs_to_qap.hpp:229-230.  ONLY the basic radix-2 domain
+    // (m = next power of two) exists here; crypto3-math may pick an extended / step radix-2 domain of another size for
+    // some M + n + 1 -- a key generated over such a domain has H_query.size() != m - 1 and is rejected by the shim's
+    // proving-key constructors (and omega of the wrong order by the NTT).
+    while (r->m < r->M + r->n + 1) {
         r->m <<= 1;
         ++r->log_m;
+    }
+    if (r->log_m > 32) {
+        delete r;
+        return ZKHIP_ERR_RANGE;
     }
     const uint32_t *rp[3] = {rowptr_a, rowptr_b, rowptr_c}, *cl[3] = {col_a, col_b, col_c};
     const uint64_t *cf[3] = {coeff_a, coeff_b, coeff_c};
@@ -297,12 +311,12 @@ void zkhip_r1cs_free(zkhip_ctx *ctx, zkhip_r1cs *r) {
     delete r;
 }
 
-int zkhip_fr_gather_dev(zkhip_ctx *ctx, const void *d_src, const void *d_indices, size_t count, void *d_dst) {
+int zkhip_fr_gather_dev(zkhip_ctx *ctx, const void *d_src, size_t src_count, const void *d_indices, size_t count, void *d_dst) {
     if (!ctx || (count && (!d_src || !d_indices || !d_dst))) return ZKHIP_ERR_INVALID;
     if (count == 0) return ZKHIP_OK;
     ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    ZK_LAUNCH(ctx, "fr_gather", fr_gather, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (const uint4 *)d_src, (const uint32_t *)d_indices,
-              count, (uint4 *)d_dst);
+    ZK_LAUNCH(ctx, "fr_gather", fr_gather, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (const uint4 *)d_src, src_count,
+              (const uint32_t *)d_indices, count, (uint4 *)d_dst, ctx->d_status);
     return ZKHIP_OK;
 }
 

@@ -133,17 +133,22 @@ __global__ __launch_bounds__(256) void msm_scan_add(uint32_t *__restrict__ offs,
 // The digit array is read twice per pass, no thread ever waits on a global atomic.
 static constexpr uint32_t SORT_TILE = 4096;  // digits per pass-1 tile (256 lanes x 16)
 
+// Window partition (wrank of wworld): the carry chain runs over all windows, only the digits of windows
+// w = wrank + k wworld are kept, as local window k.
 template <class FR>
-__global__ __launch_bounds__(256) void msm_digits_only(const uint32_t *__restrict__ scalars, uint32_t n, MsmWindows win,
-                                                       uint32_t *__restrict__ dig) {
+__global__ __launch_bounds__(256) void msm_digits_only(const uint32_t *__restrict__ scalars, uint32_t n, MsmWindows win, uint32_t wrank,
+                                                       uint32_t wworld, uint32_t *__restrict__ dig) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t s[8];
     const uint32_t flip = msm_fold_scalar<FR>(scalars + (size_t)i * 8, s) ? 0x80000000u : 0u;  // |s| <= (r - 1) / 2
-    uint32_t carry = 0;
+    uint32_t carry = 0, next = wrank, lw = 0;
     for (int w = 0; w < win.W; ++w) {
         uint32_t d = msm_recode(s, win.off(w), win.width(w), carry);
-        dig[(size_t)w * n + i] = d == DIG_NONE ? d : d ^ flip;
+        if ((uint32_t)w != next) continue;
+        dig[(size_t)lw * n + i] = d == DIG_NONE ? d : d ^ flip;
+        next += wworld;
+        ++lw;
     }
 }
 
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(256) void msm_size_scatter(const uint32_t *__restri
 // large[j] = {bucket, first task, task count}.
 __global__ __launch_bounds__(256) void msm_plan_large(const uint32_t *__restrict__ offs, uint32_t nbuckets, uint32_t *__restrict__ plan,
                                                       uint32_t *__restrict__ tasks, uint32_t *__restrict__ large, uint32_t task_cap,
-                                                      uint32_t large_cap, uint32_t thresh) {
+                                                      uint32_t large_cap, uint32_t thresh, uint32_t *__restrict__ status) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nbuckets) return;
     uint32_t lo = offs[g], hi = offs[g + 1], size = hi - lo;
@@ -336,7 +341,10 @@ __global__ __launch_bounds__(256) void msm_plan_large(const uint32_t *__restrict
     uint32_t nt = (size + MSM_LARGE_CHUNK - 1) / MSM_LARGE_CHUNK;
     uint32_t first = atomicAdd(&plan[0], nt);
     uint32_t slot = atomicAdd(&plan[1], 1u);
-    if (first + nt > task_cap || slot >= large_cap) return;  // cannot happen: capacities are worst-case (see host)
+    if (first + nt > task_cap || slot >= large_cap) {  // capacities are worst-case (see host): never expected, but never silent
+        atomicOr(status, ZK_STATUS_MSM_PLAN_OVERFLOW);
+        return;
+    }
     for (uint32_t t = 0; t < nt; ++t) {
         tasks[3 * (first + t)] = g;
         tasks[3 * (first + t) + 1] = lo + t * MSM_LARGE_CHUNK;
@@ -548,44 +556,50 @@ __global__ __launch_bounds__(64) void bases_mul(uint32_t *__restrict__ pts, cons
     affine_store<F>(pts + (size_t)i * (2 * NL), xyzz_to_affine(acc));
 }
 
-// Window tables: table w holds 2^(c w) P_i in affine form.  One lane per point: c doublings per table in
-// XYZZ, the W-1 intermediate points parked in `tmp`, one shared inversion (Montgomery's trick over the
-// lane's own W-1 denominators ZZ*ZZZ), then the affine results are written to their tables.
-// tmp: (W-1) x n entries of 5 field elements (X, Y, ZZ, ZZZ, prefix product).
+// Window tables: the table of window w holds 2^off(w) P_i in affine form.  One lane per point: width(w - 1) doublings
+// per window in XYZZ, the intermediate points of the windows THIS object keeps parked in `tmp`, one shared inversion
+// (Montgomery's trick over the lane's own denominators ZZ*ZZZ), then the affine results are written to their slots.
+// Window partition (wrank of wworld): only windows w = wrank + k wworld are kept, in slot k + (wrank != 0); slot 0 holds
+// the points themselves (= window 0, rank 0's).  tmp: kept x cnt entries of 5 field elements (X, Y, ZZ, ZZZ, prefix product).
 template <class F>
 __global__ __launch_bounds__(64) void bases_precompute_range(uint32_t *__restrict__ pts, uint32_t n, uint32_t lo, uint32_t cnt, MsmWindows win,
-                                                             uint32_t *__restrict__ tmp_base) {
+                                                             uint32_t wrank, uint32_t wworld, uint32_t *__restrict__ tmp) {
     const int W = win.W;
     typedef FieldOps<F> O;
     constexpr int NL = O::WORDS;
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;  // index inside the chunk
     if (j >= cnt) return;
     const uint32_t i = lo + j;
-    // tmp is laid out [w-1][j] over the chunk: shift so that the expressions below can use (w-1) * n + i
-    uint32_t *tmp = tmp_base;
+    const uint32_t extra = wrank != 0 ? 1u : 0u;
+    auto slot_ptr = [&](uint32_t w) { return pts + ((size_t)(w / wworld + extra) * n + i) * (2 * NL); };  // w mod wworld == wrank
     Affine<F> p = affine_load<F>(pts + (size_t)i * (2 * NL));
     if (p.is_inf()) {
-        for (int w = 1; w < W; ++w) affine_store<F>(pts + ((size_t)w * n + i) * (2 * NL), Affine<F>::infinity());
+        for (uint32_t w = (wrank != 0 ? wrank : wworld); w < (uint32_t)W; w += wworld) affine_store<F>(slot_ptr(w), Affine<F>::infinity());
         return;
     }
     XYZZ<F> acc = XYZZ<F>::from_affine(p);
     F pre = F::one();
+    uint32_t kept = 0;
     for (int w = 1; w < W; ++w) {
-        for (int k = 0; k < win.width(w - 1); ++k) acc = xyzz_dbl(acc);  // table w holds 2^off(w) P
-        uint32_t *slot = tmp + ((size_t)(w - 1) * cnt + j) * (5 * NL);
+        for (int k = 0; k < win.width(w - 1); ++k) acc = xyzz_dbl(acc);  // now 2^off(w) P
+        if ((uint32_t)w % wworld != wrank) continue;
+        uint32_t *slot = tmp + ((size_t)kept * cnt + j) * (5 * NL);
         xyzz_store<F>(slot, acc);
         pre = O::mul(pre, O::mul(acc.ZZ, acc.ZZZ));
         O::store(slot + 4 * NL, pre);
+        ++kept;
     }
-    F inv = O::inv(pre);  // 1 / prod_w (ZZ_w ZZZ_w)
-    for (int w = W - 1; w >= 1; --w) {
-        const uint32_t *slot = tmp + ((size_t)(w - 1) * cnt + j) * (5 * NL);
+    if (kept == 0) return;
+    F inv = O::inv(pre);  // 1 / prod (ZZ_w ZZZ_w) over the kept windows
+    uint32_t w = ((uint32_t)(W - 1) - wrank) / wworld * wworld + wrank;  // the last kept window (kept > 0: it is >= 1)
+    for (uint32_t k = kept; k-- > 0; w -= wworld) {
+        const uint32_t *slot = tmp + ((size_t)k * cnt + j) * (5 * NL);
         XYZZ<F> q = xyzz_load<F>(slot);
-        F before = w > 1 ? O::load(tmp + ((size_t)(w - 2) * cnt + j) * (5 * NL) + 4 * NL) : F::one();
+        F before = k > 0 ? O::load(tmp + ((size_t)(k - 1) * cnt + j) * (5 * NL) + 4 * NL) : F::one();
         F dinv = O::mul(inv, before);            // 1 / (ZZ_w ZZZ_w)
         inv = O::mul(inv, O::mul(q.ZZ, q.ZZZ));  // drop this factor
         Affine<F> a = {O::mul(q.X, O::mul(dinv, q.ZZZ)), O::mul(q.Y, O::mul(dinv, q.ZZ))};
-        affine_store<F>(pts + ((size_t)w * n + i) * (2 * NL), a);
+        affine_store<F>(slot_ptr(w), a);
     }
 }
 
@@ -734,15 +748,24 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     constexpr int NL = FieldOps<F>::WORDS;
     typedef typename BucketLane<F>::type FL;           // what a lane holds in the bucket / tail kernels
     constexpr int LPB = BucketLane<F>::LANES;          // lanes per point (2 for G2: fu2_pair.hpp)
-    const bool tables = bases->ntab > 1;
+    const bool tables = bases->tables();
     // window size: 2^(c-1) buckets per window.  With window tables c is fixed by the tables.
     int c = tables ? bases->c_tab : ctx->opt_msm_window_bits;
     if (c <= 0) c = zk_msm_auto_window(n);
-    c = std::max(2, std::min(16, c));
-    const int W = msm_windows(zk_scalar_bits(bases->curve), c);  // scalars are folded to |s| <= (r - 1) / 2: no carry out of window W - 1
-    const MsmWindows win = msm_make_windows(zk_scalar_bits(bases->curve), W);
+    c = std::max(2, std::min(ZK_MSM_MAX_C, c));
+    const int W_all = msm_windows(zk_scalar_bits(bases->curve), c);  // scalars are folded to |s| <= (r - 1) / 2: no carry out of the top window
+    const MsmWindows win = msm_make_windows(zk_scalar_bits(bases->curve), W_all);
+    // window partition over GPUs: this call handles the windows {w : w mod win_world == win_rank} only (all equal-weight thanks
+    // to the tables), W of them; everything after the digit extraction just sees W windows
+    const uint32_t wrank = tables ? (uint32_t)bases->win_rank : 0u, wworld = tables ? (uint32_t)bases->win_world : 1u;
+    const int W = tables ? bases->local_windows() : W_all;
     const uint32_t B = 1u << (c - 1);
     const uint32_t nb = (uint32_t)W * B;
+    // every sort offset / prefix sum / idx position is a u32 over the W * n digit entries
+    if ((uint64_t)W * n >= (1ull << 32)) {
+        ctx->last_error = "MSM of " + std::to_string(n) + " points x " + std::to_string(W) + " windows exceeds the 2^32-entry sort (split the range)";
+        return ZKHIP_ERR_RANGE;
+    }
     const int Wr = tables ? 1 : W;  // windows left after the equal-weight merge
     const uint32_t L = msm_tail_segment(ctx, B, tables ? 1 : W);  // buckets per tail segment
     const uint32_t tail_slots = MSM_TAIL_THREADS / BucketLane<F>::LANES;  // points per tail workgroup
@@ -799,12 +822,13 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     uint32_t *large = ctx->ws_take<uint32_t>((size_t)large_cap * 3);
     uint32_t *partials = ctx->ws_take<uint32_t>((size_t)task_cap * 4 * NL);
 
-    const uint32_t *d_b = bases->d + offset * bases->stride_u32;
     const size_t tab_stride_words = tables ? bases->n * bases->stride_u32 : 0;
+    const uint32_t *d_b = bases->d + offset * bases->stride_u32 + (tables ? (size_t)bases->slot_of_local(0) * tab_stride_words : 0);
 
     unsigned gn = (unsigned)((n + 255) / 256);
-    if (bases->curve == CURVE_BLS12_381) ZK_LAUNCH(ctx, "msm_digits", msm_digits_only<BlsFr>, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, win, dig);
-    else ZK_LAUNCH(ctx, "msm_digits", msm_digits_only<BnFr>, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, win, dig);
+    if (bases->curve == CURVE_BLS12_381) ZK_LAUNCH(ctx, "msm_digits", msm_digits_only<BlsFr>, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, win, wrank,
+                                                         wworld, dig);
+    else ZK_LAUNCH(ctx, "msm_digits", msm_digits_only<BnFr>, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, win, wrank, wworld, dig);
     ZK_LAUNCH(ctx, "msm_sort_hist", msm_sort_hist, dim3(ntile, W), dim3(256), 0, dig, (uint32_t)n, lowb, nsuper, ntile, bh);
     ZK_LAUNCH(ctx, "msm_scan", msm_scan_local, dim3(nblk), dim3(256), 0, bh, nbh, bo, bsums);
     ZK_LAUNCH(ctx, "msm_scan", msm_scan_top, dim3(1), dim3(1024), 0, bsums, nblk, bo + nbh);
@@ -835,7 +859,8 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     }
     // large buckets: plan on the device (no host round trip), then fixed-size grids that read the plan
     ZK_HIP_CHECK(ctx, hipMemsetAsync(plan, 0, 16, ctx->stream));
-    ZK_LAUNCH(ctx, "msm_plan_large", msm_plan_large, dim3((nb + 255) / 256), dim3(256), 0, offs, nb, plan, tasks, large, task_cap, large_cap, large_thresh);
+    ZK_LAUNCH(ctx, "msm_plan_large", msm_plan_large, dim3((nb + 255) / 256), dim3(256), 0, offs, nb, plan, tasks, large, task_cap, large_cap, large_thresh,
+              ctx->d_status);
     {
         size_t lds_large = (size_t)128 / LPB * 4 * NL * 4;
         if (lds_large > 48 * 1024) ZK_MAX_LDS(ctx, (msm_bucket_large<FL, LPB>), lds_large);
@@ -865,26 +890,27 @@ static int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, si
     return 0;
 }
 
-// Build tables 1..ntab-1 of a bases object whose table 0 is filled (called once at upload).
+// Build the window tables of a bases object whose slot 0 (the points) is filled (called once at upload).
 template <class F>
 static int bases_precompute_t(zkhip_ctx *ctx, zkhip_bases *b) {
     constexpr int NL = FieldOps<F>::WORDS;
-    const size_t chunk = 1u << 18;  // bounds the temporary to (ntab-1) * 2^18 * 5 field elements
-    size_t per = (size_t)(b->ntab - 1) * 5 * NL * 4;
+    const size_t chunk = 1u << 18;  // bounds the temporary to kept * 2^18 * 5 field elements
+    const int kept = b->local_windows() - (b->win_rank == 0 ? 1 : 0);  // window 0 is the points themselves
+    if (kept <= 0) return 0;
+    size_t per = (size_t)kept * 5 * NL * 4;
     ZK_TRY(ctx->ws_reserve(per * std::min(chunk, b->n) + 4096));
     for (size_t lo = 0; lo < b->n; lo += chunk) {
         size_t cnt = std::min(chunk, b->n - lo);
         ctx->ws_reset();
         uint32_t *tmp = ctx->ws_take<uint32_t>(per / 4 * cnt);
-        // the kernel indexes tables with stride n: hand it the sub-range through a shifted base pointer
         ZK_LAUNCH(ctx, "bases_precompute", bases_precompute_range<F>, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, b->d, (uint32_t)b->n,
-                  (uint32_t)lo, (uint32_t)cnt, msm_make_windows(zk_scalar_bits(b->curve), b->ntab), tmp);
+                  (uint32_t)lo, (uint32_t)cnt, msm_make_windows(zk_scalar_bits(b->curve), b->ntab), (uint32_t)b->win_rank, (uint32_t)b->win_world, tmp);
     }
     return 0;
 }
 
 int zk_bases_precompute(zkhip_ctx *ctx, zkhip_bases *b) {
-    if (b->ntab <= 1 || b->n == 0) return 0;
+    if (!b->tables() || b->n == 0) return 0;
     ZK_DISPATCH_CG(b->curve, b->group, return bases_precompute_t<F>(ctx, b));
     return 0;
 }
@@ -944,7 +970,7 @@ static int msm_batch_t(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *b
     ctx->ws_floor = ctx->ws_off;  // the per-MSM stages bump-allocate above the batch area
     int rc = 0;
     for (size_t i = 0; i < count && rc == 0; ++i) {
-        if (ns[i] == 0) {
+        if (ns[i] == 0 || bases[i]->local_windows() == 0) {
             hipError_t e = hipMemsetAsync(slots + i * slot_words, 0, slot_words * 4, ctx->stream);  // all buckets at infinity
             if (e != hipSuccess) rc = ZKHIP_ERR_HIP;
         } else {
@@ -997,6 +1023,8 @@ static void key_add_bases(std::string &k, const zkhip_bases *b) {
     key_add(k, b->n);
     key_add(k, b->c_tab);
     key_add(k, b->ntab);
+    key_add(k, b->win_rank);
+    key_add(k, b->win_world);
     key_add(k, b->curve);
     key_add(k, b->group);
 }
@@ -1075,7 +1103,7 @@ int zk_msm_run_batch(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bas
         key_add(key, ns[i]);
         key_add(key, d_scalars[i]);
         key_add(key, d_outs[i]);
-        uniform = uniform && bases[i]->ntab > 1 && bases[i]->curve == bases[0]->curve && bases[i]->group == bases[0]->group &&
+        uniform = uniform && bases[i]->tables() && bases[i]->curve == bases[0]->curve && bases[i]->group == bases[0]->group &&
                   bases[i]->c_tab == bases[0]->c_tab;
     }
     auto direct = [&]() { return zk_msm_run_batch_direct(ctx, count, bases, offsets, ns, d_scalars, d_outs); };
@@ -1097,7 +1125,7 @@ static int zk_msm_run_batch_direct(zkhip_ctx *ctx, size_t count, const zkhip_bas
         std::vector<const uint32_t *> gs;
         std::vector<uint32_t *> gd;
         for (size_t j = i; j < count; ++j) {
-            if (done[j] || bases[j]->ntab <= 1 || bases[i]->ntab <= 1 || bases[j]->curve != bases[i]->curve || bases[j]->group != bases[i]->group ||
+            if (done[j] || !bases[j]->tables() || !bases[i]->tables() || bases[j]->curve != bases[i]->curve || bases[j]->group != bases[i]->group ||
                 bases[j]->c_tab != bases[i]->c_tab)
                 continue;
             done[j] = 1;
@@ -1119,7 +1147,7 @@ static int zk_msm_run_batch_direct(zkhip_ctx *ctx, size_t count, const zkhip_bas
 
 int zk_msm_run(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac) {
     if (offset + n > bases->n) return ZKHIP_ERR_RANGE;
-    if (n == 0 || n >= (1ull << 31)) return zk_msm_run_direct(ctx, bases, offset, n, d_scalars, d_out_jac);
+    if (n == 0 || n >= (1ull << 31) || bases->win_world > 1) return zk_msm_run_direct(ctx, bases, offset, n, d_scalars, d_out_jac);
     std::string key = key_begin(ctx, 'S');
     key_add_bases(key, bases);
     key_add(key, offset);
@@ -1129,10 +1157,17 @@ int zk_msm_run(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n
     return zk_graph_run(ctx, key, [&]() { return zk_msm_run_direct(ctx, bases, offset, n, d_scalars, d_out_jac); });
 }
 
+// window partition: a rank with no window of its own (more ranks than windows, or too few points for tables: then rank 0
+// runs the whole MSM) contributes the point at infinity
+static bool msm_rank_idle(const zkhip_bases *b) {
+    if (b->win_world <= 1) return false;
+    return b->tables() ? b->local_windows() == 0 : b->win_rank != 0;
+}
+
 static int zk_msm_run_direct(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac) {
     if (offset + n > bases->n) return ZKHIP_ERR_RANGE;
     if (n >= (1ull << 31)) return ZKHIP_ERR_RANGE;
-    if (n == 0) {
+    if (n == 0 || msm_rank_idle(bases)) {
         ZK_DISPATCH_CG(bases->curve, bases->group, ZK_LAUNCH(ctx, "msm_write_infinity", msm_write_infinity<F>, dim3(1), dim3(64), 0, d_out_jac));
         return 0;
     }

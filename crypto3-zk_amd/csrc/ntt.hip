@@ -281,8 +281,27 @@ static int ntt_get_tables(zkhip_ctx *ctx, int curve, size_t log_m, const uint64_
         ZK_LAUNCH(ctx, "ntt_pow_table", ntt_pow_table<U>, dim3((nhi + 255) / 256), dim3(256), 0, t->d_base + U::SL, nhi, (uint32_t)t->lo_bits,
                   t->d_chi);
     }
+    // omega must be a PRIMITIVE m-th root of unity (the caller's evaluation domain is the basic radix-2 one): omega^m = 1
+    // and omega^(m/2) != 1, read back from the tables just built.  Anything else would transform over the wrong domain.
+    const size_t half = ((size_t)1 << log_m) >> 1;
+    uint32_t w_m[U::L], w_half[U::L];
+    const uint32_t *d_half = half < nlo ? t->d_lo + half * U::SL : t->d_hi + (half >> t->lo_bits) * U::SL;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(w_m, t->d_hi + (size_t)(nhi - 1) * U::SL, sizeof(w_m), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(w_half, d_half, sizeof(w_half), hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     (void)hipFree(d_in);
+    bool m_is_one = true, half_is_one = true;
+    for (int i = 0; i < U::L; ++i) {
+        m_is_one = m_is_one && w_m[i] == U::r1(i);
+        half_is_one = half_is_one && w_half[i] == U::r1(i);
+    }
+    if (!m_is_one || half_is_one) {
+        ctx->ntt_tables.pop_back();
+        (void)hipFree(t->d_lo), (void)hipFree(t->d_hi), (void)hipFree(t->d_clo), (void)hipFree(t->d_chi), (void)hipFree(t->d_scale), (void)hipFree(t->d_base);
+        delete t;
+        ctx->last_error = "omega is not a primitive 2^" + std::to_string(log_m) + "-th root of unity";
+        return ZKHIP_ERR_INVALID;
+    }
     *out = t;
     return 0;
 }

@@ -41,6 +41,11 @@ int zkhip_init(int device_id, zkhip_ctx **out) {
         return ZKHIP_ERR_HIP;
     }
     ctx->own_stream = true;
+    if (hipMalloc((void **)&ctx->d_status, 4) != hipSuccess || hipMemset(ctx->d_status, 0, 4) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return ZKHIP_ERR_OOM;
+    }
     *out = ctx;
     return ZKHIP_OK;
 }
@@ -61,6 +66,7 @@ void zkhip_destroy(zkhip_ctx *ctx) {
     zk_graphs_clear(ctx);
     if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -96,6 +102,21 @@ int zkhip_sync(zkhip_ctx *ctx) {
     return ZKHIP_OK;
 }
 
+int zkhip_device_status(zkhip_ctx *ctx, uint32_t *flags) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    uint32_t f = 0;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(&f, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (f) ZK_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
+    if (flags) *flags = f;
+    if (f) {
+        ctx->last_error = std::string("device status:") + ((f & ZK_STATUS_GATHER_RANGE) ? " gather index out of range;" : "") +
+                          ((f & ZK_STATUS_MSM_PLAN_OVERFLOW) ? " MSM large-bucket plan overflow;" : "");
+        return ZKHIP_ERR_RANGE;
+    }
+    return ZKHIP_OK;
+}
+
 int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return ZKHIP_ERR_INVALID;
     std::string n(name);
@@ -105,6 +126,14 @@ int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value) {
     else if (n == "ntt_tile_log") ctx->opt_ntt_tile_log = (int)value;
     else if (n == "msm_precompute") ctx->opt_msm_precompute = (int)value;
     else if (n == "msm_precompute_min") ctx->opt_msm_precompute_min = (int)value;
+    else if (n == "msm_shard_world") {
+        if (value < 1 || value > 64) return ZKHIP_ERR_RANGE;
+        ctx->opt_msm_shard_world = (int)value;
+        if (ctx->opt_msm_shard_rank >= ctx->opt_msm_shard_world) ctx->opt_msm_shard_rank = 0;
+    } else if (n == "msm_shard_rank") {
+        if (value < 0 || value >= ctx->opt_msm_shard_world) return ZKHIP_ERR_RANGE;
+        ctx->opt_msm_shard_rank = (int)value;
+    }
     else if (n == "msm_graphs") ctx->opt_msm_graphs = (int)value;
     else return ZKHIP_ERR_INVALID;
     return ZKHIP_OK;
@@ -169,17 +198,30 @@ static int bases_alloc(zkhip_ctx *ctx, int curve, int group, size_t n, zkhip_bas
     b->d = nullptr;
     b->ntab = 1;
     b->c_tab = 0;
+    b->nslots = 1;
+    const bool shard = ctx->opt_msm_shard_world > 1;
     if (ctx->opt_msm_precompute && n >= (size_t)ctx->opt_msm_precompute_min) {
-        b->c_tab = ctx->opt_msm_window_bits > 0 ? std::max(2, std::min(16, ctx->opt_msm_window_bits)) : zk_msm_auto_window(n);
+        b->c_tab = ctx->opt_msm_window_bits > 0 ? std::max(2, std::min(ZK_MSM_MAX_C, ctx->opt_msm_window_bits)) : zk_msm_auto_window(n);
         b->ntab = msm_windows(zk_scalar_bits(curve), b->c_tab);
+        if (shard) {
+            b->win_rank = ctx->opt_msm_shard_rank;
+            b->win_world = ctx->opt_msm_shard_world;
+        }
+        b->nslots = shard ? b->local_windows() + (b->win_rank != 0 ? 1 : 0) : b->ntab;
+        if (b->nslots < 1) b->nslots = 1;
+    } else if (shard) {
+        // too few points for tables: the whole (tiny) MSM is rank 0's, the other ranks contribute the point at infinity
+        b->win_rank = ctx->opt_msm_shard_rank;
+        b->win_world = ctx->opt_msm_shard_world;
     }
-    hipError_t e = hipMalloc((void **)&b->d, std::max<size_t>(1, n) * b->ntab * b->stride_u32 * 4);
-    if (e != hipSuccess && b->ntab > 1) {
+    hipError_t e = hipMalloc((void **)&b->d, std::max<size_t>(1, n) * b->nslots * b->stride_u32 * 4);
+    if (e != hipSuccess && b->tables() && !shard) {
         // the window tables do not fit (ntab x n points): keep the points alone; the MSM then folds the windows by the
         // Horner pass of msm_final instead of bucket-wise
         (void)hipGetLastError();
         b->ntab = 1;
         b->c_tab = 0;
+        b->nslots = 1;
         e = hipMalloc((void **)&b->d, std::max<size_t>(1, n) * b->stride_u32 * 4);
     }
     if (e != hipSuccess) {

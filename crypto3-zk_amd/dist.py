@@ -1,8 +1,12 @@
 """Multi-GPU sharding of the MSM path: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).
 
-The path shards by POINT RANGE: rank g owns bases / scalars [lo_g, hi_g), computes one partial sum with the
-full single-GPU pipeline, and the only exchange is one all-gather of the Jacobian partial results
-(3 coordinates x 48 B for BLS12-381 G1).  RCCL has no elliptic-curve reduction operator, so the "reduce" is
+Two partitions of one MSM, both ending in the same exchange:
+  * POINT RANGE: rank g owns bases / scalars [lo_g, hi_g) and computes their partial sum with the full single-GPU
+    pipeline (`shard_range`);
+  * WINDOWS: rank g holds, for ALL points, the window tables {w : w mod world == g} (`shard_windows`; the library
+    builds exactly those when the options msm_shard_rank / msm_shard_world are set at upload) and sums those
+    windows only -- the bucket-window shard BASELINE.json's north_star names.
+The only exchange is one all-gather of the Jacobian partial results (3 coordinates x 48 B for BLS12-381 G1).  RCCL has no elliptic-curve reduction operator, so the "reduce" is
 all-gather + a fold of `world` points on every rank (zkhip_jacobian_sum_dev).  The message is latency-bound
 (about a microsecond class transfer over xGMI), nothing here is bandwidth-bound.
 
@@ -21,6 +25,14 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     base, extra = divmod(n, world)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_windows(num_windows: int, rank: int, world: int) -> List[int]:
+    """Pippenger windows owned by `rank` under the window partition: w = rank, rank + world, ... (the tables are
+    equal-weight, so any assignment is balanced up to one window; ranks >= num_windows stay idle)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    return list(range(rank, num_windows, world))
 
 
 def shard_polys(batch: int, rank: int, world: int) -> List[int]:

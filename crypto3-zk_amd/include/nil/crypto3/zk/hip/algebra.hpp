@@ -74,9 +74,59 @@ struct fr_value {
         std::memcpy(r.limbs.data(), w, 32);
         return r;
     }
-    fr_value operator*(const fr_value &o) const { return from_mont(zkhip::FieldOps<F>::mul(mont(), o.mont())); }
-    fr_value operator+(const fr_value &o) const { return from_mont(zkhip::FieldOps<F>::add(mont(), o.mont())); }
-    fr_value operator-(const fr_value &o) const { return from_mont(zkhip::FieldOps<F>::template sub<zkhip::FieldOps<F>::K1>(mont(), o.mont())); }
+    /// a * b on canonical limbs: (a R) * b / R with ONE conversion -- the Montgomery product of the converted left operand
+    /// and the plain right operand is the canonical product (the same mixed-form trick the NTT kernels use).
+    fr_value operator*(const fr_value &o) const {
+        alignas(16) std::uint32_t w[8];
+        std::memcpy(w, o.limbs.data(), 32);
+        const F p = zkhip::fu_cond_sub_p(zkhip::fu_mul(mont(), zkhip::fu_unpack<typename F::params>(w)));
+        zkhip::fu_pack<typename F::params>(w, p);
+        fr_value r;
+        std::memcpy(r.limbs.data(), w, 32);
+        return r;
+    }
+    /// canonical + and -: plain 256-bit integer arithmetic with one conditional correction by r
+    fr_value operator+(const fr_value &o) const {
+        fr_value r;
+        unsigned __int128 c = 0;
+        for (int i = 0; i < 4; ++i) {
+            c += (unsigned __int128)limbs[i] + o.limbs[i];
+            r.limbs[i] = (std::uint64_t)c;
+            c >>= 64;
+        }
+        std::uint64_t d[4], mod[4];
+        modulus(mod);
+        if (!sub_limbs(d, r.limbs.data(), mod)) std::memcpy(r.limbs.data(), d, 32);    // r >= modulus (no carry out: 2 r < 2^256)
+        return r;
+    }
+    fr_value operator-(const fr_value &o) const {
+        fr_value r;
+        if (sub_limbs(r.limbs.data(), limbs.data(), o.limbs.data())) {    // borrowed: add the modulus back
+            std::uint64_t mod[4];
+            modulus(mod);
+            unsigned __int128 c = 0;
+            for (int i = 0; i < 4; ++i) {
+                c += (unsigned __int128)r.limbs[i] + mod[i];
+                r.limbs[i] = (std::uint64_t)c;
+                c >>= 64;
+            }
+        }
+        return r;
+    }
+    static void modulus(std::uint64_t *out) {
+        typedef typename F::params::sat P;
+        for (int i = 0; i < 4; ++i) out[i] = (std::uint64_t)P::mod(2 * i) | ((std::uint64_t)P::mod(2 * i + 1) << 32);
+    }
+    /// d = a - b; returns the borrow
+    static bool sub_limbs(std::uint64_t *d, const std::uint64_t *a, const std::uint64_t *b) {
+        std::uint64_t borrow = 0;
+        for (int i = 0; i < 4; ++i) {
+            const std::uint64_t t = a[i] - b[i], t2 = t - borrow;
+            borrow = (a[i] < b[i]) | (t < borrow);
+            d[i] = t2;
+        }
+        return borrow != 0;
+    }
     fr_value inversed() const { return from_mont(zkhip::FieldOps<F>::inv(mont())); }
 };
 
@@ -183,6 +233,8 @@ struct curve_adapter<native_curve<Curve>> {
         std::memcpy(s.limbs.data(), in, 32);
         return s;
     }
+    /// the scalar-field modulus r, canonical little-endian limbs (what rejection sampling of the blinders compares against)
+    static void scalar_modulus(std::uint64_t *out) { scalar_value_type::modulus(out); }
     template <typename G>
     static bool point_to_affine_limbs(const G &p, std::uint64_t *out) { return p.to_affine(out); }
     static g1_value_type g1_from_jacobian(const std::uint64_t *xyz) { return g1_value_type::from_jacobian(xyz); }

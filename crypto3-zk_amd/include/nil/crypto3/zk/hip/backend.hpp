@@ -7,11 +7,14 @@
 #ifndef ZKHIP_SHIM_BACKEND_HPP
 #define ZKHIP_SHIM_BACKEND_HPP
 
+#include <cerrno>
 #include <cstdint>
 #include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+#include <sys/random.h>
 
 #include "algebra.hpp"
 
@@ -19,6 +22,22 @@ namespace nil {
 namespace crypto3 {
 namespace zk {
 namespace hip {
+
+namespace detail {
+    /// `bytes` bytes from the kernel's CSPRNG (getrandom(2), blocking until the pool is initialised); throws on failure
+    inline void os_random_bytes(void *out, std::size_t bytes) {
+        unsigned char *p = static_cast<unsigned char *>(out);
+        while (bytes) {
+            const ssize_t k = getrandom(p, bytes, 0);
+            if (k < 0) {
+                if (errno == EINTR) continue;
+                throw std::runtime_error("getrandom failed: no entropy source for the prover's blinding factors");
+            }
+            p += k;
+            bytes -= (std::size_t)k;
+        }
+    }
+}    // namespace detail
 
 inline void check(int rc, const char *what, const zkhip_ctx *ctx = nullptr) {
     if (rc != ZKHIP_OK) {

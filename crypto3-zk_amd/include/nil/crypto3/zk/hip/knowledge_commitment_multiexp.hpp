@@ -73,7 +73,7 @@ element_kc<CurveType> kc_multiexp_with_mixed_addition(const device_kc_vector<Cur
     auto d_sel = ctx.alloc(count * 32);
     const char *src = static_cast<const char *>(d_s.get()) - 32 * min_idx;
     const char *idx = static_cast<const char *>(vec.d_indices.get()) + 4 * lo;
-    check(zkhip_fr_gather_dev(ctx.get(), src, idx, count, d_sel.get()), "zkhip_fr_gather_dev", ctx.get());
+    check(zkhip_fr_gather_dev(ctx.get(), src, min_idx + scalar_length, idx, count, d_sel.get()), "zkhip_fr_gather_dev", ctx.get());
     acc.g = multiexp_dev<CurveType, ZKHIP_G2>(ctx, vec.g_bases, lo, count, d_sel.get());
     acc.h = multiexp_dev<CurveType, ZKHIP_G1>(ctx, vec.h_bases, lo, count, d_sel.get());
     return acc;

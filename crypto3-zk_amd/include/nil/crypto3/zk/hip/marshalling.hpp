@@ -85,6 +85,8 @@ std::unique_ptr<loaded_proving_key<CurveType>> proving_key_from_bytes(const cont
     detail::byte_reader rb {rd.take(b_bytes), nullptr};
     rb.end = rb.p + b_bytes;
     const std::size_t b_count = rb.u32();
+    /* count, b_count indices, b_count (g, h) pairs, domain size: checked BEFORE anything is sized from the count */
+    if (b_count > (b_bytes - 8) / (4 + G2B + G1B) || b_bytes < 8) throw std::runtime_error("proving key blob: B query count exceeds its byte length");
     std::vector<std::uint32_t> b_indices(b_count);
     for (auto &i : b_indices) i = (std::uint32_t)rb.u32();
     std::vector<std::uint8_t> bg(b_count * G2B), bh(b_count * G1B);

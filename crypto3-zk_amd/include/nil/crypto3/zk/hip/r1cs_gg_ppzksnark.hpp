@@ -11,8 +11,8 @@
 // `r1cs_gg_ppzksnark_prover_hip<CurveType>::process(pk, primary_input, auxiliary_input)` has the reference's
 // static signature; the facade `r1cs_gg_ppzksnark<...>` insists on the exact reference prover type
 // (r1cs_gg_ppzksnark.hpp:50-59, 112-115), so the sibling class is called directly.
-// The overload taking (r, s) makes proofs reproducible; the three-argument form draws them at random exactly
-// like prover.hpp:92-93.
+// The overload taking (r, s) exists for TESTS (reproducible proofs); the three-argument form draws the blinders from
+// the operating system's CSPRNG, as prover.hpp:92-93 draws them with algebra::random_element.
 //---------------------------------------------------------------------------//
 #ifndef ZKHIP_SHIM_R1CS_GG_PPZKSNARK_HPP
 #define ZKHIP_SHIM_R1CS_GG_PPZKSNARK_HPP
@@ -20,7 +20,8 @@
 #include <algorithm>
 #include <future>
 #include <memory>
-#include <random>
+#include <stdexcept>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -117,12 +118,16 @@ template <typename CurveType>
 class device_r1cs {
 public:
     typedef curve_adapter<CurveType> adapter;
-    device_r1cs(const context &ctx, const r1cs_constraint_system<CurveType> &cs) : ctx_(&ctx) {
+    /// `ConstraintSystem` is duck-typed on the reference's member names (r1cs.hpp:61-64, 125-133): `constraints[i].{a,b,c}.terms[j].
+    /// {index, coeff}`, `num_constraints()`, `num_inputs()`, `num_variables()` -- the reference's own r1cs_constraint_system
+    /// is consumed as it is (coefficients go through curve_adapter::scalar_to_limbs), no look-alike copy.
+    template <typename ConstraintSystem>
+    device_r1cs(const context &ctx, const ConstraintSystem &cs) : ctx_(&ctx) {
         std::vector<std::uint32_t> rp[3], cl[3];
         std::vector<std::uint64_t> cf[3];
         for (int k = 0; k < 3; ++k) rp[k].push_back(0);
         for (const auto &c : cs.constraints) {
-            const linear_combination<CurveType> *lc[3] = {&c.a, &c.b, &c.c};
+            const decltype(c.a) *lc[3] = {&c.a, &c.b, &c.c};
             for (int k = 0; k < 3; ++k) {
                 for (const auto &t : lc[k]->terms) {
                     cl[k].push_back((std::uint32_t)t.index);
@@ -225,11 +230,15 @@ struct query_shard {
 };
 
 // ---- proving key with its device-resident queries -------------------------------------------------------------
-template <typename CurveType>
+/// `KeyType` is duck-typed on the reference's member names (proving_key.hpp:43-56): alpha_g1, beta_g1, beta_g2, delta_g1,
+/// delta_g2, A_query, B_query.{indices, values[i].{g, h}, domain_size_}, H_query, L_query, constraint_system -- a key
+/// object of the reference is consumed where it lies (its group / field values go through curve_adapter), the shim's
+/// own r1cs_gg_ppzksnark_proving_key is just the default.
+template <typename CurveType, typename KeyType = r1cs_gg_ppzksnark_proving_key<CurveType>>
 class r1cs_gg_ppzksnark_proving_key_hip {
 public:
     typedef curve_adapter<CurveType> adapter;
-    typedef r1cs_gg_ppzksnark_proving_key<CurveType> host_key_type;
+    typedef KeyType host_key_type;
 
     /// Rank `rank` of `world`: uploads only this rank's slice of the four queries (and the whole constraint system:
     /// the witness map is replicated).  Proofs then go through prover::process_partial + an all-gather of the partial
@@ -237,48 +246,21 @@ public:
     r1cs_gg_ppzksnark_proving_key_hip(const context &ctx, const host_key_type &pk, const domain_params<CurveType> &dom, std::size_t rank,
                                       std::size_t world) :
         ctx(ctx), host(pk), domain(dom), constraint_system(ctx, pk.constraint_system) {
+        check_host_key(pk);
         const std::size_t N = pk.constraint_system.num_variables(), n = pk.constraint_system.num_inputs();
         shard = query_shard::make(rank, world, N + 1, pk.B_query.values.size(), constraint_system.domain_size() - 1, N - n);
         A_query = device_bases<CurveType, ZKHIP_G1>(ctx, pk.A_query.begin() + shard.A_lo, pk.A_query.begin() + shard.A_lo + shard.A_n);
         H_query = device_bases<CurveType, ZKHIP_G1>(ctx, pk.H_query.begin() + shard.H_lo, pk.H_query.begin() + shard.H_lo + shard.H_n);
         L_query = device_bases<CurveType, ZKHIP_G1>(ctx, pk.L_query.begin() + shard.L_lo, pk.L_query.begin() + shard.L_lo + shard.L_n);
-        std::vector<typename adapter::g2_value_type> g;
-        std::vector<typename adapter::g1_value_type> h;
-        std::vector<std::uint32_t> idx;
-        for (std::size_t i = shard.B_lo; i < shard.B_lo + shard.B_n; ++i) {
-            g.push_back(pk.B_query.values[i].g);
-            h.push_back(pk.B_query.values[i].h);
-            idx.push_back((std::uint32_t)pk.B_query.indices[i]);
-        }
-        B_query_g = device_bases<CurveType, ZKHIP_G2>(ctx, g.begin(), g.end());
-        B_query_h = device_bases<CurveType, ZKHIP_G1>(ctx, h.begin(), h.end());
-        d_B_indices = ctx.alloc(std::max<std::size_t>(1, idx.size()) * 4);
-        if (!idx.empty()) ctx.h2d(d_B_indices.get(), idx.data(), idx.size() * 4);
-        B_count = idx.size();
+        upload_b_query(pk, shard.B_lo, shard.B_n);
     }
 
     /// Uploads the four queries and the constraint system once; proofs then only move the assignment.
     r1cs_gg_ppzksnark_proving_key_hip(const context &ctx, const host_key_type &pk, const domain_params<CurveType> &dom) :
-        ctx(ctx), host(pk), domain(dom), A_query(ctx, pk.A_query.begin(), pk.A_query.end()), H_query(ctx, pk.H_query.begin(), pk.H_query.end()),
-        L_query(ctx, pk.L_query.begin(), pk.L_query.end()), constraint_system(ctx, pk.constraint_system) {
-        std::vector<typename adapter::g2_value_type> g;
-        std::vector<typename adapter::g1_value_type> h;
-        std::vector<std::uint32_t> idx;
-        for (std::size_t i = 0; i < pk.B_query.values.size(); ++i) {
-            g.push_back(pk.B_query.values[i].g);
-            h.push_back(pk.B_query.values[i].h);
-            idx.push_back((std::uint32_t)pk.B_query.indices[i]);
-        }
-        B_query_g = device_bases<CurveType, ZKHIP_G2>(ctx, g.begin(), g.end());
-        B_query_h = device_bases<CurveType, ZKHIP_G1>(ctx, h.begin(), h.end());
-        d_B_indices = ctx.alloc(std::max<std::size_t>(1, idx.size()) * 4);
-        if (!idx.empty()) ctx.h2d(d_B_indices.get(), idx.data(), idx.size() * 4);
-        B_count = idx.size();
-        set_full_shard();
-    }
+        r1cs_gg_ppzksnark_proving_key_hip(ctx, pk, dom, 0, 1) {}
 
-    /// Adopts queries that already live on the device (e.g. produced by device_bases::from_scalars); `pk` supplies
-    /// the five single group elements and the constraint system, its query vectors are not read.
+    /// Adopts queries that already live on the device (e.g. produced by device_bases::from_scalars or decoded from the
+    /// wire form); `pk` supplies the five single group elements and the constraint system, its query vectors are not read.
     r1cs_gg_ppzksnark_proving_key_hip(const context &ctx, const host_key_type &pk, const domain_params<CurveType> &dom,
                                       device_bases<CurveType, ZKHIP_G1> &&a_query, device_bases<CurveType, ZKHIP_G2> &&b_query_g,
                                       device_bases<CurveType, ZKHIP_G1> &&b_query_h, const std::vector<std::uint32_t> &b_indices,
@@ -286,11 +268,16 @@ public:
                                       const query_shard *slice = nullptr) :
         ctx(ctx), host(pk), domain(dom), A_query(std::move(a_query)), H_query(std::move(h_query)), L_query(std::move(l_query)),
         B_query_h(std::move(b_query_h)), B_query_g(std::move(b_query_g)), constraint_system(ctx, pk.constraint_system) {
+        const std::size_t N = pk.constraint_system.num_variables(), n = pk.constraint_system.num_inputs();
+        check_b_indices(b_indices.begin(), b_indices.end(), N);
+        if (B_query_g.size() != b_indices.size() || B_query_h.size() != b_indices.size())
+            throw std::invalid_argument("proving key: the B query's index list and its (g, h) values differ in length");
         d_B_indices = ctx.alloc(std::max<std::size_t>(1, b_indices.size()) * 4);
         if (!b_indices.empty()) ctx.h2d(d_B_indices.get(), b_indices.data(), b_indices.size() * 4);
         B_count = b_indices.size();
         if (slice) shard = *slice;    // the adopted bases are this rank's slices
-        else set_full_shard();
+        else shard = query_shard::make(0, 1, N + 1, B_count, constraint_system.domain_size() - 1, N - n);
+        if (A_query.size() != shard.A_n || H_query.size() != shard.H_n || L_query.size() != shard.L_n) throw_query_sizes();
     }
 
     const context &ctx;
@@ -328,15 +315,56 @@ public:
     }
 
 private:
-    void set_full_shard() {
-        const std::size_t N = host.constraint_system.num_variables(), n = host.constraint_system.num_inputs();
-        shard = query_shard::make(0, 1, N + 1, B_count, constraint_system.domain_size() - 1, N - n);
+    /// The key must have been generated over the BASIC radix-2 domain of size m = 2^ceil(log2(M + n + 1)) (the only one this
+    /// backend transforms over; crypto3-math's extended / step radix-2 domains have other sizes): H_query has m - 1
+    /// entries, A_query N + 1, L_query N - n, and the sparse B query's indices are strictly increasing and <= N.
+    void check_host_key(const host_key_type &pk) const {
+        const std::size_t N = pk.constraint_system.num_variables(), n = pk.constraint_system.num_inputs(), m = constraint_system.domain_size();
+        if (pk.H_query.size() != m - 1)
+            throw std::invalid_argument("proving key: H_query has " + std::to_string(pk.H_query.size()) + " entries, the basic radix-2 domain of size " +
+                                        std::to_string(m) + " needs " + std::to_string(m - 1) +
+                                        " (keys generated over an extended / step radix-2 domain are not supported)");
+        if (pk.A_query.size() != N + 1 || pk.L_query.size() != N - n) throw_query_sizes();
+        if (pk.B_query.indices.size() != pk.B_query.values.size())
+            throw std::invalid_argument("proving key: the B query's index list and its values differ in length");
+        check_b_indices(pk.B_query.indices.begin(), pk.B_query.indices.end(), N);
+    }
+    template <typename It>
+    static void check_b_indices(It first, It last, std::size_t N) {
+        bool have = false;
+        std::size_t prev = 0;
+        for (It it = first; it != last; ++it) {
+            const std::size_t i = (std::size_t)*it;
+            if (i > N || (have && i <= prev)) throw std::invalid_argument("proving key: B query indices must be strictly increasing and <= num_variables");
+            prev = i;
+            have = true;
+        }
+    }
+    [[noreturn]] static void throw_query_sizes() {
+        throw std::invalid_argument("proving key: query sizes do not match the constraint system (A: N + 1, H: m - 1, L: N - n entries, or the slice of them)");
+    }
+    void upload_b_query(const host_key_type &pk, std::size_t lo, std::size_t cnt) {
+        std::vector<typename adapter::g2_value_type> g;
+        std::vector<typename adapter::g1_value_type> h;
+        std::vector<std::uint32_t> idx;
+        for (std::size_t i = lo; i < lo + cnt; ++i) {
+            g.push_back(pk.B_query.values[i].g);
+            h.push_back(pk.B_query.values[i].h);
+            idx.push_back((std::uint32_t)pk.B_query.indices[i]);
+        }
+        B_query_g = device_bases<CurveType, ZKHIP_G2>(ctx, g.begin(), g.end());
+        B_query_h = device_bases<CurveType, ZKHIP_G1>(ctx, h.begin(), h.end());
+        d_B_indices = ctx.alloc(std::max<std::size_t>(1, idx.size()) * 4);
+        if (!idx.empty()) ctx.h2d(d_B_indices.get(), idx.data(), idx.size() * 4);
+        B_count = idx.size();
     }
     mutable std::size_t work_cpa_ = 0;
 };
 
 // ---- r1cs_gg_ppzksnark_prover<CurveType, basic>::process -------------------------------------------------------
-template <typename CurveType>
+/// `KeyType` / `ProofType`: the host-side key the device key was built from and the proof type to return (the
+/// reference's r1cs_gg_ppzksnark_proving_key / r1cs_gg_ppzksnark_proof, proof.hpp:41-46: constructible from (g_A, g_B, g_C)).
+template <typename CurveType, typename KeyType = r1cs_gg_ppzksnark_proving_key<CurveType>, typename ProofType = r1cs_gg_ppzksnark_proof<CurveType>>
 class r1cs_gg_ppzksnark_prover_hip {
     typedef curve_adapter<CurveType> adapter;
 
@@ -344,8 +372,8 @@ public:
     typedef typename adapter::scalar_value_type scalar_value_type;
     typedef std::vector<scalar_value_type> primary_input_type;
     typedef std::vector<scalar_value_type> auxiliary_input_type;
-    typedef r1cs_gg_ppzksnark_proving_key_hip<CurveType> proving_key_type;
-    typedef r1cs_gg_ppzksnark_proof<CurveType> proof_type;
+    typedef r1cs_gg_ppzksnark_proving_key_hip<CurveType, KeyType> proving_key_type;
+    typedef ProofType proof_type;
 
     static proof_type process(const proving_key_type &proving_key, const primary_input_type &primary_input,
                               const auxiliary_input_type &auxiliary_input) {
@@ -455,7 +483,7 @@ private:
               "zkhip_groth16_witness_h_dev", ctx.get());
         /* evaluation_Bt: kc_multiexp_with_mixed_addition over the sparse (G2, G1) query (prover.hpp:116-123); a sharded key
            holds a slice of the index list */
-        check(zkhip_fr_gather_dev(ctx.get(), cpa, pk.d_B_indices.get(), pk.B_count, pk.d_bs.get()), "zkhip_fr_gather_dev", ctx.get());
+        check(zkhip_fr_gather_dev(ctx.get(), cpa, num_variables + 1, pk.d_B_indices.get(), pk.B_count, pk.d_bs.get()), "zkhip_fr_gather_dev", ctx.get());
         if (pk.side) {
             /* the G2 part on the second stream, after the gather; the four G1 multiexps below do not depend on it */
             pk.side->wait_for(ctx);
@@ -480,6 +508,9 @@ private:
         std::vector<std::uint64_t> res(partial_limbs());
         if (pk.side) pk.ctx.wait_for(*pk.side);
         pk.ctx.d2h(res.data(), pk.d_results.get(), res.size() * 8);
+        /* kernels flag what they cannot signal otherwise (a B-query index beyond the assignment, a plan overflow) */
+        check(zkhip_device_status(pk.ctx.get(), nullptr), "zkhip_device_status", pk.ctx.get());
+        if (pk.side) check(zkhip_device_status(pk.side->get(), nullptr), "zkhip_device_status", pk.side->get());
         return res;
     }
     /// fold the ranks' partial sums and build the proof (prover.hpp:141-157)
@@ -507,18 +538,28 @@ private:
         return proof_type {g1_A, g2_B, g1_C};
     }
 
+public:
+    /// Uniform element of Fr from the operating system's CSPRNG (getrandom(2)): bitlen(r) random bits, rejection
+    /// sampled below r.  No generator state: nothing links the blinders of two proofs and concurrent provers do
+    /// not share anything.  (The reference: algebra::random_element<scalar_field_type>(), prover.hpp:92-93.)
     static scalar_value_type random_scalar() {
-        static std::random_device rd;
-        static std::mt19937_64 gen(rd());
-        // uniform via two products: (a * b + c) of independent 255-bit draws reduced by the field arithmetic
-        std::uint64_t w[4];
-        auto draw = [&]() {
-            for (auto &x : w) x = gen();
-            w[3] &= 0x0fffffffffffffffULL;    // < 2^252 < r for both curves: already canonical
-            return adapter::scalar_from_limbs(w);
-        };
-        scalar_value_type a = draw(), b = draw(), c = draw();
-        return a * b + c;
+        std::uint64_t mod[4], w[4];
+        adapter::scalar_modulus(mod);
+        int top = 63;
+        while (top > 0 && !((mod[3] >> top) & 1)) --top;
+        const std::uint64_t mask = top == 63 ? ~(std::uint64_t)0 : (((std::uint64_t)1 << (top + 1)) - 1);
+        for (;;) {
+            detail::os_random_bytes(w, sizeof(w));
+            w[3] &= mask;
+            bool lt = false;
+            for (int i = 3; i >= 0; --i) {
+                if (w[i] != mod[i]) {
+                    lt = w[i] < mod[i];
+                    break;
+                }
+            }
+            if (lt) return adapter::scalar_from_limbs(w);
+        }
     }
 };
 

@@ -1,0 +1,268 @@
+//---------------------------------------------------------------------------//
+// zkhip shim: Groth16 key generation with the queries computed ON THE DEVICE.
+//
+// Mirrors
+//   reductions::r1cs_to_qap<F>::instance_map_with_evaluation     zk/snark/reductions/r1cs_to_qap.hpp:138-187
+//   r1cs_gg_ppzksnark_generator::deterministic_basic_process     .../r1cs_gg_ppzksnark/generator.hpp:240-377
+//   r1cs_constraint_system::swap_AB_if_beneficial                .../constraint_satisfaction_problems/r1cs.hpp:192-215
+// The reference evaluates the QAP at t on the host (O(nnz + m) field operations) and then runs five fixed-base
+// batch exponentiations (algebra::batch_exp / kc_batch_exp over a window table, generator.hpp:187-214) -- the
+// part that costs minutes at 2^20 constraints.  Here the host part is the same arithmetic (spread over a few
+// threads) and every batch exponentiation is one zkhip_bases_from_scalars call whose result STAYS on the device as
+// the proving key's query (A, B.g, B.h, H, L), ready for the prover: no point ever crosses PCIe.
+//
+// `deterministic_basic_process` takes the toxic waste (t, alpha, beta, gamma, delta) as arguments, exactly like the
+// reference's testing entry point; `basic_process` draws it from the operating system's CSPRNG.  The group
+// generators are the standard ones (the reference draws random generators, generator.hpp:161,172: any generator
+// yields a valid key).  gamma only enters the verification key, which this backend does not build (verifier and
+// pairings are out of scope); it is accepted for signature parity.
+//---------------------------------------------------------------------------//
+#ifndef ZKHIP_SHIM_R1CS_GG_PPZKSNARK_GENERATOR_HPP
+#define ZKHIP_SHIM_R1CS_GG_PPZKSNARK_GENERATOR_HPP
+
+#include <algorithm>
+#include <array>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#include "r1cs_gg_ppzksnark.hpp"
+
+namespace nil {
+namespace crypto3 {
+namespace zk {
+namespace hip {
+
+namespace detail {
+    /// fn(lo, hi) over [0, n) in contiguous chunks on up to 32 host threads (the QAP evaluation is embarrassingly parallel)
+    template <typename Fn>
+    void parallel_chunks(std::size_t n, Fn fn) {
+        const std::size_t hw = std::max<std::size_t>(1, std::min<std::size_t>(32, std::thread::hardware_concurrency()));
+        const std::size_t parts = n < (std::size_t)1 << 14 ? 1 : hw, per = (n + parts - 1) / parts;
+        std::vector<std::thread> th;
+        for (std::size_t k = 1; k < parts; ++k)
+            if (k * per < n) th.emplace_back([=]() { fn(k * per, std::min(n, (k + 1) * per)); });
+        fn(0, std::min(n, per));
+        for (auto &t : th) t.join();
+    }
+    template <typename Fr>
+    Fr pow_u64(Fr b, std::uint64_t e) {
+        Fr r = Fr::one();
+        for (; e; e >>= 1) {
+            if (e & 1) r = r * b;
+            b = b * b;
+        }
+        return r;
+    }
+}    // namespace detail
+
+/// qap_instance_evaluation (reductions/qap.hpp) restricted to what the generator reads
+template <typename CurveType>
+struct qap_instance_evaluation_hip {
+    typedef typename curve_adapter<CurveType>::scalar_value_type value_type;
+    std::size_t num_variables = 0, degree = 0, num_inputs = 0;
+    value_type t, Zt;
+    std::vector<value_type> At, Bt, Ct, Ht;    // N + 1 each; Ht = (1, t, ..., t^m)
+};
+
+/// r1cs_to_qap<F>::instance_map_with_evaluation(cs, t) over the basic radix-2 domain of size m = 2^ceil(log2(M + n + 1))
+/// with primitive root `omega` (r1cs_to_qap.hpp:138-187).  `ConstraintSystem` is duck-typed like device_r1cs.
+template <typename CurveType, typename ConstraintSystem>
+qap_instance_evaluation_hip<CurveType> instance_map_with_evaluation(const ConstraintSystem &cs, const typename curve_adapter<CurveType>::scalar_value_type &t,
+                                                                    const typename curve_adapter<CurveType>::scalar_value_type &omega) {
+    typedef typename curve_adapter<CurveType>::scalar_value_type Fr;
+    const std::size_t M = cs.num_constraints(), n = cs.num_inputs(), N = cs.num_variables();
+    std::size_t m = 1;
+    while (m < M + n + 1) m <<= 1;
+    qap_instance_evaluation_hip<CurveType> q;
+    q.num_variables = N;
+    q.degree = m;
+    q.num_inputs = n;
+    q.t = t;
+    q.Zt = detail::pow_u64(t, m) - Fr::one();    // compute_vanishing_polynomial(t) = t^m - 1
+    /* evaluate_all_lagrange_polynomials(t): u_i = Z(t) omega^i / (m (t - omega^i)); one inversion per chunk (Montgomery's
+       trick).  t on the domain itself (probability m / r) would make one u_i = 1 and the rest 0: the closed form does not
+       cover it and a trapdoor must not lie there anyway. */
+    if (q.Zt.is_zero()) throw std::invalid_argument("instance_map_with_evaluation: t lies in the evaluation domain");
+    std::vector<Fr> u(m);
+    const Fr z_over_m = q.Zt * Fr((std::uint64_t)m).inversed();
+    detail::parallel_chunks(m, [&](std::size_t lo, std::size_t hi) {
+        std::vector<Fr> pre(hi - lo);
+        Fr x = detail::pow_u64(omega, lo), acc = Fr::one();
+        for (std::size_t i = lo; i < hi; ++i) {
+            u[i] = x;    // omega^i for now
+            pre[i - lo] = acc;
+            acc = acc * (t - x);
+            x = x * omega;
+        }
+        Fr inv = acc.inversed();
+        for (std::size_t i = hi; i-- > lo;) {
+            const Fr den = t - u[i];
+            u[i] = u[i] * z_over_m * (inv * pre[i - lo]);
+            inv = inv * den;
+        }
+    });
+    q.At.assign(N + 1, Fr::zero());
+    q.Bt.assign(N + 1, Fr::zero());
+    q.Ct.assign(N + 1, Fr::zero());
+    /* the constraints input_i * 0 = 0 that make the input consistent (r1cs_to_qap.hpp:160-162) */
+    for (std::size_t i = 0; i <= n; ++i) q.At[i] = u[M + i];
+    for (std::size_t i = 0; i < M; ++i) {
+        const auto &c = cs.constraints[i];
+        for (const auto &term : c.a.terms) q.At[term.index] = q.At[term.index] + u[i] * term.coeff;
+        for (const auto &term : c.b.terms) q.Bt[term.index] = q.Bt[term.index] + u[i] * term.coeff;
+        for (const auto &term : c.c.terms) q.Ct[term.index] = q.Ct[term.index] + u[i] * term.coeff;
+    }
+    q.Ht.resize(m + 1);
+    detail::parallel_chunks(m + 1, [&](std::size_t lo, std::size_t hi) {
+        Fr ti = detail::pow_u64(t, lo);
+        for (std::size_t i = lo; i < hi; ++i) {
+            q.Ht[i] = ti;
+            ti = ti * t;
+        }
+    });
+    return q;
+}
+
+/// A generated key: the host part (five group elements + the constraint system the prover's witness map runs over, A / B
+/// swapped when that makes the B query lighter) and the device part (the resident queries).  `device` refers to `host`.
+template <typename CurveType>
+struct generated_proving_key {
+    r1cs_gg_ppzksnark_proving_key<CurveType> host;    // its query vectors stay empty: the queries live on the device
+    std::unique_ptr<r1cs_gg_ppzksnark_proving_key_hip<CurveType>> device;
+};
+
+template <typename CurveType>
+class r1cs_gg_ppzksnark_generator_hip {
+    typedef curve_adapter<CurveType> adapter;
+
+public:
+    typedef typename adapter::scalar_value_type scalar_value_type;
+    typedef r1cs_constraint_system<CurveType> constraint_system_type;
+
+    /// generator.hpp:240-377 (testing entry point: the toxic waste is an argument)
+    static std::unique_ptr<generated_proving_key<CurveType>> deterministic_basic_process(const context &ctx, const constraint_system_type &constraint_system,
+                                                                                         const domain_params<CurveType> &dom, const scalar_value_type &t,
+                                                                                         const scalar_value_type &alpha, const scalar_value_type &beta,
+                                                                                         const scalar_value_type & /*gamma*/, const scalar_value_type &delta,
+                                                                                         std::size_t rank = 0, std::size_t world = 1) {
+        typedef scalar_value_type Fr;
+        std::unique_ptr<generated_proving_key<CurveType>> key(new generated_proving_key<CurveType>());
+        auto &pk = key->host;
+        /* Make the B_query "lighter" if possible (generator.hpp:250-252) */
+        pk.constraint_system = constraint_system;
+        swap_AB_if_beneficial(pk.constraint_system);
+        const Fr delta_inverse = delta.inversed();
+        /* A quadratic arithmetic program evaluated at t. */
+        const auto qap = instance_map_with_evaluation<CurveType>(pk.constraint_system, t, dom.omega);
+        const std::size_t N = qap.num_variables, n = qap.num_inputs, m = qap.degree;
+        /* The delta inverse product component: (beta*A_i(t) + alpha*B_i(t) + C_i(t)) * delta^{-1} (generator.hpp:296-304) */
+        std::vector<Fr> Lt(N - n);
+        detail::parallel_chunks(N - n, [&](std::size_t lo, std::size_t hi) {
+            for (std::size_t i = lo; i < hi; ++i) Lt[i] = (beta * qap.At[n + 1 + i] + alpha * qap.Bt[n + 1 + i] + qap.Ct[n + 1 + i]) * delta_inverse;
+        });
+        /* H for Groth's proof system is degree d - 2: Ht loses its top two entries (:310-315); coefficient Zt / delta (:353-355) */
+        std::vector<Fr> Hs(m - 1);
+        const Fr zd = qap.Zt * delta_inverse;
+        detail::parallel_chunks(m - 1, [&](std::size_t lo, std::size_t hi) {
+            for (std::size_t i = lo; i < hi; ++i) Hs[i] = qap.Ht[i] * zd;
+        });
+        /* B query: sparse over the non-zero B_i(t) (kc_batch_exp, knowledge_commitment_multiexp.hpp:143-208) */
+        std::vector<Fr> Bnz;
+        std::vector<std::uint32_t> b_indices;
+        for (std::size_t i = 0; i <= N; ++i)
+            if (!qap.Bt[i].is_zero()) {
+                Bnz.push_back(qap.Bt[i]);
+                b_indices.push_back((std::uint32_t)i);
+            }
+        pk.B_query.domain_size_ = N + 1;
+        /* alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2 (:333-337): the same device path, read back */
+        {
+            std::vector<Fr> fx = {alpha, beta, delta};
+            auto f1 = device_bases<CurveType, ZKHIP_G1>::from_scalars(ctx, fx.begin(), fx.end());
+            auto f2 = device_bases<CurveType, ZKHIP_G2>::from_scalars(ctx, fx.begin(), fx.end());
+            pk.alpha_g1 = f1.at(0);
+            pk.beta_g1 = f1.at(1);
+            pk.delta_g1 = f1.at(2);
+            pk.beta_g2 = f2.at(1);
+            pk.delta_g2 = f2.at(2);
+        }
+        /* the five batch exponentiations (:339-366), left resident as the key's queries.  rank / world > 1: this process
+           generates (and will hold) only its slice of every query -- the point-range partition of a sharded proof. */
+        const query_shard sh = query_shard::make(rank, world, N + 1, Bnz.size(), m - 1, N - n);
+        auto a_query = device_bases<CurveType, ZKHIP_G1>::from_scalars(ctx, qap.At.begin() + sh.A_lo, qap.At.begin() + sh.A_lo + sh.A_n);
+        auto b_query_g = device_bases<CurveType, ZKHIP_G2>::from_scalars(ctx, Bnz.begin() + sh.B_lo, Bnz.begin() + sh.B_lo + sh.B_n);
+        auto b_query_h = device_bases<CurveType, ZKHIP_G1>::from_scalars(ctx, Bnz.begin() + sh.B_lo, Bnz.begin() + sh.B_lo + sh.B_n);
+        auto h_query = device_bases<CurveType, ZKHIP_G1>::from_scalars(ctx, Hs.begin() + sh.H_lo, Hs.begin() + sh.H_lo + sh.H_n);
+        auto l_query = device_bases<CurveType, ZKHIP_G1>::from_scalars(ctx, Lt.begin() + sh.L_lo, Lt.begin() + sh.L_lo + sh.L_n);
+        b_indices = std::vector<std::uint32_t>(b_indices.begin() + sh.B_lo, b_indices.begin() + sh.B_lo + sh.B_n);
+        key->device.reset(new r1cs_gg_ppzksnark_proving_key_hip<CurveType>(ctx, pk, dom, std::move(a_query), std::move(b_query_g), std::move(b_query_h),
+                                                                          b_indices, std::move(h_query), std::move(l_query), world > 1 ? &sh : nullptr));
+        return key;
+    }
+
+    /// generator.hpp:84-236: fresh toxic waste from the operating system's CSPRNG
+    static std::unique_ptr<generated_proving_key<CurveType>> basic_process(const context &ctx, const constraint_system_type &constraint_system,
+                                                                           const domain_params<CurveType> &dom) {
+        typedef r1cs_gg_ppzksnark_prover_hip<CurveType> prover;
+        return deterministic_basic_process(ctx, constraint_system, dom, prover::random_scalar(), prover::random_scalar(), prover::random_scalar(),
+                                           prover::random_scalar(), prover::random_scalar());
+    }
+
+    /// r1cs.hpp:192-215
+    static void swap_AB_if_beneficial(constraint_system_type &cs) {
+        std::vector<bool> touched_by_A(cs.num_variables() + 1, false), touched_by_B(cs.num_variables() + 1, false);
+        for (const auto &c : cs.constraints) {
+            for (const auto &term : c.a.terms) touched_by_A[term.index] = true;
+            for (const auto &term : c.b.terms) touched_by_B[term.index] = true;
+        }
+        std::size_t non_zero_A_count = 0, non_zero_B_count = 0;
+        for (std::size_t i = 0; i < cs.num_variables() + 1; ++i) {
+            non_zero_A_count += touched_by_A[i] ? 1 : 0;
+            non_zero_B_count += touched_by_B[i] ? 1 : 0;
+        }
+        if (non_zero_B_count > non_zero_A_count)
+            for (auto &c : cs.constraints) std::swap(c.a, c.b);
+    }
+};
+
+/// The proof a correct prover outputs for (primary, auxiliary) under the key of trapdoor (t, alpha, beta, delta) with
+/// blinders (r, s), as three EXPONENTS (prover.hpp:141,145,151-153 comment formulas):
+///   A = a G1, B = b G2, C = c G1 with
+///   a = alpha + sum z_i A_i(t) + r delta,   b = beta + sum z_i B_i(t) + s delta,
+///   c = (sum_{i > n} z_i (beta A_i + alpha B_i + C_i)(t) + A(t) B(t) - C(t)) / delta + s a + r b - r s delta
+/// (H(t) Z(t) = A(t) B(t) - C(t) for a satisfying assignment).  O(nnz + m) field operations and no group
+/// arithmetic: what bench.py and the tests hold a full-size proof against.
+template <typename CurveType, typename ConstraintSystem>
+std::array<typename curve_adapter<CurveType>::scalar_value_type, 3> groth16_proof_exponents(
+    const ConstraintSystem &swapped_cs, const domain_params<CurveType> &dom, const std::vector<typename curve_adapter<CurveType>::scalar_value_type> &primary_input,
+    const std::vector<typename curve_adapter<CurveType>::scalar_value_type> &auxiliary_input, const typename curve_adapter<CurveType>::scalar_value_type &t,
+    const typename curve_adapter<CurveType>::scalar_value_type &alpha, const typename curve_adapter<CurveType>::scalar_value_type &beta,
+    const typename curve_adapter<CurveType>::scalar_value_type &delta, const typename curve_adapter<CurveType>::scalar_value_type &r,
+    const typename curve_adapter<CurveType>::scalar_value_type &s) {
+    typedef typename curve_adapter<CurveType>::scalar_value_type Fr;
+    const auto qap = instance_map_with_evaluation<CurveType>(swapped_cs, t, dom.omega);
+    const std::size_t N = qap.num_variables, n = qap.num_inputs;
+    std::vector<Fr> z;
+    z.push_back(Fr::one());
+    z.insert(z.end(), primary_input.begin(), primary_input.end());
+    z.insert(z.end(), auxiliary_input.begin(), auxiliary_input.end());
+    if (z.size() != N + 1) throw std::invalid_argument("groth16_proof_exponents: assignment size");
+    Fr at = Fr::zero(), bt = Fr::zero(), ct = Fr::zero(), lt = Fr::zero();
+    for (std::size_t i = 0; i <= N; ++i) {
+        at = at + z[i] * qap.At[i];
+        bt = bt + z[i] * qap.Bt[i];
+        ct = ct + z[i] * qap.Ct[i];
+        if (i > n) lt = lt + z[i] * (beta * qap.At[i] + alpha * qap.Bt[i] + qap.Ct[i]);
+    }
+    const Fr a = alpha + at + r * delta, b = beta + bt + s * delta;
+    const Fr c = (lt + at * bt - ct) * delta.inversed() + s * a + r * b - r * s * delta;
+    return {a, b, c};
+}
+
+}    // namespace hip
+}    // namespace zk
+}    // namespace crypto3
+}    // namespace nil
+
+#endif    // ZKHIP_SHIM_R1CS_GG_PPZKSNARK_GENERATOR_HPP

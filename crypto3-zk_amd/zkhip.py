@@ -13,7 +13,7 @@ G1, G2 = 1, 2
 _FQ = {BLS12_381: 6, BN254: 4}
 
 EXPORTS = [
-    "zkhip_init", "zkhip_destroy", "zkhip_strerror", "zkhip_last_error", "zkhip_set_stream", "zkhip_sync", "zkhip_stream_wait", "zkhip_device",
+    "zkhip_init", "zkhip_destroy", "zkhip_strerror", "zkhip_last_error", "zkhip_set_stream", "zkhip_sync", "zkhip_device_status", "zkhip_stream_wait", "zkhip_device",
     "zkhip_set_option", "zkhip_malloc", "zkhip_free", "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_memcpy_h2d_async", "zkhip_memcpy_d2d_async", "zkhip_host_alloc", "zkhip_host_free",
     "zkhip_bases_upload", "zkhip_bases_upload_compressed", "zkhip_bases_from_scalars", "zkhip_bases_download", "zkhip_bases_size",
     "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_batch_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
@@ -118,6 +118,16 @@ class Context:
 
     def sync(self):
         self._check(self.lib.zkhip_sync(self.h), "zkhip_sync")
+
+    def device_status(self) -> int:
+        """sticky kernel-raised error flags since the last call (raises ZkhipError if any was set)"""
+        f = ctypes.c_uint32()
+        self._check(self.lib.zkhip_device_status(self.h, ctypes.byref(f)), "zkhip_device_status")
+        return f.value
+
+    def fr_gather_dev(self, d_src: int, src_count: int, d_indices: int, count: int, d_dst: int):
+        self._check(self.lib.zkhip_fr_gather_dev(self.h, ctypes.c_void_p(d_src), ctypes.c_size_t(src_count), ctypes.c_void_p(d_indices),
+                                                 ctypes.c_size_t(count), ctypes.c_void_p(d_dst)), "zkhip_fr_gather_dev")
 
     def set_option(self, name: str, value: int):
         self._check(self.lib.zkhip_set_option(self.h, name.encode(), ctypes.c_int64(value)), "zkhip_set_option")

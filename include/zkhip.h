@@ -57,6 +57,10 @@ int zkhip_set_stream(zkhip_ctx *ctx, void *hip_stream);
 int zkhip_stream_wait(zkhip_ctx *waiter, zkhip_ctx *signal);
 int zkhip_device(const zkhip_ctx *ctx);
 int zkhip_sync(zkhip_ctx *ctx);
+/* Sticky error flags raised by kernels since the last call (bit 0: a gather index out of range, bit 1: the MSM's
+ * large-bucket plan overflowed its capacity).  Synchronises the stream, clears the flags; returns ZKHIP_ERR_RANGE if
+ * any was set (the results computed meanwhile are then not to be used).  The shims call it once per proof. */
+int zkhip_device_status(zkhip_ctx *ctx, uint32_t *flags /* nullable */);
 /* Tunables: "msm_window_bits" (0 = auto), "msm_segment_log" (tail: 2^k buckets per lane, < 0 = auto), "ntt_radix_log", "ntt_tile_log",
  * "msm_precompute" / "msm_precompute_min" (window tables at upload), "msm_graphs" (HIP-graph replay of repeated MSM calls; off). */
 int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value);
@@ -153,7 +157,9 @@ int zkhip_groth16_witness_h_dev(zkhip_ctx *ctx, const zkhip_r1cs *r, const void 
 /* d_dst[j] = d_src[d_indices[j]] on Fr elements (u32 indices): gathers the scalars of a sparse query, i.e. the
  * `*(scalar_start + scalar_position)` walk over vec.indices of kc_multiexp_with_mixed_addition
  * (knowledge_commitment_multiexp.hpp:66-100).  Zero and one scalars need no peeling on the device. */
-int zkhip_fr_gather_dev(zkhip_ctx *ctx, const void *d_src, const void *d_indices, size_t count, void *d_dst);
+/* d_src holds src_count elements; an index >= src_count (malformed key) gathers the zero scalar and raises the sticky
+ * device status (zkhip_device_status). */
+int zkhip_fr_gather_dev(zkhip_ctx *ctx, const void *d_src, size_t src_count, const void *d_indices, size_t count, void *d_dst);
 
 /* ---- LPC / FRI polynomial helpers on top of the NTT -------------------------------------------------
  * polynomial_dfs::resize as precommit<FRI> applies it to every committed polynomial

@@ -177,6 +177,13 @@ class Groth16:
         assert lib().zko_g16_keygen(self.h, _p(_u64(trapdoor)), _p(_u64(omega))) == 0
         self._dims()
 
+    def expected_exponents(self, trapdoor, omega, r, s) -> np.ndarray:
+        """(a, b, c) with A = a G1, B = b G2, C = c G1 the proof a correct prover outputs under the key of `trapdoor` with
+        blinders (r, s): from the trapdoor identities alone, no MSM / NTT / group arithmetic.  Swaps A / B like keygen."""
+        out = np.zeros((3, 4), dtype=np.uint64)
+        assert lib().zko_g16_expected_exponents(self.h, _p(_u64(trapdoor)), _p(_u64(omega)), _p(_u64(r)), _p(_u64(s)), _p(out)) == 0
+        return out
+
     def csr(self, which: int):
         nnz = (self.nnzA, self.nnzB, self.nnzC)[which]
         rowptr = np.zeros(self.M + 1, dtype=np.uint32)

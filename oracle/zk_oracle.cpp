@@ -785,6 +785,34 @@ struct G16 {
         delta_g2 = o2[2];
         has_key = true;
     }
+    // The proof of a correct prover as three EXPONENTS of the standard generators, from the trapdoor alone (comment
+    // formulas prover.hpp:141,145,151-153; H(t) Z(t) = A(t) B(t) - C(t) for a satisfying assignment):
+    //   a = alpha + sum z_i A_i(t) + r delta,  b = beta + sum z_i B_i(t) + s delta,
+    //   c = (sum_{i>n} z_i (beta A_i + alpha B_i + C_i)(t) + A(t) B(t) - C(t)) / delta + s a + r b - r s delta
+    // No MSM, no NTT, no group arithmetic: O(nnz + m) field operations, usable at 2^20 constraints.
+    void expected_exponents(const uint64_t *trap, const uint64_t *omega_c, const uint64_t *r_c, const uint64_t *s_c,
+                            uint64_t *out /*3 x 4 canonical*/) {
+        swap_AB_if_beneficial();  // the key is generated over the swapped system (generator.hpp:250-252); idempotent
+        S t = S::from_canonical(trap), alpha = S::from_canonical(trap + 4), beta = S::from_canonical(trap + 8),
+          delta = S::from_canonical(trap + 16);
+        S r = S::from_canonical(r_c), s = S::from_canonical(s_c);
+        std::vector<S> At, Bt, Ct;
+        S Zt;
+        qap_at(t, S::from_canonical(omega_c), At, Bt, Ct, Zt);
+        auto z = full_with_one();
+        S at = S::zero(), bt = S::zero(), ct = S::zero(), lt = S::zero();
+        for (size_t i = 0; i <= N; ++i) {
+            at = at + z[i] * At[i];
+            bt = bt + z[i] * Bt[i];
+            ct = ct + z[i] * Ct[i];
+            if (i > n) lt = lt + z[i] * (beta * At[i] + alpha * Bt[i] + Ct[i]);
+        }
+        S a = alpha + at + r * delta, b = beta + bt + s * delta;
+        S c = (lt + at * bt - ct) * delta.inv() + s * a + r * b - r * s * delta;
+        a.to_canonical(out);
+        b.to_canonical(out + 4);
+        c.to_canonical(out + 8);
+    }
     // r1cs_to_qap.hpp:219-325 (d1 = d2 = d3 = 0): m+1 coefficients
     std::vector<S> witness_map(const S &omega, const S &g) const {
         auto f = full_with_one();
@@ -1103,6 +1131,12 @@ int zko_g16_is_satisfied(void *hv) {
 int zko_g16_keygen(void *hv, const uint64_t *trapdoor, const uint64_t *omega) {
     G16Handle *h = (G16Handle *)hv;
     G16_DISPATCH(h, g->keygen(trapdoor, omega));
+    return 0;
+}
+int zko_g16_expected_exponents(void *hv, const uint64_t *trapdoor, const uint64_t *omega, const uint64_t *r, const uint64_t *s,
+                               uint64_t *out) {
+    G16Handle *h = (G16Handle *)hv;
+    G16_DISPATCH(h, g->expected_exponents(trapdoor, omega, r, s, out));
     return 0;
 }
 // which: 0 = A, 1 = B, 2 = C (after swap_AB if keygen ran)

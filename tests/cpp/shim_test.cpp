@@ -15,6 +15,7 @@
 #include <nil/crypto3/zk/hip/marshalling.hpp>
 #include <nil/crypto3/zk/hip/powers_of_tau.hpp>
 #include <nil/crypto3/zk/hip/r1cs_gg_ppzksnark.hpp>
+#include <nil/crypto3/zk/hip/r1cs_gg_ppzksnark_generator.hpp>
 
 using namespace nil::crypto3::zk::hip;
 
@@ -327,6 +328,75 @@ int host_group_t(const uint64_t *p_aff, const uint64_t *q_aff, const uint64_t *s
     return 0;
 }
 
+template <typename Curve>
+r1cs_constraint_system<Curve> cs_from_csr(size_t M, size_t n, size_t N, const uint32_t *const rowptr[3], const uint32_t *const col[3],
+                                          const uint64_t *const coeff[3]) {
+    typedef curve_adapter<Curve> A;
+    r1cs_constraint_system<Curve> cs;
+    cs.primary_input_size = n;
+    cs.auxiliary_input_size = N - n;
+    cs.constraints.reserve(M);
+    for (size_t i = 0; i < M; ++i) {
+        r1cs_constraint<Curve> c;
+        linear_combination<Curve> *lc[3] = {&c.a, &c.b, &c.c};
+        for (int k = 0; k < 3; ++k)
+            for (uint32_t j = rowptr[k][i]; j < rowptr[k][i + 1]; ++j) lc[k]->add_term(col[k][j], A::scalar_from_limbs(coeff[k] + 4 * j));
+        cs.add_constraint(c);
+    }
+    return cs;
+}
+
+/// host only: the trapdoor exponents of the proof (generator header), for the CPU suite to hold against the oracle
+template <typename Curve>
+int host_qap_exponents_t(size_t M, size_t n, size_t N, const uint32_t *const rowptr[3], const uint32_t *const col[3], const uint64_t *const coeff[3],
+                         const uint64_t *assignment, const uint64_t *trap, const uint64_t *omega, const uint64_t *r, const uint64_t *s, uint64_t *out) {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::scalar_value_type Fr;
+    auto cs = cs_from_csr<Curve>(M, n, N, rowptr, col, coeff);
+    r1cs_gg_ppzksnark_generator_hip<Curve>::swap_AB_if_beneficial(cs);
+    std::vector<Fr> primary, auxiliary;
+    for (size_t i = 0; i < n; ++i) primary.push_back(A::scalar_from_limbs(assignment + 4 * i));
+    for (size_t i = n; i < N; ++i) auxiliary.push_back(A::scalar_from_limbs(assignment + 4 * i));
+    domain_params<Curve> dom {A::scalar_from_limbs(omega), Fr::one()};
+    auto e = groth16_proof_exponents<Curve>(cs, dom, primary, auxiliary, A::scalar_from_limbs(trap), A::scalar_from_limbs(trap + 4),
+                                            A::scalar_from_limbs(trap + 8), A::scalar_from_limbs(trap + 16), A::scalar_from_limbs(r), A::scalar_from_limbs(s));
+    for (int k = 0; k < 3; ++k) A::scalar_to_limbs(e[k], out + 4 * k);
+    return 0;
+}
+
+/// key generated ON THE DEVICE from the trapdoor (r1cs_gg_ppzksnark_generator_hip), then one proof with injected (r, s);
+/// `queries` (nullable) receives A | B.h | H | L entry 0..min(count, 4) of each query for spot checks: 4 x 4 G1 affine points
+template <typename Curve>
+int groth16_generate_prove_t(size_t M, size_t n, size_t N, const uint32_t *const rowptr[3], const uint32_t *const col[3], const uint64_t *const coeff[3],
+                             const uint64_t *assignment, const uint64_t *trap, const uint64_t *omega, const uint64_t *coset, const uint64_t *r,
+                             const uint64_t *s, uint64_t *proof, double *ms) {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::scalar_value_type Fr;
+    const size_t L1 = 2 * A::g1_coord_limbs, L2 = 2 * A::g2_coord_limbs;
+    auto cs = cs_from_csr<Curve>(M, n, N, rowptr, col, coeff);
+    std::vector<Fr> primary, auxiliary;
+    for (size_t i = 0; i < n; ++i) primary.push_back(A::scalar_from_limbs(assignment + 4 * i));
+    for (size_t i = n; i < N; ++i) auxiliary.push_back(A::scalar_from_limbs(assignment + 4 * i));
+    context ctx(0);
+    domain_params<Curve> dom {A::scalar_from_limbs(omega), A::scalar_from_limbs(coset)};
+    auto t0 = std::chrono::steady_clock::now();
+    auto key = r1cs_gg_ppzksnark_generator_hip<Curve>::deterministic_basic_process(ctx, cs, dom, A::scalar_from_limbs(trap), A::scalar_from_limbs(trap + 4),
+                                                                                   A::scalar_from_limbs(trap + 8), A::scalar_from_limbs(trap + 12),
+                                                                                   A::scalar_from_limbs(trap + 16));
+    ctx.sync();
+    auto t1 = std::chrono::steady_clock::now();
+    auto pv = r1cs_gg_ppzksnark_prover_hip<Curve>::process(*key->device, primary, auxiliary, A::scalar_from_limbs(r), A::scalar_from_limbs(s));
+    auto t2 = std::chrono::steady_clock::now();
+    pv.g_A.to_affine(proof);
+    pv.g_B.to_affine(proof + L1);
+    pv.g_C.to_affine(proof + L1 + L2);
+    if (ms) {
+        ms[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        ms[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    }
+    return 0;
+}
+
 extern "C" {
 
 int shim_host_small_poly(int curve, const uint64_t *xs, const uint64_t *ys, size_t k, const uint64_t *at, uint64_t *u_at, uint64_t *u_coeffs,
@@ -403,6 +473,23 @@ int shim_kzg_v2_proof_eval(int curve, const uint64_t *srs, size_t n_srs, size_t 
         fprintf(stderr, name ": %s\n", e.what());                   \
         return -1;                                                  \
     }
+
+int shim_host_qap_exponents(int curve, size_t M, size_t n, size_t N, const uint32_t *rpa, const uint32_t *cla, const uint64_t *cfa, const uint32_t *rpb,
+                            const uint32_t *clb, const uint64_t *cfb, const uint32_t *rpc, const uint32_t *clc, const uint64_t *cfc,
+                            const uint64_t *assignment, const uint64_t *trap, const uint64_t *omega, const uint64_t *r, const uint64_t *s, uint64_t *out) {
+    const uint32_t *rp[3] = {rpa, rpb, rpc}, *cl[3] = {cla, clb, clc};
+    const uint64_t *cf[3] = {cfa, cfb, cfc};
+    CURVE_CALL("shim_host_qap_exponents", host_qap_exponents_t, M, n, N, rp, cl, cf, assignment, trap, omega, r, s, out)
+}
+
+int shim_groth16_generate_prove(int curve, size_t M, size_t n, size_t N, const uint32_t *rpa, const uint32_t *cla, const uint64_t *cfa,
+                                const uint32_t *rpb, const uint32_t *clb, const uint64_t *cfb, const uint32_t *rpc, const uint32_t *clc,
+                                const uint64_t *cfc, const uint64_t *assignment, const uint64_t *trap, const uint64_t *omega, const uint64_t *coset,
+                                const uint64_t *r, const uint64_t *s, uint64_t *proof, double *ms) {
+    const uint32_t *rp[3] = {rpa, rpb, rpc}, *cl[3] = {cla, clb, clc};
+    const uint64_t *cf[3] = {cfa, cfb, cfc};
+    CURVE_CALL("shim_groth16_generate_prove", groth16_generate_prove_t, M, n, N, rp, cl, cf, assignment, trap, omega, coset, r, s, proof, ms)
+}
 
 int shim_precommit_leaves(int curve, const uint64_t *evals, size_t npolys, const uint64_t *log_n, size_t log_domain, size_t fri_step,
                           const uint64_t *roots, uint64_t *out) {

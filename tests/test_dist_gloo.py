@@ -69,6 +69,11 @@ def test_shard_range():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         zd.shard_range(10, 2, 2)
+    for W in (16, 17, 3):
+        for world in (1, 2, 4, 8, 19):
+            owned = [zd.shard_windows(W, r, world) for r in range(world)]
+            assert sorted(sum(owned, [])) == list(range(W))
+            assert max(map(len, owned)) - min(map(len, owned)) <= 1
 
 
 def test_point_range_sharding_world2_gloo():

@@ -333,3 +333,61 @@ def test_msm_batch(ctx, zk):
     assert fetch(0) == singles[0] and fetch(1) == jac_to_affine_py(0, 1, ctx.msm(small, scs[1][:40]))
     for d in d_s + d_o:
         ctx.free(d)
+
+
+@pytest.mark.parametrize("curve,group,n", [(0, 1, 5000), (0, 1, 20), (1, 1, 700), (0, 2, 300), (1, 2, 150)])
+@pytest.mark.parametrize("world", [2, 4, 8, 19])
+def test_msm_partitions_over_ranks(zk, ctx, curve, group, n, world):
+    """SURVEY 8e's two ways to spread one MSM over `world` GPUs, emulated rank by rank on this GPU and folded with
+    zkhip_jacobian_sum_dev exactly as the all-gather's receiver does:
+      (i)  point-range partition: rank g runs the whole pipeline over points [lo_g, hi_g);
+      (ii) window partition: rank g holds the tables of windows {w : w mod world == g} for ALL points
+           (options msm_shard_rank / msm_shard_world at upload) and sums those windows only.
+    Both must give the unsharded result, bit for bit in affine.  world = 19 exceeds the 16-17 windows: idle ranks."""
+    from crypto3_zk_amd import dist as zd
+
+    ks = cp.random_fr(curve, 900 + n, n)
+    pts, _ = cp.batch_mul(curve, group, ks)
+    sc = cp.random_fr(curve, 901 + n, n)
+    sc[::7] = 0
+    sc[1::11] = fr_arr([1])[0]
+    sc[2::13] = fr_arr([CURVES[curve].r - 1])[0]
+    exp, einf = cp.msm(curve, group, pts, sc, chunks=4)
+    cl = zk.coord_limbs(curve, group)
+    d_parts = ctx.malloc(world * 3 * cl * 8)
+    d_tot = ctx.malloc(3 * cl * 8)
+    d_sc = ctx.malloc(sc.nbytes)
+    ctx.h2d(d_sc, sc)
+
+    def folded():
+        ctx.jacobian_sum_dev(curve, group, d_parts, world, d_tot)
+        jac = np.zeros((3, cl), dtype=np.uint64)
+        ctx.d2h(jac, d_tot)
+        return ctx.jacobian_to_affine(curve, group, jac)
+
+    try:
+        # (i) point ranges
+        full = ctx.upload_bases(curve, group, pts)
+        for rank in range(world):
+            lo, hi = zd.shard_range(n, rank, world)
+            ctx.msm_dev(full, d_sc + 32 * lo, d_parts + rank * 3 * cl * 8, lo, hi - lo)
+        aff, inf = folded()
+        assert inf == einf and (aff == exp).all()
+        full.free()
+        # (ii) windows
+        for rank in range(world):
+            ctx.set_option("msm_shard_world", world)
+            ctx.set_option("msm_shard_rank", rank)
+            part = ctx.upload_bases(curve, group, pts)
+            ctx.set_option("msm_shard_world", 1)
+            dl, _ = part.download()
+            assert (dl == pts).all()
+            ctx.msm_dev(part, d_sc, d_parts + rank * 3 * cl * 8, 0, n)
+            ctx.sync()
+            part.free()
+        aff, inf = folded()
+        assert inf == einf and (aff == exp).all()
+    finally:
+        ctx.set_option("msm_shard_world", 1)
+        for p in (d_parts, d_tot, d_sc):
+            ctx.free(p)

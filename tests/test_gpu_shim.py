@@ -11,7 +11,7 @@ import pytest
 
 import cport as cp
 import pyoracle as po
-from util import CURVES, fr_arr, limbs, pt_limbs
+from util import CURVES, FQ_LIMBS, fr_arr, limbs, pt_limbs
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -83,6 +83,38 @@ def _groth16_prover_shim(shim, curve, M, n):
         rr, ss = rng.next_mod(C.r), rng.next_mod(C.r)
         eA, eB, eC = po.groth16_expected_in_exponent(C, cs, prim, aux, tr, rr, ss, C.root_of_unity(g.log_m))
         assert (proof == np.concatenate([pt_limbs(curve, 1, eA), pt_limbs(curve, 2, eB), pt_limbs(curve, 1, eC)])).all()
+
+
+@pytest.mark.parametrize("curve,M,n", [(0, 100, 10), (1, 1024, 10), (0, (1 << 15) + 5, 3), (0, (1 << 20) - 11, 10), (0, 1 << 20, 10)])
+def test_groth16_device_generated_key_matches_trapdoor(shim, curve, M, n):
+    """BASELINE config 4 AT ITS SIZE (M = 2^20, n = 10: domain 2^21; and the m = 2^20 variant M = 2^20 - 11): the key is generated
+    on the device from a fixed trapdoor (r1cs_gg_ppzksnark_generator_hip = generator.hpp:240-377 with the batch
+    exponentiations on the GPU), one proof is made with injected (r, s), and it must EQUAL the proof the trapdoor dictates
+    (A = a G1, B = b G2, C = c G1; prover.hpp:141,145,151-153) -- a, b, c computed by the oracle without any MSM / NTT.
+    A wrong bucket, twiddle or query entry anywhere in the 5.2 M-point key or the 2^21-point transforms changes the result."""
+    C = CURVES[curve]
+    g = cp.Groth16(curve, M, n, seed=1)
+    w = limbs(C.root_of_unity(g.log_m), 4)
+    gen = limbs(C.fr_generator, 4)
+    rng = po.SplitMix64(4242)
+    trap = fr_arr([rng.next_mod(C.r) for _ in range(5)])
+    r_, s_ = limbs(rng.next_mod(C.r), 4), limbs(rng.next_mod(C.r), 4)
+    args = []
+    for k in range(3):
+        rp, cl, cf = g.csr(k)
+        args += [P(rp), P(cl), P(cf)]
+    L1, L2 = 2 * FQ_LIMBS[curve], 4 * FQ_LIMBS[curve]
+    proof = np.zeros(2 * L1 + L2, dtype=np.uint64)
+    ms = np.zeros(2, dtype=np.float64)
+    rc = shim.shim_groth16_generate_prove(curve, ctypes.c_size_t(g.M), ctypes.c_size_t(g.n), ctypes.c_size_t(g.N), *args, P(g.assignment()), P(trap), P(w),
+                                          P(gen), P(r_), P(s_), P(proof), P(ms))
+    assert rc == 0
+    a, b, c = g.expected_exponents(trap, w, r_, s_)
+    eA, _ = cp.batch_mul(curve, 1, a.reshape(1, 4))
+    eB, _ = cp.batch_mul(curve, 2, b.reshape(1, 4))
+    eC, _ = cp.batch_mul(curve, 1, c.reshape(1, 4))
+    assert (proof == np.concatenate([eA[0], eB[0], eC[0]])).all()
+    print("M = %d: key generated on the device in %.0f ms, first proof %.1f ms" % (M, ms[0], ms[1]))
 
 
 @pytest.mark.parametrize("curve,log_n,batch", [(0, 10, 3), (1, 8, 2)])

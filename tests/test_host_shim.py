@@ -9,8 +9,9 @@ import subprocess
 import numpy as np
 import pytest
 
+import cport as cp
 import pyoracle as po
-from util import CURVES, fr_arr, limbs, pt_from_limbs, pt_limbs
+from util import CURVES, fr_arr, fr_ints, limbs, pt_from_limbs, pt_limbs
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -69,3 +70,34 @@ def test_query_shards_partition(shim, world):
         lo, n = out[:, col].astype(int), out[:, col + 1].astype(int)
         assert lo[0] == 0 and (lo[1:] == lo[:-1] + n[:-1]).all() and lo[-1] + n[-1] == total  # contiguous, complete
         assert n.max() - n.min() <= 1                                                          # balanced
+
+
+@pytest.mark.parametrize("curve,M,n", [(0, 16, 3), (1, 100, 10), (0, 5000, 10)])
+def test_generator_host_side_matches_oracles(shim, curve, M, n):
+    """The host half of the device key generator (hip/r1cs_gg_ppzksnark_generator.hpp: swap_AB_if_beneficial,
+    instance_map_with_evaluation = r1cs_to_qap.hpp:138-187, and the trapdoor exponents of a proof) against the C++ oracle,
+    and at the small sizes against the big-integer oracle (po.groth16_expected_in_exponent)."""
+    C = CURVES[curve]
+    g = cp.Groth16(curve, M, n, seed=3)
+    w = C.root_of_unity(g.log_m)
+    rng = po.SplitMix64(77 + M)
+    trap = [rng.next_mod(C.r) for _ in range(5)]
+    rr, ss = rng.next_mod(C.r), rng.next_mod(C.r)
+    args = []
+    keep = []
+    for k in range(3):  # the UNswapped system: the shim swaps itself
+        rp, cl, cf = g.csr(k)
+        keep += [rp, cl, cf]
+        args += [P(rp), P(cl), P(cf)]
+    assignment = g.assignment()
+    out = np.zeros((3, 4), dtype=np.uint64)
+    T, W, R, S = fr_arr(trap), limbs(w, 4), limbs(rr, 4), limbs(ss, 4)
+    assert shim.shim_host_qap_exponents(curve, ctypes.c_size_t(g.M), ctypes.c_size_t(g.n), ctypes.c_size_t(g.N), *args, P(assignment), P(T), P(W), P(R),
+                                        P(S), P(out)) == 0
+    exp = g.expected_exponents(T, W, R, S)
+    assert (out == exp).all()
+    if M <= 100:
+        cs, prim, aux = po.r1cs_example_field_input(C.r, M, n, seed=3)
+        eA, eB, eC = po.groth16_expected_in_exponent(C, cs, prim, aux, trap, rr, ss, w)
+        a, b, c = fr_ints(out)
+        assert (C.g1.mul(C.g1.gen, a), C.g2.mul(C.g2.gen, b), C.g1.mul(C.g1.gen, c)) == (eA, eB, eC)
