@@ -28,7 +28,7 @@
         if (rc__ != 0) return rc__; \
     } while (0)
 
-static constexpr int ZK_MSM_MAX_C = 16;  // largest Pippenger window (bits); 2^(c-1) buckets per window
+static constexpr int ZK_MSM_MAX_C = 21;  // largest Pippenger window (bits); 2^(c-1) buckets per set (the sort handles <= 2^20 x sets / 1024 super-buckets)
 
 // bits of the sticky device status word (kernels atomicOr them in; zkhip_device_status reports and clears)
 enum : uint32_t { ZK_STATUS_GATHER_RANGE = 1u, ZK_STATUS_MSM_PLAN_OVERFLOW = 2u };
@@ -95,6 +95,7 @@ struct zkhip_ctx {
     size_t pinned_cap = 0;
     // options
     int opt_msm_window_bits = 0;
+    int opt_msm_sets = 0;          // bucket sets S with window tables (entry (i, w) -> set w mod S); 0: from the lane target
     int opt_msm_segment_log = -1;  // tail segments of 2^k buckets per lane; < 0: chosen from the lane count
     int opt_ntt_radix_log = 8;
     int opt_ntt_tile_log = 3;

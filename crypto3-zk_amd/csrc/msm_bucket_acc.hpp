@@ -61,16 +61,15 @@ struct LdsAcc {
 // F is the type a LANE holds: the coordinate field itself (LPB = 1 lane per bucket), or one half of an Fq2
 // coordinate (Fu2h, LPB = 2: an even / odd lane pair per bucket, fu2_pair.hpp).
 template <class F, int NT, int WAVES, int LPB = 1>
-__global__ __launch_bounds__(NT, WAVES) void msm_bucket_acc_lds(const uint32_t *__restrict__ bases, size_t tab_stride_words, uint32_t B,
-                                                           const uint32_t *__restrict__ offs, const uint32_t *__restrict__ idx, uint32_t nbuckets,
-                                                           uint32_t large, const uint32_t *__restrict__ order, uint32_t *__restrict__ buckets) {
+__global__ __launch_bounds__(NT, WAVES) void msm_bucket_acc_lds(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ offs,
+                                                           const uint32_t *__restrict__ idx, uint32_t nbuckets, uint32_t large,
+                                                           const uint32_t *__restrict__ order, uint32_t *__restrict__ buckets) {
     typedef FieldOps<F> O;
     constexpr int NL = O::WORDS;
     extern __shared__ __attribute__((aligned(16))) uint4 acc_lds[];
     const uint32_t tid = threadIdx.x, slot = (blockIdx.x * NT + tid) / LPB;
     if (slot >= nbuckets) return;
     const uint32_t g = order[slot];  // buckets by descending size (msm_size_*)
-    const uint32_t *tab = bases + (size_t)(g / B) * tab_stride_words;
     const uint32_t lo = offs[g], hi = offs[g + 1];
     if (hi - lo > large) return;
     LdsAcc<F, NT> A = {acc_lds, tid};
@@ -79,7 +78,7 @@ __global__ __launch_bounds__(NT, WAVES) void msm_bucket_acc_lds(const uint32_t *
     bool inf = true;
     for (uint32_t k = lo; k < hi; ++k) {
         const uint32_t e = idx[k];
-        Affine<F> p = affine_load<F>(tab + (size_t)(e & 0x7FFFFFFFu) * (2 * NL));
+        Affine<F> p = affine_load<F>(bases + (size_t)(e & 0x7FFFFFFFu) * (2 * NL));  // entry = table row (slot * n + point) | sign
         if (p.is_inf()) continue;
         if (e >> 31) p.y = O::template sub<O::K1>(F::zero(), p.y);
         if (inf) {
