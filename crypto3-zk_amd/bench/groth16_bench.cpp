@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -42,8 +43,6 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
     typedef typename A::scalar_value_type Fr;
     auto t0 = std::chrono::steady_clock::now();
     SplitMix rng {seed};
-    std::uint64_t mod[4];
-    A::scalar_modulus(mod);
     auto rnd = [&]() {    // < 2^252 < r for both curves: canonical
         uint64_t w[4] = {rng.next(), rng.next(), rng.next(), rng.next() & 0x0fffffffffffffffULL};
         return A::scalar_from_limbs(w);
@@ -100,6 +99,7 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
     const Fr t = rnd_key(), alpha = rnd_key(), beta = rnd_key(), gamma = rnd_key(), delta = rnd_key();
     auto key = r1cs_gg_ppzksnark_generator_hip<Curve>::deterministic_basic_process(ctx, cs, dom, t, alpha, beta, gamma, delta, rank, world);
     auto &dpk = *key->device;
+    if (const char *e = getenv("ZKHIP_G16_OVERLAP")) dpk.overlap_g2 = atoi(e) != 0;    // experiments: G2 multiexp on the main stream
     ctx.sync();
     *setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     Fr r = rnd(), s = rnd();

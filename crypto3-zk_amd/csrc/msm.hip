@@ -2,6 +2,7 @@
 // units (msm_bls_g1.hip, msm_bls_g2.hip, msm_bn_g1.hip, msm_bn_g2.hip; kernels and per-call logic in msm_core.hpp),
 // batching, and the optional HIP-graph replay of repeated calls.
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -75,19 +76,28 @@ static int ilog2(size_t v) {
 
 int zk_scalar_bits(int curve) { return curve == CURVE_BLS12_381 ? 255 : 254; }  // bit length of r
 
-// Window size from the number of points.  With window tables all W = ceil(bitlen(r) / c) windows of a point feed ONE bucket
-// set (msm_core.hpp), so the work is n W mixed additions + ~3 B full additions of bucket reduction, B = 2^(c-1): c grows
-// with log2 n (tools/msm_window_sweep.py: 2^20 points -> c = 20, 13 windows).  Keys of 2^20 - k and 2^21 - 1 points get
-// neighbouring sizes; zkhip_msm_batch_dev shares one bucket reduction among members of equal c.
+// Window size from the number of points (tools/msm_window_sweep.py, profiles/r02_msm_window_sweep.json).  With window
+// tables all W = ceil(bitlen(r) / c) windows of a point feed the same bucket set(s) (msm_core.hpp): the work is n W mixed
+// additions + ~3 full additions per bucket of reduction, and the accumulation kernel wants ~2^19 lanes (buckets) of a few
+// entries each.  From 2^19 points on one set of 2^19 buckets does it (c = 20: 13 windows instead of the 16 of c = 16;
+// c = 21 has the same 13 windows and twice the buckets to reduce, c = 22 would need 2^21); below, c stops at 17 and the set is replicated (zk_msm_target_lanes) -- at 2^10 .. 2^16 points
+// that is one set per window again, which the sweep shows to be as good as anything there.
+// ZKHIP_MSM_WINDOW_BITS in the environment overrides the automatic choice (experiments).
 int zk_msm_auto_window(size_t n) {
+    static const int env_c = []() {
+        const char *e = getenv("ZKHIP_MSM_WINDOW_BITS");
+        return e ? atoi(e) : 0;
+    }();
+    if (env_c > 0) return std::max(2, std::min(ZK_MSM_MAX_C, env_c));
     int l = ilog2(n);
     if ((double)n >= 1.41421356237 * (double)((size_t)1 << l)) ++l;
-    return std::max(2, std::min(ZK_MSM_MAX_C, l));
+    const int c = l >= 19 ? 20 : std::min(17, l + 1);
+    return std::max(2, std::min(ZK_MSM_MAX_C, c));
 }
 
-// Lanes the accumulation kernel should have at least (one per bucket): three waves per SIMD on 1024 SIMDs are ~2^17.6
-// lanes; below that the bucket set is replicated into S sets (entry (i, w) -> set w mod S) that are folded afterwards.
-size_t zk_msm_target_lanes() { return (size_t)1 << 18; }
+// Lanes the accumulation kernel should have at least (one per bucket): below that the bucket set is replicated into S
+// sets (entry (i, w) -> set w mod S) that are folded bucket-wise afterwards.
+size_t zk_msm_target_lanes() { return (size_t)1 << 19; }
 
 static int zk_msm_run_direct(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac);
 

@@ -176,14 +176,23 @@ struct SortGeom {
     uint32_t S;           // sets: set(w) = w % S
     uint32_t lowb;        // low key bits (pass 2)
     uint32_t nsuper;      // ceil(S * B / 2^lowb)
+    uint32_t tile;        // entries per tile
     uint32_t ntile;       // tiles per window
     uint32_t slot0;       // table slot of local window 0 (slot(lw) = slot0 + lw); all windows share slot 0 without tables
     uint32_t tables;      // 1: window lw reads table slot0 + lw; 0: every window reads the points themselves
     uint32_t bases_n;     // points per table
     uint32_t base_off;    // first point of this MSM inside the table
 };
-constexpr uint32_t SORT_TILE = 16384;   // entries per pass-1 tile / pass-2 chunk (1024 lanes x 16)
-constexpr uint32_t SORT_THREADS = 1024;
+// Two tile shapes: 2^14 entries staged by 1024 lanes (~140 KiB of LDS: the workgroup owns its CU) when the MSM has the GPU
+// to itself, and 2^12 entries by 256 lanes (~40 KiB) when another context's kernels share the chip (option
+// "msm_sort_tile_log" = 12: the Groth16 shim's G2 multiexp on a second stream keeps ~98 KiB of every CU's LDS busy, a
+// 140-KiB workgroup would wait for a CU to drain completely -- measured 7.8 ms for a 0.09-ms kernel).
+struct SortBig {
+    static constexpr uint32_t TILE = 16384, THREADS = 1024;
+};
+struct SortSmall {
+    static constexpr uint32_t TILE = 4096, THREADS = 256;
+};
 constexpr uint32_t SORT_MAX_LOW = 10;   // <= 1024 destinations in pass 2
 constexpr uint32_t SORT_MAX_SUPER = 1024;  // LDS: 3 counters per super-bucket next to the 128 KiB staged tile
 
@@ -193,7 +202,9 @@ ZK_D uint32_t sort_entry(const SortGeom &g, uint32_t w, uint32_t i, uint32_t d) 
 }
 
 // bh[sb * (W * ntile) + w * ntile + tile] = number of entries of window w, tile `tile`, in super-bucket sb
-__global__ __launch_bounds__(SORT_THREADS) void msm_sort_hist(const uint32_t *__restrict__ dig, SortGeom g, uint32_t *__restrict__ bh) {
+template <class SZ>
+__global__ __launch_bounds__(SZ::THREADS) void msm_sort_hist(const uint32_t *__restrict__ dig, SortGeom g, uint32_t *__restrict__ bh) {
+    constexpr uint32_t SORT_TILE = SZ::TILE, SORT_THREADS = SZ::THREADS;
     extern __shared__ uint32_t lh[];  // nsuper
     const uint32_t tile = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
     for (uint32_t k = t; k < g.nsuper; k += SORT_THREADS) lh[k] = 0;
@@ -209,6 +220,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_sort_hist(const uint32_t *__
 }
 
 // block-wide exclusive scan of `count` (<= SORT_MAX_SUPER) LDS counters in place; returns the total
+template <uint32_t SORT_THREADS>
 ZK_D uint32_t block_excl_scan(uint32_t *v, uint32_t count, uint32_t *scratch /* SORT_THREADS */) {
     const uint32_t t = threadIdx.x, per = (count + SORT_THREADS - 1) / SORT_THREADS;
     const uint32_t lo = min(count, t * per), hi = min(count, lo + per);
@@ -234,8 +246,10 @@ ZK_D uint32_t block_excl_scan(uint32_t *v, uint32_t count, uint32_t *scratch /* 
 }
 
 // tmp_idx / tmp_key: entries grouped by super-bucket; order inside a group is arbitrary.
-__global__ __launch_bounds__(SORT_THREADS) void msm_sort_split(const uint32_t *__restrict__ dig, SortGeom g, const uint32_t *__restrict__ bo,
-                                                               uint32_t *__restrict__ tmp_idx, uint16_t *__restrict__ tmp_key) {
+template <class SZ>
+__global__ __launch_bounds__(SZ::THREADS) void msm_sort_split(const uint32_t *__restrict__ dig, SortGeom g, const uint32_t *__restrict__ bo,
+                                                              uint32_t *__restrict__ tmp_idx, uint16_t *__restrict__ tmp_key) {
+    constexpr uint32_t SORT_TILE = SZ::TILE, SORT_THREADS = SZ::THREADS;
     extern __shared__ uint32_t sm[];
     uint32_t *loff = sm;                      // nsuper + 1: local exclusive offsets
     uint32_t *cur = loff + g.nsuper + 1;      // nsuper
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_sort_split(const uint32_t *_
         if (d != DIG_NONE) atomicAdd(&loff[sort_key(g, w, d) >> g.lowb], 1u);
     }
     __syncthreads();
-    const uint32_t total = block_excl_scan(loff, g.nsuper, scratch);
+    const uint32_t total = block_excl_scan<SORT_THREADS>(loff, g.nsuper, scratch);
     if (t == 0) loff[g.nsuper] = total;
     for (uint32_t k = t; k < g.nsuper; k += SORT_THREADS) cur[k] = loff[k];
     __syncthreads();
@@ -279,10 +293,39 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_sort_split(const uint32_t *_
 
 // one workgroup per super-bucket: final order + bucket offsets offs[sb * 2^lowb + low].
 // The group is sorted chunk by chunk inside LDS and written out in runs per key (same reason as above).
-__global__ __launch_bounds__(SORT_THREADS) void msm_sort_final(const uint32_t *__restrict__ tmp_idx, const uint16_t *__restrict__ tmp_key, SortGeom g,
-                                                               uint32_t nb, const uint32_t *__restrict__ bo, uint32_t *__restrict__ offs,
-                                                               uint32_t *__restrict__ idx) {
-    __shared__ uint32_t cnt[SORT_THREADS], scan[SORT_THREADS], cursor[SORT_THREADS], loff[SORT_THREADS + 1], cur[SORT_THREADS];
+// NLOW = 2^lowb <= 1024 counters, CPT = NLOW / THREADS of them per lane.
+constexpr uint32_t SORT_NLOW_MAX = 1u << SORT_MAX_LOW;
+
+template <uint32_t THREADS>
+ZK_D void block_scan_counts(const uint32_t *cnt, uint32_t *excl, uint32_t *scratch) {  // excl[k] = sum_{j < k} cnt[j], k < SORT_NLOW_MAX
+    constexpr uint32_t CPT = SORT_NLOW_MAX / THREADS;
+    const uint32_t t = threadIdx.x;
+    uint32_t s = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < CPT; ++k) s += cnt[t * CPT + k];
+    scratch[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < THREADS; d <<= 1) {
+        uint32_t x = t >= d ? scratch[t - d] : 0;
+        __syncthreads();
+        scratch[t] += x;
+        __syncthreads();
+    }
+    uint32_t run = scratch[t] - s;
+#pragma unroll
+    for (uint32_t k = 0; k < CPT; ++k) {
+        excl[t * CPT + k] = run;
+        run += cnt[t * CPT + k];
+    }
+    __syncthreads();
+}
+
+template <class SZ>
+__global__ __launch_bounds__(SZ::THREADS) void msm_sort_final(const uint32_t *__restrict__ tmp_idx, const uint16_t *__restrict__ tmp_key, SortGeom g,
+                                                              uint32_t nb, const uint32_t *__restrict__ bo, uint32_t *__restrict__ offs,
+                                                              uint32_t *__restrict__ idx) {
+    constexpr uint32_t SORT_TILE = SZ::TILE, SORT_THREADS = SZ::THREADS;
+    __shared__ uint32_t cnt[SORT_NLOW_MAX], cursor[SORT_NLOW_MAX], loff[SORT_NLOW_MAX], cur[SORT_NLOW_MAX], scratch[SORT_THREADS];
     extern __shared__ uint32_t sm[];
     uint32_t *sidx = sm;                                            // SORT_TILE
     uint16_t *skey = reinterpret_cast<uint16_t *>(sidx + SORT_TILE);  // SORT_TILE
@@ -290,43 +333,27 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_sort_final(const uint32_t *_
     const size_t stride = (size_t)g.W * g.ntile;
     const uint32_t start = bo[(size_t)grp * stride];
     const uint32_t end = bo[(size_t)(grp + 1) * stride];  // bo has one trailing entry = total (grp + 1 == nsuper)
-    const uint32_t nlow = 1u << g.lowb;                   // <= SORT_THREADS
-    cnt[t] = 0;
+    const uint32_t nlow = 1u << g.lowb;                   // <= SORT_NLOW_MAX
+    for (uint32_t k = t; k < SORT_NLOW_MAX; k += SORT_THREADS) cnt[k] = 0;
     __syncthreads();
     for (uint32_t k = start + t; k < end; k += SORT_THREADS) atomicAdd(&cnt[tmp_key[k]], 1u);
     __syncthreads();
-    uint32_t mine = cnt[t];
-    scan[t] = mine;
-    __syncthreads();
-    for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
-        uint32_t x = t >= d ? scan[t - d] : 0;
-        __syncthreads();
-        scan[t] += x;
-        __syncthreads();
+    block_scan_counts<SORT_THREADS>(cnt, cursor, scratch);  // cursor[key] = offset of key inside the group
+    for (uint32_t k = t; k < nlow; k += SORT_THREADS) {
+        const uint32_t bucket = grp * nlow + k;
+        cursor[k] += start;  // next free slot of key k
+        if (bucket < nb) offs[bucket] = cursor[k];
     }
-    uint32_t excl = start + scan[t] - mine;
-    const uint32_t bucket = grp * nlow + t;
-    if (t < nlow && bucket < nb) offs[bucket] = excl;
     if (grp + 1 == g.nsuper && t == 0) offs[nb] = end;
-    cursor[t] = excl;  // next free slot of key t
     __syncthreads();
     for (uint32_t c0 = start; c0 < end; c0 += SORT_TILE) {
         const uint32_t c1 = min(end, c0 + SORT_TILE);
-        cnt[t] = 0;
+        for (uint32_t k = t; k < SORT_NLOW_MAX; k += SORT_THREADS) cnt[k] = 0;
         __syncthreads();
         for (uint32_t k = c0 + t; k < c1; k += SORT_THREADS) atomicAdd(&cnt[tmp_key[k]], 1u);
         __syncthreads();
-        const uint32_t cm = cnt[t];
-        scan[t] = cm;
-        __syncthreads();
-        for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
-            uint32_t x = t >= d ? scan[t - d] : 0;
-            __syncthreads();
-            scan[t] += x;
-            __syncthreads();
-        }
-        loff[t] = scan[t] - cm;
-        cur[t] = scan[t] - cm;
+        block_scan_counts<SORT_THREADS>(cnt, loff, scratch);
+        for (uint32_t k = t; k < SORT_NLOW_MAX; k += SORT_THREADS) cur[k] = loff[k];
         __syncthreads();
         for (uint32_t k = c0 + t; k < c1; k += SORT_THREADS) {
             const uint32_t key = tmp_key[k];
@@ -340,7 +367,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_sort_final(const uint32_t *_
             idx[cursor[key] + (s - loff[key])] = sidx[s];
         }
         __syncthreads();
-        cursor[t] += cm;
+        for (uint32_t k = t; k < SORT_NLOW_MAX; k += SORT_THREADS) cursor[k] += cnt[k];
         __syncthreads();
     }
 }
@@ -712,14 +739,21 @@ __global__ __launch_bounds__(64) void msm_final_batch(const uint32_t *__restrict
 
 // ---- host side ------------------------------------------------------------------------------------
 
-// Buckets per tail lane.  One bucket per lane gives the shortest dependency chain (~20 additions for the scalar
-// multiple) and is right while the lanes fit the chip once.  More buckets than ~2 waves per SIMD of lanes make the tail
-// work-bound, and a segment of L buckets costs 2 + ~25/L additions per bucket instead of ~25.
-inline uint32_t msm_tail_segment(const zkhip_ctx *ctx, uint32_t B, size_t sets) {
+// Buckets per tail lane (segment length L).  Every operation of the tail is a full addition or doubling, ~13.6 us for a
+// wave that has its SIMD (almost) to itself, so a segment costs 2 L (running sums) + ~38 (the multiple seg L, a 20-bit
+// double-and-add whose additions run on every step of a diverged wave) + 8 (LDS tree) dependent operations; measured
+// (tools/msm_profile.py, 2^19 / 2^20 buckets): L = 8: 0.84 ms, 16: 1.06, 4: 1.38 (twice the waves per SIMD: the
+// operations get slower than the chain gets shorter), 32: 1.5.  So: L = 8 once there are >= 2^18 buckets, doubled while
+// the lanes (sets B lanes_per_point / L) exceed ~2^18; small bucket sets keep one bucket per lane.
+inline uint32_t msm_tail_segment(const zkhip_ctx *ctx, uint32_t B, size_t sets, int lanes_per_point) {
     uint32_t L = 1;
     if (ctx->opt_msm_segment_log >= 0) L = 1u << std::min(ctx->opt_msm_segment_log, 8);
-    else
-        while (L < 16 && sets * B / L > 131072) L <<= 1;
+    else {
+        const size_t lanes = sets * B * (size_t)lanes_per_point;
+        const uint32_t knee = lanes_per_point > 1 ? 16 : 8;  // G2 (lane pairs, 1.5x the instructions per operation): 16 measured 1.8 ms against 2.6 for 8
+        while (L < knee && lanes / L > 65536) L <<= 1;
+        while (L < 64 && lanes / L > 262144) L <<= 1;
+    }
     return std::min(B, L);
 }
 
@@ -768,6 +802,24 @@ inline MsmPlan msm_plan(const zkhip_ctx *ctx, const zkhip_bases *bases, size_t n
     return p;
 }
 
+// the sort's launch sequence for one tile shape
+template <class SZ>
+int msm_sort_run(zkhip_ctx *ctx, const SortGeom &g, int W, uint32_t nb, uint32_t nbh, uint32_t nblk, const uint32_t *dig, uint32_t *bh, uint32_t *bo,
+                 uint32_t *bsums, uint32_t *tmp_idx, uint16_t *tmp_key, uint32_t *offs, uint32_t *idx) {
+    const size_t lds_hist = (size_t)g.nsuper * 4;
+    const size_t lds_split = ((size_t)3 * g.nsuper + 1 + SZ::THREADS + 2 * SZ::TILE) * 4;
+    const size_t lds_final = (size_t)SZ::TILE * 6;
+    if (lds_split > 48 * 1024) ZK_MAX_LDS(ctx, msm_sort_split<SZ>, 160 * 1024 - 256);
+    if (lds_final > 40 * 1024) ZK_MAX_LDS(ctx, msm_sort_final<SZ>, 160 * 1024 - (4 * SORT_NLOW_MAX + SZ::THREADS) * 4 - 256);
+    ZK_LAUNCH(ctx, "msm_sort_hist", msm_sort_hist<SZ>, dim3(g.ntile, W), dim3(SZ::THREADS), lds_hist, dig, g, bh);
+    ZK_LAUNCH(ctx, "msm_scan", msm_scan_local, dim3(nblk), dim3(256), 0, bh, nbh, bo, bsums);
+    ZK_LAUNCH(ctx, "msm_scan", msm_scan_top, dim3(1), dim3(1024), 0, bsums, nblk, bo + nbh);
+    ZK_LAUNCH(ctx, "msm_scan", msm_scan_add, dim3(nblk), dim3(256), 0, bo, nbh, bsums, bo);
+    ZK_LAUNCH(ctx, "msm_sort_split", msm_sort_split<SZ>, dim3(g.ntile, W), dim3(SZ::THREADS), lds_split, dig, g, bo, tmp_idx, tmp_key);
+    ZK_LAUNCH(ctx, "msm_sort_final", msm_sort_final<SZ>, dim3(g.nsuper), dim3(SZ::THREADS), lds_final, tmp_idx, tmp_key, g, nb, bo, offs, idx);
+    return 0;
+}
+
 template <class F>
 int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac,
               uint32_t *batch_slot = nullptr, size_t *need_out = nullptr) {
@@ -783,7 +835,7 @@ int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
         return ZKHIP_ERR_RANGE;
     }
     const int Sr = P.tables ? 1 : W;  // sets left after the equal-weight merge
-    const uint32_t L = msm_tail_segment(ctx, B, Sr);  // buckets per tail segment
+    const uint32_t L = msm_tail_segment(ctx, B, Sr, LPB);  // buckets per tail segment
     const uint32_t tail_slots = MSM_TAIL_THREADS / LPB;  // points per tail workgroup
     const uint32_t nseg = B / L, nblk_tail = (nseg + tail_slots - 1) / tail_slots;
     // two-level LDS counting sort (see msm_sort_*): the low bits inside a super-bucket, the rest across super-buckets
@@ -794,7 +846,9 @@ int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
     g.S = S;
     g.lowb = (uint32_t)std::min<int>(SORT_MAX_LOW, P.c - 1);
     g.nsuper = (nb + (1u << g.lowb) - 1) >> g.lowb;
-    g.ntile = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
+    const bool big_tiles = ctx->opt_msm_sort_tile_log >= 14;
+    g.tile = big_tiles ? SortBig::TILE : SortSmall::TILE;
+    g.ntile = (uint32_t)((n + g.tile - 1) / g.tile);
     g.tables = P.tables ? 1u : 0u;
     g.slot0 = P.tables ? (uint32_t)bases->slot_of_local(0) : 0u;
     g.bases_n = (uint32_t)bases->n;
@@ -858,17 +912,7 @@ int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
     if (bases->curve == CURVE_BLS12_381)
         ZK_LAUNCH(ctx, "msm_digits", msm_digits_only<BlsFr>, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, P.win, P.wrank, P.wworld, dig);
     else ZK_LAUNCH(ctx, "msm_digits", msm_digits_only<BnFr>, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, P.win, P.wrank, P.wworld, dig);
-    const size_t lds_hist = (size_t)g.nsuper * 4;
-    const size_t lds_split = ((size_t)3 * g.nsuper + 1 + SORT_THREADS + 2 * SORT_TILE) * 4;
-    const size_t lds_final = (size_t)SORT_TILE * 6;
-    ZK_MAX_LDS(ctx, msm_sort_split, 160 * 1024 - 256);
-    ZK_MAX_LDS(ctx, msm_sort_final, 160 * 1024 - 5 * SORT_THREADS * 4 - 256);
-    ZK_LAUNCH(ctx, "msm_sort_hist", msm_sort_hist, dim3(g.ntile, W), dim3(SORT_THREADS), lds_hist, dig, g, bh);
-    ZK_LAUNCH(ctx, "msm_scan", msm_scan_local, dim3(nblk), dim3(256), 0, bh, nbh, bo, bsums);
-    ZK_LAUNCH(ctx, "msm_scan", msm_scan_top, dim3(1), dim3(1024), 0, bsums, nblk, bo + nbh);
-    ZK_LAUNCH(ctx, "msm_scan", msm_scan_add, dim3(nblk), dim3(256), 0, bo, nbh, bsums, bo);
-    ZK_LAUNCH(ctx, "msm_sort_split", msm_sort_split, dim3(g.ntile, W), dim3(SORT_THREADS), lds_split, dig, g, bo, tmp_idx, tmp_key);
-    ZK_LAUNCH(ctx, "msm_sort_final", msm_sort_final, dim3(g.nsuper), dim3(SORT_THREADS), lds_final, tmp_idx, tmp_key, g, nb, bo, offs, idx);
+    ZK_TRY((big_tiles ? msm_sort_run<SortBig> : msm_sort_run<SortSmall>)(ctx, g, W, nb, nbh, nblk, dig, bh, bo, bsums, tmp_idx, tmp_key, offs, idx));
     // buckets by descending size
     ZK_LAUNCH(ctx, "msm_size_sort", msm_size_hist, dim3(sblk), dim3(256), 0, offs, nb, sblk, large_thresh, sh);
     ZK_LAUNCH(ctx, "msm_size_sort", msm_scan_local, dim3(sblk2), dim3(256), 0, sh, nsh, so, ssums);
@@ -953,7 +997,7 @@ int msm_batch_t(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases, c
     constexpr int LPB = BucketLane<F>::LANES;
     const int c = bases[0]->c_tab;
     const uint32_t B = 1u << (c - 1);
-    const uint32_t L = msm_tail_segment(ctx, B, count);
+    const uint32_t L = msm_tail_segment(ctx, B, count, LPB);
     const uint32_t tail_slots = MSM_TAIL_THREADS / LPB;  // points per tail workgroup
     const uint32_t nseg = B / L, nblk_tail = (nseg + tail_slots - 1) / tail_slots;
     size_t max_need = 0;

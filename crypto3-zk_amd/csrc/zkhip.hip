@@ -123,6 +123,7 @@ int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value) {
     if (n == "msm_window_bits") ctx->opt_msm_window_bits = (int)value;
     else if (n == "msm_segment_log") ctx->opt_msm_segment_log = (int)value;
     else if (n == "msm_sets") ctx->opt_msm_sets = (int)value;
+    else if (n == "msm_sort_tile_log") ctx->opt_msm_sort_tile_log = (int)value;
     else if (n == "ntt_radix_log") ctx->opt_ntt_radix_log = (int)value;
     else if (n == "ntt_tile_log") ctx->opt_ntt_tile_log = (int)value;
     else if (n == "msm_precompute") ctx->opt_msm_precompute = (int)value;

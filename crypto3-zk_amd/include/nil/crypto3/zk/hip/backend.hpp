@@ -61,6 +61,7 @@ public:
     /// work enqueued here from now on runs after what `other` has enqueued so far (both on the same GPU)
     void wait_for(const context &other) const { check(zkhip_stream_wait(ctx_, other.ctx_), "zkhip_stream_wait", ctx_); }
     void sync() const { check(zkhip_sync(ctx_), "zkhip_sync", ctx_); }
+    void set_option(const char *name, std::int64_t value) const { check(zkhip_set_option(ctx_, name, value), "zkhip_set_option", ctx_); }
 
     /// device buffer of `bytes` bytes, freed with the returned handle
     std::shared_ptr<void> alloc(std::size_t bytes) const {

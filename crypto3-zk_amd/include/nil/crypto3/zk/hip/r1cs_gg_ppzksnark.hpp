@@ -310,7 +310,13 @@ public:
         d_scratch = ctx.alloc(zkhip_groth16_scratch_bytes(constraint_system.get()));
         d_bs = ctx.alloc(std::max<std::size_t>(1, B_count) * 32);
         d_results = ctx.alloc(result_bytes);
-        if (overlap_g2 && !side && B_count >= ((std::size_t)1 << 14)) side.reset(new context(ctx.device()));    // pays off for large queries only
+        if (overlap_g2 && !side && B_count >= ((std::size_t)1 << 14)) {    // pays off for large queries only
+            side.reset(new context(ctx.device()));
+            /* two streams share the GPU from here on: sort tiles small enough to sit next to the other stream's resident
+               accumulation workgroups (see "msm_sort_tile_log" in include/zkhip.h) */
+            ctx.set_option("msm_sort_tile_log", 12);
+            side->set_option("msm_sort_tile_log", 12);
+        }
         work_cpa_ = cpa_elems;
     }
 

@@ -91,10 +91,16 @@ def test_msm_edge_cases(ctx, curve, group):
     exp = po.msm_naive(G, P, sc)
     assert gpu_affine(ctx, bases, fr_arr(sc)) == exp
     # every window size, with window tables (rebuilt for each c) ...
-    for c in (2, 3, 5, 7, 12, 15, 16):  # 3, 5, 15 divide 255: the top window is full
+    for c in (2, 3, 5, 7, 12, 15, 16, 17, 20, 21):  # 3, 5, 15, 17 divide 255: the top window is full
         ctx.set_option("msm_window_bits", c)
         tb = ctx.upload_bases(curve, group, arr, infs)
-        assert gpu_affine(ctx, tb, fr_arr(sc)) == exp, c
+        # all windows in one bucket set, a few sets folded afterwards, one set per window; both sort tile shapes
+        for sets, tile_log in ((0, 14), (1, 14), (2, 12), (5, 14), (64, 12)):
+            ctx.set_option("msm_sets", sets)
+            ctx.set_option("msm_sort_tile_log", tile_log)
+            assert gpu_affine(ctx, tb, fr_arr(sc)) == exp, (c, sets, tile_log)
+        ctx.set_option("msm_sets", 0)
+        ctx.set_option("msm_sort_tile_log", 14)
         tb.free()
     # ... and without them (the per-window sums are combined by the Horner pass of msm_final)
     ctx.set_option("msm_precompute", 0)
@@ -102,7 +108,7 @@ def test_msm_edge_cases(ctx, curve, group):
     bases.free()
     bases = ctx.upload_bases(curve, group, arr, infs)
     ctx.set_option("msm_precompute", 1)
-    for c in (0, 2, 3, 5, 7, 12, 15, 16):
+    for c in (0, 2, 3, 5, 7, 12, 15, 16, 19):
         ctx.set_option("msm_window_bits", c)
         assert gpu_affine(ctx, bases, fr_arr(sc)) == exp, c
     # scalars that are not canonical are taken mod r (the reference's field type cannot hold them)
