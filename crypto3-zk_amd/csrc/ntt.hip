@@ -22,9 +22,18 @@
 // canonical.  Global reads are runs of T*32 B, writes runs of >= T*32 B.
 //
 // Data stays CANONICAL in HBM between passes; twiddles are Montgomery, so mul(x, w) = x*w is canonical and no
-// conversion pass exists.  omega^e for arbitrary e comes from a two-level table (lo[e mod 2^h] * hi[e >> h],
-// 2 * 2^h entries, L2-resident) instead of an m/2-entry table in HBM.  The coset pre-scale (forward), the 1/m
-// and the coset^-1 post-scale (inverse) ride on the first load / the last store.
+// conversion pass exists.  Every per-element factor is ONE product against a table entry read next to the element:
+//   tw[i]     the factor pass i applies while storing (the next pass's omega_(Ns R)^(k t), times 1/m on the first
+//             boundary of an inverse transform), m entries of 32 B in output order -- read once per tile and shared by
+//             the PB polynomials a workgroup carries, so the tables add m * 32 B of traffic per pass to a batch's
+//             2 * batch * m * 32 B;
+//   pre/post  g^i (forward coset, first load) / (1/m) g^-i (inverse coset, last store);
+//   stage     omega_R^q, q < R/2, staged in LDS per workgroup without any arithmetic.
+// The tables are built once per (size, omega, direction, coset, radix plan) from a two-level power table and cached
+// in the context.  A last pass with nothing to multiply by (forward, no coset) brings its lazy values (< 64p) back
+// below p by a 7-bit quotient estimate instead of a product (fu_reduce_small).
+// Two radix-2 stages run per LDS round trip (a thread holds the four rows i0 + {0, h, 2h, 3h}: the same four products
+// as two separate stages, half the LDS traffic and barriers).
 #include <algorithm>
 
 #include "ctx.hpp"
@@ -32,13 +41,20 @@
 
 using namespace zkhip;
 
+static constexpr int NTT_MAX_PASSES = 32;  // log_m <= 32 at radix 2
+static constexpr uint32_t NTT_PAD = 0;  // extra elements per LDS row (see lds_get)
+
 struct NttTables {
     int curve;
     size_t log_m;
     int inverse;
     bool has_coset;
+    int smax, tile_log;  // the radix plan the per-pass tables were built for
     uint64_t omega[4], coset[4];
     int lo_bits;
+    uint32_t *d_tw[NTT_MAX_PASSES] = {};     // store factors of pass i (i < passes - 1): m x 8 u32, Montgomery, saturated limbs
+    uint32_t *d_stage[NTT_MAX_PASSES] = {};  // omega_R^q, q < R/2, Fu form (SL words)
+    uint32_t *d_prepost = nullptr;           // coset: g^i (forward) or (1/m) g^-i (inverse), m x 8 u32
     uint32_t *d_lo = nullptr, *d_hi = nullptr;    // omega^i, omega^(i << lo_bits)          (Montgomery, SL words each)
     uint32_t *d_clo = nullptr, *d_chi = nullptr;  // g^i, g^(i << lo_bits), g = coset or coset^-1
     uint32_t *d_scale = nullptr;                  // [0] = 1/m (inverse) or 1 (forward), Montgomery
@@ -51,12 +67,19 @@ struct NttPass {
     uint32_t log_m, s, log_ns, log_t;
     uint32_t tiles_per_poly;
     uint32_t next_s;            // radix bits of the following pass, 0 on the last pass
+    const uint32_t *stage;      // omega_R^q, q < R/2 (Fu form)
+    const uint32_t *tw;         // store factors in output order (not on the last pass)
+    const uint32_t *pre;        // first pass of a forward coset transform: g^index, else null
+    const uint32_t *post;       // last pass of an inverse coset transform: (1/m) g^-index, else null
+    const uint32_t *scale;      // single-pass inverse transform: 1/m (Fu form), else null
+};
+
+// parameters of the table-building kernel: everything ntt_pass used to look up on the fly
+struct NttTwGeom {
+    uint32_t log_m, s, log_ns, next_s;
     const uint32_t *lo, *hi;
     uint32_t lo_bits;
-    const uint32_t *clo, *chi;  // coset power tables (g or g^-1), or null
-    const uint32_t *scale;      // last pass: 1/m (inverse) or the Montgomery one (forward)
-    uint32_t pre_coset;         // multiply by g^index while loading   (first pass, forward coset)
-    uint32_t post_coset;        // multiply by g^index while storing   (last pass, inverse coset)
+    const uint32_t *scale;  // folded into the first boundary of an inverse transform, else null
 };
 
 // out[i] = base^(i << shift), i < count  (Montgomery in/out, canonical representatives)
@@ -108,23 +131,27 @@ ZK_D Fu<U> tw_lookup(const uint32_t *__restrict__ lo, const uint32_t *__restrict
 
 ZK_D uint32_t bitrev(uint32_t v, uint32_t bits) { return bits == 0 ? 0 : (__brev(v) >> (32 - bits)); }
 
-// LDS element e of `nelem`: limbs 0-3 at plane 0, 4-7 at plane 1 (uint4 each), limb 8 at plane 2 (u32)
+// LDS tile: rows of T elements at a pitch of T + NTT_PAD.  NTT_PAD = 0: the 2^8 x 8 tile (73.7 KiB + 4.6 KiB of stage
+// twiddles) then fits twice per CU -- two workgroups, two waves per SIMD -- which padding the rows to 9 elements (83 KiB)
+// would halve; the kernel is bound by VALU issue, not by LDS.  Element slot e: limbs 0-3 at plane 0, 4-7 at plane 1
+// (uint4 each), limb 8 at plane 2 (u32).  `slots` = rows * pitch.
 template <class U>
-ZK_D Fu<U> lds_get(const uint4 *lds, uint32_t nelem, uint32_t e) {
+ZK_D Fu<U> lds_get(const uint4 *lds, uint32_t slots, uint32_t e) {
     static_assert(U::L == 9, "Fr compute form is 9 x 29-bit limbs");
     Fu<U> r;
-    uint4 a = lds[e], b = lds[nelem + e];
+    uint4 a = lds[e], b = lds[slots + e];
     r.v[0] = a.x, r.v[1] = a.y, r.v[2] = a.z, r.v[3] = a.w;
     r.v[4] = b.x, r.v[5] = b.y, r.v[6] = b.z, r.v[7] = b.w;
-    r.v[8] = reinterpret_cast<const uint32_t *>(lds + 2 * nelem)[e];
+    r.v[8] = reinterpret_cast<const uint32_t *>(lds + 2 * slots)[e];
     return r;
 }
 template <class U>
-ZK_D void lds_put(uint4 *lds, uint32_t nelem, uint32_t e, const Fu<U> &x) {
+ZK_D void lds_put(uint4 *lds, uint32_t slots, uint32_t e, const Fu<U> &x) {
     lds[e] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
-    lds[nelem + e] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
-    reinterpret_cast<uint32_t *>(lds + 2 * nelem)[e] = x.v[8];
+    lds[slots + e] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+    reinterpret_cast<uint32_t *>(lds + 2 * slots)[e] = x.v[8];
 }
+ZK_HD uint32_t ntt_tile_u4(uint32_t slots) { return 2 * slots + (slots + 3) / 4; }  // uint4 units of one tile's three planes
 
 // canonical 8 x u32 in global memory <-> lazy limbs
 template <class U>
@@ -143,60 +170,153 @@ ZK_D void g_store(uint32_t *p, const Fu<U> &x) {
     q[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
+// normalised limbs, value < 64 p  ->  [0, p), without a Montgomery product: q = floor(x / p) is estimated from the
+// top 13 bits of x with a 24-bit reciprocal (one short too low at most), x - q p < 2p, one conditional subtraction.
 template <class U>
+ZK_D Fu<U> fu_reduce_small(const Fu<U> &x) {
+    constexpr int L = U::L, B = U::B;
+    static_assert(L == 9 && B == 29, "sized for the 9 x 29-bit scalar fields");
+    // mu = floor(2^272 / p), p < 2^255  =>  mu < 2^24 for p > 2^248; t = x >> 248 < 2^13
+    constexpr uint32_t mu = U::MU272;
+    const uint32_t t = x.v[8] >> 16;
+    const uint32_t q = (uint32_t)(((uint64_t)t * mu) >> 24);
+    Fu<U> y;
+    uint64_t carry = 0;  // q p, limb by limb
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        carry += (uint64_t)q * U::mod(i);
+        const uint32_t qp = (uint32_t)carry & Fu<U>::MASK;
+        carry >>= B;
+        const uint32_t d = x.v[i] - qp - borrow;  // limbs < 2^30: bit 31 of d is its sign
+        borrow = i + 1 < L ? d >> 31 : 0;
+        y.v[i] = i + 1 < L ? d & Fu<U>::MASK : d;
+    }
+    return fu_cond_sub_p(y);
+}
+
+// tw[oi] for one pass boundary (output order of the pass being stored = input order of the next): the next pass's
+// omega_(Ns' R')^(k' t'), times `scale` when given.  Saturated Montgomery limbs, canonical representative.
+template <class U>
+__global__ __launch_bounds__(256) void ntt_build_tw(NttTwGeom g, uint32_t *__restrict__ out) {
+    const uint64_t oi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (oi >> g.log_m) return;
+    const uint32_t n_log_ns = g.log_ns + g.s, n_log_stride = g.log_m - g.next_s;
+    const uint32_t n_tw_shift = g.log_m - n_log_ns - g.next_s;  // omega_(Ns' R') = omega^(m / (Ns' R'))
+    const uint64_t jn = oi & ((1ull << n_log_stride) - 1), tn = oi >> n_log_stride;
+    const uint64_t ex = ((jn & ((1ull << n_log_ns) - 1)) * tn) << n_tw_shift;
+    Fu<U> f = tw_lookup<U>(g.lo, g.hi, g.lo_bits, ex);
+    if (g.scale != nullptr) f = fu_cond_sub_p(fu_mul(f, fu_load<U>(g.scale)));
+    g_store<U>(out + oi * 8, f);
+}
+// out[i] = scale * base^i (the coset factors), same format
+template <class U>
+__global__ __launch_bounds__(256) void ntt_build_powers(const uint32_t *__restrict__ lo, const uint32_t *__restrict__ hi, uint32_t lo_bits, uint32_t log_m,
+                                                        const uint32_t *__restrict__ scale, uint32_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> log_m) return;
+    Fu<U> f = tw_lookup<U>(lo, hi, lo_bits, i);
+    if (scale != nullptr) f = fu_cond_sub_p(fu_mul(f, fu_load<U>(scale)));
+    g_store<U>(out + i * 8, f);
+}
+// stage[q] = omega^(q << shift), q < count, Fu form
+template <class U>
+__global__ __launch_bounds__(256) void ntt_build_stage(const uint32_t *__restrict__ lo, const uint32_t *__restrict__ hi, uint32_t lo_bits, uint32_t shift,
+                                                       uint32_t count, uint32_t *__restrict__ out) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= count) return;
+    fu_store<U>(out + (size_t)q * U::SL, tw_lookup<U>(lo, hi, lo_bits, (uint64_t)q << shift));
+}
+
+// One pass over PB polynomials of the batch per workgroup (they share every index, twiddle and table entry).
+template <class U, int PB>
 __global__ __launch_bounds__(256) void ntt_pass(NttPass p) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     const uint32_t R = 1u << p.s, T = 1u << p.log_t, nelem = R * T;
+    const uint32_t pitch = T + NTT_PAD, slots = R * pitch;
     const uint32_t tid = threadIdx.x, nth = blockDim.x;
-    // tile: 2 * nelem uint4 + nelem u32 (rounded to uint4); stage twiddles behind it, same three-plane shape
-    const uint32_t tile_u4 = 2 * nelem + (nelem + 3) / 4;
-    uint4 *twr = lds + tile_u4;
+    const uint32_t tile_u4 = ntt_tile_u4(slots);
+    uint4 *twr = lds + PB * tile_u4;  // stage twiddles behind the tiles, same three-plane shape
+    const uint32_t nhalf = R / 2 > 0 ? R / 2 : 1;
 
-    const uint32_t poly = blockIdx.x / p.tiles_per_poly;
+    const uint32_t poly0 = (blockIdx.x / p.tiles_per_poly) * PB;
     const uint32_t tile = blockIdx.x % p.tiles_per_poly;
     const uint32_t log_stride = p.log_m - p.s;  // m / R
     const uint64_t j0 = (uint64_t)tile << p.log_t;
-    const uint32_t *src = p.in + ((size_t)poly << p.log_m) * 8;
-    uint32_t *dst = p.out + ((size_t)poly << p.log_m) * 8;
     const uint32_t ns_mask = (1u << p.log_ns) - 1;  // log_ns < 32 always (m <= 2^32)
-    const uint32_t nhalf = R / 2 > 0 ? R / 2 : 1;
 
-    // stage twiddles omega_R^q = omega^(q m/R), q < R/2
-    for (uint32_t q = tid; q < R / 2; q += nth) lds_put(twr, nhalf, q, tw_lookup<U>(p.lo, p.hi, p.lo_bits, (uint64_t)q << log_stride));
+    for (uint32_t q = tid; q < R / 2; q += nth) lds_put(twr, nhalf, q, fu_load<U>(p.stage + (size_t)q * U::SL));
     // load tile: row bitrev(t), column c  <-  x[j0 + c + t m/R]   [* g^index on the first pass of a coset transform]
     for (uint32_t e = tid; e < nelem; e += nth) {
-        uint32_t t = e >> p.log_t, c = e & (T - 1);
-        uint64_t gi = j0 + c + ((uint64_t)t << log_stride);
-        Fu<U> x = g_load<U>(src + gi * 8);
-        if (p.pre_coset) x = fu_mul(x, tw_lookup<U>(p.clo, p.chi, p.lo_bits, gi));
-        lds_put(lds, nelem, (bitrev(t, p.s) << p.log_t) + c, x);
+        const uint32_t t = e >> p.log_t, c = e & (T - 1);
+        const uint64_t gi = j0 + c + ((uint64_t)t << log_stride);
+        const uint32_t slot = bitrev(t, p.s) * pitch + c;
+        Fu<U> g;
+        if (p.pre) g = g_load<U>(p.pre + gi * 8);
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            Fu<U> x = g_load<U>(p.in + ((((size_t)(poly0 + b)) << p.log_m) + gi) * 8);
+            if (p.pre) x = fu_mul(x, g);
+            lds_put(lds + b * tile_u4, slots, slot, x);
+        }
     }
     __syncthreads();
-    // s radix-2 DIT stages over the rows (bit-reversed in, natural out): (a, b) -> (a + w b, a + 4p - w b)
-    const uint32_t nbf = nelem >> 1;
-    for (uint32_t st = 0; st < p.s; ++st) {
+    // s radix-2 DIT stages over the rows (bit-reversed in, natural out), (a, b) -> (a + w b, a + 4p - w b), two per round trip
+    uint32_t st = 0;
+    if (p.s & 1) {  // odd stage count: stage 0 alone (w = 1; loaded values are < 2p: keep the subtrahend below 3p)
+        for (uint32_t bf = tid; bf < (nelem >> 1); bf += nth) {
+            const uint32_t c = bf & (T - 1), q = bf >> p.log_t;
+            const uint32_t e0 = (q << 1) * pitch + c, e1 = e0 + pitch;
+#pragma unroll
+            for (int b = 0; b < PB; ++b) {
+                uint4 *tl = lds + b * tile_u4;
+                Fu<U> x0 = lds_get<U>(tl, slots, e0), x1 = fu_cond_sub_p(lds_get<U>(tl, slots, e1));
+                lds_put(tl, slots, e0, fu_add(x0, x1));
+                lds_put(tl, slots, e1, fu_sub<4>(x0, x1));
+            }
+        }
+        st = 1;
+        __syncthreads();
+    }
+    for (; st < p.s; st += 2) {
         const uint32_t h = 1u << st;
-        for (uint32_t bf = tid; bf < nbf; bf += nth) {
-            uint32_t c = bf & (T - 1), q = bf >> p.log_t;
-            uint32_t qq = q & (h - 1);
-            uint32_t i0 = ((q - qq) << 1) + qq;
-            uint32_t e0 = (i0 << p.log_t) + c, e1 = ((i0 + h) << p.log_t) + c;
-            Fu<U> a = lds_get<U>(lds, nelem, e0), b = lds_get<U>(lds, nelem, e1);
-            if (st != 0) b = fu_mul(b, lds_get<U>(twr, nhalf, qq << (p.s - 1 - st)));  // st = 0: w = 1
-            else b = fu_cond_sub_p(b);  // loaded values are < 2p; keep the subtrahend below 3p
-            lds_put(lds, nelem, e0, fu_add(a, b));
-            lds_put(lds, nelem, e1, fu_sub<4>(a, b));
+        for (uint32_t gq = tid; gq < (nelem >> 2); gq += nth) {
+            const uint32_t c = gq & (T - 1), q = gq >> p.log_t;
+            const uint32_t qq = q & (h - 1);
+            const uint32_t i0 = ((q - qq) << 2) + qq;  // rows i0, i0 + h, i0 + 2h, i0 + 3h
+            const uint32_t e0 = i0 * pitch + c, eh = h * pitch;
+            // stage st pairs (i0, i0 + h) and (i0 + 2h, i0 + 3h) with omega_R^(qq << (s-1-st)); stage st + 1 pairs
+            // (i0, i0 + 2h) with omega_R^(qq << (s-2-st)) and (i0 + h, i0 + 3h) with omega_R^((qq + h) << (s-2-st))
+            Fu<U> w1, w2a, w2b;
+            if (st != 0) w1 = lds_get<U>(twr, nhalf, qq << (p.s - 1 - st));
+            w2a = lds_get<U>(twr, nhalf, qq << (p.s - 2 - st));
+            w2b = lds_get<U>(twr, nhalf, (qq + h) << (p.s - 2 - st));
+#pragma unroll
+            for (int b = 0; b < PB; ++b) {
+                uint4 *tl = lds + b * tile_u4;
+                Fu<U> x0 = lds_get<U>(tl, slots, e0), x1 = lds_get<U>(tl, slots, e0 + eh), x2 = lds_get<U>(tl, slots, e0 + 2 * eh),
+                      x3 = lds_get<U>(tl, slots, e0 + 3 * eh);
+                if (st != 0) {
+                    x1 = fu_mul(x1, w1);
+                    x3 = fu_mul(x3, w1);
+                } else {  // w = 1; values straight from the load are < 2p
+                    x1 = fu_cond_sub_p(x1);
+                    x3 = fu_cond_sub_p(x3);
+                }
+                const Fu<U> a0 = fu_add(x0, x1), a1 = fu_sub<4>(x0, x1), a2 = fu_add(x2, x3), a3 = fu_sub<4>(x2, x3);
+                const Fu<U> b2 = fu_mul(a2, w2a), b3 = fu_mul(a3, w2b);
+                lds_put(tl, slots, e0, fu_add(a0, b2));
+                lds_put(tl, slots, e0 + 2 * eh, fu_sub<4>(a0, b2));
+                lds_put(tl, slots, e0 + eh, fu_add(a1, b3));
+                lds_put(tl, slots, e0 + 3 * eh, fu_sub<4>(a1, b3));
+            }
         }
         __syncthreads();
     }
-    // store: y[(j - k) R + k + t' Ns] = v[t'] * (next pass's twiddle | final scale)
+    // store: y[(j - k) R + k + t' Ns] = v[t'] * (this boundary's table entry | coset / scale factor | nothing)
     const uint32_t last = p.next_s == 0;
-    const uint32_t n_log_ns = p.log_ns + p.s;                  // next pass: Ns' = Ns R
-    const uint32_t n_log_stride = p.log_m - p.next_s;          // m / R'
-    const uint32_t n_ns_mask = (1u << n_log_ns) - 1;
-    const uint32_t n_tw_shift = p.log_m - n_log_ns - p.next_s;  // omega_(Ns' R') = omega^(m / (Ns' R'))
-    Fu<U> scale = Fu<U>::one();
-    if (last) scale = fu_load<U>(p.scale);
+    Fu<U> scale;
+    if (p.scale) scale = fu_load<U>(p.scale);
     for (uint32_t e = tid; e < nelem; e += nth) {
         uint32_t tp, c;
         if (p.log_ns >= p.log_t) {
@@ -208,59 +328,95 @@ __global__ __launch_bounds__(256) void ntt_pass(NttPass p) {
             uint32_t c_hi = e >> (p.log_ns + p.s);
             c = (c_hi << p.log_ns) + k_lo;
         }
-        uint64_t j = j0 + c;
-        uint64_t k = j & ns_mask;
-        uint64_t oi = ((j - k) << p.s) + k + ((uint64_t)tp << p.log_ns);
-        Fu<U> x = lds_get<U>(lds, nelem, (tp << p.log_t) + c);
+        const uint64_t j = j0 + c;
+        const uint64_t k = j & ns_mask;
+        const uint64_t oi = ((j - k) << p.s) + k + ((uint64_t)tp << p.log_ns);
+        const uint32_t *ftab = last ? p.post : p.tw;
         Fu<U> f;
-        if (!last) {
-            uint64_t jn = oi & ((1ull << n_log_stride) - 1), tn = oi >> n_log_stride;
-            uint64_t ex = ((jn & n_ns_mask) * tn) << n_tw_shift;
-            f = tw_lookup<U>(p.lo, p.hi, p.lo_bits, ex);
-        } else {
-            f = scale;
-            if (p.post_coset) f = fu_cond_sub_p(fu_mul(f, tw_lookup<U>(p.clo, p.chi, p.lo_bits, oi)));
+        if (ftab) f = g_load<U>(ftab + oi * 8);
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            Fu<U> x = lds_get<U>(lds + b * tile_u4, slots, tp * pitch + c);
+            if (ftab) x = fu_cond_sub_p(fu_mul(x, f));
+            else if (p.scale) x = fu_cond_sub_p(fu_mul(x, scale));
+            else x = fu_reduce_small(x);
+            g_store<U>(p.out + ((((size_t)(poly0 + b)) << p.log_m) + oi) * 8, x);
         }
-        g_store<U>(dst + oi * 8, fu_cond_sub_p(fu_mul(x, f)));
     }
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-void zk_ntt_free_tables(zkhip_ctx *ctx) {
-    for (NttTables *t : ctx->ntt_tables) {
-        (void)hipFree(t->d_lo);
-        (void)hipFree(t->d_hi);
-        (void)hipFree(t->d_clo);
-        (void)hipFree(t->d_chi);
-        (void)hipFree(t->d_scale);
-        (void)hipFree(t->d_base);
-        delete t;
+static void ntt_free_one(NttTables *t) {
+    (void)hipFree(t->d_lo);
+    (void)hipFree(t->d_hi);
+    (void)hipFree(t->d_clo);
+    (void)hipFree(t->d_chi);
+    (void)hipFree(t->d_scale);
+    (void)hipFree(t->d_base);
+    (void)hipFree(t->d_prepost);
+    for (int i = 0; i < NTT_MAX_PASSES; ++i) {
+        (void)hipFree(t->d_tw[i]);
+        (void)hipFree(t->d_stage[i]);
     }
+    delete t;
+}
+
+void zk_ntt_free_tables(zkhip_ctx *ctx) {
+    for (NttTables *t : ctx->ntt_tables) ntt_free_one(t);
     ctx->ntt_tables.clear();
 }
 
+// the radix plan: log_m split into np nearly equal radices (larger first), tile widths
+struct NttPlan {
+    int np;
+    int sv[NTT_MAX_PASSES], log_t[NTT_MAX_PASSES];
+};
+static NttPlan ntt_plan(size_t log_m, int smax, int tile_log) {
+    NttPlan pl;
+    pl.np = (int)((log_m + smax - 1) / smax);
+    for (int i = 0; i < pl.np; ++i) {
+        pl.sv[i] = (int)(log_m / pl.np) + (i < (int)(log_m % pl.np) ? 1 : 0);
+        const int log_cols = (int)log_m - pl.sv[i];  // log2(m / R)
+        pl.log_t[i] = std::min(std::max(0, tile_log), log_cols);
+        while (pl.sv[i] + pl.log_t[i] > 12 && pl.log_t[i] > 0) --pl.log_t[i];  // LDS budget: R * T * 36 B <= 144 KiB
+    }
+    return pl;
+}
+
 template <class U>
-static int ntt_get_tables(zkhip_ctx *ctx, int curve, size_t log_m, const uint64_t *omega, int inverse, const uint64_t *coset,
+static int ntt_get_tables(zkhip_ctx *ctx, int curve, size_t log_m, const uint64_t *omega, int inverse, const uint64_t *coset, int smax, int tile_log,
                           NttTables **out) {
     for (NttTables *t : ctx->ntt_tables) {
-        if (t->curve == curve && t->log_m == log_m && t->inverse == inverse && t->has_coset == (coset != nullptr) &&
-            memcmp(t->omega, omega, 32) == 0 && (coset == nullptr || memcmp(t->coset, coset, 32) == 0)) {
+        if (t->curve == curve && t->log_m == log_m && t->inverse == inverse && t->has_coset == (coset != nullptr) && t->smax == smax &&
+            t->tile_log == tile_log && memcmp(t->omega, omega, 32) == 0 && (coset == nullptr || memcmp(t->coset, coset, 32) == 0)) {
             *out = t;
             return 0;
         }
+    }
+    if ((int)((log_m + smax - 1) / smax) > NTT_MAX_PASSES) return ZKHIP_ERR_RANGE;
+    const NttPlan pl = ntt_plan(log_m, smax, tile_log);
+    // the per-index tables are m x 32 B each: keep the cache within a few entries per size (a prover alternates between a
+    // handful of (direction, coset) variants of one or two sizes)
+    if (ctx->ntt_tables.size() >= 24) {
+        ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        ntt_free_one(ctx->ntt_tables.front());
+        ctx->ntt_tables.erase(ctx->ntt_tables.begin());
     }
     NttTables *t = new NttTables();
     t->curve = curve;
     t->log_m = log_m;
     t->inverse = inverse;
     t->has_coset = coset != nullptr;
+    t->smax = smax;
+    t->tile_log = tile_log;
     memcpy(t->omega, omega, 32);
     if (coset) memcpy(t->coset, coset, 32);
     t->lo_bits = (int)((log_m + 1) / 2);
     if (t->lo_bits < 1) t->lo_bits = 1;
     const uint32_t nlo = 1u << t->lo_bits;
     const uint32_t nhi = (uint32_t)(((size_t)1 << log_m) >> t->lo_bits) + 1;
-    const size_t eb = U::SL * 4;  // bytes per table entry
+    const size_t eb = U::SL * 4;  // bytes per power-table entry
+    const size_t m = (size_t)1 << log_m;
     ctx->ntt_tables.push_back(t);  // owned by the context from here on (freed in zk_ntt_free_tables)
     uint32_t *d_in = nullptr;
     ZK_HIP_CHECK(ctx, hipMalloc((void **)&d_in, 64));
@@ -274,16 +430,45 @@ static int ntt_get_tables(zkhip_ctx *ctx, int curve, size_t log_m, const uint64_
               (uint32_t)log_m, t->d_base, t->d_scale);
     ZK_LAUNCH(ctx, "ntt_pow_table", ntt_pow_table<U>, dim3((nlo + 255) / 256), dim3(256), 0, t->d_base, nlo, 0u, t->d_lo);
     ZK_LAUNCH(ctx, "ntt_pow_table", ntt_pow_table<U>, dim3((nhi + 255) / 256), dim3(256), 0, t->d_base, nhi, (uint32_t)t->lo_bits, t->d_hi);
+    const unsigned gm = (unsigned)((m + 255) / 256);
     if (coset) {
         ZK_HIP_CHECK(ctx, hipMalloc((void **)&t->d_clo, (size_t)nlo * eb));
         ZK_HIP_CHECK(ctx, hipMalloc((void **)&t->d_chi, (size_t)nhi * eb));
         ZK_LAUNCH(ctx, "ntt_pow_table", ntt_pow_table<U>, dim3((nlo + 255) / 256), dim3(256), 0, t->d_base + U::SL, nlo, 0u, t->d_clo);
         ZK_LAUNCH(ctx, "ntt_pow_table", ntt_pow_table<U>, dim3((nhi + 255) / 256), dim3(256), 0, t->d_base + U::SL, nhi, (uint32_t)t->lo_bits,
                   t->d_chi);
+        // g^i while loading (forward) / (1/m) g^-i while storing (inverse): one entry per index
+        ZK_HIP_CHECK(ctx, hipMalloc((void **)&t->d_prepost, m * 32));
+        ZK_LAUNCH(ctx, "ntt_build_tw", ntt_build_powers<U>, dim3(gm), dim3(256), 0, t->d_clo, t->d_chi, (uint32_t)t->lo_bits, (uint32_t)log_m,
+                  inverse ? t->d_scale : (const uint32_t *)nullptr, t->d_prepost);
+    }
+    // per pass: stage twiddles omega_R^q = omega^(q m / R); per boundary: the store factors in output order.  An inverse
+    // transform without coset folds 1/m into its first boundary (with a coset it rides on the post table; a single
+    // pass multiplies by it directly).
+    uint32_t log_ns = 0;
+    for (int i = 0; i < pl.np; ++i) {
+        const uint32_t s = (uint32_t)pl.sv[i], half = std::max<uint32_t>(1, (1u << s) / 2);
+        ZK_HIP_CHECK(ctx, hipMalloc((void **)&t->d_stage[i], (size_t)half * eb));
+        ZK_LAUNCH(ctx, "ntt_build_tw", ntt_build_stage<U>, dim3((half + 255) / 256), dim3(256), 0, t->d_lo, t->d_hi, (uint32_t)t->lo_bits,
+                  (uint32_t)log_m - s, half, t->d_stage[i]);
+        if (i + 1 < pl.np) {
+            NttTwGeom g;
+            g.log_m = (uint32_t)log_m;
+            g.s = s;
+            g.log_ns = log_ns;
+            g.next_s = (uint32_t)pl.sv[i + 1];
+            g.lo = t->d_lo;
+            g.hi = t->d_hi;
+            g.lo_bits = (uint32_t)t->lo_bits;
+            g.scale = (inverse && !coset && i == 0) ? t->d_scale : nullptr;
+            ZK_HIP_CHECK(ctx, hipMalloc((void **)&t->d_tw[i], m * 32));
+            ZK_LAUNCH(ctx, "ntt_build_tw", ntt_build_tw<U>, dim3(gm), dim3(256), 0, g, t->d_tw[i]);
+        }
+        log_ns += s;
     }
     // omega must be a PRIMITIVE m-th root of unity (the caller's evaluation domain is the basic radix-2 one): omega^m = 1
     // and omega^(m/2) != 1, read back from the tables just built.  Anything else would transform over the wrong domain.
-    const size_t half = ((size_t)1 << log_m) >> 1;
+    const size_t half = m >> 1;
     uint32_t w_m[U::L], w_half[U::L];
     const uint32_t *d_half = half < nlo ? t->d_lo + half * U::SL : t->d_hi + (half >> t->lo_bits) * U::SL;
     ZK_HIP_CHECK(ctx, hipMemcpyAsync(w_m, t->d_hi + (size_t)(nhi - 1) * U::SL, sizeof(w_m), hipMemcpyDeviceToHost, ctx->stream));
@@ -297,8 +482,7 @@ static int ntt_get_tables(zkhip_ctx *ctx, int curve, size_t log_m, const uint64_
     }
     if (!m_is_one || half_is_one) {
         ctx->ntt_tables.pop_back();
-        (void)hipFree(t->d_lo), (void)hipFree(t->d_hi), (void)hipFree(t->d_clo), (void)hipFree(t->d_chi), (void)hipFree(t->d_scale), (void)hipFree(t->d_base);
-        delete t;
+        ntt_free_one(t);
         ctx->last_error = "omega is not a primitive 2^" + std::to_string(log_m) + "-th root of unity";
         return ZKHIP_ERR_INVALID;
     }
@@ -310,13 +494,11 @@ template <class U>
 static int ntt_run_t(zkhip_ctx *ctx, int curve, uint32_t *d_data, size_t log_m, size_t batch, const uint64_t *omega, int inverse,
                      const uint64_t *coset) {
     if (batch == 0 || log_m == 0) return 0;  // a 1-point transform is the identity (also with coset: g^0 = 1, 1/1 = 1)
-    NttTables *tb = nullptr;
-    ZK_TRY(ntt_get_tables<U>(ctx, curve, log_m, omega, inverse, coset, &tb));
     const int smax = std::max(1, std::min(10, ctx->opt_ntt_radix_log));
-    const int np = (int)((log_m + smax - 1) / smax);
-    // split log_m into np nearly equal radices, larger ones first
-    int sv[64];
-    for (int i = 0; i < np; ++i) sv[i] = (int)(log_m / np) + (i < (int)(log_m % np) ? 1 : 0);
+    NttTables *tb = nullptr;
+    ZK_TRY(ntt_get_tables<U>(ctx, curve, log_m, omega, inverse, coset, smax, ctx->opt_ntt_tile_log, &tb));
+    const NttPlan pl = ntt_plan(log_m, smax, ctx->opt_ntt_tile_log);
+    const int np = pl.np;
     const size_t m = (size_t)1 << log_m;
     const size_t bytes = batch * m * 32;
     uint32_t *wsA = nullptr, *wsB = nullptr;
@@ -340,29 +522,24 @@ static int ntt_run_t(zkhip_ctx *ctx, int curve, uint32_t *d_data, size_t log_m, 
         p.in = src;
         p.out = dst;
         p.log_m = (uint32_t)log_m;
-        p.s = (uint32_t)sv[i];
-        p.next_s = i + 1 < np ? (uint32_t)sv[i + 1] : 0u;
+        p.s = (uint32_t)pl.sv[i];
+        p.next_s = i + 1 < np ? (uint32_t)pl.sv[i + 1] : 0u;
         p.log_ns = log_ns;
-        uint32_t log_cols = (uint32_t)log_m - p.s;  // log2(m / R)
-        p.log_t = std::min<uint32_t>((uint32_t)std::max(0, ctx->opt_ntt_tile_log), log_cols);
-        // LDS budget: R * T * 36 B <= 144 KiB
-        while (p.s + p.log_t > 12 && p.log_t > 0) --p.log_t;
-        p.tiles_per_poly = 1u << (log_cols - p.log_t);
-        p.lo = tb->d_lo;
-        p.hi = tb->d_hi;
-        p.lo_bits = (uint32_t)tb->lo_bits;
-        p.clo = tb->d_clo;
-        p.chi = tb->d_chi;
-        p.scale = tb->d_scale;
-        p.pre_coset = (!inverse && coset != nullptr && i == 0) ? 1u : 0u;
-        p.post_coset = (inverse && coset != nullptr && i == np - 1) ? 1u : 0u;
-        size_t nelem = (size_t)1 << (p.s + p.log_t), nhalf = std::max<size_t>(1, ((size_t)1 << p.s) / 2);
-        size_t lds = (2 * nelem + (nelem + 3) / 4 + 2 * nhalf + (nhalf + 3) / 4) * 16;
-        ZK_MAX_LDS(ctx, ntt_pass<U>, 160 * 1024);
+        p.log_t = (uint32_t)pl.log_t[i];
+        p.tiles_per_poly = 1u << ((uint32_t)log_m - p.s - p.log_t);
+        p.stage = tb->d_stage[i];
+        p.tw = tb->d_tw[i];  // null on the last pass
+        p.pre = (!inverse && coset != nullptr && i == 0) ? tb->d_prepost : nullptr;
+        p.post = (inverse && coset != nullptr && i == np - 1) ? tb->d_prepost : nullptr;
+        p.scale = (inverse && coset == nullptr && np == 1) ? tb->d_scale : nullptr;
+        const size_t nelem = (size_t)1 << (p.s + p.log_t), nhalf = std::max<size_t>(1, ((size_t)1 << p.s) / 2);
+        const size_t slots = ((size_t)1 << p.s) * (((size_t)1 << p.log_t) + NTT_PAD);
+        const size_t lds = ((size_t)ntt_tile_u4((uint32_t)slots) + ntt_tile_u4((uint32_t)nhalf)) * 16;
+        ZK_MAX_LDS(ctx, (ntt_pass<U, 1>), 160 * 1024);
         size_t grid = batch * p.tiles_per_poly;
         if (grid >= (1ull << 31)) return ZKHIP_ERR_RANGE;
-        unsigned threads = (unsigned)std::min<size_t>(256, std::max<size_t>(64, nelem / 2));
-        ZK_LAUNCH(ctx, "ntt_pass", ntt_pass<U>, dim3((unsigned)grid), dim3(threads), lds, p);
+        unsigned threads = (unsigned)std::min<size_t>(256, std::max<size_t>(64, nelem / 4));
+        ZK_LAUNCH(ctx, "ntt_pass", (ntt_pass<U, 1>), dim3((unsigned)grid), dim3(threads), lds, p);
         src = dst;
         log_ns += p.s;
     }

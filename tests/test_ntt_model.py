@@ -1,5 +1,6 @@
 """Line-by-line CPU replay of the index arithmetic of crypto3-zk_amd/csrc/ntt.hip (pass planning, tile
-bit-reversed tile load, in-LDS DIT stages, store with the next pass's twiddle and both store decodings,
+bit-reversed tile load, in-LDS DIT stages fused two per round trip, store with the next pass's twiddle (what
+ntt_build_tw tabulates) and both store decodings,
 ping-pong buffer choice) on Python integers, checked against the O(n^2) DFT.  Catches indexing mistakes
 without a GPU; the arithmetic itself is covered by test_host_arith.py."""
 import random
@@ -51,17 +52,32 @@ def kernel_pass(x, log_m, s, log_ns, log_t, next_s, w, r, pre=None, post=None, s
             if pre is not None:
                 v = v * pow(pre, gi, r) % r
             lds[(bitrev(t, s) << log_t) + c] = v
-        for st in range(s):
-            h = 1 << st
+        # the kernel runs stage 0 alone when s is odd, then TWO stages per LDS round trip: a thread holds the rows
+        # i0 + {0, h, 2h, 3h} (ntt_pass: "two per round trip"); replayed here in exactly that order
+        st = 0
+        if s & 1:
             for bf in range(nelem >> 1):
                 c, q = bf & (T - 1), bf >> log_t
-                qq = q & (h - 1)
-                i0 = ((q - qq) << 1) + qq
-                e0, e1 = (i0 << log_t) + c, ((i0 + h) << log_t) + c
+                e0 = ((q << 1) << log_t) + c
+                e1 = e0 + T
                 a, b = lds[e0], lds[e1]
-                if st != 0:
-                    b = b * twr[qq << (s - 1 - st)] % r
                 lds[e0], lds[e1] = (a + b) % r, (a - b) % r
+            st = 1
+        while st < s:
+            h = 1 << st
+            for gq in range(nelem >> 2):
+                c, q = gq & (T - 1), gq >> log_t
+                qq = q & (h - 1)
+                i0 = ((q - qq) << 2) + qq
+                e = [((i0 + k * h) << log_t) + c for k in range(4)]
+                x0, x1, x2, x3 = (lds[i] for i in e)
+                w1 = twr[qq << (s - 1 - st)] if st != 0 else 1
+                w2a, w2b = twr[qq << (s - 2 - st)], twr[(qq + h) << (s - 2 - st)]
+                x1, x3 = x1 * w1 % r, x3 * w1 % r
+                a0, a1, a2, a3 = (x0 + x1) % r, (x0 - x1) % r, (x2 + x3) % r, (x2 - x3) % r
+                b2, b3 = a2 * w2a % r, a3 * w2b % r
+                lds[e[0]], lds[e[2]], lds[e[1]], lds[e[3]] = (a0 + b2) % r, (a0 - b2) % r, (a1 + b3) % r, (a1 - b3) % r
+            st += 2
         for e in range(nelem):
             if log_ns >= log_t:
                 tp, c = e >> log_t, e & (T - 1)
