@@ -106,6 +106,42 @@ __global__ __launch_bounds__(256) void fr_vec_op(const uint32_t *__restrict__ a,
     fu_pack<U>(out + i * U::NL, r);
 }
 
+// out[i] = prod_k in_k[i]: math::polynomial_product on polynomials already brought to the product's domain
+// (placeholder/permutation_argument.hpp:148, gates_argument.hpp:117); `ptrs` is a device array of `count` pointers.
+template <class U>
+__global__ __launch_bounds__(256) void fr_vec_prod(const uint32_t *const *__restrict__ ptrs, uint32_t count, size_t n, uint32_t *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // canonical operands: mul(x, y) = x y / R.  The accumulator stays in Montgomery form (acc R): every factor is lifted
+    // (x_k R^2 / R = x_k R) and multiplied in ((acc R)(x_k R) / R = acc x_k R); one last product by the plain 1 drops the R.
+    Fu<U> acc = fu_mul(fu_unpack<U>(ptrs[0] + i * U::NL), Fu<U>::r2());
+    for (uint32_t k = 1; k < count; ++k) acc = fu_mul(acc, fu_mul(fu_unpack<U>(ptrs[k] + i * U::NL), Fu<U>::r2()));
+    Fu<U> one = Fu<U>::zero();
+    one.v[0] = 1;
+    fu_pack<U>(out + i * U::NL, fu_cond_sub_p(fu_mul(acc, one)));
+}
+
+// out[i] = in[(i + rot) mod 2^log_n] on 32-byte elements: math::polynomial_shift (f(X) -> f(omega^shift X) on the
+// evaluation vector: index i reads i + shift * (size / domain_size)), permutation_argument.hpp:148, lookup_argument.hpp:232
+__global__ __launch_bounds__(256) void poly_rotate(const uint4 *__restrict__ in, uint32_t log_n, size_t rot, uint4 *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> log_n) return;
+    const size_t s = (i + rot) & (((size_t)1 << log_n) - 1);
+    out[2 * i] = in[2 * s];
+    out[2 * i + 1] = in[2 * s + 1];
+}
+
+// out[b][i] = in[b][i << shift]: polynomial_dfs::resize to a SMALLER domain -- the evaluations of a polynomial of degree
+// < 2^log_out on the 2^log_out-point domain are every 2^shift-th of its evaluations on the larger one
+__global__ __launch_bounds__(256) void poly_subsample(const uint4 *__restrict__ in, uint32_t log_n, uint32_t log_out, size_t total, uint4 *__restrict__ out) {
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const size_t b = e >> log_out, i = e & (((size_t)1 << log_out) - 1);
+    const size_t s = (b << log_n) + (i << (log_n - log_out));
+    out[2 * e] = in[2 * s];
+    out[2 * e + 1] = in[2 * s + 1];
+}
+
 // canonical -> Montgomery (canonical representative) for a short table of constants
 template <class U>
 __global__ void fr_table_to_mont(const uint32_t *__restrict__ canon, uint32_t count, uint32_t *__restrict__ mont) {
@@ -285,10 +321,16 @@ extern "C" {
 int zkhip_poly_resize_dev(zkhip_ctx *ctx, int curve, void *d_in, size_t log_n, size_t batch, const uint64_t *omega_n, void *d_out, size_t log_out,
                           const uint64_t *omega_out) {
     if (!ctx || !omega_n || !omega_out || (batch && (!d_in || !d_out))) return ZKHIP_ERR_INVALID;
-    if (log_out < log_n || log_out > 32) return ZKHIP_ERR_RANGE;
+    if (log_out > 32 || log_n > 32) return ZKHIP_ERR_RANGE;
     if (curve != CURVE_BLS12_381 && curve != CURVE_BN254) return ZKHIP_ERR_INVALID;
     if (batch == 0) return ZKHIP_OK;
     ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (log_out < log_n) {  // smaller domain: every 2^(log_n - log_out)-th evaluation (the caller vouches for degree < 2^log_out); d_in is left as it is
+        const size_t tot = batch << log_out;
+        ZK_LAUNCH(ctx, "poly_subsample", poly_subsample, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (const uint4 *)d_in, (uint32_t)log_n,
+                  (uint32_t)log_out, tot, (uint4 *)d_out);
+        return ZKHIP_OK;
+    }
     // coefficients in place (d_in is consumed), zero-extended copy, evaluation on the larger domain
     ZK_TRY(zk_ntt_run(ctx, curve, (uint32_t *)d_in, log_n, batch, omega_n, 1, nullptr));
     size_t total = batch << log_out;
@@ -338,6 +380,35 @@ int zkhip_fr_vec_op_dev(zkhip_ctx *ctx, int curve, int op, const void *d_a, cons
     ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     ZK_FR_DISPATCH(curve, ZK_LAUNCH(ctx, "fr_vec_op", fr_vec_op<U>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (const uint32_t *)d_a,
                                     (const uint32_t *)d_b, count, op, (uint32_t *)d_out));
+    return ZKHIP_OK;
+}
+
+int zkhip_fr_vec_prod_dev(zkhip_ctx *ctx, int curve, size_t count, const void *const *d_in, void *d_out, size_t n) {
+    if (!ctx || !d_in || count == 0 || (n && !d_out)) return ZKHIP_ERR_INVALID;
+    if (curve != CURVE_BLS12_381 && curve != CURVE_BN254) return ZKHIP_ERR_INVALID;
+    if (count >= 65536) return ZKHIP_ERR_RANGE;
+    for (size_t k = 0; k < count; ++k)
+        if (n && !d_in[k]) return ZKHIP_ERR_INVALID;
+    if (n == 0) return ZKHIP_OK;
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ZK_TRY(ctx->ws_reserve(zkhip_ctx::ws_round(count * sizeof(void *))));
+    ctx->ws_reset();
+    const uint32_t **d_ptrs = ctx->ws_take<const uint32_t *>(count);
+    ctx->batch_ptrs.assign((uint32_t *const *)d_in, (uint32_t *const *)d_in + count);  // host copy alive until the async copy ran
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_ptrs, ctx->batch_ptrs.data(), count * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+    ZK_FR_DISPATCH(curve, ZK_LAUNCH(ctx, "fr_vec_prod", fr_vec_prod<U>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_ptrs, (uint32_t)count, n,
+                                    (uint32_t *)d_out));
+    return ZKHIP_OK;
+}
+
+int zkhip_poly_shift_dev(zkhip_ctx *ctx, const void *d_in, size_t log_size, int64_t rotation, void *d_out) {
+    if (!ctx || !d_in || !d_out || d_in == d_out) return ZKHIP_ERR_INVALID;
+    if (log_size > 40) return ZKHIP_ERR_RANGE;
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)1 << log_size;
+    const int64_t m = (int64_t)n;
+    const size_t rot = (size_t)(((rotation % m) + m) % m);
+    ZK_LAUNCH(ctx, "poly_rotate", poly_rotate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (const uint4 *)d_in, (uint32_t)log_size, rot, (uint4 *)d_out);
     return ZKHIP_OK;
 }
 

@@ -2,7 +2,8 @@
 // zkhip shim: the NTT side of the LPC / FRI commitment layer and polynomial_dfs arithmetic, on the MI355X.
 //
 // Mirrors (same names, same argument meaning):
-//   math::polynomial_dfs::{resize, coefficients, from_coefficients, operator+=, -=, *=}   (crypto3-math; used at
+//   math::polynomial_dfs::{resize, coefficients, from_coefficients, operator+=, -=, *=}, math::polynomial_product,
+//   math::polynomial_shift   (crypto3-math; used at
 //        zk/snark/systems/plonk/placeholder/prover.hpp:255,277, gates_argument.hpp:119-121,
 //        permutation_argument.hpp:148-167, zk/commitments/detail/polynomial/basic_fri.hpp:452-455)
 //   detail::fold_polynomial, DFS form        zk/commitments/detail/polynomial/fold_polynomial.hpp:68-93
@@ -13,7 +14,9 @@
 #ifndef ZKHIP_SHIM_FRI_HPP
 #define ZKHIP_SHIM_FRI_HPP
 
+#include <algorithm>
 #include <functional>
+#include <stdexcept>
 #include <vector>
 
 #include "kzg.hpp"
@@ -31,13 +34,19 @@ public:
     typedef typename adapter::scalar_value_type value_type;
     typedef std::function<value_type(std::size_t log_n)> root_of_unity_type;
 
-    device_polynomial_dfs(const context &ctx, std::size_t size) : ctx_(&ctx), size_(size), d_(ctx.alloc(std::max<std::size_t>(1, size) * 32)) { }
-    device_polynomial_dfs(const context &ctx, const polynomial_dfs<CurveType> &p) : device_polynomial_dfs(ctx, p.size()) {
+    device_polynomial_dfs(const context &ctx, std::size_t size) :
+        ctx_(&ctx), size_(size), degree_(size ? size - 1 : 0), d_(ctx.alloc(std::max<std::size_t>(1, size) * 32)) { }
+    /// `degree`: polynomial_dfs carries its degree next to the evaluations (polynomial_product sizes its result from
+    /// it); without one the vector is taken to be full (size - 1)
+    device_polynomial_dfs(const context &ctx, const polynomial_dfs<CurveType> &p, std::size_t degree = (std::size_t)-1) : device_polynomial_dfs(ctx, p.size()) {
         std::vector<std::uint64_t> h(4 * size_);
         for (std::size_t i = 0; i < size_; ++i) adapter::scalar_to_limbs(p.values[i], &h[4 * i]);
         if (size_) ctx.h2d(d_.get(), h.data(), h.size() * 8);
+        if (degree != (std::size_t)-1) degree_ = degree;
     }
     std::size_t size() const { return size_; }
+    std::size_t degree() const { return degree_; }
+    void set_degree(std::size_t d) { degree_ = d; }
     void *data() const { return d_.get(); }
     const context &ctx() const { return *ctx_; }
 
@@ -50,17 +59,25 @@ public:
     }
 
     /// resize(new_size): evaluations on the size()-point domain -> evaluations of the same polynomial on the
-    /// new_size-point domain (new_size >= size(), both powers of two)
+    /// new_size-point domain (both powers of two).  Growing goes through the coefficients (inverse NTT, zero padding,
+    /// NTT); shrinking -- legal while degree() < new_size -- keeps every (size / new_size)-th evaluation.
     void resize(std::size_t new_size, const root_of_unity_type &root) {
         if (new_size == size_) return;
         const std::size_t lo = log2_exact(size_), ln = log2_exact(new_size);
-        if (ln < lo) throw std::runtime_error("device_polynomial_dfs::resize: shrinking is not supported");
+        if (ln < lo && degree_ >= new_size) throw std::runtime_error("device_polynomial_dfs::resize: the polynomial's degree does not fit the smaller domain");
         auto d_new = ctx_->alloc(new_size * 32);
         std::uint64_t wo[4], wn[4];
         adapter::scalar_to_limbs(root(lo), wo);
         adapter::scalar_to_limbs(root(ln), wn);
-        check(zkhip_poly_resize_dev(ctx_->get(), adapter::id, d_.get(), lo, 1, wo, d_new.get(), ln, wn), "zkhip_poly_resize_dev", ctx_->get());
-        ctx_->sync();    // the old buffer is released below
+        /* growing consumes its input (zkhip_poly_resize_dev leaves the coefficients there) and copies of this object
+           share the buffer: work on a private copy */
+        std::shared_ptr<void> src = d_;
+        if (ln > lo) {
+            src = ctx_->alloc(size_ * 32);
+            check(zkhip_memcpy_d2d_async(ctx_->get(), src.get(), d_.get(), size_ * 32), "zkhip_memcpy_d2d_async", ctx_->get());
+        }
+        check(zkhip_poly_resize_dev(ctx_->get(), adapter::id, src.get(), lo, 1, wo, d_new.get(), ln, wn), "zkhip_poly_resize_dev", ctx_->get());
+        ctx_->sync();    // the temporaries are released below
         d_ = d_new;
         size_ = new_size;
     }
@@ -81,9 +98,19 @@ public:
         check(zkhip_ntt_dev(ctx_->get(), adapter::id, d_.get(), log2_exact(size_), 1, w, 0, nullptr), "zkhip_ntt_dev", ctx_->get());
         ctx_->sync();
     }
-    device_polynomial_dfs &operator+=(const device_polynomial_dfs &o) { return pointwise(0, o); }
-    device_polynomial_dfs &operator-=(const device_polynomial_dfs &o) { return pointwise(1, o); }
-    device_polynomial_dfs &operator*=(const device_polynomial_dfs &o) { return pointwise(2, o); }
+    device_polynomial_dfs &operator+=(const device_polynomial_dfs &o) {
+        degree_ = std::max(degree_, o.degree_);
+        return pointwise(0, o);
+    }
+    device_polynomial_dfs &operator-=(const device_polynomial_dfs &o) {
+        degree_ = std::max(degree_, o.degree_);
+        return pointwise(1, o);
+    }
+    /// pointwise product on the shared domain (the caller resized first, as the reference's operator*= does internally)
+    device_polynomial_dfs &operator*=(const device_polynomial_dfs &o) {
+        degree_ = std::min(size_ ? size_ - 1 : 0, degree_ + o.degree_);
+        return pointwise(2, o);
+    }
 
 private:
     static std::size_t log2_exact(std::size_t n) {
@@ -99,9 +126,49 @@ private:
     }
 
     const context *ctx_;
-    std::size_t size_;
+    std::size_t size_, degree_;
     std::shared_ptr<void> d_;
 };
+
+/// math::polynomial_product(multipliers) (ph/permutation_argument.hpp:148, gates_argument.hpp:117): the product of k
+/// DFS polynomials on the smallest power-of-two domain that holds its degree (sum of the degrees): every factor is
+/// resized to it, then ONE k-way pointwise pass multiplies them.
+template <typename CurveType>
+device_polynomial_dfs<CurveType> polynomial_product(std::vector<device_polynomial_dfs<CurveType>> multipliers,
+                                                    const typename device_polynomial_dfs<CurveType>::root_of_unity_type &root) {
+    typedef curve_adapter<CurveType> adapter;
+    if (multipliers.empty()) throw std::invalid_argument("polynomial_product: no factors");
+    const context &ctx = multipliers[0].ctx();
+    std::size_t degree = 0, size = 1;
+    for (const auto &m : multipliers) degree += m.degree();
+    while (size < degree + 1) size <<= 1;
+    std::vector<const void *> ptrs;
+    for (auto &m : multipliers) {
+        m.resize(size, root);
+        ptrs.push_back(m.data());
+    }
+    device_polynomial_dfs<CurveType> out(ctx, size);
+    out.set_degree(degree);
+    check(zkhip_fr_vec_prod_dev(ctx.get(), adapter::id, ptrs.size(), ptrs.data(), out.data(), size), "zkhip_fr_vec_prod_dev", ctx.get());
+    ctx.sync();    // the resized copies are released on return
+    return out;
+}
+
+/// math::polynomial_shift(f, shift, domain_size) (ph/permutation_argument.hpp:148, lookup_argument.hpp:232,315,360):
+/// the evaluations of f(omega^shift X), omega the generator of the domain_size-point domain f is an extension over
+/// (domain_size = 0: f's own domain): entry i reads entry i + shift * (size / domain_size), cyclically.
+template <typename CurveType>
+device_polynomial_dfs<CurveType> polynomial_shift(const device_polynomial_dfs<CurveType> &f, int shift, std::size_t domain_size = 0) {
+    if (domain_size == 0) domain_size = f.size();
+    if (domain_size == 0 || f.size() % domain_size) throw std::invalid_argument("polynomial_shift: the vector is not an extension of the domain");
+    std::size_t log_size = 0;
+    while (((std::size_t)1 << log_size) < f.size()) ++log_size;
+    device_polynomial_dfs<CurveType> out(f.ctx(), f.size());
+    out.set_degree(f.degree());
+    check(zkhip_poly_shift_dev(f.ctx().get(), f.data(), log_size, (std::int64_t)shift * (std::int64_t)(f.size() / domain_size), out.data()),
+          "zkhip_poly_shift_dev", f.ctx().get());
+    return out;
+}
 
 /// detail::fold_polynomial, DFS form (fold_polynomial.hpp:68-93): f over the size()-point domain with generator
 /// `omega` -> the folded polynomial over the half-size domain.

@@ -15,8 +15,11 @@
 // hashes them.  Here TranscriptType is duck-typed on VALUES, the caller's adapter does the packing:
 //   transcript(const single_commitment_type &), transcript(const scalar_value_type &),
 //   scalar_value_type transcript.challenge().
-// commit() returns the vector of single commitments (the reference returns their concatenated byte blob,
-// kzg_v2.hpp:208-226).  verify_eval needs pairings and is not part of this path.
+// kzg_commitment_scheme_v2_hip::commit() returns the vector of single commitments; the class placeholder takes as
+// `commitment_scheme_type` is kzg_commitment_scheme_v2_placeholder_hip below: its commit() returns the reference's byte
+// blob (every single commitment through the caller's Packer, concatenated: kzg_v2.hpp:208-226 with nil::marshalling
+// behind the functor) and its verify_eval() hands (proof, commitments, transcript) to the caller's Verifier (the
+// pairing check of kzg_v2.hpp:312-395 is CPU-side reference code outside this backend).
 //---------------------------------------------------------------------------//
 #ifndef ZKHIP_SHIM_KZG_V2_HPP
 #define ZKHIP_SHIM_KZG_V2_HPP
@@ -451,6 +454,51 @@ protected:
     std::map<std::size_t, device_batch> _dev;
     std::map<std::size_t, commitment_type> _ind_commitments;
     std::vector<scalar_value_type> _merged_points;
+};
+
+
+/// The scheme object placeholder_prover / placeholder_verifier take as ParamsType::commitment_scheme_type
+/// (ph/params.hpp:50-63; the consumer contract is what dummy_commitment_scheme_type implements,
+/// test/systems/plonk/placeholder/placeholder.cpp:96-148): the device scheme above with the reference's commitment_type
+/// (a byte blob) and a verify_eval.
+///   Packer:   std::vector<std::uint8_t>(const single_commitment_type &)   -- nil::marshalling::pack<endianness>(point, status)
+///   Verifier: bool(scheme &, const proof_type &, const std::map<std::size_t, commitment_type> &, transcript_type &)
+template <typename CurveType, typename TranscriptType, typename Packer, typename Verifier>
+class kzg_commitment_scheme_v2_placeholder_hip : public kzg_commitment_scheme_v2_hip<CurveType, TranscriptType> {
+    typedef kzg_commitment_scheme_v2_hip<CurveType, TranscriptType> base;
+
+public:
+    typedef std::vector<std::uint8_t> commitment_type;
+    typedef typename base::proof_type proof_type;
+    typedef typename base::transcript_type transcript_type;
+    typedef typename base::params_type params_type;
+    typedef typename base::root_of_unity_type root_of_unity_type;
+
+    kzg_commitment_scheme_v2_placeholder_hip(const params_type &kzg_params, root_of_unity_type root_of_unity, Packer packer, Verifier verifier) :
+        base(kzg_params, std::move(root_of_unity)), _packer(std::move(packer)), _verifier(std::move(verifier)) { }
+
+    /// kzg_v2.hpp:208-226: "Differs from static, because we pack the result into byte blob."
+    commitment_type commit(std::size_t index) {
+        commitment_type result;
+        for (const auto &single_commitment : base::commit(index)) {
+            const std::vector<std::uint8_t> bytes = _packer(single_commitment);
+            result.insert(result.end(), bytes.begin(), bytes.end());
+        }
+        _commitments[index] = result;
+        return result;
+    }
+    /// kzg_v2.hpp:312: the caller's pairing check, with this object's evaluation points / batch layout at hand
+    bool verify_eval(const proof_type &proof, const std::map<std::size_t, commitment_type> &commitments, transcript_type &transcript) {
+        return _verifier(*this, proof, commitments, transcript);
+    }
+    const std::map<std::size_t, commitment_type> &packed_commitments() const { return _commitments; }
+    /// the evaluation points of (batch, polynomial), for the verifier's U / Z_{T \ S} polynomials
+    const std::vector<typename base::scalar_value_type> &eval_points(std::size_t batch, std::size_t poly) const { return this->_points.at(batch).at(poly); }
+
+private:
+    Packer _packer;
+    Verifier _verifier;
+    std::map<std::size_t, commitment_type> _commitments;
 };
 
 }    // namespace hip

@@ -1,0 +1,416 @@
+//---------------------------------------------------------------------------//
+// zkhip shim: the LPC (list polynomial commitment, FRI-based) scheme placeholder plugs in as `commitment_scheme_type`,
+// with every polynomial-sized step on the MI355X.
+//
+// Mirrors zk/commitments/polynomial/lpc.hpp (class lpc_commitment_scheme, :50-300) on top of
+// zk/commitments/batched_commitment.hpp (polys_evaluator, :58-249) and the commit phase of
+// algorithms::proof_eval<FRI> (zk/commitments/detail/polynomial/basic_fri.hpp:666-742) -- same member names, same call
+// order: append_to_batch / commit(batch) / append_eval_point[s] / set_batch_size / mark_batch_as_fixed /
+// preprocess / setup / proof_eval(transcript), public `_z`, `is_lpc()`.
+//
+// What runs where
+//   device  commit: the batch's inverse NTTs (the coefficient forms stay resident: the reference re-derives them per use,
+//           lpc.hpp:150,173), the extension of every polynomial to D[0] and the coset-ordered leaf layout
+//           (basic_fri.hpp:433-496); proof_eval: eval_polys (block-Horner), the combined quotient
+//           Q = sum_points (sum_k theta^k (g_k - z_k)) / (X - point)  (lpc.hpp:139-186; one pass over the resident
+//           coefficients + one synthetic division per point), its extension, and the FRI commit phase
+//           (fold_polynomial rounds + per-round leaf layouts, basic_fri.hpp:705-742).
+//   caller  hashing: TreeBuilder(leaves, elements_per_leaf) builds the Merkle tree of a precommitment and exposes
+//           .root() (containers::merkle_tree + the scheme's hash, outside this tree's scope: SURVEY 2); transcript:
+//           duck-typed on VALUES like kzg_v2.hpp (transcript(root), transcript.challenge()); the QUERY phase of
+//           proof_eval<FRI> (basic_fri.hpp:747-930: lambda Merkle openings at transcript-derived indices) reads only
+//           trees and a few evaluations and is left to the caller, who finds everything it needs through
+//           trees() / fri_trees() / fri_round_polynomial(i) / fri_alphas().
+//---------------------------------------------------------------------------//
+#ifndef ZKHIP_SHIM_LPC_HPP
+#define ZKHIP_SHIM_LPC_HPP
+
+#include <algorithm>
+#include <functional>
+#include <map>
+#include <set>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "fri.hpp"
+#include "kzg_v2.hpp"
+
+namespace nil {
+namespace crypto3 {
+namespace zk {
+namespace hip {
+
+/// What the scheme reads of basic_fri::params_type (basic_fri.hpp:86-140): the domains D[t] (size 2^(log_domain - t),
+/// generator root_of_unity(log_domain - t)) and the step list; r = sum(step_list) folding rounds.
+template <typename CurveType>
+struct fri_params_hip {
+    typedef typename curve_adapter<CurveType>::scalar_value_type value_type;
+    std::size_t log_domain = 0;
+    std::vector<std::size_t> step_list;
+    std::function<value_type(std::size_t log_n)> root_of_unity;
+};
+
+template <typename CurveType, typename TranscriptType, typename TreeBuilder>
+class lpc_commitment_scheme_hip {
+public:
+    static constexpr bool is_lpc() { return true; }
+
+    typedef curve_adapter<CurveType> adapter;
+    typedef CurveType curve_type;
+    typedef typename adapter::scalar_value_type value_type;
+    typedef fri_params_hip<CurveType> params_type;
+    typedef TranscriptType transcript_type;
+    typedef polynomial_dfs<CurveType> poly_type;
+    typedef eval_storage_hip<CurveType> eval_storage_type;
+    typedef typename std::decay<decltype(std::declval<TreeBuilder &>()(std::declval<const std::vector<value_type> &>(), std::size_t()))>::type
+        precommitment_type;
+    typedef typename std::decay<decltype(std::declval<const precommitment_type &>().root())>::type commitment_type;
+    typedef std::map<std::size_t, std::vector<value_type>> preprocessed_data_type;
+    struct fri_proof_type {
+        std::vector<commitment_type> fri_roots;
+        std::vector<value_type> final_polynomial;    // coefficients (math::polynomial(f.coefficients()), basic_fri.hpp:736-742)
+        /* query_proofs: the caller's (see the header) */
+    };
+    struct proof_type {
+        eval_storage_type z;
+        fri_proof_type fri_proof;
+    };
+
+    eval_storage_type _z;
+
+    lpc_commitment_scheme_hip(const context &ctx, const params_type &fri_params, TreeBuilder builder) :
+        _ctx(ctx), _fri_params(fri_params), _builder(std::move(builder)), _etha(value_type::zero()) {
+        std::size_t r = 0;
+        for (std::size_t s : fri_params.step_list) r += s;
+        if (fri_params.step_list.empty() || r > fri_params.log_domain) throw std::invalid_argument("lpc: step_list does not fit the domain");
+    }
+
+    const params_type &get_commitment_params() const { return _fri_params; }
+
+    /// lpc.hpp:82-96: the fixed batches' polynomials evaluated at etha
+    preprocessed_data_type preprocess(transcript_type &transcript) const {
+        const value_type etha = transcript.challenge();
+        preprocessed_data_type result;
+        for (const auto &it : _batch_fixed) {
+            if (!it.second) continue;
+            result[it.first] = evaluate_batch_at(it.first, etha);
+        }
+        return result;
+    }
+    void setup(transcript_type &transcript, const preprocessed_data_type &preprocessed_data) {
+        _etha = transcript.challenge();
+        _fixed_polys_values = preprocessed_data;
+    }
+    /// Should be done after commitment (lpc.hpp:109-111)
+    void mark_batch_as_fixed(std::size_t index) { _batch_fixed[index] = true; }
+
+    // ---- polys_evaluator (batched_commitment.hpp:197-247) ----
+    void append_to_batch(std::size_t index, const poly_type &poly) {
+        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
+        _polys[index].push_back(poly);
+    }
+    template <typename ContainerType>
+    void append_to_batch(std::size_t index, const ContainerType &polys) {
+        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
+        _polys[index].insert(_polys[index].end(), std::begin(polys), std::end(polys));
+    }
+    void append_eval_point(std::size_t batch_id, const value_type &point) {
+        for (auto &pts : _points.at(batch_id)) pts.push_back(point);
+    }
+    void append_eval_point(std::size_t batch_id, std::size_t poly_id, const value_type &point) { _points.at(batch_id).at(poly_id).push_back(point); }
+    void append_eval_points(std::size_t batch_id, const std::vector<value_type> &points) {
+        for (auto &pts : _points.at(batch_id)) pts.insert(pts.end(), points.begin(), points.end());
+    }
+    void append_eval_points(std::size_t batch_id, std::size_t poly_id, const std::vector<value_type> &points) {
+        auto &pts = _points.at(batch_id).at(poly_id);
+        pts.insert(pts.end(), points.begin(), points.end());
+    }
+    void set_batch_size(std::size_t batch_id, std::size_t batch_size) {
+        _points[batch_id].resize(batch_size);
+        _locked[batch_id] = true;
+    }
+
+    /// commit(index) (lpc.hpp:101-106): precommit<FRI>(polys, D[0], step_list.front()) -> the tree's root
+    commitment_type commit(std::size_t index) {
+        const auto &polys = _polys[index];
+        _locked[index] = true;    // state_commited (batched_commitment.hpp:163-166)
+        _points[index].resize(polys.size());
+        device_batch db;
+        std::size_t total = 0;
+        for (const auto &p : polys) {
+            if (p.size() == 0 || (p.size() & (p.size() - 1)) || p.size() > domain_size(0)) throw std::runtime_error("lpc commit: bad polynomial size");
+            db.offset.push_back(total);
+            db.len.push_back(p.size());
+            total += p.size();
+        }
+        db.data = _ctx.alloc(std::max<std::size_t>(1, total) * 32);
+        std::vector<std::uint64_t> host(4 * total);
+        std::size_t at = 0;
+        for (const auto &p : polys)
+            for (const auto &v : p.values) adapter::scalar_to_limbs(v, &host[4 * at++]);
+        if (total) _ctx.h2d(db.data.get(), host.data(), host.size() * 8);
+        /* poly.resize(D[0]->size()) for every polynomial (basic_fri.hpp:452-455): one call per run of equal sizes; it leaves
+           the COEFFICIENTS in the source buffer, which is what proof_eval reads later */
+        const std::size_t D = domain_size(0);
+        auto d_ext = _ctx.alloc(std::max<std::size_t>(1, polys.size()) * D * 32);
+        std::uint64_t wd[4];
+        adapter::scalar_to_limbs(_fri_params.root_of_unity(_fri_params.log_domain), wd);
+        for (std::size_t i = 0; i < polys.size();) {
+            std::size_t j = i;
+            while (j < polys.size() && db.len[j] == db.len[i]) ++j;
+            const std::size_t log_n = log2_of(db.len[i]);
+            std::uint64_t wn[4];
+            adapter::scalar_to_limbs(_fri_params.root_of_unity(log_n), wn);
+            check(zkhip_poly_resize_dev(_ctx.get(), adapter::id, db.at(i), log_n, j - i, wn, static_cast<char *>(d_ext.get()) + 32 * i * D,
+                                        _fri_params.log_domain, wd),
+                  "zkhip_poly_resize_dev", _ctx.get());
+            i = j;
+        }
+        _trees.erase(index);
+        _trees.emplace(index, build_tree(d_ext.get(), polys.size(), _fri_params.log_domain, _fri_params.step_list.front()));
+        _dev[index] = std::move(db);
+        return _trees.at(index).root();
+    }
+
+    /// proof_eval (lpc.hpp:113-200) up to and including the FRI commit phase (basic_fri.hpp:705-742)
+    proof_type proof_eval(transcript_type &transcript) {
+        eval_polys();
+        for (const auto &it : _trees) transcript(it.second.root());
+
+        /* Prepare z-s and combined_Q (lpc.hpp:124-186), coefficient form, resident */
+        const value_type theta = transcript.challenge();
+        value_type theta_acc = value_type::one();
+        std::size_t max_len = 1;
+        for (const auto &it : _dev)
+            for (std::size_t l : it.second.len) max_len = std::max(max_len, l);
+        auto d_combined = _ctx.alloc(max_len * 32), d_q = _ctx.alloc(max_len * 32);
+        bool have_combined = false;
+        auto add_quotient = [&](const std::vector<const void *> &ptrs, const std::vector<std::size_t> &lens, const std::vector<std::uint64_t> &coeffs,
+                                const value_type &constant, const value_type &point) {
+            if (ptrs.empty()) return;
+            /* Q_normal = sum theta_acc g - sum theta_acc z;  Q_normal /= (X - point);  combined_Q_normal += Q_normal */
+            check(zkhip_poly_lincomb_dev(_ctx.get(), adapter::id, ptrs.size(), ptrs.data(), lens.data(), coeffs.data(), 1, d_q.get(), max_len, 0),
+                  "zkhip_poly_lincomb_dev", _ctx.get());
+            std::uint64_t c[4], z[4], rem[4];
+            adapter::scalar_to_limbs(value_type::zero() - constant, c);
+            auto d_c = _ctx.alloc(32);
+            _ctx.h2d(d_c.get(), c, 32);
+            check(zkhip_fr_vec_op_dev(_ctx.get(), adapter::id, 0, d_q.get(), d_c.get(), d_q.get(), 1), "zkhip_fr_vec_op_dev", _ctx.get());
+            adapter::scalar_to_limbs(point, z);
+            check(zkhip_poly_div_linear_dev(_ctx.get(), adapter::id, d_q.get(), max_len, z, d_q.get(), rem), "zkhip_poly_div_linear_dev", _ctx.get());
+            if (rem[0] | rem[1] | rem[2] | rem[3]) throw std::runtime_error("lpc proof_eval: a quotient does not divide (evaluation / point mismatch)");
+            /* the quotient's max_len - 1 coefficients sit at d_q + 1; slot 0 held the (zero) remainder */
+            void *q = static_cast<char *>(d_q.get()) + 32;
+            if (!have_combined) {
+                check(zkhip_memcpy_d2d_async(_ctx.get(), d_combined.get(), q, (max_len - 1) * 32), "zkhip_memcpy_d2d_async", _ctx.get());
+                have_combined = true;
+            } else if (max_len > 1) {
+                check(zkhip_fr_vec_op_dev(_ctx.get(), adapter::id, 0, d_combined.get(), q, d_combined.get(), max_len - 1), "zkhip_fr_vec_op_dev", _ctx.get());
+            }
+            _ctx.sync();    // d_c is released on return
+        };
+        for (const auto &point : get_unique_points()) {
+            std::vector<const void *> ptrs;
+            std::vector<std::size_t> lens;
+            std::vector<std::uint64_t> coeffs;
+            value_type constant = value_type::zero();
+            for (std::size_t i : _z.get_batches()) {
+                for (std::size_t j = 0; j < _z.get_batch_size(i); ++j) {
+                    const auto &pts = _points.at(i)[j];
+                    auto it = std::find(pts.begin(), pts.end(), point);
+                    if (it == pts.end()) continue;
+                    ptrs.push_back(_dev.at(i).at(j));
+                    lens.push_back(_dev.at(i).len[j]);
+                    coeffs.resize(coeffs.size() + 4);
+                    adapter::scalar_to_limbs(theta_acc, &coeffs[coeffs.size() - 4]);
+                    constant = constant + _z.get(i, j, it - pts.begin()) * theta_acc;
+                    theta_acc = theta_acc * theta;
+                }
+            }
+            add_quotient(ptrs, lens, coeffs, constant, point);
+        }
+        for (std::size_t i : _z.get_batches()) {    // the fixed batches at etha (lpc.hpp:164-186)
+            auto fx = _batch_fixed.find(i);
+            if (fx == _batch_fixed.end() || !fx->second) continue;
+            std::vector<const void *> ptrs;
+            std::vector<std::size_t> lens;
+            std::vector<std::uint64_t> coeffs;
+            value_type constant = value_type::zero();
+            for (std::size_t j = 0; j < _z.get_batch_size(i); ++j) {
+                ptrs.push_back(_dev.at(i).at(j));
+                lens.push_back(_dev.at(i).len[j]);
+                coeffs.resize(coeffs.size() + 4);
+                adapter::scalar_to_limbs(theta_acc, &coeffs[coeffs.size() - 4]);
+                constant = constant + _fixed_polys_values.at(i).at(j) * theta_acc;
+                theta_acc = theta_acc * theta;
+            }
+            add_quotient(ptrs, lens, coeffs, constant, _etha);
+        }
+        if (!have_combined) throw std::runtime_error("lpc proof_eval: nothing to open");
+
+        /* combined_Q.from_coefficients + precommit(combined_Q, D[0], step_list.front()) (lpc.hpp:188-198): the extension to
+           D[0] is the NTT of the zero-padded coefficients */
+        const std::size_t D0 = domain_size(0);
+        device_polynomial_dfs<CurveType> f(_ctx, D0);
+        check(zkhip_memcpy_d2d_async(_ctx.get(), f.data(), d_combined.get(), (max_len - 1) * 32), "zkhip_memcpy_d2d_async", _ctx.get());
+        zero_fill(static_cast<char *>(f.data()) + 32 * (max_len - 1), D0 - (max_len - 1));
+        {
+            std::uint64_t w[4];
+            adapter::scalar_to_limbs(_fri_params.root_of_unity(_fri_params.log_domain), w);
+            check(zkhip_ntt_dev(_ctx.get(), adapter::id, f.data(), _fri_params.log_domain, 1, w, 0, nullptr), "zkhip_ntt_dev", _ctx.get());
+        }
+        precommitment_type precommitment = build_tree(f.data(), 1, _fri_params.log_domain, _fri_params.step_list.front());
+
+        /* Commit phase (basic_fri.hpp:705-742) */
+        proof_type proof;
+        _fri_trees.clear();
+        _fs.clear();
+        _alphas.clear();
+        std::size_t t = 0;
+        for (std::size_t i = 0; i < _fri_params.step_list.size(); ++i) {
+            _fs.push_back(f);
+            _fri_trees.push_back(precommitment);
+            proof.fri_proof.fri_roots.push_back(precommitment.root());
+            transcript(precommitment.root());
+            for (std::size_t step_i = 0; step_i < _fri_params.step_list[i]; ++step_i, ++t) {
+                _alphas.push_back(transcript.challenge());
+                f = fold_polynomial<CurveType>(f, _alphas[t], _fri_params.root_of_unity(_fri_params.log_domain - t));
+            }
+            if (i != _fri_params.step_list.size() - 1)
+                precommitment = build_tree(f.data(), 1, _fri_params.log_domain - t, _fri_params.step_list[i + 1]);
+        }
+        _fs.push_back(f);
+        {
+            auto d_c = f.coefficients(_fri_params.root_of_unity);
+            std::vector<std::uint64_t> h(4 * f.size());
+            _ctx.d2h(h.data(), d_c.get(), h.size() * 8);
+            for (std::size_t k = 0; k < f.size(); ++k) proof.fri_proof.final_polynomial.push_back(adapter::scalar_from_limbs(&h[4 * k]));
+        }
+        proof.z = _z;
+        return proof;
+    }
+
+    // ---- what the caller's query phase reads (basic_fri.hpp:747-930) ----
+    const std::map<std::size_t, precommitment_type> &trees() const { return _trees; }
+    const std::vector<precommitment_type> &fri_trees() const { return _fri_trees; }
+    const std::vector<value_type> &fri_alphas() const { return _alphas; }
+    /// fs[i] of the commit phase (i <= step_list.size()): the round polynomials, evaluations over their domains
+    polynomial_dfs<CurveType> fri_round_polynomial(std::size_t i) const { return _fs.at(i).to_host(); }
+    /// coefficient form of committed polynomial (batch, index): `g_coeffs` of the query phase (basic_fri.hpp:753-771)
+    std::vector<value_type> coefficients(std::size_t batch, std::size_t index) const {
+        const device_batch &db = _dev.at(batch);
+        std::vector<std::uint64_t> h(4 * db.len.at(index));
+        _ctx.d2h(h.data(), db.at(index), h.size() * 8);
+        std::vector<value_type> out;
+        for (std::size_t k = 0; k < db.len[index]; ++k) out.push_back(adapter::scalar_from_limbs(&h[4 * k]));
+        return out;
+    }
+
+protected:
+    struct device_batch {
+        std::shared_ptr<void> data;    // after commit: the coefficient forms
+        std::vector<std::size_t> offset, len;
+        void *at(std::size_t i) const { return static_cast<char *>(data.get()) + 32 * offset[i]; }
+    };
+    std::size_t domain_size(std::size_t t) const { return (std::size_t)1 << (_fri_params.log_domain - t); }
+    static std::size_t log2_of(std::size_t n) {
+        std::size_t l = 0;
+        while (((std::size_t)1 << l) < n) ++l;
+        return l;
+    }
+    void zero_fill(void *d, std::size_t elems) const {
+        if (elems == 0) return;
+        std::vector<std::uint64_t> z(4 * std::min<std::size_t>(elems, (std::size_t)1 << 16), 0);
+        for (std::size_t done = 0; done < elems; done += z.size() / 4)
+            _ctx.h2d(static_cast<char *>(d) + 32 * done, z.data(), 32 * std::min(z.size() / 4, elems - done));
+    }
+    /// the leaf layout of `batch` polynomials resident as evaluations over the 2^log_domain-point domain -> the caller's tree
+    precommitment_type build_tree(const void *d_evals, std::size_t batch, std::size_t log_domain, std::size_t fri_step) const {
+        const std::size_t D = (std::size_t)1 << log_domain;
+        auto d_leaves = _ctx.alloc(std::max<std::size_t>(1, batch) * D * 32);
+        check(zkhip_fri_leaves_dev(_ctx.get(), d_evals, log_domain, batch, fri_step, d_leaves.get()), "zkhip_fri_leaves_dev", _ctx.get());
+        std::vector<std::uint64_t> h(4 * batch * D);
+        _ctx.d2h(h.data(), d_leaves.get(), h.size() * 8);
+        std::vector<value_type> leaves;
+        leaves.reserve(batch * D);
+        for (std::size_t e = 0; e < batch * D; ++e) leaves.push_back(adapter::scalar_from_limbs(&h[4 * e]));
+        return _builder(leaves, batch * ((std::size_t)1 << fri_step));
+    }
+    std::vector<value_type> evaluate_batch_at(std::size_t k, const value_type &x) const {
+        const device_batch &db = _dev.at(k);
+        std::vector<value_type> out(db.len.size());
+        std::uint64_t pt[4];
+        adapter::scalar_to_limbs(x, pt);
+        for (std::size_t i = 0; i < db.len.size();) {
+            std::size_t j = i;
+            while (j < db.len.size() && db.len[j] == db.len[i]) ++j;
+            std::vector<std::uint64_t> vals(4 * (j - i));
+            check(zkhip_poly_eval_dev(_ctx.get(), adapter::id, db.at(i), db.len[i], db.len[i], j - i, pt, 1, vals.data()), "zkhip_poly_eval_dev", _ctx.get());
+            for (std::size_t p = i; p < j; ++p) out[p] = adapter::scalar_from_limbs(&vals[4 * (p - i)]);
+            i = j;
+        }
+        return out;
+    }
+    /// eval_polys (batched_commitment.hpp:168-183)
+    void eval_polys() {
+        for (const auto &it : _dev) {
+            const std::size_t k = it.first;
+            const device_batch &db = it.second;
+            const auto &point = _points.at(k);
+            _z.set_batch_size(k, db.len.size());
+            std::vector<value_type> uni;
+            for (const auto &pl : point)
+                for (const auto &x : pl)
+                    if (std::find(uni.begin(), uni.end(), x) == uni.end()) uni.push_back(x);
+            std::vector<std::uint64_t> pts(4 * uni.size());
+            for (std::size_t j = 0; j < uni.size(); ++j) adapter::scalar_to_limbs(uni[j], &pts[4 * j]);
+            for (std::size_t i = 0; i < db.len.size();) {
+                std::size_t j = i;
+                while (j < db.len.size() && db.len[j] == db.len[i]) ++j;
+                std::vector<std::uint64_t> vals(4 * (j - i) * uni.size());
+                if (!uni.empty())
+                    check(zkhip_poly_eval_dev(_ctx.get(), adapter::id, db.at(i), db.len[i], db.len[i], j - i, pts.data(), uni.size(), vals.data()),
+                          "zkhip_poly_eval_dev", _ctx.get());
+                for (std::size_t p = i; p < j; ++p) {
+                    _z.set_poly_points_number(k, p, point[p].size());
+                    for (std::size_t q = 0; q < point[p].size(); ++q) {
+                        const std::size_t u = std::find(uni.begin(), uni.end(), point[p][q]) - uni.begin();
+                        _z.set(k, p, q, adapter::scalar_from_limbs(&vals[4 * ((p - i) * uni.size() + u)]));
+                    }
+                }
+                i = j;
+            }
+        }
+    }
+    /// get_unique_points (batched_commitment.hpp:113-129): first-seen order over batches, polynomials, points
+    std::vector<value_type> get_unique_points() const {
+        std::vector<value_type> result;
+        for (const auto &it : _points)
+            for (const auto &point_set : it.second)
+                for (const auto &point : point_set)
+                    if (std::find(result.begin(), result.end(), point) == result.end()) result.push_back(point);
+        return result;
+    }
+
+    const context &_ctx;
+    params_type _fri_params;
+    mutable TreeBuilder _builder;
+    value_type _etha;
+    std::map<std::size_t, std::vector<poly_type>> _polys;
+    std::map<std::size_t, bool> _locked, _batch_fixed;
+    std::map<std::size_t, std::vector<std::vector<value_type>>> _points;
+    std::map<std::size_t, device_batch> _dev;
+    std::map<std::size_t, precommitment_type> _trees;
+    preprocessed_data_type _fixed_polys_values;
+    std::vector<precommitment_type> _fri_trees;
+    std::vector<device_polynomial_dfs<CurveType>> _fs;
+    std::vector<value_type> _alphas;
+};
+
+}    // namespace hip
+}    // namespace zk
+}    // namespace crypto3
+}    // namespace nil
+
+#endif    // ZKHIP_SHIM_LPC_HPP

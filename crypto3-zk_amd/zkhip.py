@@ -18,7 +18,7 @@ EXPORTS = [
     "zkhip_bases_upload", "zkhip_bases_upload_compressed", "zkhip_bases_from_scalars", "zkhip_bases_download", "zkhip_bases_size",
     "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_batch_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_domain_size", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev", "zkhip_fr_gather_dev", "zkhip_poly_resize_dev", "zkhip_fri_fold_dev", "zkhip_fri_leaves_dev", "zkhip_ec_ntt_dev",
-    "zkhip_fr_vec_op_dev", "zkhip_poly_eval_dev", "zkhip_poly_div_linear_dev", "zkhip_poly_lincomb_dev",
+    "zkhip_fr_vec_op_dev", "zkhip_fr_vec_prod_dev", "zkhip_poly_shift_dev", "zkhip_poly_eval_dev", "zkhip_poly_div_linear_dev", "zkhip_poly_lincomb_dev",
     "zkhip_profile_enable", "zkhip_profile_reset", "zkhip_profile_get", "zkhip_profile_dump",
 ]
 
@@ -279,6 +279,18 @@ class Context:
     def fr_vec_op_dev(self, curve: int, op: int, d_a: int, d_b: int, d_out: int, count: int):
         self._check(self.lib.zkhip_fr_vec_op_dev(self.h, curve, op, ctypes.c_void_p(d_a), ctypes.c_void_p(d_b), ctypes.c_void_p(d_out),
                                                  ctypes.c_size_t(count)), "fr_vec_op_dev")
+
+    def fr_vec_prod_dev(self, curve: int, d_in, d_out: int, n: int):
+        ptrs = (ctypes.c_void_p * len(d_in))(*d_in)
+        self._check(self.lib.zkhip_fr_vec_prod_dev(self.h, curve, ctypes.c_size_t(len(d_in)), ptrs, ctypes.c_void_p(d_out), ctypes.c_size_t(n)), "fr_vec_prod_dev")
+
+    def poly_shift_dev(self, d_in: int, log_size: int, rotation: int, d_out: int):
+        self._check(self.lib.zkhip_poly_shift_dev(self.h, ctypes.c_void_p(d_in), ctypes.c_size_t(log_size), ctypes.c_int64(rotation), ctypes.c_void_p(d_out)),
+                    "poly_shift_dev")
+
+    def poly_resize_dev(self, curve: int, d_in: int, log_n: int, batch: int, omega_n, d_out: int, log_out: int, omega_out):
+        self._check(self.lib.zkhip_poly_resize_dev(self.h, curve, ctypes.c_void_p(d_in), ctypes.c_size_t(log_n), ctypes.c_size_t(batch), _p(_u64(omega_n)),
+                                                   ctypes.c_void_p(d_out), ctypes.c_size_t(log_out), _p(_u64(omega_out))), "poly_resize_dev")
 
     def poly_eval_dev(self, curve: int, d_polys: int, n: int, batch: int, points: np.ndarray, stride=None) -> np.ndarray:
         """out[b, p] = poly_b(points[p]) for `batch` coefficient vectors of n elements, `stride` elements apart"""

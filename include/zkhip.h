@@ -172,6 +172,17 @@ int zkhip_fr_gather_dev(zkhip_ctx *ctx, const void *d_src, size_t src_count, con
  * primitive roots of the two domains. */
 int zkhip_poly_resize_dev(zkhip_ctx *ctx, int curve, void *d_in, size_t log_n, size_t batch, const uint64_t *omega_n, void *d_out,
                           size_t log_out, const uint64_t *omega_out);
+/* log_out < log_n (a SMALLER domain, for a polynomial whose degree fits it): d_out receives every 2^(log_n - log_out)-th
+ * evaluation, d_in is left untouched.
+ * math::polynomial_shift(f, shift, domain_size) on the evaluation vector (ph/permutation_argument.hpp:148,
+ * lookup_argument.hpp:232): d_out[i] = d_in[(i + rotation) mod 2^log_size], rotation = shift * (size / domain_size), may be
+ * negative; d_out must not alias d_in. */
+int zkhip_poly_shift_dev(zkhip_ctx *ctx, const void *d_in, size_t log_size, int64_t rotation, void *d_out);
+/* d_out[i] = prod_k d_in[k][i], i < n: the pointwise core of math::polynomial_product (ph/permutation_argument.hpp:148,
+ * gates_argument.hpp:117) once every factor sits on the product's domain (zkhip_poly_resize_dev); d_in is a HOST array of
+ * `count` device pointers, d_out may be one of them. */
+int zkhip_fr_vec_prod_dev(zkhip_ctx *ctx, int curve, size_t count, const void *const *d_in, void *d_out, size_t n);
+
 /* detail::fold_polynomial, DFS form (commitments/detail/polynomial/fold_polynomial.hpp:68-93):
  * d_out[i] = 1/2 [(1 + alpha omega^-i) d_f[i] + (1 - alpha omega^-i) d_f[i + size/2]], i < size/2 = 2^(log_size-1). */
 int zkhip_fri_fold_dev(zkhip_ctx *ctx, int curve, const void *d_f, size_t log_size, const uint64_t *alpha, const uint64_t *omega, void *d_out);

@@ -766,6 +766,124 @@ def groth16_expected_in_exponent(curve: Curve, cs: R1CS, primary, aux, trapdoor,
 
 
 # --------------------------------------------------------------------------------------
+# LPC / FRI, as far as the polynomial arithmetic goes (hashing stays outside: `tree_root` is any function of
+# (leaves, elements_per_leaf)); restates
+#   zk/commitments/polynomial/lpc.hpp:101-106, 113-200                 commit, proof_eval's combined_Q
+#   zk/commitments/detail/polynomial/basic_fri.hpp:433-496            precommit: resize to D, coset-ordered leaves
+#   zk/commitments/detail/polynomial/basic_fri.hpp:705-742            the FRI commit phase
+#   zk/commitments/detail/polynomial/fold_polynomial.hpp:68-93        fold_polynomial, DFS form
+#   zk/commitments/batched_commitment.hpp:113-129, 168-183            get_unique_points, eval_polys
+# --------------------------------------------------------------------------------------
+def dfs_resize(evals: Sequence[int], new_size: int, root_of_unity, r: int) -> List[int]:
+    """polynomial_dfs::resize to a LARGER power-of-two domain: coefficients, zero padding, evaluation"""
+    n = len(evals)
+    c = intt(list(evals), root_of_unity(n.bit_length() - 1), r)
+    return ntt(c + [0] * (new_size - n), root_of_unity(new_size.bit_length() - 1), r)
+
+
+def fri_leaves(polys_on_D: Sequence[Sequence[int]], fri_step: int) -> List[int]:
+    """basic_fri.hpp:456-492 (FRI::m = 2): leaf x holds, for every polynomial, the pairs (f[s_i], f[s_i + D/2])"""
+    D, m = len(polys_on_D[0]), 2
+    coset = 1 << fri_step
+    out = []
+    for x in range(D // coset):
+        for f in polys_on_D:
+            s = [[0, 0] for _ in range(coset // m)]
+            s[0] = [x, (x + D // 2) % D]
+            out += [f[s[0][0]], f[s[0][1]]]
+            base, prev_half, i = D // (m * m), 1, 1
+            while i < coset // m:
+                for j in range(prev_half):
+                    s[i][0] = (base + s[j][0]) % D
+                    s[i][1] = (s[i][0] + D // 2) % D
+                    out += [f[s[i][0]], f[s[i][1]]]
+                    i += 1
+                base //= m
+                prev_half <<= 1
+    return out
+
+
+def fold_polynomial_dfs(f: Sequence[int], alpha: int, omega: int, r: int) -> List[int]:
+    """fold_polynomial.hpp:68-93: f'(i) = 1/2 [(1 + alpha w^-i) f(i) + (1 - alpha w^-i) f(i + size/2)]"""
+    half, inv2, winv = len(f) // 2, pow(2, -1, r), pow(omega, -1, r)
+    out, wi = [], 1
+    for i in range(half):
+        out.append(inv2 * ((1 + alpha * wi) * f[i] + (1 - alpha * wi) * f[half + i]) % r)
+        wi = wi * winv % r
+    return out
+
+
+def polynomial_shift(evals: Sequence[int], shift: int, domain_size: int = 0) -> List[int]:
+    """math::polynomial_shift on a DFS vector (placeholder/permutation_argument.hpp:148): f(omega^shift X)"""
+    n = len(evals)
+    domain_size = domain_size or n
+    step = n // domain_size
+    return [evals[(i + shift * step) % n] for i in range(n)]
+
+
+def lpc_proof_eval(r: int, batches: dict, points: dict, fixed: Sequence[int], log_domain: int, step_list: Sequence[int], root_of_unity,
+                   challenges: Sequence[int], tree_root):
+    """batches[k] = list of DFS polynomials (lists of ints); points[k][i] = evaluation points of polynomial i of batch k;
+    fixed = batch ids marked fixed; challenges = (etha_preprocess, etha_setup, theta, alpha_0, ...) in drawing order.
+    -> (commit roots {k: root}, z {k: [[values]]}, fri_roots, final polynomial coefficients)"""
+    D = 1 << log_domain
+    ch = iter(challenges)
+    coeffs = {k: [intt(list(p), root_of_unity(len(p).bit_length() - 1), r) for p in ps] for k, ps in batches.items()}
+    roots = {}
+    for k in sorted(batches):
+        ext = [dfs_resize(p, D, root_of_unity, r) if len(p) < D else list(p) for p in batches[k]]
+        roots[k] = tree_root(fri_leaves(ext, step_list[0]), len(ext) << step_list[0])
+    etha = next(ch)
+    fixed_vals = {k: [poly_eval(c, etha, r) for c in coeffs[k]] for k in fixed}
+    assert next(ch) == etha  # setup draws the same challenge from its copy of the preprocessed transcript
+    z = {k: [[poly_eval(coeffs[k][i], x, r) for x in points[k][i]] for i in range(len(coeffs[k]))] for k in sorted(batches)}
+    theta = next(ch)
+    uniq = []
+    for k in sorted(points):
+        for pl in points[k]:
+            for x in pl:
+                if x not in uniq:
+                    uniq.append(x)
+    theta_acc, combined = 1, []
+    for pt in uniq:
+        q = []
+        for k in sorted(batches):
+            for i, c in enumerate(coeffs[k]):
+                if pt not in points[k][i]:
+                    continue
+                zi = z[k][i][points[k][i].index(pt)]
+                q = poly_add(q, poly_scale(c, theta_acc, r), r)
+                q = poly_sub(q, [zi * theta_acc % r], r)
+                theta_acc = theta_acc * theta % r
+        qq, rem = poly_divmod(q, [(-pt) % r, 1], r)
+        assert not poly_trim(rem)
+        combined = poly_add(combined, qq, r)
+    for k in sorted(batches):
+        if k not in fixed:
+            continue
+        q = []
+        for i, c in enumerate(coeffs[k]):
+            q = poly_add(q, poly_scale(c, theta_acc, r), r)
+            q = poly_sub(q, [fixed_vals[k][i] * theta_acc % r], r)
+            theta_acc = theta_acc * theta % r
+        qq, rem = poly_divmod(q, [(-etha) % r, 1], r)
+        assert not poly_trim(rem)
+        combined = poly_add(combined, qq, r)
+    f = ntt(list(combined) + [0] * (D - len(combined)), root_of_unity(log_domain), r)
+    pre = tree_root(fri_leaves([f], step_list[0]), 1 << step_list[0])
+    fri_roots, t = [], 0
+    for i, step in enumerate(step_list):
+        fri_roots.append(pre)
+        for _ in range(step):
+            f = fold_polynomial_dfs(f, next(ch), root_of_unity(log_domain - t), r)
+            t += 1
+        if i != len(step_list) - 1:
+            pre = tree_root(fri_leaves([f], step_list[i + 1]), 1 << step_list[i + 1])
+    final = intt(f, root_of_unity(log_domain - t), r)
+    return roots, z, fri_roots, final
+
+
+# --------------------------------------------------------------------------------------
 # the reference's KAT carrier (SnarkPack commitment-key openings)
 # --------------------------------------------------------------------------------------
 def ipp2_poly_coeffs(tr: Sequence[int], r_shift: int, r: int) -> List[int]:

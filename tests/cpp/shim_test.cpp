@@ -12,6 +12,7 @@
 #include <nil/crypto3/zk/hip/fri.hpp>
 #include <nil/crypto3/zk/hip/knowledge_commitment_multiexp.hpp>
 #include <nil/crypto3/zk/hip/kzg_v2.hpp>
+#include <nil/crypto3/zk/hip/lpc.hpp>
 #include <nil/crypto3/zk/hip/marshalling.hpp>
 #include <nil/crypto3/zk/hip/powers_of_tau.hpp>
 #include <nil/crypto3/zk/hip/r1cs_gg_ppzksnark.hpp>
@@ -20,6 +21,64 @@
 using namespace nil::crypto3::zk::hip;
 
 namespace {
+
+// ---- a proving key / proof declared the way the reference declares them (proving_key.hpp:43-56, proof.hpp:41-61,
+// r1cs.hpp:61-64,125-133, sparse_vector): distinct C++ types with the reference's member names, consumed by the
+// templated prover without a copy into the shim's own structs
+namespace ref_like {
+    template <typename Fr>
+    struct linear_term {
+        std::size_t index;
+        Fr coeff;
+    };
+    template <typename Fr>
+    struct linear_combination {
+        std::vector<linear_term<Fr>> terms;
+    };
+    template <typename Fr>
+    struct r1cs_constraint {
+        linear_combination<Fr> a, b, c;
+    };
+    template <typename Fr>
+    struct r1cs_constraint_system {
+        std::size_t primary_input_size = 0, auxiliary_input_size = 0;
+        std::vector<r1cs_constraint<Fr>> constraints;
+        std::size_t num_inputs() const { return primary_input_size; }
+        std::size_t num_variables() const { return primary_input_size + auxiliary_input_size; }
+        std::size_t num_constraints() const { return constraints.size(); }
+    };
+    template <typename G2, typename G1>
+    struct element_kc {
+        G2 g;
+        G1 h;
+    };
+    template <typename T>
+    struct sparse_vector {
+        std::vector<std::size_t> indices;
+        std::vector<T> values;
+        std::size_t domain_size_ = 0;
+    };
+    template <typename A>
+    struct r1cs_gg_ppzksnark_proving_key {
+        typename A::g1_value_type alpha_g1, beta_g1;
+        typename A::g2_value_type beta_g2;
+        typename A::g1_value_type delta_g1;
+        typename A::g2_value_type delta_g2;
+        std::vector<typename A::g1_value_type> A_query;
+        sparse_vector<element_kc<typename A::g2_value_type, typename A::g1_value_type>> B_query;
+        std::vector<typename A::g1_value_type> H_query, L_query;
+        r1cs_constraint_system<typename A::scalar_value_type> constraint_system;
+    };
+    template <typename A>
+    struct r1cs_gg_ppzksnark_proof {
+        typename A::g1_value_type g_A;
+        typename A::g2_value_type g_B;
+        typename A::g1_value_type g_C;
+        r1cs_gg_ppzksnark_proof() = default;
+        r1cs_gg_ppzksnark_proof(const typename A::g1_value_type &a, const typename A::g2_value_type &b, const typename A::g1_value_type &c) :
+            g_A(a), g_B(b), g_C(c) { }
+    };
+}    // namespace ref_like
 
 int g_world = 1;    // > 1: shim_groth16_prove emulates that many ranks one after the other on this GPU
 
@@ -99,7 +158,52 @@ int groth16_prove_t(size_t M, size_t n, size_t N, const uint32_t *const rowptr[3
     proof_v.g_C.to_affine(proof + L1 + L2);
     // the randomised overload must run too (its output is not comparable)
     auto p2 = r1cs_gg_ppzksnark_prover_hip<Curve>::process(dpk, primary, auxiliary);
-    return p2.g_A.is_zero() ? -101 : 0;
+    if (p2.g_A.is_zero()) return -101;
+    // the same key held in structs declared like the reference's own (distinct types, same member names): consumed in place
+    {
+        ref_like::r1cs_gg_ppzksnark_proving_key<A> rk;
+        rk.alpha_g1 = pk.alpha_g1, rk.beta_g1 = pk.beta_g1, rk.beta_g2 = pk.beta_g2, rk.delta_g1 = pk.delta_g1, rk.delta_g2 = pk.delta_g2;
+        rk.A_query = pk.A_query, rk.H_query = pk.H_query, rk.L_query = pk.L_query;
+        rk.B_query.indices = pk.B_query.indices;
+        rk.B_query.domain_size_ = pk.B_query.domain_size_;
+        for (const auto &v : pk.B_query.values) rk.B_query.values.push_back({v.g, v.h});
+        rk.constraint_system.primary_input_size = n;
+        rk.constraint_system.auxiliary_input_size = N - n;
+        for (const auto &c : pk.constraint_system.constraints) {
+            ref_like::r1cs_constraint<Fr> rc;
+            for (const auto &t : c.a.terms) rc.a.terms.push_back({t.index, t.coeff});
+            for (const auto &t : c.b.terms) rc.b.terms.push_back({t.index, t.coeff});
+            for (const auto &t : c.c.terms) rc.c.terms.push_back({t.index, t.coeff});
+            rk.constraint_system.constraints.push_back(rc);
+        }
+        typedef ref_like::r1cs_gg_ppzksnark_proving_key<A> key_t;
+        typedef ref_like::r1cs_gg_ppzksnark_proof<A> proof_t;
+        r1cs_gg_ppzksnark_proving_key_hip<Curve, key_t> rdpk(ctx, rk, dom);
+        proof_t rp = r1cs_gg_ppzksnark_prover_hip<Curve, key_t, proof_t>::process(rdpk, primary, auxiliary, A::scalar_from_limbs(r), A::scalar_from_limbs(s));
+        if (!(rp.g_A == proof_v.g_A) || !(rp.g_B == proof_v.g_B) || !(rp.g_C == proof_v.g_C)) return -103;
+        /* a key whose H query was generated over another domain size is refused, not read past its end */
+        key_t bad = rk;
+        bad.H_query.pop_back();
+        bool refused = false;
+        try {
+            r1cs_gg_ppzksnark_proving_key_hip<Curve, key_t> b(ctx, bad, dom);
+        } catch (const std::invalid_argument &) {
+            refused = true;
+        }
+        if (!refused) return -104;
+        bad = rk;
+        if (bad.B_query.indices.size() >= 2) {
+            bad.B_query.indices.back() = N + 5;    // an index beyond the assignment
+            refused = false;
+            try {
+                r1cs_gg_ppzksnark_proving_key_hip<Curve, key_t> b(ctx, bad, dom);
+            } catch (const std::invalid_argument &) {
+                refused = true;
+            }
+            if (!refused) return -105;
+        }
+    }
+    return 0;
 }
 
 template <typename Curve>
@@ -328,6 +432,191 @@ int host_group_t(const uint64_t *p_aff, const uint64_t *q_aff, const uint64_t *s
     return 0;
 }
 
+/// polynomial_product / polynomial_shift / shrinking resize on device polynomial_dfs
+template <typename Curve>
+int dfs_product_shift_t(const uint64_t *evals, size_t count, const uint64_t *log_n, const uint64_t *degrees, const uint64_t *roots, int64_t shift,
+                        size_t shift_domain, uint64_t *out_prod, uint64_t *out_prod_size, uint64_t *out_shift, uint64_t *out_small) {
+    typedef curve_adapter<Curve> A;
+    context ctx(0);
+    auto root = [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); };
+    std::vector<device_polynomial_dfs<Curve>> ps;
+    size_t at = 0;
+    for (size_t k = 0; k < count; ++k) {
+        polynomial_dfs<Curve> h;
+        for (size_t i = 0; i < ((size_t)1 << log_n[k]); ++i) h.values.push_back(A::scalar_from_limbs(evals + 4 * at++));
+        ps.emplace_back(ctx, h, (size_t)degrees[k]);
+    }
+    auto dump = [&](const device_polynomial_dfs<Curve> &p, uint64_t *out) {
+        auto h = p.to_host();
+        for (size_t i = 0; i < h.size(); ++i) A::scalar_to_limbs(h.values[i], out + 4 * i);
+    };
+    auto prod = polynomial_product<Curve>(ps, root);
+    out_prod_size[0] = prod.size();
+    out_prod_size[1] = prod.degree();
+    dump(prod, out_prod);
+    dump(ps[0], out_small + 0);    // the factors are untouched (the product worked on copies): first factor back, unchanged
+    dump(polynomial_shift<Curve>(prod, (int)shift, shift_domain), out_shift);
+    /* shrink the product's first factor's extension back: resize up then down must round-trip */
+    device_polynomial_dfs<Curve> f0 = ps[0];
+    const size_t n0 = f0.size();
+    f0.resize(4 * n0, root);
+    f0.resize(n0, root);
+    dump(f0, out_small + 4 * n0);
+    bool threw = false;
+    try {
+        device_polynomial_dfs<Curve> g = prod;    // degree >= size / 2 unless tiny: must refuse to shrink below its degree
+        if (g.degree() >= 2) g.resize(2, root);
+    } catch (const std::exception &) {
+        threw = true;
+    }
+    return threw || prod.degree() < 2 ? 0 : -5;
+}
+
+/// transcript double for the duck-typed scheme classes: hands out the caller's challenges, counts what it absorbed
+template <typename Curve>
+struct scripted_any_transcript {
+    typedef curve_adapter<Curve> A;
+    std::vector<typename A::scalar_value_type> challenges;
+    std::size_t next = 0, absorbed = 0;
+    template <typename T>
+    void operator()(const T &) { ++absorbed; }
+    typename A::scalar_value_type challenge() { return challenges.at(next++); }
+};
+
+/// toy Merkle stand-in: root = elements_per_leaf + sum_i (i + 1) leaves[i]  (the real tree + hash are the caller's)
+template <typename Curve>
+struct toy_tree {
+    typedef typename curve_adapter<Curve>::scalar_value_type Fr;
+    Fr r;
+    std::size_t leaves = 0;
+    const Fr &root() const { return r; }
+};
+template <typename Curve>
+struct toy_tree_builder {
+    typedef typename curve_adapter<Curve>::scalar_value_type Fr;
+    toy_tree<Curve> operator()(const std::vector<Fr> &leaves, std::size_t per_leaf) const {
+        toy_tree<Curve> t;
+        t.r = Fr((std::uint64_t)per_leaf);
+        for (std::size_t i = 0; i < leaves.size(); ++i) t.r = t.r + Fr((std::uint64_t)(i + 1)) * leaves[i];
+        t.leaves = per_leaf ? leaves.size() / per_leaf : 0;
+        return t;
+    }
+};
+
+/// The consumer contract placeholder has with its commitment_scheme_type (what dummy_commitment_scheme_type implements,
+/// test/systems/plonk/placeholder/placeholder.cpp:96-148, and what placeholder_prover calls: ph/prover.hpp:82-300):
+/// compiled against BOTH device schemes.  batch 0 (fixed) = polys[0..1], batch 1 = polys[2..]; returns the proof.
+template <typename Scheme, typename Poly, typename Fr>
+typename Scheme::proof_type placeholder_consumer(Scheme &scheme, typename Scheme::transcript_type &transcript, const std::vector<Poly> &polys,
+                                                 const std::vector<Fr> &points, std::map<std::size_t, typename Scheme::commitment_type> &commitments) {
+    (void)scheme.get_commitment_params();
+    scheme.append_to_batch(0, polys[0]);
+    scheme.append_to_batch(0, std::vector<Poly>(polys.begin() + 1, polys.begin() + 2));
+    commitments[0] = scheme.commit(0);
+    scheme.mark_batch_as_fixed(0);
+    typename Scheme::preprocessed_data_type prep = scheme.preprocess(transcript);
+    scheme.setup(transcript, prep);
+    scheme.append_to_batch(1, std::vector<Poly>(polys.begin() + 2, polys.end()));
+    commitments[1] = scheme.commit(1);
+    scheme.append_eval_point(0, points[0]);
+    scheme.append_eval_point(1, points[0]);
+    scheme.append_eval_point(1, 0, points[1]);
+    scheme.append_eval_points(0, 1, std::vector<Fr> {points[2]});
+    typename Scheme::proof_type proof = scheme.proof_eval(transcript);
+    (void)proof.z.get_batches_num();
+    return proof;
+}
+
+template <typename Curve>
+int lpc_scheme_t(const uint64_t *evals, size_t npolys, const uint64_t *log_n, size_t log_domain, const uint64_t *steps, size_t nsteps, const uint64_t *roots,
+                 const uint64_t *points, const uint64_t *challenges, size_t nchallenges, uint64_t *out_roots, uint64_t *out_z, uint64_t *out_fri_roots,
+                 uint64_t *out_final, uint64_t *out_counts) {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::scalar_value_type Fr;
+    context ctx(0);
+    fri_params_hip<Curve> fp;
+    fp.log_domain = log_domain;
+    for (size_t i = 0; i < nsteps; ++i) fp.step_list.push_back(steps[i]);
+    fp.root_of_unity = [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); };
+    typedef lpc_commitment_scheme_hip<Curve, scripted_any_transcript<Curve>, toy_tree_builder<Curve>> scheme_type;
+    static_assert(scheme_type::is_lpc(), "placeholder branches on is_lpc()");
+    scheme_type scheme(ctx, fp, toy_tree_builder<Curve>());
+    std::vector<polynomial_dfs<Curve>> polys(npolys);
+    size_t at = 0;
+    for (size_t p = 0; p < npolys; ++p)
+        for (size_t i = 0; i < ((size_t)1 << log_n[p]); ++i) polys[p].values.push_back(A::scalar_from_limbs(evals + 4 * at++));
+    std::vector<Fr> pts = {A::scalar_from_limbs(points), A::scalar_from_limbs(points + 4), A::scalar_from_limbs(points + 8)};
+    scripted_any_transcript<Curve> tr;
+    for (size_t i = 0; i < nchallenges; ++i) tr.challenges.push_back(A::scalar_from_limbs(challenges + 4 * i));
+    std::map<std::size_t, typename scheme_type::commitment_type> commitments;
+    auto proof = placeholder_consumer(scheme, tr, polys, pts, commitments);
+    A::scalar_to_limbs(commitments.at(0), out_roots);
+    A::scalar_to_limbs(commitments.at(1), out_roots + 4);
+    size_t zi = 0;
+    for (std::size_t k : proof.z.get_batches())
+        for (std::size_t i = 0; i < proof.z.get_batch_size(k); ++i)
+            for (std::size_t q = 0; q < proof.z.get_poly_points_number(k, i); ++q) A::scalar_to_limbs(proof.z.get(k, i, q), out_z + 4 * zi++);
+    for (size_t i = 0; i < proof.fri_proof.fri_roots.size(); ++i) A::scalar_to_limbs(proof.fri_proof.fri_roots[i], out_fri_roots + 4 * i);
+    for (size_t i = 0; i < proof.fri_proof.final_polynomial.size(); ++i) A::scalar_to_limbs(proof.fri_proof.final_polynomial[i], out_final + 4 * i);
+    out_counts[0] = zi;
+    out_counts[1] = proof.fri_proof.fri_roots.size();
+    out_counts[2] = proof.fri_proof.final_polynomial.size();
+    out_counts[3] = tr.next;        // challenges drawn
+    out_counts[4] = tr.absorbed;    // roots absorbed
+    out_counts[5] = scheme.fri_trees().size() + 100 * scheme.fri_alphas().size() + 10000 * scheme.trees().size();
+    /* what the caller's query phase reads must be there: round polynomials and coefficient forms */
+    if (scheme.fri_round_polynomial(0).size() != ((size_t)1 << log_domain)) return -7;
+    if (scheme.coefficients(1, 0).size() != polys[2].size()) return -8;
+    return 0;
+}
+
+/// the same consumer against the placeholder-facing KZG scheme: byte-blob commitments through a packer, verify_eval through a hook
+template <typename Curve>
+int kzg_placeholder_contract_t(const uint64_t *srs, size_t n_srs, const uint64_t *evals, size_t npolys, size_t log_n, const uint64_t *roots,
+                               const uint64_t *points, const uint64_t *challenges, size_t nchallenges, uint64_t *out_blob_sizes, uint64_t *out_pi) {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::g1_value_type G1;
+    typedef typename A::scalar_value_type Fr;
+    const size_t L1 = 2 * A::g1_coord_limbs;
+    context ctx(0);
+    std::vector<G1> ck;
+    for (size_t i = 0; i < n_srs; ++i) ck.push_back(G1::from_affine(srs + i * L1));
+    kzg_params_hip<Curve> params(ctx, ck.begin(), ck.end());
+    auto packer = [L1](const G1 &p) {    // stand-in for nil::marshalling::pack: the affine limbs, little-endian bytes
+        std::vector<std::uint64_t> xy(L1);
+        p.to_affine(xy.data());
+        std::vector<std::uint8_t> b(L1 * 8);
+        std::memcpy(b.data(), xy.data(), b.size());
+        return b;
+    };
+    std::size_t verify_calls = 0;
+    typedef scripted_any_transcript<Curve> tr_type;
+    auto verifier = [&verify_calls](auto &scheme, const auto &proof, const std::map<std::size_t, std::vector<std::uint8_t>> &commitments, tr_type &) {
+        ++verify_calls;
+        return commitments.size() == 2 && proof.z.get_batches_num() == 2 && scheme.eval_points(1, 0).size() == 2;
+    };
+    typedef kzg_commitment_scheme_v2_placeholder_hip<Curve, tr_type, decltype(packer), decltype(verifier)> scheme_type;
+    scheme_type scheme(params, [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); }, packer, verifier);
+    std::vector<polynomial_dfs<Curve>> polys(npolys);
+    size_t at = 0;
+    for (size_t p = 0; p < npolys; ++p)
+        for (size_t i = 0; i < ((size_t)1 << log_n); ++i) polys[p].values.push_back(A::scalar_from_limbs(evals + 4 * at++));
+    std::vector<Fr> pts = {A::scalar_from_limbs(points), A::scalar_from_limbs(points + 4), A::scalar_from_limbs(points + 8)};
+    tr_type tr;
+    for (size_t i = 0; i < nchallenges; ++i) tr.challenges.push_back(A::scalar_from_limbs(challenges + 4 * i));
+    std::map<std::size_t, typename scheme_type::commitment_type> commitments;
+    auto proof = placeholder_consumer(scheme, tr, polys, pts, commitments);
+    out_blob_sizes[0] = commitments.at(0).size();
+    out_blob_sizes[1] = commitments.at(1).size();
+    proof.pi_1.to_affine(out_pi);
+    proof.pi_2.to_affine(out_pi + L1);
+    tr_type tr2;
+    tr2.challenges = tr.challenges;
+    if (!scheme.verify_eval(proof, commitments, tr2) || verify_calls != 1) return -9;
+    return 0;
+}
+
+
 template <typename Curve>
 r1cs_constraint_system<Curve> cs_from_csr(size_t M, size_t n, size_t N, const uint32_t *const rowptr[3], const uint32_t *const col[3],
                                           const uint64_t *const coeff[3]) {
@@ -499,6 +788,25 @@ int shim_precommit_leaves(int curve, const uint64_t *evals, size_t npolys, const
 int shim_dfs_ops(int curve, const uint64_t *a_evals, const uint64_t *b_evals, size_t log_n, size_t log_big, const uint64_t *roots, const uint64_t *alpha,
                  uint64_t *out_prod, uint64_t *out_round, uint64_t *out_addsub, uint64_t *out_fold) {
     CURVE_CALL("shim_dfs_ops", dfs_ops_t, a_evals, b_evals, log_n, log_big, roots, alpha, out_prod, out_round, out_addsub, out_fold)
+}
+
+int shim_dfs_product_shift(int curve, const uint64_t *evals, size_t count, const uint64_t *log_n, const uint64_t *degrees, const uint64_t *roots,
+                           int64_t shift, size_t shift_domain, uint64_t *out_prod, uint64_t *out_prod_size, uint64_t *out_shift, uint64_t *out_small) {
+    CURVE_CALL("shim_dfs_product_shift", dfs_product_shift_t, evals, count, log_n, degrees, roots, shift, shift_domain, out_prod, out_prod_size, out_shift,
+               out_small)
+}
+
+int shim_lpc_scheme(int curve, const uint64_t *evals, size_t npolys, const uint64_t *log_n, size_t log_domain, const uint64_t *steps, size_t nsteps,
+                    const uint64_t *roots, const uint64_t *points, const uint64_t *challenges, size_t nchallenges, uint64_t *out_roots, uint64_t *out_z,
+                    uint64_t *out_fri_roots, uint64_t *out_final, uint64_t *out_counts) {
+    CURVE_CALL("shim_lpc_scheme", lpc_scheme_t, evals, npolys, log_n, log_domain, steps, nsteps, roots, points, challenges, nchallenges, out_roots, out_z,
+               out_fri_roots, out_final, out_counts)
+}
+
+int shim_kzg_placeholder_contract(int curve, const uint64_t *srs, size_t n_srs, const uint64_t *evals, size_t npolys, size_t log_n, const uint64_t *roots,
+                                  const uint64_t *points, const uint64_t *challenges, size_t nchallenges, uint64_t *out_blob_sizes, uint64_t *out_pi) {
+    CURVE_CALL("shim_kzg_placeholder_contract", kzg_placeholder_contract_t, srs, n_srs, evals, npolys, log_n, roots, points, challenges, nchallenges,
+               out_blob_sizes, out_pi)
 }
 
 int shim_kc_multiexp(int curve, const uint64_t *g_pts, const uint64_t *h_pts, const uint64_t *indices, size_t count, size_t domain_size, size_t min_idx,

@@ -11,7 +11,7 @@ import pytest
 
 import cport as cp
 import pyoracle as po
-from util import CURVES, FQ_LIMBS, fr_arr, limbs, pt_limbs
+from util import CURVES, FQ_LIMBS, fr_arr, fr_ints, limbs, pt_limbs
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -402,3 +402,106 @@ def test_groth16_from_serialised_key(shim):
     # a truncated blob is reported, not read past
     assert shim.shim_groth16_prove_from_bytes(P(blob), ctypes.c_size_t(len(blob) - 7), P(g.assignment()), ctypes.c_size_t(g.n),
                                               ctypes.c_size_t(g.N), P(w), P(gen), P(r_), P(s_), P(proof)) == -1
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_polynomial_product_shift_shim(shim, curve):
+    """SURVEY 8a row a13: math::polynomial_product (k factors, each resized to the product's domain, one k-way pointwise pass),
+    math::polynomial_shift (rotation of the evaluation vector, also over an extension of the shift's domain) and
+    polynomial_dfs::resize to a smaller domain -- against the oracle's coefficient-form arithmetic."""
+    C = CURVES[curve]
+    r = C.r
+    logs, degs = [4, 5, 4], [9, 31, 15]
+    root = lambda l: C.root_of_unity(l)
+    coeffs = [[po.SplitMix64(70 + k).next_mod(r) for _ in range(d + 1)] for k, d in enumerate(degs)]
+    evals = [po.ntt(c + [0] * ((1 << l) - len(c)), root(l), r) for c, l in zip(coeffs, logs)]
+    prod_c = [1]
+    for c in coeffs:
+        prod_c = po.poly_mul(prod_c, c, r)
+    size = 1
+    while size < sum(degs) + 1:
+        size <<= 1
+    prod_e = po.ntt(prod_c + [0] * (size - len(prod_c)), root(size.bit_length() - 1), r)
+    roots = np.stack([limbs(root(l), 4) for l in range(10)])
+    o_prod, o_shift = np.zeros((size, 4), dtype=np.uint64), np.zeros((size, 4), dtype=np.uint64)
+    o_size = np.zeros(2, dtype=np.uint64)
+    n0 = 1 << logs[0]
+    o_small = np.zeros((2 * n0, 4), dtype=np.uint64)
+    for shift, dom in ((1, 0), (-3, 0), (1, 16), (-1, 8)):
+        rc = shim.shim_dfs_product_shift(curve, P(fr_arr(sum(evals, []))), ctypes.c_size_t(3), P(np.array(logs, dtype=np.uint64)),
+                                         P(np.array(degs, dtype=np.uint64)), P(roots), ctypes.c_int64(shift), ctypes.c_size_t(dom), P(o_prod), P(o_size),
+                                         P(o_shift), P(o_small))
+        assert rc == 0
+        assert list(o_size) == [size, sum(degs)]
+        assert fr_ints(o_prod) == prod_e
+        assert fr_ints(o_shift) == po.polynomial_shift(prod_e, shift, dom)
+        assert fr_ints(o_small[:n0]) == evals[0] and fr_ints(o_small[n0:]) == evals[0]  # factors untouched; grow-then-shrink round trip
+    # the shift really is f(omega^shift X): check one case in coefficient form
+    w = root(size.bit_length() - 1)
+    assert po.polynomial_shift(prod_e, 1) == po.ntt([c * pow(w, i, r) % r for i, c in enumerate(prod_c + [0] * (size - len(prod_c)))], w, r)
+
+
+def _toy_root(r):
+    return lambda leaves, per_leaf: (per_leaf + sum((i + 1) * v for i, v in enumerate(leaves))) % r
+
+
+@pytest.mark.parametrize("curve,log_domain,steps", [(0, 8, [1, 2]), (1, 7, [2, 1, 1]), (0, 7, [3])])
+def test_lpc_scheme_shim(shim, curve, log_domain, steps):
+    """lpc_commitment_scheme_hip driven through the consumer contract placeholder has with its commitment scheme (fixed batch,
+    preprocess / setup, two batches, ragged point sets): commit roots, evaluations, FRI round roots and the final polynomial
+    against po.lpc_proof_eval (lpc.hpp:101-200 + basic_fri.hpp:433-496, 705-742); the Merkle tree is a toy functor on both sides."""
+    C = CURVES[curve]
+    r = C.r
+    logs = [log_domain - 3, log_domain - 3, log_domain - 2, log_domain - 3]
+    evals = [fr_ints(cp.random_fr(curve, 1300 + i, 1 << l)) for i, l in enumerate(logs)]
+    rng = po.SplitMix64(55 + curve)
+    p0, p1, p2 = (rng.next_mod(r) for _ in range(3))
+    etha, theta = rng.next_mod(r), rng.next_mod(r)
+    alphas = [rng.next_mod(r) for _ in range(sum(steps))]
+    challenges = [etha, etha, theta] + alphas
+    batches = {0: evals[:2], 1: evals[2:]}
+    points = {0: [[p0], [p0, p2]], 1: [[p0, p1], [p0]]}
+    e_roots, e_z, e_fri, e_final = po.lpc_proof_eval(r, batches, points, [0], log_domain, steps, C.root_of_unity, challenges, _toy_root(r))
+    roots = np.stack([limbs(C.root_of_unity(l), 4) for l in range(log_domain + 1)])
+    o_roots, o_z, o_fri = np.zeros((2, 4), dtype=np.uint64), np.zeros((6, 4), dtype=np.uint64), np.zeros((len(steps), 4), dtype=np.uint64)
+    nfinal = 1 << (log_domain - sum(steps))
+    o_final, o_counts = np.zeros((nfinal, 4), dtype=np.uint64), np.zeros(6, dtype=np.uint64)
+    rc = shim.shim_lpc_scheme(curve, P(fr_arr(sum(evals, []))), ctypes.c_size_t(4), P(np.array(logs, dtype=np.uint64)), ctypes.c_size_t(log_domain),
+                              P(np.array(steps, dtype=np.uint64)), ctypes.c_size_t(len(steps)), P(roots), P(fr_arr([p0, p1, p2])), P(fr_arr(challenges)),
+                              ctypes.c_size_t(len(challenges)), P(o_roots), P(o_z), P(o_fri), P(o_final), P(o_counts))
+    assert rc == 0
+    assert fr_ints(o_roots) == [e_roots[0], e_roots[1]]
+    assert fr_ints(o_z) == [v for k in (0, 1) for pl in e_z[k] for v in pl]
+    assert fr_ints(o_fri) == e_fri
+    assert fr_ints(o_final) == (e_final + [0] * nfinal)[:nfinal]
+    # 6 evaluations, one root per step, all challenges drawn, 2 batch roots + the round roots absorbed, and what the caller's
+    # query phase needs is kept (round trees, alphas, batch trees)
+    assert list(o_counts) == [6, len(steps), nfinal, len(challenges), 2 + len(steps), len(steps) + 100 * sum(steps) + 10000 * 2]
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_kzg_placeholder_contract_shim(shim, curve):
+    """kzg_commitment_scheme_v2_placeholder_hip under the same consumer: byte-blob commitments through the caller's packer
+    (kzg_v2.hpp:208-226), verify_eval through the caller's hook (:312), and the opening proof equal to the oracle's."""
+    C = CURVES[curve]
+    r = C.r
+    log_n, npolys, alpha = 5, 4, 7
+    n = 1 << log_n
+    srs = _srs(curve, alpha, n + 4)
+    evals = [fr_ints(cp.random_fr(curve, 1400 + i, n)) for i in range(npolys)]
+    rng = po.SplitMix64(91 + curve)
+    p0, p1, p2 = (rng.next_mod(r) for _ in range(3))
+    theta, theta2 = rng.next_mod(r), rng.next_mod(r)
+    roots = np.stack([limbs(C.root_of_unity(l), 4) for l in range(log_n + 1)])
+    blob, pi = np.zeros(2, dtype=np.uint64), np.zeros((2, srs.shape[1]), dtype=np.uint64)
+    rc = shim.shim_kzg_placeholder_contract(curve, P(srs), ctypes.c_size_t(n + 4), P(fr_arr(sum(evals, []))), ctypes.c_size_t(npolys), ctypes.c_size_t(log_n),
+                                            P(roots), P(fr_arr([p0, p1, p2])), P(fr_arr([theta, theta2])), ctypes.c_size_t(2), P(blob), P(pi))
+    assert rc == 0
+    point_bytes = srs.shape[1] * 8
+    assert list(blob) == [2 * point_bytes, 2 * point_bytes]  # two polynomials per batch, one packed point each
+    w = C.root_of_unity(log_n)
+    polys = {0: [po.intt(e, w, r) for e in evals[:2]], 1: [po.intt(e, w, r) for e in evals[2:]]}
+    points = {0: [[p0], [p0, p2]], 1: [[p0, p1], [p0]]}
+    _, f, L = po.kzg_v2_proof_eval(r, polys, points, theta, theta2)
+    g = lambda e: cp.batch_mul(curve, 1, fr_arr([e]))[0][0]
+    assert (pi[0] == g(po.poly_eval(f, alpha, r))).all() and (pi[1] == g(po.poly_eval(L, alpha, r))).all()

@@ -157,3 +157,41 @@ def test_reference_serialisation_vectors():
             P = G.mul(G.gen, s)
             assert po.bls12_381_decompress(grp, po.bls12_381_compress(grp, P)) == P
         assert po.bls12_381_decompress(grp, po.bls12_381_compress(grp, None)) is None
+
+
+def test_lpc_oracle_definitions():
+    """The oracle's LPC / FRI restatement is unpinned in the reference (its tests only check verify == true with hashes this
+    tree does not hold): pin it to the definitions -- folding in coefficient form (f = f_e(X^2) + X f_o(X^2) -> f_e + alpha f_o),
+    the shift as f(omega X), the leaf layout as a permutation into cosets, and the low degree of the final polynomial."""
+    C = CURVES[0]
+    r = C.r
+    rng = po.SplitMix64(8)
+    log_n = 6
+    n = 1 << log_n
+    w = C.root_of_unity(log_n)
+    c = [rng.next_mod(r) for _ in range(n)]
+    f = po.ntt(c, w, r)
+    alpha = rng.next_mod(r)
+    folded_c = [(c[2 * i] + alpha * c[2 * i + 1]) % r for i in range(n // 2)]
+    assert po.fold_polynomial_dfs(f, alpha, w, r) == po.ntt(folded_c, w * w % r, r)
+    assert po.polynomial_shift(f, 1) == po.ntt([x * pow(w, i, r) % r for i, x in enumerate(c)], w, r)
+    assert po.polynomial_shift(f, -2, 16) == [f[(i - 2 * (n // 16)) % n] for i in range(n)]
+    # leaves: every evaluation appears exactly once, and a leaf is closed under x -> -x (pairs s, s + D/2) and, for step 2, x -> i x
+    ident = list(range(n))
+    for step in (1, 2, 3):
+        lv = po.fri_leaves([ident], step)
+        assert sorted(lv) == ident
+        per = 1 << step
+        for x in range(n // per):
+            leaf = set(lv[x * per:(x + 1) * per])
+            assert all((s + n // 2) % n in leaf for s in leaf)
+            if step >= 2:
+                assert all((s + n // 4) % n in leaf for s in leaf)
+    # whole proof_eval on a toy tree: final polynomial of degree < 2^(max log n) / 2^rounds
+    evals = [[rng.next_mod(r) for _ in range(8)], [rng.next_mod(r) for _ in range(8)], [rng.next_mod(r) for _ in range(16)]]
+    p0, p1, etha, theta, a0, a1 = (rng.next_mod(r) for _ in range(6))
+    root = lambda leaves, per: (per + sum((i + 1) * v for i, v in enumerate(leaves))) % r
+    roots, z, fri_roots, final = po.lpc_proof_eval(r, {0: evals[:2], 1: evals[2:]}, {0: [[p0], [p0, p1]], 1: [[p1]]}, [0], 6, [1, 1], C.root_of_unity,
+                                                   [etha, etha, theta, a0, a1], root)
+    assert len(fri_roots) == 2 and len(final) == 16 and not any(final[16 // 4:])
+    assert z[1][0][0] == po.poly_eval(po.intt(evals[2], C.root_of_unity(4), r), p1, r)
