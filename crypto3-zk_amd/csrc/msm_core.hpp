@@ -54,6 +54,7 @@
 #include "msm_ops.hpp"
 #include "msm_recode.hpp"
 #include "msm_bucket_acc.hpp"
+#include "fu_pair.hpp"
 
 namespace {
 
@@ -538,7 +539,7 @@ ZK_D XYZZ<F> block_tree_sum(uint32_t *lds, XYZZ<F> acc, uint32_t t, uint32_t nth
 
 // grid = sets x nblk workgroups; partial[s * nblk + j] = weighted sum of segments [SLOTS j, SLOTS j + SLOTS) of set s
 template <class F, int LPB>
-__global__ __launch_bounds__(MSM_TAIL_THREADS) void msm_bucket_red(const uint32_t *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t nseg,
+__global__ __launch_bounds__(MSM_TAIL_THREADS, 2) void msm_bucket_red(const uint32_t *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t nseg,
                                                                    uint32_t nblk, uint32_t *__restrict__ partial) {
     constexpr int NL = FieldOps<F>::WORDS;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -739,19 +740,21 @@ __global__ __launch_bounds__(64) void msm_final_batch(const uint32_t *__restrict
 
 // ---- host side ------------------------------------------------------------------------------------
 
-// Buckets per tail lane (segment length L).  Every operation of the tail is a full addition or doubling, ~13.6 us for a
-// wave that has its SIMD (almost) to itself, so a segment costs 2 L (running sums) + ~38 (the multiple seg L, a 20-bit
-// double-and-add whose additions run on every step of a diverged wave) + 8 (LDS tree) dependent operations; measured
-// (tools/msm_profile.py, 2^19 / 2^20 buckets): L = 8: 0.84 ms, 16: 1.06, 4: 1.38 (twice the waves per SIMD: the
-// operations get slower than the chain gets shorter), 32: 1.5.  So: L = 8 once there are >= 2^18 buckets, doubled while
-// the lanes (sets B lanes_per_point / L) exceed ~2^18; small bucket sets keep one bucket per lane.
-inline uint32_t msm_tail_segment(const zkhip_ctx *ctx, uint32_t B, size_t sets, int lanes_per_point) {
+// Buckets per tail lane (segment length L).  Every operation of the tail is a full addition or doubling on a chain: a
+// segment costs 2 L (running sums) + ~38 (the multiple seg L, a 20-bit double-and-add whose additions run on every step of
+// a diverged wave) + 8 (LDS tree) dependent operations, each ~13.6 us on one lane, 9.2 us on a lane pair (fu_pair.hpp).
+// Measured (tools/msm_profile.py, 2^19 buckets, G1): one lane per bucket L = 8: 0.84 ms, 16: 1.06, 4: 1.38; lane pairs
+// L = 16: 0.72, 8: 0.92 (two waves per SIMD: the operations slow down more than the chain shortens).
+inline uint32_t msm_tail_segment(const zkhip_ctx *ctx, uint32_t B, size_t sets, int lanes_per_point, bool g2) {
     uint32_t L = 1;
     if (ctx->opt_msm_segment_log >= 0) L = 1u << std::min(ctx->opt_msm_segment_log, 8);
     else {
         const size_t lanes = sets * B * (size_t)lanes_per_point;
-        const uint32_t knee = lanes_per_point > 1 ? 16 : 8;  // G2 (lane pairs, 1.5x the instructions per operation): 16 measured 1.8 ms against 2.6 for 8
-        while (L < knee && lanes / L > 65536) L <<= 1;
+        // one wave per SIMD (2^16 lanes) is where an operation is fastest -- the lane-pair group law (fu_pair.hpp: 9.2 us per
+        // operation alone on a SIMD, 14.8 us when two waves share it), G2's pair-split Fq2 likewise: L doubles up to 16 to get
+        // there, and beyond only when the lanes would otherwise exceed ~4 waves per SIMD (batches of many MSMs)
+        (void)g2;
+        while (L < 16 && lanes / L > 65536) L <<= 1;
         while (L < 64 && lanes / L > 262144) L <<= 1;
     }
     return std::min(B, L);
@@ -760,9 +763,9 @@ inline uint32_t msm_tail_segment(const zkhip_ctx *ctx, uint32_t B, size_t sets, 
 // the tail workgroups keep 256 XYZZ points in LDS (56 KiB for G1, 128 KiB for BLS12-381 G2)
 template <class F>
 int msm_tail_attr(zkhip_ctx *ctx) {
-    typedef typename BucketLane<F>::type FL;
-    constexpr int LPB = BucketLane<F>::LANES;
-    ZK_MAX_LDS(ctx, (msm_bucket_red<FL, LPB>), MSM_TAIL_THREADS / LPB * 4 * FieldOps<F>::WORDS * 4);
+    typedef typename TailLane<F>::type TL;
+    constexpr int TLPB = TailLane<F>::LANES;
+    ZK_MAX_LDS(ctx, (msm_bucket_red<TL, TLPB>), MSM_TAIL_THREADS / TLPB * 4 * FieldOps<F>::WORDS * 4);
     return 0;
 }
 
@@ -781,6 +784,7 @@ inline MsmPlan msm_plan(const zkhip_ctx *ctx, const zkhip_bases *bases, size_t n
     int c = p.tables ? bases->c_tab : ctx->opt_msm_window_bits;
     if (c <= 0) c = zk_msm_auto_window(n);
     p.c = std::max(2, std::min(ZK_MSM_MAX_C, c));
+    if (!p.tables) p.c = std::min(p.c, 16);  // one bucket set PER WINDOW there (W 2^(c-1) buckets): stay within the sort's key range
     p.W_all = msm_windows(zk_scalar_bits(bases->curve), p.c);  // scalars are folded to |s| <= (r - 1) / 2: no carry out of the top window
     p.win = msm_make_windows(zk_scalar_bits(bases->curve), p.W_all);
     // window partition over GPUs: this call handles the windows {w : w mod win_world == win_rank} only (all equal-weight
@@ -824,8 +828,11 @@ template <class F>
 int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac,
               uint32_t *batch_slot = nullptr, size_t *need_out = nullptr) {
     constexpr int NL = FieldOps<F>::WORDS;
-    typedef typename BucketLane<F>::type FL;           // what a lane holds in the bucket / tail kernels
+    typedef typename BucketLane<F>::type FL;           // what a lane holds in the bucket kernels
     constexpr int LPB = BucketLane<F>::LANES;          // lanes per point (2 for G2: fu2_pair.hpp)
+    typedef typename TailLane<F>::type TL;             // ... and in the latency-bound tail (G1: group law over a lane pair, fu_pair.hpp)
+    constexpr int TLPB = TailLane<F>::LANES;
+    constexpr bool G2 = FieldOps<F>::WORDS > 16;
     const MsmPlan P = msm_plan(ctx, bases, n);
     const int W = P.W;
     const uint32_t B = P.B, S = P.S, nb = P.nb;
@@ -835,8 +842,8 @@ int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
         return ZKHIP_ERR_RANGE;
     }
     const int Sr = P.tables ? 1 : W;  // sets left after the equal-weight merge
-    const uint32_t L = msm_tail_segment(ctx, B, Sr, LPB);  // buckets per tail segment
-    const uint32_t tail_slots = MSM_TAIL_THREADS / LPB;  // points per tail workgroup
+    const uint32_t L = msm_tail_segment(ctx, B, Sr, TLPB, G2);  // buckets per tail segment
+    const uint32_t tail_slots = MSM_TAIL_THREADS / TLPB;  // points per tail workgroup
     const uint32_t nseg = B / L, nblk_tail = (nseg + tail_slots - 1) / tail_slots;
     // two-level LDS counting sort (see msm_sort_*): the low bits inside a super-bucket, the rest across super-buckets
     SortGeom g;
@@ -960,10 +967,10 @@ int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
         return 0;
     }
     ZK_TRY(msm_tail_attr<F>(ctx));
-    ZK_LAUNCH(ctx, "msm_bucket_red", (msm_bucket_red<FL, LPB>), dim3((unsigned)Sr * nblk_tail), dim3(MSM_TAIL_THREADS), (size_t)tail_slots * 4 * NL * 4, buckets, B,
+    ZK_LAUNCH(ctx, "msm_bucket_red", (msm_bucket_red<TL, TLPB>), dim3((unsigned)Sr * nblk_tail), dim3(MSM_TAIL_THREADS), (size_t)tail_slots * 4 * NL * 4, buckets, B,
               L, nseg, nblk_tail, segsum);
-    ZK_LAUNCH(ctx, "msm_window_sum", (msm_window_sum<FL, LPB>), dim3(Sr), dim3(64), (size_t)64 / LPB * 4 * NL * 4, segsum, nblk_tail, winsum);
-    ZK_LAUNCH(ctx, "msm_final", (msm_final<FL, LPB>), dim3(1), dim3(64), 0, winsum, Sr, P.win, d_out_jac);
+    ZK_LAUNCH(ctx, "msm_window_sum", (msm_window_sum<TL, TLPB>), dim3(Sr), dim3(64), (size_t)64 / TLPB * 4 * NL * 4, segsum, nblk_tail, winsum);
+    ZK_LAUNCH(ctx, "msm_final", (msm_final<TL, TLPB>), dim3(1), dim3(64), 0, winsum, Sr, P.win, d_out_jac);
     return 0;
 }
 
@@ -993,12 +1000,12 @@ template <class F>
 int msm_batch_t(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases, const size_t *offsets, const size_t *ns,
                 const uint32_t *const *d_scalars, uint32_t *const *d_outs) {
     constexpr int NL = FieldOps<F>::WORDS;
-    typedef typename BucketLane<F>::type FL;
-    constexpr int LPB = BucketLane<F>::LANES;
+    typedef typename TailLane<F>::type TL;
+    constexpr int TLPB = TailLane<F>::LANES;
     const int c = bases[0]->c_tab;
     const uint32_t B = 1u << (c - 1);
-    const uint32_t L = msm_tail_segment(ctx, B, count, LPB);
-    const uint32_t tail_slots = MSM_TAIL_THREADS / LPB;  // points per tail workgroup
+    const uint32_t L = msm_tail_segment(ctx, B, count, TLPB, FieldOps<F>::WORDS > 16);
+    const uint32_t tail_slots = MSM_TAIL_THREADS / TLPB;  // points per tail workgroup
     const uint32_t nseg = B / L, nblk_tail = (nseg + tail_slots - 1) / tail_slots;
     size_t max_need = 0;
     for (size_t i = 0; i < count; ++i) {
@@ -1036,10 +1043,10 @@ int msm_batch_t(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases, c
         ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_ptrs, ctx->batch_ptrs.data(), count * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
     }
     ZK_TRY(msm_tail_attr<F>(ctx));
-    ZK_LAUNCH(ctx, "msm_bucket_red", (msm_bucket_red<FL, LPB>), dim3((unsigned)count * nblk_tail), dim3(MSM_TAIL_THREADS), (size_t)tail_slots * 4 * NL * 4, slots,
+    ZK_LAUNCH(ctx, "msm_bucket_red", (msm_bucket_red<TL, TLPB>), dim3((unsigned)count * nblk_tail), dim3(MSM_TAIL_THREADS), (size_t)tail_slots * 4 * NL * 4, slots,
               B, L, nseg, nblk_tail, segsum);
-    ZK_LAUNCH(ctx, "msm_window_sum", (msm_window_sum<FL, LPB>), dim3((unsigned)count), dim3(64), (size_t)64 / LPB * 4 * NL * 4, segsum, nblk_tail, winsum);
-    ZK_LAUNCH(ctx, "msm_final", (msm_final_batch<FL, LPB>), dim3((unsigned)count), dim3(64), 0, winsum, (uint32_t)count, d_ptrs);
+    ZK_LAUNCH(ctx, "msm_window_sum", (msm_window_sum<TL, TLPB>), dim3((unsigned)count), dim3(64), (size_t)64 / TLPB * 4 * NL * 4, segsum, nblk_tail, winsum);
+    ZK_LAUNCH(ctx, "msm_final", (msm_final_batch<TL, TLPB>), dim3((unsigned)count), dim3(64), 0, winsum, (uint32_t)count, d_ptrs);
     return 0;
 }
 
