@@ -179,13 +179,24 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # the timed region carries HIP events around the dominant kernel only (roofline.achieved); the full per-kernel breakdown
+    # comes from three extra, untimed steps below
     ctx.profile_reset()
+    ctx.profile_filter("msm_bucket_acc")
     ctx.profile(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         result = step()
     fence()
     elapsed = time.perf_counter() - t0
+    ctx.profile(False)
+    dom_ms, dom_cnt = ctx.profile_get("msm_bucket_acc")
+    ctx.profile_filter("")
+    ctx.profile_reset()
+    ctx.profile(True)
+    for _ in range(3):
+        step()
+    fence()
     ctx.profile(False)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -216,7 +227,6 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * n * args.steps / elapsed / 1e6
-        dom_ms, dom_cnt = prof.get("msm_bucket_acc", (0.0, 0))
         dom_avg_ms = dom_ms / max(1, dom_cnt)
         alg_bytes = ALG_BYTES_PER_POINT * n_local if not windows else ALG_BYTES_PER_POINT * n_local // world  # a rank's share of the job's bytes
         achieved = alg_bytes / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
@@ -242,7 +252,8 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "avg_launch_ms": round(dom_avg_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
                          "honest_bound": "integer VALU issue (DESIGN.md section 4): the kernel moves 128 algorithmic bytes per ~4.9 k VALU instructions"},
-            "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
+            "kernel_ms_per_step": {k: round(v[0] / 3, 4) for k, v in sorted(prof.items())},
+            "kernel_ms_per_step_source": "three extra untimed steps with HIP events around every launch (the timed region times msm_bucket_acc only)",
         }
         traffic = None
         if world == 1 and not args.no_pmc:

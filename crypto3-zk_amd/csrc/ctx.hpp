@@ -56,6 +56,8 @@ struct ZkEventPair {
 
 struct ZkProfile {
     bool on = false;
+    bool last_recorded = false;  // prof_begin recorded an event pair for the launch in flight
+    std::string filter;          // non-empty: only kernels whose name starts with it are timed (fewer events in a timed region)
     std::vector<std::pair<std::string, ZkEventPair>> pending;
     std::vector<ZkEventPair> pool;
     std::map<std::string, std::pair<double, uint64_t>> acc;
@@ -144,7 +146,10 @@ struct zkhip_ctx {
 
     // ---- profiler
     void prof_begin(const char *name) {
+        prof.last_recorded = false;
         if (!prof.on) return;
+        if (!prof.filter.empty() && strncmp(name, prof.filter.c_str(), prof.filter.size()) != 0) return;
+        prof.last_recorded = true;
         ZkEventPair ev;
         if (!prof.pool.empty()) {
             ev = prof.pool.back();
@@ -157,7 +162,7 @@ struct zkhip_ctx {
         prof.pending.emplace_back(name, ev);
     }
     void prof_end() {
-        if (!prof.on) return;
+        if (!prof.on || !prof.last_recorded) return;
         (void)hipEventRecord(prof.pending.back().second.b, stream);
     }
     void prof_collect() {

@@ -519,6 +519,12 @@ int zkhip_profile_enable(zkhip_ctx *ctx, int on) {
     ctx->prof.on = on != 0;
     return ZKHIP_OK;
 }
+int zkhip_profile_filter(zkhip_ctx *ctx, const char *prefix) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ctx->prof_collect();
+    ctx->prof.filter = prefix ? prefix : "";
+    return ZKHIP_OK;
+}
 int zkhip_profile_reset(zkhip_ctx *ctx) {
     if (!ctx) return ZKHIP_ERR_INVALID;
     ctx->prof_collect();

@@ -19,7 +19,7 @@ EXPORTS = [
     "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_batch_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_domain_size", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev", "zkhip_fr_gather_dev", "zkhip_poly_resize_dev", "zkhip_fri_fold_dev", "zkhip_fri_leaves_dev", "zkhip_ec_ntt_dev",
     "zkhip_fr_vec_op_dev", "zkhip_fr_vec_prod_dev", "zkhip_poly_shift_dev", "zkhip_poly_eval_dev", "zkhip_poly_div_linear_dev", "zkhip_poly_lincomb_dev",
-    "zkhip_profile_enable", "zkhip_profile_reset", "zkhip_profile_get", "zkhip_profile_dump",
+    "zkhip_profile_enable", "zkhip_profile_reset", "zkhip_profile_filter", "zkhip_profile_get", "zkhip_profile_dump",
 ]
 
 
@@ -319,6 +319,9 @@ class Context:
 
     def profile(self, on: bool):
         self._check(self.lib.zkhip_profile_enable(self.h, 1 if on else 0), "zkhip_profile_enable")
+
+    def profile_filter(self, prefix: str = ""):
+        self._check(self.lib.zkhip_profile_filter(self.h, prefix.encode()), "zkhip_profile_filter")
 
     def profile_reset(self):
         self._check(self.lib.zkhip_profile_reset(self.h), "zkhip_profile_reset")

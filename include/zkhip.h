@@ -226,6 +226,9 @@ int zkhip_poly_lincomb_dev(zkhip_ctx *ctx, int curve, size_t count, const void *
 /* ---- profiling (HIP events on the context's stream around every kernel launch) ------------------ */
 int zkhip_profile_enable(zkhip_ctx *ctx, int on);
 int zkhip_profile_reset(zkhip_ctx *ctx);
+/* Only kernels whose name starts with `prefix` are timed from now on (NULL / "": all): keeps a timed region's event traffic to
+ * the one kernel whose duration is wanted. */
+int zkhip_profile_filter(zkhip_ctx *ctx, const char *prefix);
 /* Total milliseconds and launch count recorded for kernels whose name starts with `prefix`. */
 int zkhip_profile_get(zkhip_ctx *ctx, const char *prefix, double *total_ms, uint64_t *launches);
 /* Writes "name total_ms launches\n" lines; returns bytes needed. */

@@ -1,7 +1,7 @@
 """One 2^20 BLS12-381 G2 MSM (after a warm-up) for counter collection."""
 import sys
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import bench
 zk = bench.load_pkg()
 ctx = zk.Context(0)
