@@ -24,9 +24,7 @@
 // Data stays CANONICAL in HBM between passes; twiddles are Montgomery, so mul(x, w) = x*w is canonical and no
 // conversion pass exists.  Every per-element factor is ONE product against a table entry read next to the element:
 //   tw[i]     the factor pass i applies while storing (the next pass's omega_(Ns R)^(k t), times 1/m on the first
-//             boundary of an inverse transform), m entries of 32 B in output order -- read once per tile and shared by
-//             the PB polynomials a workgroup carries, so the tables add m * 32 B of traffic per pass to a batch's
-//             2 * batch * m * 32 B;
+//             boundary of an inverse transform), m entries in output order, read next to the element it multiplies;
 //   pre/post  g^i (forward coset, first load) / (1/m) g^-i (inverse coset, last store);
 //   stage     omega_R^q, q < R/2, staged in LDS per workgroup without any arithmetic.
 // The tables are built once per (size, omega, direction, coset, radix plan) from a two-level power table and cached
@@ -72,6 +70,8 @@ struct NttPass {
     const uint32_t *pre;        // first pass of a forward coset transform: g^index, else null
     const uint32_t *post;       // last pass of an inverse coset transform: (1/m) g^-index, else null
     const uint32_t *scale;      // single-pass inverse transform: 1/m (Fu form), else null
+    uint32_t in_lazy, out_lazy; // the vector read / written is in limb form (an intermediate between passes), else canonical
+    size_t planeb;              // words from a limb-form data buffer's base to its limb-8 plane (batch x m x 8)
 };
 
 // parameters of the table-building kernel: everything ntt_pass used to look up on the fly
@@ -170,6 +170,28 @@ ZK_D void g_store(uint32_t *p, const Fu<U> &x) {
     q[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
+// "limb form": the 9 x 29-bit limbs as they are -- limbs 0-7 in 32 bytes at element index i, limb 8 in a 4-byte plane
+// `planeb` words behind the array's base.  The factor tables and the intermediate vectors between passes use it: no
+// unpack / pack / conditional subtraction at a pass boundary (values there are lazy, < 2p); only the transform's input
+// and output are canonical.
+template <class U>
+ZK_D Fu<U> l_load(const uint32_t *base, size_t planeb, size_t i) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(base) + 2 * i;
+    const uint4 a = q[0], b = q[1];
+    Fu<U> r;
+    r.v[0] = a.x, r.v[1] = a.y, r.v[2] = a.z, r.v[3] = a.w;
+    r.v[4] = b.x, r.v[5] = b.y, r.v[6] = b.z, r.v[7] = b.w;
+    r.v[8] = base[planeb + i];
+    return r;
+}
+template <class U>
+ZK_D void l_store(uint32_t *base, size_t planeb, size_t i, const Fu<U> &x) {
+    uint4 *q = reinterpret_cast<uint4 *>(base) + 2 * i;
+    q[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    q[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+    base[planeb + i] = x.v[8];
+}
+
 // normalised limbs, value < 64 p  ->  [0, p), without a Montgomery product: q = floor(x / p) is estimated from the
 // top 13 bits of x with a 24-bit reciprocal (one short too low at most), x - q p < 2p, one conditional subtraction.
 template <class U>
@@ -196,7 +218,7 @@ ZK_D Fu<U> fu_reduce_small(const Fu<U> &x) {
 }
 
 // tw[oi] for one pass boundary (output order of the pass being stored = input order of the next): the next pass's
-// omega_(Ns' R')^(k' t'), times `scale` when given.  Saturated Montgomery limbs, canonical representative.
+// omega_(Ns' R')^(k' t'), times `scale` when given.  Montgomery form, canonical representative, limb form (m x 36 B).
 template <class U>
 __global__ __launch_bounds__(256) void ntt_build_tw(NttTwGeom g, uint32_t *__restrict__ out) {
     const uint64_t oi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -207,7 +229,7 @@ __global__ __launch_bounds__(256) void ntt_build_tw(NttTwGeom g, uint32_t *__res
     const uint64_t ex = ((jn & ((1ull << n_log_ns) - 1)) * tn) << n_tw_shift;
     Fu<U> f = tw_lookup<U>(g.lo, g.hi, g.lo_bits, ex);
     if (g.scale != nullptr) f = fu_cond_sub_p(fu_mul(f, fu_load<U>(g.scale)));
-    g_store<U>(out + oi * 8, f);
+    l_store<U>(out, (size_t)8 << g.log_m, oi, f);
 }
 // out[i] = scale * base^i (the coset factors), same format
 template <class U>
@@ -217,7 +239,7 @@ __global__ __launch_bounds__(256) void ntt_build_powers(const uint32_t *__restri
     if (i >> log_m) return;
     Fu<U> f = tw_lookup<U>(lo, hi, lo_bits, i);
     if (scale != nullptr) f = fu_cond_sub_p(fu_mul(f, fu_load<U>(scale)));
-    g_store<U>(out + i * 8, f);
+    l_store<U>(out, (size_t)8 << log_m, i, f);
 }
 // stage[q] = omega^(q << shift), q < count, Fu form
 template <class U>
@@ -252,10 +274,11 @@ __global__ __launch_bounds__(256) void ntt_pass(NttPass p) {
         const uint64_t gi = j0 + c + ((uint64_t)t << log_stride);
         const uint32_t slot = bitrev(t, p.s) * pitch + c;
         Fu<U> g;
-        if (p.pre) g = g_load<U>(p.pre + gi * 8);
+        if (p.pre) g = l_load<U>(p.pre, (size_t)8 << p.log_m, gi);
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
-            Fu<U> x = g_load<U>(p.in + ((((size_t)(poly0 + b)) << p.log_m) + gi) * 8);
+            const size_t ei = (((size_t)(poly0 + b)) << p.log_m) + gi;
+            Fu<U> x = p.in_lazy ? l_load<U>(p.in, p.planeb, ei) : g_load<U>(p.in + ei * 8);
             if (p.pre) x = fu_mul(x, g);
             lds_put(lds + b * tile_u4, slots, slot, x);
         }
@@ -289,7 +312,7 @@ __global__ __launch_bounds__(256) void ntt_pass(NttPass p) {
             // (i0, i0 + 2h) with omega_R^(qq << (s-2-st)) and (i0 + h, i0 + 3h) with omega_R^((qq + h) << (s-2-st))
             Fu<U> w1, w2a, w2b;
             if (st != 0) w1 = lds_get<U>(twr, nhalf, qq << (p.s - 1 - st));
-            w2a = lds_get<U>(twr, nhalf, qq << (p.s - 2 - st));
+            if (st != 0) w2a = lds_get<U>(twr, nhalf, qq << (p.s - 2 - st));
             w2b = lds_get<U>(twr, nhalf, (qq + h) << (p.s - 2 - st));
 #pragma unroll
             for (int b = 0; b < PB; ++b) {
@@ -304,7 +327,8 @@ __global__ __launch_bounds__(256) void ntt_pass(NttPass p) {
                     x3 = fu_cond_sub_p(x3);
                 }
                 const Fu<U> a0 = fu_add(x0, x1), a1 = fu_sub<4>(x0, x1), a2 = fu_add(x2, x3), a3 = fu_sub<4>(x2, x3);
-                const Fu<U> b2 = fu_mul(a2, w2a), b3 = fu_mul(a3, w2b);
+                // in the first round (h = 1, qq = 0) the even twiddle of the second stage is omega^0 = 1: a2 (< 3p) goes through as it is
+                const Fu<U> b2 = st != 0 ? fu_mul(a2, w2a) : a2, b3 = fu_mul(a3, w2b);
                 lds_put(tl, slots, e0, fu_add(a0, b2));
                 lds_put(tl, slots, e0 + 2 * eh, fu_sub<4>(a0, b2));
                 lds_put(tl, slots, e0 + eh, fu_add(a1, b3));
@@ -333,14 +357,19 @@ __global__ __launch_bounds__(256) void ntt_pass(NttPass p) {
         const uint64_t oi = ((j - k) << p.s) + k + ((uint64_t)tp << p.log_ns);
         const uint32_t *ftab = last ? p.post : p.tw;
         Fu<U> f;
-        if (ftab) f = g_load<U>(ftab + oi * 8);
+        if (ftab) f = l_load<U>(ftab, (size_t)8 << p.log_m, oi);
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
             Fu<U> x = lds_get<U>(lds + b * tile_u4, slots, tp * pitch + c);
+            const size_t eo = (((size_t)(poly0 + b)) << p.log_m) + oi;
+            if (p.out_lazy) {  // an intermediate vector: the product (< 2p, limbs normalised) is stored as it is
+                l_store<U>(p.out, p.planeb, eo, fu_mul(x, f));
+                continue;
+            }
             if (ftab) x = fu_cond_sub_p(fu_mul(x, f));
             else if (p.scale) x = fu_cond_sub_p(fu_mul(x, scale));
             else x = fu_reduce_small(x);
-            g_store<U>(p.out + ((((size_t)(poly0 + b)) << p.log_m) + oi) * 8, x);
+            g_store<U>(p.out + eo * 8, x);
         }
     }
 }
@@ -438,7 +467,7 @@ static int ntt_get_tables(zkhip_ctx *ctx, int curve, size_t log_m, const uint64_
         ZK_LAUNCH(ctx, "ntt_pow_table", ntt_pow_table<U>, dim3((nhi + 255) / 256), dim3(256), 0, t->d_base + U::SL, nhi, (uint32_t)t->lo_bits,
                   t->d_chi);
         // g^i while loading (forward) / (1/m) g^-i while storing (inverse): one entry per index
-        ZK_HIP_CHECK(ctx, hipMalloc((void **)&t->d_prepost, m * 32));
+        ZK_HIP_CHECK(ctx, hipMalloc((void **)&t->d_prepost, m * 36));
         ZK_LAUNCH(ctx, "ntt_build_tw", ntt_build_powers<U>, dim3(gm), dim3(256), 0, t->d_clo, t->d_chi, (uint32_t)t->lo_bits, (uint32_t)log_m,
                   inverse ? t->d_scale : (const uint32_t *)nullptr, t->d_prepost);
     }
@@ -461,7 +490,7 @@ static int ntt_get_tables(zkhip_ctx *ctx, int curve, size_t log_m, const uint64_
             g.hi = t->d_hi;
             g.lo_bits = (uint32_t)t->lo_bits;
             g.scale = (inverse && !coset && i == 0) ? t->d_scale : nullptr;
-            ZK_HIP_CHECK(ctx, hipMalloc((void **)&t->d_tw[i], m * 32));
+            ZK_HIP_CHECK(ctx, hipMalloc((void **)&t->d_tw[i], m * 36));
             ZK_LAUNCH(ctx, "ntt_build_tw", ntt_build_tw<U>, dim3(gm), dim3(256), 0, g, t->d_tw[i]);
         }
         log_ns += s;
@@ -500,24 +529,21 @@ static int ntt_run_t(zkhip_ctx *ctx, int curve, uint32_t *d_data, size_t log_m, 
     const NttPlan pl = ntt_plan(log_m, smax, ctx->opt_ntt_tile_log);
     const int np = pl.np;
     const size_t m = (size_t)1 << log_m;
-    const size_t bytes = batch * m * 32;
-    uint32_t *wsA = nullptr, *wsB = nullptr;
+    // intermediates between passes live in the workspace in limb form (36 B per element: no unpack / pack at a boundary),
+    // two buffers alternating; the first pass reads and the last pass writes the caller's canonical vector
+    const size_t lbytes = batch * m * 36;
+    uint32_t *ws2[2] = {nullptr, nullptr};
     if (np > 1) {
-        size_t need = zkhip_ctx::ws_round(bytes) * ((np & 1) ? 2 : 1);
+        size_t need = zkhip_ctx::ws_round(lbytes) * (np > 2 ? 2 : 1);
         ZK_TRY(ctx->ws_reserve(need));
         ctx->ws_reset();
-        wsA = ctx->ws_take<uint32_t>(bytes / 4);
-        if (np & 1) wsB = ctx->ws_take<uint32_t>(bytes / 4);
+        ws2[0] = ctx->ws_take<uint32_t>(lbytes / 4);
+        if (np > 2) ws2[1] = ctx->ws_take<uint32_t>(lbytes / 4);
     }
     uint32_t log_ns = 0;
     const uint32_t *src = d_data;
     for (int i = 0; i < np; ++i) {
-        uint32_t *dst;
-        if (np == 1) dst = d_data;  // the single tile is the whole polynomial: read fully into LDS before any store
-        else {
-            dst = ((np - 1 - i) % 2 == 0) ? d_data : wsA;
-            if (i == 0 && dst == d_data) dst = wsB;  // odd pass count: never write the buffer being read
-        }
+        uint32_t *dst = i == np - 1 ? d_data : ws2[i & 1];  // np == 1: in place (the single tile is read fully into LDS before any store)
         NttPass p;
         p.in = src;
         p.out = dst;
@@ -532,6 +558,9 @@ static int ntt_run_t(zkhip_ctx *ctx, int curve, uint32_t *d_data, size_t log_m, 
         p.pre = (!inverse && coset != nullptr && i == 0) ? tb->d_prepost : nullptr;
         p.post = (inverse && coset != nullptr && i == np - 1) ? tb->d_prepost : nullptr;
         p.scale = (inverse && coset == nullptr && np == 1) ? tb->d_scale : nullptr;
+        p.in_lazy = i > 0 ? 1u : 0u;
+        p.out_lazy = i < np - 1 ? 1u : 0u;
+        p.planeb = batch * m * 8;
         const size_t nelem = (size_t)1 << (p.s + p.log_t), nhalf = std::max<size_t>(1, ((size_t)1 << p.s) / 2);
         const size_t slots = ((size_t)1 << p.s) * (((size_t)1 << p.log_t) + NTT_PAD);
         const size_t lds = ((size_t)ntt_tile_u4((uint32_t)slots) + ntt_tile_u4((uint32_t)nhalf)) * 16;

@@ -75,6 +75,7 @@ def kernel_pass(x, log_m, s, log_ns, log_t, next_s, w, r, pre=None, post=None, s
                 w2a, w2b = twr[qq << (s - 2 - st)], twr[(qq + h) << (s - 2 - st)]
                 x1, x3 = x1 * w1 % r, x3 * w1 % r
                 a0, a1, a2, a3 = (x0 + x1) % r, (x0 - x1) % r, (x2 + x3) % r, (x2 - x3) % r
+                assert st != 0 or w2a == 1  # the kernel skips this product in the first round
                 b2, b3 = a2 * w2a % r, a3 * w2b % r
                 lds[e[0]], lds[e[2]], lds[e[1]], lds[e[3]] = (a0 + b2) % r, (a0 - b2) % r, (a1 + b3) % r, (a1 - b3) % r
             st += 2
@@ -143,16 +144,13 @@ def test_kernel_index_model(log_m, smax, tile_log):
 
 
 def test_buffer_schedule():
-    """Mirror of the ping-pong choice in ntt_run_t: the last pass writes `data`, no pass reads what it writes."""
+    """Mirror of the buffer choice in ntt_run_t: the first pass reads and the last pass writes the caller's vector, the
+    intermediates alternate between two workspace buffers (limb form), no pass reads what it writes unless it is alone."""
     for np_ in range(1, 9):
         src = "data"
         for i in range(np_):
-            if np_ == 1:
-                dst = "data"
-            else:
-                dst = "data" if (np_ - 1 - i) % 2 == 0 else "A"
-                if i == 0 and dst == "data":
-                    dst = "B"
+            dst = "data" if i == np_ - 1 else ("A", "B")[i & 1]
+            if np_ > 1:
                 assert dst != src
             src = dst
         assert src == "data"
