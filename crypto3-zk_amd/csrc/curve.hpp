@@ -126,17 +126,22 @@ ZK_HD XYZZ<F> xyzz_add(const XYZZ<F> &a, const XYZZ<F> &b) {
     return {X3, Y3, O::mul(O::mul(a.ZZ, b.ZZ), PP), O::mul(O::mul(a.ZZZ, b.ZZZ), PPP)};
 }
 
-// k * a for a small unsigned k (bucket weights / segment offsets, k < 2^32): left-to-right double-and-add
+// k * a for a small unsigned k (bucket weights / segment offsets, k < 2^32): left-to-right over 2-bit digits with the
+// multiples a, 2a, 3a.  The lanes of a wave hold different k, so a bit-by-bit double-and-add executes its addition at
+// EVERY bit (some lane always has it set): 2-bit digits halve the additions -- b doublings + b/2 + 2 additions
+// instead of b + b for a b-bit k -- on a path whose length is what the MSM's tail costs (msm_core.hpp).
 template <class F>
 ZK_HD XYZZ<F> xyzz_mul_small(const XYZZ<F> &a, uint32_t k) {
     XYZZ<F> r = XYZZ<F>::infinity();
     if (k == 0 || a.is_inf()) return r;
     int top = 31;
     while (!((k >> top) & 1)) --top;
-    r = a;
-    for (int i = top - 1; i >= 0; --i) {
-        r = xyzz_dbl(r);
-        if ((k >> i) & 1) r = xyzz_add(r, a);
+    if (top == 0) return a;
+    const XYZZ<F> a2 = xyzz_dbl(a), a3 = xyzz_add(a2, a);
+    for (int i = top >> 1; i >= 0; --i) {
+        if (!r.is_inf()) r = xyzz_dbl(xyzz_dbl(r));
+        const uint32_t d = (k >> (2 * i)) & 3u;
+        if (d != 0) r = xyzz_add(r, d == 1 ? a : (d == 2 ? a2 : a3));
     }
     return r;
 }
