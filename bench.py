@@ -117,6 +117,12 @@ def main():
     if args.dry_run:
         return dry_run(args)
 
+    # stdout carries exactly ONE line, rank 0's JSON: libraries that print to the C stdout (librccl announces its path there,
+    # flushed at exit, i.e. AFTER our line) are sent to stderr for the whole run; the line is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch  # first: libzkhip.so must share torch's HIP runtime
 
@@ -274,7 +280,7 @@ def main():
             line["kzg"] = kzg_leg(np, zk, ctx, verify=not args.no_verify)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(np, bases)
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     fence()
     bases.free()
     ctx.close()
