@@ -80,7 +80,7 @@ int zk_scalar_bits(int curve) { return curve == CURVE_BLS12_381 ? 255 : 254; }  
 // tables all W = ceil(bitlen(r) / c) windows of a point feed the same bucket set(s) (msm_core.hpp): the work is n W mixed
 // additions + ~3 full additions per bucket of reduction, and the accumulation kernel wants ~2^19 lanes (buckets) of a few
 // entries each.  From 2^19 points on one set of 2^19 buckets does it (c = 20: 13 windows instead of the 16 of c = 16;
-// c = 21 has the same 13 windows and twice the buckets to reduce, c = 22 would need 2^21); below, c stops at 17 and the set is replicated (zk_msm_target_lanes) -- at 2^10 .. 2^16 points
+// c = 21 has the same 13 windows and twice the buckets to reduce, c = 22 would need 2^21); below, c follows the sweep and c stops at 17 and the set is replicated (zk_msm_target_lanes) -- at 2^10 .. 2^16 points
 // that is one set per window again, which the sweep shows to be as good as anything there.
 // ZKHIP_MSM_WINDOW_BITS in the environment overrides the automatic choice (experiments).
 int zk_msm_auto_window(size_t n) {
@@ -91,7 +91,9 @@ int zk_msm_auto_window(size_t n) {
     if (env_c > 0) return std::max(2, std::min(ZK_MSM_MAX_C, env_c));
     int l = ilog2(n);
     if ((double)n >= 1.41421356237 * (double)((size_t)1 << l)) ++l;
-    const int c = l >= 19 ? 20 : std::min(17, l + 1);
+    // profiles/r02_msm_window_sweep_g1.json: 2^10: c11 / S24, 2^12: c13 / S20, 2^14: c15 / S8, 2^16: c15 / S17, 2^18: c16 / S16 ~ c17 / S8,
+    // 2^20, 2^21: c20 / S1
+    const int c = l >= 19 ? 20 : (l == 18 ? 17 : (l == 17 ? 16 : (l >= 15 ? 15 : l + 1)));
     return std::max(2, std::min(ZK_MSM_MAX_C, c));
 }
 

@@ -139,6 +139,51 @@ __global__ __launch_bounds__(256) void msm_scan_add(uint32_t *__restrict__ offs,
     }
 }
 
+// the same three steps in ONE launch for short arrays (small MSMs are bound by launch gaps, not by work): one workgroup walks the
+// array in 1024-counter strips, carrying the running total
+__global__ __launch_bounds__(1024) void msm_scan_single(const uint32_t *__restrict__ hist, uint32_t count, uint32_t *__restrict__ offs,
+                                                        uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < count; base += 1024) {
+        const uint32_t v = base + t < count ? hist[base + t] : 0;
+        part[t] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            uint32_t x = t >= d ? part[t - d] : 0;
+            __syncthreads();
+            part[t] += x;
+            __syncthreads();
+        }
+        const uint32_t excl = carry + part[t] - v;
+        if (base + t < count) {
+            offs[base + t] = excl;
+            if (cursor != offs) cursor[base + t] = excl;
+        }
+        __syncthreads();
+        if (t == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (t == 0) offs[count] = carry;
+}
+constexpr uint32_t MSM_SCAN_SINGLE_MAX = 1u << 16;
+
+// exclusive scan of hist[0 .. count) into offs[0 .. count], offs[count] = total (bsums: scratch for the three-launch form)
+inline int msm_scan(zkhip_ctx *ctx, const char *name, const uint32_t *hist, uint32_t count, uint32_t *offs, uint32_t *bsums) {
+    if (count <= MSM_SCAN_SINGLE_MAX) {
+        ZK_LAUNCH(ctx, name, msm_scan_single, dim3(1), dim3(1024), 0, hist, count, offs, offs);
+        return 0;
+    }
+    const uint32_t nblk = (count + 1023) / 1024;
+    ZK_LAUNCH(ctx, name, msm_scan_local, dim3(nblk), dim3(256), 0, hist, count, offs, bsums);
+    ZK_LAUNCH(ctx, name, msm_scan_top, dim3(1), dim3(1024), 0, bsums, nblk, offs + count);
+    ZK_LAUNCH(ctx, name, msm_scan_add, dim3(nblk), dim3(256), 0, offs, count, bsums, offs);
+    return 0;
+}
+
 // Window partition (wrank of wworld): the carry chain runs over all windows, only the digits of windows
 // w = wrank + k wworld are kept, as local window k.
 template <class FR>
@@ -816,9 +861,8 @@ int msm_sort_run(zkhip_ctx *ctx, const SortGeom &g, int W, uint32_t nb, uint32_t
     if (lds_split > 48 * 1024) ZK_MAX_LDS(ctx, msm_sort_split<SZ>, 160 * 1024 - 256);
     if (lds_final > 40 * 1024) ZK_MAX_LDS(ctx, msm_sort_final<SZ>, 160 * 1024 - (4 * SORT_NLOW_MAX + SZ::THREADS) * 4 - 256);
     ZK_LAUNCH(ctx, "msm_sort_hist", msm_sort_hist<SZ>, dim3(g.ntile, W), dim3(SZ::THREADS), lds_hist, dig, g, bh);
-    ZK_LAUNCH(ctx, "msm_scan", msm_scan_local, dim3(nblk), dim3(256), 0, bh, nbh, bo, bsums);
-    ZK_LAUNCH(ctx, "msm_scan", msm_scan_top, dim3(1), dim3(1024), 0, bsums, nblk, bo + nbh);
-    ZK_LAUNCH(ctx, "msm_scan", msm_scan_add, dim3(nblk), dim3(256), 0, bo, nbh, bsums, bo);
+    (void)nblk;
+    ZK_TRY(msm_scan(ctx, "msm_scan", bh, nbh, bo, bsums));
     ZK_LAUNCH(ctx, "msm_sort_split", msm_sort_split<SZ>, dim3(g.ntile, W), dim3(SZ::THREADS), lds_split, dig, g, bo, tmp_idx, tmp_key);
     ZK_LAUNCH(ctx, "msm_sort_final", msm_sort_final<SZ>, dim3(g.nsuper), dim3(SZ::THREADS), lds_final, tmp_idx, tmp_key, g, nb, bo, offs, idx);
     return 0;
@@ -922,9 +966,7 @@ int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
     ZK_TRY((big_tiles ? msm_sort_run<SortBig> : msm_sort_run<SortSmall>)(ctx, g, W, nb, nbh, nblk, dig, bh, bo, bsums, tmp_idx, tmp_key, offs, idx));
     // buckets by descending size
     ZK_LAUNCH(ctx, "msm_size_sort", msm_size_hist, dim3(sblk), dim3(256), 0, offs, nb, sblk, large_thresh, sh);
-    ZK_LAUNCH(ctx, "msm_size_sort", msm_scan_local, dim3(sblk2), dim3(256), 0, sh, nsh, so, ssums);
-    ZK_LAUNCH(ctx, "msm_size_sort", msm_scan_top, dim3(1), dim3(1024), 0, ssums, sblk2, so + nsh);
-    ZK_LAUNCH(ctx, "msm_size_sort", msm_scan_add, dim3(sblk2), dim3(256), 0, so, nsh, ssums, so);
+    ZK_TRY(msm_scan(ctx, "msm_size_sort", sh, nsh, so, ssums));
     ZK_LAUNCH(ctx, "msm_size_sort", msm_size_scatter, dim3(sblk), dim3(256), 0, offs, nb, sblk, large_thresh, so, order);
     if constexpr (FieldOps<F>::WORDS <= 16) {
         // G1: accumulator coordinates in LDS, three waves per SIMD
