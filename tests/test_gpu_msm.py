@@ -397,3 +397,56 @@ def test_msm_partitions_over_ranks(zk, ctx, curve, group, n, world):
         ctx.set_option("msm_shard_world", 1)
         for p in (d_parts, d_tot, d_sc):
             ctx.free(p)
+
+
+def test_gather_bounds_and_device_status(zk, ctx):
+    """zkhip_fr_gather_dev bounds every index by the source length: an index beyond it gathers the zero scalar and
+    raises the sticky device status, which zkhip_device_status reports once and clears."""
+    src = cp.random_fr(0, 7, 10)
+    idx = np.array([0, 9, 3, 10, 4000000000, 2], dtype=np.uint32)
+    d_src, d_idx, d_dst = ctx.malloc(src.nbytes), ctx.malloc(idx.nbytes), ctx.malloc(len(idx) * 32)
+    ctx.h2d(d_src, src)
+    ctx.h2d(d_idx, idx)
+    assert ctx.device_status() == 0
+    ctx.fr_gather_dev(d_src, 10, d_idx, len(idx), d_dst)
+    out = np.zeros((len(idx), 4), dtype=np.uint64)
+    ctx.d2h(out, d_dst)
+    assert (out[[0, 1, 2, 5]] == src[[0, 9, 3, 2]]).all() and not out[[3, 4]].any()
+    with pytest.raises(zk.ZkhipError):
+        ctx.device_status()
+    assert ctx.device_status() == 0  # cleared
+    ctx.fr_gather_dev(d_src, 10, d_idx, 3, d_dst)  # in range: stays clean
+    assert ctx.device_status() == 0
+    for p in (d_src, d_idx, d_dst):
+        ctx.free(p)
+
+
+def test_msm_random_configurations(zk, ctx):
+    """the same MSM under randomly drawn (window size, bucket sets, sort tile shape, tail segment, tables on / off, sub-range)
+    combinations -- every path of the planner -- against the oracle."""
+    rng = np.random.default_rng(2024)
+    for curve, group, n in ((0, 1, 3000), (1, 1, 900), (0, 2, 500)):
+        ks = cp.random_fr(curve, 300 + n, n)
+        pts, _ = cp.batch_mul(curve, group, ks)
+        sc = cp.random_fr(curve, 301 + n, n)
+        sc[::9] = 0
+        sc[1::17] = fr_arr([1])[0]
+        try:
+            for _ in range(10):
+                c = int(rng.integers(2, 22))
+                tables = bool(rng.integers(0, 4))
+                ctx.set_option("msm_precompute", 1 if tables else 0)
+                ctx.set_option("msm_window_bits", c)
+                b = ctx.upload_bases(curve, group, pts)
+                ctx.set_option("msm_sets", int(rng.integers(0, 9)))
+                ctx.set_option("msm_sort_tile_log", int(rng.choice([12, 14])))
+                ctx.set_option("msm_segment_log", int(rng.integers(-1, 6)))
+                lo = int(rng.integers(0, n // 2))
+                cnt = int(rng.integers(1, n - lo + 1))
+                exp, einf = cp.msm(curve, group, pts[lo:lo + cnt], sc[lo:lo + cnt], chunks=4)
+                got, ginf = ctx.msm_affine(b, sc[lo:lo + cnt], lo, cnt)
+                assert ginf == einf and (got == exp).all(), (curve, group, c, tables, lo, cnt)
+                b.free()
+        finally:
+            for name, v in (("msm_precompute", 1), ("msm_window_bits", 0), ("msm_sets", 0), ("msm_sort_tile_log", 14), ("msm_segment_log", -1)):
+                ctx.set_option(name, v)

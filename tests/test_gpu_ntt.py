@@ -149,3 +149,16 @@ def test_lpc_resize_and_fold(ctx, zk, curve, log_n, expand):
     assert fr_ints(gotf) == expf
     for p in (d_in, d_out, d_f):
         ctx.free(p)
+
+
+def test_ntt_rejects_a_root_of_the_wrong_order(zk, ctx):
+    """omega must be a PRIMITIVE 2^log_m-th root of unity (a key generated over another domain must fail loudly,
+    not transform over the wrong domain): the square of the right root (order m / 2), 1, and the root of the next size are refused."""
+    C = po.BLS12_381
+    log_m = 8
+    a = cp.random_fr(0, 3, 1 << log_m).reshape(1, -1, 4)
+    w = C.root_of_unity(log_m)
+    assert (ctx.ntt(0, a, log_m, limbs(w, 4)) == cp.ntt(0, a, log_m, limbs(w, 4))).all()
+    for bad in (w * w % C.r, 1, C.root_of_unity(log_m + 1), C.r - 1):
+        with pytest.raises(zk.ZkhipError):
+            ctx.ntt(0, a, log_m, limbs(bad, 4))
