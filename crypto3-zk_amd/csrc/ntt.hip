@@ -563,12 +563,34 @@ static int ntt_run_t(zkhip_ctx *ctx, int curve, uint32_t *d_data, size_t log_m, 
         p.planeb = batch * m * 8;
         const size_t nelem = (size_t)1 << (p.s + p.log_t), nhalf = std::max<size_t>(1, ((size_t)1 << p.s) / 2);
         const size_t slots = ((size_t)1 << p.s) * (((size_t)1 << p.log_t) + NTT_PAD);
-        const size_t lds = ((size_t)ntt_tile_u4((uint32_t)slots) + ntt_tile_u4((uint32_t)nhalf)) * 16;
-        ZK_MAX_LDS(ctx, (ntt_pass<U, 1>), 160 * 1024);
-        size_t grid = batch * p.tiles_per_poly;
+        // PB = 1, 2 or 4 polynomials of the batch per workgroup (they share indices, twiddle registers and the factor-table
+        // reads) while the batch divides and the tiles leave room for a second workgroup on the CU; option "ntt_pair" = log2(PB) wanted
+        int pb = 1 << std::max(0, std::min(2, ctx->opt_ntt_pair));
+        while (pb > 1 && batch % pb != 0) pb >>= 1;
+        // a narrower tile that lets the polynomials share a workgroup beats a wider one that does not (measured)
+        while (pb > 1 && p.log_t > 2 && ((size_t)pb * ntt_tile_u4((1u << p.s) * ((1u << p.log_t) + NTT_PAD)) + ntt_tile_u4((uint32_t)nhalf)) * 16 > 80 * 1024) {
+            --p.log_t;
+            p.tiles_per_poly <<= 1;
+        }
+        const size_t slots_p = ((size_t)1 << p.s) * (((size_t)1 << p.log_t) + NTT_PAD);
+        while (pb > 1 && ((size_t)pb * ntt_tile_u4((uint32_t)slots_p) + ntt_tile_u4((uint32_t)nhalf)) * 16 > 80 * 1024) pb >>= 1;
+        const size_t nelem_p = (size_t)1 << (p.s + p.log_t);
+        const size_t lds = ((size_t)pb * ntt_tile_u4((uint32_t)slots_p) + ntt_tile_u4((uint32_t)nhalf)) * 16;
+        size_t grid = batch / pb * p.tiles_per_poly;
         if (grid >= (1ull << 31)) return ZKHIP_ERR_RANGE;
-        unsigned threads = (unsigned)std::min<size_t>(256, std::max<size_t>(64, nelem / 4));
-        ZK_LAUNCH(ctx, "ntt_pass", (ntt_pass<U, 1>), dim3((unsigned)grid), dim3(threads), lds, p);
+        unsigned threads = (unsigned)std::min<size_t>(256, std::max<size_t>(64, nelem_p / 4));
+        (void)nelem;
+        (void)slots;
+        if (pb == 4) {
+            ZK_MAX_LDS(ctx, (ntt_pass<U, 4>), 160 * 1024);
+            ZK_LAUNCH(ctx, "ntt_pass", (ntt_pass<U, 4>), dim3((unsigned)grid), dim3(threads), lds, p);
+        } else if (pb == 2) {
+            ZK_MAX_LDS(ctx, (ntt_pass<U, 2>), 160 * 1024);
+            ZK_LAUNCH(ctx, "ntt_pass", (ntt_pass<U, 2>), dim3((unsigned)grid), dim3(threads), lds, p);
+        } else {
+            ZK_MAX_LDS(ctx, (ntt_pass<U, 1>), 160 * 1024);
+            ZK_LAUNCH(ctx, "ntt_pass", (ntt_pass<U, 1>), dim3((unsigned)grid), dim3(threads), lds, p);
+        }
         src = dst;
         log_ns += p.s;
     }

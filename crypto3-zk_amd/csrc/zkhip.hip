@@ -126,6 +126,7 @@ int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value) {
     else if (n == "msm_sort_tile_log") ctx->opt_msm_sort_tile_log = (int)value;
     else if (n == "ntt_radix_log") ctx->opt_ntt_radix_log = (int)value;
     else if (n == "ntt_tile_log") ctx->opt_ntt_tile_log = (int)value;
+    else if (n == "ntt_pair") ctx->opt_ntt_pair = (int)value;
     else if (n == "msm_precompute") ctx->opt_msm_precompute = (int)value;
     else if (n == "msm_precompute_min") ctx->opt_msm_precompute_min = (int)value;
     else if (n == "msm_shard_world") {

@@ -43,12 +43,20 @@ def test_ntt_pass_structure_options(ctx):
     try:
         for radix in (1, 2, 3, 4, 5, 6, 8, 10):
             for tile in (0, 1, 3, 4):
-                ctx.set_option("ntt_radix_log", radix)
-                ctx.set_option("ntt_tile_log", tile)
-                assert (ctx.ntt(0, a, log_m, w) == exp).all(), (radix, tile)
+                for pair in (0, 1, 2):  # 1 / 2 / 4 polynomials of the (even) batch per workgroup
+                    ctx.set_option("ntt_radix_log", radix)
+                    ctx.set_option("ntt_tile_log", tile)
+                    ctx.set_option("ntt_pair", pair)
+                    assert (ctx.ntt(0, a, log_m, w) == exp).all(), (radix, tile, pair)
+        a4 = cp.random_fr(0, 10, 4 * m).reshape(4, m, 4)
+        ctx.set_option("ntt_radix_log", 6)
+        ctx.set_option("ntt_pair", 2)
+        assert (ctx.ntt(0, a4, log_m, w) == cp.ntt(0, a4, log_m, w)).all()
+        assert (ctx.ntt(0, a4[:3], log_m, w) == cp.ntt(0, a4[:3], log_m, w)).all()  # odd batch: falls back to one per workgroup
     finally:
         ctx.set_option("ntt_radix_log", 8)
         ctx.set_option("ntt_tile_log", 3)
+        ctx.set_option("ntt_pair", 1)
 
 
 def test_ntt_edge_values(ctx):
