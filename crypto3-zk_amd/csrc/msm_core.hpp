@@ -44,6 +44,7 @@
 #pragma once
 #include <algorithm>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #ifndef ZK_NOINLINE_MUL2
@@ -1038,12 +1039,14 @@ int bases_precompute_t(zkhip_ctx *ctx, zkhip_bases *b) {
 
 // Several MSMs over table-backed bases of one group with one window size: per MSM digits / sort / accumulate /
 // merge as usual, then ONE bucket reduction, set sum and output conversion for the whole batch.
-template <class F>
-int msm_batch_t(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases, const size_t *offsets, const size_t *ns,
-                const uint32_t *const *d_scalars, uint32_t *const *d_outs) {
+// TL / TLPB: what a lane of the shared tail holds.  A few members: the latency-bound shape of a single MSM (G1: the group law over
+// lane pairs).  Many members (50 KZG columns x 2^19 buckets) have lanes to spare and are bound by WORK: one lane per point then
+// does the same additions without the pair's selects and DPP swaps (measured: msm_bucket_red of a 50-column 2^20-row commit
+// 16.2 -> 13.7 ms).
+template <class F, class TL, int TLPB>
+int msm_batch_tail(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases, const size_t *offsets, const size_t *ns,
+                   const uint32_t *const *d_scalars, uint32_t *const *d_outs) {
     constexpr int NL = FieldOps<F>::WORDS;
-    typedef typename TailLane<F>::type TL;
-    constexpr int TLPB = TailLane<F>::LANES;
     const int c = bases[0]->c_tab;
     const uint32_t B = 1u << (c - 1);
     const uint32_t L = msm_tail_segment(ctx, B, count, TLPB, FieldOps<F>::WORDS > 16);
@@ -1084,12 +1087,24 @@ int msm_batch_t(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases, c
         ctx->batch_ptrs.assign(d_outs, d_outs + count);
         ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_ptrs, ctx->batch_ptrs.data(), count * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
     }
-    ZK_TRY(msm_tail_attr<F>(ctx));
+    ZK_MAX_LDS(ctx, (msm_bucket_red<TL, TLPB>), MSM_TAIL_THREADS / TLPB * 4 * NL * 4);
     ZK_LAUNCH(ctx, "msm_bucket_red", (msm_bucket_red<TL, TLPB>), dim3((unsigned)count * nblk_tail), dim3(MSM_TAIL_THREADS), (size_t)tail_slots * 4 * NL * 4, slots,
               B, L, nseg, nblk_tail, segsum);
     ZK_LAUNCH(ctx, "msm_window_sum", (msm_window_sum<TL, TLPB>), dim3((unsigned)count), dim3(64), (size_t)64 / TLPB * 4 * NL * 4, segsum, nblk_tail, winsum);
     ZK_LAUNCH(ctx, "msm_final", (msm_final_batch<TL, TLPB>), dim3((unsigned)count), dim3(64), 0, winsum, (uint32_t)count, d_ptrs);
     return 0;
+}
+
+template <class F>
+int msm_batch_t(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases, const size_t *offsets, const size_t *ns,
+                const uint32_t *const *d_scalars, uint32_t *const *d_outs) {
+    typedef typename BucketLane<F>::type FL;
+    typedef typename TailLane<F>::type TL;
+    const size_t buckets = count << (bases[0]->c_tab - 1);
+    // >= 2^22 buckets in all: even at 64 per lane the one-lane shape keeps every SIMD busy (4 waves) -- work-bound
+    if (!std::is_same<FL, TL>::value && buckets >= ((size_t)1 << 22))
+        return msm_batch_tail<F, FL, BucketLane<F>::LANES>(ctx, count, bases, offsets, ns, d_scalars, d_outs);
+    return msm_batch_tail<F, TL, TailLane<F>::LANES>(ctx, count, bases, offsets, ns, d_scalars, d_outs);
 }
 
 // ---- the per-(curve, group) operation table ----------------------------------------------------------------------
