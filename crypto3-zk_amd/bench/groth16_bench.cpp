@@ -112,6 +112,9 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
         times[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     }
     if (prof && prof_cap) zkhip_profile_dump(ctx.get(), prof, prof_cap);    // per-kernel HIP-event ms of the last proof
+    if (getenv("ZKHIP_G16_PHASES"))
+        fprintf(stderr, "proof phases (host ms): stage+launch %.3f | host products %.3f | wait %.3f | assemble %.3f\n", dpk.last_phase_ms[0],
+                dpk.last_phase_ms[1], dpk.last_phase_ms[2], dpk.last_phase_ms[3]);
     /* the check, outside the timed region: the proof must be the one the trapdoor dictates */
     if (verified) {
         const auto e = groth16_proof_exponents<Curve>(key->host.constraint_system, dom, primary, auxiliary, t, alpha, beta, delta, r, s);

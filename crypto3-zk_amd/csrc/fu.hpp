@@ -36,38 +36,38 @@ struct Fu {
 
     ZK_HD static Fu zero() {
         Fu r;
-#pragma unroll
+ZK_UNROLL
         for (int i = 0; i < L; ++i) r.v[i] = 0;
         return r;
     }
     ZK_HD static Fu one() {  // Montgomery form of 1 (R mod p)
         Fu r;
-#pragma unroll
+ZK_UNROLL
         for (int i = 0; i < L; ++i) r.v[i] = U::r1(i);
         return r;
     }
     ZK_HD static Fu r2() {
         Fu r;
-#pragma unroll
+ZK_UNROLL
         for (int i = 0; i < L; ++i) r.v[i] = U::r2(i);
         return r;
     }
     ZK_HD static Fu modulus() {
         Fu r;
-#pragma unroll
+ZK_UNROLL
         for (int i = 0; i < L; ++i) r.v[i] = U::mod(i);
         return r;
     }
     // all limbs zero (exact representation of 0; NOT a test for 0 mod p)
     ZK_HD bool limbs_zero() const {
         uint32_t o = 0;
-#pragma unroll
+ZK_UNROLL
         for (int i = 0; i < L; ++i) o |= v[i];
         return o == 0;
     }
     ZK_HD bool limbs_equal(const Fu &b) const {
         uint32_t o = 0;
-#pragma unroll
+ZK_UNROLL
         for (int i = 0; i < L; ++i) o |= v[i] ^ b.v[i];
         return o == 0;
     }
@@ -77,7 +77,7 @@ struct Fu {
 template <class U>
 ZK_HD void fu_norm(Fu<U> &a) {
     constexpr int L = U::L, B = U::B;
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < L - 1; ++i) {
         a.v[i + 1] += a.v[i] >> B;
         a.v[i] &= Fu<U>::MASK;
@@ -87,7 +87,7 @@ ZK_HD void fu_norm(Fu<U> &a) {
 template <class U>
 ZK_HD Fu<U> fu_add(const Fu<U> &a, const Fu<U> &b) {
     Fu<U> r;
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < U::L; ++i) r.v[i] = a.v[i] + b.v[i];
     fu_norm(r);
     return r;
@@ -97,7 +97,7 @@ ZK_HD Fu<U> fu_add(const Fu<U> &a, const Fu<U> &b) {
 template <int K, class U>
 ZK_HD Fu<U> fu_sub(const Fu<U> &a, const Fu<U> &b) {
     Fu<U> r;
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < U::L; ++i) r.v[i] = a.v[i] + (U::template spread<K>(i) - b.v[i]);
     fu_norm(r);
     return r;
@@ -111,21 +111,21 @@ ZK_HD Fu<U> fu_mul(const Fu<U> &a, const Fu<U> &b) {
     uint32_t m[L];
     Fu<U> r;
     uint64_t acc = 0;
-#pragma unroll
+ZK_UNROLL
     for (int k = 0; k < L; ++k) {
-#pragma unroll
+ZK_UNROLL
         for (int i = 0; i <= k; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
-#pragma unroll
+ZK_UNROLL
         for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * U::mod(k - i);
         m[k] = ((uint32_t)acc * U::QINV) & MASK;
         acc += (uint64_t)m[k] * U::mod(0);
         acc >>= B;
     }
-#pragma unroll
+ZK_UNROLL
     for (int k = L; k < 2 * L - 1; ++k) {
-#pragma unroll
+ZK_UNROLL
         for (int i = k - L + 1; i < L; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
-#pragma unroll
+ZK_UNROLL
         for (int i = k - L + 1; i < L; ++i) acc += (uint64_t)m[i] * U::mod(k - i);
         r.v[k - L] = (uint32_t)acc & MASK;
         acc >>= B;
@@ -146,25 +146,25 @@ ZK_HD Fu<U> fu_mul2(const Fu<U> &a, const Fu<U> &b, const Fu<U> &c, const Fu<U> 
     uint32_t m[L];
     Fu<U> r;
     uint64_t acc = 0;
-#pragma unroll
+ZK_UNROLL
     for (int k = 0; k < L; ++k) {
-#pragma unroll
+ZK_UNROLL
         for (int i = 0; i <= k; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
-#pragma unroll
+ZK_UNROLL
         for (int i = 0; i <= k; ++i) acc += (uint64_t)c.v[i] * d.v[k - i];
-#pragma unroll
+ZK_UNROLL
         for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * U::mod(k - i);
         m[k] = ((uint32_t)acc * U::QINV) & MASK;
         acc += (uint64_t)m[k] * U::mod(0);
         acc >>= B;
     }
-#pragma unroll
+ZK_UNROLL
     for (int k = L; k < 2 * L - 1; ++k) {
-#pragma unroll
+ZK_UNROLL
         for (int i = k - L + 1; i < L; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
-#pragma unroll
+ZK_UNROLL
         for (int i = k - L + 1; i < L; ++i) acc += (uint64_t)c.v[i] * d.v[k - i];
-#pragma unroll
+ZK_UNROLL
         for (int i = k - L + 1; i < L; ++i) acc += (uint64_t)m[i] * U::mod(k - i);
         r.v[k - L] = (uint32_t)acc & MASK;
         acc >>= B;
@@ -180,23 +180,23 @@ ZK_HD Fu<U> fu_sqr(const Fu<U> &a) {
     constexpr int L = U::L, B = U::B;
     constexpr uint32_t MASK = Fu<U>::MASK;
     uint32_t m[L], d[L];
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < L; ++i) d[i] = a.v[i] << 1;
     Fu<U> r;
     uint64_t acc = 0;
-#pragma unroll
+ZK_UNROLL
     for (int k = 0; k < 2 * L - 1; ++k) {
         // a_i * (2 a_(k-i)) over i < k - i, both indices inside [0, L)
-#pragma unroll
+ZK_UNROLL
         for (int i = (k < L ? 0 : k - L + 1); 2 * i < k; ++i) acc += (uint64_t)a.v[i] * d[k - i];
         if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
         if (k < L) {
-#pragma unroll
+ZK_UNROLL
             for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * U::mod(k - i);
             m[k] = ((uint32_t)acc * U::QINV) & MASK;
             acc += (uint64_t)m[k] * U::mod(0);
         } else {
-#pragma unroll
+ZK_UNROLL
             for (int i = k - L + 1; i < L; ++i) acc += (uint64_t)m[i] * U::mod(k - i);
             r.v[k - L] = (uint32_t)acc & MASK;
         }
@@ -220,7 +220,7 @@ ZK_NOINLINE_HD Fu<U> fu_mul2_call(Fu<U> a, Fu<U> b, Fu<U> c, Fu<U> d) {
 template <class U>
 ZK_HD bool fu_is_zero_lt2p(const Fu<U> &a) {
     uint32_t z = 0, e = 0;
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < U::L; ++i) {
         z |= a.v[i];
         e |= a.v[i] ^ U::mod(i);
@@ -234,14 +234,14 @@ ZK_HD Fu<U> fu_cond_sub_p(const Fu<U> &a) {
     constexpr int L = U::L;
     Fu<U> d;
     uint32_t borrow = 0;
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < L; ++i) {
         uint32_t t = a.v[i] - U::mod(i) - borrow;  // limbs are < 2^30: bit 31 of t is its sign
         borrow = t >> 31;
         d.v[i] = t & Fu<U>::MASK;
     }
     Fu<U> r;
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < L; ++i) r.v[i] = borrow ? a.v[i] : d.v[i];
     return r;
 }
@@ -263,7 +263,7 @@ template <class U>
 ZK_HD Fu<U> fu_unpack(const uint32_t *sat) {
     constexpr int L = U::L, B = U::B, NL = U::NL;
     Fu<U> r;
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < L; ++i) {
         const int bit = i * B, w = bit >> 5, off = bit & 31;
         uint64_t x = w < NL ? sat[w] : 0u;
@@ -276,7 +276,7 @@ ZK_HD Fu<U> fu_unpack(const uint32_t *sat) {
 template <class U>
 ZK_HD void fu_pack(uint32_t *sat, const Fu<U> &a) {
     constexpr int L = U::L, B = U::B, NL = U::NL;
-#pragma unroll
+ZK_UNROLL
     for (int w = 0; w < NL; ++w) {
         const int bit = w * 32, i = bit / B, off = bit - i * B;
         uint64_t x = 0;
@@ -305,7 +305,7 @@ ZK_HD Fu<U> fu_load(const uint32_t *p) {
     constexpr int L = U::L, SL = U::SL;
     Fu<U> r;
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < SL / 4; ++i) {
         uint4 t = q[i];
         if (4 * i + 0 < L) r.v[4 * i + 0] = t.x;
@@ -319,7 +319,7 @@ template <class U>
 ZK_HD void fu_store(uint32_t *p, const Fu<U> &a) {
     constexpr int L = U::L, SL = U::SL;
     uint4 *q = reinterpret_cast<uint4 *>(p);
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < SL / 4; ++i) {
         uint4 t;
         t.x = 4 * i + 0 < L ? a.v[4 * i + 0] : 0u;
@@ -438,7 +438,7 @@ ZK_HD Fu<U> fu_inv(const Fu<U> &a) {
     constexpr int NL = U::NL;
     uint32_t e[NL];
     uint64_t br = 2;
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < NL; ++i) {
         uint64_t t = (uint64_t)U::sat::mod(i) - br;
         e[i] = (uint32_t)t;

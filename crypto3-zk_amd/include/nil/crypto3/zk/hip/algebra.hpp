@@ -187,12 +187,46 @@ struct group_value {
         return r;
     }
     group_value operator-(const group_value &o) const { return *this + (-o); }
-    /// scalar multiplication, double-and-add from the top bit (the handful of products at prover.hpp:142-155)
+    /// scalar multiplication (the handful of products at prover.hpp:142-155, two of them on a proof's critical path after the
+    /// device results arrive): width-5 signed windows -- 255 doublings + ~43 additions against P, 3P, ..., 15P
     group_value operator*(const fr_value<Curve> &k) const {
         group_value r;
-        for (int b = 255; b >= 0; --b) {
+        if (p.is_inf() || k.is_zero()) return r;
+        std::uint64_t e[5] = {k.limbs[0], k.limbs[1], k.limbs[2], k.limbs[3], 0};
+        signed char naf[260];
+        int len = 0;
+        while (e[0] | e[1] | e[2] | e[3] | e[4]) {
+            int d = 0;
+            if (e[0] & 1) {
+                d = (int)(e[0] & 31);
+                if (d >= 16) d -= 32;
+                if (d > 0) {    // e -= d: d is the low bits of e[0], no borrow
+                    e[0] -= (std::uint64_t)d;
+                } else {    // e += |d|
+                    std::uint64_t c = (std::uint64_t)(-d);
+                    for (int i = 0; i < 5 && c; ++i) {
+                        e[i] += c;
+                        c = e[i] < c ? 1 : 0;
+                    }
+                }
+            }
+            naf[len++] = (signed char)d;
+            for (int i = 0; i < 4; ++i) e[i] = (e[i] >> 1) | (e[i + 1] << 63);
+            e[4] >>= 1;
+        }
+        zkhip::XYZZ<F> odd[8];
+        odd[0] = p;
+        const zkhip::XYZZ<F> twice = zkhip::xyzz_dbl(p);
+        for (int i = 1; i < 8; ++i) odd[i] = zkhip::xyzz_add(odd[i - 1], twice);
+        for (int i = len - 1; i >= 0; --i) {
             r.p = zkhip::xyzz_dbl(r.p);
-            if ((k.limbs[b >> 6] >> (b & 63)) & 1) r.p = zkhip::xyzz_add(r.p, p);
+            const int d = naf[i];
+            if (d > 0) r.p = zkhip::xyzz_add(r.p, odd[(d - 1) >> 1]);
+            else if (d < 0) {
+                zkhip::XYZZ<F> m = odd[(-d - 1) >> 1];
+                if (!m.is_inf()) m.Y = O::template sub<O::K2>(F::zero(), m.Y);
+                r.p = zkhip::xyzz_add(r.p, m);
+            }
         }
         return r;
     }

@@ -18,6 +18,7 @@
 #define ZKHIP_SHIM_R1CS_GG_PPZKSNARK_HPP
 
 #include <algorithm>
+#include <chrono>
 #include <future>
 #include <memory>
 #include <stdexcept>
@@ -296,6 +297,8 @@ public:
     mutable std::shared_ptr<void> h_cpa;    // page-locked staging for (1, x, w): H2D at link speed, asynchronous
     /// second in-order stream on the same GPU for the G2 multiexp (its own workspace); false: everything on `ctx`
     bool overlap_g2 = true;
+    /// host wall time of the last proof's phases, ms: staging + launches | host products (device busy) | waiting for the device | assembly
+    mutable double last_phase_ms[4] = {0, 0, 0, 0};
     mutable std::unique_ptr<context> side;
     void reserve_work(std::size_t cpa_elems, std::size_t degree, std::size_t result_bytes) const {
         if (d_cpa && work_cpa_ >= cpa_elems) return;
@@ -390,10 +393,19 @@ public:
     static proof_type process(const proving_key_type &pk, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input,
                               const scalar_value_type &r, const scalar_value_type &s) {
         if (pk.shard.world != 1) throw std::runtime_error("process: sharded key -- use process_partial / finish (or the all-gather overload)");
+        typedef std::chrono::steady_clock clock;
+        const auto t0 = clock::now();
         enqueue(pk, primary_input, auxiliary_input);
+        const auto t1 = clock::now();
         /* host products that do not depend on the MSM results, computed while the GPU works (prover.hpp:142-155) */
         const host_terms t = host_products(pk, r, s);
-        return assemble(pk, collect(pk), 1, r, s, t);    // collect(): the one synchronisation of the proof
+        const auto t2 = clock::now();
+        const std::vector<std::uint64_t> sums = collect(pk);    // the one synchronisation of the proof
+        const auto t3 = clock::now();
+        proof_type proof = assemble(pk, sums, 1, r, s, t);
+        const clock::time_point marks[5] = {t0, t1, t2, t3, clock::now()};
+        for (int i = 0; i < 4; ++i) pk.last_phase_ms[i] = std::chrono::duration<double, std::milli>(marks[i + 1] - marks[i]).count();
+        return proof;
     }
 
     // ---- one proof sharded over several GPUs (one process per GPU) ---------------------------------------
@@ -431,13 +443,23 @@ public:
     }
 
 private:
+    /* What the proof needs besides the five multiexps (prover.hpp:141-155), regrouped so that everything that does not depend on
+       a device result is computed while the device works:
+           A = alpha + At + r delta                           B = beta + Bt + s delta     (G2; the G1 copy only feeds C)
+           C = Ht + Lt + s A + r B_g1 - r s delta
+             = Ht + Lt + s At + r Bt_h + [s alpha + r beta_g1 + r s delta]
+       -- the bracket and r delta, s delta_g2 are `host_terms`; s At and r Bt_h are the two products left for after the results
+       arrive (`assemble` runs them on two threads). */
     struct host_terms {
-        typename adapter::g1_value_type r_delta, s_delta, rs_delta;
+        typename adapter::g1_value_type r_delta, c_base;
         typename adapter::g2_value_type s_delta2;
     };
     static host_terms host_products(const proving_key_type &pk, const scalar_value_type &r, const scalar_value_type &s) {
         const auto &k = pk.host;
-        return {r * k.delta_g1, s * k.delta_g1, (r * s) * k.delta_g1, s * k.delta_g2};
+        auto g2 = std::async(std::launch::async, [&]() { return s * k.delta_g2; });
+        auto r_delta = r * k.delta_g1;
+        auto c_base = s * k.alpha_g1 + r * k.beta_g1 + s * r_delta;
+        return {r_delta, c_base, g2.get()};
     }
 
     /// enqueue the whole device side of a proof on the context's stream (no synchronisation)
@@ -534,13 +556,15 @@ private:
             evaluation_Bt_g = evaluation_Bt_g + adapter::g2_from_jacobian(&res[4 * jl1]);
         }
         const auto &k = pk.host;
+        /* the two products that need a device result, side by side */
+        auto s_At = std::async(std::launch::async, [&]() { return s * evaluation_At; });
+        const auto r_Bt_h = r * evaluation_Bt_h;
         /* A = alpha + sum_i(a_i*A_i(t)) + r*delta */
         auto g1_A = k.alpha_g1 + evaluation_At + t.r_delta;
         /* B = beta + sum_i(a_i*B_i(t)) + s*delta */
-        auto g1_B = k.beta_g1 + evaluation_Bt_h + t.s_delta;
         auto g2_B = k.beta_g2 + evaluation_Bt_g + t.s_delta2;
-        /* C = sum_i(a_i*((beta*A_i(t) + alpha*B_i(t) + C_i(t)) + H(t)*Z(t))/delta) + A*s + r*b - r*s*delta */
-        auto g1_C = evaluation_Ht + evaluation_Lt + s * g1_A + r * g1_B - t.rs_delta;
+        /* C = sum_i(a_i*((beta*A_i(t) + alpha*B_i(t) + C_i(t)) + H(t)*Z(t))/delta) + A*s + r*b - r*s*delta  (regrouped: host_terms) */
+        auto g1_C = evaluation_Ht + evaluation_Lt + s_At.get() + r_Bt_h + t.c_base;
         return proof_type {g1_A, g2_B, g1_C};
     }
 
