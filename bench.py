@@ -267,6 +267,9 @@ def main():
         if traffic is not None:
             line["roofline"]["traffic"] = traffic["msm_bucket_acc"]
             line["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run (2 x FETCH_SIZE + WRITE_SIZE, KiB -> B)"
+            if traffic.get("valu", {}).get("msm_bucket_acc"):
+                line["roofline"]["valu"] = dict(traffic["valu"]["msm_bucket_acc"], bound="VALU issue: 4 cycles per wave instruction on 1024 SIMDs",
+                                                source="SQ_INSTS_VALU, GRBM_GUI_ACTIVE / 8 of a third child pass")
         else:
             line["roofline"]["traffic_source"] = "not collected in this run (rocprofv3 unavailable, --no-pmc, or N > 1); see profiles/ for the offline passes"
         if world == 1 and not args.no_ntt:
@@ -316,10 +319,13 @@ def dry_run(args):
 
 
 def pmc_traffic_live(log_n):
-    """HBM bytes per launch of the dominant kernels, measured in THIS run: two child passes of tools/pmc_child.py (the same
-    MSM and NTT workloads) under `rocprofv3 --pmc`, FETCH_SIZE and WRITE_SIZE in passes of their own (they do not fit one
-    pass: MI355X_MICROARCH.md), counters only.  gfx950 reports half the bytes of 16-B-per-lane reads: 2 x FETCH_SIZE
-    (KiB) + WRITE_SIZE (KiB).  None when rocprofv3 is absent or a pass fails (bounded by a timeout)."""
+    """HBM bytes per launch of the dominant kernels -- and how busy their SIMDs are --, measured in THIS run: child passes of
+    tools/pmc_child.py (the same MSM and NTT workloads) under `rocprofv3 --pmc`, FETCH_SIZE and WRITE_SIZE in passes of their
+    own (they do not fit one pass: MI355X_MICROARCH.md), counters only.  gfx950 reports half the bytes of 16-B-per-lane reads:
+    2 x FETCH_SIZE (KiB) + WRITE_SIZE (KiB).  A third pass reads SQ_INSTS_VALU and GRBM_GUI_ACTIVE: a 64-lane wave instruction
+    occupies its 16-lane SIMD for 4 cycles, so insts x 4 / 1024 SIMDs over the GPU cycles of the launch (GRBM_GUI_ACTIVE / 8
+    XCDs) is the fraction of the VALU issue capacity in use -- the bound these integer kernels actually sit on.
+    {kernel: bytes, "valu": {kernel: {...}}}; None when rocprofv3 is absent or a traffic pass fails (bounded by a timeout)."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
@@ -327,30 +333,40 @@ def pmc_traffic_live(log_n):
     tmp = tempfile.mkdtemp(prefix="zkhip_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "-d", out, "-o", "pmc", "--output-format", "csv", "--", sys.executable,
-                   os.path.join(ROOT, "tools", "pmc_child.py"), str(log_n)]
+        for group in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE")):
+            out = os.path.join(tmp, group[0])
+            cmd = [exe, "--pmc"] + list(group) + ["-d", out, "-o", "pmc", "--output-format", "csv", "--", sys.executable,
+                                                  os.path.join(ROOT, "tools", "pmc_child.py"), str(log_n)]
             try:
                 subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
             except Exception:
-                return None
+                if len(group) == 1:
+                    return None
+                continue  # the issue-rate pass is an extra: the traffic figures stand without it
             acc = {}
             for path in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
                 for row in csv.DictReader(open(path)):
-                    if row["Counter_Name"] != counter:
+                    if row["Counter_Name"] not in group:
                         continue
                     name = row["Kernel_Name"]
                     key = "msm_bucket_acc" if "msm_bucket_acc" in name else ("ntt_pass" if "ntt_pass" in name else None)
                     if key:
-                        a = acc.setdefault(key, [0.0, set()])
+                        a = acc.setdefault((key, row["Counter_Name"]), [0.0, set()])
                         a[0] += float(row["Counter_Value"])
                         a[1].add(row["Dispatch_Id"])
-            if "msm_bucket_acc" not in acc:
+            if len(group) == 1 and ("msm_bucket_acc", group[0]) not in acc:
                 return None
-            for key, (tot, ids) in acc.items():
+            for (key, counter), (tot, ids) in acc.items():
                 sums.setdefault(key, {})[counter] = tot / max(1, len(ids))
-        return {k: int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024) for k, v in sums.items() if len(v) == 2}
+        res = {k: int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024) for k, v in sums.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
+        valu = {}
+        for k, v in sums.items():
+            if v.get("SQ_INSTS_VALU") and v.get("GRBM_GUI_ACTIVE"):
+                cycles = v["GRBM_GUI_ACTIVE"] / 8  # summed over the 8 XCDs
+                valu[k] = {"wave_insts_per_launch": int(v["SQ_INSTS_VALU"]), "gpu_cycles_per_launch": int(cycles),
+                           "issue_frac": round(v["SQ_INSTS_VALU"] * 4 / 1024 / cycles, 4)}
+        res["valu"] = valu
+        return res
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -381,25 +397,31 @@ def ntt_leg(np, zk, ctx, log_m=22, batch=8, steps=5, verify=True, traffic=None):
     else:
         ctx.ntt_dev(zk.BLS12_381, d, log_m, batch, omega)  # warm-up: builds the twiddle tables
     ctx.sync()
-    ctx.profile_reset()
-    ctx.profile(True)
     t0 = time.perf_counter()
     for _ in range(steps):
         ctx.ntt_dev(zk.BLS12_381, d, log_m, batch, omega)
     ctx.sync()
-    dt = (time.perf_counter() - t0) / steps
+    dt = (time.perf_counter() - t0) / steps  # `value`: a plain loop; the per-launch HIP events come from a second one
+    ctx.profile_reset()
+    ctx.profile(True)
+    for _ in range(steps):
+        ctx.ntt_dev(zk.BLS12_381, d, log_m, batch, omega)
+    ctx.sync()
     ctx.profile(False)
     k_ms, k_cnt = ctx.profile_get("ntt_pass")
     ctx.free(d)
     alg = batch * m * 64  # one read + one write of every element per transform
     achieved = alg / (k_ms / steps * 1e-3) / 1e9
     passes = k_cnt // steps
-    return {"metric": "NTT elements/sec, BLS12-381 Fr, 2^%d x %d" % (log_m, batch), "value": round(batch * m / dt / 1e6, 2), "unit": "Melements/s",
-            "ms_per_transform_batch": round(dt * 1e3, 4), "verified": verified,
-            "roofline": {"bound": "hbm", "kernel": "ntt_pass (x%d per transform)" % passes, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic["ntt_pass"] * passes if traffic and "ntt_pass" in traffic else None,  # per transform batch, like `achieved`
-                         "algorithmic_bytes_per_transform_batch": alg}}
+    leg = {"metric": "NTT elements/sec, BLS12-381 Fr, 2^%d x %d" % (log_m, batch), "value": round(batch * m / dt / 1e6, 2), "unit": "Melements/s",
+           "ms_per_transform_batch": round(dt * 1e3, 4), "verified": verified,
+           "roofline": {"bound": "hbm", "kernel": "ntt_pass (x%d per transform)" % passes, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                        "traffic": traffic["ntt_pass"] * passes if traffic and "ntt_pass" in traffic else None,  # per transform batch, like `achieved`
+                        "algorithmic_bytes_per_transform_batch": alg}}
+    if traffic and traffic.get("valu", {}).get("ntt_pass"):
+        leg["roofline"]["valu"] = traffic["valu"]["ntt_pass"]  # per pass
+    return leg
 
 
 def _bench_lib():
