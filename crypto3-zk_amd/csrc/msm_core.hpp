@@ -609,17 +609,19 @@ __global__ __launch_bounds__(MSM_TAIL_THREADS, 2) void msm_bucket_red(const uint
     if (t == 0) xyzz_store<F>(partial + (size_t)blockIdx.x * (4 * NL), sum);
 }
 
-// one 64-lane workgroup per set: winsum[s] = sum_j partial[s][j]
+// one workgroup (64 or 256 lanes: msm_window_threads) per set: winsum[s] = sum_j partial[s][j]
 template <class F, int LPB>
-__global__ __launch_bounds__(64) void msm_window_sum(const uint32_t *__restrict__ partial, uint32_t nblk, uint32_t *__restrict__ winsum) {
+__global__ __launch_bounds__(256) void msm_window_sum(const uint32_t *__restrict__ partial, uint32_t nblk, uint32_t *__restrict__ winsum) {
     constexpr int NL = FieldOps<F>::WORDS;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t w = blockIdx.x, t = threadIdx.x / LPB;
+    const uint32_t w = blockIdx.x, t = threadIdx.x / LPB, slots = blockDim.x / LPB;
     XYZZ<F> acc = XYZZ<F>::infinity();
-    for (uint32_t j = t; j < nblk; j += 64 / LPB) acc = xyzz_add(acc, xyzz_load<F>(partial + ((size_t)w * nblk + j) * (4 * NL)));
-    if (nblk > 1) acc = block_tree_sum<F>(lds, acc, t, 64 / LPB);
+    for (uint32_t j = t; j < nblk; j += slots) acc = xyzz_add(acc, xyzz_load<F>(partial + ((size_t)w * nblk + j) * (4 * NL)));
+    if (nblk > 1) acc = block_tree_sum<F>(lds, acc, t, slots);
     if (t == 0) xyzz_store<F>(winsum + (size_t)w * (4 * NL), acc);
 }
+// every operation is ~10 us of one wave: a tree level more (256 lanes) is cheaper than three more serial additions per lane
+inline uint32_t msm_window_threads(uint32_t nblk, int lanes_per_point) { return (size_t)nblk * lanes_per_point > 128 ? 256u : 64u; }
 
 // result = sum_w 2^off(w) winsum[w]  (Horner from the top window; a single set with tables), emitted as canonical Jacobian
 template <class F, int LPB>
@@ -1012,7 +1014,8 @@ int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
     ZK_TRY(msm_tail_attr<F>(ctx));
     ZK_LAUNCH(ctx, "msm_bucket_red", (msm_bucket_red<TL, TLPB>), dim3((unsigned)Sr * nblk_tail), dim3(MSM_TAIL_THREADS), (size_t)tail_slots * 4 * NL * 4, buckets, B,
               L, nseg, nblk_tail, segsum);
-    ZK_LAUNCH(ctx, "msm_window_sum", (msm_window_sum<TL, TLPB>), dim3(Sr), dim3(64), (size_t)64 / TLPB * 4 * NL * 4, segsum, nblk_tail, winsum);
+    const uint32_t wthreads = msm_window_threads(nblk_tail, TLPB);
+    ZK_LAUNCH(ctx, "msm_window_sum", (msm_window_sum<TL, TLPB>), dim3(Sr), dim3(wthreads), (size_t)wthreads / TLPB * 4 * NL * 4, segsum, nblk_tail, winsum);
     ZK_LAUNCH(ctx, "msm_final", (msm_final<TL, TLPB>), dim3(1), dim3(64), 0, winsum, Sr, P.win, d_out_jac);
     return 0;
 }
@@ -1090,7 +1093,8 @@ int msm_batch_tail(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases
     ZK_MAX_LDS(ctx, (msm_bucket_red<TL, TLPB>), MSM_TAIL_THREADS / TLPB * 4 * NL * 4);
     ZK_LAUNCH(ctx, "msm_bucket_red", (msm_bucket_red<TL, TLPB>), dim3((unsigned)count * nblk_tail), dim3(MSM_TAIL_THREADS), (size_t)tail_slots * 4 * NL * 4, slots,
               B, L, nseg, nblk_tail, segsum);
-    ZK_LAUNCH(ctx, "msm_window_sum", (msm_window_sum<TL, TLPB>), dim3((unsigned)count), dim3(64), (size_t)64 / TLPB * 4 * NL * 4, segsum, nblk_tail, winsum);
+    const uint32_t wthreads = msm_window_threads(nblk_tail, TLPB);
+    ZK_LAUNCH(ctx, "msm_window_sum", (msm_window_sum<TL, TLPB>), dim3((unsigned)count), dim3(wthreads), (size_t)wthreads / TLPB * 4 * NL * 4, segsum, nblk_tail, winsum);
     ZK_LAUNCH(ctx, "msm_final", (msm_final_batch<TL, TLPB>), dim3((unsigned)count), dim3(64), 0, winsum, (uint32_t)count, d_ptrs);
     return 0;
 }
