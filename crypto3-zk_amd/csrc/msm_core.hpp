@@ -585,7 +585,10 @@ ZK_D XYZZ<F> block_tree_sum(uint32_t *lds, XYZZ<F> acc, uint32_t t, uint32_t nth
 
 // grid = sets x nblk workgroups; partial[s * nblk + j] = weighted sum of segments [SLOTS j, SLOTS j + SLOTS) of set s
 template <class F, int LPB>
-__global__ __launch_bounds__(MSM_TAIL_THREADS, 2) void msm_bucket_red(const uint32_t *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t nseg,
+#ifndef ZK_TAIL_OCC
+#define ZK_TAIL_OCC 2
+#endif
+__global__ __launch_bounds__(MSM_TAIL_THREADS, ZK_TAIL_OCC) void msm_bucket_red(const uint32_t *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t nseg,
                                                                    uint32_t nblk, uint32_t *__restrict__ partial) {
     constexpr int NL = FieldOps<F>::WORDS;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
