@@ -583,12 +583,12 @@ ZK_D XYZZ<F> block_tree_sum(uint32_t *lds, XYZZ<F> acc, uint32_t t, uint32_t nth
     return acc;  // lane 0: the sum
 }
 
-// grid = sets x nblk workgroups; partial[s * nblk + j] = weighted sum of segments [SLOTS j, SLOTS j + SLOTS) of set s
+// grid = sets x nblk workgroups; partial[s * nblk + j] = weighted sum of segments [SLOTS j, SLOTS j + SLOTS) of set s.
+// Two waves per SIMD: the G1 kernels then spill (pairs 154 registers, one lane 765); bound 1 has no spills (330 / 446 VGPRs) and
+// measures the same for a single MSM (0.699 against 0.716 ms at 2^19 buckets) but worse for batches, whose many waves want
+// the second slot (50 x 2^19 buckets: 17.4 against 13.7 ms).
 template <class F, int LPB>
-#ifndef ZK_TAIL_OCC
-#define ZK_TAIL_OCC 2
-#endif
-__global__ __launch_bounds__(MSM_TAIL_THREADS, ZK_TAIL_OCC) void msm_bucket_red(const uint32_t *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t nseg,
+__global__ __launch_bounds__(MSM_TAIL_THREADS, 2) void msm_bucket_red(const uint32_t *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t nseg,
                                                                    uint32_t nblk, uint32_t *__restrict__ partial) {
     constexpr int NL = FieldOps<F>::WORDS;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
