@@ -36,11 +36,11 @@ def test_bench_under_external_launcher():
 @pytest.mark.gpu
 def test_bench_rccl_path_on_one_gpu():
     """The N > 1 code path with the real backend, as far as one GPU can take it: torch.distributed.run starts one rank, --force-dist
-    makes it initialise RCCL, all-gather + fold the 144-byte partial sums every step and run the sharded Groth16 proof (864-byte
-    all-gather) at world = 1.  stdout must carry exactly one JSON line, every leg verified."""
+    makes it initialise RCCL, all-gather + fold the 144-byte partial sums every step, run the sharded Groth16 proof (864-byte
+    all-gather) and the KZG commit with its columns dealt over the ranks (all-gather of the commitments) at world = 1.  stdout must carry exactly one JSON line, every leg verified."""
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                           "--master-port", "29619", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--force-dist",
-                          "--no-kzg", "--no-ntt", "--no-pmc", "--no-cpu-baseline"],
+                          "--no-ntt", "--no-pmc", "--no-cpu-baseline"],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -48,4 +48,5 @@ def test_bench_rccl_path_on_one_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["verified"] is True and line["scaling"] == "weak"
     assert line["groth16_sharded"]["verified"] is True and line["groth16"]["verified"] is True
+    assert line["kzg_sharded"]["verified"] is True and line["kzg"]["verified"] is True
     assert line["roofline"]["bound"] == "hbm" and line["roofline"]["achieved"] > 0

@@ -88,3 +88,22 @@ def test_point_range_sharding_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(0, True), (1, True)]
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8, 64])
+def test_column_deal_and_gathered_layout(world):
+    """bench.py's kzg_sharded leg: column c of a batch lives on rank c % world in slot c // world of that rank's padded block of
+    the all-gathered commitments; every column is owned exactly once and no rank holds more than ceil(cols / world)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conftest
+
+    conftest.load_pkg()
+    from crypto3_zk_amd import dist as zd
+
+    cols = 50
+    slots = (cols + world - 1) // world
+    owned = [zd.shard_polys(cols, g, world) for g in range(world)]
+    assert sorted(sum(owned, [])) == list(range(cols))
+    assert max(len(o) for o in owned) <= slots
+    for c in range(cols):
+        assert owned[c % world][c // world] == c
