@@ -11,6 +11,11 @@ python3 bench.py > gpurun_out/${R}_bench_final.json 2> gpurun_out/${R}_bench_fin
 # kernel trace + stats of the MSM / NTT legs of the same command
 rm -rf /tmp/rp && ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rp -o msm --output-format csv -- python3 "$root/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-groth16 --no-kzg --no-pmc --no-verify > /tmp/rp.log 2>&1 )
 cp $(find /tmp/rp -name '*kernel_stats.csv' | head -1) gpurun_out/${R}_rocprofv3_kernel_stats_msm_bench.csv 2>/dev/null
+# the same for a whole Groth16 proof (both streams) and the 50-column KZG commit
+rm -rf /tmp/rp2 && ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rp2 -o g16 --output-format csv -- python3 "$root/tools/bench_groth16.py" --steps 4 > /tmp/rp2.log 2>&1 )
+cp $(find /tmp/rp2 -name '*kernel_stats.csv' | head -1) gpurun_out/${R}_rocprofv3_kernel_stats_groth16.csv 2>/dev/null
+rm -rf /tmp/rp3 && ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rp3 -o kzg --output-format csv -- python3 "$root/tools/bench_kzg.py" > /tmp/rp3.log 2>&1 )
+cp $(find /tmp/rp3 -name '*kernel_stats.csv' | head -1) gpurun_out/${R}_rocprofv3_kernel_stats_kzg.csv 2>/dev/null
 # PMC: one counter group per pass (FETCH_SIZE / WRITE_SIZE in passes of their own), over the MSM + NTT workload of tools/pmc_child.py
 tools/pmc_collect.sh gpurun_out/${R}_pmc_msm_ntt.json tools/pmc_child.py 20 > /dev/null 2>&1
 PMC_GROUPS="GRBM_GUI_ACTIVE;SQ_BUSY_CYCLES SQ_WAVES" tools/pmc_collect.sh gpurun_out/${R}_pmc_clock.json tools/pmc_child.py 20 > /dev/null 2>&1
