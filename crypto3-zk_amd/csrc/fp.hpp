@@ -21,31 +21,31 @@ struct Fp {
 
     ZK_HD static Fp zero() {
         Fp r;
-#pragma unroll
+ZK_UNROLL
         for (int i = 0; i < NL; ++i) r.v[i] = 0;
         return r;
     }
     ZK_HD static Fp one() {  // Montgomery form of 1
         Fp r;
-#pragma unroll
+ZK_UNROLL
         for (int i = 0; i < NL; ++i) r.v[i] = P::r1(i);
         return r;
     }
     ZK_HD static Fp r2() {
         Fp r;
-#pragma unroll
+ZK_UNROLL
         for (int i = 0; i < NL; ++i) r.v[i] = P::r2(i);
         return r;
     }
     ZK_HD bool is_zero() const {
         uint32_t o = 0;
-#pragma unroll
+ZK_UNROLL
         for (int i = 0; i < NL; ++i) o |= v[i];
         return o == 0;
     }
     ZK_HD bool operator==(const Fp &b) const {
         uint32_t o = 0;
-#pragma unroll
+ZK_UNROLL
         for (int i = 0; i < NL; ++i) o |= v[i] ^ b.v[i];
         return o == 0;
     }
@@ -58,14 +58,14 @@ ZK_HD void fp_reduce_once(Fp<P> &a) {
     constexpr int NL = P::NL;
     uint32_t d[NL];
     uint64_t br = 0;
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < NL; ++i) {
         uint64_t t = (uint64_t)a.v[i] - P::mod(i) - br;
         d[i] = (uint32_t)t;
         br = (t >> 32) & 1;
     }
     bool keep = br != 0;  // a < p
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < NL; ++i) a.v[i] = keep ? a.v[i] : d[i];
 }
 
@@ -74,7 +74,7 @@ ZK_HD Fp<P> operator+(const Fp<P> &a, const Fp<P> &b) {
     constexpr int NL = P::NL;
     Fp<P> r;
     uint64_t c = 0;
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < NL; ++i) {
         c += (uint64_t)a.v[i] + b.v[i];
         r.v[i] = (uint32_t)c;
@@ -90,7 +90,7 @@ ZK_HD Fp<P> operator-(const Fp<P> &a, const Fp<P> &b) {
     constexpr int NL = P::NL;
     Fp<P> r;
     uint64_t br = 0;
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < NL; ++i) {
         uint64_t t = (uint64_t)a.v[i] - b.v[i] - br;
         r.v[i] = (uint32_t)t;
@@ -98,7 +98,7 @@ ZK_HD Fp<P> operator-(const Fp<P> &a, const Fp<P> &b) {
     }
     uint32_t mask = (uint32_t)0 - (uint32_t)br;  // all ones when a < b
     uint64_t c = 0;
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < NL; ++i) {
         c += (uint64_t)r.v[i] + (P::mod(i) & mask);
         r.v[i] = (uint32_t)c;
@@ -122,16 +122,16 @@ template <class P>
 ZK_HD Fp<P> fp_mul_inline(const Fp<P> &a, const Fp<P> &b) {
     constexpr int NL = P::NL;
     uint32_t t[NL];
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < NL; ++i) t[i] = 0;
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < NL; ++i) {
         uint64_t A = (uint64_t)a.v[0] * b.v[i] + t[0];
         uint32_t m = (uint32_t)A * P::INV;
         uint64_t C = (uint64_t)m * P::mod(0) + (uint32_t)A;
         A >>= 32;
         C >>= 32;
-#pragma unroll
+ZK_UNROLL
         for (int j = 1; j < NL; ++j) {
             A += (uint64_t)a.v[j] * b.v[i] + t[j];
             C += (uint64_t)m * P::mod(j) + (uint32_t)A;
@@ -142,7 +142,7 @@ ZK_HD Fp<P> fp_mul_inline(const Fp<P> &a, const Fp<P> &b) {
         t[NL - 1] = (uint32_t)(A + C);
     }
     Fp<P> r;
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < NL; ++i) r.v[i] = t[i];
     fp_reduce_once(r);
     return r;
@@ -203,7 +203,7 @@ ZK_HD Fp<P> fp_inv(const Fp<P> &a) {
     // exponent e = p - 2, limb-wise with borrow
     uint32_t e[NL];
     uint64_t br = 2;
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < NL; ++i) {
         uint64_t t = (uint64_t)P::mod(i) - br;
         e[i] = (uint32_t)t;
@@ -224,7 +224,7 @@ ZK_HD Fp<P> fp_load(const uint32_t *p) {
     static_assert(NL % 4 == 0, "limb count must be a multiple of 4 for dwordx4 access");
     Fp<P> r;
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < NL / 4; ++i) {
         uint4 t = q[i];
         r.v[4 * i + 0] = t.x;
@@ -238,7 +238,7 @@ template <class P>
 ZK_HD void fp_store(uint32_t *p, const Fp<P> &a) {
     constexpr int NL = P::NL;
     uint4 *q = reinterpret_cast<uint4 *>(p);
-#pragma unroll
+ZK_UNROLL
     for (int i = 0; i < NL / 4; ++i) q[i] = make_uint4(a.v[4 * i], a.v[4 * i + 1], a.v[4 * i + 2], a.v[4 * i + 3]);
 }
 

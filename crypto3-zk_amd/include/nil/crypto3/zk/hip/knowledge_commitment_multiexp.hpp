@@ -26,7 +26,7 @@ template <typename CurveType>
 class device_kc_vector {
 public:
     typedef curve_adapter<CurveType> adapter;
-    device_kc_vector(const context &ctx, const knowledge_commitment_vector<CurveType> &vec) : ctx_(&ctx), indices(vec.indices), domain_size_(vec.domain_size_) {
+    device_kc_vector(const context &ctx, const knowledge_commitment_vector<CurveType> &vec) : indices(vec.indices), domain_size_(vec.domain_size_), ctx_(&ctx) {
         std::vector<typename adapter::g2_value_type> g;
         std::vector<typename adapter::g1_value_type> h;
         std::vector<std::uint32_t> idx;

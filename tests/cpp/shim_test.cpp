@@ -210,7 +210,6 @@ template <typename Curve>
 int kzg_commit_t(const uint64_t *srs, size_t n, const uint64_t *evals, size_t log_n, size_t batch, const uint64_t *omega, uint64_t *out, uint8_t *out_inf) {
     typedef curve_adapter<Curve> A;
     typedef typename A::g1_value_type G1;
-    typedef typename A::scalar_value_type Fr;
     const size_t L1 = 2 * A::g1_coord_limbs;
     context ctx(0);
     std::vector<G1> ck;
@@ -241,7 +240,6 @@ int kzg_v2_t(const uint64_t *srs, size_t n_srs, size_t npolys, const uint64_t *b
              uint64_t *zvals, uint64_t *pi, uint64_t *absorbed) {
     typedef curve_adapter<Curve> A;
     typedef typename A::g1_value_type G1;
-    typedef typename A::scalar_value_type Fr;
     const size_t L1 = 2 * A::g1_coord_limbs;
     context ctx(0);
     std::vector<G1> ck;
