@@ -1,4 +1,5 @@
-"""Per-kernel HIP-event times of one MSM configuration: python tools/msm_profile.py LOG_N C S [G1|G2] [SEGLOG]"""
+"""Per-kernel HIP-event times of one MSM configuration: python tools/msm_profile.py LOG_N C S [G1|G2] [SEGLOG]
+(ZK_SORT_TILE_LOG=12|14 in the environment picks the sort tile shape: 12 is what contexts that share the GPU use)"""
 import os
 import sys
 
@@ -15,6 +16,8 @@ if len(sys.argv) > 5:
     ctx.set_option("msm_segment_log", int(sys.argv[5]))
 n = 1 << log_n
 ctx.set_option("msm_window_bits", c)
+if "ZK_SORT_TILE_LOG" in os.environ:
+    ctx.set_option("msm_sort_tile_log", int(os.environ["ZK_SORT_TILE_LOG"]))
 ctx.set_option("msm_sets", S)
 b = ctx.bases_from_scalars(zk.BLS12_381, group, bench.random_scalars(np, n, 1))
 sc = bench.random_scalars(np, n, 2)
