@@ -59,6 +59,17 @@ def test_host_group_operators(shim, curve):
     assert shim.shim_host_group(curve, P(pt_limbs(curve, 1, Pt)), P(pt_limbs(curve, 1, Qt)), P(limbs(k, 4)), P(o_sum), P(o_mul)) == 0
     assert pt_from_limbs(curve, 1, o_sum) == G.add(Pt, Qt)
     assert pt_from_limbs(curve, 1, o_mul) == G.mul(Pt, k)
+    # the width-5 signed-window multiplication at its edges: 0, 1, digit boundaries (15, 16, 17, 31, 32), runs of ones that carry
+    # through every limb, the largest canonical scalar and 2^255 - 1 (not canonical, still a 256-bit integer the operator accepts)
+    edge = [0, 1, 15, 16, 17, 31, 32, 33, (1 << 64) - 1, (1 << 64), (1 << 128) - 1, (1 << 192) + 16, C.r - 1, C.r - 16, (1 << 254) + (1 << 253) - 1,
+            (1 << 255) - 1, 0x5555555555555555555555555555555555555555555555555555555555555555 % C.r, 0x0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F]
+    for e in edge:
+        assert shim.shim_host_group(curve, P(pt_limbs(curve, 1, Pt)), P(pt_limbs(curve, 1, Qt)), P(limbs(e, 4)), P(o_sum), P(o_mul)) == 0
+        want = G.mul(Pt, e % G.order) if hasattr(G, "order") else G.mul(Pt, e)
+        if want is None:  # the point at infinity leaves the shim as zeroed limbs
+            assert not o_mul.any(), hex(e)
+        else:
+            assert pt_from_limbs(curve, 1, o_mul) == want, hex(e)
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
