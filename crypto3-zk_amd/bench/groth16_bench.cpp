@@ -35,6 +35,9 @@ struct SplitMix {
 // slice of every query, runs the replicated witness map and its five partial MSMs, and `all_gather` (supplied by the
 // caller: RCCL through torch.distributed in bench.py) exchanges the 864-byte partial sums.
 typedef void (*all_gather_fn)(const uint64_t *mine, size_t words, uint64_t *all);
+// called between key generation and the timed proofs (tools/groth16_two_provers.py lines its threads up there)
+typedef void (*after_setup_fn)();
+after_setup_fn g_after_setup = nullptr;
 
 template <typename Curve>
 int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gather, size_t M, size_t n, uint64_t seed, int steps, const uint64_t *omega,
@@ -102,6 +105,7 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
     if (const char *e = getenv("ZKHIP_G16_OVERLAP")) dpk.overlap_g2 = atoi(e) != 0;    // experiments: G2 multiexp on the main stream
     ctx.sync();
     *setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (g_after_setup) g_after_setup();
     Fr r = rnd(), s = rnd();
     typedef r1cs_gg_ppzksnark_prover_hip<Curve> prover;
     typename prover::proof_type proof;
@@ -129,6 +133,8 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
 }    // namespace
 
 extern "C" {
+
+void zkhip_bench_set_after_setup(void (*fn)()) { g_after_setup = fn; }
 
 int zkhip_bench_groth16(int device, int curve, size_t M, size_t n, uint64_t seed, int steps, const uint64_t *omega, const uint64_t *coset, double *times,
                         double *setup_ms, int *verified, char *prof, size_t prof_cap) {
