@@ -16,6 +16,8 @@ if len(sys.argv) > 5:
     ctx.set_option("msm_segment_log", int(sys.argv[5]))
 n = 1 << log_n
 ctx.set_option("msm_window_bits", c)
+if "ZK_TAIL_SPLIT" in os.environ:
+    ctx.set_option("msm_tail_split", int(os.environ["ZK_TAIL_SPLIT"]))
 if "ZK_SORT_TILE_LOG" in os.environ:
     ctx.set_option("msm_sort_tile_log", int(os.environ["ZK_SORT_TILE_LOG"]))
 ctx.set_option("msm_sets", S)
@@ -36,4 +38,11 @@ ctx.sync()
 ctx.profile(False)
 p = ctx.profile_dump()
 tot = sum(v[0] for v in p.values()) / reps
-print("log_n %d c %d S %d: %.3f ms kernels |" % (log_n, c, S, tot), " ".join("%s %.3f" % (k.replace("msm_", ""), v[0] / reps) for k, v in sorted(p.items())))
+ctx.sync()
+import time
+t0 = time.perf_counter()
+for _ in range(20):
+    ctx.msm_dev(b, d_s, d_o)
+ctx.sync()
+wall = (time.perf_counter() - t0) / 20 * 1e3
+print("log_n %d c %d S %d: %.3f ms wall, %.3f ms kernels |" % (log_n, c, S, wall, tot), " ".join("%s %.3f" % (k.replace("msm_", ""), v[0] / reps) for k, v in sorted(p.items())))
