@@ -2,6 +2,7 @@
 (ZK_SORT_TILE_LOG=12|14 in the environment picks the sort tile shape: 12 is what contexts that share the GPU use)"""
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -16,8 +17,6 @@ if len(sys.argv) > 5:
     ctx.set_option("msm_segment_log", int(sys.argv[5]))
 n = 1 << log_n
 ctx.set_option("msm_window_bits", c)
-if "ZK_TAIL_SPLIT" in os.environ:
-    ctx.set_option("msm_tail_split", int(os.environ["ZK_TAIL_SPLIT"]))
 if "ZK_SORT_TILE_LOG" in os.environ:
     ctx.set_option("msm_sort_tile_log", int(os.environ["ZK_SORT_TILE_LOG"]))
 ctx.set_option("msm_sets", S)
@@ -39,7 +38,6 @@ ctx.profile(False)
 p = ctx.profile_dump()
 tot = sum(v[0] for v in p.values()) / reps
 ctx.sync()
-import time
 t0 = time.perf_counter()
 for _ in range(20):
     ctx.msm_dev(b, d_s, d_o)
