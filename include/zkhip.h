@@ -109,7 +109,9 @@ void zkhip_bases_free(zkhip_ctx *ctx, zkhip_bases *b);
  * Replaces algebra::multiexp<multiexp_method_BDLO12>(b0, b1, s0, s1, chunks) and
  * multiexp_with_mixed_addition (prover.hpp:108-139, kzg.hpp:143-148,409-435,505-508,
  * knowledge_commitment_multiexp.hpp:107).  `chunks` has no counterpart: the device splits the work itself.
- * out_jacobian: 3 * (coordinate limbs) u64. */
+ * out_jacobian: 3 * (coordinate limbs) u64, canonical X | Y | Z of the group element; WHICH projective representative comes out is
+ * not fixed (the order of additions inside a bucket follows the sort's atomics): compare points after zkhip_jacobian_to_affine,
+ * as the reference's own operator== normalises before comparing. */
 int zkhip_msm(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint64_t *scalars /* host, n x 4 */,
               uint64_t *out_jacobian /* host */);
 /* Same, scalars and result resident in device memory; asynchronous on the context's stream. */
