@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 R=r02
 python3 bench.py > gpurun_out/${R}_bench_final.json 2> gpurun_out/${R}_bench_final.err
 # kernel trace + stats of the MSM / NTT legs of the same command
-rm -rf /tmp/rp && ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rp -o msm --output-format csv -- python3 "$root/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-groth16 --no-kzg --no-pmc --no-verify > /tmp/rp.log 2>&1 )
+rm -rf /tmp/rp && ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rp -o msm --output-format csv -- python3 "$root/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-groth16 --no-kzg --no-pmc --no-verify --no-two-in-flight > /tmp/rp.log 2>&1 )
 cp $(find /tmp/rp -name '*kernel_stats.csv' | head -1) gpurun_out/${R}_rocprofv3_kernel_stats_msm_bench.csv 2>/dev/null
 # the same for a whole Groth16 proof (both streams) and the 50-column KZG commit
 rm -rf /tmp/rp2 && ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rp2 -o g16 --output-format csv -- python3 "$root/tools/bench_groth16.py" --steps 4 > /tmp/rp2.log 2>&1 )
