@@ -261,6 +261,8 @@ struct curve_adapter<native_curve<Curve>> {
     static constexpr std::size_t g1_coord_limbs = g1_value_type::coord_limbs;
     static constexpr std::size_t g2_coord_limbs = g2_value_type::coord_limbs;
 
+    /// fr_value IS four canonical little-endian u64 limbs: bulk uploads send the caller's vectors as they lie (backend.hpp, upload_scalars)
+    static constexpr bool scalars_are_canonical_limbs = true;
     static void scalar_to_limbs(const scalar_value_type &s, std::uint64_t *out) { std::memcpy(out, s.limbs.data(), 32); }
     static scalar_value_type scalar_from_limbs(const std::uint64_t *in) {
         scalar_value_type s;

@@ -7,11 +7,15 @@
 #ifndef ZKHIP_SHIM_BACKEND_HPP
 #define ZKHIP_SHIM_BACKEND_HPP
 
+#include <algorithm>
 #include <cerrno>
 #include <cstdint>
+#include <future>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <type_traits>
 #include <vector>
 
 #include <sys/random.h>
@@ -76,6 +80,43 @@ public:
 private:
     zkhip_ctx *ctx_ = nullptr;
 };
+
+/// `count` scalar-field values -> canonical limbs in device memory at d_dst (32 bytes each).
+/// A curve adapter whose scalar type IS four canonical little-endian u64 limbs says so (`scalars_are_canonical_limbs`): the
+/// values then go out as they lie in the caller's vector, one copy at link speed.  Any other representation (crypto3-algebra's
+/// Montgomery form) is converted slice by slice on a few host threads, each slice sent as soon as it is ready.
+namespace detail {
+    template <typename A, typename = void>
+    struct canonical_scalars : std::false_type { };
+    template <typename A>
+    struct canonical_scalars<A, std::void_t<decltype(A::scalars_are_canonical_limbs)>> : std::integral_constant<bool, A::scalars_are_canonical_limbs> { };
+}    // namespace detail
+template <typename Adapter>
+void upload_scalars(const context &ctx, void *d_dst, const typename Adapter::scalar_value_type *values, std::size_t count) {
+    if (count == 0) return;
+    if constexpr (detail::canonical_scalars<Adapter>::value) {
+        static_assert(sizeof(typename Adapter::scalar_value_type) == 32, "canonical-limb scalars are 4 x u64");
+        ctx.h2d(d_dst, values, count * 32);
+    } else {
+        const std::size_t slice = (std::size_t)1 << 18, nslices = (count + slice - 1) / slice;
+        const std::size_t lanes = std::min<std::size_t>(nslices, std::max(2u, std::min(8u, std::thread::hardware_concurrency())));
+        std::vector<std::vector<std::uint64_t>> stage(lanes);    // one staging slice per thread in flight
+        for (std::size_t base = 0; base < nslices; base += lanes) {
+            std::vector<std::future<void>> ready;
+            for (std::size_t k = 0; k < lanes && base + k < nslices; ++k)
+                ready.push_back(std::async(std::launch::async, [&, k]() {
+                    const std::size_t lo = (base + k) * slice, hi = std::min(count, lo + slice);
+                    stage[k].resize(4 * (hi - lo));
+                    for (std::size_t i = lo; i < hi; ++i) Adapter::scalar_to_limbs(values[i], &stage[k][4 * (i - lo)]);
+                }));
+            for (std::size_t k = 0; k < ready.size(); ++k) {
+                ready[k].get();
+                const std::size_t lo = (base + k) * slice;
+                ctx.h2d(static_cast<char *>(d_dst) + 32 * lo, stage[k].data(), stage[k].size() * 8);    // synchronous: the slice may be reused
+            }
+        }
+    }
+}
 
 /// Resident bases (a proving-key query or an SRS): uploaded once, reused for every proof / commitment.
 template <typename CurveType, int Group>

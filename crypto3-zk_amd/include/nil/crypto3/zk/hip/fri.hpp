@@ -39,9 +39,7 @@ public:
     /// `degree`: polynomial_dfs carries its degree next to the evaluations (polynomial_product sizes its result from
     /// it); without one the vector is taken to be full (size - 1)
     device_polynomial_dfs(const context &ctx, const polynomial_dfs<CurveType> &p, std::size_t degree = (std::size_t)-1) : device_polynomial_dfs(ctx, p.size()) {
-        std::vector<std::uint64_t> h(4 * size_);
-        for (std::size_t i = 0; i < size_; ++i) adapter::scalar_to_limbs(p.values[i], &h[4 * i]);
-        if (size_) ctx.h2d(d_.get(), h.data(), h.size() * 8);
+        upload_scalars<adapter>(ctx, d_.get(), p.values.data(), size_);
         if (degree != (std::size_t)-1) degree_ = degree;
     }
     std::size_t size() const { return size_; }
@@ -209,15 +207,12 @@ std::vector<typename curve_adapter<CurveType>::scalar_value_type>
         std::size_t log_n = 0;
         while (((std::size_t)1 << log_n) < n) ++log_n;
         if (n == 0 || ((std::size_t)1 << log_n) != n || log_n > log_domain) throw std::runtime_error("precommit: bad polynomial size");
-        std::vector<std::uint64_t> h(4 * n * (j - i));
-        for (std::size_t p = i; p < j; ++p)
-            for (std::size_t e = 0; e < n; ++e) adapter::scalar_to_limbs(polys[p].values[e], &h[4 * ((p - i) * n + e)]);
         char *dst = static_cast<char *>(d_ext.get()) + 32 * i * D;
         if (log_n == log_domain) {
-            ctx.h2d(dst, h.data(), h.size() * 8);
+            for (std::size_t p = i; p < j; ++p) upload_scalars<adapter>(ctx, dst + 32 * (p - i) * n, polys[p].values.data(), n);
         } else {
-            auto d_in = ctx.alloc(h.size() * 8);
-            ctx.h2d(d_in.get(), h.data(), h.size() * 8);
+            auto d_in = ctx.alloc(n * (j - i) * 32);
+            for (std::size_t p = i; p < j; ++p) upload_scalars<adapter>(ctx, static_cast<char *>(d_in.get()) + 32 * (p - i) * n, polys[p].values.data(), n);
             std::uint64_t wn[4];
             adapter::scalar_to_limbs(root(log_n), wn);
             check(zkhip_poly_resize_dev(ctx.get(), adapter::id, d_in.get(), log_n, j - i, wn, dst, log_domain, wd), "zkhip_poly_resize_dev", ctx.get());

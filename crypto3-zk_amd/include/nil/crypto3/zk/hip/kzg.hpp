@@ -33,6 +33,8 @@ struct kzg_params_hip {
     typedef multiexp_method_hip multiexp_method;    // shadows kzg.hpp:82's BDLO12 typedef
     template <typename InputIt>
     kzg_params_hip(const context &ctx, InputIt ck_first, InputIt ck_last) : ctx(ctx), commitment_key(ctx, ck_first, ck_last) { }
+    /// a commitment key that is already resident (device_bases::from_scalars / from_compressed, the powers-of-tau result)
+    kzg_params_hip(const context &ctx, device_bases<CurveType, ZKHIP_G1> &&key) : ctx(ctx), commitment_key(std::move(key)) { }
     const context &ctx;
     device_bases<CurveType, ZKHIP_G1> commitment_key;
 };
@@ -51,13 +53,10 @@ std::vector<typename curve_adapter<CurveType>::g1_value_type>
     std::size_t log_n = 0;
     while (((std::size_t)1 << log_n) < n) ++log_n;
     if (((std::size_t)1 << log_n) != n || n > params.commitment_key.size()) throw std::runtime_error("kzg_commit_batch: bad polynomial size");
-    std::vector<std::uint64_t> host(4 * n * batch);
-    for (std::size_t b = 0; b < batch; ++b) {
+    for (std::size_t b = 0; b < batch; ++b)
         if (polys[b].size() != n) throw std::runtime_error("kzg_commit_batch: ragged batch");
-        for (std::size_t i = 0; i < n; ++i) adapter::scalar_to_limbs(polys[b].values[i], &host[4 * (b * n + i)]);
-    }
-    auto d = ctx.alloc(host.size() * 8);
-    ctx.h2d(d.get(), host.data(), host.size() * 8);
+    auto d = ctx.alloc(n * batch * 32);
+    for (std::size_t b = 0; b < batch; ++b) upload_scalars<adapter>(ctx, static_cast<char *>(d.get()) + 32 * b * n, polys[b].values.data(), n);
     std::uint64_t w[4];
     adapter::scalar_to_limbs(omega, w);
     /* p.coefficients() for every polynomial of the batch (kzg.hpp:431) */

@@ -145,11 +145,7 @@ public:
             total += p.size();
         }
         db.data = _ctx.alloc(std::max<std::size_t>(1, total) * 32);
-        std::vector<std::uint64_t> host(4 * total);
-        std::size_t at = 0;
-        for (const auto &p : polys)
-            for (const auto &v : p.values) adapter::scalar_to_limbs(v, &host[4 * at++]);
-        if (total) _ctx.h2d(db.data.get(), host.data(), host.size() * 8);
+        for (std::size_t i = 0; i < polys.size(); ++i) upload_scalars<adapter>(_ctx, db.at(i), polys[i].values.data(), polys[i].size());
         /* poly.resize(D[0]->size()) for every polynomial (basic_fri.hpp:452-455): one call per run of equal sizes; it leaves
            the COEFFICIENTS in the source buffer, which is what proof_eval reads later */
         const std::size_t D = domain_size(0);

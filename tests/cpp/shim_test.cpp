@@ -206,6 +206,38 @@ int groth16_prove_t(size_t M, size_t n, size_t N, const uint32_t *const rowptr[3
     return 0;
 }
 
+/// A curve whose scalar type is NOT four canonical limbs in memory (stand-in for crypto3-algebra's Montgomery-form field values): the
+/// limbs are kept in reverse order and complemented.  Bulk uploads of such values take upload_scalars' converting path (host threads,
+/// slice by slice); the native model takes the direct copy.  Same groups, so the commitments must agree.
+}    // namespace (the specialisation below lives in the shim's namespace)
+template <int Curve>
+struct foreign_scalar_curve { };
+namespace nil {
+namespace crypto3 {
+namespace zk {
+namespace hip {
+template <int Curve>
+struct curve_adapter<foreign_scalar_curve<Curve>> : curve_adapter<native_curve<Curve>> {
+    typedef curve_adapter<native_curve<Curve>> base;
+    struct scalar_value_type {
+        uint64_t stored[4];
+    };
+    static constexpr bool scalars_are_canonical_limbs = false;
+    static void scalar_to_limbs(const scalar_value_type &s, uint64_t *out) {
+        for (int i = 0; i < 4; ++i) out[i] = ~s.stored[3 - i];
+    }
+    static scalar_value_type scalar_from_limbs(const uint64_t *in) {
+        scalar_value_type s;
+        for (int i = 0; i < 4; ++i) s.stored[3 - i] = ~in[i];
+        return s;
+    }
+};
+}    // namespace hip
+}    // namespace zk
+}    // namespace crypto3
+}    // namespace nil
+namespace {
+
 template <typename Curve>
 int kzg_commit_t(const uint64_t *srs, size_t n, const uint64_t *evals, size_t log_n, size_t batch, const uint64_t *omega, uint64_t *out, uint8_t *out_inf) {
     typedef curve_adapter<Curve> A;
@@ -724,6 +756,18 @@ int shim_groth16_prove(int curve, size_t M, size_t n, size_t N, const uint32_t *
                                               assignment, omega, coset, r, s, proof);
     } catch (const std::exception &e) {
         fprintf(stderr, "shim_groth16_prove: %s\n", e.what());
+        return -1;
+    }
+}
+
+/// the same commit with scalar values in a foreign memory layout (upload_scalars' converting path)
+int shim_kzg_commit_foreign(int curve, const uint64_t *srs, size_t n, const uint64_t *evals, size_t log_n, size_t batch, const uint64_t *omega,
+                            uint64_t *out, uint8_t *out_inf) {
+    try {
+        if (curve == ZKHIP_BLS12_381) return kzg_commit_t<foreign_scalar_curve<ZKHIP_BLS12_381>>(srs, n, evals, log_n, batch, omega, out, out_inf);
+        return kzg_commit_t<foreign_scalar_curve<ZKHIP_BN254>>(srs, n, evals, log_n, batch, omega, out, out_inf);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "shim_kzg_commit_foreign: %s\n", e.what());
         return -1;
     }
 }

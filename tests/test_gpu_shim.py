@@ -117,14 +117,24 @@ def test_groth16_device_generated_key_matches_trapdoor(shim, curve, M, n):
     print("M = %d: key generated on the device in %.0f ms, first proof %.1f ms" % (M, ms[0], ms[1]))
 
 
-@pytest.mark.parametrize("curve,log_n,batch", [(0, 10, 3), (1, 8, 2)])
-def test_kzg_commit_shim(shim, curve, log_n, batch):
-    """commit(batch) = per column iNTT + MSM against {alpha^i G} (kzg.hpp:427-435); alpha = 7 as placeholder.cpp:175"""
+@pytest.mark.parametrize("curve,log_n,batch", [(0, 10, 3), (1, 8, 2), (0, 19, 2)])
+def test_kzg_commit_shim(shim, zk, ctx, curve, log_n, batch):
+    """commit(batch) = per column iNTT + MSM against {alpha^i G} (kzg.hpp:427-435); alpha = 7 as placeholder.cpp:175.
+    2^19 rows: columns longer than one staging slice of upload_scalars (2^18 elements)."""
     C = CURVES[curve]
     n = 1 << log_n
     alpha = 7
-    powers = fr_arr([pow(alpha, i, C.r) for i in range(n)])
-    srs, _ = cp.batch_mul(curve, 1, powers)
+    big = log_n >= 16
+    if big:  # the SRS by the device's fixed-base kernel (itself checked against the oracle in test_gpu_msm.py)
+        x, pw = 1, np.empty((n, 4), dtype=np.uint64)
+        for i in range(n):
+            pw[i] = limbs(x, 4)
+            x = x * alpha % C.r
+        b = ctx.bases_from_scalars(curve, 1, pw)
+        srs, _ = b.download()
+        b.free()
+    else:
+        srs, _ = cp.batch_mul(curve, 1, fr_arr([pow(alpha, i, C.r) for i in range(n)]))
     w = limbs(C.root_of_unity(log_n), 4)
     evals = cp.random_fr(curve, 5, batch * n).reshape(batch, n, 4)
     coeffs = cp.ntt(curve, evals, log_n, w, inverse=True)
@@ -132,12 +142,19 @@ def test_kzg_commit_shim(shim, curve, log_n, batch):
     oinf = np.zeros(batch, dtype=np.uint8)
     assert shim.shim_kzg_commit(curve, P(srs), ctypes.c_size_t(n), P(evals), ctypes.c_size_t(log_n), ctypes.c_size_t(batch), P(w), P(out), P(oinf)) == 0
     for b in range(batch):
-        exp, einf = cp.msm(curve, 1, srs, coeffs[b], chunks=4)
-        assert oinf[b] == einf and (out[b] == exp).all()
+        if not big:
+            exp, einf = cp.msm(curve, 1, srs, coeffs[b], chunks=4)
+            assert oinf[b] == einf and (out[b] == exp).all()
         # the commitment is f(alpha) * G: Horner on the coefficients
         fa = cp.fr_horner(curve, coeffs[b], limbs(alpha, 4))
         pt, _ = cp.batch_mul(curve, 1, fa.reshape(1, 4))
-        assert (out[b] == pt[0]).all()
+        assert oinf[b] == 0 and (out[b] == pt[0]).all()
+    # the same batch through an adapter whose scalar values are NOT canonical limbs in memory (the stand-in for crypto3-algebra's
+    # Montgomery-form field type): upload_scalars converts on host threads instead of copying the vectors as they lie
+    out2 = np.zeros_like(out)
+    oinf2 = np.zeros_like(oinf)
+    assert shim.shim_kzg_commit_foreign(curve, P(srs), ctypes.c_size_t(n), P(evals), ctypes.c_size_t(log_n), ctypes.c_size_t(batch), P(w), P(out2), P(oinf2)) == 0
+    assert (out2 == out).all() and (oinf2 == oinf).all()
 
 
 def _srs(curve, alpha, n):
