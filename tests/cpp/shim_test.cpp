@@ -179,6 +179,7 @@ int groth16_prove_t(size_t M, size_t n, size_t N, const uint32_t *const rowptr[3
         typedef ref_like::r1cs_gg_ppzksnark_proving_key<A> key_t;
         typedef ref_like::r1cs_gg_ppzksnark_proof<A> proof_t;
         r1cs_gg_ppzksnark_proving_key_hip<Curve, key_t> rdpk(ctx, rk, dom);
+        rdpk.direct_assignment_upload = false;    // this key takes the staged upload (page-locked buffer, host threads); `dpk` above the direct one
         proof_t rp = r1cs_gg_ppzksnark_prover_hip<Curve, key_t, proof_t>::process(rdpk, primary, auxiliary, A::scalar_from_limbs(r), A::scalar_from_limbs(s));
         if (!(rp.g_A == proof_v.g_A) || !(rp.g_B == proof_v.g_B) || !(rp.g_C == proof_v.g_C)) return -103;
         /* a key whose H query was generated over another domain size is refused, not read past its end */
