@@ -170,9 +170,20 @@ struct group_value {
             return false;
         }
         alignas(16) std::uint32_t w[2 * O::CANON_WORDS];
-        zkhip::Affine<F> a = zkhip::xyzz_to_affine(p);
-        O::to_canonical(w, a.x);
-        O::to_canonical(w + O::CANON_WORDS, a.y);
+        /* a point that is already normalised (ZZ = ZZZ = 1: every element of a key after batch_to_special, generator.hpp:190-192)
+           needs no inversion -- what makes handing a 2^20-constraint key to the device seconds instead of minutes */
+        O::to_canonical(w, p.ZZ);
+        O::to_canonical(w + O::CANON_WORDS, p.ZZZ);
+        bool unit = w[0] == 1 && w[O::CANON_WORDS] == 1;
+        for (int i = 1; i < O::CANON_WORDS && unit; ++i) unit = w[i] == 0 && w[O::CANON_WORDS + i] == 0;
+        if (unit) {
+            O::to_canonical(w, p.X);
+            O::to_canonical(w + O::CANON_WORDS, p.Y);
+        } else {
+            zkhip::Affine<F> a = zkhip::xyzz_to_affine(p);
+            O::to_canonical(w, a.x);
+            O::to_canonical(w + O::CANON_WORDS, a.y);
+        }
         std::memcpy(xy, w, sizeof(w));
         return true;
     }

@@ -11,6 +11,7 @@
 #include <cerrno>
 #include <cstdint>
 #include <future>
+#include <iterator>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -130,9 +131,24 @@ public:
         const std::size_t cl = Group == ZKHIP_G1 ? adapter::g1_coord_limbs : adapter::g2_coord_limbs;
         std::vector<std::uint64_t> xy;
         std::vector<std::uint8_t> inf;
-        for (InputIt it = first; it != last; ++it) {
-            xy.resize(xy.size() + 2 * cl);
-            inf.push_back(adapter::point_to_affine_limbs(*it, xy.data() + xy.size() - 2 * cl) ? 0 : 1);
+        if constexpr (std::is_base_of<std::random_access_iterator_tag, typename std::iterator_traits<InputIt>::iterator_category>::value) {
+            /* a query of a large key: the conversions (the adapter's to-affine + to-canonical per point) on a few host threads */
+            const std::size_t n = (std::size_t)(last - first);
+            xy.resize(n * 2 * cl);
+            inf.resize(n);
+            const std::size_t lanes = n >= ((std::size_t)1 << 14) ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+            std::vector<std::future<void>> work;
+            for (std::size_t k = 0; k < lanes; ++k)
+                work.push_back(std::async(lanes > 1 ? std::launch::async : std::launch::deferred, [&, k]() {
+                    for (std::size_t i = n * k / lanes; i < n * (k + 1) / lanes; ++i)
+                        inf[i] = adapter::point_to_affine_limbs(first[i], xy.data() + i * 2 * cl) ? 0 : 1;
+                }));
+            for (auto &w : work) w.get();
+        } else {
+            for (InputIt it = first; it != last; ++it) {
+                xy.resize(xy.size() + 2 * cl);
+                inf.push_back(adapter::point_to_affine_limbs(*it, xy.data() + xy.size() - 2 * cl) ? 0 : 1);
+            }
         }
         size_ = inf.size();
         check(zkhip_bases_upload(ctx.get(), adapter::id, Group, xy.data(), inf.data(), size_, &b_), "zkhip_bases_upload", ctx.get());
