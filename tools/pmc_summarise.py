@@ -7,7 +7,7 @@ acc = defaultdict(lambda: defaultdict(lambda: [0.0, set()]))
 regs = {}
 for path in glob.glob(src + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(path)):
-        name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").replace("zkhip::", "")
+        name = re.sub(r"\(.*", "", row["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "").replace("zkhip::", "")
         a = acc[name][row["Counter_Name"]]
         a[0] += float(row["Counter_Value"])
         a[1].add(row["Dispatch_Id"])
