@@ -119,6 +119,28 @@ void upload_scalars(const context &ctx, void *d_dst, const typename Adapter::sca
     }
 }
 
+/// The way back: `count` canonical 32-byte elements at d_src -> scalar-field values appended to `out` (same two paths).
+template <typename Adapter>
+void download_scalars(const context &ctx, const void *d_src, std::size_t count, std::vector<typename Adapter::scalar_value_type> &out) {
+    if (count == 0) return;
+    const std::size_t at = out.size();
+    out.resize(at + count);
+    if constexpr (detail::canonical_scalars<Adapter>::value) {
+        static_assert(sizeof(typename Adapter::scalar_value_type) == 32, "canonical-limb scalars are 4 x u64");
+        ctx.d2h(out.data() + at, d_src, count * 32);
+    } else {
+        std::vector<std::uint64_t> h(4 * count);
+        ctx.d2h(h.data(), d_src, h.size() * 8);
+        const std::size_t lanes = count >= ((std::size_t)1 << 16) ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+        std::vector<std::future<void>> work;
+        for (std::size_t k = 0; k < lanes; ++k)
+            work.push_back(std::async(lanes > 1 ? std::launch::async : std::launch::deferred, [&, k]() {
+                for (std::size_t i = count * k / lanes; i < count * (k + 1) / lanes; ++i) out[at + i] = Adapter::scalar_from_limbs(&h[4 * i]);
+            }));
+        for (auto &w : work) w.get();
+    }
+}
+
 /// Resident bases (a proving-key query or an SRS): uploaded once, reused for every proof / commitment.
 template <typename CurveType, int Group>
 class device_bases {

@@ -49,10 +49,8 @@ public:
     const context &ctx() const { return *ctx_; }
 
     polynomial_dfs<CurveType> to_host() const {
-        std::vector<std::uint64_t> h(4 * size_);
-        if (size_) ctx_->d2h(h.data(), d_.get(), h.size() * 8);
         polynomial_dfs<CurveType> out;
-        for (std::size_t i = 0; i < size_; ++i) out.values.push_back(adapter::scalar_from_limbs(&h[4 * i]));
+        download_scalars<adapter>(*ctx_, d_.get(), size_, out.values);
         return out;
     }
 
@@ -222,9 +220,7 @@ std::vector<typename curve_adapter<CurveType>::scalar_value_type>
     }
     auto d_leaves = ctx.alloc(batch * D * 32);
     check(zkhip_fri_leaves_dev(ctx.get(), d_ext.get(), log_domain, batch, fri_step, d_leaves.get()), "zkhip_fri_leaves_dev", ctx.get());
-    std::vector<std::uint64_t> h(4 * batch * D);
-    ctx.d2h(h.data(), d_leaves.get(), h.size() * 8);
-    for (std::size_t e = 0; e < batch * D; ++e) out.push_back(adapter::scalar_from_limbs(&h[4 * e]));
+    download_scalars<adapter>(ctx, d_leaves.get(), batch * D, out);
     return out;
 }
 

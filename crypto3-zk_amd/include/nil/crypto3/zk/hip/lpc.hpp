@@ -296,10 +296,8 @@ public:
     /// coefficient form of committed polynomial (batch, index): `g_coeffs` of the query phase (basic_fri.hpp:753-771)
     std::vector<value_type> coefficients(std::size_t batch, std::size_t index) const {
         const device_batch &db = _dev.at(batch);
-        std::vector<std::uint64_t> h(4 * db.len.at(index));
-        _ctx.d2h(h.data(), db.at(index), h.size() * 8);
         std::vector<value_type> out;
-        for (std::size_t k = 0; k < db.len[index]; ++k) out.push_back(adapter::scalar_from_limbs(&h[4 * k]));
+        download_scalars<adapter>(_ctx, db.at(index), db.len.at(index), out);
         return out;
     }
 
@@ -326,11 +324,8 @@ protected:
         const std::size_t D = (std::size_t)1 << log_domain;
         auto d_leaves = _ctx.alloc(std::max<std::size_t>(1, batch) * D * 32);
         check(zkhip_fri_leaves_dev(_ctx.get(), d_evals, log_domain, batch, fri_step, d_leaves.get()), "zkhip_fri_leaves_dev", _ctx.get());
-        std::vector<std::uint64_t> h(4 * batch * D);
-        _ctx.d2h(h.data(), d_leaves.get(), h.size() * 8);
         std::vector<value_type> leaves;
-        leaves.reserve(batch * D);
-        for (std::size_t e = 0; e < batch * D; ++e) leaves.push_back(adapter::scalar_from_limbs(&h[4 * e]));
+        download_scalars<adapter>(_ctx, d_leaves.get(), batch * D, leaves);    // one copy for canonical-limb scalar types (backend.hpp)
         return _builder(leaves, batch * ((std::size_t)1 << fri_step));
     }
     std::vector<value_type> evaluate_batch_at(std::size_t k, const value_type &x) const {

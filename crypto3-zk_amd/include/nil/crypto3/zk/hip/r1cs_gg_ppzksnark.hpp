@@ -196,10 +196,8 @@ struct r1cs_to_qap_hip {
         std::shared_ptr<void> d_z;
         auto d_h = witness_map(ctx, cs, dom, primary_input, auxiliary_input, d_z);
         const std::size_t m = cs.domain_size();
-        std::vector<std::uint64_t> raw(4 * (m + 1));
-        ctx.d2h(raw.data(), d_h.get(), raw.size() * 8);
         std::vector<value_type> out;
-        for (std::size_t i = 0; i <= m; ++i) out.push_back(adapter::scalar_from_limbs(&raw[4 * i]));
+        download_scalars<adapter>(ctx, d_h.get(), m + 1, out);
         return out;
     }
 };

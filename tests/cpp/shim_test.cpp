@@ -253,6 +253,17 @@ int kzg_commit_t(const uint64_t *srs, size_t n, const uint64_t *evals, size_t lo
         for (size_t i = 0; i < ((size_t)1 << log_n); ++i) polys[b].values.push_back(A::scalar_from_limbs(evals + 4 * ((b << log_n) + i)));
     auto commits = kzg_commit_batch<Curve>(params, polys, A::scalar_from_limbs(omega));
     for (size_t b = 0; b < batch; ++b) out_inf[b] = commits[b].to_affine(out + b * L1) ? 0 : 1;
+    {   // the way back through this adapter's download path: a device polynomial_dfs returns what went up
+        device_polynomial_dfs<Curve> up(ctx, polys[0]);
+        const polynomial_dfs<Curve> back = up.to_host();
+        if (back.size() != polys[0].size()) return -201;
+        for (size_t i = 0; i < back.size(); ++i) {
+            uint64_t a[4], b[4];
+            A::scalar_to_limbs(back.values[i], a);
+            A::scalar_to_limbs(polys[0].values[i], b);
+            if (std::memcmp(a, b, 32) != 0) return -202;
+        }
+    }
     return 0;
 }
 
