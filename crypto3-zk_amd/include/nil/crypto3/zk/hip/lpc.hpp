@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <functional>
+#include <iterator>
 #include <map>
 #include <set>
 #include <type_traits>
@@ -114,6 +115,16 @@ public:
     void append_to_batch(std::size_t index, const ContainerType &polys) {
         if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
         _polys[index].insert(_polys[index].end(), std::begin(polys), std::end(polys));
+    }
+    /// hand the polynomials over instead of copying them (see kzg_v2.hpp)
+    void append_to_batch(std::size_t index, poly_type &&poly) {
+        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
+        _polys[index].push_back(std::move(poly));
+    }
+    void append_to_batch(std::size_t index, std::vector<poly_type> &&polys) {
+        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
+        _polys[index].insert(_polys[index].end(), std::make_move_iterator(polys.begin()), std::make_move_iterator(polys.end()));
+        polys.clear();
     }
     void append_eval_point(std::size_t batch_id, const value_type &point) {
         for (auto &pts : _points.at(batch_id)) pts.push_back(point);
