@@ -57,7 +57,15 @@ int main(int argc, char **argv) {
         auto t1 = std::chrono::steady_clock::now();
         auto commits = scheme.commit(0);
         auto t2 = std::chrono::steady_clock::now();
+        scheme.append_eval_point(0, Fr(1234567));
+        scheme.append_eval_point(0, Fr(7654321));
+        transcript tr;
+        auto t3 = std::chrono::steady_clock::now();
+        auto proof = scheme.proof_eval(tr);
+        auto t4 = std::chrono::steady_clock::now();
+        printf("proof_eval of the same %zu polynomials at 2 points through the shim: %.1f ms\n", cols, std::chrono::duration<double, std::milli>(t4 - t3).count());
         uint64_t xy[12];
+        proof.pi_1.to_affine(xy);
         commits[0].to_affine(xy);
         printf("commit of %zu x 2^%zu through the shim: append_to_batch (host copy) %.1f ms, commit (upload + iNTT + MSM + download) %.1f ms  [%016llx]\n", cols,
                log_n, std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(),
