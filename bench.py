@@ -303,8 +303,8 @@ def main():
         if world == 1 and not args.no_ntt:
             line["ntt"] = ntt_leg(np, zk, ctx, verify=not args.no_verify, traffic=traffic)
         if world == 1 and not args.no_groth16:
-            line["groth16"] = groth16_leg(np, verify=not args.no_verify)
-            line["groth16_m2p20"] = groth16_leg(np, constraints=(1 << 20) - 11, steps=3, verify=not args.no_verify)
+            line["groth16"] = groth16_leg(np, steps=8, verify=not args.no_verify)
+            line["groth16_m2p20"] = groth16_leg(np, constraints=(1 << 20) - 11, steps=6, verify=not args.no_verify)
         if g16_sharded is not None:
             line["groth16_sharded"] = g16_sharded
         if kzg_sharded is not None:
