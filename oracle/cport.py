@@ -142,6 +142,22 @@ def ntt(curve: int, data: np.ndarray, log_m: int, omega: np.ndarray, inverse=Fal
     return d
 
 
+def domain_choice(min_size: int, two_adicity: int):
+    """(kind, m) of make_evaluation_domain(min_size): 0 basic / 1 extended / 2 step radix-2"""
+    out = np.zeros(2, dtype=np.uint64)
+    assert lib().zko_domain_choice(ctypes.c_size_t(min_size), ctypes.c_size_t(two_adicity), _p(out)) == 0
+    return int(out[0]), int(out[1])
+
+
+def domain_fft(curve: int, kind: int, data: np.ndarray, omega, shift=None, inverse=False) -> np.ndarray:
+    """one vector (m, 4) over the domain (kind, m = len(data)); returns a transformed copy"""
+    d = _u64(data).copy()
+    rc = lib().zko_domain_fft(curve, int(kind), ctypes.c_size_t(d.shape[0]), _p(_u64(omega)), _p(_u64(shift)) if shift is not None else None,
+                              _p(d), 1 if inverse else 0)
+    assert rc == 0
+    return d
+
+
 def fr_horner(curve: int, coeffs: np.ndarray, x: np.ndarray) -> np.ndarray:
     coeffs = _u64(coeffs)
     out = np.zeros(4, dtype=np.uint64)
@@ -172,6 +188,12 @@ class Groth16:
 
     def is_satisfied(self) -> bool:
         return bool(lib().zko_g16_is_satisfied(self.h))
+
+    def set_domain(self, kind: int, m: int, omega, shift=None):
+        """install the evaluation domain every later call reduces over (default: the basic radix-2 domain of 2^ceil(log2(M+n+1))
+        points over the omega each call passes); kind / omega / shift as pyoracle.EvaluationDomain"""
+        assert lib().zko_g16_set_domain(self.h, int(kind), ctypes.c_size_t(m), _p(_u64(omega)), _p(_u64(shift)) if shift is not None else None) == 0
+        self._dims()
 
     def keygen(self, trapdoor: np.ndarray, omega: np.ndarray):
         assert lib().zko_g16_keygen(self.h, _p(_u64(trapdoor)), _p(_u64(omega))) == 0

@@ -516,6 +516,255 @@ def stockham_model(a: Sequence[int], w: int, r: int, radices: Sequence[int]) -> 
 
 
 # --------------------------------------------------------------------------------------
+# Evaluation domains (crypto3-math `evaluation_domain` and `make_evaluation_domain`)
+#
+# crypto3-math is NOT in /root/reference (un-vendored dependency, no version pin).  What is restated here is
+# the published algorithm of the library it descends from -- libfqfft's `get_evaluation_domain`, `basic_radix2_domain`,
+# `extended_radix2_domain`, `step_radix2_domain` (SCIPR-lab libfqfft, evaluation_domain/{get_evaluation_domain.tcc,
+# domains/*.tcc}), whose selection order and member names crypto3-math keeps -- anchored on the reference's call sites:
+#   reductions/r1cs_to_qap.hpp:229-230, 138-139      make_evaluation_domain(num_constraints + num_inputs + 1)
+#   reductions/r1cs_to_qap.hpp:150-153, 250-315      compute_vanishing_polynomial, evaluate_all_lagrange_polynomials,
+#                                                    inverse_fft, fft, add_poly_z, divide_by_z_on_coset
+# PIN: every method is held to its DEFINITION over the domain's point set by tests/test_oracle_kat.py
+# (fft = evaluation at get_domain_element(i), inverse_fft its inverse, Lagrange / vanishing polynomials by their
+# products, divide_by_z_on_coset = division by Z(g x_i)); the reference asserts no transform output ("parity unpinned").
+# Geometric / arithmetic sequence domains (the selection's last resort, reached only beyond 2^two_adicity points) are
+# out of scope: make_evaluation_domain raises there.
+# --------------------------------------------------------------------------------------
+def _ceil_log2(n: int) -> int:
+    """libff::log2 / std::ceil(std::log2(n))"""
+    return 0 if n <= 1 else (n - 1).bit_length()
+
+
+class EvaluationDomain:
+    BASIC, EXTENDED, STEP = 0, 1, 2
+    KIND_NAMES = {0: "basic_radix2", 1: "extended_radix2", 2: "step_radix2"}
+
+    def __init__(self, kind: int, m: int, omega: int, r: int, shift: int = 0):
+        """basic: omega = primitive m-th root.  extended: omega = primitive (m/2)-th root, the points are <omega> and
+        shift <omega>.  step: big_m = 2^(ceil(log2 m) - 1), small_m = m - big_m (a power of two); omega = primitive
+        (2 big_m)-th root; the points are <omega^2> followed by omega <omega^(2 big_m / small_m)>."""
+        self.kind, self.m, self.omega, self.r, self.shift = kind, m, omega % r, r, shift % r
+        if kind == self.BASIC:
+            assert m > 1 and m & (m - 1) == 0
+            assert pow(omega, m, r) == 1 and pow(omega, m // 2, r) != 1
+        elif kind == self.EXTENDED:
+            assert m > 1 and m & (m - 1) == 0
+            self.small_m = m // 2
+            assert pow(omega, self.small_m, r) == 1 and (self.small_m == 1 or pow(omega, self.small_m // 2, r) != 1)
+        else:
+            assert m > 1
+            self.big_m = 1 << (_ceil_log2(m) - 1)
+            self.small_m = m - self.big_m
+            assert self.small_m == 1 << _ceil_log2(self.small_m), "step_radix2(): expected small_m == 1ul<<log2(small_m)"
+            assert pow(omega, 2 * self.big_m, r) == 1 and pow(omega, self.big_m, r) != 1
+            self.big_omega = omega * omega % r
+            self.compr = self.big_m // self.small_m
+            self.small_omega = pow(omega, 2 * self.compr, r)  # = unity_root(small_m) on the same root chain
+
+    # ---- the point set
+    def get_domain_element(self, idx: int) -> int:
+        r = self.r
+        if self.kind == self.BASIC:
+            return pow(self.omega, idx, r)
+        if self.kind == self.EXTENDED:
+            return pow(self.omega, idx, r) if idx < self.small_m else self.shift * pow(self.omega, idx - self.small_m, r) % r
+        if idx < self.big_m:
+            return pow(self.big_omega, idx, r)
+        return self.omega * pow(self.small_omega, idx - self.big_m, r) % r
+
+    def elements(self) -> List[int]:
+        return [self.get_domain_element(i) for i in range(self.m)]
+
+    # ---- transforms
+    def fft(self, a: Sequence[int]) -> List[int]:
+        r = self.r
+        assert len(a) == self.m
+        if self.kind == self.BASIC:
+            return ntt(a, self.omega, r)
+        if self.kind == self.EXTENDED:
+            sm, sh = self.small_m, self.shift
+            s_to_sm = pow(sh, sm, r)
+            a0 = [(a[i] + a[sm + i]) % r for i in range(sm)]
+            a1 = [pow(sh, i, r) * (a[i] + s_to_sm * a[sm + i]) % r for i in range(sm)]
+            return ntt(a0, self.omega, r) + ntt(a1, self.omega, r)
+        bm, sm, w = self.big_m, self.small_m, self.omega
+        c = [(a[i] + a[i + bm]) % r if i < sm else a[i] % r for i in range(bm)]
+        d = []
+        wi = 1
+        for i in range(bm):
+            d.append(wi * ((a[i] - a[i + bm]) if i < sm else a[i]) % r)
+            wi = wi * w % r
+        e = [sum(d[i + j * sm] for j in range(self.compr)) % r for i in range(sm)]
+        return ntt(c, self.big_omega, r) + ntt(e, self.small_omega, r)
+
+    def inverse_fft(self, a: Sequence[int]) -> List[int]:
+        r = self.r
+        assert len(a) == self.m
+        if self.kind == self.BASIC:
+            return intt(a, self.omega, r)
+        if self.kind == self.EXTENDED:
+            sm, sh = self.small_m, self.shift
+            winv = pow(self.omega, -1, r)
+            a0 = ntt(a[:sm], winv, r)
+            a1 = ntt(a[sm:], winv, r)
+            s_to_sm = pow(sh, sm, r)
+            sconst = pow(sm * (1 - s_to_sm) % r, -1, r)
+            shinv = pow(sh, -1, r)
+            lo, hi = [], []
+            x = 1
+            for i in range(sm):
+                lo.append(sconst * (-s_to_sm * a0[i] + x * a1[i]) % r)
+                hi.append(sconst * (a0[i] - x * a1[i]) % r)
+                x = x * shinv % r
+            return lo + hi
+        bm, sm, w = self.big_m, self.small_m, self.omega
+        U0 = intt(a[:bm], self.big_omega, r)
+        U1 = intt(a[bm:], self.small_omega, r)
+        tmp = []
+        wi = 1
+        for i in range(bm):
+            tmp.append(U0[i] * wi % r)
+            wi = wi * w % r
+        out = [0] * self.m
+        for i in range(sm, bm):
+            out[i] = U0[i]
+        winv = pow(w, -1, r)
+        half = pow(2, -1, r)
+        x = 1
+        for i in range(sm):
+            u1 = (U1[i] - sum(tmp[i + j * sm] for j in range(1, self.compr))) % r * x % r
+            out[i] = (U0[i] + u1) * half % r
+            out[bm + i] = (U0[i] - u1) * half % r
+            x = x * winv % r
+        return out
+
+    # ---- what the QAP reduction reads (r1cs_to_qap.hpp:150-153, 261, 308)
+    def compute_vanishing_polynomial(self, t: int) -> int:
+        r = self.r
+        if self.kind == self.BASIC:
+            return (pow(t, self.m, r) - 1) % r
+        if self.kind == self.EXTENDED:
+            tm = pow(t, self.small_m, r)
+            return (tm - 1) * (tm - pow(self.shift, self.small_m, r)) % r
+        return (pow(t, self.big_m, r) - 1) * (pow(t, self.small_m, r) - pow(self.omega, self.small_m, r)) % r
+
+    def evaluate_all_lagrange_polynomials(self, t: int) -> List[int]:
+        r = self.r
+        if self.kind == self.BASIC:
+            return lagrange_at(self.m, self.omega, t, r)
+        if self.kind == self.EXTENDED:
+            sm, sh = self.small_m, self.shift
+            T0 = lagrange_at(sm, self.omega, t, r)
+            T1 = lagrange_at(sm, self.omega, t * pow(sh, -1, r) % r, r)
+            t_sm, s_sm = pow(t, sm, r), pow(sh, sm, r)
+            ood = pow((s_sm - 1) % r, -1, r)
+            c0 = (t_sm - s_sm) * (-ood) % r
+            c1 = (t_sm - 1) * ood % r
+            return [x * c0 % r for x in T0] + [x * c1 % r for x in T1]
+        bm, sm, w = self.big_m, self.small_m, self.omega
+        inner_big = lagrange_at(bm, self.big_omega, t, r)
+        inner_small = lagrange_at(sm, self.small_omega, t * pow(w, -1, r) % r, r)
+        L0 = (pow(t, sm, r) - pow(w, sm, r)) % r
+        w_sm = pow(w, sm, r)
+        bw_sm = pow(self.big_omega, sm, r)
+        out = []
+        elt = 1
+        for i in range(bm):
+            out.append(inner_big[i] * L0 % r * pow((elt - w_sm) % r, -1, r) % r)
+            elt = elt * bw_sm % r
+        L1 = (pow(t, bm, r) - 1) * pow((pow(w, bm, r) - 1) % r, -1, r) % r
+        return out + [L1 * x % r for x in inner_small]
+
+    def add_poly_z(self, coeff: int, H: List[int]) -> None:
+        r = self.r
+        assert len(H) == self.m + 1
+        if self.kind == self.BASIC:
+            H[self.m] = (H[self.m] + coeff) % r
+            H[0] = (H[0] - coeff) % r
+        elif self.kind == self.EXTENDED:
+            s_sm = pow(self.shift, self.small_m, r)
+            H[2 * self.small_m] = (H[2 * self.small_m] + coeff) % r
+            H[self.small_m] = (H[self.small_m] - coeff * (s_sm + 1)) % r
+            H[0] = (H[0] + coeff * s_sm) % r
+        else:
+            w_sm = pow(self.omega, self.small_m, r)
+            H[self.m] = (H[self.m] + coeff) % r
+            H[self.big_m] = (H[self.big_m] - coeff * w_sm) % r
+            H[self.small_m] = (H[self.small_m] - coeff) % r
+            H[0] = (H[0] + coeff * w_sm) % r
+
+    def divide_by_z_on_coset(self, P: Sequence[int], g: int) -> List[int]:
+        """P[i] / Z(g x_i): P holds evaluations on the coset g * domain (multiply_by_coset(g) followed by fft)."""
+        r = self.r
+        if self.kind == self.BASIC:
+            zi = pow(self.compute_vanishing_polynomial(g), -1, r)
+            return [x * zi % r for x in P]
+        if self.kind == self.EXTENDED:
+            z0 = pow(self.compute_vanishing_polynomial(g), -1, r)
+            z1 = pow(self.compute_vanishing_polynomial(g * self.shift % r), -1, r)
+            return [x * z0 % r for x in P[: self.small_m]] + [x * z1 % r for x in P[self.small_m :]]
+        bm, sm, w = self.big_m, self.small_m, self.omega
+        Z0 = (pow(g, bm, r) - 1) % r
+        c_sm_Z0 = pow(g, sm, r) * Z0 % r
+        w_sm_Z0 = pow(w, sm, r) * Z0 % r
+        w_2sm = pow(w, 2 * sm, r)
+        out = []
+        elt = 1
+        for i in range(bm):
+            out.append(P[i] * pow((c_sm_Z0 * elt - w_sm_Z0) % r, -1, r) % r)
+            elt = elt * w_2sm % r
+        gw = g * w % r
+        Z1 = (pow(gw, bm, r) - 1) * (pow(gw, sm, r) - pow(w, sm, r)) % r
+        z1i = pow(Z1, -1, r)
+        return out + [x * z1i % r for x in P[bm:]]
+
+    def describe(self) -> str:
+        return "%s(m=%d)" % (self.KIND_NAMES[self.kind], self.m)
+
+
+def evaluation_domain_choice(min_size: int, two_adicity: int) -> Tuple[int, int]:
+    """(kind, m) that make_evaluation_domain(min_size) returns over a field of the given two-adicity: the selection order of
+    libfqfft's get_evaluation_domain -- basic, extended, step at min_size, then the same three at big + rounded_small."""
+    s = two_adicity
+
+    def basic_ok(n):
+        return n > 1 and n == 1 << _ceil_log2(n) and _ceil_log2(n) <= s
+
+    def extended_ok(n):
+        return n > 1 and _ceil_log2(n) == s + 1 and n == 1 << (s + 1)
+
+    def step_ok(n):
+        if n <= 1:
+            return False
+        small = n - (1 << (_ceil_log2(n) - 1))
+        return small == 1 << _ceil_log2(small) and _ceil_log2(n) <= s
+
+    big = 1 << (_ceil_log2(min_size) - 1) if min_size > 1 else 0
+    small = min_size - big
+    rounded = big + (1 << _ceil_log2(small))
+    for n in (min_size, rounded):
+        for kind, ok in ((EvaluationDomain.BASIC, basic_ok), (EvaluationDomain.EXTENDED, extended_ok), (EvaluationDomain.STEP, step_ok)):
+            if ok(n):
+                return kind, n
+    raise ValueError("make_evaluation_domain(%d): only the radix-2 family is restated (geometric / arithmetic sequence domains are out of scope)" % min_size)
+
+
+def make_evaluation_domain(curve: "Curve", min_size: int, two_adicity: Optional[int] = None, root=None) -> EvaluationDomain:
+    """math::make_evaluation_domain<Fr>(min_size).  `two_adicity` / `root` (log -> primitive 2^log-th root) let the tests
+    exercise the extended domain -- which a real field only reaches at 2^(s+1) points -- over a pretended smaller s."""
+    s = curve.two_adicity if two_adicity is None else two_adicity
+    root = root or curve.root_of_unity
+    kind, m = evaluation_domain_choice(min_size, s)
+    if kind == EvaluationDomain.BASIC:
+        return EvaluationDomain(kind, m, root(_ceil_log2(m)), curve.r)
+    if kind == EvaluationDomain.EXTENDED:
+        # detail::coset_shift<F>() = multiplicative_generator^2
+        return EvaluationDomain(kind, m, root(_ceil_log2(m) - 1), curve.r, pow(curve.fr_generator, 2, curve.r))
+    return EvaluationDomain(kind, m, root(_ceil_log2(m)), curve.r)
+
+
+# --------------------------------------------------------------------------------------
 # R1CS / QAP / Groth16
 # --------------------------------------------------------------------------------------
 @dataclass
@@ -601,11 +850,26 @@ def swap_AB_if_beneficial(cs: R1CS) -> R1CS:
 
 
 def domain_size(cs: R1CS) -> int:
+    """size of the BASIC radix-2 domain that holds the instance (what a bare root of unity `w` stands for below)"""
     need = cs.num_constraints + cs.num_inputs + 1
     m = 1
     while m < need:
         m *= 2
     return m
+
+
+def qap_domain(curve: "Curve", cs: R1CS, two_adicity: Optional[int] = None) -> EvaluationDomain:
+    """the domain the reference reduces over: make_evaluation_domain(num_constraints + num_inputs + 1)
+    (r1cs_to_qap.hpp:138-139, 229-230)"""
+    return make_evaluation_domain(curve, cs.num_constraints + cs.num_inputs + 1, two_adicity)
+
+
+def _domain_of(cs: R1CS, w, r: int) -> EvaluationDomain:
+    """`w`: an EvaluationDomain, or a bare primitive root = the basic radix-2 domain of domain_size(cs) points"""
+    if isinstance(w, EvaluationDomain):
+        assert w.m >= cs.num_constraints + cs.num_inputs + 1
+        return w
+    return EvaluationDomain(EvaluationDomain.BASIC, domain_size(cs), w, r)
 
 
 def lagrange_at(m: int, w: int, t: int, r: int) -> List[int]:
@@ -628,10 +892,11 @@ def lagrange_at(m: int, w: int, t: int, r: int) -> List[int]:
     return out
 
 
-def qap_evaluate_at(cs: R1CS, t: int, w: int, r: int):
-    """r1cs_to_qap.hpp:138-187: (At, Bt, Ct, Ht, Zt) with At/Bt/Ct of length num_variables+1."""
-    m = domain_size(cs)
-    u = lagrange_at(m, w, t, r)
+def qap_evaluate_at(cs: R1CS, t: int, w, r: int):
+    """r1cs_to_qap.hpp:138-187: (At, Bt, Ct, Ht, Zt) with At/Bt/Ct of length num_variables+1.  `w`: see _domain_of."""
+    dom = _domain_of(cs, w, r)
+    m = dom.m
+    u = dom.evaluate_all_lagrange_polynomials(t)
     nv = cs.num_variables
     At = [0] * (nv + 1)
     Bt = [0] * (nv + 1)
@@ -646,13 +911,14 @@ def qap_evaluate_at(cs: R1CS, t: int, w: int, r: int):
         for idx, co in C:
             Ct[idx] = (Ct[idx] + u[i] * co) % r
     Ht = [pow(t, i, r) for i in range(m + 1)]
-    Zt = (pow(t, m, r) - 1) % r
+    Zt = dom.compute_vanishing_polynomial(t)
     return At, Bt, Ct, Ht, Zt
 
 
-def witness_map(cs: R1CS, primary, aux, w: int, g: int, r: int) -> List[int]:
-    """r1cs_to_qap.hpp:219-325 with d1=d2=d3=0: coefficients of H, length m+1."""
-    m = domain_size(cs)
+def witness_map(cs: R1CS, primary, aux, w, g: int, r: int) -> List[int]:
+    """r1cs_to_qap.hpp:219-325 with d1=d2=d3=0: coefficients of H, length m+1.  `w`: see _domain_of."""
+    dom = _domain_of(cs, w, r)
+    m = dom.m
     full = list(primary) + list(aux)
     aA = [0] * m
     aB = [0] * m
@@ -663,12 +929,11 @@ def witness_map(cs: R1CS, primary, aux, w: int, g: int, r: int) -> List[int]:
         aA[i] = (aA[i] + _lc_eval(A, full, r)) % r
         aB[i] = (aB[i] + _lc_eval(B, full, r)) % r
         aC[i] = (aC[i] + _lc_eval(C, full, r)) % r
-    aA = ntt(multiply_by_coset(intt(aA, w, r), g, r), w, r)
-    aB = ntt(multiply_by_coset(intt(aB, w, r), g, r), w, r)
-    aC = ntt(multiply_by_coset(intt(aC, w, r), g, r), w, r)
-    zinv = pow((pow(g, m, r) - 1) % r, -1, r)  # divide_by_z_on_coset: Z(g w^i) = g^m - 1
-    H = [((aA[i] * aB[i] - aC[i]) % r) * zinv % r for i in range(m)]
-    H = multiply_by_coset(intt(H, w, r), pow(g, -1, r), r)
+    aA = dom.fft(multiply_by_coset(dom.inverse_fft(aA), g, r))
+    aB = dom.fft(multiply_by_coset(dom.inverse_fft(aB), g, r))
+    aC = dom.fft(multiply_by_coset(dom.inverse_fft(aC), g, r))
+    H = dom.divide_by_z_on_coset([(aA[i] * aB[i] - aC[i]) % r for i in range(m)], g)  # :283-308
+    H = multiply_by_coset(dom.inverse_fft(H), pow(g, -1, r), r)
     return H + [0]
 
 
@@ -697,7 +962,7 @@ def groth16_keygen(curve: Curve, cs: R1CS, trapdoor, w: int) -> Groth16Key:
     n = cs.num_inputs
     N = cs.num_variables
     Lt = [(beta * At[i] + alpha * Bt[i] + Ct[i]) * dinv % r for i in range(n + 1, N + 1)]
-    m = domain_size(cs)
+    m = _domain_of(cs, w, r).m
     Hs = [Ht[i] * Zt % r * dinv % r for i in range(m - 1)]
     g1, g2 = curve.g1, curve.g2
     A_query = g1.batch_mul_gen(At)
@@ -723,7 +988,7 @@ def groth16_prove(curve: Curve, pk: Groth16Key, primary, aux, rr: int, ss: int, 
     g1, g2 = curve.g1, curve.g2
     cs = pk.cs
     H = witness_map(cs, primary, aux, w, curve.fr_generator, r)
-    m = domain_size(cs)
+    m = _domain_of(cs, w, r).m
     assert H[m - 1] == 0 and H[m] == 0
     cpa = [1] + list(primary) + list(aux)
     N = cs.num_variables

@@ -563,6 +563,206 @@ static void ntt_batch(uint64_t *data, size_t log_m, size_t batch, const uint64_t
 }
 
 // ------------------------------------------------------------------------------------------------
+// Evaluation domains: what math::make_evaluation_domain(min_size) returns (r1cs_to_qap.hpp:138-139, 229-230).
+// crypto3-math is not in /root/reference; this restates the published algorithm of its libfqfft lineage
+// (get_evaluation_domain: basic, extended, step radix-2 at min_size, then at big + rounded_small; the domains'
+// FFT / iFFT / evaluate_all_lagrange_polynomials / compute_vanishing_polynomial / divide_by_Z_on_coset).
+// Pinned by tests/test_oracle_kat.py against pyoracle.EvaluationDomain, which is held to the definitions over the
+// domain's point set.
+// ------------------------------------------------------------------------------------------------
+static inline size_t ceil_log2(size_t n) {
+    size_t r = 0;
+    while (((size_t)1 << r) < n) ++r;
+    return r;
+}
+enum { DOM_BASIC = 0, DOM_EXTENDED = 1, DOM_STEP = 2 };
+// (kind, m) for a field of the given two-adicity; returns false when only a geometric / arithmetic domain would do
+static bool domain_choice(size_t min_size, size_t s, int &kind, size_t &m) {
+    auto basic_ok = [&](size_t n) { return n > 1 && n == (size_t)1 << ceil_log2(n) && ceil_log2(n) <= s; };
+    auto ext_ok = [&](size_t n) { return n > 1 && ceil_log2(n) == s + 1 && n == (size_t)1 << (s + 1); };
+    auto step_ok = [&](size_t n) {
+        if (n <= 1) return false;
+        size_t small = n - ((size_t)1 << (ceil_log2(n) - 1));
+        return small == (size_t)1 << ceil_log2(small) && ceil_log2(n) <= s;
+    };
+    if (min_size <= 1) return false;
+    size_t big = (size_t)1 << (ceil_log2(min_size) - 1), small = min_size - big, rounded = big + ((size_t)1 << ceil_log2(small));
+    for (size_t n : {min_size, rounded}) {
+        if (basic_ok(n)) return kind = DOM_BASIC, m = n, true;
+        if (ext_ok(n)) return kind = DOM_EXTENDED, m = n, true;
+        if (step_ok(n)) return kind = DOM_STEP, m = n, true;
+    }
+    return false;
+}
+
+template <class S>
+struct Domain {
+    int kind = DOM_BASIC;
+    size_t m = 0, big_m = 0, small_m = 0, compr = 1;
+    S omega, shift, big_omega, small_omega;  // omega: basic m-th / extended (m/2)-th / step (2 big_m)-th primitive root
+
+    static Domain make(int kind, size_t m, const S &omega, const S &shift) {
+        Domain d;
+        d.kind = kind;
+        d.m = m;
+        d.omega = omega;
+        d.shift = shift;
+        if (kind == DOM_EXTENDED) {
+            d.small_m = m / 2;
+        } else if (kind == DOM_STEP) {
+            d.big_m = (size_t)1 << (ceil_log2(m) - 1);
+            d.small_m = m - d.big_m;
+            d.compr = d.big_m / d.small_m;
+            d.big_omega = omega * omega;
+            d.small_omega = omega.pow_u64(2 * d.compr);
+        }
+        return d;
+    }
+    static void basic_fft(std::vector<S> &a, const S &w) { ntt_inplace<S>(a.data(), ceil_log2(a.size()), w); }
+    static void scale(std::vector<S> &a, const S &c) {
+        for (auto &x : a) x = x * c;
+    }
+    // L_i(t) over {w^i}, i < n: (t^n - 1) w^i / (n (t - w^i)), one inversion
+    static std::vector<S> basic_lagrange(size_t n, const S &w, const S &t) {
+        std::vector<S> u(n), den(n), pre(n);
+        S x = S::one(), acc = S::one();
+        for (size_t i = 0; i < n; ++i) {
+            den[i] = t - x;
+            u[i] = x;
+            pre[i] = acc;
+            acc = acc * den[i];
+            x = x * w;
+        }
+        S inv = acc.inv(), z = (t.pow_u64(n) - S::one()) * S::from_u64(n).inv();
+        for (size_t i = n; i-- > 0;) {
+            S di = inv * pre[i];
+            inv = inv * den[i];
+            u[i] = u[i] * z * di;
+        }
+        return u;
+    }
+    void fft(std::vector<S> &a) const {
+        if (kind == DOM_BASIC) return basic_fft(a, omega);
+        if (kind == DOM_EXTENDED) {
+            std::vector<S> a0(small_m), a1(small_m);
+            S s_sm = shift.pow_u64(small_m), x = S::one();
+            for (size_t i = 0; i < small_m; ++i) {
+                a0[i] = a[i] + a[small_m + i];
+                a1[i] = x * (a[i] + s_sm * a[small_m + i]);
+                x = x * shift;
+            }
+            basic_fft(a0, omega);
+            basic_fft(a1, omega);
+            for (size_t i = 0; i < small_m; ++i) a[i] = a0[i], a[small_m + i] = a1[i];
+            return;
+        }
+        std::vector<S> c(big_m), e(small_m, S::zero());
+        S wi = S::one();
+        for (size_t i = 0; i < big_m; ++i) {
+            c[i] = i < small_m ? a[i] + a[i + big_m] : a[i];
+            S d = wi * (i < small_m ? a[i] - a[i + big_m] : a[i]);
+            e[i % small_m] = e[i % small_m] + d;
+            wi = wi * omega;
+        }
+        basic_fft(c, big_omega);
+        basic_fft(e, small_omega);
+        for (size_t i = 0; i < big_m; ++i) a[i] = c[i];
+        for (size_t i = 0; i < small_m; ++i) a[big_m + i] = e[i];
+    }
+    void ifft(std::vector<S> &a) const {
+        if (kind == DOM_BASIC) {
+            basic_fft(a, omega.inv());
+            scale(a, S::from_u64(m).inv());
+            return;
+        }
+        if (kind == DOM_EXTENDED) {
+            std::vector<S> a0(a.begin(), a.begin() + small_m), a1(a.begin() + small_m, a.end());
+            S winv = omega.inv();
+            basic_fft(a0, winv);
+            basic_fft(a1, winv);
+            S s_sm = shift.pow_u64(small_m), sconst = (S::from_u64(small_m) * (S::one() - s_sm)).inv(), shinv = shift.inv(), x = S::one();
+            for (size_t i = 0; i < small_m; ++i) {
+                a[i] = sconst * (x * a1[i] - s_sm * a0[i]);
+                a[small_m + i] = sconst * (a0[i] - x * a1[i]);
+                x = x * shinv;
+            }
+            return;
+        }
+        std::vector<S> U0(a.begin(), a.begin() + big_m), U1(a.begin() + big_m, a.end());
+        basic_fft(U0, big_omega.inv());
+        basic_fft(U1, small_omega.inv());
+        scale(U0, S::from_u64(big_m).inv());
+        scale(U1, S::from_u64(small_m).inv());
+        S wi = S::one();
+        for (size_t i = 0; i < big_m; ++i) {
+            if (i >= small_m) {
+                a[i] = U0[i];
+                U1[i % small_m] = U1[i % small_m] - U0[i] * wi;
+            }
+            wi = wi * omega;
+        }
+        S winv = omega.inv(), x = S::one(), half = S::from_u64(2).inv();
+        for (size_t i = 0; i < small_m; ++i) {
+            S u1 = U1[i] * x;
+            a[i] = (U0[i] + u1) * half;
+            a[big_m + i] = (U0[i] - u1) * half;
+            x = x * winv;
+        }
+    }
+    S vanishing(const S &t) const {
+        if (kind == DOM_BASIC) return t.pow_u64(m) - S::one();
+        if (kind == DOM_EXTENDED) {
+            S tm = t.pow_u64(small_m);
+            return (tm - S::one()) * (tm - shift.pow_u64(small_m));
+        }
+        return (t.pow_u64(big_m) - S::one()) * (t.pow_u64(small_m) - omega.pow_u64(small_m));
+    }
+    std::vector<S> lagrange(const S &t) const {
+        if (kind == DOM_BASIC) return basic_lagrange(m, omega, t);
+        std::vector<S> out(m);
+        if (kind == DOM_EXTENDED) {
+            auto T0 = basic_lagrange(small_m, omega, t), T1 = basic_lagrange(small_m, omega, t * shift.inv());
+            S t_sm = t.pow_u64(small_m), s_sm = shift.pow_u64(small_m), ood = (s_sm - S::one()).inv();
+            S c0 = (s_sm - t_sm) * ood, c1 = (t_sm - S::one()) * ood;
+            for (size_t i = 0; i < small_m; ++i) out[i] = T0[i] * c0, out[small_m + i] = T1[i] * c1;
+            return out;
+        }
+        auto ib = basic_lagrange(big_m, big_omega, t), is = basic_lagrange(small_m, small_omega, t * omega.inv());
+        S w_sm = omega.pow_u64(small_m), L0 = t.pow_u64(small_m) - w_sm;
+        // 1 / (big_omega^(small_m i) - omega^small_m) takes compr distinct values
+        std::vector<S> dinv(compr);
+        S step = big_omega.pow_u64(small_m), elt = S::one();
+        for (size_t i = 0; i < compr; ++i) {
+            dinv[i] = (elt - w_sm).inv();
+            elt = elt * step;
+        }
+        for (size_t i = 0; i < big_m; ++i) out[i] = ib[i] * L0 * dinv[i % compr];
+        S L1 = (t.pow_u64(big_m) - S::one()) * (omega.pow_u64(big_m) - S::one()).inv();
+        for (size_t i = 0; i < small_m; ++i) out[big_m + i] = L1 * is[i];
+        return out;
+    }
+    // P[i] /= Z(g x_i) with P the evaluations on the coset g * domain
+    void divide_by_z_on_coset(std::vector<S> &P, const S &g) const {
+        if (kind == DOM_BASIC) return scale(P, vanishing(g).inv());
+        if (kind == DOM_EXTENDED) {
+            S z0 = vanishing(g).inv(), z1 = vanishing(g * shift).inv();
+            for (size_t i = 0; i < small_m; ++i) P[i] = P[i] * z0, P[small_m + i] = P[small_m + i] * z1;
+            return;
+        }
+        S Z0 = g.pow_u64(big_m) - S::one(), a = g.pow_u64(small_m) * Z0, b = omega.pow_u64(small_m) * Z0;
+        std::vector<S> zi(compr);
+        S step = omega.pow_u64(2 * small_m), elt = S::one();
+        for (size_t i = 0; i < compr; ++i) {
+            zi[i] = (a * elt - b).inv();
+            elt = elt * step;
+        }
+        for (size_t i = 0; i < big_m; ++i) P[i] = P[i] * zi[i % compr];
+        S z1 = vanishing(g * omega).inv();
+        for (size_t i = 0; i < small_m; ++i) P[big_m + i] = P[big_m + i] * z1;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
 // splitmix64, shared with pyoracle.SplitMix64
 // ------------------------------------------------------------------------------------------------
 struct SplitMix64 {
@@ -600,6 +800,17 @@ struct G16 {
     typedef typename Tr<CURVE, 1>::F F1;
     typedef typename Tr<CURVE, 2>::F F2;
     size_t M = 0, n = 0, N = 0, m = 0, log_m = 0;
+    // the evaluation domain: unset = the BASIC radix-2 domain of m = 2^log_m >= M + n + 1 points over the omega each call passes;
+    // set_domain() installs what make_evaluation_domain(M + n + 1) picks (or any other) and then every call uses it
+    bool dom_set = false;
+    Domain<S> dom;
+    Domain<S> domain(const S &omega) const { return dom_set ? dom : Domain<S>::make(DOM_BASIC, m, omega, S::zero()); }
+    void set_domain(int kind, size_t size, const S &omega, const S &shift) {
+        dom = Domain<S>::make(kind, size, omega, shift);
+        dom_set = true;
+        m = size;
+        log_m = ceil_log2(size);
+    }
     Csr<S> A, B, C;
     std::vector<S> assignment;  // N values (primary then auxiliary)
     // key
@@ -702,28 +913,9 @@ struct G16 {
     // r1cs_to_qap.hpp:138-187
     void qap_at(const S &t, const S &omega, std::vector<S> &At, std::vector<S> &Bt, std::vector<S> &Ct,
                 S &Zt) const {
-        // Lagrange basis on {omega^i}: L_i(t) = Z(t) omega^i / (m (t - omega^i)), batch-inverted
-        S tm = t.pow_u64(m);
-        Zt = tm - S::one();
-        std::vector<S> u(m), den(m), pre(m);
-        S x = S::one();
-        for (size_t i = 0; i < m; ++i) {
-            den[i] = t - x;
-            u[i] = x;
-            x = x * omega;
-        }
-        S acc = S::one();
-        for (size_t i = 0; i < m; ++i) {
-            pre[i] = acc;
-            acc = acc * den[i];
-        }
-        S inv = acc.inv();
-        S z = Zt * S::from_u64(m).inv();
-        for (size_t i = m; i-- > 0;) {
-            S di = inv * pre[i];
-            inv = inv * den[i];
-            u[i] = u[i] * z * di;
-        }
+        const Domain<S> d = domain(omega);
+        Zt = d.vanishing(t);
+        const std::vector<S> u = d.lagrange(t);
         At.assign(N + 1, S::zero());
         Bt.assign(N + 1, S::zero());
         Ct.assign(N + 1, S::zero());
@@ -824,15 +1016,15 @@ struct G16 {
             aB[i] = aB[i] + B.row_dot(i, f);
             aC[i] = aC[i] + C.row_dot(i, f);
         }
-        S oinv = omega.inv(), minv = S::from_u64(m).inv();
+        const Domain<S> d = domain(omega);
         auto coset_fft = [&](std::vector<S> &a) {
-            ntt_inplace<S>(a.data(), log_m, oinv);
-            S x = minv;
+            d.ifft(a);
+            S x = S::one();
             for (size_t i = 0; i < m; ++i) {
                 a[i] = a[i] * x;
                 x = x * g;
             }
-            ntt_inplace<S>(a.data(), log_m, omega);
+            d.fft(a);
         };
 #pragma omp parallel sections
         {
@@ -843,11 +1035,11 @@ struct G16 {
 #pragma omp section
             coset_fft(aC);
         }
-        S zinv = (g.pow_u64(m) - S::one()).inv();
 #pragma omp parallel for
-        for (size_t i = 0; i < m; ++i) aA[i] = (aA[i] * aB[i] - aC[i]) * zinv;
-        ntt_inplace<S>(aA.data(), log_m, oinv);
-        S ginv = g.inv(), x = minv;
+        for (size_t i = 0; i < m; ++i) aA[i] = aA[i] * aB[i] - aC[i];
+        d.divide_by_z_on_coset(aA, g);
+        d.ifft(aA);
+        S ginv = g.inv(), x = S::one();
         for (size_t i = 0; i < m; ++i) {
             aA[i] = aA[i] * x;
             x = x * ginv;
@@ -1120,6 +1312,42 @@ int zko_g16_dims(void *hv, uint64_t *d) {
         d[6] = g->B.col.size();
         d[7] = g->C.col.size();
     });
+    return 0;
+}
+// kind: 0 basic, 1 extended, 2 step radix-2; omega / shift as pyoracle.EvaluationDomain takes them (shift nullable)
+int zko_g16_set_domain(void *hv, int kind, size_t m, const uint64_t *omega, const uint64_t *shift) {
+    G16Handle *h = (G16Handle *)hv;
+    G16_DISPATCH(h, {
+        typedef typename std::remove_reference<decltype(*g)>::type GT;
+        typedef typename GT::S S;
+        if (m < g->M + g->n + 1) return -1;
+        g->set_domain(kind, m, S::from_canonical(omega), shift ? S::from_canonical(shift) : S::zero());
+    });
+    return 0;
+}
+// what make_evaluation_domain(min_size) picks over a field of the given two-adicity: out = {kind, m}; -1: none of the radix-2 family
+int zko_domain_choice(size_t min_size, size_t two_adicity, uint64_t *out) {
+    int kind;
+    size_t m;
+    if (!domain_choice(min_size, two_adicity, kind, m)) return -1;
+    out[0] = (uint64_t)kind;
+    out[1] = m;
+    return 0;
+}
+// in-place transform of one vector of m elements over a domain (for the tests of the device transforms)
+int zko_domain_fft(int curve, int kind, size_t m, const uint64_t *omega, const uint64_t *shift, uint64_t *data, int inverse) {
+    auto run = [&](auto tag) {
+        typedef decltype(tag) S;
+        Domain<S> d = Domain<S>::make(kind, m, S::from_canonical(omega), shift ? S::from_canonical(shift) : S::zero());
+        std::vector<S> a(m);
+        for (size_t i = 0; i < m; ++i) a[i] = S::from_canonical(data + 4 * i);
+        if (inverse) d.ifft(a);
+        else d.fft(a);
+        for (size_t i = 0; i < m; ++i) a[i].to_canonical(data + 4 * i);
+    };
+    if (curve == 0) run(typename Tr<0, 1>::S());
+    else if (curve == 1) run(typename Tr<1, 1>::S());
+    else return -1;
     return 0;
 }
 int zko_g16_is_satisfied(void *hv) {

@@ -195,3 +195,106 @@ def test_lpc_oracle_definitions():
                                                    [etha, etha, theta, a0, a1], root)
     assert len(fri_roots) == 2 and len(final) == 16 and not any(final[16 // 4:])
     assert z[1][0][0] == po.poly_eval(po.intt(evals[2], C.root_of_unity(4), r), p1, r)
+
+
+# ---- evaluation domains: crypto3-math is absent from the reference tree, so the restatement of
+# make_evaluation_domain's radix-2 family is pinned to the DEFINITIONS over each domain's point set --------------------
+def _domain_definitions(C, dom, rng):
+    r, m, xs = C.r, dom.m, dom.elements()
+    assert len(set(xs)) == m
+    a = [rng.next_mod(r) for _ in range(m)]
+    ev = [po.poly_eval(a, x, r) for x in xs]
+    assert dom.fft(a) == ev                       # fft = evaluation at get_domain_element(i)
+    assert dom.inverse_fft(ev) == a               # inverse_fft = interpolation
+    t = rng.next_mod(r)
+    Z = 1
+    for x in xs:
+        Z = Z * (t - x) % r
+    assert dom.compute_vanishing_polynomial(t) == Z
+    lag = []
+    for i, x in enumerate(xs):
+        num = den = 1
+        for j, y in enumerate(xs):
+            if i != j:
+                num, den = num * (t - y) % r, den * (x - y) % r
+        lag.append(num * pow(den, -1, r) % r)
+    assert dom.evaluate_all_lagrange_polynomials(t) == lag
+    g = C.fr_generator
+    P = [rng.next_mod(r) for _ in range(m)]
+    assert dom.divide_by_z_on_coset(P, g) == [P[i] * pow(dom.compute_vanishing_polynomial(g * xs[i] % r), -1, r) % r for i in range(m)]
+    # multiply_by_coset + fft = evaluation on g * domain (what divide_by_z_on_coset is applied to, r1cs_to_qap.hpp:266-308)
+    assert dom.fft(po.multiply_by_coset(a, g, r)) == [po.poly_eval(a, g * x % r, r) for x in xs]
+    H = [rng.next_mod(r) for _ in range(m + 1)]
+    H2, c, zc = list(H), rng.next_mod(r), po.vanishing_poly(xs, r)
+    dom.add_poly_z(c, H2)
+    assert H2 == [(H[i] + c * zc[i]) % r for i in range(m + 1)]
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_evaluation_domain_definitions(curve):
+    C = CURVES[curve]
+    rng = po.SplitMix64(21 + curve)
+    for n in (2, 3, 5, 6, 9, 10, 12, 17, 18, 19, 20, 24, 27, 33, 40, 48):
+        _domain_definitions(C, po.make_evaluation_domain(C, n), rng)
+    for s in (1, 2, 3, 4):    # the extended domain exists at 2^(s+1) points only: pretend a small two-adicity
+        dom = po.make_evaluation_domain(C, 1 << (s + 1), two_adicity=s)
+        assert dom.kind == po.EvaluationDomain.EXTENDED
+        _domain_definitions(C, dom, rng)
+
+
+def test_evaluation_domain_selection():
+    """the order of get_evaluation_domain: basic, extended, step at min_size, then at big + rounded_small"""
+    B, E, S = po.EvaluationDomain.BASIC, po.EvaluationDomain.EXTENDED, po.EvaluationDomain.STEP
+    table = {2: (B, 2), 3: (S, 3), 7: (B, 8),          # 7 = 4 + 3: step(7) fails (3 is no power of two), 4 + 4 = 8 is basic
+             11: (S, 12), 19: (S, 20), 27: (B, 32), 1 << 20: (B, 1 << 20),
+             (1 << 20) + 11: (S, (1 << 20) + 16),      # BASELINE cfg 4: M = 2^20, n = 10
+             (1 << 15) + 16: (S, (1 << 15) + 16), (1 << 10) + 11: (S, (1 << 10) + 16), (1 << 4) + 3: (S, 20),
+             (1 << 20) + (1 << 19) + 1: (B, 1 << 21)}
+    for n, exp in table.items():
+        assert po.evaluation_domain_choice(n, 32) == exp, n
+        assert cp.domain_choice(n, 32) == exp, n
+    # beyond the two-adicity (BN254: s = 28): the extended domain at exactly 2^(s+1), also reached by rounding up
+    for n in (1 << 29, (1 << 28) + (1 << 27) + 1):
+        assert po.evaluation_domain_choice(n, 28) == (E, 1 << 29) and cp.domain_choice(n, 28) == (E, 1 << 29)
+    with pytest.raises(ValueError):    # only a geometric / arithmetic sequence domain would do: out of scope
+        po.evaluation_domain_choice((1 << 28) + 5, 28)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_evaluation_domain_cport(curve):
+    """the C++ restatement's domains against pyoracle's: transforms, and the whole Groth16 pipeline over the domain
+    make_evaluation_domain(M + n + 1) picks (witness map, key, proof == the trapdoor identity)"""
+    C = CURVES[curve]
+    r = C.r
+    rng = po.SplitMix64(5 + curve)
+    for n, s in ((3, None), (5, None), (12, None), (20, None), (48, None), (1040, None), (32, None), (16, 3)):
+        dom = po.make_evaluation_domain(C, n, two_adicity=s)
+        a = [rng.next_mod(r) for _ in range(dom.m)]
+        f = cp.domain_fft(curve, dom.kind, fr_arr(a), limbs(dom.omega, 4), limbs(dom.shift, 4))
+        assert fr_ints(f) == dom.fft(a)
+        assert fr_ints(cp.domain_fft(curve, dom.kind, f, limbs(dom.omega, 4), limbs(dom.shift, 4), inverse=True)) == a
+    for M, n in ((8, 2), (13, 3), (16, 3), (1024, 11)):
+        cs, prim, aux = po.r1cs_example_field_input(r, M, n, 7)
+        dom = po.qap_domain(C, cs)
+        assert dom.kind == po.EvaluationDomain.STEP
+        g = cp.Groth16(curve, M, n, 7)
+        g.set_domain(dom.kind, dom.m, limbs(dom.omega, 4), limbs(dom.shift, 4))
+        assert g.m == dom.m
+        trap = [rng.next_mod(r) for _ in range(5)]
+        rr, ss = rng.next_mod(r), rng.next_mod(r)
+        w, gen = limbs(dom.omega, 4), limbs(C.fr_generator, 4)
+        small = M <= 16
+        if small:
+            assert fr_ints(g.witness_map(w, gen)) == po.witness_map(cs, prim, aux, dom, C.fr_generator, r)
+        ex = [po.from_limbs(x) for x in g.expected_exponents(fr_arr(trap), w, limbs(rr, 4), limbs(ss, 4))]
+        G1, G2 = C.g1, C.g2
+        expect = (G1.mul(G1.gen, ex[0]), G2.mul(G2.gen, ex[1]), G1.mul(G1.gen, ex[2]))
+        if small:
+            assert po.groth16_expected_in_exponent(C, cs, prim, aux, trap, rr, ss, dom) == expect
+            pk = po.groth16_keygen(C, cs, trap, dom)
+            assert len(pk.H_query) == dom.m - 1
+            assert po.groth16_prove(C, pk, prim, aux, rr, ss, dom) == expect
+        g.keygen(fr_arr(trap), w)
+        assert g.query(3)[0].shape[0] == dom.m - 1
+        proof = g.prove(limbs(rr, 4), limbs(ss, 4), w, gen, chunks=2)
+        assert (proof == np.concatenate([pt_limbs(curve, 1, expect[0]), pt_limbs(curve, 2, expect[1]), pt_limbs(curve, 1, expect[2])])).all()
