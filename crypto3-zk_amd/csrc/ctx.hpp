@@ -64,6 +64,7 @@ struct ZkProfile {
 };
 
 struct NttTables;  // ntt.hip
+struct DomTables;  // domain.hip
 
 // a captured launch sequence (HIP graph) of one MSM / MSM batch, replayed when the same call comes again
 struct ZkGraph {
@@ -108,6 +109,9 @@ struct zkhip_ctx {
     int opt_msm_precompute_min = 32;  // without tables the windows are combined by a serial Horner pass (~255 doublings on one lane: 3.8 ms)
     ZkProfile prof;
     std::vector<NttTables *> ntt_tables;
+    std::vector<DomTables *> dom_tables;  // step / extended radix-2 domains (domain.hip)
+    char *dom_ws = nullptr;               // scratch of zkhip_domain_fft_dev (the NTTs inside it use `ws`)
+    size_t dom_ws_cap = 0;
 
     int ws_reserve(size_t bytes) {
         if (bytes <= ws_cap) return 0;
@@ -218,3 +222,4 @@ int zk_jac_to_affine(zkhip_ctx *ctx, int curve, int group, const uint32_t *d_jac
 int zk_ntt_run(zkhip_ctx *ctx, int curve, uint32_t *d_data, size_t log_m, size_t batch, const uint64_t *omega, int inverse,
                const uint64_t *coset);
 void zk_ntt_free_tables(zkhip_ctx *ctx);
+void zk_dom_free_tables(zkhip_ctx *ctx);

@@ -5,21 +5,26 @@
 //     aA[i] = <A_i, z>, aB[i] = <B_i, z>, aC[i] = <C_i, z>          (:245-248, :288-291)  sparse mat-vec
 //     aA[M + i] = z_i for i <= n (input-consistency rows)             (:240-243)
 //     inverse_fft; multiply_by_coset(g); fft    on aA, aB, aC         (:250-276, :293-299)  6 NTTs, batched x3
-//     H_tmp = (aA o aB - aC) / Z(g w^i),  Z on the coset = g^m - 1    (:283-308)            one pointwise pass
+//     H_tmp = (aA o aB - aC) / Z on the coset (divide_by_z_on_coset)  (:283-308)            one pointwise pass
 //     inverse_fft; multiply_by_coset(g^-1)                            (:310-315)            1 NTT
 //     coefficients_for_H = H_tmp | 0                                  (m + 1 entries)
 // z = (1, primary, auxiliary) and all vectors stay in HBM; the result is consumed in place by zkhip_msm_dev.
+// The transforms run over the domain make_evaluation_domain(M + n + 1) picks (:229-230) -- basic, extended or step radix-2,
+// domain.hip -- with every vector held split in (part 0, part 1) of that domain.
 #include <algorithm>
 #include <cstring>
 
 #include "ctx.hpp"
+#include "domain.hpp"
 #include "fu.hpp"
 
 using namespace zkhip;
 
 struct zkhip_r1cs {
     int curve;
-    size_t M, n, N, m, log_m;
+    size_t M, n, N, m;
+    int dkind = ZKHIP_DOMAIN_BASIC_RADIX2;  // the evaluation domain's kind and split (domain.hpp): m = n0 + n1
+    size_t n0 = 0, n1 = 0;
     // CSR, three matrices; coefficients in Montgomery form of the lazy Fr type (SL words each)
     uint32_t *rowptr[3] = {nullptr, nullptr, nullptr};
     uint32_t *col[3] = {nullptr, nullptr, nullptr};
@@ -28,13 +33,16 @@ struct zkhip_r1cs {
     uint32_t n_long[3] = {0, 0, 0};
     size_t nnz[3] = {0, 0, 0};
     size_t long_terms[3] = {0, 0, 0};  // total terms in long rows
-    // 1 / Z on the coset (groth16_h_setup: a field inversion on one lane, 0.3 ms) cached per coset generator
-    mutable uint32_t *h_consts = nullptr;
-    mutable uint64_t h_consts_coset[4] = {0, 0, 0, 0};
-    mutable bool h_consts_valid = false;
 };
 
 static constexpr uint32_t LONG_ROW = 64;
+
+// one vector of m = n0 + n1 elements held split: element r lives at p0 + 8 r (r < n0) or p1 + 8 (r - n0)
+struct SplitVec {
+    uint32_t *p0, *p1;
+    uint32_t n0;
+    ZK_D uint32_t *at(uint32_t r) const { return r < n0 ? p0 + (size_t)r * 8 : p1 + (size_t)(r - n0) * 8; }
+};
 
 // value < 2p (product output) -> [0, p)
 template <class U>
@@ -55,7 +63,7 @@ __global__ __launch_bounds__(256) void r1cs_coeff_to_mont(const uint32_t *__rest
 template <class U>
 __global__ __launch_bounds__(256) void r1cs_eval_rows(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
                                                       const uint32_t *__restrict__ coeff, const uint32_t *__restrict__ z, uint32_t M,
-                                                      uint32_t *__restrict__ out) {
+                                                      SplitVec out) {
     uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= M) return;
     uint32_t lo = rowptr[row], hi = rowptr[row + 1];
@@ -65,7 +73,7 @@ __global__ __launch_bounds__(256) void r1cs_eval_rows(const uint32_t *__restrict
         Fu<U> t = fu_mul(fu_unpack<U>(z + (size_t)col[k] * U::NL), fu_load<U>(coeff + (size_t)k * U::SL));
         acc = fr_add_mod(acc, fr_reduce(t));
     }
-    fu_pack<U>(out + (size_t)row * U::NL, acc);
+    fu_pack<U>(out.at(row), acc);
 }
 
 // one workgroup per long row: strided partial sums, LDS tree
@@ -104,23 +112,24 @@ __global__ __launch_bounds__(256) void r1cs_eval_long(const uint32_t *__restrict
 // out[row] = sum of the row's `nslice` partial sums
 template <class U>
 __global__ __launch_bounds__(64) void r1cs_long_combine(const uint32_t *__restrict__ long_rows, uint32_t n_long, uint32_t nslice,
-                                                        const uint32_t *__restrict__ partial, uint32_t *__restrict__ out) {
+                                                        const uint32_t *__restrict__ partial, SplitVec out) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_long) return;
     Fu<U> acc = Fu<U>::zero();
     for (uint32_t s = 0; s < nslice; ++s) acc = fr_add_mod(acc, fu_load<U>(partial + ((size_t)j * nslice + s) * U::SL));
-    fu_pack<U>(out + (size_t)long_rows[j] * U::NL, acc);
+    fu_pack<U>(out.at(long_rows[j]), acc);
 }
 
 // rows M .. m-1 of the three vectors: aA[M + i] = z_i (i <= n), everything else zero
 template <class U>
-__global__ __launch_bounds__(256) void r1cs_fill_tail(uint32_t *__restrict__ abc, const uint32_t *__restrict__ z, uint32_t M, uint32_t n,
-                                                      uint32_t m) {
+__global__ __launch_bounds__(256) void r1cs_fill_tail(uint32_t *__restrict__ p0, uint32_t *__restrict__ p1, uint32_t n0, uint32_t n1,
+                                                      const uint32_t *__restrict__ z, uint32_t M, uint32_t n, uint32_t m) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // index in [M, m) x 3
     uint32_t tail = m - M;
     if (i >= 3 * tail) return;
     uint32_t mat = i / tail, r = M + i % tail;
-    uint4 *dst = reinterpret_cast<uint4 *>(abc + ((size_t)mat * m + r) * U::NL);
+    const SplitVec v{p0 + (size_t)mat * n0 * 8, p1 + (size_t)mat * n1 * 8, n0};
+    uint4 *dst = reinterpret_cast<uint4 *>(v.at(r));
     uint4 a = make_uint4(0, 0, 0, 0), b = a;
     if (mat == 0 && r - M <= n) {
         const uint4 *src = reinterpret_cast<const uint4 *>(z + (size_t)(r - M) * U::NL);
@@ -131,31 +140,22 @@ __global__ __launch_bounds__(256) void r1cs_fill_tail(uint32_t *__restrict__ abc
     dst[1] = b;
 }
 
-// consts[0] = zinv = 1/(g^m - 1) in Montgomery form, consts[1] = zinv * R (so that mul(mul(a, b), consts[1]) = a b zinv)
+// h[i] = (a[i] b[i] - c[i]) / Z(g x_i) (divide_by_z_on_coset), canonical in and out.  The three vectors are split like the
+// domain (part 0: 3 x n0, part 1: 3 x n1); zinv: nz Montgomery entries for part 0 (entry i mod nz), then the one of part 1; h is
+// contiguous (part 1 follows part 0).
 template <class U>
-__global__ void groth16_h_setup(const uint32_t *__restrict__ coset_c, uint32_t log_m, uint32_t *__restrict__ consts) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    Fu<U> g = fu_from_canonical<U>(coset_c);
-    Fu<U> gm = g;
-    for (uint32_t i = 0; i < log_m; ++i) gm = fu_mul_call(gm, gm);
-    Fu<U> zinv = fu_inv(fu_sub<4>(gm, Fu<U>::one()));
-    fu_store<U>(consts, fu_cond_sub_p(zinv));
-    fu_store<U>(consts + U::SL, fu_cond_sub_p(fu_mul_call(zinv, Fu<U>::r2())));
-}
-
-// h[i] = (a[i] b[i] - c[i]) * zinv, canonical in and out
-template <class U>
-__global__ __launch_bounds__(256) void groth16_h_pointwise(const uint32_t *__restrict__ abc, uint32_t m, const uint32_t *__restrict__ consts,
-                                                           uint32_t *__restrict__ h) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    Fu<U> a = fu_unpack<U>(abc + (size_t)i * U::NL), b = fu_unpack<U>(abc + ((size_t)m + i) * U::NL),
-          c = fu_unpack<U>(abc + ((size_t)2 * m + i) * U::NL);
-    Fu<U> k1 = fu_load<U>(consts), k2 = fu_load<U>(consts + U::SL);
-    Fu<U> ab = fu_mul(fu_mul(a, b), k2);  // a b zinv        (< 2p)
-    Fu<U> cz = fu_mul(c, k1);             // c zinv          (< 2p)
-    Fu<U> r = fu_sub<4>(ab, cz);          // < 6p
-    fu_pack<U>(h + (size_t)i * U::NL, fu_canon(r));  // canonical Montgomery form of r, i.e. r itself as an integer mod p
+__global__ __launch_bounds__(256) void groth16_h_pointwise(const uint32_t *__restrict__ p0, const uint32_t *__restrict__ p1, uint32_t n0, uint32_t n1,
+                                                           const uint32_t *__restrict__ zinv, uint32_t nz, uint32_t *__restrict__ h) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n0 + n1) return;
+    const bool lo = e < n0;
+    const uint32_t *base = lo ? p0 : p1;
+    const size_t i = lo ? e : e - n0, stride = lo ? n0 : n1;
+    Fu<U> a = fu_unpack<U>(base + i * U::NL), b = fu_unpack<U>(base + (stride + i) * U::NL), c = fu_unpack<U>(base + (2 * stride + i) * U::NL);
+    Fu<U> k = fu_unpack<U>(zinv + (size_t)(lo ? e & (nz - 1) : nz) * 8);
+    Fu<U> ab = fu_mul(fu_mul(a, Fu<U>::r2()), b);  // a b as an integer mod p (< 2p)
+    Fu<U> r = fu_mul(fu_sub<2>(ab, c), k);         // (a b - c) zinv       (< 2p)
+    fu_pack<U>(h + (size_t)e * U::NL, fu_cond_sub_p(r));
 }
 
 // dst[j] = src[idx[j]] on 32-byte elements: the scalar side of a sparse query (B_query.indices)
@@ -221,11 +221,13 @@ static int r1cs_upload_t(zkhip_ctx *ctx, zkhip_r1cs *r, const uint32_t *const ro
 }
 
 template <class U>
-static int witness_h_t(zkhip_ctx *ctx, const zkhip_r1cs *r, const uint32_t *d_z, const uint64_t *omega, const uint64_t *coset, uint32_t *d_h,
-                       uint32_t *d_abc) {
-    const uint32_t M = (uint32_t)r->M, m = (uint32_t)r->m;
+static int witness_h_t(zkhip_ctx *ctx, const zkhip_r1cs *r, const uint32_t *d_z, const ZkDomain &dom, const uint64_t *coset, uint32_t *d_h,
+                       uint32_t *d_scratch) {
+    const uint32_t M = (uint32_t)r->M, m = (uint32_t)r->m, n0 = (uint32_t)dom.n0, n1 = (uint32_t)dom.n1;
+    // scratch: the three vectors split like the domain (3 x n0, then 3 x n1), then the domain's own scratch
+    uint32_t *p0 = d_scratch, *p1 = p0 + (size_t)3 * n0 * 8, *dscr = p1 + (size_t)3 * n1 * 8;
     for (int k = 0; k < 3; ++k) {
-        uint32_t *out = d_abc + (size_t)k * m * U::NL;
+        const SplitVec out{p0 + (size_t)k * n0 * 8, p1 + (size_t)k * n1 * 8, n0};
         ZK_LAUNCH(ctx, "r1cs_eval_rows", r1cs_eval_rows<U>, dim3((M + 255) / 256), dim3(256), 0, r->rowptr[k], r->col[k], r->coeff[k], d_z, M, out);
         if (r->n_long[k]) {
             // slices of ~4096 terms, at most 64 per row; per-slice partial sums live in the context workspace
@@ -239,24 +241,33 @@ static int witness_h_t(zkhip_ctx *ctx, const zkhip_r1cs *r, const uint32_t *d_z,
                       partial, out);
         }
     }
-    if (m > M) ZK_LAUNCH(ctx, "r1cs_fill_tail", r1cs_fill_tail<U>, dim3((3 * (m - M) + 255) / 256), dim3(256), 0, d_abc, d_z, M, (uint32_t)r->n, m);
-    // coefficients, then evaluations on the coset g<omega>
-    ZK_TRY(zk_ntt_run(ctx, r->curve, d_abc, r->log_m, 3, omega, 1, nullptr));
-    ZK_TRY(zk_ntt_run(ctx, r->curve, d_abc, r->log_m, 3, omega, 0, coset));
-    // 1 / Z(coset) constants: computed once per (constraint system, coset generator), kept with the constraint system
-    if (!r->h_consts) ZK_HIP_CHECK(ctx, hipMalloc((void **)&r->h_consts, (2 * U::SL + 8) * 4));
-    uint32_t *consts = r->h_consts;
-    if (!r->h_consts_valid || memcmp(r->h_consts_coset, coset, 32) != 0) {
-        uint32_t *d_g = consts + 2 * U::SL;
-        ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_g, coset, 32, hipMemcpyHostToDevice, ctx->stream));
-        ZK_LAUNCH(ctx, "groth16_h_setup", groth16_h_setup<U>, dim3(1), dim3(64), 0, d_g, (uint32_t)r->log_m, consts);
-        memcpy(r->h_consts_coset, coset, 32);
-        r->h_consts_valid = true;
-    }
-    ZK_LAUNCH(ctx, "groth16_h_pointwise", groth16_h_pointwise<U>, dim3((m + 255) / 256), dim3(256), 0, d_abc, m, consts, d_h);
-    ZK_TRY(zk_ntt_run(ctx, r->curve, d_h, r->log_m, 1, omega, 1, coset));
+    if (m > M) ZK_LAUNCH(ctx, "r1cs_fill_tail", r1cs_fill_tail<U>, dim3((3 * (m - M) + 255) / 256), dim3(256), 0, p0, p1, n0, n1, d_z, M, (uint32_t)r->n, m);
+    // coefficients, then evaluations on the coset g * domain
+    ZK_TRY(zk_dom_fft_split(ctx, r->curve, dom, p0, p1, 3, 1, nullptr, dscr));
+    ZK_TRY(zk_dom_fft_split(ctx, r->curve, dom, p0, p1, 3, 0, coset, dscr));
+    // 1 / Z on the coset: a table the domain caches per coset generator
+    const uint32_t *zinv = nullptr;
+    size_t nz = 1;
+    ZK_TRY(zk_dom_zinv(ctx, r->curve, dom, coset, &zinv, &nz));
+    ZK_LAUNCH(ctx, "groth16_h_pointwise", groth16_h_pointwise<U>, dim3((m + 255) / 256), dim3(256), 0, p0, p1, n0, n1, zinv, (uint32_t)nz, d_h);
+    ZK_TRY(zk_dom_fft_split(ctx, r->curve, dom, d_h, d_h + (size_t)n0 * 8, 1, 1, coset, dscr));
     ZK_LAUNCH(ctx, "fr_zero_one", fr_zero_one<U>, dim3(1), dim3(64), 0, d_h + (size_t)m * U::NL);
     return 0;
+}
+
+static int r1cs_shape(zkhip_r1cs *r, int kind, size_t m) {
+    zkhip_domain d;
+    memset(&d, 0, sizeof(d));
+    d.kind = kind;
+    d.m = m;
+    ZkDomain z;
+    ZK_TRY(zk_dom_parse(r->curve, &d, &z));
+    if (m < r->M + r->n + 1 || m >= ((size_t)1 << 32)) return ZKHIP_ERR_RANGE;
+    r->dkind = kind;
+    r->m = m;
+    r->n0 = z.n0;
+    r->n1 = z.n1;
+    return ZKHIP_OK;
 }
 
 extern "C" {
@@ -273,19 +284,15 @@ int zkhip_r1cs_upload(zkhip_ctx *ctx, int curve, size_t num_constraints, size_t 
     r->M = num_constraints;
     r->n = num_inputs;
     r->N = num_variables;
-    r->m = 1;
-    r->log_m = 0;
-    // make_evaluation_domain(num_constraints + num_inputs + 1), r1cs_to_qap.hpp:229-230.  ONLY the basic radix-2 domain
-    // (m = next power of two) exists here; crypto3-math may pick an extended / step radix-2 domain of another size for
-    // some M + n + 1 -- a key generated over such a domain has H_query.size() != m - 1 and is rejected by the shim's
-    // proving-key constructors (and omega of the wrong order by the NTT).
-    while (r->m < r->M + r->n + 1) {
-        r->m <<= 1;
-        ++r->log_m;
-    }
-    if (r->log_m > 32) {
-        delete r;
-        return ZKHIP_ERR_RANGE;
+    // make_evaluation_domain(num_constraints + num_inputs + 1), r1cs_to_qap.hpp:229-230: the radix-2 family's selection
+    // (basic, extended, step at that size, then at big + rounded_small); zkhip_r1cs_set_domain overrides it
+    {
+        int kind = 0;
+        size_t m = 0;
+        if (!zk_dom_choice(r->M + r->n + 1, (size_t)zk_dom_two_adicity(curve), &kind, &m) || r1cs_shape(r, kind, m) != ZKHIP_OK) {
+            delete r;
+            return ZKHIP_ERR_RANGE;
+        }
     }
     const uint32_t *rp[3] = {rowptr_a, rowptr_b, rowptr_c}, *cl[3] = {col_a, col_b, col_c};
     const uint64_t *cf[3] = {coeff_a, coeff_b, coeff_c};
@@ -307,7 +314,6 @@ void zkhip_r1cs_free(zkhip_ctx *ctx, zkhip_r1cs *r) {
         (void)hipFree(r->coeff[k]);
         (void)hipFree(r->long_rows[k]);
     }
-    (void)hipFree(r->h_consts);
     delete r;
 }
 
@@ -321,16 +327,50 @@ int zkhip_fr_gather_dev(zkhip_ctx *ctx, const void *d_src, size_t src_count, con
 }
 
 size_t zkhip_r1cs_domain_size(const zkhip_r1cs *r) { return r ? r->m : 0; }
+int zkhip_r1cs_domain_kind(const zkhip_r1cs *r) { return r ? r->dkind : ZKHIP_ERR_INVALID; }
+int zkhip_r1cs_set_domain(zkhip_r1cs *r, int kind, size_t m) {
+    if (!r) return ZKHIP_ERR_INVALID;
+    return r1cs_shape(r, kind, m);
+}
 
-size_t zkhip_groth16_scratch_bytes(const zkhip_r1cs *r) { return r ? (size_t)3 * r->m * 32 + 4096 : 0; }
+size_t zkhip_groth16_scratch_bytes(const zkhip_r1cs *r) {
+    if (!r) return 0;
+    ZkDomain d;
+    d.kind = r->dkind;
+    d.m = r->m;
+    d.n0 = r->n0;
+    d.n1 = r->n1;
+    return ((size_t)3 * r->m + zk_dom_scratch_elems(d, 3)) * 32 + 4096;
+}
+
+int zkhip_groth16_witness_h_domain_dev(zkhip_ctx *ctx, const zkhip_r1cs *r, const void *d_assignment, const zkhip_domain *dom,
+                                       const uint64_t *coset_gen, void *d_h, void *d_scratch) {
+    if (!ctx || !r || !d_assignment || !dom || !coset_gen || !d_h || !d_scratch) return ZKHIP_ERR_INVALID;
+    ZkDomain d;
+    ZK_TRY(zk_dom_parse(r->curve, dom, &d));
+    if (d.kind != r->dkind || d.m != r->m) {
+        ctx->last_error = "the domain passed differs from the constraint system's (zkhip_r1cs_set_domain)";
+        return ZKHIP_ERR_INVALID;
+    }
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (r->curve == CURVE_BLS12_381)
+        return witness_h_t<BlsFrU>(ctx, r, (const uint32_t *)d_assignment, d, coset_gen, (uint32_t *)d_h, (uint32_t *)d_scratch);
+    return witness_h_t<BnFrU>(ctx, r, (const uint32_t *)d_assignment, d, coset_gen, (uint32_t *)d_h, (uint32_t *)d_scratch);
+}
 
 int zkhip_groth16_witness_h_dev(zkhip_ctx *ctx, const zkhip_r1cs *r, const void *d_assignment, const uint64_t *omega, const uint64_t *coset_gen,
                                 void *d_h, void *d_scratch) {
-    if (!ctx || !r || !d_assignment || !omega || !coset_gen || !d_h || !d_scratch) return ZKHIP_ERR_INVALID;
-    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    if (r->curve == CURVE_BLS12_381)
-        return witness_h_t<BlsFrU>(ctx, r, (const uint32_t *)d_assignment, omega, coset_gen, (uint32_t *)d_h, (uint32_t *)d_scratch);
-    return witness_h_t<BnFrU>(ctx, r, (const uint32_t *)d_assignment, omega, coset_gen, (uint32_t *)d_h, (uint32_t *)d_scratch);
+    if (!ctx || !r || !omega) return ZKHIP_ERR_INVALID;
+    if (r->dkind == ZKHIP_DOMAIN_EXTENDED_RADIX2) {
+        ctx->last_error = "an extended radix-2 domain needs its shift: use zkhip_groth16_witness_h_domain_dev";
+        return ZKHIP_ERR_INVALID;
+    }
+    zkhip_domain d;
+    memset(&d, 0, sizeof(d));
+    d.kind = r->dkind;
+    d.m = r->m;
+    memcpy(d.omega, omega, 32);
+    return zkhip_groth16_witness_h_domain_dev(ctx, r, d_assignment, &d, coset_gen, d_h, d_scratch);
 }
 
 }  // extern "C"

@@ -55,6 +55,7 @@ void zkhip_destroy(zkhip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     zk_ntt_free_tables(ctx);
+    zk_dom_free_tables(ctx);
     for (auto &p : ctx->prof.pending) {
         (void)hipEventDestroy(p.second.a);
         (void)hipEventDestroy(p.second.b);

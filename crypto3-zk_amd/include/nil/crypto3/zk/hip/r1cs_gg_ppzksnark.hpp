@@ -26,6 +26,7 @@
 #include <utility>
 #include <vector>
 
+#include "evaluation_domain.hpp"
 #include "multiexp.hpp"
 
 namespace nil {
@@ -123,7 +124,7 @@ public:
     /// {index, coeff}`, `num_constraints()`, `num_inputs()`, `num_variables()` -- the reference's own r1cs_constraint_system
     /// is consumed as it is (coefficients go through curve_adapter::scalar_to_limbs), no look-alike copy.
     template <typename ConstraintSystem>
-    device_r1cs(const context &ctx, const ConstraintSystem &cs) : ctx_(&ctx) {
+    device_r1cs(const context &ctx, const ConstraintSystem &cs) : ctx_(&ctx), min_size_(cs.num_constraints() + cs.num_inputs() + 1) {
         std::vector<std::uint32_t> rp[3], cl[3];
         std::vector<std::uint64_t> cf[3];
         for (int k = 0; k < 3; ++k) rp[k].push_back(0);
@@ -146,19 +147,18 @@ public:
     device_r1cs(const device_r1cs &) = delete;
     device_r1cs &operator=(const device_r1cs &) = delete;
     const zkhip_r1cs *get() const { return r_; }
+    /// the evaluation domain the witness map reduces over: after construction what make_evaluation_domain(M + n + 1) picks
+    /// (r1cs_to_qap.hpp:229-230), until set_domain installs another (e.g. the basic one a key was generated over)
     std::size_t domain_size() const { return zkhip_r1cs_domain_size(r_); }
+    int domain_kind() const { return zkhip_r1cs_domain_kind(r_); }
+    void set_domain(int kind, std::size_t m) { check(zkhip_r1cs_set_domain(r_, kind, m), "zkhip_r1cs_set_domain", ctx_->get()); }
+    void set_domain(const evaluation_domain_hip<CurveType> &d) { set_domain(d.kind, d.m); }
+    std::size_t min_domain_size() const { return min_size_; }
 
 private:
     const context *ctx_;
+    std::size_t min_size_ = 0;
     zkhip_r1cs *r_ = nullptr;
-};
-
-/// The evaluation-domain constants the reference takes from crypto3-algebra / crypto3-math
-/// (`arithmetic_params<F>::multiplicative_generator`, the root of unity make_evaluation_domain picks).
-template <typename CurveType>
-struct domain_params {
-    typename curve_adapter<CurveType>::scalar_value_type omega;             // primitive m-th root of unity
-    typename curve_adapter<CurveType>::scalar_value_type coset_generator;    // multiplicative generator
 };
 
 // ---- reductions::r1cs_to_qap<F>::witness_map on the device ---------------------------------------------------
@@ -168,10 +168,13 @@ struct r1cs_to_qap_hip {
     typedef typename adapter::scalar_value_type value_type;
 
     /// coefficients_for_H (m + 1 elements) left RESIDENT on the device; `d_assignment` receives (1, x, w).
-    static std::shared_ptr<void> witness_map(const context &ctx, const device_r1cs<CurveType> &cs, const domain_params<CurveType> &dom,
+    static std::shared_ptr<void> witness_map(const context &ctx, device_r1cs<CurveType> &cs, const domain_params<CurveType> &dom,
                                              const std::vector<value_type> &primary_input, const std::vector<value_type> &auxiliary_input,
                                              std::shared_ptr<void> &d_assignment) {
-        const std::size_t N = primary_input.size() + auxiliary_input.size(), m = cs.domain_size();
+        /* make_evaluation_domain(cs.num_constraints() + cs.num_inputs() + 1) (r1cs_to_qap.hpp:229-230), or the domain `dom` names */
+        const evaluation_domain_hip<CurveType> domain = evaluation_domain_hip<CurveType>::make(dom, cs.min_domain_size());
+        cs.set_domain(domain);
+        const std::size_t N = primary_input.size() + auxiliary_input.size(), m = domain.m;
         std::vector<std::uint64_t> z(4 * (N + 1), 0);
         z[0] = 1;
         std::size_t k = 1;
@@ -181,16 +184,16 @@ struct r1cs_to_qap_hip {
         ctx.h2d(d_assignment.get(), z.data(), z.size() * 8);
         auto d_h = ctx.alloc((m + 1) * 32);
         auto d_scratch = ctx.alloc(zkhip_groth16_scratch_bytes(cs.get()));
-        std::uint64_t w[4], g[4];
-        adapter::scalar_to_limbs(dom.omega, w);
+        std::uint64_t g[4];
+        const zkhip_domain dd = domain.c_desc();
         adapter::scalar_to_limbs(dom.coset_generator, g);
-        check(zkhip_groth16_witness_h_dev(ctx.get(), cs.get(), d_assignment.get(), w, g, d_h.get(), d_scratch.get()),
-              "zkhip_groth16_witness_h_dev", ctx.get());
+        check(zkhip_groth16_witness_h_domain_dev(ctx.get(), cs.get(), d_assignment.get(), &dd, g, d_h.get(), d_scratch.get()),
+              "zkhip_groth16_witness_h_domain_dev", ctx.get());
         ctx.sync();    // d_scratch is released on return
         return d_h;
     }
     /// host copy of the same (the reference's return value, qap_witness::coefficients_for_H)
-    static std::vector<value_type> witness_map_host(const context &ctx, const device_r1cs<CurveType> &cs, const domain_params<CurveType> &dom,
+    static std::vector<value_type> witness_map_host(const context &ctx, device_r1cs<CurveType> &cs, const domain_params<CurveType> &dom,
                                                     const std::vector<value_type> &primary_input,
                                                     const std::vector<value_type> &auxiliary_input) {
         std::shared_ptr<void> d_z;
@@ -245,6 +248,7 @@ public:
     r1cs_gg_ppzksnark_proving_key_hip(const context &ctx, const host_key_type &pk, const domain_params<CurveType> &dom, std::size_t rank,
                                       std::size_t world) :
         ctx(ctx), host(pk), domain(dom), constraint_system(ctx, pk.constraint_system) {
+        resolve_domain(pk.H_query.size());
         check_host_key(pk);
         const std::size_t N = pk.constraint_system.num_variables(), n = pk.constraint_system.num_inputs();
         shard = query_shard::make(rank, world, N + 1, pk.B_query.values.size(), constraint_system.domain_size() - 1, N - n);
@@ -268,6 +272,7 @@ public:
         ctx(ctx), host(pk), domain(dom), A_query(std::move(a_query)), H_query(std::move(h_query)), L_query(std::move(l_query)),
         B_query_h(std::move(b_query_h)), B_query_g(std::move(b_query_g)), constraint_system(ctx, pk.constraint_system) {
         const std::size_t N = pk.constraint_system.num_variables(), n = pk.constraint_system.num_inputs();
+        resolve_domain(slice ? 0 : H_query.size());
         check_b_indices(b_indices.begin(), b_indices.end(), N);
         if (B_query_g.size() != b_indices.size() || B_query_h.size() != b_indices.size())
             throw std::invalid_argument("proving key: the B query's index list and its (g, h) values differ in length");
@@ -282,6 +287,9 @@ public:
     const context &ctx;
     const host_key_type &host;
     domain_params<CurveType> domain;
+    /// the domain the key was generated over and proofs reduce over: `domain` resolved against the constraint system (and, for
+    /// kind "auto", against the key's H_query size: make_evaluation_domain's choice, or the basic domain of the next power of two)
+    evaluation_domain_hip<CurveType> evaluation_domain;
     device_bases<CurveType, ZKHIP_G1> A_query, H_query, L_query, B_query_h;
     device_bases<CurveType, ZKHIP_G2> B_query_g;
     device_r1cs<CurveType> constraint_system;
@@ -325,15 +333,29 @@ public:
     }
 
 private:
-    /// The key must have been generated over the BASIC radix-2 domain of size m = 2^ceil(log2(M + n + 1)) (the only one this
-    /// backend transforms over; crypto3-math's extended / step radix-2 domains have other sizes): H_query has m - 1
+    /// `h_entries`: the size of the FULL H query when known (0: a slice of it -- then `domain` decides alone)
+    void resolve_domain(std::size_t h_entries) {
+        typedef evaluation_domain_hip<CurveType> ED;
+        const std::size_t min_size = constraint_system.min_domain_size();
+        if (domain.kind >= 0) {
+            evaluation_domain = ED::make(domain, min_size);
+        } else {
+            const auto c = ED::choice(min_size);
+            const std::size_t pow2 = (std::size_t)1 << detail::ceil_log2(min_size);
+            if (h_entries != 0 && h_entries + 1 != c.second && h_entries + 1 == pow2)
+                evaluation_domain = ED(ZKHIP_DOMAIN_BASIC_RADIX2, pow2, domain.omega);    // a key generated over the basic domain
+            else
+                evaluation_domain = ED(c.first, c.second, domain.omega, domain.shift);
+        }
+        constraint_system.set_domain(evaluation_domain);
+    }
+    /// The key must have been generated over the evaluation domain proofs will reduce over (m points): H_query has m - 1
     /// entries, A_query N + 1, L_query N - n, and the sparse B query's indices are strictly increasing and <= N.
     void check_host_key(const host_key_type &pk) const {
         const std::size_t N = pk.constraint_system.num_variables(), n = pk.constraint_system.num_inputs(), m = constraint_system.domain_size();
         if (pk.H_query.size() != m - 1)
-            throw std::invalid_argument("proving key: H_query has " + std::to_string(pk.H_query.size()) + " entries, the basic radix-2 domain of size " +
-                                        std::to_string(m) + " needs " + std::to_string(m - 1) +
-                                        " (keys generated over an extended / step radix-2 domain are not supported)");
+            throw std::invalid_argument("proving key: H_query has " + std::to_string(pk.H_query.size()) + " entries, the evaluation domain of " +
+                                        std::to_string(m) + " points needs " + std::to_string(m - 1));
         if (pk.A_query.size() != N + 1 || pk.L_query.size() != N - n) throw_query_sizes();
         if (pk.B_query.indices.size() != pk.B_query.values.size())
             throw std::invalid_argument("proving key: the B query's index list and its values differ in length");
@@ -512,11 +534,11 @@ private:
             }
         }
         /* qap_wit.coefficients_for_H, resident (prover.hpp:79-83) */
-        std::uint64_t w[4], g[4];
-        adapter::scalar_to_limbs(pk.domain.omega, w);
+        std::uint64_t g[4];
+        const zkhip_domain dd = pk.evaluation_domain.c_desc();
         adapter::scalar_to_limbs(pk.domain.coset_generator, g);
-        check(zkhip_groth16_witness_h_dev(ctx.get(), pk.constraint_system.get(), cpa, w, g, pk.d_h.get(), pk.d_scratch.get()),
-              "zkhip_groth16_witness_h_dev", ctx.get());
+        check(zkhip_groth16_witness_h_domain_dev(ctx.get(), pk.constraint_system.get(), cpa, &dd, g, pk.d_h.get(), pk.d_scratch.get()),
+              "zkhip_groth16_witness_h_domain_dev", ctx.get());
         /* evaluation_Bt: kc_multiexp_with_mixed_addition over the sparse (G2, G1) query (prover.hpp:116-123); a sharded key
            holds a slice of the index list */
         check(zkhip_fr_gather_dev(ctx.get(), cpa, num_variables + 1, pk.d_B_indices.get(), pk.B_count, pk.d_bs.get()), "zkhip_fr_gather_dev", ctx.get());

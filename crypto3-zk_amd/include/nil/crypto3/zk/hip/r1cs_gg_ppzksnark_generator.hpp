@@ -23,7 +23,6 @@
 #include <algorithm>
 #include <array>
 #include <memory>
-#include <thread>
 #include <vector>
 
 #include "r1cs_gg_ppzksnark.hpp"
@@ -32,29 +31,6 @@ namespace nil {
 namespace crypto3 {
 namespace zk {
 namespace hip {
-
-namespace detail {
-    /// fn(lo, hi) over [0, n) in contiguous chunks on up to 32 host threads (the QAP evaluation is embarrassingly parallel)
-    template <typename Fn>
-    void parallel_chunks(std::size_t n, Fn fn) {
-        const std::size_t hw = std::max<std::size_t>(1, std::min<std::size_t>(32, std::thread::hardware_concurrency()));
-        const std::size_t parts = n < (std::size_t)1 << 14 ? 1 : hw, per = (n + parts - 1) / parts;
-        std::vector<std::thread> th;
-        for (std::size_t k = 1; k < parts; ++k)
-            if (k * per < n) th.emplace_back([=]() { fn(k * per, std::min(n, (k + 1) * per)); });
-        fn(0, std::min(n, per));
-        for (auto &t : th) t.join();
-    }
-    template <typename Fr>
-    Fr pow_u64(Fr b, std::uint64_t e) {
-        Fr r = Fr::one();
-        for (; e; e >>= 1) {
-            if (e & 1) r = r * b;
-            b = b * b;
-        }
-        return r;
-    }
-}    // namespace detail
 
 /// qap_instance_evaluation (reductions/qap.hpp) restricted to what the generator reads
 template <typename CurveType>
@@ -65,43 +41,23 @@ struct qap_instance_evaluation_hip {
     std::vector<value_type> At, Bt, Ct, Ht;    // N + 1 each; Ht = (1, t, ..., t^m)
 };
 
-/// r1cs_to_qap<F>::instance_map_with_evaluation(cs, t) over the basic radix-2 domain of size m = 2^ceil(log2(M + n + 1))
-/// with primitive root `omega` (r1cs_to_qap.hpp:138-187).  `ConstraintSystem` is duck-typed like device_r1cs.
+/// r1cs_to_qap<F>::instance_map_with_evaluation(cs, t) (r1cs_to_qap.hpp:138-187) over the evaluation domain `dom` describes:
+/// make_evaluation_domain(num_constraints + num_inputs + 1)'s choice unless it names another.  `ConstraintSystem` is
+/// duck-typed like device_r1cs.
 template <typename CurveType, typename ConstraintSystem>
 qap_instance_evaluation_hip<CurveType> instance_map_with_evaluation(const ConstraintSystem &cs, const typename curve_adapter<CurveType>::scalar_value_type &t,
-                                                                    const typename curve_adapter<CurveType>::scalar_value_type &omega) {
+                                                                    const domain_params<CurveType> &dom) {
     typedef typename curve_adapter<CurveType>::scalar_value_type Fr;
     const std::size_t M = cs.num_constraints(), n = cs.num_inputs(), N = cs.num_variables();
-    std::size_t m = 1;
-    while (m < M + n + 1) m <<= 1;
+    const evaluation_domain_hip<CurveType> domain = evaluation_domain_hip<CurveType>::make(dom, M + n + 1);
+    const std::size_t m = domain.m;
     qap_instance_evaluation_hip<CurveType> q;
     q.num_variables = N;
     q.degree = m;
     q.num_inputs = n;
     q.t = t;
-    q.Zt = detail::pow_u64(t, m) - Fr::one();    // compute_vanishing_polynomial(t) = t^m - 1
-    /* evaluate_all_lagrange_polynomials(t): u_i = Z(t) omega^i / (m (t - omega^i)); one inversion per chunk (Montgomery's
-       trick).  t on the domain itself (probability m / r) would make one u_i = 1 and the rest 0: the closed form does not
-       cover it and a trapdoor must not lie there anyway. */
-    if (q.Zt.is_zero()) throw std::invalid_argument("instance_map_with_evaluation: t lies in the evaluation domain");
-    std::vector<Fr> u(m);
-    const Fr z_over_m = q.Zt * Fr((std::uint64_t)m).inversed();
-    detail::parallel_chunks(m, [&](std::size_t lo, std::size_t hi) {
-        std::vector<Fr> pre(hi - lo);
-        Fr x = detail::pow_u64(omega, lo), acc = Fr::one();
-        for (std::size_t i = lo; i < hi; ++i) {
-            u[i] = x;    // omega^i for now
-            pre[i - lo] = acc;
-            acc = acc * (t - x);
-            x = x * omega;
-        }
-        Fr inv = acc.inversed();
-        for (std::size_t i = hi; i-- > lo;) {
-            const Fr den = t - u[i];
-            u[i] = u[i] * z_over_m * (inv * pre[i - lo]);
-            inv = inv * den;
-        }
-    });
+    q.Zt = domain.compute_vanishing_polynomial(t);
+    const std::vector<Fr> u = domain.evaluate_all_lagrange_polynomials(t);
     q.At.assign(N + 1, Fr::zero());
     q.Bt.assign(N + 1, Fr::zero());
     q.Ct.assign(N + 1, Fr::zero());
@@ -154,7 +110,7 @@ public:
         swap_AB_if_beneficial(pk.constraint_system);
         const Fr delta_inverse = delta.inversed();
         /* A quadratic arithmetic program evaluated at t. */
-        const auto qap = instance_map_with_evaluation<CurveType>(pk.constraint_system, t, dom.omega);
+        const auto qap = instance_map_with_evaluation<CurveType>(pk.constraint_system, t, dom);
         const std::size_t N = qap.num_variables, n = qap.num_inputs, m = qap.degree;
         /* The delta inverse product component: (beta*A_i(t) + alpha*B_i(t) + C_i(t)) * delta^{-1} (generator.hpp:296-304) */
         std::vector<Fr> Lt(N - n);
@@ -196,7 +152,14 @@ public:
         auto h_query = device_bases<CurveType, ZKHIP_G1>::from_scalars(ctx, Hs.begin() + sh.H_lo, Hs.begin() + sh.H_lo + sh.H_n);
         auto l_query = device_bases<CurveType, ZKHIP_G1>::from_scalars(ctx, Lt.begin() + sh.L_lo, Lt.begin() + sh.L_lo + sh.L_n);
         b_indices = std::vector<std::uint32_t>(b_indices.begin() + sh.B_lo, b_indices.begin() + sh.B_lo + sh.B_n);
-        key->device.reset(new r1cs_gg_ppzksnark_proving_key_hip<CurveType>(ctx, pk, dom, std::move(a_query), std::move(b_query_g), std::move(b_query_h),
+        /* the device key reduces over the very domain the queries were evaluated on (explicit: a rank's H slice does not tell) */
+        domain_params<CurveType> key_dom = dom;
+        {
+            const evaluation_domain_hip<CurveType> ed = evaluation_domain_hip<CurveType>::make(dom, pk.constraint_system.num_constraints() + n + 1);
+            key_dom.kind = ed.kind;
+            key_dom.m = ed.m;
+        }
+        key->device.reset(new r1cs_gg_ppzksnark_proving_key_hip<CurveType>(ctx, pk, key_dom, std::move(a_query), std::move(b_query_g), std::move(b_query_h),
                                                                           b_indices, std::move(h_query), std::move(l_query), world > 1 ? &sh : nullptr));
         return key;
     }
@@ -241,7 +204,7 @@ std::array<typename curve_adapter<CurveType>::scalar_value_type, 3> groth16_proo
     const typename curve_adapter<CurveType>::scalar_value_type &delta, const typename curve_adapter<CurveType>::scalar_value_type &r,
     const typename curve_adapter<CurveType>::scalar_value_type &s) {
     typedef typename curve_adapter<CurveType>::scalar_value_type Fr;
-    const auto qap = instance_map_with_evaluation<CurveType>(swapped_cs, t, dom.omega);
+    const auto qap = instance_map_with_evaluation<CurveType>(swapped_cs, t, dom);
     const std::size_t N = qap.num_variables, n = qap.num_inputs;
     std::vector<Fr> z;
     z.push_back(Fr::one());

@@ -17,7 +17,8 @@ EXPORTS = [
     "zkhip_set_option", "zkhip_malloc", "zkhip_free", "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_memcpy_h2d_async", "zkhip_memcpy_d2d_async", "zkhip_host_alloc", "zkhip_host_free",
     "zkhip_bases_upload", "zkhip_bases_upload_compressed", "zkhip_bases_from_scalars", "zkhip_bases_download", "zkhip_bases_size",
     "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_batch_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
-    "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_domain_size", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev", "zkhip_fr_gather_dev", "zkhip_poly_resize_dev", "zkhip_fri_fold_dev", "zkhip_fri_leaves_dev", "zkhip_ec_ntt_dev",
+    "zkhip_domain_choice", "zkhip_domain_fft_dev",
+    "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_set_domain", "zkhip_r1cs_domain_size", "zkhip_r1cs_domain_kind", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev", "zkhip_groth16_witness_h_domain_dev", "zkhip_fr_gather_dev", "zkhip_poly_resize_dev", "zkhip_fri_fold_dev", "zkhip_fri_leaves_dev", "zkhip_ec_ntt_dev",
     "zkhip_fr_vec_op_dev", "zkhip_fr_vec_prod_dev", "zkhip_poly_shift_dev", "zkhip_poly_eval_dev", "zkhip_poly_div_linear_dev", "zkhip_poly_lincomb_dev",
     "zkhip_profile_enable", "zkhip_profile_reset", "zkhip_profile_filter", "zkhip_profile_get", "zkhip_profile_dump",
 ]
@@ -25,6 +26,35 @@ EXPORTS = [
 
 class ZkhipError(RuntimeError):
     pass
+
+
+DOMAIN_BASIC, DOMAIN_EXTENDED, DOMAIN_STEP = 0, 1, 2
+
+
+class Domain(ctypes.Structure):
+    """zkhip_domain"""
+    _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_uint32), ("m", ctypes.c_uint64), ("omega", ctypes.c_uint64 * 4),
+                ("shift", ctypes.c_uint64 * 4)]
+
+    @staticmethod
+    def make(kind: int, m: int, omega, shift=None) -> "Domain":
+        d = Domain()
+        d.kind, d.reserved, d.m = int(kind), 0, int(m)
+        for i, v in enumerate(np.asarray(omega, dtype=np.uint64).reshape(4)):
+            d.omega[i] = int(v)
+        if shift is not None:
+            for i, v in enumerate(np.asarray(shift, dtype=np.uint64).reshape(4)):
+                d.shift[i] = int(v)
+        return d
+
+
+def domain_choice(curve: int, min_size: int):
+    """(kind, m) of make_evaluation_domain(min_size) over the curve's scalar field (zkhip_domain_choice; host arithmetic only)"""
+    kind, m = ctypes.c_int(), ctypes.c_size_t()
+    rc = load_library().zkhip_domain_choice(curve, ctypes.c_size_t(min_size), ctypes.byref(kind), ctypes.byref(m))
+    if rc != 0:
+        raise ZkhipError(f"zkhip_domain_choice({min_size}): {rc}")
+    return kind.value, m.value
 
 
 def coord_limbs(curve: int, group: int) -> int:
@@ -69,6 +99,8 @@ def load_library() -> ctypes.CDLL:
     lib.zkhip_groth16_scratch_bytes.restype = ctypes.c_size_t
     lib.zkhip_groth16_scratch_bytes.argtypes = [ctypes.c_void_p]
     lib.zkhip_r1cs_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.zkhip_r1cs_set_domain.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+    lib.zkhip_r1cs_domain_kind.argtypes = [ctypes.c_void_p]
     lib.zkhip_destroy.argtypes = [ctypes.c_void_p]
     lib.zkhip_bases_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     _LIB = lib
@@ -250,8 +282,30 @@ class Context:
         self._check(self.lib.zkhip_groth16_witness_h_dev(self.h, r1cs.h, ctypes.c_void_p(d_assignment), _p(_u64(omega)), _p(_u64(coset)),
                                                          ctypes.c_void_p(d_h), ctypes.c_void_p(d_scratch)), "zkhip_groth16_witness_h_dev")
 
+    def groth16_witness_h_domain_dev(self, r1cs: "R1CS", d_assignment: int, dom: Domain, coset, d_h: int, d_scratch: int):
+        self._check(self.lib.zkhip_groth16_witness_h_domain_dev(self.h, r1cs.h, ctypes.c_void_p(d_assignment), ctypes.byref(dom), _p(_u64(coset)),
+                                                                ctypes.c_void_p(d_h), ctypes.c_void_p(d_scratch)), "zkhip_groth16_witness_h_domain_dev")
+
+    def domain_fft_dev(self, curve: int, dom: Domain, d_data: int, batch: int, inverse=False, coset=None):
+        self._check(self.lib.zkhip_domain_fft_dev(self.h, curve, ctypes.byref(dom), ctypes.c_void_p(d_data), ctypes.c_size_t(batch), 1 if inverse else 0,
+                                                  _p(_u64(coset)) if coset is not None else None), "zkhip_domain_fft_dev")
+
+    def domain_fft(self, curve: int, dom: Domain, data: np.ndarray, inverse=False, coset=None) -> np.ndarray:
+        """host convenience: (batch, m, 4) canonical -> transformed copy"""
+        d = _u64(data).copy()
+        batch = d.shape[0] if d.ndim == 3 else 1
+        dp = self.malloc(d.nbytes)
+        try:
+            self.h2d(dp, d)
+            self.domain_fft_dev(curve, dom, dp, batch, inverse, coset)
+            self.d2h(d, dp)
+        finally:
+            self.free(dp)
+        return d
+
     def groth16_witness_h(self, r1cs: "R1CS", assignment_with_one: np.ndarray, omega, coset) -> np.ndarray:
-        """host convenience: (N+1, 4) canonical assignment (1 | primary | auxiliary) -> (m+1, 4) coefficients of H"""
+        """host convenience: (N+1, 4) canonical assignment (1 | primary | auxiliary) -> (m+1, 4) coefficients of H.  `omega`: the
+        domain's root (4 limbs) or a Domain"""
         z = _u64(assignment_with_one)
         m = r1cs.m
         d_z = self.malloc(z.nbytes)
@@ -259,7 +313,10 @@ class Context:
         d_s = self.malloc(self.lib.zkhip_groth16_scratch_bytes(r1cs.h))
         try:
             self.h2d(d_z, z)
-            self.groth16_witness_h_dev(r1cs, d_z, omega, coset, d_h, d_s)
+            if isinstance(omega, Domain):
+                self.groth16_witness_h_domain_dev(r1cs, d_z, omega, coset, d_h, d_s)
+            else:
+                self.groth16_witness_h_dev(r1cs, d_z, omega, coset, d_h, d_s)
             out = np.zeros((m + 1, 4), dtype=np.uint64)
             self.d2h(out, d_h)
         finally:
@@ -348,8 +405,17 @@ class R1CS:
 
     def __init__(self, ctx: "Context", h, curve, M, n, N):
         self.ctx, self.h, self.curve, self.M, self.n, self.N = ctx, h, curve, M, n, N
-        self.m = ctx.lib.zkhip_r1cs_domain_size(h)
-        self.log_m = self.m.bit_length() - 1
+        self._dims()
+
+    def _dims(self):
+        self.m = self.ctx.lib.zkhip_r1cs_domain_size(self.h)
+        self.kind = self.ctx.lib.zkhip_r1cs_domain_kind(self.h)
+        self.log_m = (self.m - 1).bit_length()    # log2 of the power of two that holds the domain (basic: of m itself)
+
+    def set_domain(self, kind: int, m: int):
+        """another evaluation domain than make_evaluation_domain's choice (e.g. the basic one of the next power of two)"""
+        self.ctx._check(self.ctx.lib.zkhip_r1cs_set_domain(self.h, int(kind), ctypes.c_size_t(m)), "zkhip_r1cs_set_domain")
+        self._dims()
 
     def free(self):
         if self.h is not None and self.ctx.h:

@@ -139,6 +139,35 @@ int zkhip_ntt(zkhip_ctx *ctx, int curve, uint64_t *data /* host, batch x m x 4 *
 int zkhip_ntt_dev(zkhip_ctx *ctx, int curve, void *d_data, size_t log_m, size_t batch, const uint64_t *omega, int inverse,
                   const uint64_t *coset_gen);
 
+/* ---- evaluation domains ------------------------------------------------------------------------------
+ * What math::make_evaluation_domain<Fr>(min_size) returns (reductions/r1cs_to_qap.hpp:138-139, 229-230 call it with
+ * num_constraints + num_inputs + 1, which is rarely a power of two).  crypto3-math is not part of the reference tree; the
+ * family and the selection order are those of its libfqfft lineage: basic_radix2 (m = 2^k), extended_radix2
+ * (m = 2^(s+1), s the field's two-adicity) and step_radix2 (m = 2^k + 2^j), tried at min_size and then at
+ * big + rounded_small.  The point sets, in get_domain_element order:
+ *   basic     omega^i, i < m                                    omega = primitive m-th root of unity
+ *   extended  omega^i, then shift omega^i, i < m/2              omega = primitive (m/2)-th root
+ *   step      omega^(2i), i < big, then omega (omega^(2 big/small))^i, i < small
+ *                                                               omega = primitive (2 big)-th root (the domain's `omega` member)
+ * The roots are ARGUMENTS like everywhere in this ABI (arithmetic_params<F> lives in crypto3-algebra); a root of the
+ * wrong order is refused (ZKHIP_ERR_INVALID). */
+enum zkhip_domain_kind { ZKHIP_DOMAIN_BASIC_RADIX2 = 0, ZKHIP_DOMAIN_EXTENDED_RADIX2 = 1, ZKHIP_DOMAIN_STEP_RADIX2 = 2 };
+typedef struct zkhip_domain {
+    int32_t kind;      /* zkhip_domain_kind */
+    uint32_t reserved; /* 0 */
+    uint64_t m;        /* number of points */
+    uint64_t omega[4]; /* see above */
+    uint64_t shift[4]; /* extended: detail::coset_shift<F>() (= multiplicative_generator^2); ignored otherwise */
+} zkhip_domain;
+/* (kind, m) make_evaluation_domain(min_size) picks over the curve's scalar field (two-adicity 32 for BLS12-381, 28 for BN254).
+ * ZKHIP_ERR_RANGE when only a geometric / arithmetic sequence domain would do (beyond 2^(s+1) points: out of scope). */
+int zkhip_domain_choice(int curve, size_t min_size, int *kind, size_t *m);
+/* evaluation_domain<F>::fft / inverse_fft over any of the three domains, in place on `batch` vectors of dom->m Fr elements:
+ *   forward:  [coset != NULL: v[j] *= coset^j;]  out[i] = sum_j v[j] x_i^j        (x_i = get_domain_element(i))
+ *   inverse:  the interpolation;  [coset != NULL: out[j] *= coset^(-j)]
+ * For the basic kind this is zkhip_ntt_dev. */
+int zkhip_domain_fft_dev(zkhip_ctx *ctx, int curve, const zkhip_domain *dom, void *d_data, size_t batch, int inverse, const uint64_t *coset_gen);
+
 /* ---- Groth16 witness map ------------------------------------------------------------------------
  * Resident R1CS in CSR form (three matrices A, B, C; column 0 is the constant 1, column j >= 1 is variable
  * j - 1; coefficients canonical Fr, 4 limbs each).  Replaces the constraint_system member of the proving key
@@ -149,16 +178,27 @@ int zkhip_r1cs_upload(zkhip_ctx *ctx, int curve, size_t num_constraints, size_t 
                       const uint32_t *col_a, const uint64_t *coeff_a, const uint32_t *rowptr_b, const uint32_t *col_b, const uint64_t *coeff_b,
                       const uint32_t *rowptr_c, const uint32_t *col_c, const uint64_t *coeff_c, zkhip_r1cs **out);
 void zkhip_r1cs_free(zkhip_ctx *ctx, zkhip_r1cs *r);
-/* m = the radix-2 domain size make_evaluation_domain(num_constraints + num_inputs + 1) picks (r1cs_to_qap.hpp:229-230) */
+/* The evaluation domain the witness map reduces over.  After upload it is (kind, m) = what
+ * make_evaluation_domain(num_constraints + num_inputs + 1) picks (r1cs_to_qap.hpp:229-230; zkhip_domain_choice) -- a step
+ * radix-2 domain for most instances.  zkhip_r1cs_set_domain installs another kind / size (m >= num_constraints + num_inputs + 1),
+ * e.g. the basic domain of the next power of two for a key that was generated over that one; only kind and m are read
+ * (the roots come with every witness-map call). */
+int zkhip_r1cs_set_domain(zkhip_r1cs *r, int kind, size_t m);
 size_t zkhip_r1cs_domain_size(const zkhip_r1cs *r);
+int zkhip_r1cs_domain_kind(const zkhip_r1cs *r);
 size_t zkhip_groth16_scratch_bytes(const zkhip_r1cs *r);
 /* coefficients_for_H of witness_map with d1 = d2 = d3 = 0 (as prover.hpp:79-83 calls it): m + 1 Fr elements
  * written to d_h.  d_assignment = (1, primary_input, auxiliary_input), num_variables + 1 elements, device
- * resident; omega = the primitive m-th root of the caller's evaluation domain; coset_gen = the field's
- * multiplicative generator (arithmetic_params<F>::multiplicative_generator).  3 sparse mat-vecs, 7 NTTs and
- * one fused pointwise pass, all on the context's stream; the result feeds zkhip_msm_dev directly. */
+ * resident; omega = the `omega` of the constraint system's evaluation domain (see zkhip_domain: the primitive m-th root for the
+ * basic kind, the primitive (2 big)-th root for the step kind); coset_gen = the field's multiplicative generator
+ * (arithmetic_params<F>::multiplicative_generator).  3 sparse mat-vecs, 7 transforms and one fused pointwise pass, all on
+ * the context's stream; the result feeds zkhip_msm_dev directly.  An extended radix-2 domain also needs its shift: use
+ * zkhip_groth16_witness_h_domain_dev, which takes the whole domain description (its kind and m must match the constraint
+ * system's). */
 int zkhip_groth16_witness_h_dev(zkhip_ctx *ctx, const zkhip_r1cs *r, const void *d_assignment, const uint64_t *omega,
                                 const uint64_t *coset_gen, void *d_h, void *d_scratch);
+int zkhip_groth16_witness_h_domain_dev(zkhip_ctx *ctx, const zkhip_r1cs *r, const void *d_assignment, const zkhip_domain *dom,
+                                       const uint64_t *coset_gen, void *d_h, void *d_scratch);
 
 /* d_dst[j] = d_src[d_indices[j]] on Fr elements (u32 indices): gathers the scalars of a sparse query, i.e. the
  * `*(scalar_start + scalar_position)` walk over vec.indices of kc_multiexp_with_mixed_addition

@@ -81,6 +81,19 @@ namespace ref_like {
 }    // namespace ref_like
 
 int g_world = 1;    // > 1: shim_groth16_prove emulates that many ranks one after the other on this GPU
+// evaluation domain the Groth16 entry points name: kind < 0 = "auto" (make_evaluation_domain's choice, or what the key's H query says)
+int g_dom_kind = -1;
+size_t g_dom_m = 0;
+uint64_t g_dom_shift[4] = {0, 0, 0, 0};
+template <typename Curve>
+domain_params<Curve> make_dom(const uint64_t *omega, const uint64_t *coset) {
+    typedef curve_adapter<Curve> A;
+    domain_params<Curve> dom {A::scalar_from_limbs(omega), coset ? A::scalar_from_limbs(coset) : A::scalar_value_type::one()};
+    dom.kind = g_dom_kind;
+    dom.m = g_dom_m;
+    dom.shift = A::scalar_from_limbs(g_dom_shift);
+    return dom;
+}
 
 template <typename Curve>
 int groth16_prove_t(size_t M, size_t n, size_t N, const uint32_t *const rowptr[3], const uint32_t *const col[3], const uint64_t *const coeff[3],
@@ -125,7 +138,7 @@ int groth16_prove_t(size_t M, size_t n, size_t N, const uint32_t *const rowptr[3
     if (!pk.constraint_system.is_satisfied(primary, auxiliary)) return -100;
 
     context ctx(0);
-    domain_params<Curve> dom {A::scalar_from_limbs(omega), A::scalar_from_limbs(coset)};
+    const domain_params<Curve> dom = make_dom<Curve>(omega, coset);
     if (g_world > 1) {
         /* one proof sharded over g_world ranks: every rank holds a slice of each query and contributes its partial sums;
            the all-gather is the concatenation below */
@@ -431,7 +444,7 @@ int groth16_prove_from_bytes_t(const uint8_t *blob, size_t size, const uint64_t 
     typedef typename A::scalar_value_type Fr;
     const size_t L1 = 2 * A::g1_coord_limbs, L2 = 2 * A::g2_coord_limbs;
     context ctx(0);
-    domain_params<Curve> dom {A::scalar_from_limbs(omega), A::scalar_from_limbs(coset)};
+    const domain_params<Curve> dom = make_dom<Curve>(omega, coset);
     auto key = proving_key_from_bytes<Curve>(ctx, blob, size, dom);
     if (key->host.constraint_system.num_inputs() != n || key->host.constraint_system.num_variables() != N) return -103;
     std::vector<Fr> primary, auxiliary;
@@ -688,7 +701,7 @@ int host_qap_exponents_t(size_t M, size_t n, size_t N, const uint32_t *const row
     std::vector<Fr> primary, auxiliary;
     for (size_t i = 0; i < n; ++i) primary.push_back(A::scalar_from_limbs(assignment + 4 * i));
     for (size_t i = n; i < N; ++i) auxiliary.push_back(A::scalar_from_limbs(assignment + 4 * i));
-    domain_params<Curve> dom {A::scalar_from_limbs(omega), Fr::one()};
+    const domain_params<Curve> dom = make_dom<Curve>(omega, nullptr);
     auto e = groth16_proof_exponents<Curve>(cs, dom, primary, auxiliary, A::scalar_from_limbs(trap), A::scalar_from_limbs(trap + 4),
                                             A::scalar_from_limbs(trap + 8), A::scalar_from_limbs(trap + 16), A::scalar_from_limbs(r), A::scalar_from_limbs(s));
     for (int k = 0; k < 3; ++k) A::scalar_to_limbs(e[k], out + 4 * k);
@@ -709,7 +722,7 @@ int groth16_generate_prove_t(size_t M, size_t n, size_t N, const uint32_t *const
     for (size_t i = 0; i < n; ++i) primary.push_back(A::scalar_from_limbs(assignment + 4 * i));
     for (size_t i = n; i < N; ++i) auxiliary.push_back(A::scalar_from_limbs(assignment + 4 * i));
     context ctx(0);
-    domain_params<Curve> dom {A::scalar_from_limbs(omega), A::scalar_from_limbs(coset)};
+    const domain_params<Curve> dom = make_dom<Curve>(omega, coset);
     auto t0 = std::chrono::steady_clock::now();
     auto key = r1cs_gg_ppzksnark_generator_hip<Curve>::deterministic_basic_process(ctx, cs, dom, A::scalar_from_limbs(trap), A::scalar_from_limbs(trap + 4),
                                                                                    A::scalar_from_limbs(trap + 8), A::scalar_from_limbs(trap + 12),
@@ -751,6 +764,11 @@ void shim_host_query_shards(size_t world, size_t a, size_t b, size_t h, size_t l
 }
 
 void shim_set_world(int world) { g_world = world < 1 ? 1 : world; }
+void shim_set_domain(int kind, size_t m, const uint64_t *shift) {
+    g_dom_kind = kind;
+    g_dom_m = m;
+    for (int i = 0; i < 4; ++i) g_dom_shift[i] = shift ? shift[i] : 0;
+}
 
 int shim_groth16_prove(int curve, size_t M, size_t n, size_t N, const uint32_t *rpa, const uint32_t *cla, const uint64_t *cfa, const uint32_t *rpb,
                        const uint32_t *clb, const uint64_t *cfb, const uint32_t *rpc, const uint32_t *clc, const uint64_t *cfc,

@@ -8,7 +8,7 @@ import pytest
 
 import cport as cp
 import pyoracle as po
-from util import CURVES, fr_arr, fr_ints, jac_to_affine_py, limbs, pt_from_limbs, pt_limbs, pts_arr
+from util import CURVES, fr_arr, fr_ints, jac_to_affine_py, limbs, pt_from_limbs, pt_limbs, pts_arr, qap_domains
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -288,22 +288,35 @@ def test_msm_large_other_configs(ctx, zk, curve, group, log_n):
     b.free()
 
 
-@pytest.mark.parametrize("curve,M,n", [(1, 1024, 10), (0, 1024, 10), (0, 50, 3), (0, 4085, 10)])
-def test_groth16_witness_map(ctx, curve, M, n):
-    """r1cs_to_qap::witness_map on the device (sparse mat-vec, 7 NTTs, pointwise) against the oracle; the
-    example system has two rows of ~M terms (long-row path) and M short rows."""
+# M + n + 1: 2^4+3 -> step(20); 2^10+11 -> step(2^10+16); 54 -> basic(64); 4096 -> basic; 65 -> step(64 + 1);
+# 2^11+256 -> step, 256 columns; 2^12+1000 -> step(2^12 + 2^10): column tiles; 2^15+16 -> step
+@pytest.mark.parametrize("curve,M,n", [(0, 16, 2), (1, 1024, 10), (0, 1024, 10), (0, 50, 3), (0, 4085, 10), (1, 60, 4), (0, 2048 + 250, 5),
+                                       (0, 4096 + 990, 9), (1, 32768, 15), (0, 32768, 15)])
+def test_groth16_witness_map(ctx, zk, curve, M, n):
+    """r1cs_to_qap::witness_map on the device (sparse mat-vec, 7 transforms, pointwise) against the oracle, over the domain
+    make_evaluation_domain(M + n + 1) picks -- a step radix-2 domain for most sizes -- and over the basic domain of the next
+    power of two; the example system has two rows of ~M terms (long-row path) and M short rows."""
     C = CURVES[curve]
     g16 = cp.Groth16(curve, M, n, seed=3)
     assert g16.is_satisfied()
-    w = limbs(C.root_of_unity(g16.log_m), 4)
     gen = limbs(C.fr_generator, 4)
-    exp = g16.witness_map(w, gen)
     r1cs = ctx.upload_r1cs(curve, g16.M, g16.n, g16.N, g16.csr(0), g16.csr(1), g16.csr(2))
-    assert r1cs.m == g16.m
     z = np.concatenate([np.array([[1, 0, 0, 0]], dtype=np.uint64), g16.assignment()])
-    got = ctx.groth16_witness_h(r1cs, z, w, gen)
-    assert (got == exp).all()
-    assert not got[g16.m - 1].any() and not got[g16.m].any()  # prover.hpp:88-89
+    dom, zd = qap_domains(zk, curve, M + n + 1)
+    assert (r1cs.kind, r1cs.m) == (dom.kind, dom.m) == zk.zkhip.domain_choice(curve, M + n + 1)
+    # the basic domain of the next power of two first (the oracle's default), then the reference's choice
+    m2 = 1 << (M + n).bit_length()
+    for kind, m, w in ((0, m2, limbs(C.root_of_unity(m2.bit_length() - 1), 4)), (dom.kind, dom.m, limbs(dom.omega, 4))):
+        r1cs.set_domain(kind, m)
+        if kind != 0:
+            g16.set_domain(kind, m, w)
+        assert r1cs.m == g16.m == m
+        exp = g16.witness_map(w, gen)
+        got = ctx.groth16_witness_h(r1cs, z, w, gen)
+        assert (got == exp).all()
+        assert not got[m - 1].any() and not got[m].any()  # prover.hpp:88-89
+        if kind != 0:    # the same through the whole domain description
+            assert (ctx.groth16_witness_h(r1cs, z, zd, gen) == exp).all()
     r1cs.free()
 
 

@@ -6,7 +6,7 @@ import pytest
 
 import cport as cp
 import pyoracle as po
-from util import CURVES, fr_ints, limbs
+from util import CURVES, fr_arr, fr_ints, limbs, qap_domains
 
 pytestmark = pytest.mark.gpu
 
@@ -170,3 +170,43 @@ def test_ntt_rejects_a_root_of_the_wrong_order(zk, ctx):
     for bad in (w * w % C.r, 1, C.root_of_unity(log_m + 1), C.r - 1):
         with pytest.raises(zk.ZkhipError):
             ctx.ntt(0, a, log_m, limbs(bad, 4))
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_domain_fft_all_kinds(ctx, zk, curve):
+    """evaluation_domain::fft / inverse_fft over the domains make_evaluation_domain returns for sizes that are no power of
+    two (step radix-2; extended radix-2 over a pretended small two-adicity), against the oracle's domains -- which are pinned
+    to the definitions over each point set (tests/test_oracle_kat.py) -- and, at the small sizes, against the definition
+    directly; with and without the coset, batches, both directions, round trips."""
+    C = CURVES[curve]
+    r = C.r
+    g = C.fr_generator
+    gl = limbs(g, 4)
+    # (min_size, pretended two-adicity): step domains with 1, 4, 16, 256, 512, 1024 columns and compr 2 .. 2^11; extended at 2^(s+1)
+    cases = [(3, None), (5, None), (12, None), (20, None), (48, None), (65, None), (1040, None), (2048 + 256, None), (4096 + 512, None),
+             (4096 + 2048, None), (8192 + 1024, None), (32768 + 16, None), (8, 2), (64, 5), (2048, 10), (32, None)]
+    for n, s in cases:
+        dom, zd = qap_domains(zk, curve, n, two_adicity=s)
+        m = dom.m
+        batch = 3 if m < 4096 else 2
+        a = cp.random_fr(curve, 77 + n, batch * m).reshape(batch, m, 4)
+        sh = limbs(dom.shift, 4)
+        exp = np.stack([cp.domain_fft(curve, dom.kind, a[b], limbs(dom.omega, 4), sh) for b in range(batch)])
+        got = ctx.domain_fft(curve, zd, a)
+        assert (got == exp).all(), (curve, dom.describe())
+        if m <= 64:
+            xs = dom.elements()
+            assert fr_ints(got[0]) == [po.poly_eval(fr_ints(a[0]), x, r) for x in xs]
+        assert (ctx.domain_fft(curve, zd, got, inverse=True) == a).all()
+        # coset: multiply_by_coset(g) then fft; inverse_fft then multiply_by_coset(g^-1)
+        ac = np.stack([fr_arr(po.multiply_by_coset(fr_ints(a[b]), g, r)) for b in range(batch)]) if m <= 4096 else None
+        gotc = ctx.domain_fft(curve, zd, a, coset=gl)
+        if ac is not None:
+            expc = np.stack([cp.domain_fft(curve, dom.kind, ac[b], limbs(dom.omega, 4), sh) for b in range(batch)])
+            assert (gotc == expc).all(), (curve, dom.describe(), "coset")
+        assert (ctx.domain_fft(curve, zd, gotc, inverse=True, coset=gl) == a).all()
+    # a root of the wrong order is refused
+    dom, zd = qap_domains(zk, curve, 20)
+    bad = zk.zkhip.Domain.make(dom.kind, dom.m, limbs(C.root_of_unity(4), 4))
+    with pytest.raises(zk.zkhip.ZkhipError):
+        ctx.domain_fft(curve, bad, cp.random_fr(curve, 1, 20).reshape(1, 20, 4))

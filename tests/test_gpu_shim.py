@@ -35,22 +35,39 @@ def P(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-@pytest.mark.parametrize("curve,M,n,world", [(1, 1024, 10, 1), (0, 1024, 10, 1), (0, 100, 10, 1), (0, 1 << 15, 10, 1),
-                                             (0, 1024, 10, 2), (1, 1024, 10, 3), (0, 100, 10, 8)])
-def test_groth16_prover_shim(shim, curve, M, n, world):
-    """world > 1: the same proof sharded over `world` ranks (each holding a slice of every query; process_partial, the
-    all-gather emulated by concatenation, finish) must equal the single-GPU proof -- SURVEY 8e's point-range partition."""
+def _oracle_domain(g, curve, M, n, domain):
+    """the oracle instance on the domain the test names: "basic" = 2^ceil(log2(M + n + 1)) points (the oracle's default), "ref" = what
+    make_evaluation_domain(M + n + 1) picks (r1cs_to_qap.hpp:229-230).  Both use the same root: the primitive 2^ceil(log2)-th one."""
+    C = CURVES[curve]
+    w = limbs(C.root_of_unity((M + n).bit_length()), 4)
+    if domain == "ref":
+        kind, m = cp.domain_choice(M + n + 1, C.two_adicity)
+        g.set_domain(kind, m, w)
+    return w
+
+
+# M + n + 1 = 2^4+3 -> step(20), 2^10+11 -> step(2^10+16), 2^15+11 -> step(2^15+16), 111 -> basic(128)
+@pytest.mark.parametrize("curve,M,n,world,domain", [(1, 1024, 10, 1, "basic"), (0, 1024, 10, 1, "basic"), (0, 100, 10, 1, "basic"), (0, 1 << 15, 10, 1, "basic"),
+                                                    (0, 1024, 10, 2, "basic"), (1, 1024, 10, 3, "basic"), (0, 100, 10, 8, "basic"),
+                                                    (0, 16, 2, 1, "ref"), (1, 1024, 10, 1, "ref"), (0, 1024, 10, 1, "ref"), (0, 1 << 15, 10, 1, "ref"),
+                                                    (0, 1024, 10, 2, "ref"), (1, 1024, 10, 3, "ref")])
+def test_groth16_prover_shim(shim, curve, M, n, world, domain):
+    """A key made by the oracle, over the basic domain of the next power of two or over the domain the reference's
+    make_evaluation_domain picks (the shim tells them apart by the H query's size), proven with through the shim: bit-exact
+    against the oracle's proof.  world > 1: the same proof sharded over `world` ranks (each holding a slice of every query;
+    process_partial, the all-gather emulated by concatenation, finish) must equal the single-GPU proof -- SURVEY 8e's
+    point-range partition."""
     shim.shim_set_world(world)
     try:
-        _groth16_prover_shim(shim, curve, M, n)
+        _groth16_prover_shim(shim, curve, M, n, domain)
     finally:
         shim.shim_set_world(1)
 
 
-def _groth16_prover_shim(shim, curve, M, n):
+def _groth16_prover_shim(shim, curve, M, n, domain):
     C = CURVES[curve]
     g = cp.Groth16(curve, M, n, seed=1)
-    w = limbs(C.root_of_unity(g.log_m), 4)
+    w = _oracle_domain(g, curve, M, n, domain)
     gen = limbs(C.fr_generator, 4)
     rng = po.SplitMix64(2024)
     trap = fr_arr([rng.next_mod(C.r) for _ in range(5)])
@@ -85,16 +102,20 @@ def _groth16_prover_shim(shim, curve, M, n):
         assert (proof == np.concatenate([pt_limbs(curve, 1, eA), pt_limbs(curve, 2, eB), pt_limbs(curve, 1, eC)])).all()
 
 
-@pytest.mark.parametrize("curve,M,n", [(0, 100, 10), (1, 1024, 10), (0, (1 << 15) + 5, 3), (0, (1 << 20) - 11, 10), (0, 1 << 20, 10)])
-def test_groth16_device_generated_key_matches_trapdoor(shim, curve, M, n):
-    """BASELINE config 4 AT ITS SIZE (M = 2^20, n = 10: domain 2^21; and the m = 2^20 variant M = 2^20 - 11): the key is generated
-    on the device from a fixed trapdoor (r1cs_gg_ppzksnark_generator_hip = generator.hpp:240-377 with the batch
-    exponentiations on the GPU), one proof is made with injected (r, s), and it must EQUAL the proof the trapdoor dictates
-    (A = a G1, B = b G2, C = c G1; prover.hpp:141,145,151-153) -- a, b, c computed by the oracle without any MSM / NTT.
-    A wrong bucket, twiddle or query entry anywhere in the 5.2 M-point key or the 2^21-point transforms changes the result."""
+@pytest.mark.parametrize("curve,M,n,domain", [(0, 100, 10, "ref"), (0, 16, 2, "ref"), (1, 1024, 10, "ref"), (1, 1024, 10, "basic"), (0, (1 << 15) + 5, 3, "ref"),
+                                              (0, (1 << 20) - 11, 10, "ref"), (0, 1 << 20, 10, "ref"), (0, 1 << 20, 10, "basic")])
+def test_groth16_device_generated_key_matches_trapdoor(shim, curve, M, n, domain):
+    """BASELINE config 4 AT ITS SIZE (M = 2^20, n = 10) over the domain the reference reduces over -- make_evaluation_domain(2^20 + 11)
+    = the step radix-2 domain of 2^20 + 16 points -- and over the basic domain of 2^21 points, plus the m = 2^20 variant
+    (M = 2^20 - 11): the key is generated on the device from a fixed trapdoor (r1cs_gg_ppzksnark_generator_hip =
+    generator.hpp:240-377 with the batch exponentiations on the GPU), one proof is made with injected (r, s), and it must
+    EQUAL the proof the trapdoor dictates (A = a G1, B = b G2, C = c G1; prover.hpp:141,145,151-153) -- a, b, c computed by
+    the oracle without any MSM / NTT.  A wrong bucket, twiddle or query entry anywhere in the key or the transforms changes
+    the result."""
     C = CURVES[curve]
     g = cp.Groth16(curve, M, n, seed=1)
-    w = limbs(C.root_of_unity(g.log_m), 4)
+    w = _oracle_domain(g, curve, M, n, domain)
+    shim.shim_set_domain(0 if domain == "basic" else -1, ctypes.c_size_t(g.m if domain == "basic" else 0), None)
     gen = limbs(C.fr_generator, 4)
     rng = po.SplitMix64(4242)
     trap = fr_arr([rng.next_mod(C.r) for _ in range(5)])
@@ -106,15 +127,18 @@ def test_groth16_device_generated_key_matches_trapdoor(shim, curve, M, n):
     L1, L2 = 2 * FQ_LIMBS[curve], 4 * FQ_LIMBS[curve]
     proof = np.zeros(2 * L1 + L2, dtype=np.uint64)
     ms = np.zeros(2, dtype=np.float64)
-    rc = shim.shim_groth16_generate_prove(curve, ctypes.c_size_t(g.M), ctypes.c_size_t(g.n), ctypes.c_size_t(g.N), *args, P(g.assignment()), P(trap), P(w),
-                                          P(gen), P(r_), P(s_), P(proof), P(ms))
+    try:
+        rc = shim.shim_groth16_generate_prove(curve, ctypes.c_size_t(g.M), ctypes.c_size_t(g.n), ctypes.c_size_t(g.N), *args, P(g.assignment()), P(trap), P(w),
+                                              P(gen), P(r_), P(s_), P(proof), P(ms))
+    finally:
+        shim.shim_set_domain(-1, ctypes.c_size_t(0), None)
     assert rc == 0
     a, b, c = g.expected_exponents(trap, w, r_, s_)
     eA, _ = cp.batch_mul(curve, 1, a.reshape(1, 4))
     eB, _ = cp.batch_mul(curve, 2, b.reshape(1, 4))
     eC, _ = cp.batch_mul(curve, 1, c.reshape(1, 4))
     assert (proof == np.concatenate([eA[0], eB[0], eC[0]])).all()
-    print("M = %d: key generated on the device in %.0f ms, first proof %.1f ms" % (M, ms[0], ms[1]))
+    print("M = %d, domain of %d points: key generated on the device in %.0f ms, first proof %.1f ms" % (M, g.m, ms[0], ms[1]))
 
 
 @pytest.mark.parametrize("curve,log_n,batch", [(0, 10, 3), (1, 8, 2), (0, 19, 2)])

@@ -83,14 +83,31 @@ def test_query_shards_partition(shim, world):
         assert n.max() - n.min() <= 1                                                          # balanced
 
 
-@pytest.mark.parametrize("curve,M,n", [(0, 16, 3), (1, 100, 10), (0, 5000, 10)])
-def test_generator_host_side_matches_oracles(shim, curve, M, n):
+# domain: "ref" = what make_evaluation_domain(M + n + 1) picks (step radix-2 for 20, 5011; basic for 111), "basic" = the basic
+# domain of the next power of two named explicitly, "extended" = an extended radix-2 domain named explicitly
+@pytest.mark.parametrize("curve,M,n,domain", [(0, 16, 3, "ref"), (0, 16, 3, "basic"), (0, 16, 3, "extended"), (1, 100, 10, "ref"), (1, 1024, 10, "ref"),
+                                              (0, 5000, 10, "ref"), (0, 5000, 10, "basic"), (1, 5000, 10, "extended")])
+def test_generator_host_side_matches_oracles(shim, curve, M, n, domain):
     """The host half of the device key generator (hip/r1cs_gg_ppzksnark_generator.hpp: swap_AB_if_beneficial,
-    instance_map_with_evaluation = r1cs_to_qap.hpp:138-187, and the trapdoor exponents of a proof) against the C++ oracle,
-    and at the small sizes against the big-integer oracle (po.groth16_expected_in_exponent)."""
+    instance_map_with_evaluation = r1cs_to_qap.hpp:138-187 over hip/evaluation_domain.hpp, and the trapdoor exponents of a
+    proof) against the C++ oracle, and at the small sizes against the big-integer oracle (po.groth16_expected_in_exponent)."""
     C = CURVES[curve]
     g = cp.Groth16(curve, M, n, seed=3)
-    w = C.root_of_unity(g.log_m)
+    pow2 = 1 << (M + n).bit_length()
+    shift = None
+    if domain == "ref":
+        dom = po.make_evaluation_domain(C, M + n + 1)
+        assert (dom.kind, dom.m) == cp.domain_choice(M + n + 1, C.two_adicity)
+        shim.shim_set_domain(-1, ctypes.c_size_t(0), None)
+    elif domain == "basic":
+        dom = po.EvaluationDomain(po.EvaluationDomain.BASIC, pow2, C.root_of_unity(pow2.bit_length() - 1), C.r)
+        shim.shim_set_domain(0, ctypes.c_size_t(pow2), None)
+    else:
+        dom = po.EvaluationDomain(po.EvaluationDomain.EXTENDED, pow2, C.root_of_unity(pow2.bit_length() - 2), C.r, pow(C.fr_generator, 2, C.r))
+        shift = limbs(dom.shift, 4)
+        shim.shim_set_domain(1, ctypes.c_size_t(pow2), P(shift))
+    g.set_domain(dom.kind, dom.m, limbs(dom.omega, 4), shift)
+    w = dom.omega
     rng = po.SplitMix64(77 + M)
     trap = [rng.next_mod(C.r) for _ in range(5)]
     rr, ss = rng.next_mod(C.r), rng.next_mod(C.r)
@@ -103,12 +120,15 @@ def test_generator_host_side_matches_oracles(shim, curve, M, n):
     assignment = g.assignment()
     out = np.zeros((3, 4), dtype=np.uint64)
     T, W, R, S = fr_arr(trap), limbs(w, 4), limbs(rr, 4), limbs(ss, 4)
-    assert shim.shim_host_qap_exponents(curve, ctypes.c_size_t(g.M), ctypes.c_size_t(g.n), ctypes.c_size_t(g.N), *args, P(assignment), P(T), P(W), P(R),
-                                        P(S), P(out)) == 0
+    try:
+        assert shim.shim_host_qap_exponents(curve, ctypes.c_size_t(g.M), ctypes.c_size_t(g.n), ctypes.c_size_t(g.N), *args, P(assignment), P(T), P(W), P(R),
+                                            P(S), P(out)) == 0
+    finally:
+        shim.shim_set_domain(-1, ctypes.c_size_t(0), None)
     exp = g.expected_exponents(T, W, R, S)
     assert (out == exp).all()
     if M <= 100:
         cs, prim, aux = po.r1cs_example_field_input(C.r, M, n, seed=3)
-        eA, eB, eC = po.groth16_expected_in_exponent(C, cs, prim, aux, trap, rr, ss, w)
+        eA, eB, eC = po.groth16_expected_in_exponent(C, cs, prim, aux, trap, rr, ss, dom)
         a, b, c = fr_ints(out)
         assert (C.g1.mul(C.g1.gen, a), C.g2.mul(C.g2.gen, b), C.g1.mul(C.g1.gen, c)) == (eA, eB, eC)

@@ -61,3 +61,11 @@ def jac_to_affine_py(curve, group, jac):
 def group_of(curve, group):
     C = CURVES[curve]
     return C.g1 if group == 1 else C.g2
+
+
+def qap_domains(zkmod, curve, min_size, two_adicity=None):
+    """make_evaluation_domain(min_size) twice: pyoracle's EvaluationDomain and the zkhip_domain describing the same"""
+    C = CURVES[curve]
+    dom = po.make_evaluation_domain(C, min_size, two_adicity=two_adicity)
+    zd = zkmod.zkhip.Domain.make(dom.kind, dom.m, limbs(dom.omega, 4), limbs(dom.shift, 4))
+    return dom, zd
