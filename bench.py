@@ -299,12 +299,17 @@ def main():
                 line["roofline"]["valu"] = dict(traffic["valu"]["msm_bucket_acc"], bound="VALU issue: 4 cycles per wave instruction on 1024 SIMDs",
                                                 source="SQ_INSTS_VALU, GRBM_GUI_ACTIVE / 8 of a third child pass")
         else:
-            line["roofline"]["traffic_source"] = "not collected in this run (rocprofv3 unavailable, --no-pmc, or N > 1); see profiles/ for the offline passes"
+            line["roofline"]["traffic_source"] = ("not collected: bench.py itself runs under a profiler (no nested rocprofv3)" if under_profiler() else
+                                                  "not collected in this run (rocprofv3 unavailable, --no-pmc, or N > 1); see profiles/ for the offline passes")
         if world == 1 and not args.no_ntt:
             line["ntt"] = ntt_leg(np, zk, ctx, verify=not args.no_verify, traffic=traffic)
         if world == 1 and not args.no_groth16:
-            line["groth16"] = groth16_leg(np, steps=8, verify=not args.no_verify)
-            line["groth16_m2p20"] = groth16_leg(np, constraints=(1 << 20) - 11, steps=6, verify=not args.no_verify)
+            valu = (traffic or {}).get("valu", {}).get("msm_bucket_acc")
+            # BASELINE cfg 4's instance (M = 2^20, n = 10) over the domain the reference reduces over (step radix-2, 2^20 + 16 points),
+            # the same instance over the basic domain of 2^21 points (round 2's figure), and the m = 2^20 variant (M = 2^20 - 11)
+            line["groth16"] = groth16_leg(np, steps=8, verify=not args.no_verify, valu=valu)
+            line["groth16_basic_2p21"] = groth16_leg(np, steps=6, verify=not args.no_verify, domain="basic", valu=valu)
+            line["groth16_m2p20"] = groth16_leg(np, constraints=(1 << 20) - 11, steps=6, verify=not args.no_verify, valu=valu)
         if g16_sharded is not None:
             line["groth16_sharded"] = g16_sharded
         if kzg_sharded is not None:
@@ -348,6 +353,19 @@ def dry_run(args):
     return 0
 
 
+def _profiler_var(name):
+    return name in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB") or name.startswith(("ROCPROF", "ROCP_", "ROCTRACER_", "ROCTX_"))
+
+
+def under_profiler():
+    """True when this process runs under rocprofv3 / rocprof (its tool library is preloaded into every child): the live PMC
+    passes are skipped then -- the launcher of a nested rocprofv3 would initialise the GPU before exec'ing its target."""
+    env = os.environ
+    if any("rocprof" in env.get(k, "").lower() or "roctracer" in env.get(k, "").lower() for k in ("LD_PRELOAD", "HSA_TOOLS_LIB")):
+        return True
+    return any(k == "ROCP_TOOL_LIBRARIES" or k.startswith(("ROCPROFILER_", "ROCPROF_")) for k in env)
+
+
 def pmc_traffic_live(log_n):
     """HBM bytes per launch of the dominant kernels -- and how busy their SIMDs are --, measured in THIS run: child passes of
     tools/pmc_child.py (the same MSM and NTT workloads) under `rocprofv3 --pmc`, FETCH_SIZE and WRITE_SIZE in passes of their
@@ -357,11 +375,12 @@ def pmc_traffic_live(log_n):
     XCDs) is the fraction of the VALU issue capacity in use -- the bound these integer kernels actually sit on.
     {kernel: bytes, "valu": {kernel: {...}}}; None when rocprofv3 is absent or a traffic pass fails (bounded by a timeout)."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(exe):
-        return None
+    if not os.path.exists(exe) or under_profiler():
+        return None  # a profiled bench.py must not start a nested profiler (its launcher would inherit the preloaded tool library)
     sums = {}
     tmp = tempfile.mkdtemp(prefix="zkhip_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = {k: v for k, v in os.environ.items() if not _profiler_var(k)}
+    env["TMPDIR"] = "/tmp"
     try:
         for group in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE")):
             out = os.path.join(tmp, group[0])
@@ -461,15 +480,19 @@ def _bench_lib():
 
     so = os.path.join(ROOT, "crypto3-zk_amd", "libzkhip_bench.so")
     if not os.path.exists(so):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "crypto3-zk_amd"), "libzkhip_bench.so"], stdout=subprocess.DEVNULL)
+        # never build from here: this process has initialised the GPU (and may be profiled) -- spawning a compiler driver from it
+        # is exactly the exec the pool forbids
+        raise SystemExit("bench.py: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` first" % so)
     return ctypes.CDLL(so)
 
 
-def groth16_leg(np, constraints=1 << 20, inputs=10, steps=4, verify=True):
-    """The other half of BASELINE.json's metric: Groth16 prove constraints/s on one GPU (config 4's single-GPU leg:
-    M = 2^20, n = 10, domain 2^21; and the m = 2^20 variant M = 2^20 - 11) through the header-only shim, assignment H2D and
-    result D2H included.  The key is a VALID key generated on the device from a fixed trapdoor; after the timed proofs the
-    last one is held against the trapdoor identity (bench/groth16_bench.cpp)."""
+def groth16_leg(np, constraints=1 << 20, inputs=10, steps=4, verify=True, domain="ref", valu=None):
+    """The other half of BASELINE.json's metric: Groth16 prove constraints/s on one GPU (config 4's single-GPU leg: M = 2^20,
+    n = 10) through the header-only shim, assignment H2D and result D2H included.  domain = "ref": the evaluation domain the
+    reference reduces over, make_evaluation_domain(M + n + 1) (r1cs_to_qap.hpp:229-230) -- for M = 2^20, n = 10 the step radix-2
+    domain of 2^20 + 16 points; "basic": the basic radix-2 domain of the next power of two (2^21: round 2's figure).  The key is a
+    VALID key generated on the device from a fixed trapdoor over that domain; after the timed proofs the last one is held against
+    the trapdoor identity (bench/groth16_bench.cpp)."""
     import ctypes
 
     lib = _bench_lib()
@@ -478,23 +501,53 @@ def groth16_leg(np, constraints=1 << 20, inputs=10, steps=4, verify=True):
     m = 1
     while m < M + inputs + 1:
         m <<= 1
+    # the one root both domains use: the primitive 2^ceil(log2(M + n + 1))-th (step domain: big = m / 2, omega of order 2 big)
     omega, coset = lim(np, pow(g, (r - 1) // m, r)), lim(np, g)
     times = np.zeros(steps, dtype=np.float64)
     setup = ctypes.c_double()
     verified = ctypes.c_int(-1)
     prof = ctypes.create_string_buffer(16384)
-    rc = lib.zkhip_bench_groth16(0, 0, ctypes.c_size_t(M), ctypes.c_size_t(inputs), ctypes.c_uint64(1), steps, omega.ctypes.data_as(ctypes.c_void_p),
-                                 coset.ctypes.data_as(ctypes.c_void_p), times.ctypes.data_as(ctypes.c_void_p), ctypes.byref(setup),
-                                 ctypes.byref(verified) if verify else None, prof, ctypes.c_size_t(16384))
+    lib.zkhip_bench_set_domain(0 if domain == "basic" else -1, ctypes.c_size_t(m if domain == "basic" else 0))
+    try:
+        rc = lib.zkhip_bench_groth16(0, 0, ctypes.c_size_t(M), ctypes.c_size_t(inputs), ctypes.c_uint64(1), steps, omega.ctypes.data_as(ctypes.c_void_p),
+                                     coset.ctypes.data_as(ctypes.c_void_p), times.ctypes.data_as(ctypes.c_void_p), ctypes.byref(setup),
+                                     ctypes.byref(verified) if verify else None, prof, ctypes.c_size_t(16384))
+    finally:
+        lib.zkhip_bench_set_domain(-1, ctypes.c_size_t(0))
     if rc != 0:
         return {"error": rc}
+    info = np.zeros(8, dtype=np.uint64)
+    lib.zkhip_bench_last_info(info.ctypes.data_as(ctypes.c_void_p))
+    kind, dm, qa, qb, qh, ql = (int(x) for x in info[:6])
     timed = times[1:] if steps > 1 else times  # the first proof allocates the key's work buffers
     mean = float(timed.mean())
+    kern = {}
+    for ln in prof.value.decode(errors="ignore").splitlines():
+        f = ln.split()
+        if len(f) == 3:
+            kern[f[0]] = round(float(f[1]), 4)
+    # SURVEY 8d's algorithmic bytes of a proof: 7 transforms x m x 64 B + every G1 base and its scalar once (96 + 32 B) + the G2
+    # bases of the B query (192 + 32 B)
+    alg = 7 * dm * 64 + (qa + qb + qh + ql) * 128 + qb * 224
+    ach = alg / (mean * 1e-3) / 1e9
+    tot = sum(kern.values()) or 1.0
+    dom_k = max(kern, key=kern.get) if kern else None
+    roof = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+            "algorithmic_bytes_per_proof": alg, "per": "whole proof (wall time of process(), H2D of the assignment and D2H of the results included)",
+            "dominant_kernel": dom_k, "dominant_kernel_share_of_kernel_time": round(kern[dom_k] / tot, 4) if dom_k else None,
+            "honest_bound": "integer VALU issue: 5 G1 + 1 G2 bucket accumulations are %.0f %% of the kernel time of a proof" %
+                            (100 * sum(v for k, v in kern.items() if k.startswith("msm_bucket_acc")) / tot)}
+    if valu:
+        roof["valu"] = dict(valu, note="msm_bucket_acc<G1> as measured by this run's PMC child pass (the same kernel a proof spends most of its time in)")
     return {"metric": "Groth16 prove constraints/sec, BLS12-381, %d constraints, 1 GPU" % M, "value": round(M / mean * 1e3, 1),
-            "unit": "constraints/s", "statistic": "mean of the proofs after the first", "ms_per_proof": [round(float(x), 2) for x in times], "domain": m,
+            "unit": "constraints/s", "statistic": "mean of the proofs after the first", "ms_per_proof": [round(float(x), 2) for x in times],
+            "domain": {"kind": ("basic_radix2", "extended_radix2", "step_radix2")[kind], "points": dm,
+                       "chosen_by": "make_evaluation_domain(M + n + 1), as the reference (r1cs_to_qap.hpp:229-230)" if domain == "ref" else "named: next power of two"},
+            "query_sizes": {"A": qa, "B": qb, "H": qh, "L": ql},
             "key": "valid Groth16 key, generated on the device from a fixed trapdoor (r1cs_gg_ppzksnark_generator_hip), resident",
             "key_setup_ms": round(setup.value, 1), "verified": None if not verify else bool(verified.value == 1),
-            "verification": "proof == (a G1, b G2, c G1) with a, b, c from the trapdoor identities (prover.hpp:141-153)"}
+            "verification": "proof == (a G1, b G2, c G1) with a, b, c from the trapdoor identities (prover.hpp:141-153)",
+            "roofline": roof, "kernel_ms_last_proof": kern}
 
 
 def groth16_sharded_leg(np, torch, dist, rank, world, local_rank, log_constraints=20, inputs=10, steps=3, verify=True):

@@ -38,6 +38,10 @@ typedef void (*all_gather_fn)(const uint64_t *mine, size_t words, uint64_t *all)
 // called between key generation and the timed proofs (tools/groth16_two_provers.py lines its threads up there)
 typedef void (*after_setup_fn)();
 after_setup_fn g_after_setup = nullptr;
+// the evaluation domain the next runs name (kind < 0: make_evaluation_domain's choice, the default) and what the last run used
+int g_dom_kind = -1;
+size_t g_dom_m = 0;
+uint64_t g_last_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // domain kind, domain points, A / B / H / L query sizes of this rank, N, n
 
 template <typename Curve>
 int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gather, size_t M, size_t n, uint64_t seed, int steps, const uint64_t *omega,
@@ -93,6 +97,8 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
 
     context ctx(device);
     domain_params<Curve> dom {A::scalar_from_limbs(omega), A::scalar_from_limbs(coset)};
+    dom.kind = g_dom_kind;
+    dom.m = g_dom_m;
     /* the toxic waste: fixed by the seed (identical on every rank of a sharded proof) */
     SplitMix key_rng {seed * 1000003 + 1};
     auto rnd_key = [&]() {
@@ -102,6 +108,11 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
     const Fr t = rnd_key(), alpha = rnd_key(), beta = rnd_key(), gamma = rnd_key(), delta = rnd_key();
     auto key = r1cs_gg_ppzksnark_generator_hip<Curve>::deterministic_basic_process(ctx, cs, dom, t, alpha, beta, gamma, delta, rank, world);
     auto &dpk = *key->device;
+    {
+        const uint64_t info[8] = {(uint64_t)dpk.evaluation_domain.kind, dpk.evaluation_domain.m, dpk.A_query.size(), dpk.B_count, dpk.H_query.size(),
+                                  dpk.L_query.size(), cs.num_variables(), cs.num_inputs()};
+        memcpy(g_last_info, info, sizeof(info));
+    }
     if (const char *e = getenv("ZKHIP_G16_OVERLAP")) dpk.overlap_g2 = atoi(e) != 0;    // experiments: G2 multiexp on the main stream
     ctx.sync();
     *setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -135,6 +146,12 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
 extern "C" {
 
 void zkhip_bench_set_after_setup(void (*fn)()) { g_after_setup = fn; }
+/* kind < 0: make_evaluation_domain(M + n + 1)'s choice (r1cs_to_qap.hpp:229-230); 0 with m = 2^k: the basic domain of that size */
+void zkhip_bench_set_domain(int kind, size_t m) {
+    g_dom_kind = kind;
+    g_dom_m = m;
+}
+void zkhip_bench_last_info(uint64_t *out) { memcpy(out, g_last_info, sizeof(g_last_info)); }
 
 int zkhip_bench_groth16(int device, int curve, size_t M, size_t n, uint64_t seed, int steps, const uint64_t *omega, const uint64_t *coset, double *times,
                         double *setup_ms, int *verified, char *prof, size_t prof_cap) {
