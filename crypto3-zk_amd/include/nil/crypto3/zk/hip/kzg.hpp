@@ -4,6 +4,8 @@
 // Mirrors zk/commitments/polynomial/kzg.hpp:
 //   params_type { commitment_key = { alpha^i * G1 } }                      (:262-290)
 //   commit_one<KZG>(params, polynomial_dfs)  = multiexp(ck, p.coefficients()) (:427-435: iNTT then MSM, chunks = 1)
+//   commit_one<KZG>(params, polynomial)      = multiexp(ck, coefficients)        (:409-420)
+//   commit_g2<KZG>(params, polynomial)       = multiexp(verification_key, coefficients) in G2 (:497-510, 659-664)
 //   kzg_commitment_scheme[_v2]::commit(batch) loops commit_one over the batch (:748-765, kzg_v2.hpp:208-226)
 // Here the whole batch is transformed by ONE batched inverse NTT and the coefficient vectors never leave HBM:
 // each column's MSM reads them in place against the resident SRS.
@@ -35,8 +37,15 @@ struct kzg_params_hip {
     kzg_params_hip(const context &ctx, InputIt ck_first, InputIt ck_last) : ctx(ctx), commitment_key(ctx, ck_first, ck_last) { }
     /// a commitment key that is already resident (device_bases::from_scalars / from_compressed, the powers-of-tau result)
     kzg_params_hip(const context &ctx, device_bases<CurveType, ZKHIP_G1> &&key) : ctx(ctx), commitment_key(std::move(key)) { }
+    /// batched_kzg::params_type (kzg.hpp:236-280): commitment_key = { alpha^i G1 }, verification_key = { alpha^i G2 }, i <= t
+    template <typename InputIt, typename VkIt>
+    kzg_params_hip(const context &ctx, InputIt ck_first, InputIt ck_last, VkIt vk_first, VkIt vk_last) :
+        ctx(ctx), commitment_key(ctx, ck_first, ck_last), verification_key(ctx, vk_first, vk_last) { }
+    kzg_params_hip(const context &ctx, device_bases<CurveType, ZKHIP_G1> &&key, device_bases<CurveType, ZKHIP_G2> &&vkey) :
+        ctx(ctx), commitment_key(std::move(key)), verification_key(std::move(vkey)) { }
     const context &ctx;
     device_bases<CurveType, ZKHIP_G1> commitment_key;
+    device_bases<CurveType, ZKHIP_G2> verification_key;    // empty unless given: only commit_g2 reads it
 };
 
 /// commit(batch): one commitment per polynomial; all polynomials must have the same power-of-two size
@@ -85,6 +94,23 @@ template <typename CurveType>
 typename curve_adapter<CurveType>::g1_value_type commit_one(const kzg_params_hip<CurveType> &params, const polynomial_dfs<CurveType> &poly,
                                                             const typename curve_adapter<CurveType>::scalar_value_type &omega) {
     return kzg_commit_batch<CurveType>(params, std::vector<polynomial_dfs<CurveType>> {poly}, omega)[0];
+}
+
+/// commit_one<KZG>(params, math::polynomial) (kzg.hpp:409-420): the polynomial given by its coefficients
+template <typename CurveType>
+typename curve_adapter<CurveType>::g1_value_type commit_one(const kzg_params_hip<CurveType> &params,
+                                                            const std::vector<typename curve_adapter<CurveType>::scalar_value_type> &poly) {
+    if (poly.size() > params.commitment_key.size()) throw std::runtime_error("commit_one: polynomial longer than the commitment key");
+    return multiexp<CurveType, ZKHIP_G1>(params.ctx, params.commitment_key, 0, poly.begin(), poly.end(), 1);
+}
+
+/// commit_g2<KZG>(params, poly) (kzg.hpp:497-510; kzg_commitment_scheme::commit_g2 :659-664): sum_i poly[i] * verification_key[i]
+template <typename CurveType>
+typename curve_adapter<CurveType>::g2_value_type commit_g2(const kzg_params_hip<CurveType> &params,
+                                                           const std::vector<typename curve_adapter<CurveType>::scalar_value_type> &poly) {
+    if (poly.size() > params.verification_key.size()) throw std::runtime_error("commit_g2: polynomial longer than the verification key");
+    if (poly.empty()) return curve_adapter<CurveType>::g2_value_type::zero();
+    return multiexp<CurveType, ZKHIP_G2>(params.ctx, params.verification_key, 0, poly.begin(), poly.end(), 1);
 }
 
 }    // namespace hip

@@ -141,8 +141,11 @@ typename curve_adapter<CurveType>::g1_value_type kzg_proof_eval(const kzg_params
     return multiexp_dev<CurveType, ZKHIP_G1>(ctx, params.commitment_key, 0, f.size() - 1, static_cast<const char *>(d.get()) + 32);
 }
 
+/// What kzg_commitment_scheme (kzg.hpp:636-873) and kzg_commitment_scheme_v2 (kzg_v2.hpp:56-360) share: the polys_evaluator
+/// state (batched_commitment.hpp:58-249), commit(batch) with the coefficient forms left resident, eval_polys, get_U,
+/// the transcript update and the device helpers of the opening proofs.
 template <typename CurveType, typename TranscriptType>
-class kzg_commitment_scheme_v2_hip {
+class kzg_polys_evaluator_hip {
 public:
     typedef curve_adapter<CurveType> adapter;
     typedef CurveType curve_type;
@@ -154,16 +157,12 @@ public:
     typedef polynomial_dfs<CurveType> poly_type;
     typedef eval_storage_hip<CurveType> eval_storage_type;
     typedef bool preprocessed_data_type;
-    struct proof_type {
-        eval_storage_type z;
-        single_commitment_type pi_1, pi_2;
-    };
     /// primitive 2^log_n-th root of unity of the evaluation domains (math::make_evaluation_domain's choice)
     typedef std::function<scalar_value_type(std::size_t log_n)> root_of_unity_type;
 
     eval_storage_type _z;
 
-    kzg_commitment_scheme_v2_hip(const params_type &kzg_params, root_of_unity_type root_of_unity) :
+    kzg_polys_evaluator_hip(const params_type &kzg_params, root_of_unity_type root_of_unity) :
         _params(kzg_params), _root_of_unity(std::move(root_of_unity)) { }
 
     const params_type &get_commitment_params() const { return _params; }
@@ -241,98 +240,6 @@ public:
         _locked[index] = true;
         _points[index].resize(polys.size());
         return _ind_commitments[index];
-    }
-
-    /// proof_eval (kzg_v2.hpp:236-305)
-    proof_type proof_eval(transcript_type &transcript) {
-        typedef detail::small_poly<scalar_value_type> SP;
-        const context &ctx = _params.ctx;
-        eval_polys();
-        merge_eval_points();
-        for (const auto &it : _ind_commitments) update_transcript(it.first, transcript);
-
-        auto theta = transcript.challenge();
-        const std::vector<scalar_value_type> V = SP::vanishing(_merged_points);
-
-        /* every committed polynomial in the reference's iteration order (batches ascending, then index) */
-        struct item {
-            std::size_t k, i;
-            const void *d;
-            std::size_t len;
-            std::vector<scalar_value_type> U, diff;
-        };
-        std::vector<item> items;
-        std::size_t max_len = 0, taps = 1;
-        for (const auto &it : _dev) {
-            const std::size_t k = it.first;
-            for (std::size_t i = 0; i < it.second.len.size(); ++i) {
-                item e {k, i, it.second.at(i), it.second.len[i], get_U(k, i), set_difference_polynom(_points.at(k)[i])};
-                max_len = std::max(max_len, e.len);
-                taps = std::max(taps, e.diff.size());
-                items.push_back(std::move(e));
-            }
-        }
-        single_commitment_type pi_1 = single_commitment_type::zero(), pi_2 = single_commitment_type::zero();
-        if (!items.empty()) {
-            /* f = sum_i theta^i (f_i - U_i) diffpoly_i (kzg_v2.hpp:251-263): the f_i part in one pass over the resident
-               coefficients, the U_i part (a few coefficients) on the host */
-            const std::size_t acc_len = max_len + taps - 1;
-            std::vector<const void *> ptrs;
-            std::vector<std::size_t> lens;
-            std::vector<std::uint64_t> coeffs(items.size() * taps * 4, 0);
-            std::vector<scalar_value_type> corr;
-            scalar_value_type theta_i = scalar_value_type::one();
-            for (std::size_t n = 0; n < items.size(); ++n) {
-                ptrs.push_back(items[n].d);
-                lens.push_back(items[n].len);
-                auto c = SP::scale(items[n].diff, theta_i);
-                for (std::size_t t = 0; t < c.size(); ++t) adapter::scalar_to_limbs(c[t], &coeffs[4 * (n * taps + t)]);
-                corr = SP::add(corr, SP::scale(SP::mul(items[n].U, c), scalar_value_type::zero() - scalar_value_type::one()));
-                theta_i = theta_i * theta;
-            }
-            auto d_f = ctx.alloc(acc_len * 32);
-            check(zkhip_poly_lincomb_dev(ctx.get(), adapter::id, items.size(), ptrs.data(), lens.data(), coeffs.data(), taps, d_f.get(), acc_len, 0),
-                  "zkhip_poly_lincomb_dev", ctx.get());
-            add_low_coefficients(d_f.get(), corr, acc_len);
-            /* f /= V, one root at a time (kzg_v2.hpp:266-267); the remainders are the BOOST_ASSERT */
-            char *f_ptr = static_cast<char *>(d_f.get());
-            std::size_t f_len = acc_len;
-            for (const auto &root : _merged_points) divide_in_place(f_ptr, f_len, root, "proof_eval: f is not divisible by V");
-            pi_1 = commit_range(f_ptr, f_len);
-            transcript(pi_1);
-
-            auto theta_2 = transcript.challenge();
-            /* L = sum_i theta^i Z_{T\S_i}(theta_2) (f_i - U_i(theta_2)) - V(theta_2) f (kzg_v2.hpp:281-289) */
-            ptrs.push_back(f_ptr);
-            lens.push_back(f_len);
-            std::vector<std::uint64_t> c1((items.size() + 1) * 4, 0);
-            scalar_value_type l0 = scalar_value_type::zero();
-            theta_i = scalar_value_type::one();
-            for (std::size_t n = 0; n < items.size(); ++n) {
-                auto s = theta_i * SP::evaluate(items[n].diff, theta_2);
-                adapter::scalar_to_limbs(s, &c1[4 * n]);
-                l0 = l0 - s * SP::evaluate(items[n].U, theta_2);
-                theta_i = theta_i * theta;
-            }
-            adapter::scalar_to_limbs(scalar_value_type::zero() - SP::evaluate(V, theta_2), &c1[4 * items.size()]);
-            const std::size_t l_len = std::max(max_len, f_len);
-            auto d_l = ctx.alloc(std::max<std::size_t>(1, l_len) * 32);
-            check(zkhip_poly_lincomb_dev(ctx.get(), adapter::id, ptrs.size(), ptrs.data(), lens.data(), c1.data(), 1, d_l.get(), l_len, 0),
-                  "zkhip_poly_lincomb_dev", ctx.get());
-            add_low_coefficients(d_l.get(), {l0}, l_len);
-            /* L /= (X - theta_2) (kzg_v2.hpp:290-291) */
-            char *l_ptr = static_cast<char *>(d_l.get());
-            std::size_t ll = l_len;
-            divide_in_place(l_ptr, ll, theta_2, "proof_eval: L(theta_2) != 0");
-            pi_2 = commit_range(l_ptr, ll);
-            ctx.sync();    // d_f / d_l are released on return
-        } else {
-            transcript(pi_1);
-            (void)transcript.challenge();
-        }
-        /* TODO in the reference: "Review the necessity of sending pi_2 to transcript" (kzg_v2.hpp:295) -- kept */
-        transcript(pi_2);
-        return proof_type {_z, pi_1, pi_2};
     }
 
     const std::map<std::size_t, commitment_type> &commitments() const { return _ind_commitments; }
@@ -462,6 +369,257 @@ protected:
     std::map<std::size_t, device_batch> _dev;
     std::map<std::size_t, commitment_type> _ind_commitments;
     std::vector<scalar_value_type> _merged_points;
+};
+
+/// kzg_commitment_scheme_v2 (kzg_v2.hpp:56-360): two quotient commitments (pi_1, pi_2)
+template <typename CurveType, typename TranscriptType>
+class kzg_commitment_scheme_v2_hip : public kzg_polys_evaluator_hip<CurveType, TranscriptType> {
+    typedef kzg_polys_evaluator_hip<CurveType, TranscriptType> base;
+
+public:
+    typedef typename base::adapter adapter;
+    typedef typename base::curve_type curve_type;
+    typedef typename base::scalar_value_type scalar_value_type;
+    typedef typename base::single_commitment_type single_commitment_type;
+    typedef typename base::commitment_type commitment_type;
+    typedef typename base::transcript_type transcript_type;
+    typedef typename base::params_type params_type;
+    typedef typename base::poly_type poly_type;
+    typedef typename base::eval_storage_type eval_storage_type;
+    typedef typename base::preprocessed_data_type preprocessed_data_type;
+    typedef typename base::root_of_unity_type root_of_unity_type;
+    using base::_z;
+    struct proof_type {
+        eval_storage_type z;
+        single_commitment_type pi_1, pi_2;
+    };
+
+    kzg_commitment_scheme_v2_hip(const params_type &kzg_params, root_of_unity_type root_of_unity) : base(kzg_params, std::move(root_of_unity)) { }
+
+    /// proof_eval (kzg_v2.hpp:236-305)
+    proof_type proof_eval(transcript_type &transcript) {
+        typedef detail::small_poly<scalar_value_type> SP;
+        const context &ctx = _params.ctx;
+        eval_polys();
+        merge_eval_points();
+        for (const auto &it : _ind_commitments) update_transcript(it.first, transcript);
+
+        auto theta = transcript.challenge();
+        const std::vector<scalar_value_type> V = SP::vanishing(_merged_points);
+
+        /* every committed polynomial in the reference's iteration order (batches ascending, then index) */
+        struct item {
+            std::size_t k, i;
+            const void *d;
+            std::size_t len;
+            std::vector<scalar_value_type> U, diff;
+        };
+        std::vector<item> items;
+        std::size_t max_len = 0, taps = 1;
+        for (const auto &it : _dev) {
+            const std::size_t k = it.first;
+            for (std::size_t i = 0; i < it.second.len.size(); ++i) {
+                item e {k, i, it.second.at(i), it.second.len[i], get_U(k, i), set_difference_polynom(_points.at(k)[i])};
+                max_len = std::max(max_len, e.len);
+                taps = std::max(taps, e.diff.size());
+                items.push_back(std::move(e));
+            }
+        }
+        single_commitment_type pi_1 = single_commitment_type::zero(), pi_2 = single_commitment_type::zero();
+        if (!items.empty()) {
+            /* f = sum_i theta^i (f_i - U_i) diffpoly_i (kzg_v2.hpp:251-263): the f_i part in one pass over the resident
+               coefficients, the U_i part (a few coefficients) on the host */
+            const std::size_t acc_len = max_len + taps - 1;
+            std::vector<const void *> ptrs;
+            std::vector<std::size_t> lens;
+            std::vector<std::uint64_t> coeffs(items.size() * taps * 4, 0);
+            std::vector<scalar_value_type> corr;
+            scalar_value_type theta_i = scalar_value_type::one();
+            for (std::size_t n = 0; n < items.size(); ++n) {
+                ptrs.push_back(items[n].d);
+                lens.push_back(items[n].len);
+                auto c = SP::scale(items[n].diff, theta_i);
+                for (std::size_t t = 0; t < c.size(); ++t) adapter::scalar_to_limbs(c[t], &coeffs[4 * (n * taps + t)]);
+                corr = SP::add(corr, SP::scale(SP::mul(items[n].U, c), scalar_value_type::zero() - scalar_value_type::one()));
+                theta_i = theta_i * theta;
+            }
+            auto d_f = ctx.alloc(acc_len * 32);
+            check(zkhip_poly_lincomb_dev(ctx.get(), adapter::id, items.size(), ptrs.data(), lens.data(), coeffs.data(), taps, d_f.get(), acc_len, 0),
+                  "zkhip_poly_lincomb_dev", ctx.get());
+            add_low_coefficients(d_f.get(), corr, acc_len);
+            /* f /= V, one root at a time (kzg_v2.hpp:266-267); the remainders are the BOOST_ASSERT */
+            char *f_ptr = static_cast<char *>(d_f.get());
+            std::size_t f_len = acc_len;
+            for (const auto &root : _merged_points) divide_in_place(f_ptr, f_len, root, "proof_eval: f is not divisible by V");
+            pi_1 = commit_range(f_ptr, f_len);
+            transcript(pi_1);
+
+            auto theta_2 = transcript.challenge();
+            /* L = sum_i theta^i Z_{T\S_i}(theta_2) (f_i - U_i(theta_2)) - V(theta_2) f (kzg_v2.hpp:281-289) */
+            ptrs.push_back(f_ptr);
+            lens.push_back(f_len);
+            std::vector<std::uint64_t> c1((items.size() + 1) * 4, 0);
+            scalar_value_type l0 = scalar_value_type::zero();
+            theta_i = scalar_value_type::one();
+            for (std::size_t n = 0; n < items.size(); ++n) {
+                auto s = theta_i * SP::evaluate(items[n].diff, theta_2);
+                adapter::scalar_to_limbs(s, &c1[4 * n]);
+                l0 = l0 - s * SP::evaluate(items[n].U, theta_2);
+                theta_i = theta_i * theta;
+            }
+            adapter::scalar_to_limbs(scalar_value_type::zero() - SP::evaluate(V, theta_2), &c1[4 * items.size()]);
+            const std::size_t l_len = std::max(max_len, f_len);
+            auto d_l = ctx.alloc(std::max<std::size_t>(1, l_len) * 32);
+            check(zkhip_poly_lincomb_dev(ctx.get(), adapter::id, ptrs.size(), ptrs.data(), lens.data(), c1.data(), 1, d_l.get(), l_len, 0),
+                  "zkhip_poly_lincomb_dev", ctx.get());
+            add_low_coefficients(d_l.get(), {l0}, l_len);
+            /* L /= (X - theta_2) (kzg_v2.hpp:290-291) */
+            char *l_ptr = static_cast<char *>(d_l.get());
+            std::size_t ll = l_len;
+            divide_in_place(l_ptr, ll, theta_2, "proof_eval: L(theta_2) != 0");
+            pi_2 = commit_range(l_ptr, ll);
+            ctx.sync();    // d_f / d_l are released on return
+        } else {
+            transcript(pi_1);
+            (void)transcript.challenge();
+        }
+        /* TODO in the reference: "Review the necessity of sending pi_2 to transcript" (kzg_v2.hpp:295) -- kept */
+        transcript(pi_2);
+        return proof_type {_z, pi_1, pi_2};
+    }
+
+protected:
+    using base::_params;
+    using base::_points;
+    using base::_dev;
+    using base::_ind_commitments;
+    using base::_merged_points;
+    using base::eval_polys;
+    using base::merge_eval_points;
+    using base::update_transcript;
+    using base::get_U;
+    using base::set_difference_polynom;
+    using base::add_low_coefficients;
+    using base::divide_in_place;
+    using base::commit_range;
+};
+
+/// kzg_commitment_scheme (kzg.hpp:636-873), the first batched scheme ("Placeholder-friendly class"): ONE quotient commitment,
+///   kzg_proof = commit( sum_j gamma^j (f_j - U_j) / V(S_j) )                                  (:782-807)
+/// with the same polys_evaluator state and commit(batch) as v2.  The quotients are exact: polynomials that share an
+/// evaluation-point set S are combined first (one pass over their resident coefficients), the few coefficients of their U_j
+/// are subtracted, and the group is divided by V(S) root by root -- |S| synthetic divisions per GROUP instead of per polynomial.
+/// verify_eval (:809-868) is pairings: the caller's, like v2's; commit_g2 (:659-664, 497-510) is provided for it.
+template <typename CurveType, typename TranscriptType>
+class kzg_commitment_scheme_hip : public kzg_polys_evaluator_hip<CurveType, TranscriptType> {
+    typedef kzg_polys_evaluator_hip<CurveType, TranscriptType> base;
+
+public:
+    typedef typename base::adapter adapter;
+    typedef typename base::curve_type curve_type;
+    typedef typename base::scalar_value_type scalar_value_type;
+    typedef typename base::single_commitment_type single_commitment_type;
+    typedef typename base::commitment_type commitment_type;
+    typedef typename base::transcript_type transcript_type;
+    typedef typename base::params_type params_type;
+    typedef typename base::poly_type poly_type;
+    typedef typename base::eval_storage_type eval_storage_type;
+    typedef typename base::preprocessed_data_type preprocessed_data_type;
+    typedef typename base::root_of_unity_type root_of_unity_type;
+    using base::_z;
+    typedef typename adapter::g2_value_type verification_key_type;
+    struct proof_type {
+        eval_storage_type z;
+        single_commitment_type kzg_proof;
+    };
+
+    kzg_commitment_scheme_hip(const params_type &kzg_params, root_of_unity_type root_of_unity) : base(kzg_params, std::move(root_of_unity)) { }
+
+    /// proof_eval (kzg.hpp:782-807)
+    proof_type proof_eval(transcript_type &transcript) {
+        typedef detail::small_poly<scalar_value_type> SP;
+        const context &ctx = _params.ctx;
+        eval_polys();
+        merge_eval_points();
+        for (const auto &it : _ind_commitments) update_transcript(it.first, transcript);
+        const scalar_value_type gamma = transcript.challenge();
+
+        /* the committed polynomials in the reference's iteration order (batches ascending, then index), grouped by point set */
+        struct group {
+            std::vector<scalar_value_type> pts;    // sorted
+            std::vector<const void *> ptrs;
+            std::vector<std::size_t> lens;
+            std::vector<std::uint64_t> coeffs;     // gamma^j, canonical limbs
+            std::vector<scalar_value_type> u_sum;  // sum_j gamma^j U_j
+            std::size_t max_len = 0;
+        };
+        std::vector<group> groups;
+        scalar_value_type factor = scalar_value_type::one();
+        for (const auto &it : _dev) {
+            const std::size_t k = it.first;
+            for (std::size_t i = 0; i < it.second.len.size(); ++i) {
+                std::vector<scalar_value_type> pts = _points.at(k)[i];
+                std::sort(pts.begin(), pts.end(), detail::limbs_less<scalar_value_type>);
+                auto g = std::find_if(groups.begin(), groups.end(), [&](const group &x) { return x.pts == pts; });
+                if (g == groups.end()) {
+                    groups.emplace_back();
+                    g = groups.end() - 1;
+                    g->pts = pts;
+                }
+                g->ptrs.push_back(it.second.at(i));
+                g->lens.push_back(it.second.len[i]);
+                g->coeffs.resize(g->coeffs.size() + 4);
+                adapter::scalar_to_limbs(factor, g->coeffs.data() + g->coeffs.size() - 4);
+                g->u_sum = SP::add(g->u_sum, SP::scale(get_U(k, i), factor));
+                g->max_len = std::max(g->max_len, it.second.len[i]);
+                factor = factor * gamma;
+            }
+        }
+        single_commitment_type kzg_proof = single_commitment_type::zero();
+        std::size_t acc_len = 0;
+        for (const auto &g : groups) acc_len = std::max(acc_len, g.max_len > g.pts.size() ? g.max_len - g.pts.size() : 0);
+        if (acc_len != 0) {
+            auto d_acc = ctx.alloc(acc_len * 32);
+            bool first = true;
+            const std::uint64_t one[4] = {1, 0, 0, 0};
+            for (const auto &g : groups) {
+                if (g.max_len <= g.pts.size()) continue;    // deg f < |S|: f = U, the quotient is zero
+                auto d_g = ctx.alloc(g.max_len * 32);
+                check(zkhip_poly_lincomb_dev(ctx.get(), adapter::id, g.ptrs.size(), g.ptrs.data(), g.lens.data(), g.coeffs.data(), 1, d_g.get(), g.max_len, 0),
+                      "zkhip_poly_lincomb_dev", ctx.get());
+                add_low_coefficients(d_g.get(), SP::scale(g.u_sum, scalar_value_type::zero() - scalar_value_type::one()), g.max_len);
+                char *q_ptr = static_cast<char *>(d_g.get());
+                std::size_t q_len = g.max_len;
+                for (const auto &root : g.pts) divide_in_place(q_ptr, q_len, root, "proof_eval: (f - U) is not divisible by V");
+                const void *qp = q_ptr;
+                check(zkhip_poly_lincomb_dev(ctx.get(), adapter::id, 1, &qp, &q_len, one, 1, d_acc.get(), acc_len, first ? 0 : 1), "zkhip_poly_lincomb_dev",
+                      ctx.get());
+                first = false;
+                ctx.sync();    // d_g is released at the end of the iteration
+            }
+            if (!first) kzg_proof = commit_range(d_acc.get(), acc_len);
+            ctx.sync();
+        }
+        return proof_type {_z, kzg_proof};
+    }
+
+    /// commit_g2 (kzg.hpp:659-664): the verifier's G2 commitments of the few-coefficient polynomials Z_{T \ S}, V(T)
+    verification_key_type commit_g2(const std::vector<scalar_value_type> &poly) const { return nil::crypto3::zk::hip::commit_g2<CurveType>(_params, poly); }
+
+protected:
+    using base::_params;
+    using base::_points;
+    using base::_dev;
+    using base::_ind_commitments;
+    using base::_merged_points;
+    using base::eval_polys;
+    using base::merge_eval_points;
+    using base::update_transcript;
+    using base::get_U;
+    using base::set_difference_polynom;
+    using base::add_low_coefficients;
+    using base::divide_in_place;
+    using base::commit_range;
 };
 
 

@@ -6,12 +6,18 @@
 //   zk/commitments/polynomial/knowledge_commitment_multiexp.hpp:107
 // Same argument order and meaning; `chunks` is accepted and ignored (the device splits the work itself).
 // `multiexp_method_hip` is the policy tag a KZG parameter struct shadows `multiexp_method` with
-// (kzg.hpp:82,231 declare `using multiexp_method = ...BDLO12` and use it as `typename KZG::multiexp_method`).
+// (kzg.hpp:82,231 declare `using multiexp_method = ...BDLO12` and use it as `typename KZG::multiexp_method`): the
+// REFERENCE-ARITY overloads at the end of this file -- multiexp<multiexp_method_hip>(b0, b1, s0, s1, chunks), no context
+// argument, the group read off the bases' value type -- are what such a struct's call sites (kzg.hpp:146, 417, 434, 505)
+// resolve to; they run on the calling thread's default context (default_context()).
 //---------------------------------------------------------------------------//
 #ifndef ZKHIP_SHIM_MULTIEXP_HPP
 #define ZKHIP_SHIM_MULTIEXP_HPP
 
+#include <cstdlib>
 #include <iterator>
+#include <memory>
+#include <type_traits>
 #include <vector>
 
 #include "backend.hpp"
@@ -87,6 +93,50 @@ typename detail::jac_result<CurveType, Group>::type multiexp_with_mixed_addition
                                                                                  ScalarIt scalars_begin, ScalarIt scalars_end,
                                                                                  std::size_t chunks = 1) {
     return multiexp<Method, CurveType, Group>(ctx, bases_begin, bases_end, scalars_begin, scalars_end, chunks);
+}
+
+// ---- the reference's arity: no context argument ---------------------------------------------------------------------
+/// Which curve / group a group value type belongs to (what algebra::multiexp reads off its iterators' value_type).  A
+/// crypto3 maintainer specialises it for `typename curve_type::template g1_type<>::value_type` / g2 next to curve_adapter.
+template <typename G>
+struct group_traits;
+template <int Curve, int Group>
+struct group_traits<group_value<Curve, Group>> {
+    typedef native_curve<Curve> curve_type;
+    static constexpr int group = Group;
+};
+
+namespace detail {
+    inline context *&default_context_override() {
+        thread_local context *p = nullptr;
+        return p;
+    }
+}    // namespace detail
+/// The context the context-less overloads run on: one per host thread, created on first use on device ZKHIP_DEVICE (default 0)
+/// -- "one context per GPU per process, a context is not thread-safe" (include/zkhip.h) -- unless the caller installed its own.
+inline const context &default_context() {
+    if (context *p = detail::default_context_override()) return *p;
+    thread_local std::unique_ptr<context> own;
+    if (!own) {
+        const char *e = std::getenv("ZKHIP_DEVICE");
+        own.reset(new context(e ? std::atoi(e) : 0));
+    }
+    return *own;
+}
+/// make `ctx` the calling thread's default context (nullptr: back to the thread's own); the caller keeps it alive
+inline void set_default_context(context *ctx) { detail::default_context_override() = ctx; }
+
+/// algebra::multiexp<Method>(bases_begin, bases_end, scalars_begin, scalars_end, chunks) with Method = multiexp_method_hip
+template <typename Method, typename BaseIt, typename ScalarIt, typename std::enable_if<std::is_same<Method, multiexp_method_hip>::value, bool>::type = true>
+typename std::iterator_traits<BaseIt>::value_type multiexp(BaseIt bases_begin, BaseIt bases_end, ScalarIt scalars_begin, ScalarIt scalars_end,
+                                                           std::size_t chunks) {
+    typedef group_traits<typename std::iterator_traits<BaseIt>::value_type> T;
+    return multiexp<Method, typename T::curve_type, T::group>(default_context(), bases_begin, bases_end, scalars_begin, scalars_end, chunks);
+}
+template <typename Method, typename BaseIt, typename ScalarIt, typename std::enable_if<std::is_same<Method, multiexp_method_hip>::value, bool>::type = true>
+typename std::iterator_traits<BaseIt>::value_type multiexp_with_mixed_addition(BaseIt bases_begin, BaseIt bases_end, ScalarIt scalars_begin,
+                                                                               ScalarIt scalars_end, std::size_t chunks) {
+    return multiexp<Method>(bases_begin, bases_end, scalars_begin, scalars_end, chunks);
 }
 
 }    // namespace hip

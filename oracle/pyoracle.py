@@ -22,6 +22,7 @@ CI ref NilFoundation/crypto3@1bd56b12f410f3f1a4891076705a9261a6b1efaa,
   * r1cs_gg_ppzksnark_prover::process       -> groth16_prove (prover.hpp:73-158)
   * ipp2 prove_commitment_{v,w} (the KAT carrier) -> ipp2_prove_commitment_{v,w}
       zk/snark/systems/ppzksnark/r1cs_gg_ppzksnark/ipp2/prover.hpp:99-290, ipp2/srs.hpp:44-56
+  * kzg_commitment_scheme::proof_eval (v1)  -> kzg_v1_proof_eval   zk/commitments/polynomial/kzg.hpp:782-807
   * kzg_commitment_scheme_v2::proof_eval    -> kzg_v2_proof_eval (+ get_U / get_V / set_difference_polynom:
       lagrange_interpolation, vanishing_poly)
       zk/commitments/polynomial/kzg_v2.hpp:121-148, 236-305; zk/commitments/batched_commitment.hpp:79-111, 168-183
@@ -1329,6 +1330,23 @@ def kzg_v2_proof_eval(r: int, polys: dict, points: dict, theta: int, theta2: int
     L, rem = poly_divmod(L, [(-theta2) % r, 1], r)
     assert not rem
     return z, f, L
+
+
+def kzg_v1_proof_eval(r: int, polys: dict, points: dict, gamma: int):
+    """kzg_commitment_scheme::proof_eval (kzg.hpp:782-807), the first batched scheme: polys[k][i] = coefficient list of polynomial i
+    of batch k, points[k][i] = its evaluation points.  Returns (z, accum): z[k][i][j] = poly(point) (eval_polys) and
+    accum = sum_j gamma^j (f_j - U_j) / V(S_j) (:793-800), the polynomial committed as kzg_proof.  The challenge is an input:
+    the transcript (hashing, byte packing) is outside this path."""
+    z = {k: [[poly_eval(p, x, r) for x in points[k][i]] for i, p in enumerate(ps)] for k, ps in polys.items()}
+    factor, accum = 1, [0]
+    for k in sorted(polys):
+        for i, p in enumerate(polys[k]):
+            U = lagrange_interpolation(list(zip(points[k][i], z[k][i])), r)
+            q, rem = poly_divmod(poly_sub(p, U, r), vanishing_poly(points[k][i], r), r)
+            assert not rem                                                         # (f - U) vanishes on S
+            accum = poly_add(accum, poly_scale(q, factor, r), r)
+            factor = factor * gamma % r
+    return z, poly_trim(accum)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -338,6 +338,111 @@ int kzg_v2_t(const uint64_t *srs, size_t n_srs, size_t npolys, const uint64_t *b
     return 0;
 }
 
+/// kzg_commitment_scheme (v1, kzg.hpp:636-873) through the shim class: commit, proof_eval (one quotient commitment), and
+/// commit_g2 of a small polynomial against the verification key
+template <typename Curve>
+int kzg_v1_t(const uint64_t *srs, size_t n_srs, const uint64_t *vk, size_t n_vk, size_t npolys, const uint64_t *batch_id, const uint64_t *log_n,
+             const uint64_t *evals, const uint64_t *npts, const uint64_t *points, const uint64_t *roots, const uint64_t *gamma, const uint64_t *g2_poly,
+             size_t g2_poly_len, uint64_t *commits, uint64_t *zvals, uint64_t *proof_out, uint64_t *g2_out, uint64_t *absorbed) {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::g1_value_type G1;
+    typedef typename A::g2_value_type G2;
+    const size_t L1 = 2 * A::g1_coord_limbs, L2 = 2 * A::g2_coord_limbs;
+    context ctx(0);
+    std::vector<G1> ck;
+    for (size_t i = 0; i < n_srs; ++i) ck.push_back(G1::from_affine(srs + i * L1));
+    std::vector<G2> vkey;
+    for (size_t i = 0; i < n_vk; ++i) vkey.push_back(G2::from_affine(vk + i * L2));
+    kzg_params_hip<Curve> params(ctx, ck.begin(), ck.end(), vkey.begin(), vkey.end());
+    typedef kzg_commitment_scheme_hip<Curve, scripted_transcript<Curve>> scheme_type;
+    scheme_type scheme(params, [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); });
+    std::vector<size_t> batches;
+    size_t at = 0;
+    for (size_t p = 0; p < npolys; ++p) {
+        polynomial_dfs<Curve> poly;
+        for (size_t i = 0; i < ((size_t)1 << log_n[p]); ++i) poly.values.push_back(A::scalar_from_limbs(evals + 4 * at++));
+        scheme.append_to_batch(batch_id[p], poly);
+        if (batches.empty() || batches.back() != batch_id[p]) batches.push_back(batch_id[p]);
+    }
+    size_t ci = 0;
+    for (size_t b : batches)
+        for (const auto &c : scheme.commit(b)) {
+            c.to_affine(commits + ci * L1);
+            ++ci;
+        }
+    size_t pt = 0;
+    std::vector<size_t> idx_in_batch(npolys, 0);
+    for (size_t p = 0, i = 0; p < npolys; ++p) {
+        if (p && batch_id[p] != batch_id[p - 1]) i = 0;
+        for (size_t q = 0; q < npts[p]; ++q) scheme.append_eval_point(batch_id[p], i, A::scalar_from_limbs(points + 4 * pt++));
+        idx_in_batch[p] = i++;
+    }
+    scripted_transcript<Curve> tr;
+    tr.challenges = {A::scalar_from_limbs(gamma)};
+    auto proof = scheme.proof_eval(tr);
+    size_t zi = 0;
+    for (size_t p = 0; p < npolys; ++p)
+        for (size_t q = 0; q < npts[p]; ++q) A::scalar_to_limbs(proof.z.get(batch_id[p], idx_in_batch[p], q), zvals + 4 * zi++);
+    proof.kzg_proof.to_affine(proof_out);
+    std::vector<typename A::scalar_value_type> gp;
+    for (size_t i = 0; i < g2_poly_len; ++i) gp.push_back(A::scalar_from_limbs(g2_poly + 4 * i));
+    scheme.commit_g2(gp).to_affine(g2_out);
+    commit_g2<Curve>(params, gp).to_affine(g2_out + L2);
+    absorbed[0] = tr.absorbed_points;
+    absorbed[1] = tr.absorbed_scalars;
+    return 0;
+}
+
+/// A KZG parameter struct declared like the reference's commitments::kzg<CurveType> (kzg.hpp:76-135) with the ONE edit a
+/// maintainer makes -- `multiexp_method` names the device policy instead of multiexp_method_BDLO12 (kzg.hpp:82, 231) -- and
+/// the reference's own call shape (kzg.hpp:143-148, 409-420, 497-510): multiexp<typename KZG::multiexp_method>(b0, b1, s0, s1, 1),
+/// no context, the group read off the iterator's value type.
+template <typename Curve>
+struct ref_shaped_kzg {
+    typedef Curve curve_type;
+    using multiexp_method = multiexp_method_hip;
+    using scalar_value_type = typename curve_adapter<Curve>::scalar_value_type;
+    using single_commitment_type = std::vector<typename curve_adapter<Curve>::g1_value_type>;
+    using verification_key_type = typename curve_adapter<Curve>::g2_value_type;
+    using commitment_type = typename curve_adapter<Curve>::g1_value_type;
+    struct params_type {
+        single_commitment_type commitment_key;
+        std::vector<verification_key_type> verification_key;
+    };
+};
+template <typename KZG>
+typename KZG::commitment_type ref_shaped_commit(const typename KZG::params_type &params, const std::vector<typename KZG::scalar_value_type> &f) {
+    return multiexp<typename KZG::multiexp_method>(params.commitment_key.begin(), params.commitment_key.begin() + f.size(), f.begin(), f.end(), 1);
+}
+template <typename KZG>
+typename KZG::verification_key_type ref_shaped_commit_g2(const typename KZG::params_type &params, const std::vector<typename KZG::scalar_value_type> &poly) {
+    auto it1 = params.verification_key.begin();
+    auto it2 = params.verification_key.begin() + poly.size();
+    return multiexp_with_mixed_addition<typename KZG::multiexp_method>(it1, it2, poly.begin(), poly.end(), 1);
+}
+template <typename Curve>
+int kzg_reference_arity_t(const uint64_t *srs, size_t n_srs, const uint64_t *vk, size_t n_vk, const uint64_t *f, size_t n, const uint64_t *g, size_t ng,
+                          int own_context, uint64_t *out_g1, uint64_t *out_g2) {
+    typedef curve_adapter<Curve> A;
+    typedef ref_shaped_kzg<Curve> KZG;
+    const size_t L1 = 2 * A::g1_coord_limbs, L2 = 2 * A::g2_coord_limbs;
+    typename KZG::params_type params;
+    for (size_t i = 0; i < n_srs; ++i) params.commitment_key.push_back(A::g1_value_type::from_affine(srs + i * L1));
+    for (size_t i = 0; i < n_vk; ++i) params.verification_key.push_back(A::g2_value_type::from_affine(vk + i * L2));
+    std::vector<typename A::scalar_value_type> fv, gv;
+    for (size_t i = 0; i < n; ++i) fv.push_back(A::scalar_from_limbs(f + 4 * i));
+    for (size_t i = 0; i < ng; ++i) gv.push_back(A::scalar_from_limbs(g + 4 * i));
+    std::unique_ptr<context> mine;
+    if (own_context) {    // the caller's context instead of the thread's own
+        mine.reset(new context(0));
+        set_default_context(mine.get());
+    }
+    ref_shaped_commit<KZG>(params, fv).to_affine(out_g1);
+    ref_shaped_commit_g2<KZG>(params, gv).to_affine(out_g2);
+    set_default_context(nullptr);
+    return 0;
+}
+
 template <typename Curve>
 int kzg_basic_proof_t(const uint64_t *srs, size_t n_srs, const uint64_t *coeffs, size_t n, const uint64_t *z, uint64_t *out) {
     typedef curve_adapter<Curve> A;
@@ -822,6 +927,33 @@ int shim_kzg_v2_proof_eval(int curve, const uint64_t *srs, size_t n_srs, size_t 
         return kzg_v2_t<alt_bn128_254>(srs, n_srs, npolys, batch_id, log_n, evals, npts, points, roots, theta, theta2, commits, zvals, pi, absorbed);
     } catch (const std::exception &e) {
         fprintf(stderr, "shim_kzg_v2_proof_eval: %s\n", e.what());
+        return -1;
+    }
+}
+
+int shim_kzg_v1_proof_eval(int curve, const uint64_t *srs, size_t n_srs, const uint64_t *vk, size_t n_vk, size_t npolys, const uint64_t *batch_id,
+                           const uint64_t *log_n, const uint64_t *evals, const uint64_t *npts, const uint64_t *points, const uint64_t *roots,
+                           const uint64_t *gamma, const uint64_t *g2_poly, size_t g2_poly_len, uint64_t *commits, uint64_t *zvals, uint64_t *proof_out,
+                           uint64_t *g2_out, uint64_t *absorbed) {
+    try {
+        if (curve == ZKHIP_BLS12_381)
+            return kzg_v1_t<bls12_381>(srs, n_srs, vk, n_vk, npolys, batch_id, log_n, evals, npts, points, roots, gamma, g2_poly, g2_poly_len, commits, zvals,
+                                       proof_out, g2_out, absorbed);
+        return kzg_v1_t<alt_bn128_254>(srs, n_srs, vk, n_vk, npolys, batch_id, log_n, evals, npts, points, roots, gamma, g2_poly, g2_poly_len, commits, zvals,
+                                       proof_out, g2_out, absorbed);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "shim_kzg_v1_proof_eval: %s\n", e.what());
+        return -1;
+    }
+}
+
+int shim_kzg_reference_arity(int curve, const uint64_t *srs, size_t n_srs, const uint64_t *vk, size_t n_vk, const uint64_t *f, size_t n, const uint64_t *g,
+                             size_t ng, int own_context, uint64_t *out_g1, uint64_t *out_g2) {
+    try {
+        if (curve == ZKHIP_BLS12_381) return kzg_reference_arity_t<bls12_381>(srs, n_srs, vk, n_vk, f, n, g, ng, own_context, out_g1, out_g2);
+        return kzg_reference_arity_t<alt_bn128_254>(srs, n_srs, vk, n_vk, f, n, g, ng, own_context, out_g1, out_g2);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "shim_kzg_reference_arity: %s\n", e.what());
         return -1;
     }
 }

@@ -211,6 +211,108 @@ def test_kzg_basic_proof_eval_shim(shim, curve):
     assert (out == exp[0]).all()
 
 
+def _vk(curve, alpha, n):
+    C = CURVES[curve]
+    pts, _ = cp.batch_mul(curve, 2, fr_arr([pow(alpha, i, C.r) for i in range(n)]))
+    return pts
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_kzg_v1_proof_eval_shim(shim, curve):
+    """kzg_commitment_scheme (the first batched scheme, kzg.hpp:636-873): commit + proof_eval through the shim class against the
+    oracle's restatement of :782-807 -- evaluations z, the single quotient commitment kzg_proof, the verifier's equation in
+    the exponent with alpha known -- and commit_g2 (:497-510, 659-664) against the G2 MSM oracle."""
+    C = CURVES[curve]
+    r = C.r
+    alpha = 7
+    rng = po.SplitMix64(177 + curve)
+    x1, x2, x3 = (rng.next_mod(r) for _ in range(3))
+    # three polynomials sharing {x1, x2}, one with the same set in another order, ragged sets, and one without points
+    layout = [(0, 6, [x1, x2]), (0, 6, [x1, x2]), (0, 7, [x2, x1]), (2, 6, [x2]), (2, 7, [x1, x3, x2]), (2, 5, [])]
+    npolys = len(layout)
+    evals, coeffs = [], []
+    for p, (_, log_n, _) in enumerate(layout):
+        e = cp.random_fr(curve, 900 + p, 1 << log_n)
+        evals.append(e)
+        c = cp.ntt(curve, e.reshape(1, -1, 4), log_n, limbs(C.root_of_unity(log_n), 4), inverse=True)[0]
+        coeffs.append([po.from_limbs(x) for x in c])
+    n_srs, n_vk = 128, 6
+    srs, vk = _srs(curve, alpha, n_srs), _vk(curve, alpha, n_vk)
+    gamma = rng.next_mod(r)
+    polys, points = {}, {}
+    for p, (k, _, pts) in enumerate(layout):
+        polys.setdefault(k, []).append(coeffs[p])
+        points.setdefault(k, []).append(pts)
+    z, accum = po.kzg_v1_proof_eval(r, polys, points, gamma)
+    merged = sorted({x for _, _, pts in layout for x in pts})
+    g2_poly = po.vanishing_poly(merged, r)        # what verify_eval commits in G2: V(T) (:862-865)
+
+    u64 = lambda v: np.array(v, dtype=np.uint64)
+    roots = np.stack([limbs(C.root_of_unity(l), 4) for l in range(8)])
+    allpts = fr_arr([x for _, _, pts in layout for x in pts])
+    commits = np.zeros((npolys, srs.shape[1]), dtype=np.uint64)
+    zvals = np.zeros((len(allpts), 4), dtype=np.uint64)
+    proof = np.zeros(srs.shape[1], dtype=np.uint64)
+    g2_out = np.zeros((2, vk.shape[1]), dtype=np.uint64)
+    absorbed = np.zeros(2, dtype=np.uint64)
+    rc = shim.shim_kzg_v1_proof_eval(curve, P(srs), ctypes.c_size_t(n_srs), P(vk), ctypes.c_size_t(n_vk), ctypes.c_size_t(npolys),
+                                     P(u64([k for k, _, _ in layout])), P(u64([l for _, l, _ in layout])), P(np.concatenate(evals)),
+                                     P(u64([len(p) for _, _, p in layout])), P(allpts), P(roots), P(limbs(gamma, 4)), P(fr_arr(g2_poly)),
+                                     ctypes.c_size_t(len(g2_poly)), P(commits), P(zvals), P(proof), P(g2_out), P(absorbed))
+    assert rc == 0
+    g = lambda v: cp.batch_mul(curve, 1, fr_arr([v % r]))[0][0]
+    for p in range(npolys):
+        assert (commits[p] == g(po.poly_eval(coeffs[p], alpha, r))).all(), p
+    exp_z = [v for k in sorted(z) for zl in z[k] for v in zl]
+    assert [po.from_limbs(x) for x in zvals] == exp_z
+    # kzg_proof against the oracle's accum: through the MSM oracle, and in the exponent
+    e1, i1 = cp.msm(curve, 1, srs[: len(accum)], fr_arr(accum), chunks=2)
+    assert i1 == 0 and (proof == e1).all()
+    assert (proof == g(po.poly_eval(accum, alpha, r))).all()
+    # the verifier's equation (:809-868) with alpha in the clear: sum_j gamma^j (f_j(alpha) - U_j(alpha)) Z_{T \ S_j}(alpha) == accum(alpha) V_T(alpha)
+    lhs, fac = 0, 1
+    for k in sorted(polys):
+        for i, c in enumerate(polys[k]):
+            U = po.lagrange_interpolation(list(zip(points[k][i], z[k][i])), r)
+            diff = po.vanishing_poly([x for x in merged if x not in points[k][i]], r)
+            lhs = (lhs + fac * (po.poly_eval(c, alpha, r) - po.poly_eval(U, alpha, r)) * po.poly_eval(diff, alpha, r)) % r
+            fac = fac * gamma % r
+    assert lhs == po.poly_eval(accum, alpha, r) * po.poly_eval(g2_poly, alpha, r) % r
+    # commit_g2(V(T)): the member and the free function, against the G2 MSM oracle and in the exponent
+    e2, i2 = cp.msm(curve, 2, vk[: len(g2_poly)], fr_arr(g2_poly), chunks=1)
+    assert i2 == 0 and (g2_out[0] == e2).all() and (g2_out[1] == e2).all()
+    assert (g2_out[0] == cp.batch_mul(curve, 2, fr_arr([po.poly_eval(g2_poly, alpha, r)]))[0][0]).all()
+    # transcript traffic: 6 commitments; 8 evaluations + 8 U coefficients
+    assert absorbed[0] == npolys and absorbed[1] == 2 * len(allpts)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_multiexp_reference_arity_shim(shim, curve):
+    """A KZG parameter struct declared like the reference's (kzg.hpp:76-135) that only shadows `multiexp_method` with the device
+    policy: its call sites -- multiexp<typename KZG::multiexp_method>(b0, b1, s0, s1, 1), no context argument (kzg.hpp:146, 417,
+    505) -- compile against the shim and run on the thread's default context (or the caller's): commit == f(alpha) G1,
+    commit_g2 == g(alpha) G2."""
+    C = CURVES[curve]
+    r, alpha = C.r, 10
+    srs, vk = _srs(curve, alpha, 300), _vk(curve, alpha, 5)
+    f = cp.random_fr(curve, 31, 300)
+    f[:4] = fr_arr([r - 1, 1, 0, 3])      # scalars 0, 1, r - 1 among them (multiexp_with_mixed_addition's special cases)
+    gpoly = cp.random_fr(curve, 32, 5)
+    for own in (0, 1):
+        o1 = np.zeros(srs.shape[1], dtype=np.uint64)
+        o2 = np.zeros(vk.shape[1], dtype=np.uint64)
+        assert shim.shim_kzg_reference_arity(curve, P(srs), ctypes.c_size_t(300), P(vk), ctypes.c_size_t(5), P(f), ctypes.c_size_t(300), P(gpoly),
+                                             ctypes.c_size_t(5), own, P(o1), P(o2)) == 0
+        assert (o1 == cp.batch_mul(curve, 1, fr_arr([po.poly_eval(fr_ints(f), alpha, r)]))[0][0]).all()
+        assert (o2 == cp.batch_mul(curve, 2, fr_arr([po.poly_eval(fr_ints(gpoly), alpha, r)]))[0][0]).all()
+    # kzg_basic_test's literal through this path (kzg.cpp:83-97): commit({-1, 1, 2, 3}, alpha = 10) = 3209 G
+    o1 = np.zeros(srs.shape[1], dtype=np.uint64)
+    o2 = np.zeros(vk.shape[1], dtype=np.uint64)
+    assert shim.shim_kzg_reference_arity(curve, P(srs), ctypes.c_size_t(300), P(vk), ctypes.c_size_t(5), P(fr_arr([r - 1, 1, 2, 3])), ctypes.c_size_t(4),
+                                         P(gpoly), ctypes.c_size_t(5), 0, P(o1), P(o2)) == 0
+    assert (o1 == cp.batch_mul(curve, 1, fr_arr([3209]))[0][0]).all()
+
+
 @pytest.mark.parametrize("curve", [0, 1])
 def test_kzg_v2_proof_eval_shim(shim, curve):
     """kzg_commitment_scheme_v2::commit + proof_eval (kzg_v2.hpp:208-305) through the shim class against the oracle's

@@ -298,3 +298,28 @@ def test_evaluation_domain_cport(curve):
         assert g.query(3)[0].shape[0] == dom.m - 1
         proof = g.prove(limbs(rr, 4), limbs(ss, 4), w, gen, chunks=2)
         assert (proof == np.concatenate([pt_limbs(curve, 1, expect[0]), pt_limbs(curve, 2, expect[1]), pt_limbs(curve, 1, expect[2])])).all()
+
+
+def test_kzg_v1_oracle_identity():
+    """kzg_commitment_scheme::proof_eval (kzg.hpp:782-807) is unpinned in the reference (its test only checks verify_eval, with
+    pairings): pin the restatement to the verifier's equation (:826-866) evaluated at a clear alpha --
+    sum_j gamma^j (f_j - U_j)(alpha) Z_{T \\ S_j}(alpha) == accum(alpha) V_T(alpha) -- and to exact divisibility."""
+    C = CURVES[0]
+    r = C.r
+    rng = po.SplitMix64(31)
+    x1, x2, x3 = (rng.next_mod(r) for _ in range(3))
+    polys = {0: [[rng.next_mod(r) for _ in range(16)] for _ in range(3)], 3: [[rng.next_mod(r) for _ in range(32)], [rng.next_mod(r) for _ in range(8)]]}
+    points = {0: [[x1, x2], [x1, x2], [x2]], 3: [[x1, x3, x2], []]}
+    gamma, alpha = rng.next_mod(r), rng.next_mod(r)
+    z, accum = po.kzg_v1_proof_eval(r, polys, points, gamma)
+    merged = sorted({x for k in points for pl in points[k] for x in pl})
+    lhs, fac = 0, 1
+    for k in sorted(polys):
+        for i, c in enumerate(polys[k]):
+            assert z[k][i] == [po.poly_eval(c, x, r) for x in points[k][i]]
+            U = po.lagrange_interpolation(list(zip(points[k][i], z[k][i])), r)
+            diff = po.vanishing_poly([x for x in merged if x not in points[k][i]], r)
+            lhs = (lhs + fac * (po.poly_eval(c, alpha, r) - po.poly_eval(U, alpha, r)) * po.poly_eval(diff, alpha, r)) % r
+            fac = fac * gamma % r
+    assert lhs == po.poly_eval(accum, alpha, r) * po.poly_eval(po.vanishing_poly(merged, r), alpha, r) % r
+    assert len(accum) == 32 - 3
