@@ -1,0 +1,191 @@
+// Commitment-scheme throughput drivers for bench.py / tools: BASELINE config 5's commitment leg and the LPC commit THROUGH THE
+// SHIM CLASSES, with the columns starting in host memory as placeholder hands them over (upload included).
+// Host compiler only; part of libzkhip_bench.so.
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include <nil/crypto3/zk/hip/lpc.hpp>
+
+using namespace nil::crypto3::zk::hip;
+
+namespace {
+typedef bls12_381 C;
+typedef curve_adapter<C> A;
+typedef A::scalar_value_type Fr;
+
+struct counting_transcript {
+    std::vector<Fr> challenges;
+    std::size_t next = 0;
+    template <typename T>
+    void operator()(const T &) { }
+    Fr challenge() { return challenges.at(next++ % challenges.size()); }
+};
+
+double ms_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+
+/// 7^((r - 1) / 2^l) by square-and-multiply on the host: the primitive 2^l-th root of BLS12-381 Fr the tests use
+Fr bls_root(std::size_t l) {
+    const uint64_t rm1[4] = {0xffffffff00000000ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};
+    uint64_t e[4] = {rm1[0], rm1[1], rm1[2], rm1[3]};
+    for (std::size_t k = 0; k < l; ++k) {
+        for (int i = 0; i < 3; ++i) e[i] = (e[i] >> 1) | (e[i + 1] << 63);
+        e[3] >>= 1;
+    }
+    Fr r = Fr::one(), b(7);
+    for (int i = 255; i >= 0; --i) {
+        r = r * r;
+        if ((e[i >> 6] >> (i & 63)) & 1) r = r * b;
+    }
+    return r;
+}
+
+/// A stand-in for the caller's Merkle hash in the streaming shape (hip/lpc.hpp): every slice is folded (XOR of the low limbs) by
+/// `threads` host threads while the next slice crosses PCIe -- the memory traffic of a hash without its arithmetic.
+struct fold_tree {
+    uint64_t r = 0;
+    uint64_t root() const { return r; }
+};
+struct streaming_fold_builder {
+    unsigned threads = 8;
+    fold_tree t;
+    void begin(std::size_t, std::size_t) { t = fold_tree(); }
+    void absorb(const Fr *leaves, std::size_t, std::size_t count) {
+        std::vector<uint64_t> part(threads, 0);
+        std::vector<std::thread> th;
+        for (unsigned k = 0; k < threads; ++k)
+            th.emplace_back([&, k]() {
+                uint64_t x = 0;
+                for (std::size_t i = count * k / threads; i < count * (k + 1) / threads; ++i) x ^= leaves[i].limbs[0];
+                part[k] = x;
+            });
+        for (auto &w : th) w.join();
+        for (uint64_t x : part) t.r ^= x;
+    }
+    fold_tree finish() { return t; }
+};
+struct vector_fold_builder {    // round 2's shape: the leaves materialised in a std::vector
+    fold_tree operator()(const std::vector<Fr> &leaves, std::size_t) const {
+        fold_tree t;
+        for (const auto &v : leaves) t.r ^= v.limbs[0];
+        return t;
+    }
+};
+}    // namespace
+
+extern "C" {
+
+/* 50 (cols) polynomial_dfs of 2^log_n rows in HOST memory (evals: cols x n x 4 canonical limbs, row-major per column) ->
+ * kzg_commitment_scheme_v2_hip::append_to_batch + commit + proof_eval at two points, `steps` times on fresh scheme objects.
+ * mode 0: append_to_batch(const &) (the reference's copy), 1: handed over (&&), 2: lent (std::cref).
+ * ms: steps x {append, commit, proof_eval}.  out_commitments: cols x 12 u64 affine limbs of the last commit. */
+int zkhip_bench_kzg_scheme(int device, size_t log_n, size_t cols, int steps, int mode, size_t upload_chunk, const uint64_t *evals, double *ms,
+                           uint64_t *out_commitments) {
+    try {
+        const size_t n = (size_t)1 << log_n;
+        context ctx(device);
+        std::vector<Fr> pw(n);
+        Fr x = Fr::one(), alpha(7);
+        for (size_t i = 0; i < n; ++i) pw[i] = x, x = x * alpha;
+        kzg_params_hip<C> params(ctx, device_bases<C, ZKHIP_G1>::from_scalars(ctx, pw.begin(), pw.end()));
+        std::vector<Fr>().swap(pw);
+        std::vector<polynomial_dfs<C>> master(cols);
+        for (size_t c = 0; c < cols; ++c) {
+            master[c].values.resize(n);
+            std::memcpy(master[c].values.data(), evals + 4 * c * n, n * 32);
+        }
+        for (int rep = 0; rep < steps; ++rep) {
+            kzg_commitment_scheme_v2_hip<C, counting_transcript> scheme(params, bls_root);
+            scheme.upload_chunk = upload_chunk;
+            std::vector<polynomial_dfs<C>> handed;
+            if (mode == 1) handed = master;    // the copy a caller that hands its columns over never makes is outside the timing
+            auto t0 = std::chrono::steady_clock::now();
+            if (mode == 0) scheme.append_to_batch(0, master);
+            else if (mode == 1) scheme.append_to_batch(0, std::move(handed));
+            else {
+                std::vector<std::reference_wrapper<const polynomial_dfs<C>>> lent(master.begin(), master.end());
+                scheme.append_to_batch(0, lent);
+            }
+            ms[3 * rep] = ms_since(t0);
+            t0 = std::chrono::steady_clock::now();
+            auto commits = scheme.commit(0);
+            ms[3 * rep + 1] = ms_since(t0);
+            scheme.append_eval_point(0, Fr(1234567));
+            scheme.append_eval_point(0, Fr(7654321));
+            counting_transcript tr;
+            tr.challenges = {Fr(12345), Fr(54321)};
+            t0 = std::chrono::steady_clock::now();
+            auto proof = scheme.proof_eval(tr);
+            ms[3 * rep + 2] = ms_since(t0);
+            (void)proof;
+            if (out_commitments && rep == steps - 1)
+                for (size_t c = 0; c < cols; ++c) commits[c].to_affine(out_commitments + 12 * c);
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkhip_bench_kzg_scheme: %s\n", e.what());
+        return -1;
+    }
+}
+
+/* `cols` polynomial_dfs of 2^log_n rows in host memory -> lpc_commitment_scheme_hip::append_to_batch (lent) + commit over
+ * D[0] = 2^(log_n + expand): upload, inverse NTTs, extension, coset-ordered leaf layout, and the leaves to the caller's tree
+ * builder.  streaming != 0: the streaming builder shape (slices absorbed by `threads` host threads while the next slice is in
+ * flight); 0: round 2's std::vector shape.  ms: `steps` commit times; *root: the fold of the last one. */
+int zkhip_bench_lpc_scheme(int device, size_t log_n, size_t cols, size_t expand, int steps, int streaming, unsigned threads, double *ms, uint64_t *root) {
+    try {
+        const size_t n = (size_t)1 << log_n;
+        context ctx(device);
+        fri_params_hip<C> params;
+        params.log_domain = log_n + expand;
+        params.step_list.assign(log_n + expand - 4, 1);    // fold down to 16 points, one step per round
+        params.root_of_unity = bls_root;
+        uint64_t seed = 5;
+        auto sm = [&seed]() {
+            uint64_t z = (seed += 0x9E3779B97F4A7C15ull);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return z ^ (z >> 31);
+        };
+        std::vector<polynomial_dfs<C>> polys(cols);
+        for (auto &p : polys) {
+            p.values.resize(n);
+            for (auto &v : p.values) {
+                uint64_t w[4] = {sm(), sm(), sm(), sm() & 0x0fffffffffffffffull};
+                v = A::scalar_from_limbs(w);
+            }
+        }
+        std::vector<std::reference_wrapper<const polynomial_dfs<C>>> lent(polys.begin(), polys.end());
+        uint64_t r = 0;
+        if (streaming) {
+            streaming_fold_builder b;
+            b.threads = threads ? threads : 8;
+            lpc_commitment_scheme_hip<C, counting_transcript, streaming_fold_builder> scheme(ctx, params, b);    // ONE object: its page-locked buffers are reused
+            for (int rep = 0; rep < steps; ++rep) {
+                auto t0 = std::chrono::steady_clock::now();
+                scheme.append_to_batch(rep, lent);
+                r = scheme.commit(rep);
+                ms[rep] = ms_since(t0);
+            }
+        } else {
+            lpc_commitment_scheme_hip<C, counting_transcript, vector_fold_builder> scheme(ctx, params, vector_fold_builder());
+            for (int rep = 0; rep < steps; ++rep) {
+                auto t0 = std::chrono::steady_clock::now();
+                scheme.append_to_batch(rep, lent);
+                r = scheme.commit(rep);
+                ms[rep] = ms_since(t0);
+            }
+        }
+        if (root) *root = r;
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkhip_bench_lpc_scheme: %s\n", e.what());
+        return -1;
+    }
+}
+
+}    // extern "C"

@@ -185,6 +185,12 @@ int zkhip_memcpy_d2h(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes) {
     return ZKHIP_OK;
 }
 
+int zkhip_memcpy_d2h_async(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return ZKHIP_OK;
+}
+
 int zkhip_memcpy_d2d_async(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx) return ZKHIP_ERR_INVALID;
     ZK_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));

@@ -77,8 +77,43 @@ public:
     }
     void h2d(void *dst, const void *src, std::size_t bytes) const { check(zkhip_memcpy_h2d(ctx_, dst, src, bytes), "zkhip_memcpy_h2d", ctx_); }
     void d2h(void *dst, const void *src, std::size_t bytes) const { check(zkhip_memcpy_d2h(ctx_, dst, src, bytes), "zkhip_memcpy_d2h", ctx_); }
+    /// enqueue only; `dst` page-locked (pinned_buffer), valid after the next sync()
+    void d2h_async(void *dst, const void *src, std::size_t bytes) const {
+        check(zkhip_memcpy_d2h_async(ctx_, dst, src, bytes), "zkhip_memcpy_d2h_async", ctx_);
+    }
 
 private:
+    zkhip_ctx *ctx_ = nullptr;
+};
+
+/// Page-locked host memory that grows on demand and is reused: transfers at link speed, no first-touch page faults on reuse.
+class pinned_buffer {
+public:
+    pinned_buffer() = default;
+    ~pinned_buffer() { release(); }
+    pinned_buffer(const pinned_buffer &) = delete;
+    pinned_buffer &operator=(const pinned_buffer &) = delete;
+    /// at least `bytes` bytes (contents are not preserved when it grows)
+    void *reserve(const context &ctx, std::size_t bytes) {
+        if (bytes > cap_) {
+            release();
+            check(zkhip_host_alloc(ctx.get(), bytes, &p_), "zkhip_host_alloc", ctx.get());
+            ctx_ = ctx.get();
+            cap_ = bytes;
+        }
+        return p_;
+    }
+    void *get() const { return p_; }
+    std::size_t capacity() const { return cap_; }
+
+private:
+    void release() {
+        if (p_) zkhip_host_free(ctx_, p_);
+        p_ = nullptr;
+        cap_ = 0;
+    }
+    void *p_ = nullptr;
+    std::size_t cap_ = 0;
     zkhip_ctx *ctx_ = nullptr;
 };
 

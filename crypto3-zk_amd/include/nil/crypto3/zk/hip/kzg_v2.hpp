@@ -25,9 +25,11 @@
 #define ZKHIP_SHIM_KZG_V2_HPP
 
 #include <algorithm>
+#include <deque>
 #include <functional>
 #include <iterator>
 #include <map>
+#include <memory>
 #include <set>
 #include <vector>
 
@@ -171,25 +173,23 @@ public:
     void mark_batch_as_fixed(std::size_t) { }
 
     // ---- polys_evaluator (batched_commitment.hpp:197-247) ----
-    void append_to_batch(std::size_t index, const poly_type &poly) {
-        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
-        _polys[index].push_back(poly);
-    }
+    /// as the reference: the scheme keeps a COPY of the polynomial (batched_commitment.hpp:197-206)
+    void append_to_batch(std::size_t index, const poly_type &poly) { own(index, poly_type(poly)); }
     template <typename ContainerType>
     void append_to_batch(std::size_t index, const ContainerType &polys) {
-        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
-        _polys[index].insert(_polys[index].end(), std::begin(polys), std::end(polys));
+        for (const auto &p : polys) append_one(index, p);
     }
-    /// the reference keeps COPIES of the polynomials (batched_commitment.hpp:197-206); a caller that is done with them hands them over
-    /// instead (50 x 2^20 rows: 340 ms of host copying saved)
-    void append_to_batch(std::size_t index, poly_type &&poly) {
-        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
-        _polys[index].push_back(std::move(poly));
-    }
+    /// a caller that is done with the polynomials hands them over instead (50 x 2^20 rows: 340 ms of host copying saved) ...
+    void append_to_batch(std::size_t index, poly_type &&poly) { own(index, std::move(poly)); }
     void append_to_batch(std::size_t index, std::vector<poly_type> &&polys) {
-        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
-        _polys[index].insert(_polys[index].end(), std::make_move_iterator(polys.begin()), std::make_move_iterator(polys.end()));
+        for (auto &p : polys) own(index, std::move(p));
         polys.clear();
+    }
+    /// ... and one that keeps them alive until commit(index) returns LENDS them: std::cref(poly), or a container of
+    /// std::reference_wrapper<const poly_type> -- nothing is copied on the host, commit reads the caller's vectors where they lie
+    void append_to_batch(std::size_t index, std::reference_wrapper<const poly_type> poly) {
+        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
+        _polys[index].push_back(&poly.get());
     }
     void append_eval_point(std::size_t batch_id, const scalar_value_type &point) {
         for (auto &pts : _points.at(batch_id)) pts.push_back(point);
@@ -211,36 +211,55 @@ public:
     /// on the device for proof_eval.
     commitment_type commit(std::size_t index) {
         const context &ctx = _params.ctx;
-        const auto &polys = _polys[index];
+        const std::vector<const poly_type *> &polys = _polys[index];
         device_batch db;
         std::size_t total = 0;
-        for (const auto &p : polys) {
-            if (p.size() == 0 || (p.size() & (p.size() - 1))) throw std::runtime_error("commit: polynomial_dfs size must be a power of two");
-            if (p.size() > _params.commitment_key.size()) throw std::runtime_error("commit: polynomial longer than the commitment key");
+        for (const poly_type *p : polys) {
+            if (p->size() == 0 || (p->size() & (p->size() - 1))) throw std::runtime_error("commit: polynomial_dfs size must be a power of two");
+            if (p->size() > _params.commitment_key.size()) throw std::runtime_error("commit: polynomial longer than the commitment key");
             db.offset.push_back(total);
-            db.len.push_back(p.size());
-            total += p.size();
+            db.len.push_back(p->size());
+            total += p->size();
         }
         db.data = ctx.alloc(std::max<std::size_t>(1, total) * 32);
-        for (std::size_t i = 0; i < polys.size(); ++i) upload_scalars<adapter>(ctx, db.at(i), polys[i].values.data(), polys[i].size());
-        /* p.coefficients() (kzg.hpp:431): one batched inverse NTT per run of equally sized polynomials */
-        for (std::size_t i = 0; i < polys.size();) {
+        const std::size_t count = polys.size(), jl = 3 * adapter::g1_coord_limbs;
+        auto d_res = ctx.alloc(std::max<std::size_t>(1, count) * jl * 8);
+        /* The polynomials go up in chunks on a second in-order stream: while chunk c is transformed (p.coefficients(), kzg.hpp:431:
+           one batched inverse NTT per chunk of equally sized polynomials) and committed (multiexp against the resident key, the
+           chunk's bucket reductions sharing one launch), chunk c + 1 crosses PCIe. */
+        const bool pipelined = upload_chunk != 0 && count > upload_chunk;
+        const context &up = pipelined ? upload_context() : ctx;
+        for (std::size_t i = 0; i < count;) {
             std::size_t j = i;
-            while (j < polys.size() && db.len[j] == db.len[i]) ++j;
+            while (j < count && db.len[j] == db.len[i] && (upload_chunk == 0 || j - i < upload_chunk)) ++j;
+            for (std::size_t p = i; p < j; ++p) upload_scalars<adapter>(up, db.at(p), polys[p]->values.data(), polys[p]->size());
+            if (pipelined) ctx.wait_for(up);
             std::size_t log_n = 0;
             while (((std::size_t)1 << log_n) < db.len[i]) ++log_n;
             std::uint64_t w[4];
             adapter::scalar_to_limbs(_root_of_unity(log_n), w);
             check(zkhip_ntt_dev(ctx.get(), adapter::id, db.at(i), log_n, j - i, w, 1, nullptr), "zkhip_ntt_dev", ctx.get());
+            commit_resident(db, i, j, d_res.get());
             i = j;
         }
-        _ind_commitments[index] = commit_resident(db);
+        commitment_type out;
+        if (count) {
+            std::vector<std::uint64_t> res(count * jl);
+            ctx.d2h(res.data(), d_res.get(), res.size() * 8);
+            for (std::size_t i = 0; i < count; ++i) out.push_back(adapter::g1_from_jacobian(&res[i * jl]));
+        }
+        _ind_commitments[index] = out;
         _dev[index] = std::move(db);
-        /* state_commited (batched_commitment.hpp:163-166) */
+        /* state_commited (batched_commitment.hpp:163-166).  The host polynomials are not read again: lent ones may go; copies and
+           handed-over ones are released with the scheme (freeing gigabytes of host memory here costs ~100 ms: more than the upload) */
         _locked[index] = true;
         _points[index].resize(polys.size());
+        _polys[index].clear();    // no pointer to a lent polynomial outlives the call
         return _ind_commitments[index];
     }
+
+    /// polynomials per upload chunk (0: the whole batch in one transfer, one shared bucket reduction)
+    std::size_t upload_chunk = 10;
 
     const std::map<std::size_t, commitment_type> &commitments() const { return _ind_commitments; }
 
@@ -251,27 +270,34 @@ protected:
         void *at(std::size_t i) const { return static_cast<char *>(data.get()) + 32 * offset[i]; }
     };
 
-    /// multiexp(commitment_key[0 .. len), coefficients) for every polynomial of a resident batch, as one device batch
-    commitment_type commit_resident(const device_batch &db) const {
+    /// multiexp(commitment_key[0 .. len), coefficients) for polynomials [first, last) of a resident batch, as one device batch
+    /// (enqueued only); results: Jacobian points at d_res + i * 3 * coordinate limbs
+    void commit_resident(const device_batch &db, std::size_t first, std::size_t last, void *d_res) const {
         const context &ctx = _params.ctx;
-        const std::size_t count = db.len.size(), jl = 3 * adapter::g1_coord_limbs;
-        commitment_type out;
-        if (count == 0) return out;
-        auto d_res = ctx.alloc(count * jl * 8);
+        const std::size_t count = last - first, jl = 3 * adapter::g1_coord_limbs;
+        if (count == 0) return;
         std::vector<const zkhip_bases *> qb(count, _params.commitment_key.get());
-        std::vector<std::size_t> qo(count, 0);
+        std::vector<std::size_t> qo(count, 0), qn(db.len.begin() + first, db.len.begin() + last);
         std::vector<const void *> qs(count);
         std::vector<void *> qr(count);
         for (std::size_t i = 0; i < count; ++i) {
-            qs[i] = db.at(i);
-            qr[i] = static_cast<std::uint64_t *>(d_res.get()) + i * jl;
+            qs[i] = db.at(first + i);
+            qr[i] = static_cast<std::uint64_t *>(d_res) + (first + i) * jl;
         }
-        check(zkhip_msm_batch_dev(ctx.get(), count, qb.data(), qo.data(), db.len.data(), qs.data(), qr.data()), "zkhip_msm_batch_dev", ctx.get());
-        std::vector<std::uint64_t> res(count * jl);
-        ctx.d2h(res.data(), d_res.get(), res.size() * 8);
-        for (std::size_t i = 0; i < count; ++i) out.push_back(adapter::g1_from_jacobian(&res[i * jl]));
-        return out;
+        check(zkhip_msm_batch_dev(ctx.get(), count, qb.data(), qo.data(), qn.data(), qs.data(), qr.data()), "zkhip_msm_batch_dev", ctx.get());
     }
+    /// the second stream the uploads of commit() ride on (created on first use, same GPU)
+    const context &upload_context() const {
+        if (!_upload_ctx) _upload_ctx.reset(new context(_params.ctx.device()));
+        return *_upload_ctx;
+    }
+    void own(std::size_t index, poly_type &&poly) {
+        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
+        _owned[index].push_back(std::move(poly));
+        _polys[index].push_back(&_owned[index].back());
+    }
+    void append_one(std::size_t index, const poly_type &p) { own(index, poly_type(p)); }
+    void append_one(std::size_t index, std::reference_wrapper<const poly_type> p) { append_to_batch(index, p); }
     single_commitment_type commit_range(const void *d_coeffs, std::size_t len) const {
         if (len == 0) return single_commitment_type::zero();
         if (len > _params.commitment_key.size()) throw std::runtime_error("proof_eval: quotient longer than the commitment key");
@@ -363,12 +389,14 @@ protected:
 
     const params_type &_params;
     root_of_unity_type _root_of_unity;
-    std::map<std::size_t, std::vector<poly_type>> _polys;
+    std::map<std::size_t, std::vector<const poly_type *>> _polys;    // in append order: copies held in _owned, or the caller's (lent)
+    std::map<std::size_t, std::deque<poly_type>> _owned;             // a deque: references stay valid as it grows
     std::map<std::size_t, bool> _locked;
     std::map<std::size_t, std::vector<std::vector<scalar_value_type>>> _points;
     std::map<std::size_t, device_batch> _dev;
     std::map<std::size_t, commitment_type> _ind_commitments;
     std::vector<scalar_value_type> _merged_points;
+    mutable std::unique_ptr<context> _upload_ctx;
 };
 
 /// kzg_commitment_scheme_v2 (kzg_v2.hpp:56-360): two quotient commitments (pi_1, pi_2)

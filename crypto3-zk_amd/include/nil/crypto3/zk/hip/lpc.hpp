@@ -15,8 +15,14 @@
 //           Q = sum_points (sum_k theta^k (g_k - z_k)) / (X - point)  (lpc.hpp:139-186; one pass over the resident
 //           coefficients + one synthetic division per point), its extension, and the FRI commit phase
 //           (fold_polynomial rounds + per-round leaf layouts, basic_fri.hpp:705-742).
-//   caller  hashing: TreeBuilder(leaves, elements_per_leaf) builds the Merkle tree of a precommitment and exposes
-//           .root() (containers::merkle_tree + the scheme's hash, outside this tree's scope: SURVEY 2); transcript:
+//   caller  hashing: the TreeBuilder builds the Merkle tree of a precommitment and exposes .root() (containers::merkle_tree +
+//           the scheme's hash, outside this tree's scope: SURVEY 2).  Three shapes, best first (see tree_builder_kind):
+//             streaming  b.begin(total_elements, elements_per_leaf); b.absorb(ptr, first_element, count) ...; b.finish()
+//                        -- the leaves arrive in slices of whole leaves through two page-locked buffers: slice k + 1 crosses
+//                        PCIe while the caller hashes slice k, nothing is materialised;
+//             span       b(ptr, total_elements, elements_per_leaf) over a page-locked buffer the scheme keeps (one copy at link speed);
+//             vector     b(const std::vector<value_type> &leaves, elements_per_leaf), as round 2 (a vector the scheme keeps).
+//           transcript:
 //           duck-typed on VALUES like kzg_v2.hpp (transcript(root), transcript.challenge()); the QUERY phase of
 //           proof_eval<FRI> (basic_fri.hpp:747-930: lambda Merkle openings at transcript-derived indices) reads only
 //           trees and a few evaluations and is left to the caller, who finds everything it needs through
@@ -26,9 +32,11 @@
 #define ZKHIP_SHIM_LPC_HPP
 
 #include <algorithm>
+#include <deque>
 #include <functional>
 #include <iterator>
 #include <map>
+#include <memory>
 #include <set>
 #include <type_traits>
 #include <utility>
@@ -52,6 +60,36 @@ struct fri_params_hip {
     std::function<value_type(std::size_t log_n)> root_of_unity;
 };
 
+namespace detail {
+    /// which of the three tree-builder shapes a type offers (see the header comment)
+    enum class tree_builder_kind { streaming, span, vector };
+    template <typename B, typename V, typename = void>
+    struct is_streaming_builder : std::false_type { };
+    template <typename B, typename V>
+    struct is_streaming_builder<B, V,
+                                std::void_t<decltype(std::declval<B &>().begin(std::size_t(), std::size_t())),
+                                            decltype(std::declval<B &>().absorb(static_cast<const V *>(nullptr), std::size_t(), std::size_t())),
+                                            decltype(std::declval<B &>().finish())>> : std::true_type { };
+    template <typename B, typename V, typename = void>
+    struct is_span_builder : std::false_type { };
+    template <typename B, typename V>
+    struct is_span_builder<B, V, std::void_t<decltype(std::declval<B &>()(static_cast<const V *>(nullptr), std::size_t(), std::size_t()))>> : std::true_type { };
+    template <typename B, typename V, tree_builder_kind K>
+    struct tree_builder_result;
+    template <typename B, typename V>
+    struct tree_builder_result<B, V, tree_builder_kind::streaming> {
+        typedef typename std::decay<decltype(std::declval<B &>().finish())>::type type;
+    };
+    template <typename B, typename V>
+    struct tree_builder_result<B, V, tree_builder_kind::span> {
+        typedef typename std::decay<decltype(std::declval<B &>()(static_cast<const V *>(nullptr), std::size_t(), std::size_t()))>::type type;
+    };
+    template <typename B, typename V>
+    struct tree_builder_result<B, V, tree_builder_kind::vector> {
+        typedef typename std::decay<decltype(std::declval<B &>()(std::declval<const std::vector<V> &>(), std::size_t()))>::type type;
+    };
+}    // namespace detail
+
 template <typename CurveType, typename TranscriptType, typename TreeBuilder>
 class lpc_commitment_scheme_hip {
 public:
@@ -64,8 +102,11 @@ public:
     typedef TranscriptType transcript_type;
     typedef polynomial_dfs<CurveType> poly_type;
     typedef eval_storage_hip<CurveType> eval_storage_type;
-    typedef typename std::decay<decltype(std::declval<TreeBuilder &>()(std::declval<const std::vector<value_type> &>(), std::size_t()))>::type
-        precommitment_type;
+    static constexpr detail::tree_builder_kind builder_kind =
+        detail::is_streaming_builder<TreeBuilder, value_type>::value
+            ? detail::tree_builder_kind::streaming
+            : (detail::is_span_builder<TreeBuilder, value_type>::value ? detail::tree_builder_kind::span : detail::tree_builder_kind::vector);
+    typedef typename detail::tree_builder_result<TreeBuilder, value_type, builder_kind>::type precommitment_type;
     typedef typename std::decay<decltype(std::declval<const precommitment_type &>().root())>::type commitment_type;
     typedef std::map<std::size_t, std::vector<value_type>> preprocessed_data_type;
     struct fri_proof_type {
@@ -107,24 +148,21 @@ public:
     void mark_batch_as_fixed(std::size_t index) { _batch_fixed[index] = true; }
 
     // ---- polys_evaluator (batched_commitment.hpp:197-247) ----
-    void append_to_batch(std::size_t index, const poly_type &poly) {
-        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
-        _polys[index].push_back(poly);
-    }
+    /// as the reference: the scheme keeps a COPY of the polynomial (batched_commitment.hpp:197-206)
+    void append_to_batch(std::size_t index, const poly_type &poly) { own(index, poly_type(poly)); }
     template <typename ContainerType>
     void append_to_batch(std::size_t index, const ContainerType &polys) {
-        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
-        _polys[index].insert(_polys[index].end(), std::begin(polys), std::end(polys));
+        for (const auto &p : polys) append_one(index, p);
     }
-    /// hand the polynomials over instead of copying them (see kzg_v2.hpp)
-    void append_to_batch(std::size_t index, poly_type &&poly) {
-        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
-        _polys[index].push_back(std::move(poly));
-    }
+    /// hand the polynomials over instead of copying them, or LEND them (std::cref: alive until commit(index) returns) -- see kzg_v2.hpp
+    void append_to_batch(std::size_t index, poly_type &&poly) { own(index, std::move(poly)); }
     void append_to_batch(std::size_t index, std::vector<poly_type> &&polys) {
-        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
-        _polys[index].insert(_polys[index].end(), std::make_move_iterator(polys.begin()), std::make_move_iterator(polys.end()));
+        for (auto &p : polys) own(index, std::move(p));
         polys.clear();
+    }
+    void append_to_batch(std::size_t index, std::reference_wrapper<const poly_type> poly) {
+        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
+        _polys[index].push_back(&poly.get());
     }
     void append_eval_point(std::size_t batch_id, const value_type &point) {
         for (auto &pts : _points.at(batch_id)) pts.push_back(point);
@@ -144,41 +182,53 @@ public:
 
     /// commit(index) (lpc.hpp:101-106): precommit<FRI>(polys, D[0], step_list.front()) -> the tree's root
     commitment_type commit(std::size_t index) {
-        const auto &polys = _polys[index];
+        const std::vector<const poly_type *> &polys = _polys[index];
         _locked[index] = true;    // state_commited (batched_commitment.hpp:163-166)
         _points[index].resize(polys.size());
         device_batch db;
         std::size_t total = 0;
-        for (const auto &p : polys) {
-            if (p.size() == 0 || (p.size() & (p.size() - 1)) || p.size() > domain_size(0)) throw std::runtime_error("lpc commit: bad polynomial size");
+        for (const poly_type *p : polys) {
+            if (p->size() == 0 || (p->size() & (p->size() - 1)) || p->size() > domain_size(0)) throw std::runtime_error("lpc commit: bad polynomial size");
             db.offset.push_back(total);
-            db.len.push_back(p.size());
-            total += p.size();
+            db.len.push_back(p->size());
+            total += p->size();
         }
         db.data = _ctx.alloc(std::max<std::size_t>(1, total) * 32);
-        for (std::size_t i = 0; i < polys.size(); ++i) upload_scalars<adapter>(_ctx, db.at(i), polys[i].values.data(), polys[i].size());
-        /* poly.resize(D[0]->size()) for every polynomial (basic_fri.hpp:452-455): one call per run of equal sizes; it leaves
-           the COEFFICIENTS in the source buffer, which is what proof_eval reads later */
-        const std::size_t D = domain_size(0);
-        auto d_ext = _ctx.alloc(std::max<std::size_t>(1, polys.size()) * D * 32);
+        /* poly.resize(D[0]->size()) for every polynomial (basic_fri.hpp:452-455): one call per chunk of equally sized polynomials; it
+           leaves the COEFFICIENTS in the source buffer, which is what proof_eval reads later.  The chunks go up on a second in-order
+           stream: chunk c + 1 crosses PCIe while chunk c is transformed. */
+        const std::size_t D = domain_size(0), count = polys.size();
+        void *d_ext = scratch(_scratch_ext, _scratch_ext_cap, std::max<std::size_t>(1, count) * D * 32);    // kept across commits: no GB-sized hipMalloc per batch
         std::uint64_t wd[4];
         adapter::scalar_to_limbs(_fri_params.root_of_unity(_fri_params.log_domain), wd);
-        for (std::size_t i = 0; i < polys.size();) {
+        const bool pipelined = upload_chunk != 0 && count > upload_chunk;
+        const context &up = pipelined ? upload_context() : _ctx;
+        for (std::size_t i = 0; i < count;) {
             std::size_t j = i;
-            while (j < polys.size() && db.len[j] == db.len[i]) ++j;
+            while (j < count && db.len[j] == db.len[i] && (upload_chunk == 0 || j - i < upload_chunk)) ++j;
+            for (std::size_t p = i; p < j; ++p) upload_scalars<adapter>(up, db.at(p), polys[p]->values.data(), polys[p]->size());
+            if (pipelined) _ctx.wait_for(up);
             const std::size_t log_n = log2_of(db.len[i]);
             std::uint64_t wn[4];
             adapter::scalar_to_limbs(_fri_params.root_of_unity(log_n), wn);
-            check(zkhip_poly_resize_dev(_ctx.get(), adapter::id, db.at(i), log_n, j - i, wn, static_cast<char *>(d_ext.get()) + 32 * i * D,
+            check(zkhip_poly_resize_dev(_ctx.get(), adapter::id, db.at(i), log_n, j - i, wn, static_cast<char *>(d_ext) + 32 * i * D,
                                         _fri_params.log_domain, wd),
                   "zkhip_poly_resize_dev", _ctx.get());
             i = j;
         }
         _trees.erase(index);
-        _trees.emplace(index, build_tree(d_ext.get(), polys.size(), _fri_params.log_domain, _fri_params.step_list.front()));
+        _trees.emplace(index, build_tree(d_ext, count, _fri_params.log_domain, _fri_params.step_list.front()));
         _dev[index] = std::move(db);
+        /* the host polynomials are not read again: lent ones may go; copies and handed-over ones are released with the scheme (freeing
+           gigabytes of host memory here would cost more than the commit's device work) */
+        _polys[index].clear();    // no pointer to a lent polynomial outlives the call
         return _trees.at(index).root();
     }
+
+    /// polynomials per upload chunk of commit() (0: the whole batch in one transfer)
+    std::size_t upload_chunk = 4;
+    /// elements per slice handed to a streaming tree builder (rounded up to whole leaves)
+    std::size_t leaf_slice_elements = (std::size_t)1 << 21;
 
     /// proof_eval (lpc.hpp:113-200) up to and including the FRI commit phase (basic_fri.hpp:705-742)
     proof_type proof_eval(transcript_type &transcript) {
@@ -332,13 +382,79 @@ protected:
     }
     /// the leaf layout of `batch` polynomials resident as evaluations over the 2^log_domain-point domain -> the caller's tree
     precommitment_type build_tree(const void *d_evals, std::size_t batch, std::size_t log_domain, std::size_t fri_step) const {
-        const std::size_t D = (std::size_t)1 << log_domain;
-        auto d_leaves = _ctx.alloc(std::max<std::size_t>(1, batch) * D * 32);
-        check(zkhip_fri_leaves_dev(_ctx.get(), d_evals, log_domain, batch, fri_step, d_leaves.get()), "zkhip_fri_leaves_dev", _ctx.get());
-        std::vector<value_type> leaves;
-        download_scalars<adapter>(_ctx, d_leaves.get(), batch * D, leaves);    // one copy for canonical-limb scalar types (backend.hpp)
-        return _builder(leaves, batch * ((std::size_t)1 << fri_step));
+        const std::size_t D = (std::size_t)1 << log_domain, total = batch * D, per_leaf = batch * ((std::size_t)1 << fri_step);
+        void *d_leaves = scratch(_scratch_leaves, _scratch_leaves_cap, std::max<std::size_t>(1, total) * 32);
+        check(zkhip_fri_leaves_dev(_ctx.get(), d_evals, log_domain, batch, fri_step, d_leaves), "zkhip_fri_leaves_dev", _ctx.get());
+        if constexpr (builder_kind == detail::tree_builder_kind::streaming) {
+            /* slices of whole leaves through two page-locked buffers: the copy of slice k + 1 is in flight while the caller absorbs slice k */
+            const std::size_t slice = std::max<std::size_t>(1, (leaf_slice_elements + per_leaf - 1) / std::max<std::size_t>(1, per_leaf)) * std::max<std::size_t>(1, per_leaf);
+            _builder.begin(total, per_leaf);
+            if (total != 0) {
+                void *pin[2] = {_pin[0].reserve(_ctx, std::min(slice, total) * 32), _pin[1].reserve(_ctx, std::min(slice, total) * 32)};
+                const char *src = static_cast<const char *>(d_leaves);
+                _ctx.d2h_async(pin[0], src, std::min(slice, total) * 32);
+                _ctx.sync();
+                for (std::size_t at = 0, k = 0; at < total; at += slice, ++k) {
+                    const std::size_t cnt = std::min(slice, total - at), next = at + slice;
+                    if (next < total) _ctx.d2h_async(pin[(k + 1) & 1], src + 32 * next, std::min(slice, total - next) * 32);
+                    _builder.absorb(host_values(pin[k & 1], cnt), at, cnt);
+                    _ctx.sync();
+                }
+            }
+            return _builder.finish();
+        } else if constexpr (builder_kind == detail::tree_builder_kind::span) {
+            void *pin = _pin[0].reserve(_ctx, std::max<std::size_t>(1, total) * 32);
+            if (total != 0) {
+                _ctx.d2h_async(pin, d_leaves, total * 32);
+                _ctx.sync();
+            }
+            return _builder(host_values(pin, total), total, per_leaf);
+        } else {
+            _leaf_vec.clear();    // keeps its capacity: after the first commit no page of it is touched for the first time
+            download_scalars<adapter>(_ctx, d_leaves, total, _leaf_vec);    // one copy for canonical-limb scalar types (backend.hpp)
+            return _builder(_leaf_vec, per_leaf);
+        }
     }
+    /// `count` canonical 32-byte elements in host memory as scalar-field values: in place when the scalar type IS four canonical
+    /// limbs, through a converted copy (host threads) otherwise
+    const value_type *host_values(const void *limbs, std::size_t count) const {
+        if constexpr (detail::canonical_scalars<adapter>::value) {
+            static_assert(sizeof(value_type) == 32, "canonical-limb scalars are 4 x u64");
+            return static_cast<const value_type *>(limbs);
+        } else {
+            _conv.resize(count);
+            const std::uint64_t *h = static_cast<const std::uint64_t *>(limbs);
+            const std::size_t lanes = count >= ((std::size_t)1 << 16) ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+            std::vector<std::future<void>> work;
+            for (std::size_t k = 0; k < lanes; ++k)
+                work.push_back(std::async(lanes > 1 ? std::launch::async : std::launch::deferred, [&, k]() {
+                    for (std::size_t i = count * k / lanes; i < count * (k + 1) / lanes; ++i) _conv[i] = adapter::scalar_from_limbs(h + 4 * i);
+                }));
+            for (auto &w : work) w.get();
+            return _conv.data();
+        }
+    }
+    const context &upload_context() const {
+        if (!_upload_ctx) _upload_ctx.reset(new context(_ctx.device()));
+        return *_upload_ctx;
+    }
+    /// a device scratch buffer that grows on demand and is kept (every use is ordered on the context's stream)
+    void *scratch(std::shared_ptr<void> &buf, std::size_t &cap, std::size_t bytes) const {
+        if (bytes > cap) {
+            _ctx.sync();
+            buf.reset();
+            buf = _ctx.alloc(bytes);
+            cap = bytes;
+        }
+        return buf.get();
+    }
+    void own(std::size_t index, poly_type &&poly) {
+        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
+        _owned[index].push_back(std::move(poly));
+        _polys[index].push_back(&_owned[index].back());
+    }
+    void append_one(std::size_t index, const poly_type &p) { own(index, poly_type(p)); }
+    void append_one(std::size_t index, std::reference_wrapper<const poly_type> p) { append_to_batch(index, p); }
     std::vector<value_type> evaluate_batch_at(std::size_t k, const value_type &x) const {
         const device_batch &db = _dev.at(k);
         std::vector<value_type> out(db.len.size());
@@ -399,7 +515,13 @@ protected:
     params_type _fri_params;
     mutable TreeBuilder _builder;
     value_type _etha;
-    std::map<std::size_t, std::vector<poly_type>> _polys;
+    std::map<std::size_t, std::vector<const poly_type *>> _polys;    // in append order: copies held in _owned, or the caller's (lent)
+    std::map<std::size_t, std::deque<poly_type>> _owned;
+    mutable std::unique_ptr<context> _upload_ctx;
+    mutable pinned_buffer _pin[2];
+    mutable std::vector<value_type> _leaf_vec, _conv;
+    mutable std::shared_ptr<void> _scratch_ext, _scratch_leaves;
+    mutable std::size_t _scratch_ext_cap = 0, _scratch_leaves_cap = 0;
     std::map<std::size_t, bool> _locked, _batch_fixed;
     std::map<std::size_t, std::vector<std::vector<value_type>>> _points;
     std::map<std::size_t, device_batch> _dev;

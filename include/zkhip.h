@@ -76,6 +76,9 @@ int zkhip_memcpy_h2d(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes);
 int zkhip_memcpy_d2h(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes);
 /* enqueue only (no synchronisation): for pinned host buffers, ordered with the kernels on the context's stream */
 int zkhip_memcpy_h2d_async(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* the way back, enqueue only: `dst` must be page-locked (zkhip_host_alloc) and is valid after the next zkhip_sync.  The LPC shim
+ * streams a precommitment's leaves to the caller's hash in slices this way: slice k + 1 is in flight while slice k is absorbed. */
+int zkhip_memcpy_d2h_async(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes);
 /* page-locked host memory: H2D / D2H at link speed instead of through a staging copy */
 /* device-to-device copy in stream order (no synchronisation) */
 int zkhip_memcpy_d2d_async(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes);

@@ -663,6 +663,46 @@ struct toy_tree_builder {
     }
 };
 
+/// the same toy root through the two other builder shapes the LPC scheme accepts (hip/lpc.hpp): a span over page-locked memory, and
+/// slices absorbed while the next one crosses PCIe
+template <typename Curve>
+struct toy_span_builder {
+    typedef typename curve_adapter<Curve>::scalar_value_type Fr;
+    toy_tree<Curve> operator()(const Fr *leaves, std::size_t count, std::size_t per_leaf) const {
+        toy_tree<Curve> t;
+        t.r = Fr((std::uint64_t)per_leaf);
+        for (std::size_t i = 0; i < count; ++i) t.r = t.r + Fr((std::uint64_t)(i + 1)) * leaves[i];
+        t.leaves = per_leaf ? count / per_leaf : 0;
+        return t;
+    }
+};
+template <typename Curve>
+struct toy_streaming_builder {
+    typedef typename curve_adapter<Curve>::scalar_value_type Fr;
+    toy_tree<Curve> t;
+    std::size_t per = 0, seen = 0, slices = 0;
+    bool whole_leaves = true;
+    void begin(std::size_t, std::size_t per_leaf) {
+        t = toy_tree<Curve>();
+        t.r = Fr((std::uint64_t)per_leaf);
+        per = per_leaf;
+        seen = slices = 0;
+        whole_leaves = true;
+    }
+    void absorb(const Fr *leaves, std::size_t first, std::size_t count) {
+        if (first != seen || (per && (first % per || count % per))) whole_leaves = false;    // in order, whole leaves only
+        for (std::size_t i = 0; i < count; ++i) t.r = t.r + Fr((std::uint64_t)(first + i + 1)) * leaves[i];
+        seen += count;
+        ++slices;
+    }
+    toy_tree<Curve> finish() {
+        t.leaves = per ? seen / per : 0;
+        if (!whole_leaves) t.r = Fr::zero();    // a contract violation shows up as a wrong root
+        return t;
+    }
+};
+int g_lpc_builder = 0;    // 0: vector builder, 1: span, 2: streaming (64-element slices, one polynomial per upload chunk, lent polynomials)
+
 /// The consumer contract placeholder has with its commitment_scheme_type (what dummy_commitment_scheme_type implements,
 /// test/systems/plonk/placeholder/placeholder.cpp:96-148, and what placeholder_prover calls: ph/prover.hpp:82-300):
 /// compiled against BOTH device schemes.  batch 0 (fixed) = polys[0..1], batch 1 = polys[2..]; returns the proof.
@@ -676,7 +716,12 @@ typename Scheme::proof_type placeholder_consumer(Scheme &scheme, typename Scheme
     scheme.mark_batch_as_fixed(0);
     typename Scheme::preprocessed_data_type prep = scheme.preprocess(transcript);
     scheme.setup(transcript, prep);
-    scheme.append_to_batch(1, std::vector<Poly>(polys.begin() + 2, polys.end()));
+    if (g_lpc_builder == 2) {    // lent, not copied: the caller keeps `polys` alive until commit returns
+        std::vector<std::reference_wrapper<const Poly>> lent(polys.begin() + 2, polys.end());
+        scheme.append_to_batch(1, lent);
+    } else {
+        scheme.append_to_batch(1, std::vector<Poly>(polys.begin() + 2, polys.end()));
+    }
     commitments[1] = scheme.commit(1);
     scheme.append_eval_point(0, points[0]);
     scheme.append_eval_point(1, points[0]);
@@ -687,8 +732,8 @@ typename Scheme::proof_type placeholder_consumer(Scheme &scheme, typename Scheme
     return proof;
 }
 
-template <typename Curve>
-int lpc_scheme_t(const uint64_t *evals, size_t npolys, const uint64_t *log_n, size_t log_domain, const uint64_t *steps, size_t nsteps, const uint64_t *roots,
+template <typename Curve, typename Builder>
+int lpc_scheme_run(const uint64_t *evals, size_t npolys, const uint64_t *log_n, size_t log_domain, const uint64_t *steps, size_t nsteps, const uint64_t *roots,
                  const uint64_t *points, const uint64_t *challenges, size_t nchallenges, uint64_t *out_roots, uint64_t *out_z, uint64_t *out_fri_roots,
                  uint64_t *out_final, uint64_t *out_counts) {
     typedef curve_adapter<Curve> A;
@@ -698,9 +743,13 @@ int lpc_scheme_t(const uint64_t *evals, size_t npolys, const uint64_t *log_n, si
     fp.log_domain = log_domain;
     for (size_t i = 0; i < nsteps; ++i) fp.step_list.push_back(steps[i]);
     fp.root_of_unity = [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); };
-    typedef lpc_commitment_scheme_hip<Curve, scripted_any_transcript<Curve>, toy_tree_builder<Curve>> scheme_type;
+    typedef lpc_commitment_scheme_hip<Curve, scripted_any_transcript<Curve>, Builder> scheme_type;
     static_assert(scheme_type::is_lpc(), "placeholder branches on is_lpc()");
-    scheme_type scheme(ctx, fp, toy_tree_builder<Curve>());
+    scheme_type scheme(ctx, fp, Builder());
+    if (g_lpc_builder == 2) {
+        scheme.leaf_slice_elements = 64;
+        scheme.upload_chunk = 1;
+    }
     std::vector<polynomial_dfs<Curve>> polys(npolys);
     size_t at = 0;
     for (size_t p = 0; p < npolys; ++p)
@@ -728,6 +777,26 @@ int lpc_scheme_t(const uint64_t *evals, size_t npolys, const uint64_t *log_n, si
     if (scheme.fri_round_polynomial(0).size() != ((size_t)1 << log_domain)) return -7;
     if (scheme.coefficients(1, 0).size() != polys[2].size()) return -8;
     return 0;
+}
+
+template <typename Curve>
+int lpc_scheme_t(const uint64_t *evals, size_t npolys, const uint64_t *log_n, size_t log_domain, const uint64_t *steps, size_t nsteps, const uint64_t *roots,
+                 const uint64_t *points, const uint64_t *challenges, size_t nchallenges, uint64_t *out_roots, uint64_t *out_z, uint64_t *out_fri_roots,
+                 uint64_t *out_final, uint64_t *out_counts) {
+    typedef curve_adapter<Curve> A;
+    typedef scripted_any_transcript<Curve> T;
+    static_assert(lpc_commitment_scheme_hip<Curve, T, toy_tree_builder<Curve>>::builder_kind == detail::tree_builder_kind::vector, "vector builder");
+    static_assert(lpc_commitment_scheme_hip<Curve, T, toy_span_builder<Curve>>::builder_kind == detail::tree_builder_kind::span, "span builder");
+    static_assert(lpc_commitment_scheme_hip<Curve, T, toy_streaming_builder<Curve>>::builder_kind == detail::tree_builder_kind::streaming, "streaming builder");
+    (void)sizeof(A);
+    if (g_lpc_builder == 1)
+        return lpc_scheme_run<Curve, toy_span_builder<Curve>>(evals, npolys, log_n, log_domain, steps, nsteps, roots, points, challenges, nchallenges, out_roots,
+                                                              out_z, out_fri_roots, out_final, out_counts);
+    if (g_lpc_builder == 2)
+        return lpc_scheme_run<Curve, toy_streaming_builder<Curve>>(evals, npolys, log_n, log_domain, steps, nsteps, roots, points, challenges, nchallenges,
+                                                                   out_roots, out_z, out_fri_roots, out_final, out_counts);
+    return lpc_scheme_run<Curve, toy_tree_builder<Curve>>(evals, npolys, log_n, log_domain, steps, nsteps, roots, points, challenges, nchallenges, out_roots,
+                                                          out_z, out_fri_roots, out_final, out_counts);
 }
 
 /// the same consumer against the placeholder-facing KZG scheme: byte-blob commitments through a packer, verify_eval through a hook
@@ -869,6 +938,7 @@ void shim_host_query_shards(size_t world, size_t a, size_t b, size_t h, size_t l
 }
 
 void shim_set_world(int world) { g_world = world < 1 ? 1 : world; }
+void shim_set_lpc_builder(int kind) { g_lpc_builder = kind; }
 void shim_set_domain(int kind, size_t m, const uint64_t *shift) {
     g_dom_kind = kind;
     g_dom_m = m;

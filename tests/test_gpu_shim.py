@@ -588,11 +588,23 @@ def _toy_root(r):
     return lambda leaves, per_leaf: (per_leaf + sum((i + 1) * v for i, v in enumerate(leaves))) % r
 
 
+@pytest.mark.parametrize("builder", ["vector", "span", "streaming"])
 @pytest.mark.parametrize("curve,log_domain,steps", [(0, 8, [1, 2]), (1, 7, [2, 1, 1]), (0, 7, [3])])
-def test_lpc_scheme_shim(shim, curve, log_domain, steps):
+def test_lpc_scheme_shim(shim, curve, log_domain, steps, builder):
     """lpc_commitment_scheme_hip driven through the consumer contract placeholder has with its commitment scheme (fixed batch,
     preprocess / setup, two batches, ragged point sets): commit roots, evaluations, FRI round roots and the final polynomial
-    against po.lpc_proof_eval (lpc.hpp:101-200 + basic_fri.hpp:433-496, 705-742); the Merkle tree is a toy functor on both sides."""
+    against po.lpc_proof_eval (lpc.hpp:101-200 + basic_fri.hpp:433-496, 705-742); the Merkle tree is a toy functor on both sides.
+    builder: the three shapes of the caller's tree builder -- a std::vector of leaves, a span over page-locked memory, and slices
+    of whole leaves absorbed while the next slice is in flight (64-element slices, one polynomial per upload chunk, the second
+    batch LENT to the scheme instead of copied)."""
+    shim.shim_set_lpc_builder({"vector": 0, "span": 1, "streaming": 2}[builder])
+    try:
+        _lpc_scheme_shim(shim, curve, log_domain, steps)
+    finally:
+        shim.shim_set_lpc_builder(0)
+
+
+def _lpc_scheme_shim(shim, curve, log_domain, steps):
     C = CURVES[curve]
     r = C.r
     logs = [log_domain - 3, log_domain - 3, log_domain - 2, log_domain - 3]
