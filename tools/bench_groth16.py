@@ -5,7 +5,6 @@ import argparse
 import ctypes
 import json
 import os
-import subprocess
 
 import numpy as np
 
@@ -24,15 +23,18 @@ def main():
     ap.add_argument("--inputs", type=int, default=10)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--curve", type=int, default=0)
+    ap.add_argument("--domain", choices=("ref", "basic"), default="ref",
+                    help="ref: the domain make_evaluation_domain(M + n + 1) picks (step radix-2 for M = 2^20, n = 10); basic: the next power of two")
     a = ap.parse_args()
     so = os.path.join(ROOT, "crypto3-zk_amd", "libzkhip_bench.so")
-    if not os.path.exists(so):  # a snapshot's file times are not the build's: never let make decide on the GPU box
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "crypto3-zk_amd"), "libzkhip_bench.so"], stdout=subprocess.DEVNULL)
+    if not os.path.exists(so):  # never build from here: this script runs under rocprofv3 (no compiler driver from a profiled process)
+        raise SystemExit("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` first" % so)
     lib = ctypes.CDLL(so)
     M = 1 << a.log_constraints
     m = 1
     while m < M + a.inputs + 1:
         m <<= 1
+    lib.zkhip_bench_set_domain(0 if a.domain == "basic" else -1, ctypes.c_size_t(m if a.domain == "basic" else 0))
     r, g = R[a.curve]
     omega = limbs(pow(g, (r - 1) // m, r))
     coset = limbs(g)
@@ -44,10 +46,12 @@ def main():
                                  omega.ctypes.data_as(ctypes.c_void_p), coset.ctypes.data_as(ctypes.c_void_p),
                                  times.ctypes.data_as(ctypes.c_void_p), ctypes.byref(setup), ctypes.byref(verified), prof, ctypes.c_size_t(16384))
     assert rc == 0, rc
+    info = np.zeros(8, dtype=np.uint64)
+    lib.zkhip_bench_last_info(info.ctypes.data_as(ctypes.c_void_p))
     kern = {l.rsplit(" ", 2)[0]: round(float(l.rsplit(" ", 2)[1]), 3) for l in prof.value.decode().splitlines() if l}
     best = float(times[1:].min() if a.steps > 1 else times.min())
-    print(json.dumps({"workload": "Groth16 prove, curve %d, 2^%d constraints, %d inputs, domain 2^%d, 1 GPU, via C++ shim (H2D of the assignment and D2H of the 5 MSM results included)"
-                      % (a.curve, a.log_constraints, a.inputs, m.bit_length() - 1),
+    print(json.dumps({"workload": "Groth16 prove, curve %d, 2^%d constraints, %d inputs, %s domain of %d points, 1 GPU, via C++ shim (H2D of the assignment and D2H of the 5 MSM results included)"
+                      % (a.curve, a.log_constraints, a.inputs, ("basic", "extended", "step")[int(info[0])] + " radix-2", int(info[1])),
                       "ms_per_proof": [round(float(t), 3) for t in times], "constraints_per_s": round(M / best * 1e3, 1),
                       "setup_ms": round(setup.value, 1), "verified": verified.value == 1,
                       "kernel_ms_last_proof (main stream; the G2 multiexp runs on a second context)": kern}))

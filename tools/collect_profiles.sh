@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round-2 evidence run (on the GPU box, from the repository root): bench line, rocprofv3 kernel stats, PMC passes,
+# Round-3 evidence run (on the GPU box, from the repository root): bench line, rocprofv3 kernel stats, PMC passes,
 # sweeps.  Everything lands in gpurun_out/ (copied into profiles/ afterwards).
 set -u
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$root"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-R=r02
+R=r03
 python3 bench.py > gpurun_out/${R}_bench_final.json 2> gpurun_out/${R}_bench_final.err
 # kernel trace + stats of the MSM / NTT legs of the same command
 rm -rf /tmp/rp && ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rp -o msm --output-format csv -- python3 "$root/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-groth16 --no-kzg --no-pmc --no-verify --no-two-in-flight > /tmp/rp.log 2>&1 )
@@ -21,9 +21,11 @@ tools/pmc_collect.sh gpurun_out/${R}_pmc_msm_ntt.json tools/pmc_child.py 20 > /d
 PMC_GROUPS="GRBM_GUI_ACTIVE;SQ_BUSY_CYCLES SQ_WAVES" tools/pmc_collect.sh gpurun_out/${R}_pmc_clock.json tools/pmc_child.py 20 > /dev/null 2>&1
 tools/pmc_collect.sh gpurun_out/${R}_pmc_g2_msm.json tools/msm_g2_once.py > /dev/null 2>&1
 python3 tools/msm_sweep.py 2>/dev/null | tail -1 > gpurun_out/${R}_msm_size_sweep.json
-python3 tools/msm_window_sweep.py G1 2>/dev/null | tail -1 > gpurun_out/${R}_msm_window_sweep_g1.json
 python3 tools/shard_emulation.py 20 2>/dev/null | tail -1 > gpurun_out/${R}_shard_emulation.json
 python3 tools/bench_groth16.py --steps 6 2>/dev/null | tail -1 > gpurun_out/${R}_groth16_2p20_shim.json
+python3 tools/bench_groth16.py --steps 6 --domain basic 2>/dev/null | tail -1 > gpurun_out/${R}_groth16_2p20_basic_domain_shim.json
+./tools/kzg_shim_bench 20 50 10 > gpurun_out/${R}_kzg_shim_bench.txt 2>&1
+./tools/lpc_shim_bench 20 16 16 > gpurun_out/${R}_lpc_shim_bench.txt 2>&1
 python3 tools/bench_kzg.py 2>/dev/null | tail -1 > gpurun_out/${R}_kzg_commit_50x2p20.json
 python3 tools/bench_ntt.py 2>/dev/null | tail -1 > gpurun_out/${R}_ntt_2p22x8.json
 ls -la gpurun_out | tail -20
