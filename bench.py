@@ -109,6 +109,11 @@ def main():
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the two-MSMs-in-flight throughput figure (N = 1 only)")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic with rocprofv3 --pmc child passes")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-timing full-size checks")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
+                    help="nccl (= RCCL, the default) or gloo: the tiny exchanges staged through the host -- for the test that runs two REAL ranks on one GPU")
+    ap.add_argument("--same-device", action="store_true", help="every rank uses GPU 0 (two ranks sharing the one GPU of a test box)")
+    ap.add_argument("--log-constraints", type=int, default=20, help="constraints of the sharded Groth16 leg = 2^k (tests use a smaller instance)")
+    ap.add_argument("--kzg-log-rows", type=int, default=20, help="rows of the sharded KZG leg's columns = 2^k")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: launch the ranks, run the all-gather + fold plumbing over gloo with stand-in partial sums, print the line's frame")
     args = ap.parse_args()
@@ -129,7 +134,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(1, args.gpus) and rank == 0:
         print("bench.py: --gpus %d but the launcher started %d rank(s); using the launcher's world size" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
@@ -138,11 +143,15 @@ def main():
     dist = None
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        import torch.distributed as dist
+        import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,  # nccl == RCCL on ROCm
-                                device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            tdist.init_process_group(backend="nccl", rank=rank, world_size=world,  # nccl == RCCL on ROCm
+                                     device_id=torch.device("cuda", local_rank))
+        else:
+            tdist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        dist = Comm(torch, tdist, args.dist_backend, local_rank)
 
     zk = load_pkg()
     ctx = zk.Context(local_rank)
@@ -252,11 +261,11 @@ def main():
     g16_sharded = None
     if use_dist and not args.no_groth16:
         # BASELINE config 4: ONE 2^20-constraint proof sharded over all ranks (every rank takes part in the exchange)
-        g16_sharded = groth16_sharded_leg(np, torch, dist, rank, world, local_rank, verify=not args.no_verify)
+        g16_sharded = groth16_sharded_leg(np, torch, dist, rank, world, local_rank, log_constraints=args.log_constraints, verify=not args.no_verify)
     kzg_sharded = None
     if use_dist and not args.no_kzg:
         # BASELINE config 5's commitment leg: the 50 columns dealt over the ranks, one all-gather of the commitments
-        kzg_sharded = kzg_sharded_leg(np, torch, dist, zk, ctx, rank, world, local_rank, verify=not args.no_verify)
+        kzg_sharded = kzg_sharded_leg(np, torch, dist, zk, ctx, rank, world, local_rank, log_n=args.kzg_log_rows, verify=not args.no_verify)
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * n * args.steps / elapsed / 1e6
@@ -325,6 +334,43 @@ def main():
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+class Comm:
+    """The collectives the legs use -- one all-gather of a few hundred bytes per step, a barrier, a max-reduction of the timings --
+    over RCCL (backend "nccl": device tensors, ordered on torch's current stream, which the zkhip context runs on) or over gloo
+    (tensors staged through the host).  gloo exists for the test-suite: RCCL cannot put two ranks on ONE GPU, and that is the only
+    way a one-GPU box runs two real rank PROCESSES over the real kernels (tests/test_gpu_two_ranks.py)."""
+
+    def __init__(self, torch, tdist, backend, local_rank):
+        self.torch, self.d, self.backend, self.local_rank = torch, tdist, backend, local_rank
+        self.ReduceOp = tdist.ReduceOp
+
+    def all_gather_into_tensor(self, out, inp):
+        if self.backend == "nccl":
+            return self.d.all_gather_into_tensor(out, inp)
+        host = self.torch.empty(out.shape, dtype=out.dtype)
+        self.d.all_gather_into_tensor(host, inp.cpu())  # .cpu() waits for the stream the partial sums were computed on
+        out.copy_(host)
+
+    def all_reduce(self, t, op=None):
+        if self.backend == "nccl":
+            return self.d.all_reduce(t, op=op)
+        host = t.cpu()
+        self.d.all_reduce(host, op=op)
+        t.copy_(host)
+
+    def barrier(self, device_ids=None):
+        if self.backend == "nccl":
+            return self.d.barrier(device_ids=device_ids)
+        self.torch.cuda.synchronize()
+        self.d.barrier()
+
+    def all_gather_object(self, parts, obj):
+        return self.d.all_gather_object(parts, obj)
+
+    def destroy_process_group(self):
+        return self.d.destroy_process_group()
 
 
 def dry_run(args):
@@ -551,6 +597,14 @@ def groth16_leg(np, constraints=1 << 20, inputs=10, steps=4, verify=True, domain
             "roofline": roof, "kernel_ms_last_proof": kern}
 
 
+def _last_domain(np, lib):
+    import ctypes
+
+    info = np.zeros(8, dtype=np.uint64)
+    lib.zkhip_bench_last_info(info.ctypes.data_as(ctypes.c_void_p))
+    return {"kind": ("basic_radix2", "extended_radix2", "step_radix2")[int(info[0])], "points": int(info[1])}
+
+
 def groth16_sharded_leg(np, torch, dist, rank, world, local_rank, log_constraints=20, inputs=10, steps=3, verify=True):
     """BASELINE config 4: one Groth16 proof (M = 2^20, n = 10) sharded over `world` GPUs, one process each: every rank holds
     a point-range slice of each query of the SAME valid key (generated per rank on its device), runs the witness map in
@@ -571,14 +625,26 @@ def groth16_sharded_leg(np, torch, dist, rank, world, local_rank, log_constraint
     dev = torch.device("cuda", local_rank)
 
     @ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
-    def all_gather(mine, words, out):
+    def all_gather(mine, words, out):  # host-buffer form (kept for callers without device buffers; not used below)
         src = np.ctypeslib.as_array(ctypes.cast(mine, ctypes.POINTER(ctypes.c_uint64)), (words,))
         t = torch.from_numpy(src.view(np.int64).copy()).to(dev)
         gathered = torch.empty(world * words, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(gathered, t)  # RCCL
+        dist.all_gather_into_tensor(gathered, t)
         dst = np.ctypeslib.as_array(ctypes.cast(out, ctypes.POINTER(ctypes.c_uint64)), (world * words,))
         dst[:] = gathered.cpu().numpy().view(np.uint64)
 
+    # the exchange stays on the device: the prover copies its 864 bytes of partial sums into t_mine (device to device), the
+    # collective runs on the two tensors, one download of t_all follows (r1cs_gg_ppzksnark_prover_hip::process_device_gather)
+    words = 4 * 18 + 36  # 4 G1 + 1 G2 Jacobian points
+    t_mine = torch.zeros(words, dtype=torch.int64, device=dev)
+    t_all = torch.zeros(world * words, dtype=torch.int64, device=dev)
+
+    @ctypes.CFUNCTYPE(None)
+    def gather_dev():
+        dist.all_gather_into_tensor(t_all, t_mine)  # RCCL (or gloo through the host: Comm)
+        torch.cuda.synchronize()
+
+    lib.zkhip_bench_set_device_gather(gather_dev, ctypes.c_void_p(t_mine.data_ptr()), ctypes.c_void_p(t_all.data_ptr()))
     times = np.zeros(steps, dtype=np.float64)
     setup = ctypes.c_double()
     verified = ctypes.c_int(-1)
@@ -586,6 +652,7 @@ def groth16_sharded_leg(np, torch, dist, rank, world, local_rank, log_constraint
                                          ctypes.c_size_t(inputs), ctypes.c_uint64(1), steps, omega.ctypes.data_as(ctypes.c_void_p),
                                          coset.ctypes.data_as(ctypes.c_void_p), times.ctypes.data_as(ctypes.c_void_p), ctypes.byref(setup),
                                          ctypes.byref(verified) if verify else None)
+    lib.zkhip_bench_set_device_gather(None, None, None)
     if rc != 0:
         # this rank left the proof loop early: its peers are inside an all-gather it will never join.  Joining a DIFFERENT collective
         # now would mismatch them until the RCCL timeout -- leave, non-zero, so that the launcher tears the job down at once.
@@ -600,7 +667,7 @@ def groth16_sharded_leg(np, torch, dist, rank, world, local_rank, log_constraint
     return {"metric": "Groth16 prove constraints/sec, BLS12-381, 2^%d constraints, ONE proof sharded over %d GPU(s)" % (log_constraints, world),
             "value": round(M / mean * 1e3, 1), "unit": "constraints/s", "scaling": "strong", "statistic": "mean of the proofs after the first",
             "ms_per_proof": [round(float(x), 2) for x in t[:-1]],
-            "domain": m, "exchange": "one RCCL all-gather of 864 B per rank per proof",
+            "domain": _last_domain(np, lib), "exchange": "one all-gather of 864 B per rank per proof, on device buffers (no host round trip before the collective)",
             "key": "valid key from a fixed trapdoor, each rank generates and holds 1/%d of every query" % world,
             "verified": None if not verify else bool(t[-1] == 0)}
 

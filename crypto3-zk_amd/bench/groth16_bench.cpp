@@ -35,6 +35,12 @@ struct SplitMix {
 // slice of every query, runs the replicated witness map and its five partial MSMs, and `all_gather` (supplied by the
 // caller: RCCL through torch.distributed in bench.py) exchanges the 864-byte partial sums.
 typedef void (*all_gather_fn)(const uint64_t *mine, size_t words, uint64_t *all);
+// the exchange on DEVICE buffers the caller owns (d_mine: this rank's 108 u64, d_all: world x 108 u64): returns when d_all is complete
+typedef void (*all_gather_dev_fn)();
+all_gather_dev_fn g_gather_dev = nullptr;
+void *g_d_mine = nullptr, *g_d_all = nullptr;
+// world > 1 without any exchange: time this rank's share only (process_partial) -- the per-rank emulation of tools/shard_emulation.py
+bool g_partial_only = false;
 // called between key generation and the timed proofs (tools/groth16_two_provers.py lines its threads up there)
 typedef void (*after_setup_fn)();
 after_setup_fn g_after_setup = nullptr;
@@ -123,7 +129,9 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
     for (int k = 0; k < steps; ++k) {
         if (k == steps - 1) zkhip_profile_enable(ctx.get(), 1);    // per-kernel HIP-event times of the last proof
         auto t1 = std::chrono::steady_clock::now();
-        proof = all_gather ? prover::process(dpk, primary, auxiliary, r, s, all_gather) : prover::process(dpk, primary, auxiliary, r, s);
+        if (g_partial_only && world > 1) (void)prover::process_partial(dpk, primary, auxiliary);
+        else if (g_gather_dev) proof = prover::process_device_gather(dpk, primary, auxiliary, r, s, g_d_mine, g_d_all, g_gather_dev);
+        else proof = all_gather ? prover::process(dpk, primary, auxiliary, r, s, all_gather) : prover::process(dpk, primary, auxiliary, r, s);
         times[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     }
     if (prof && prof_cap) zkhip_profile_dump(ctx.get(), prof, prof_cap);    // per-kernel HIP-event ms of the last proof
@@ -131,7 +139,7 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
         fprintf(stderr, "proof phases (host ms): stage+launch %.3f | host products %.3f | wait %.3f | assemble %.3f\n", dpk.last_phase_ms[0],
                 dpk.last_phase_ms[1], dpk.last_phase_ms[2], dpk.last_phase_ms[3]);
     /* the check, outside the timed region: the proof must be the one the trapdoor dictates */
-    if (verified) {
+    if (verified && !(g_partial_only && world > 1)) {
         const auto e = groth16_proof_exponents<Curve>(key->host.constraint_system, dom, primary, auxiliary, t, alpha, beta, delta, r, s);
         std::vector<Fr> one = {Fr::one()};
         const auto g1 = device_bases<Curve, ZKHIP_G1>::from_scalars(ctx, one.begin(), one.end()).at(0);    // the standard generators
@@ -152,6 +160,14 @@ void zkhip_bench_set_domain(int kind, size_t m) {
     g_dom_m = m;
 }
 void zkhip_bench_last_info(uint64_t *out) { memcpy(out, g_last_info, sizeof(g_last_info)); }
+/* the sharded proof's exchange on device buffers (see all_gather_dev_fn); fn == NULL: back to the host-buffer callback */
+void zkhip_bench_set_device_gather(all_gather_dev_fn fn, void *d_mine, void *d_all) {
+    g_gather_dev = fn;
+    g_d_mine = d_mine;
+    g_d_all = d_all;
+}
+/* on: zkhip_bench_groth16_sharded times process_partial only (no exchange, no assembly, nothing verified) */
+void zkhip_bench_set_partial_only(int on) { g_partial_only = on != 0; }
 
 int zkhip_bench_groth16(int device, int curve, size_t M, size_t n, uint64_t seed, int steps, const uint64_t *omega, const uint64_t *coset, double *times,
                         double *setup_ms, int *verified, char *prof, size_t prof_cap) {

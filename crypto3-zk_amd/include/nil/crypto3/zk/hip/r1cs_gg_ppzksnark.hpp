@@ -465,6 +465,26 @@ public:
         return assemble(pk, all, pk.shard.world, r, s, t);
     }
 
+    /// The same with the partial sums STAYING ON THE DEVICE for the exchange: `d_mine` (partial_limbs() u64) and `d_all`
+    /// (world x partial_limbs() u64) are device buffers of the caller's collective library (RCCL through torch.distributed: tensors);
+    /// this rank's sums are copied into d_mine on the device, `all_gather()` -- no arguments: the caller knows its buffers -- must
+    /// return when d_all is complete, and ONE download of d_all follows.  No host round trip before the collective.
+    template <typename AllGather>
+    static proof_type process_device_gather(const proving_key_type &pk, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input,
+                                            const scalar_value_type &r, const scalar_value_type &s, void *d_mine, void *d_all, AllGather all_gather) {
+        enqueue(pk, primary_input, auxiliary_input);
+        const host_terms t = host_products(pk, r, s);
+        if (pk.side) pk.ctx.wait_for(*pk.side);
+        check(zkhip_memcpy_d2d_async(pk.ctx.get(), d_mine, pk.d_results.get(), partial_limbs() * 8), "zkhip_memcpy_d2d_async", pk.ctx.get());
+        /* kernels flag what they cannot signal otherwise; zkhip_device_status synchronises the stream: d_mine is complete after it */
+        check(zkhip_device_status(pk.ctx.get(), nullptr), "zkhip_device_status", pk.ctx.get());
+        if (pk.side) check(zkhip_device_status(pk.side->get(), nullptr), "zkhip_device_status", pk.side->get());
+        all_gather();
+        std::vector<std::uint64_t> all(pk.shard.world * partial_limbs());
+        pk.ctx.d2h(all.data(), d_all, all.size() * 8);
+        return assemble(pk, all, pk.shard.world, r, s, t);
+    }
+
 private:
     /* What the proof needs besides the five multiexps (prover.hpp:141-155), regrouped so that everything that does not depend on
        a device result is computed while the device works:

@@ -1,0 +1,370 @@
+// TEST INFRASTRUCTURE: the host side of the header-only shim under AddressSanitizer + UBSan / ThreadSanitizer, against the
+// stub backend (stub_backend.cpp: no GPU, nothing computed).  What runs here is everything the shim does on host threads --
+// std::async conversions and uploads (backend.hpp), the prover's regrouped host products and two-thread assembly
+// (r1cs_gg_ppzksnark.hpp), the generator's thread pool and the evaluation domains' chunked Lagrange evaluation, the chunked /
+// lent uploads of the KZG and LPC schemes and the LPC leaf streaming -- and a mutation loop over proving_key_from_bytes
+// (marshalling.hpp), which parses untrusted blobs: truncations at every framing boundary, oversized and zero counts,
+// non-increasing / out-of-range B indices, random byte flips.  The parser must throw or succeed; the sanitizers decide the rest.
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <random>
+#include <string>
+#include <vector>
+
+#include <nil/crypto3/zk/hip/lpc.hpp>
+#include <nil/crypto3/zk/hip/marshalling.hpp>
+#include <nil/crypto3/zk/hip/r1cs_gg_ppzksnark_generator.hpp>
+
+using namespace nil::crypto3::zk::hip;
+
+// a curve whose scalar type is NOT declared to be canonical limbs in memory: every bulk transfer takes the converting,
+// multi-threaded path (what a crypto3-algebra adapter gets)
+struct converting_curve { };
+namespace nil { namespace crypto3 { namespace zk { namespace hip {
+template <>
+struct curve_adapter<converting_curve> : curve_adapter<bls12_381> {
+    static constexpr bool scalars_are_canonical_limbs = false;
+};
+}}}}
+
+namespace {
+int failures = 0;
+#define EXPECT(cond)                                                        \
+    do {                                                                    \
+        if (!(cond)) {                                                      \
+            fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+            ++failures;                                                     \
+        }                                                                   \
+    } while (0)
+
+template <typename Curve>
+r1cs_constraint_system<Curve> example_cs(std::size_t M, std::size_t n, std::vector<typename curve_adapter<Curve>::scalar_value_type> &full) {
+    typedef typename curve_adapter<Curve>::scalar_value_type Fr;
+    r1cs_constraint_system<Curve> cs;
+    cs.primary_input_size = n;
+    cs.auxiliary_input_size = 2 + M - n;
+    Fr a(3), b(5);
+    full = {a, b};
+    for (std::size_t i = 0; i + 1 < M; ++i) {
+        r1cs_constraint<Curve> c;
+        Fr tmp;
+        if (i % 2) {
+            c.a.add_term(i + 1, 1);
+            c.b.add_term(i + 2, 1);
+            tmp = a * b;
+        } else {
+            c.b.add_term(0, 1);
+            c.a.add_term(i + 1, 1);
+            c.a.add_term(i + 2, 1);
+            tmp = a + b;
+        }
+        c.c.add_term(i + 3, 1);
+        full.push_back(tmp);
+        a = b;
+        b = tmp;
+        cs.add_constraint(c);
+    }
+    r1cs_constraint<Curve> c;
+    Fr fin = Fr::zero();
+    for (std::size_t i = 1; i < cs.num_variables(); ++i) {
+        c.a.add_term(i, 1);
+        c.b.add_term(i, 1);
+        fin = fin + full[i - 1];
+    }
+    c.c.add_term(cs.num_variables(), 1);
+    cs.add_constraint(c);
+    full.push_back(fin * fin);
+    return cs;
+}
+
+template <typename Curve>
+void groth16_host_paths(std::size_t M) {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::scalar_value_type Fr;
+    const std::size_t n = 10;
+    std::vector<Fr> full;
+    auto cs = example_cs<Curve>(M, n, full);
+    std::vector<Fr> primary(full.begin(), full.begin() + n), auxiliary(full.begin() + n, full.end());
+    EXPECT(cs.is_satisfied(primary, auxiliary));
+    context ctx(0);
+    domain_params<Curve> dom {Fr(7), Fr(5)};    // the stub does not look at the roots
+    /* the generator: parallel_chunks over the Lagrange basis and the query scalars, five from_scalars */
+    auto key = r1cs_gg_ppzksnark_generator_hip<Curve>::deterministic_basic_process(ctx, cs, dom, Fr(1234567), Fr(11), Fr(13), Fr(17), Fr(19));
+    typedef r1cs_gg_ppzksnark_prover_hip<Curve> prover;
+    for (int rep = 0; rep < 2; ++rep) (void)prover::process(*key->device, primary, auxiliary);    // CSPRNG blinders, async host products
+    /* a host-resident key uploaded whole and in two rank slices: threaded point conversions, process_partial + finish */
+    r1cs_gg_ppzksnark_proving_key<Curve> pk;
+    pk.constraint_system = key->host.constraint_system;
+    const std::size_t N = cs.num_variables(), m = key->device->evaluation_domain.m;
+    pk.A_query.assign(N + 1, A::g1_value_type::zero());
+    pk.H_query.assign(m - 1, A::g1_value_type::zero());
+    pk.L_query.assign(N - n, A::g1_value_type::zero());
+    for (std::size_t i = 0; i <= N; i += 2) {
+        pk.B_query.indices.push_back(i);
+        pk.B_query.values.push_back({A::g2_value_type::zero(), A::g1_value_type::zero()});
+    }
+    pk.B_query.domain_size_ = N + 1;
+    r1cs_gg_ppzksnark_proving_key_hip<Curve> whole(ctx, pk, dom);
+    (void)prover::process(whole, primary, auxiliary, Fr(3), Fr(4));
+    std::vector<std::uint64_t> gathered;
+    for (std::size_t rank = 0; rank < 2; ++rank) {
+        r1cs_gg_ppzksnark_proving_key_hip<Curve> part(ctx, pk, dom, rank, 2);
+        auto mine = prover::process_partial(part, primary, auxiliary);
+        gathered.insert(gathered.end(), mine.begin(), mine.end());
+        if (rank == 1) (void)prover::finish(part, gathered, Fr(3), Fr(4));
+    }
+    /* malformed keys are refused, not read past their end */
+    auto bad = pk;
+    bad.H_query.pop_back();
+    try {
+        r1cs_gg_ppzksnark_proving_key_hip<Curve> k(ctx, bad, dom);
+        EXPECT(!"a key with a short H query must be refused");
+    } catch (const std::invalid_argument &) {
+    }
+    bad = pk;
+    std::swap(bad.B_query.indices[1], bad.B_query.indices[2]);
+    try {
+        r1cs_gg_ppzksnark_proving_key_hip<Curve> k(ctx, bad, dom);
+        EXPECT(!"non-increasing B indices must be refused");
+    } catch (const std::invalid_argument &) {
+    }
+}
+
+struct any_transcript {
+    template <typename T>
+    void operator()(const T &) { }
+    fr_value<ZKHIP_BLS12_381> challenge() { return fr_value<ZKHIP_BLS12_381>(c++); }
+    std::uint64_t c = 12345;
+};
+struct toy_tree {
+    std::uint64_t r = 0;
+    std::uint64_t root() const { return r; }
+};
+template <typename Fr>
+struct vec_builder {
+    toy_tree operator()(const std::vector<Fr> &leaves, std::size_t) const {
+        toy_tree t;
+        for (const auto &v : leaves) t.r ^= v.limbs[0];
+        return t;
+    }
+};
+template <typename Fr>
+struct span_builder {
+    toy_tree operator()(const Fr *leaves, std::size_t count, std::size_t) const {
+        toy_tree t;
+        for (std::size_t i = 0; i < count; ++i) t.r ^= leaves[i].limbs[0];
+        return t;
+    }
+};
+template <typename Fr>
+struct stream_builder {
+    toy_tree t;
+    void begin(std::size_t, std::size_t) { t = toy_tree(); }
+    void absorb(const Fr *leaves, std::size_t, std::size_t count) {
+        for (std::size_t i = 0; i < count; ++i) t.r ^= leaves[i].limbs[0];
+    }
+    toy_tree finish() { return t; }
+};
+
+template <typename Curve>
+void scheme_host_paths() {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::scalar_value_type Fr;
+    context ctx(0);
+    auto root = [](std::size_t l) { return Fr((std::uint64_t)(l + 2)); };
+    std::vector<polynomial_dfs<Curve>> polys(7);
+    for (std::size_t p = 0; p < polys.size(); ++p) {
+        polys[p].values.resize(p < 5 ? 256 : 512);
+        for (std::size_t i = 0; i < polys[p].values.size(); ++i) polys[p].values[i] = Fr((std::uint64_t)(i * 7 + p));
+    }
+    {   /* KZG v2 and v1: copied, handed over, lent; chunked upload on the second context */
+        std::vector<typename A::g1_value_type> ck(600, A::g1_value_type::zero());
+        std::vector<typename A::g2_value_type> vk(4, A::g2_value_type::zero());
+        kzg_params_hip<Curve> params(ctx, ck.begin(), ck.end(), vk.begin(), vk.end());
+        kzg_commitment_scheme_v2_hip<Curve, any_transcript> v2(params, root);
+        v2.upload_chunk = 2;
+        v2.append_to_batch(0, polys[0]);
+        v2.append_to_batch(0, std::vector<polynomial_dfs<Curve>>(polys.begin() + 1, polys.begin() + 3));
+        std::vector<std::reference_wrapper<const polynomial_dfs<Curve>>> lent(polys.begin() + 3, polys.end());
+        v2.append_to_batch(0, lent);
+        auto moved = polys[0];
+        v2.append_to_batch(0, std::move(moved));
+        EXPECT(v2.commit(0).size() == 8);
+        v2.append_eval_point(0, Fr(77));
+        v2.append_eval_point(0, 2, Fr(78));
+        any_transcript tr;
+        (void)v2.proof_eval(tr);
+        kzg_commitment_scheme_hip<Curve, any_transcript> v1(params, root);
+        v1.append_to_batch(3, lent);
+        (void)v1.commit(3);
+        v1.append_eval_point(3, Fr(5));
+        v1.append_eval_point(3, 1, Fr(6));
+        (void)v1.proof_eval(tr);
+        (void)v1.commit_g2({Fr(1), Fr(2), Fr(3)});
+        (void)commit_one<Curve>(params, std::vector<Fr> {Fr(1), Fr(2)});
+    }
+    fri_params_hip<Curve> fp;
+    fp.log_domain = 10;
+    fp.step_list = {1, 2, 1};
+    fp.root_of_unity = root;
+    auto run_lpc = [&](auto builder) {
+        lpc_commitment_scheme_hip<Curve, any_transcript, decltype(builder)> s(ctx, fp, builder);
+        s.upload_chunk = 2;
+        s.leaf_slice_elements = 700;    // several slices, rounded up to whole leaves
+        std::vector<std::reference_wrapper<const polynomial_dfs<Curve>>> lent(polys.begin(), polys.end());
+        s.append_to_batch(0, lent);
+        (void)s.commit(0);
+        s.append_to_batch(1, polys[5]);
+        (void)s.commit(1);
+        s.append_eval_point(0, Fr(9));
+        s.append_eval_point(1, Fr(9));
+        any_transcript tr;
+        auto proof = s.proof_eval(tr);
+        EXPECT(proof.fri_proof.fri_roots.size() == 3);
+        (void)s.coefficients(0, 1);
+        (void)s.fri_round_polynomial(0);
+    };
+    run_lpc(vec_builder<Fr>());
+    run_lpc(span_builder<Fr>());
+    run_lpc(stream_builder<Fr>());
+}
+
+template <typename Curve>
+void bulk_transfers() {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::scalar_value_type Fr;
+    context ctx(0);
+    const std::size_t count = ((std::size_t)1 << 18) * 2 + 1000;    // several staging slices per thread
+    std::vector<Fr> v(count);
+    for (std::size_t i = 0; i < count; ++i) v[i] = Fr((std::uint64_t)i);
+    auto d = ctx.alloc(count * 32);
+    upload_scalars<A>(ctx, d.get(), v.data(), count);
+    std::vector<Fr> back;
+    download_scalars<A>(ctx, d.get(), count, back);
+    EXPECT(back.size() == count && back[12345] == v[12345] && back[count - 1] == v[count - 1]);
+    std::vector<typename A::g1_value_type> pts(((std::size_t)1 << 14) + 77, A::g1_value_type::zero());
+    device_bases<Curve, ZKHIP_G1> b(ctx, pts.begin(), pts.end());
+    EXPECT(b.size() == pts.size());
+}
+
+// ---- the parser fuzz ---------------------------------------------------------------------------------------------------
+struct blob_writer {
+    std::vector<std::uint8_t> b;
+    std::vector<std::size_t> count_fields;    // offsets of every u32 count / length / index field
+    void u32(std::size_t v) {
+        count_fields.push_back(b.size());
+        for (int s = 24; s >= 0; s -= 8) b.push_back((std::uint8_t)(v >> s));
+    }
+    void bytes(std::size_t n, std::uint8_t fill) { b.insert(b.end(), n, fill); }
+    void patch(std::size_t at, std::size_t v) {
+        for (int i = 0; i < 4; ++i) b[at + i] = (std::uint8_t)(v >> (24 - 8 * i));
+    }
+};
+/// a syntactically valid key blob for a tiny instance (the stub does not decode points: the framing is what is under test)
+blob_writer valid_blob(std::size_t M, std::size_t n) {
+    const std::size_t N = M + 2;
+    int kind = 0;
+    std::size_t m = 0;
+    zkhip_domain_choice(ZKHIP_BLS12_381, M + n + 1, &kind, &m);
+    blob_writer w;
+    w.bytes(48, 0xc0), w.bytes(48, 0xc0), w.bytes(96, 0xc0), w.bytes(48, 0xc0), w.bytes(96, 0xc0);
+    w.u32(N + 1);
+    w.bytes((N + 1) * 48, 0xc0);
+    {
+        blob_writer body;
+        const std::size_t cnt = N / 2;
+        body.u32(cnt);
+        for (std::size_t i = 0; i < cnt; ++i) body.u32(2 * i);
+        body.bytes(cnt * (96 + 48), 0xc0);
+        body.u32(N + 1);
+        w.u32(body.b.size());
+        const std::size_t base = w.b.size();
+        for (std::size_t f : body.count_fields) w.count_fields.push_back(base + f);
+        w.b.insert(w.b.end(), body.b.begin(), body.b.end());
+    }
+    w.u32(m - 1);
+    w.bytes((m - 1) * 48, 0xc0);
+    w.u32(N - n);
+    w.bytes((N - n) * 48, 0xc0);
+    w.u32(n), w.u32(N - n), w.u32(M);
+    for (std::size_t i = 0; i < M; ++i) {
+        blob_writer c;
+        for (int k = 0; k < 3; ++k) {
+            c.u32(1);
+            c.u32(k == 2 ? N : (i % N) + 1);
+            c.bytes(32, 1);
+        }
+        w.u32(c.b.size());
+        const std::size_t base = w.b.size();
+        for (std::size_t f : c.count_fields) w.count_fields.push_back(base + f);
+        w.b.insert(w.b.end(), c.b.begin(), c.b.end());
+    }
+    return w;
+}
+
+void parser_fuzz() {
+    typedef bls12_381 C;
+    typedef curve_adapter<C>::scalar_value_type Fr;
+    context ctx(0);
+    domain_params<C> dom {Fr(7), Fr(5)};
+    std::size_t accepted = 0, refused = 0;
+    auto attempt = [&](const std::vector<std::uint8_t> &b) {
+        try {
+            auto key = proving_key_from_bytes<C>(ctx, b.data(), b.size(), dom);
+            ++accepted;
+            /* whatever was accepted must also be PROVABLE-WITH without touching memory it does not own */
+            const auto &cs = key->host.constraint_system;
+            if (cs.num_variables() < 4096) {
+                std::vector<Fr> primary(cs.num_inputs(), Fr(1)), auxiliary(cs.num_variables() - cs.num_inputs(), Fr(2));
+                (void)r1cs_gg_ppzksnark_prover_hip<C>::process(*key->device, primary, auxiliary, Fr(3), Fr(4));
+            }
+        } catch (const std::exception &) {
+            ++refused;
+        }
+    };
+    const blob_writer good = valid_blob(20, 3);
+    attempt(good.b);
+    EXPECT(accepted == 1);    // the unmutated blob parses
+    /* truncations: every length around every framing boundary, and a stride through the rest */
+    for (std::size_t f : good.count_fields)
+        for (std::size_t cut : {f, f + 1, f + 3, f + 4, f + 5}) attempt(std::vector<std::uint8_t>(good.b.begin(), good.b.begin() + std::min(cut, good.b.size())));
+    for (std::size_t cut = 0; cut < good.b.size(); cut += 37) attempt(std::vector<std::uint8_t>(good.b.begin(), good.b.begin() + cut));
+    attempt({});
+    /* every count / length / index field: zero, off by one, huge, all ones */
+    for (std::size_t f : good.count_fields) {
+        const std::size_t old = ((std::size_t)good.b[f] << 24) | ((std::size_t)good.b[f + 1] << 16) | ((std::size_t)good.b[f + 2] << 8) | good.b[f + 3];
+        for (std::size_t v : {(std::size_t)0, old + 1, old ? old - 1 : 0, (std::size_t)0x7fffffff, (std::size_t)0xffffffff, (std::size_t)0x01000000}) {
+            blob_writer w = good;
+            w.patch(f, v);
+            attempt(w.b);
+        }
+    }
+    /* random byte flips */
+    std::mt19937_64 rng(20260103);
+    for (int it = 0; it < 600; ++it) {
+        std::vector<std::uint8_t> b = good.b;
+        const int flips = 1 + (int)(rng() % 4);
+        for (int k = 0; k < flips; ++k) b[rng() % b.size()] ^= (std::uint8_t)(1u << (rng() % 8));
+        attempt(b);
+    }
+    fprintf(stderr, "parser fuzz: %zu blobs accepted, %zu refused\n", accepted, refused);
+    EXPECT(refused > 100);
+}
+}    // namespace
+
+int main(int argc, char **argv) {
+    const std::string what = argc > 1 ? argv[1] : "all";
+    if (what == "all" || what == "threads") {
+        groth16_host_paths<bls12_381>((1 << 14) + 5);    // past the thresholds where the shim spreads work over threads
+        groth16_host_paths<converting_curve>(300);       // the staging path of the assignment, converting transfers
+        groth16_host_paths<alt_bn128_254>(64);
+        scheme_host_paths<bls12_381>();
+        scheme_host_paths<converting_curve>();
+        bulk_transfers<converting_curve>();
+        bulk_transfers<bls12_381>();
+    }
+    if (what == "all" || what == "fuzz") parser_fuzz();
+    fprintf(stderr, failures ? "sanitize_main: %d FAILED expectation(s)\n" : "sanitize_main: ok\n", failures);
+    return failures ? 1 : 0;
+}

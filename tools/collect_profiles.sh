@@ -22,6 +22,7 @@ PMC_GROUPS="GRBM_GUI_ACTIVE;SQ_BUSY_CYCLES SQ_WAVES" tools/pmc_collect.sh gpurun
 tools/pmc_collect.sh gpurun_out/${R}_pmc_g2_msm.json tools/msm_g2_once.py > /dev/null 2>&1
 python3 tools/msm_sweep.py 2>/dev/null | tail -1 > gpurun_out/${R}_msm_size_sweep.json
 python3 tools/shard_emulation.py 20 2>/dev/null | tail -1 > gpurun_out/${R}_shard_emulation.json
+python3 tools/shard_emulation.py --proof 20 2>/dev/null | tail -1 > gpurun_out/${R}_shard_emulation_proof.json
 python3 tools/bench_groth16.py --steps 6 2>/dev/null | tail -1 > gpurun_out/${R}_groth16_2p20_shim.json
 python3 tools/bench_groth16.py --steps 6 --domain basic 2>/dev/null | tail -1 > gpurun_out/${R}_groth16_2p20_basic_domain_shim.json
 ./tools/kzg_shim_bench 20 50 10 > gpurun_out/${R}_kzg_shim_bench.txt 2>&1
