@@ -102,6 +102,7 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
     std::vector<Fr> primary(full.begin(), full.begin() + n), auxiliary(full.begin() + n, full.end());
 
     context ctx(device);
+    if (const char *e = getenv("ZKHIP_G16_MAIN_PRIORITY")) ctx.set_option("stream_priority", atoi(e));    // experiments
     domain_params<Curve> dom {A::scalar_from_limbs(omega), A::scalar_from_limbs(coset)};
     dom.kind = g_dom_kind;
     dom.m = g_dom_m;
@@ -120,6 +121,8 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
         memcpy(g_last_info, info, sizeof(info));
     }
     if (const char *e = getenv("ZKHIP_G16_OVERLAP")) dpk.overlap_g2 = atoi(e) != 0;    // experiments: G2 multiexp on the main stream
+    if (const char *e = getenv("ZKHIP_G16_SIDE_PRIORITY")) dpk.side_stream_priority = atoi(e);
+    if (const char *e = getenv("ZKHIP_G16_SKIP_G2")) dpk.experiment_skip_g2 = atoi(e) != 0;    // ceiling experiment: the proof is then WRONG
     ctx.sync();
     *setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (g_after_setup) g_after_setup();

@@ -106,6 +106,7 @@ struct zkhip_ctx {
     int opt_ntt_pair = 1;  // log2 of the polynomials of a batch one NTT workgroup carries (1: pairs share indices, twiddles, factor-table reads)
     int opt_msm_precompute = 1;       // build window tables at upload for bases of >= opt_msm_precompute_min points
     int opt_msm_shard_rank = 0, opt_msm_shard_world = 1;  // window partition applied to bases uploaded from now on
+    int opt_stream_priority = 0;      // < 0: the own stream was recreated with the highest priority, > 0: the lowest
     int opt_msm_precompute_min = 32;  // without tables the windows are combined by a serial Horner pass (~255 doublings on one lane: 3.8 ms)
     ZkProfile prof;
     std::vector<NttTables *> ntt_tables;

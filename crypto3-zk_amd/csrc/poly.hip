@@ -327,6 +327,7 @@ int zkhip_poly_resize_dev(zkhip_ctx *ctx, int curve, void *d_in, size_t log_n, s
     ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (log_out < log_n) {  // smaller domain: every 2^(log_n - log_out)-th evaluation (the caller vouches for degree < 2^log_out); d_in is left as it is
         const size_t tot = batch << log_out;
+        if (batch >= ((size_t)1 << 31) || tot >= ((size_t)1 << 39)) return ZKHIP_ERR_RANGE;  // (tot + 255) / 256 workgroups < 2^31
         ZK_LAUNCH(ctx, "poly_subsample", poly_subsample, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (const uint4 *)d_in, (uint32_t)log_n,
                   (uint32_t)log_out, tot, (uint4 *)d_out);
         return ZKHIP_OK;
@@ -386,7 +387,7 @@ int zkhip_fr_vec_op_dev(zkhip_ctx *ctx, int curve, int op, const void *d_a, cons
 int zkhip_fr_vec_prod_dev(zkhip_ctx *ctx, int curve, size_t count, const void *const *d_in, void *d_out, size_t n) {
     if (!ctx || !d_in || count == 0 || (n && !d_out)) return ZKHIP_ERR_INVALID;
     if (curve != CURVE_BLS12_381 && curve != CURVE_BN254) return ZKHIP_ERR_INVALID;
-    if (count >= 65536) return ZKHIP_ERR_RANGE;
+    if (count >= 65536 || n >= ((size_t)1 << 39)) return ZKHIP_ERR_RANGE;  // (n + 255) / 256 workgroups < 2^31
     for (size_t k = 0; k < count; ++k)
         if (n && !d_in[k]) return ZKHIP_ERR_INVALID;
     if (n == 0) return ZKHIP_OK;
@@ -403,7 +404,7 @@ int zkhip_fr_vec_prod_dev(zkhip_ctx *ctx, int curve, size_t count, const void *c
 
 int zkhip_poly_shift_dev(zkhip_ctx *ctx, const void *d_in, size_t log_size, int64_t rotation, void *d_out) {
     if (!ctx || !d_in || !d_out || d_in == d_out) return ZKHIP_ERR_INVALID;
-    if (log_size > 40) return ZKHIP_ERR_RANGE;
+    if (log_size > 31) return ZKHIP_ERR_RANGE;  // one lane per element: (n + 255) / 256 workgroups must fit the 2^31 grid limit
     ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)1 << log_size;
     const int64_t m = (int64_t)n;

@@ -139,6 +139,41 @@ int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value) {
         ctx->opt_msm_shard_rank = (int)value;
     }
     else if (n == "msm_graphs") ctx->opt_msm_graphs = (int)value;
+    else if (n == "stream_priority") {
+        // the context's OWN stream is recreated with a scheduling priority: < 0 the highest the device offers, > 0 the lowest, 0 the
+        // default.  Two contexts on one GPU (the Groth16 shim's main and G2 streams) can so decide whose workgroups go first.
+        if (!ctx->own_stream) return ZKHIP_ERR_INVALID;
+        ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+        int least = 0, greatest = 0;
+        ZK_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        hipStream_t s = nullptr;
+        ZK_HIP_CHECK(ctx, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, value < 0 ? greatest : (value > 0 ? least : 0)));
+        (void)hipStreamDestroy(ctx->stream);
+        ctx->stream = s;
+        ctx->opt_stream_priority = (int)value;
+        zk_graphs_clear(ctx);
+    }
+    else return ZKHIP_ERR_INVALID;
+    return ZKHIP_OK;
+}
+
+int zkhip_get_option(const zkhip_ctx *ctx, const char *name, int64_t *value) {
+    if (!ctx || !name || !value) return ZKHIP_ERR_INVALID;
+    std::string n(name);
+    if (n == "msm_window_bits") *value = ctx->opt_msm_window_bits;
+    else if (n == "msm_segment_log") *value = ctx->opt_msm_segment_log;
+    else if (n == "msm_sets") *value = ctx->opt_msm_sets;
+    else if (n == "msm_sort_tile_log") *value = ctx->opt_msm_sort_tile_log;
+    else if (n == "ntt_radix_log") *value = ctx->opt_ntt_radix_log;
+    else if (n == "ntt_tile_log") *value = ctx->opt_ntt_tile_log;
+    else if (n == "ntt_pair") *value = ctx->opt_ntt_pair;
+    else if (n == "msm_precompute") *value = ctx->opt_msm_precompute;
+    else if (n == "msm_precompute_min") *value = ctx->opt_msm_precompute_min;
+    else if (n == "msm_shard_world") *value = ctx->opt_msm_shard_world;
+    else if (n == "msm_shard_rank") *value = ctx->opt_msm_shard_rank;
+    else if (n == "msm_graphs") *value = ctx->opt_msm_graphs;
+    else if (n == "stream_priority") *value = ctx->opt_stream_priority;
     else return ZKHIP_ERR_INVALID;
     return ZKHIP_OK;
 }

@@ -67,6 +67,11 @@ public:
     void wait_for(const context &other) const { check(zkhip_stream_wait(ctx_, other.ctx_), "zkhip_stream_wait", ctx_); }
     void sync() const { check(zkhip_sync(ctx_), "zkhip_sync", ctx_); }
     void set_option(const char *name, std::int64_t value) const { check(zkhip_set_option(ctx_, name, value), "zkhip_set_option", ctx_); }
+    std::int64_t get_option(const char *name) const {
+        std::int64_t v = 0;
+        check(zkhip_get_option(ctx_, name, &v), "zkhip_get_option", ctx_);
+        return v;
+    }
 
     /// device buffer of `bytes` bytes, freed with the returned handle
     std::shared_ptr<void> alloc(std::size_t bytes) const {

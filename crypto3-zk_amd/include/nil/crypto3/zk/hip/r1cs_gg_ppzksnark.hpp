@@ -303,12 +303,16 @@ public:
     mutable std::shared_ptr<void> h_cpa;    // page-locked staging for (1, x, w): H2D at link speed, asynchronous
     /// second in-order stream on the same GPU for the G2 multiexp (its own workspace); false: everything on `ctx`
     bool overlap_g2 = true;
+    /// scheduling priority of that second stream (< 0: above, > 0: below the main stream's; "stream_priority" in include/zkhip.h)
+    bool experiment_skip_g2 = false;    // timing experiments only: see enqueue()
+    int side_stream_priority = 1;    // measured: 22.7 -> 22.4 ms per 2^20 proof with the G2 stream below the main one (tools/exp_stream_priority.sh)
     /// send the auxiliary input as it lies in the caller's vector (possible when the scalar type is canonical limbs in memory);
     /// false: through the page-locked staging buffer, converted by host threads (any scalar representation)
     bool direct_assignment_upload = detail::canonical_scalars<curve_adapter<CurveType>>::value;
     /// host wall time of the last proof's phases, ms: staging + launches | host products (device busy) | waiting for the device | assembly
     mutable double last_phase_ms[4] = {0, 0, 0, 0};
     mutable std::unique_ptr<context> side;
+    mutable std::int64_t saved_sort_tile_log = 14;    // the caller's "msm_sort_tile_log", set aside for the duration of a proof
     void reserve_work(std::size_t cpa_elems, std::size_t degree, std::size_t result_bytes) const {
         if (d_cpa && work_cpa_ >= cpa_elems) return;
         d_cpa = ctx.alloc(cpa_elems * 32);
@@ -324,10 +328,11 @@ public:
         d_results = ctx.alloc(result_bytes);
         if (overlap_g2 && !side && B_count >= ((std::size_t)1 << 14)) {    // pays off for large queries only
             side.reset(new context(ctx.device()));
-            /* two streams share the GPU from here on: sort tiles small enough to sit next to the other stream's resident
-               accumulation workgroups (see "msm_sort_tile_log" in include/zkhip.h) */
-            ctx.set_option("msm_sort_tile_log", 12);
+            /* while two streams share the GPU the sorts use tiles small enough to sit next to the other stream's resident accumulation
+               workgroups ("msm_sort_tile_log" in include/zkhip.h): set on the side context for good, on the CALLER's context only for
+               the duration of a proof (sort_tiles_scope in enqueue / collect) */
             side->set_option("msm_sort_tile_log", 12);
+            if (side_stream_priority != 0) side->set_option("stream_priority", side_stream_priority);
         }
         work_cpa_ = cpa_elems;
     }
@@ -418,12 +423,14 @@ public:
         if (pk.shard.world != 1) throw std::runtime_error("process: sharded key -- use process_partial / finish (or the all-gather overload)");
         typedef std::chrono::steady_clock clock;
         const auto t0 = clock::now();
+        drain_on_unwind guard {pk};
         enqueue(pk, primary_input, auxiliary_input);
         const auto t1 = clock::now();
         /* host products that do not depend on the MSM results, computed while the GPU works (prover.hpp:142-155) */
         const host_terms t = host_products(pk, r, s);
         const auto t2 = clock::now();
         const std::vector<std::uint64_t> sums = collect(pk);    // the one synchronisation of the proof
+        guard.armed = false;
         const auto t3 = clock::now();
         proof_type proof = assemble(pk, sums, 1, r, s, t);
         const clock::time_point marks[5] = {t0, t1, t2, t3, clock::now()};
@@ -443,8 +450,11 @@ public:
     /// this rank's partial sums (synchronises)
     static std::vector<std::uint64_t> process_partial(const proving_key_type &pk, const primary_input_type &primary_input,
                                                       const auxiliary_input_type &auxiliary_input) {
+        drain_on_unwind guard {pk};
         enqueue(pk, primary_input, auxiliary_input);
-        return collect(pk);
+        std::vector<std::uint64_t> sums = collect(pk);
+        guard.armed = false;
+        return sums;
     }
     /// `gathered`: world x partial_limbs() words, rank-major (what an all-gather of process_partial's result yields)
     static proof_type finish(const proving_key_type &pk, const std::vector<std::uint64_t> &gathered, const scalar_value_type &r,
@@ -457,9 +467,11 @@ public:
     template <typename AllGather>
     static proof_type process(const proving_key_type &pk, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input,
                               const scalar_value_type &r, const scalar_value_type &s, AllGather all_gather) {
+        drain_on_unwind guard {pk};
         enqueue(pk, primary_input, auxiliary_input);
         const host_terms t = host_products(pk, r, s);
         const std::vector<std::uint64_t> mine = collect(pk);
+        guard.armed = false;
         std::vector<std::uint64_t> all(pk.shard.world * partial_limbs());
         all_gather(mine.data(), mine.size(), all.data());
         return assemble(pk, all, pk.shard.world, r, s, t);
@@ -472,13 +484,18 @@ public:
     template <typename AllGather>
     static proof_type process_device_gather(const proving_key_type &pk, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input,
                                             const scalar_value_type &r, const scalar_value_type &s, void *d_mine, void *d_all, AllGather all_gather) {
+        drain_on_unwind guard {pk};
         enqueue(pk, primary_input, auxiliary_input);
         const host_terms t = host_products(pk, r, s);
-        if (pk.side) pk.ctx.wait_for(*pk.side);
+        if (pk.side) {
+            pk.ctx.wait_for(*pk.side);
+            pk.ctx.set_option("msm_sort_tile_log", pk.saved_sort_tile_log);
+        }
         check(zkhip_memcpy_d2d_async(pk.ctx.get(), d_mine, pk.d_results.get(), partial_limbs() * 8), "zkhip_memcpy_d2d_async", pk.ctx.get());
         /* kernels flag what they cannot signal otherwise; zkhip_device_status synchronises the stream: d_mine is complete after it */
         check(zkhip_device_status(pk.ctx.get(), nullptr), "zkhip_device_status", pk.ctx.get());
         if (pk.side) check(zkhip_device_status(pk.side->get(), nullptr), "zkhip_device_status", pk.side->get());
+        guard.armed = false;    // both streams have drained
         all_gather();
         std::vector<std::uint64_t> all(pk.shard.world * partial_limbs());
         pk.ctx.d2h(all.data(), d_all, all.size() * 8);
@@ -493,6 +510,24 @@ private:
              = Ht + Lt + s At + r Bt_h + [s alpha + r beta_g1 + r s delta]
        -- the bracket and r delta, s delta_g2 are `host_terms`; s At and r Bt_h are the two products left for after the results
        arrive (`assemble` runs them on two threads). */
+    /// enqueue() leaves asynchronous copies out of the CALLER's vectors (and kernels over the key's buffers) in flight; if anything
+    /// throws before collect() has drained them -- a failed check, std::async out of threads -- the stack must not unwind under
+    /// that DMA: the guard waits for both streams (and gives the caller's context its sort-tile setting back) on the way out.
+    struct drain_on_unwind {
+        const proving_key_type &pk;
+        bool armed = true;
+        ~drain_on_unwind() {
+            if (!armed) return;
+            try {
+                pk.ctx.sync();
+                if (pk.side) {
+                    pk.side->sync();
+                    pk.ctx.set_option("msm_sort_tile_log", pk.saved_sort_tile_log);
+                }
+            } catch (...) {
+            }
+        }
+    };
     struct host_terms {
         typename adapter::g1_value_type r_delta, c_base;
         typename adapter::g2_value_type s_delta2;
@@ -517,6 +552,10 @@ private:
            buffers live in the key object (allocated on first use) so a proof costs no hipMalloc. */
         const std::size_t jl1 = 3 * adapter::g1_coord_limbs;
         pk.reserve_work(num_variables + 1, degree, partial_limbs() * 8);
+        if (pk.side) {    // for this proof only: collect() gives the caller's context its own setting back
+            pk.saved_sort_tile_log = ctx.get_option("msm_sort_tile_log");
+            ctx.set_option("msm_sort_tile_log", 12);
+        }
         char *cpa = static_cast<char *>(pk.d_cpa.get());
         std::uint64_t *d_res = static_cast<std::uint64_t *>(pk.d_results.get());
 
@@ -531,6 +570,7 @@ private:
         if (detail::canonical_scalars<adapter>::value && pk.direct_assignment_upload) {
             /* scalar values that ARE canonical limbs in memory: the auxiliary input goes out as it lies (0.3 ms per 2^20-constraint
                proof less than through the staging buffer) */
+            static_assert(!detail::canonical_scalars<adapter>::value || sizeof(scalar_value_type) == 32, "canonical-limb scalars are 4 x u64");
             check(zkhip_memcpy_h2d_async(ctx.get(), cpa, z, 32 * (1 + num_inputs)), "zkhip_memcpy_h2d_async", ctx.get());
             if (!auxiliary_input.empty())
                 check(zkhip_memcpy_h2d_async(ctx.get(), cpa + 32 * (1 + num_inputs), auxiliary_input.data(), 32 * auxiliary_input.size()),
@@ -562,7 +602,10 @@ private:
         /* evaluation_Bt: kc_multiexp_with_mixed_addition over the sparse (G2, G1) query (prover.hpp:116-123); a sharded key
            holds a slice of the index list */
         check(zkhip_fr_gather_dev(ctx.get(), cpa, num_variables + 1, pk.d_B_indices.get(), pk.B_count, pk.d_bs.get()), "zkhip_fr_gather_dev", ctx.get());
-        if (pk.side) {
+        if (pk.experiment_skip_g2) {
+            /* EXPERIMENT ONLY (wrong proof): what a proof would cost if the G2 multiexp were free -- the ceiling of anything that could be
+               gained on the second stream */
+        } else if (pk.side) {
             /* the G2 part on the second stream, after the gather; the four G1 multiexps below do not depend on it */
             pk.side->wait_for(ctx);
             check(zkhip_msm_dev(pk.side->get(), pk.B_query_g.get(), 0, pk.B_count, pk.d_bs.get(), d_res + 4 * jl1), "zkhip_msm_dev(B.g)", pk.side->get());
@@ -584,7 +627,10 @@ private:
     /// the five partial sums of this rank, after the stream has drained
     static std::vector<std::uint64_t> collect(const proving_key_type &pk) {
         std::vector<std::uint64_t> res(partial_limbs());
-        if (pk.side) pk.ctx.wait_for(*pk.side);
+        if (pk.side) {
+            pk.ctx.wait_for(*pk.side);
+            pk.ctx.set_option("msm_sort_tile_log", pk.saved_sort_tile_log);    // the caller's context gets its own sort tiles back
+        }
         pk.ctx.d2h(res.data(), pk.d_results.get(), res.size() * 8);
         /* kernels flag what they cannot signal otherwise (a B-query index beyond the assignment, a plan overflow) */
         check(zkhip_device_status(pk.ctx.get(), nullptr), "zkhip_device_status", pk.ctx.get());

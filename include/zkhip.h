@@ -68,6 +68,9 @@ int zkhip_device_status(zkhip_ctx *ctx, uint32_t *flags /* nullable */);
  * partition over GPUs: bases uploaded from now on hold the tables of windows {w : w mod world == rank} only, and an MSM over them
  * yields the partial sum of those windows). */
 int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value);
+/* "stream_priority" (value < 0: highest, > 0: lowest, 0: default) recreates the context's own stream with that scheduling priority:
+ * of two contexts on one GPU the higher one's workgroups are dispatched first (set it before any work is enqueued). */
+int zkhip_get_option(const zkhip_ctx *ctx, const char *name, int64_t *value);
 
 /* ---- device memory (plumbing for callers that keep vectors resident) -------------------------- */
 int zkhip_malloc(zkhip_ctx *ctx, size_t bytes, void **dptr);
