@@ -19,6 +19,7 @@
 #include <stdexcept>
 #include <vector>
 
+#include "scoped_profiler.hpp"
 #include "kzg.hpp"
 
 namespace nil {
@@ -191,6 +192,7 @@ std::vector<typename curve_adapter<CurveType>::scalar_value_type>
     precommit_leaves(const context &ctx, const std::vector<polynomial_dfs<CurveType>> &polys, std::size_t log_domain, std::size_t fri_step,
                      const typename device_polynomial_dfs<CurveType>::root_of_unity_type &root) {
     typedef curve_adapter<CurveType> adapter;
+    ZKHIP_PROFILE_SCOPE("Basic FRI Precommit time");    // basic_fri.hpp:449
     const std::size_t D = (std::size_t)1 << log_domain, batch = polys.size();
     std::vector<typename adapter::scalar_value_type> out;
     if (batch == 0) return out;

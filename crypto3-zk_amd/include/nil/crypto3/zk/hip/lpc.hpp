@@ -182,6 +182,7 @@ public:
 
     /// commit(index) (lpc.hpp:101-106): precommit<FRI>(polys, D[0], step_list.front()) -> the tree's root
     commitment_type commit(std::size_t index) {
+        ZKHIP_PROFILE_SCOPE("Basic FRI Precommit time");    // commit = precommit<FRI> + root (lpc.hpp:101-106; the scope of basic_fri.hpp:449)
         const std::vector<const poly_type *> &polys = _polys[index];
         _locked[index] = true;    // state_commited (batched_commitment.hpp:163-166)
         _points[index].resize(polys.size());
@@ -317,7 +318,10 @@ public:
             adapter::scalar_to_limbs(_fri_params.root_of_unity(_fri_params.log_domain), w);
             check(zkhip_ntt_dev(_ctx.get(), adapter::id, f.data(), _fri_params.log_domain, 1, w, 0, nullptr), "zkhip_ntt_dev", _ctx.get());
         }
-        precommitment_type precommitment = build_tree(f.data(), 1, _fri_params.log_domain, _fri_params.step_list.front());
+        precommitment_type precommitment = [&]() {
+            ZKHIP_PROFILE_SCOPE("Basic FRI Precommit time");    // precommit(combined_Q, ...), lpc.hpp:196-198
+            return build_tree(f.data(), 1, _fri_params.log_domain, _fri_params.step_list.front());
+        }();
 
         /* Commit phase (basic_fri.hpp:705-742) */
         proof_type proof;

@@ -29,6 +29,10 @@ def test_host_shim_under_asan_ubsan(what):
     assert "AddressSanitizer" not in log and "runtime error" not in log and "LeakSanitizer" not in log, log[-4000:]
     if what == "fuzz":
         assert "blobs accepted" in log
+    else:
+        # the driver is built with ZK_PLACEHOLDER_PROFILING_ENABLED: the one reference profiler region that lies inside replaced code
+        # (basic_fri.hpp:449) reports under the reference's name and format
+        assert "Basic FRI Precommit time: " in log and " ms" in log
 
 
 def test_host_shim_under_tsan():
