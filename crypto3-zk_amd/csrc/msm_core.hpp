@@ -56,6 +56,7 @@
 #include "msm_recode.hpp"
 #include "msm_bucket_acc.hpp"
 #include "fu_pair.hpp"
+#include "fu_quad.hpp"
 
 namespace {
 
@@ -895,6 +896,9 @@ int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
     const uint32_t L = msm_tail_segment(ctx, B, Sr, TLPB, G2);  // buckets per tail segment
     const uint32_t tail_slots = MSM_TAIL_THREADS / TLPB;  // points per tail workgroup
     const uint32_t nseg = B / L, nblk_tail = (nseg + tail_slots - 1) / tail_slots;
+    // the quad variant of the tail (below) may cut the set into more workgroups: the partial-sum buffer holds either
+    const uint32_t Lq_cap = msm_tail_segment(ctx, B, Sr, QuadLane<F>::LANES, G2);
+    const uint32_t nblk_cap = std::max(nblk_tail, (B / Lq_cap + MSM_TAIL_THREADS / QuadLane<F>::LANES - 1) / (MSM_TAIL_THREADS / QuadLane<F>::LANES));
     // two-level LDS counting sort (see msm_sort_*): the low bits inside a super-bucket, the rest across super-buckets
     SortGeom g;
     g.n = (uint32_t)n;
@@ -928,7 +932,7 @@ int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
     need += zkhip_ctx::ws_round((size_t)nb * 4 * NL * 4);  // buckets
     const uint32_t sblk = (nb + 1023) / 1024, nsh = SIZE_BINS * sblk, sblk2 = (nsh + 1023) / 1024;
     need += 2 * zkhip_ctx::ws_round(((size_t)nsh + 1) * 4) + zkhip_ctx::ws_round((size_t)sblk2 * 4) + zkhip_ctx::ws_round((size_t)nb * 4);  // size sort
-    need += zkhip_ctx::ws_round((size_t)Sr * nblk_tail * 4 * NL * 4);
+    need += zkhip_ctx::ws_round((size_t)Sr * nblk_cap * 4 * NL * 4);
     need += zkhip_ctx::ws_round((size_t)std::max(1, Sr) * 4 * NL * 4);
     // worst-case plan of the large-bucket path: every entry in a large bucket
     const size_t entries = (size_t)W * n;
@@ -956,7 +960,7 @@ int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
     uint32_t *so = ctx->ws_take<uint32_t>((size_t)nsh + 1);
     uint32_t *ssums = ctx->ws_take<uint32_t>(sblk2);
     uint32_t *order = ctx->ws_take<uint32_t>(nb);
-    uint32_t *segsum = ctx->ws_take<uint32_t>((size_t)Sr * nblk_tail * 4 * NL);
+    uint32_t *segsum = ctx->ws_take<uint32_t>((size_t)Sr * nblk_cap * 4 * NL);
     uint32_t *winsum = ctx->ws_take<uint32_t>((size_t)std::max(1, Sr) * 4 * NL);
     uint32_t *plan = ctx->ws_take<uint32_t>(4);
     uint32_t *tasks = ctx->ws_take<uint32_t>((size_t)task_cap * 3);
@@ -1012,6 +1016,21 @@ int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
     }
     if (batch_slot) {  // batched call: hand the merged buckets over, the reduction runs once for the whole batch
         ZK_HIP_CHECK(ctx, hipMemcpyAsync(batch_slot, buckets, (size_t)B * 4 * NL * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        return 0;
+    }
+    // Small bucket sets leave lanes to spare even as pairs: the group law then runs over lane QUADS (fu_quad.hpp: 4 product steps per
+    // addition instead of 7) with segments twice as long -- from 2^18 buckets down; at 2^19 the longer segments eat the gain.
+    if (QuadLane<F>::AVAILABLE && ctx->opt_msm_tail_quads && (size_t)Sr * B <= ((size_t)1 << 18)) {
+        typedef typename QuadLane<F>::type TQ;
+        constexpr int QL = QuadLane<F>::LANES;
+        const uint32_t Lq = msm_tail_segment(ctx, B, Sr, QL, G2), slots_q = MSM_TAIL_THREADS / QL;
+        const uint32_t nseg_q = B / Lq, nblk_q = (nseg_q + slots_q - 1) / slots_q;  // <= nblk_cap: the partial-sum buffer fits
+        ZK_MAX_LDS(ctx, (msm_bucket_red<TQ, QL>), MSM_TAIL_THREADS / QL * 4 * NL * 4);
+        ZK_LAUNCH(ctx, "msm_bucket_red", (msm_bucket_red<TQ, QL>), dim3((unsigned)Sr * nblk_q), dim3(MSM_TAIL_THREADS), (size_t)slots_q * 4 * NL * 4, buckets, B,
+                  Lq, nseg_q, nblk_q, segsum);
+        const uint32_t wt = msm_window_threads(nblk_q, QL);
+        ZK_LAUNCH(ctx, "msm_window_sum", (msm_window_sum<TQ, QL>), dim3(Sr), dim3(wt), (size_t)wt / QL * 4 * NL * 4, segsum, nblk_q, winsum);
+        ZK_LAUNCH(ctx, "msm_final", (msm_final<TQ, QL>), dim3(1), dim3(64), 0, winsum, Sr, P.win, d_out_jac);
         return 0;
     }
     ZK_TRY(msm_tail_attr<F>(ctx));

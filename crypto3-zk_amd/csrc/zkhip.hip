@@ -124,6 +124,7 @@ int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value) {
     if (n == "msm_window_bits") ctx->opt_msm_window_bits = (int)value;
     else if (n == "msm_segment_log") ctx->opt_msm_segment_log = (int)value;
     else if (n == "msm_sets") ctx->opt_msm_sets = (int)value;
+    else if (n == "msm_tail_quads") ctx->opt_msm_tail_quads = (int)value;
     else if (n == "msm_sort_tile_log") ctx->opt_msm_sort_tile_log = (int)value;
     else if (n == "ntt_radix_log") ctx->opt_ntt_radix_log = (int)value;
     else if (n == "ntt_tile_log") ctx->opt_ntt_tile_log = (int)value;
@@ -164,6 +165,7 @@ int zkhip_get_option(const zkhip_ctx *ctx, const char *name, int64_t *value) {
     if (n == "msm_window_bits") *value = ctx->opt_msm_window_bits;
     else if (n == "msm_segment_log") *value = ctx->opt_msm_segment_log;
     else if (n == "msm_sets") *value = ctx->opt_msm_sets;
+    else if (n == "msm_tail_quads") *value = ctx->opt_msm_tail_quads;
     else if (n == "msm_sort_tile_log") *value = ctx->opt_msm_sort_tile_log;
     else if (n == "ntt_radix_log") *value = ctx->opt_ntt_radix_log;
     else if (n == "ntt_tile_log") *value = ctx->opt_ntt_tile_log;
