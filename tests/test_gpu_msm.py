@@ -317,6 +317,18 @@ def test_groth16_witness_map(ctx, zk, curve, M, n):
         assert not got[m - 1].any() and not got[m].any()  # prover.hpp:88-89
         if kind != 0:    # the same through the whole domain description
             assert (ctx.groth16_witness_h(r1cs, z, zd, gen) == exp).all()
+    if M <= 4096:
+        # an EXTENDED radix-2 domain of the next power of two (a real field reaches that kind only at 2^(s+1) points; the kind is an
+        # argument): <omega> and shift <omega>, omega of order m2 / 2, shift = multiplicative_generator^2 (detail::coset_shift)
+        sh = limbs(pow(C.fr_generator, 2, C.r), 4)
+        we = limbs(C.root_of_unity(m2.bit_length() - 2), 4)
+        r1cs.set_domain(1, m2)
+        g16.set_domain(1, m2, we, sh)
+        exp = g16.witness_map(we, gen)
+        got = ctx.groth16_witness_h(r1cs, z, zk.zkhip.Domain.make(1, m2, we, sh), gen)
+        assert (got == exp).all() and not got[m2 - 1].any()
+        with pytest.raises(zk.zkhip.ZkhipError):    # the extended kind needs its shift: the omega-only entry point refuses it
+            ctx.groth16_witness_h(r1cs, z, we, gen)
     r1cs.free()
 
 

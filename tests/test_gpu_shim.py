@@ -43,6 +43,10 @@ def _oracle_domain(g, curve, M, n, domain):
     if domain == "ref":
         kind, m = cp.domain_choice(M + n + 1, C.two_adicity)
         g.set_domain(kind, m, w)
+    elif domain == "extended":    # <omega> and shift <omega> over the next power of two: named explicitly (shim_set_domain)
+        m = 1 << (M + n).bit_length()
+        w = limbs(C.root_of_unity(m.bit_length() - 2), 4)
+        g.set_domain(1, m, w, limbs(pow(C.fr_generator, 2, C.r), 4))
     return w
 
 
@@ -50,7 +54,7 @@ def _oracle_domain(g, curve, M, n, domain):
 @pytest.mark.parametrize("curve,M,n,world,domain", [(1, 1024, 10, 1, "basic"), (0, 1024, 10, 1, "basic"), (0, 100, 10, 1, "basic"), (0, 1 << 15, 10, 1, "basic"),
                                                     (0, 1024, 10, 2, "basic"), (1, 1024, 10, 3, "basic"), (0, 100, 10, 8, "basic"),
                                                     (0, 16, 2, 1, "ref"), (1, 1024, 10, 1, "ref"), (0, 1024, 10, 1, "ref"), (0, 1 << 15, 10, 1, "ref"),
-                                                    (0, 1024, 10, 2, "ref"), (1, 1024, 10, 3, "ref")])
+                                                    (0, 1024, 10, 2, "ref"), (1, 1024, 10, 3, "ref"), (0, 100, 10, 1, "extended"), (1, 1024, 10, 2, "extended")])
 def test_groth16_prover_shim(shim, curve, M, n, world, domain):
     """A key made by the oracle, over the basic domain of the next power of two or over the domain the reference's
     make_evaluation_domain picks (the shim tells them apart by the H query's size), proven with through the shim: bit-exact
@@ -58,10 +62,14 @@ def test_groth16_prover_shim(shim, curve, M, n, world, domain):
     process_partial, the all-gather emulated by concatenation, finish) must equal the single-GPU proof -- SURVEY 8e's
     point-range partition."""
     shim.shim_set_world(world)
+    if domain == "extended":
+        C = CURVES[curve]
+        shim.shim_set_domain(1, ctypes.c_size_t(1 << (M + n).bit_length()), P(limbs(pow(C.fr_generator, 2, C.r), 4)))
     try:
         _groth16_prover_shim(shim, curve, M, n, domain)
     finally:
         shim.shim_set_world(1)
+        shim.shim_set_domain(-1, ctypes.c_size_t(0), None)
 
 
 def _groth16_prover_shim(shim, curve, M, n, domain):
@@ -98,7 +106,10 @@ def _groth16_prover_shim(shim, curve, M, n, domain):
         rng = po.SplitMix64(2024)
         tr = [rng.next_mod(C.r) for _ in range(5)]
         rr, ss = rng.next_mod(C.r), rng.next_mod(C.r)
-        eA, eB, eC = po.groth16_expected_in_exponent(C, cs, prim, aux, tr, rr, ss, C.root_of_unity(g.log_m))
+        wd = C.root_of_unity(g.log_m)
+        if domain == "extended":
+            wd = po.EvaluationDomain(po.EvaluationDomain.EXTENDED, g.m, C.root_of_unity(g.log_m - 1), C.r, pow(C.fr_generator, 2, C.r))
+        eA, eB, eC = po.groth16_expected_in_exponent(C, cs, prim, aux, tr, rr, ss, wd)
         assert (proof == np.concatenate([pt_limbs(curve, 1, eA), pt_limbs(curve, 2, eB), pt_limbs(curve, 1, eC)])).all()
 
 
