@@ -23,7 +23,7 @@ def _jac_of(curve, group, scalars):
     return out
 
 
-@pytest.mark.parametrize("curve,group,log_m", [(0, 1, 0), (0, 1, 1), (0, 1, 4), (1, 1, 6), (0, 2, 3), (1, 2, 2), (0, 1, 8)])
+@pytest.mark.parametrize("curve,group,log_m", [(0, 1, 0), (0, 1, 1), (0, 1, 4), (1, 1, 6), (0, 2, 3), (1, 2, 2), (0, 1, 8), (0, 1, 11), (1, 2, 7)])
 def test_ec_ntt_lagrange_basis(ctx, curve, group, log_m):
     C = CURVES[curve]
     r, m = C.r, 1 << log_m
@@ -46,10 +46,11 @@ def test_ec_ntt_lagrange_basis(ctx, curve, group, log_m):
         pts, inf = cp.batch_mul(curve, group, fr_arr(scalars))
         return [pt_from_limbs(curve, group, pts[j], inf[j]) for j in range(m)]
 
-    fwd = [sum(pow(w, i * j, r) * powers[i] for i in range(m)) % r for j in range(m)]
+    # the expected exponents: the O(m^2) definition at the small sizes, the oracle's transform (itself pinned to that definition) beyond
+    fwd = [sum(pow(w, i * j, r) * powers[i] for i in range(m)) % r for j in range(m)] if m <= 64 else po.ntt(powers, w, r)
     assert run(False) == expect(fwd)
     minv, winv = pow(m, -1, r), pow(w, -1, r)
-    inv = [minv * sum(pow(winv, i * j, r) * powers[i] for i in range(m)) % r for j in range(m)]
+    inv = [minv * sum(pow(winv, i * j, r) * powers[i] for i in range(m)) % r for j in range(m)] if m <= 64 else po.intt(powers, w, r)
     assert run(True) == expect(inv)
     if m >= 4:
         powers[2] = pow(tau, 2, r)
