@@ -50,7 +50,7 @@ struct FieldOps<FuQ<U>> {
 // the value lane K of the quad holds, on all four lanes
 // (The result is pinned in a VGPR of its own: left to itself LLVM's DPP-combine pass folds the move into the consuming VALU
 // instruction, and for `p0 - p1` -- two different broadcasts of ONE source register meeting in one subtraction -- the folded code
-// computed a wrong difference on gfx950 / ROCm 7.2: Y3 of both group operations, caught by tools/quadtest.hip.)
+// computed a wrong difference on gfx950 / ROCm 7.2: Y3 of both group operations, caught by tests/cpp/quadtest.hip.)
 template <int K>
 ZK_D uint32_t quad_bcast(uint32_t x) {
     uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, K * 0x55 /* quad_perm [K,K,K,K] */, 0xF, 0xF, false);

@@ -34,7 +34,7 @@ def _built():
 
     need = {os.path.join(ROOT, "crypto3-zk_amd"): ["libzkhip.so", "libzkhip_hosttest.so"],
             os.path.join(ROOT, "oracle"): ["liboracle.so"],
-            os.path.join(ROOT, "tests", "cpp"): ["libshimtest.so"]}
+            os.path.join(ROOT, "tests", "cpp"): ["libshimtest.so", "quadtest"]}
     for d, files in need.items():
         if not all(os.path.exists(os.path.join(d, f)) for f in files):
             subprocess.check_call(["make", "-C", d, "-j4"] + (["all"] if d.endswith("crypto3-zk_amd") else []))

@@ -332,6 +332,17 @@ def test_groth16_witness_map(ctx, zk, curve, M, n):
     r1cs.free()
 
 
+def test_tail_group_law_over_lane_pairs_and_quads(ctx):
+    """the MSM tail's group law spread over lane pairs (fu_pair.hpp) and lane quads (fu_quad.hpp) against the one-lane formulas:
+    addition, doubling, small multiples, both base fields (tests/cpp/quadtest.hip, a device-only unit test)"""
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(HERE), "tests", "cpp", "quadtest")
+    assert os.path.exists(exe), "tests/cpp/quadtest is missing: python -c 'import __graft_entry__ as g; g.build()'"
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, text=True)
+    assert out.returncode == 0 and out.stdout.count("mismatch mask 0x0 ") == 2, out.stdout
+
+
 def test_msm_batch(ctx, zk):
     """zkhip_msm_batch_dev: several MSMs with one shared bucket reduction == the same MSMs one by one;
     covers an empty member, a sub-range member and the mixed (fallback) case."""
