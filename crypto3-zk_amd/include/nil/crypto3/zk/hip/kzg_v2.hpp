@@ -695,6 +695,44 @@ private:
     std::map<std::size_t, commitment_type> _commitments;
 };
 
+/// The same for the FIRST batched scheme (kzg_commitment_scheme, kzg.hpp:636-873): `commit` packs the single commitments into the
+/// reference's byte blob (:748-765), `verify_eval` (:809-868) goes to the caller's pairing check, which finds commit_g2, the
+/// evaluation points and the per-polynomial commitments on this object.
+template <typename CurveType, typename TranscriptType, typename Packer, typename Verifier>
+class kzg_commitment_scheme_placeholder_hip : public kzg_commitment_scheme_hip<CurveType, TranscriptType> {
+    typedef kzg_commitment_scheme_hip<CurveType, TranscriptType> base;
+
+public:
+    typedef std::vector<std::uint8_t> commitment_type;
+    typedef typename base::proof_type proof_type;
+    typedef typename base::transcript_type transcript_type;
+    typedef typename base::params_type params_type;
+    typedef typename base::root_of_unity_type root_of_unity_type;
+
+    kzg_commitment_scheme_placeholder_hip(const params_type &kzg_params, root_of_unity_type root_of_unity, Packer packer, Verifier verifier) :
+        base(kzg_params, std::move(root_of_unity)), _packer(std::move(packer)), _verifier(std::move(verifier)) { }
+
+    commitment_type commit(std::size_t index) {
+        commitment_type result;
+        for (const auto &single_commitment : base::commit(index)) {
+            const std::vector<std::uint8_t> bytes = _packer(single_commitment);
+            result.insert(result.end(), bytes.begin(), bytes.end());
+        }
+        _commitments[index] = result;
+        return result;
+    }
+    bool verify_eval(const proof_type &proof, const std::map<std::size_t, commitment_type> &commitments, transcript_type &transcript) {
+        return _verifier(*this, proof, commitments, transcript);
+    }
+    const std::map<std::size_t, commitment_type> &packed_commitments() const { return _commitments; }
+    const std::vector<typename base::scalar_value_type> &eval_points(std::size_t batch, std::size_t poly) const { return this->_points.at(batch).at(poly); }
+
+private:
+    Packer _packer;
+    Verifier _verifier;
+    std::map<std::size_t, commitment_type> _commitments;
+};
+
 }    // namespace hip
 }    // namespace zk
 }    // namespace crypto3

@@ -354,8 +354,21 @@ int kzg_v1_t(const uint64_t *srs, size_t n_srs, const uint64_t *vk, size_t n_vk,
     std::vector<G2> vkey;
     for (size_t i = 0; i < n_vk; ++i) vkey.push_back(G2::from_affine(vk + i * L2));
     kzg_params_hip<Curve> params(ctx, ck.begin(), ck.end(), vkey.begin(), vkey.end());
-    typedef kzg_commitment_scheme_hip<Curve, scripted_transcript<Curve>> scheme_type;
-    scheme_type scheme(params, [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); });
+    // the placeholder-facing form: commit() returns the byte blob, verify_eval() goes to the caller's pairing check
+    auto packer = [L1](const G1 &p) {
+        std::vector<std::uint64_t> xy(L1);
+        p.to_affine(xy.data());
+        std::vector<std::uint8_t> b(L1 * 8);
+        std::memcpy(b.data(), xy.data(), b.size());
+        return b;
+    };
+    std::size_t verify_calls = 0;
+    auto verifier = [&verify_calls](auto &sch, const auto &pr, const std::map<std::size_t, std::vector<std::uint8_t>> &cm, scripted_transcript<Curve> &) {
+        ++verify_calls;
+        return cm.size() == sch.commitments().size() && pr.z.get_batches_num() == cm.size();
+    };
+    typedef kzg_commitment_scheme_placeholder_hip<Curve, scripted_transcript<Curve>, decltype(packer), decltype(verifier)> scheme_type;
+    scheme_type scheme(params, [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); }, packer, verifier);
     std::vector<size_t> batches;
     size_t at = 0;
     for (size_t p = 0; p < npolys; ++p) {
@@ -365,11 +378,15 @@ int kzg_v1_t(const uint64_t *srs, size_t n_srs, const uint64_t *vk, size_t n_vk,
         if (batches.empty() || batches.back() != batch_id[p]) batches.push_back(batch_id[p]);
     }
     size_t ci = 0;
-    for (size_t b : batches)
-        for (const auto &c : scheme.commit(b)) {
+    for (size_t b : batches) {
+        const std::vector<std::uint8_t> blob = scheme.commit(b);
+        if (blob.size() != scheme.commitments().at(b).size() * L1 * 8) return -8;
+        for (const auto &c : scheme.commitments().at(b)) {
+            if (std::memcmp(blob.data() + (&c - scheme.commitments().at(b).data()) * L1 * 8, packer(c).data(), L1 * 8) != 0) return -8;
             c.to_affine(commits + ci * L1);
             ++ci;
         }
+    }
     size_t pt = 0;
     std::vector<size_t> idx_in_batch(npolys, 0);
     for (size_t p = 0, i = 0; p < npolys; ++p) {
@@ -390,6 +407,9 @@ int kzg_v1_t(const uint64_t *srs, size_t n_srs, const uint64_t *vk, size_t n_vk,
     commit_g2<Curve>(params, gp).to_affine(g2_out + L2);
     absorbed[0] = tr.absorbed_points;
     absorbed[1] = tr.absorbed_scalars;
+    scripted_transcript<Curve> tr2;
+    tr2.challenges = tr.challenges;
+    if (!scheme.verify_eval(proof, scheme.packed_commitments(), tr2) || verify_calls != 1) return -9;
     return 0;
 }
 
