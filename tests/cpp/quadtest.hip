@@ -27,15 +27,21 @@ __global__ void k(const uint32_t *in, uint32_t *bad) {
         *fb[c] = fu_mul(*fb[c], Fu<U>::r2());
     }
     const uint32_t kk = 1 + (in[q & 4095] & 0xfffff);
-    const XYZZ<Fu<U>> s1 = xyzz_add(a, b), d1 = xyzz_dbl(a), m1 = xyzz_mul_small(a, kk);
+    // the multiple by the pair / quad code's own chain (double, then add where the bit is set): off the curve -- these are arbitrary
+    // field elements -- two DIFFERENT addition chains need not meet, so the one-lane reference follows the same one
+    XYZZ<Fu<U>> m1 = a;
+    for (int i = 31 - __builtin_clz(kk) - 1; i >= 0; --i) {
+        m1 = xyzz_dbl(m1);
+        if ((kk >> i) & 1) m1 = xyzz_add(m1, a);
+    }
+    const XYZZ<Fu<U>> s1 = xyzz_add(a, b), d1 = xyzz_dbl(a);
     const XYZZ<FuQ<U>> aq {{a.X}, {a.Y}, {a.ZZ}, {a.ZZZ}}, bq {{b.X}, {b.Y}, {b.ZZ}, {b.ZZZ}};
     const XYZZ<FuQ<U>> s4 = xyzz_add(aq, bq), d4 = xyzz_dbl(aq), m4 = xyzz_mul_small(aq, kk);
     const XYZZ<FuP<U>> ap {{a.X}, {a.Y}, {a.ZZ}, {a.ZZZ}}, bp {{b.X}, {b.Y}, {b.ZZ}, {b.ZZZ}};
     const XYZZ<FuP<U>> s2 = xyzz_add(ap, bp), d2 = xyzz_dbl(ap), m2 = xyzz_mul_small(ap, kk);
     auto same = [](const Fu<U> &x, const Fu<U> &y) { return fu_canon(x).limbs_equal(fu_canon(y)); };
-    // a multiple's representative (X, Y, ZZ, ZZZ) depends on the order of operations: compare x = X / ZZ, y = Y / ZZZ cross-multiplied
     auto same_point = [&](const XYZZ<Fu<U>> &p, const Fu<U> &X, const Fu<U> &Y, const Fu<U> &ZZ, const Fu<U> &ZZZ) {
-        return same(fu_mul(p.X, ZZ), fu_mul(X, p.ZZ)) && same(fu_mul(p.Y, ZZZ), fu_mul(Y, p.ZZZ));
+        return same(p.X, X) && same(p.Y, Y) && same(p.ZZ, ZZ) && same(p.ZZZ, ZZZ);
     };
     unsigned m = 0;
     if (!same(s1.X, s4.X.v) || !same(s1.Y, s4.Y.v) || !same(s1.ZZ, s4.ZZ.v) || !same(s1.ZZZ, s4.ZZZ.v)) m |= 1;    // quad addition
@@ -52,11 +58,11 @@ unsigned run(const char *name) {
     uint32_t *din, *dbad, h[4096], bad = 0xffffffffu;
     for (int i = 0; i < 4096; ++i) h[i] = i * 2654435761u + 977;
     if (hipMalloc(&din, sizeof(h)) != hipSuccess || hipMalloc(&dbad, 4) != hipSuccess) return bad;
-    hipMemcpy(din, h, sizeof(h), hipMemcpyHostToDevice), hipMemset(dbad, 0, 4);
+    (void)hipMemcpy(din, h, sizeof(h), hipMemcpyHostToDevice), (void)hipMemset(dbad, 0, 4);
     hipLaunchKernelGGL(k<U>, dim3(16), dim3(256), 0, 0, din, dbad);
     if (hipMemcpy(&bad, dbad, 4, hipMemcpyDeviceToHost) != hipSuccess) bad = 0xffffffffu;
     printf("%s: mismatch mask 0x%x (quad add / dbl / multiple = 1 / 2 / 4, pair = 16 / 32 / 64)\n", name, bad);
-    hipFree(din), hipFree(dbad);
+    (void)hipFree(din), (void)hipFree(dbad);
     return bad;
 }
 
