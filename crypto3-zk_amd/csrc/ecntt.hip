@@ -203,7 +203,7 @@ ZK_D XYZZ<F> xyzz_dbl4(XYZZ<F> a) {
 // input v by w^(k stride) (k = 0: nothing to do); mode 1: the last stage of the INVERSE transform, lane t = point t, upper inputs take
 // 1/m, lower inputs w^k / m.  Lanes first .. first + gridDim.x * 64 of `total`; `tbl` holds 8 * HALVES points per lane of the launch.
 template <class F, class G>
-__global__ __launch_bounds__(64) void ec_ntt_mul_pass(uint32_t *__restrict__ pts, const uint32_t *__restrict__ rec_stage, const uint32_t *__restrict__ rec_last,
+__global__ __launch_bounds__(64, G::ENABLED ? 2 : 1) void ec_ntt_mul_pass(uint32_t *__restrict__ pts, const uint32_t *__restrict__ rec_stage, const uint32_t *__restrict__ rec_last,
                                                       const uint32_t *__restrict__ rec_minv, uint32_t log_m, uint32_t s, int mode, uint32_t first,
                                                       uint32_t total, uint32_t *__restrict__ tbl) {
     typedef FieldOps<F> O;
@@ -302,7 +302,8 @@ int ec_ntt_t(zkhip_ctx *ctx, uint32_t *d_jac, size_t log_m, const uint64_t *omeg
     const uint32_t m = 1u << log_m, ntw = std::max<uint32_t>(1, m / 2);
     // table slots: the lanes of one multiplication launch (<= 1 GiB of tables; a pass over more lanes runs in several launches)
     const size_t slot_bytes = (size_t)8 * HALVES * PW * 4;
-    const uint32_t slots = (uint32_t)std::max<size_t>(64, std::min<size_t>(((size_t)m + 63) / 64 * 64, ((size_t)1 << 30) / slot_bytes / 64 * 64));
+    const size_t slot_cap = ctx->opt_ec_ntt_table_lanes ? ((size_t)ctx->opt_ec_ntt_table_lanes + 63) / 64 * 64 : ((size_t)1 << 30) / slot_bytes / 64 * 64;
+    const uint32_t slots = (uint32_t)std::max<size_t>(64, std::min<size_t>(((size_t)m + 63) / 64 * 64, slot_cap));
     const size_t need = zkhip_ctx::ws_round((size_t)m * PW * 4) + 2 * zkhip_ctx::ws_round((size_t)ntw * REC_WORDS * 4) + zkhip_ctx::ws_round(512) +
                         zkhip_ctx::ws_round((size_t)slots * slot_bytes);
     ZK_TRY(ctx->ws_reserve(need));

@@ -1,5 +1,6 @@
 // extern "C" surface of libzkhip.so (declared in include/zkhip.h).  No torch types, no CPU fallback:
 // if no HIP device is usable, zkhip_init fails and nothing else can be called.
+#include <algorithm>
 #include <cstdlib>
 
 #include "ctx.hpp"
@@ -125,6 +126,7 @@ int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value) {
     else if (n == "msm_segment_log") ctx->opt_msm_segment_log = (int)value;
     else if (n == "msm_sets") ctx->opt_msm_sets = (int)value;
     else if (n == "msm_tail_quads") ctx->opt_msm_tail_quads = (int)value;
+    else if (n == "ec_ntt_table_lanes") ctx->opt_ec_ntt_table_lanes = value < 0 ? 0 : (uint32_t)std::min<int64_t>(value, 1 << 24);
     else if (n == "msm_sort_tile_log") ctx->opt_msm_sort_tile_log = (int)value;
     else if (n == "ntt_radix_log") ctx->opt_ntt_radix_log = (int)value;
     else if (n == "ntt_tile_log") ctx->opt_ntt_tile_log = (int)value;
@@ -166,6 +168,7 @@ int zkhip_get_option(const zkhip_ctx *ctx, const char *name, int64_t *value) {
     else if (n == "msm_segment_log") *value = ctx->opt_msm_segment_log;
     else if (n == "msm_sets") *value = ctx->opt_msm_sets;
     else if (n == "msm_tail_quads") *value = ctx->opt_msm_tail_quads;
+    else if (n == "ec_ntt_table_lanes") *value = ctx->opt_ec_ntt_table_lanes;
     else if (n == "msm_sort_tile_log") *value = ctx->opt_msm_sort_tile_log;
     else if (n == "ntt_radix_log") *value = ctx->opt_ntt_radix_log;
     else if (n == "ntt_tile_log") *value = ctx->opt_ntt_tile_log;

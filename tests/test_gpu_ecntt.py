@@ -23,7 +23,7 @@ def _jac_of(curve, group, scalars):
     return out
 
 
-@pytest.mark.parametrize("curve,group,log_m", [(0, 1, 0), (0, 1, 1), (0, 1, 4), (1, 1, 6), (0, 2, 3), (1, 2, 2), (0, 1, 8), (0, 1, 11), (1, 2, 7)])
+@pytest.mark.parametrize("curve,group,log_m", [(0, 1, 0), (0, 1, 1), (0, 1, 4), (1, 1, 6), (0, 2, 3), (1, 2, 2), (0, 1, 8), (0, 1, 11), (1, 2, 7), (1, 1, 9)])
 def test_ec_ntt_lagrange_basis(ctx, curve, group, log_m):
     C = CURVES[curve]
     r, m = C.r, 1 << log_m
@@ -62,3 +62,28 @@ def test_ec_ntt_lagrange_basis(ctx, curve, group, log_m):
     ctx.d2h(out, d)
     assert [jac_to_affine_py(curve, group, out[j]) for j in range(m)] == expect(powers)
     ctx.free(d)
+
+
+def test_ec_ntt_in_several_launches(ctx):
+    """The multiplication pass of a large transform runs in several launches over one table region (option
+    "ec_ntt_table_lanes"): the same result as in one."""
+    curve, group, log_m = 0, 1, 8
+    C = CURVES[curve]
+    r, m = C.r, 1 << log_m
+    w = C.root_of_unity(log_m)
+    tau = po.SplitMix64(7).next_mod(r)
+    jac = _jac_of(curve, group, [pow(tau, i, r) for i in range(m)])
+    d = ctx.malloc(jac.nbytes)
+    outs = []
+    for lanes in (0, 64):
+        ctx.set_option("ec_ntt_table_lanes", lanes)
+        ctx.h2d(d, jac)
+        ctx.ec_ntt_dev(curve, group, d, log_m, limbs(w, 4), inverse=True)
+        out = np.zeros_like(jac)
+        ctx.d2h(out, d)
+        outs.append([jac_to_affine_py(curve, group, out[j]) for j in range(m)])
+    ctx.set_option("ec_ntt_table_lanes", 0)
+    ctx.free(d)
+    assert outs[0] == outs[1]
+    pts, inf = cp.batch_mul(curve, group, fr_arr(po.lagrange_at(m, w, tau, r)))
+    assert outs[0] == [pt_from_limbs(curve, group, pts[j], inf[j]) for j in range(m)]
