@@ -118,11 +118,12 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
     auto &dpk = *key->device;
     {
         const uint64_t info[8] = {(uint64_t)dpk.evaluation_domain.kind, dpk.evaluation_domain.m, dpk.A_query.size(), dpk.B_count, dpk.H_query.size(),
-                                  dpk.L_query.size(), cs.num_variables(), cs.num_inputs()};
+                                  dpk.shard.L_n, cs.num_variables(), cs.num_inputs()};
         memcpy(g_last_info, info, sizeof(info));
     }
     if (const char *e = getenv("ZKHIP_G16_OVERLAP")) dpk.overlap_g2 = atoi(e) != 0;    // experiments: G2 multiexp on the main stream
     if (const char *e = getenv("ZKHIP_G16_SIDE_PRIORITY")) dpk.side_stream_priority = atoi(e);
+    if (const char *e = getenv("ZKHIP_G16_SHARE_SORTS")) dpk.share_sorts = atoi(e) != 0;    // experiments: 0 = every query sorts the assignment's digits itself
     if (const char *e = getenv("ZKHIP_G16_SKIP_G2")) dpk.experiment_skip_g2 = atoi(e) != 0;    // ceiling experiment: the proof is then WRONG
     ctx.sync();
     *setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

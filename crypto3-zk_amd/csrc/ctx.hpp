@@ -101,6 +101,7 @@ struct zkhip_ctx {
     int opt_msm_sets = 0;          // bucket sets S with window tables (entry (i, w) -> set w mod S); 0: from the lane target
     int opt_msm_sort_tile_log = 14;  // 14: 2^14-entry sort tiles (the MSM owns the GPU); 12: 2^12 (kernels of another context run alongside)
     uint32_t opt_ec_ntt_table_lanes = 0;  // EC-NTT: lanes per multiplication launch = window tables held at once (0: as many as fit 1 GiB)
+    int opt_msm_share_sort = 1;    // batches: consecutive members over the same scalars and table geometry share one sort (msm_same_entries)
     int opt_msm_tail_quads = 1;    // group law over lane quads in the tail of small bucket sets (fu_quad.hpp); 0: pairs everywhere
     int opt_msm_segment_log = -1;  // tail segments of 2^k buckets per lane; < 0: chosen from the lane count
     int opt_ntt_radix_log = 8;

@@ -877,7 +877,7 @@ int msm_sort_run(zkhip_ctx *ctx, const SortGeom &g, int W, uint32_t nb, uint32_t
 
 template <class F>
 int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint32_t *d_scalars, uint32_t *d_out_jac,
-              uint32_t *batch_slot = nullptr, size_t *need_out = nullptr) {
+              uint32_t *batch_slot = nullptr, size_t *need_out = nullptr, bool reuse_sort = false) {
     constexpr int NL = FieldOps<F>::WORDS;
     typedef typename BucketLane<F>::type FL;           // what a lane holds in the bucket kernels
     constexpr int LPB = BucketLane<F>::LANES;          // lanes per point (2 for G2: fu2_pair.hpp)
@@ -969,15 +969,20 @@ int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
 
     const uint32_t *d_b = bases->d;  // entries address table rows from the start of the bases object
 
-    unsigned gn = (unsigned)((n + 255) / 256);
-    if (bases->curve == CURVE_BLS12_381)
-        ZK_LAUNCH(ctx, "msm_digits", msm_digits_only<BlsFr>, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, P.win, P.wrank, P.wworld, dig);
-    else ZK_LAUNCH(ctx, "msm_digits", msm_digits_only<BnFr>, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, P.win, P.wrank, P.wworld, dig);
-    ZK_TRY((big_tiles ? msm_sort_run<SortBig> : msm_sort_run<SortSmall>)(ctx, g, W, nb, nbh, nblk, dig, bh, bo, bsums, tmp_idx, tmp_key, offs, idx));
-    // buckets by descending size
-    ZK_LAUNCH(ctx, "msm_size_sort", msm_size_hist, dim3(sblk), dim3(256), 0, offs, nb, sblk, large_thresh, sh);
-    ZK_TRY(msm_scan(ctx, "msm_size_sort", sh, nsh, so, ssums));
-    ZK_LAUNCH(ctx, "msm_size_sort", msm_size_scatter, dim3(sblk), dim3(256), 0, offs, nb, sblk, large_thresh, so, order);
+    // reuse_sort (batches: the previous member had the SAME scalars over an entry-compatible bases object -- msm_same_entries): the
+    // sorted entries, bucket offsets, size order and large-bucket plan in the workspace are this member's too (same sizes, so the same
+    // addresses); only the gathers read another table
+    if (!reuse_sort) {
+        unsigned gn = (unsigned)((n + 255) / 256);
+        if (bases->curve == CURVE_BLS12_381)
+            ZK_LAUNCH(ctx, "msm_digits", msm_digits_only<BlsFr>, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, P.win, P.wrank, P.wworld, dig);
+        else ZK_LAUNCH(ctx, "msm_digits", msm_digits_only<BnFr>, dim3(gn), dim3(256), 0, d_scalars, (uint32_t)n, P.win, P.wrank, P.wworld, dig);
+        ZK_TRY((big_tiles ? msm_sort_run<SortBig> : msm_sort_run<SortSmall>)(ctx, g, W, nb, nbh, nblk, dig, bh, bo, bsums, tmp_idx, tmp_key, offs, idx));
+        // buckets by descending size
+        ZK_LAUNCH(ctx, "msm_size_sort", msm_size_hist, dim3(sblk), dim3(256), 0, offs, nb, sblk, large_thresh, sh);
+        ZK_TRY(msm_scan(ctx, "msm_size_sort", sh, nsh, so, ssums));
+        ZK_LAUNCH(ctx, "msm_size_sort", msm_size_scatter, dim3(sblk), dim3(256), 0, offs, nb, sblk, large_thresh, so, order);
+    }
     if constexpr (FieldOps<F>::WORDS <= 16) {
         // G1: accumulator coordinates in LDS, three waves per SIMD
         constexpr int NT = MSM_G1_THREADS;
@@ -995,9 +1000,11 @@ int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
                   offs, idx, nb, large_thresh, order, buckets);
     }
     // large buckets: plan on the device (no host round trip), then fixed-size grids that read the plan
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(plan, 0, 16, ctx->stream));
-    ZK_LAUNCH(ctx, "msm_plan_large", msm_plan_large, dim3((nb + 255) / 256), dim3(256), 0, offs, nb, plan, tasks, large, task_cap, large_cap, large_thresh,
-              ctx->d_status);
+    if (!reuse_sort) {
+        ZK_HIP_CHECK(ctx, hipMemsetAsync(plan, 0, 16, ctx->stream));
+        ZK_LAUNCH(ctx, "msm_plan_large", msm_plan_large, dim3((nb + 255) / 256), dim3(256), 0, offs, nb, plan, tasks, large, task_cap, large_cap, large_thresh,
+                  ctx->d_status);
+    }
     {
         size_t lds_large = (size_t)128 / LPB * 4 * NL * 4;
         if (lds_large > 48 * 1024) ZK_MAX_LDS(ctx, (msm_bucket_large<FL, LPB>), lds_large);
@@ -1062,6 +1069,15 @@ int bases_precompute_t(zkhip_ctx *ctx, zkhip_bases *b) {
     return 0;
 }
 
+// Do two members of a batch produce the same sorted entries?  An entry is (bucket of the digit, table row of the point): the same
+// scalars, range and table geometry give the same list whatever the points are -- the queries of one Groth16 proof that run over the
+// same assignment vector (A, the dense B.h, the padded L) then share one digit extraction, sort, size order and large-bucket plan.
+inline bool msm_same_entries(const zkhip_bases *a, size_t off_a, size_t n_a, const uint32_t *s_a, const zkhip_bases *b, size_t off_b, size_t n_b,
+                             const uint32_t *s_b) {
+    return s_a == s_b && n_a == n_b && off_a == off_b && a->curve == b->curve && a->n == b->n && a->c_tab == b->c_tab && a->ntab == b->ntab &&
+           a->win_rank == b->win_rank && a->win_world == b->win_world && a->nslots == b->nslots && a->tables() && b->tables();
+}
+
 // Several MSMs over table-backed bases of one group with one window size: per MSM digits / sort / accumulate /
 // merge as usual, then ONE bucket reduction, set sum and output conversion for the whole batch.
 // TL / TLPB: what a lane of the shared tail holds.  A few members: the latency-bound shape of a single MSM (G1: the group law over
@@ -1096,12 +1112,16 @@ int msm_batch_tail(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases
     uint32_t **d_ptrs = ctx->ws_take<uint32_t *>(count);
     ctx->ws_floor = ctx->ws_off;  // the per-MSM stages bump-allocate above the batch area
     int rc = 0;
+    size_t prev = (size_t)-1;  // the member whose sort the workspace holds
     for (size_t i = 0; i < count && rc == 0; ++i) {
         if (ns[i] == 0 || bases[i]->local_windows() == 0) {
             hipError_t e = hipMemsetAsync(slots + i * slot_words, 0, slot_words * 4, ctx->stream);  // all buckets at infinity
             if (e != hipSuccess) rc = ZKHIP_ERR_HIP;
         } else {
-            rc = msm_run_t<F>(ctx, bases[i], offsets[i], ns[i], d_scalars[i], nullptr, slots + i * slot_words, nullptr);
+            const bool reuse = ctx->opt_msm_share_sort && prev != (size_t)-1 &&
+                               msm_same_entries(bases[prev], offsets[prev], ns[prev], d_scalars[prev], bases[i], offsets[i], ns[i], d_scalars[i]);
+            rc = msm_run_t<F>(ctx, bases[i], offsets[i], ns[i], d_scalars[i], nullptr, slots + i * slot_words, nullptr, reuse);
+            prev = i;
         }
     }
     ctx->ws_floor = 0;

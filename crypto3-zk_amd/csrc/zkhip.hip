@@ -126,6 +126,7 @@ int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value) {
     else if (n == "msm_segment_log") ctx->opt_msm_segment_log = (int)value;
     else if (n == "msm_sets") ctx->opt_msm_sets = (int)value;
     else if (n == "msm_tail_quads") ctx->opt_msm_tail_quads = (int)value;
+    else if (n == "msm_share_sort") ctx->opt_msm_share_sort = (int)value;
     else if (n == "ec_ntt_table_lanes") ctx->opt_ec_ntt_table_lanes = value < 0 ? 0 : (uint32_t)std::min<int64_t>(value, 1 << 24);
     else if (n == "msm_sort_tile_log") ctx->opt_msm_sort_tile_log = (int)value;
     else if (n == "ntt_radix_log") ctx->opt_ntt_radix_log = (int)value;
@@ -168,6 +169,7 @@ int zkhip_get_option(const zkhip_ctx *ctx, const char *name, int64_t *value) {
     else if (n == "msm_segment_log") *value = ctx->opt_msm_segment_log;
     else if (n == "msm_sets") *value = ctx->opt_msm_sets;
     else if (n == "msm_tail_quads") *value = ctx->opt_msm_tail_quads;
+    else if (n == "msm_share_sort") *value = ctx->opt_msm_share_sort;
     else if (n == "ec_ntt_table_lanes") *value = ctx->opt_ec_ntt_table_lanes;
     else if (n == "msm_sort_tile_log") *value = ctx->opt_msm_sort_tile_log;
     else if (n == "ntt_radix_log") *value = ctx->opt_ntt_radix_log;
@@ -421,6 +423,56 @@ int zkhip_bases_from_scalars(zkhip_ctx *ctx, int curve, int group, const uint64_
     } while (0);
     if (d_s) (void)hipFree(d_s);
     if (d_g) (void)hipFree(d_g);
+    if (rc) {
+        (void)hipFree(b->d);
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return ZKHIP_OK;
+}
+
+// out row d_rows[j] (or first + j) <- src row j; a row is `stride` words
+__global__ void bases_spread_rows(const uint32_t *__restrict__ src, size_t count, uint32_t stride, const uint32_t *__restrict__ d_rows, uint32_t first,
+                                  uint32_t n_total, uint32_t *__restrict__ out, uint32_t *__restrict__ status) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= count * stride) return;
+    const size_t j = g / stride;
+    const uint32_t w = (uint32_t)(g % stride), row = d_rows ? d_rows[j] : first + (uint32_t)j;
+    if (row >= n_total) {
+        if (w == 0) atomicOr(status, ZK_STATUS_GATHER_RANGE);
+        return;
+    }
+    out[(size_t)row * stride + w] = src[g];
+}
+
+int zkhip_bases_spread(zkhip_ctx *ctx, const zkhip_bases *src, const uint32_t *d_rows, size_t first, size_t n_total, zkhip_bases **out) {
+    if (!ctx || !src || !out) return ZKHIP_ERR_INVALID;
+    if (n_total >= ((size_t)1 << 32) || (!d_rows && first + src->n > n_total)) return ZKHIP_ERR_RANGE;
+    ZK_TRY(check_device(ctx));
+    zkhip_bases *b = nullptr;
+    ZK_TRY(bases_alloc(ctx, src->curve, src->group, n_total, &b));
+    int rc = 0;
+    do {
+        if (n_total == 0) break;
+        const size_t words = n_total * b->stride_u32;
+        if (hipMemsetAsync(b->d, 0, words * 4, ctx->stream) != hipSuccess) {  // (0, 0): the point at infinity
+            rc = ZKHIP_ERR_HIP;
+            break;
+        }
+        if (src->n) {
+            const size_t lanes = src->n * src->stride_u32;
+            hipLaunchKernelGGL(bases_spread_rows, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, ctx->stream, src->d, src->n, (uint32_t)src->stride_u32,
+                               d_rows, (uint32_t)first, (uint32_t)n_total, b->d, ctx->d_status);
+            if (hipGetLastError() != hipSuccess) {
+                rc = ZKHIP_ERR_HIP;
+                break;
+            }
+        }
+        rc = zk_bases_precompute(ctx, b);
+        if (rc) break;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
+    } while (0);
     if (rc) {
         (void)hipFree(b->d);
         delete b;

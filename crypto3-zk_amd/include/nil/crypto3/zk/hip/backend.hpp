@@ -237,6 +237,15 @@ public:
         check(zkhip_bases_upload_compressed(ctx.get(), adapter::id, Group, octets, n, &r.b_), "zkhip_bases_upload_compressed", ctx.get());
         return r;
     }
+    /// these points at the rows d_rows[j] (device array of size() u32; nullptr: the consecutive rows first + j) of an object of
+    /// n_total points, the point at infinity everywhere else (zkhip_bases_spread: queries laid out over the same rows share a sort)
+    device_bases spread(const void *d_rows, std::size_t first, std::size_t n_total) const {
+        device_bases r;
+        r.ctx_ = ctx_;
+        r.size_ = n_total;
+        check(zkhip_bases_spread(ctx_->get(), b_, static_cast<const std::uint32_t *>(d_rows), first, n_total, &r.b_), "zkhip_bases_spread", ctx_->get());
+        return r;
+    }
     /// host copy of entry i as a group value
     typename std::conditional<Group == ZKHIP_G1, typename adapter::g1_value_type, typename adapter::g2_value_type>::type at(std::size_t i) const {
         typedef typename std::conditional<Group == ZKHIP_G1, typename adapter::g1_value_type, typename adapter::g2_value_type>::type G;

@@ -15,7 +15,7 @@ _FQ = {BLS12_381: 6, BN254: 4}
 EXPORTS = [
     "zkhip_init", "zkhip_destroy", "zkhip_strerror", "zkhip_last_error", "zkhip_set_stream", "zkhip_sync", "zkhip_device_status", "zkhip_stream_wait", "zkhip_device",
     "zkhip_set_option", "zkhip_get_option", "zkhip_malloc", "zkhip_free", "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_memcpy_h2d_async", "zkhip_memcpy_d2h_async", "zkhip_memcpy_d2d_async", "zkhip_host_alloc", "zkhip_host_free",
-    "zkhip_bases_upload", "zkhip_bases_upload_compressed", "zkhip_bases_from_scalars", "zkhip_bases_download", "zkhip_bases_size",
+    "zkhip_bases_upload", "zkhip_bases_upload_compressed", "zkhip_bases_from_scalars", "zkhip_bases_spread", "zkhip_bases_download", "zkhip_bases_size",
     "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_batch_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_domain_choice", "zkhip_domain_fft_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_set_domain", "zkhip_r1cs_domain_size", "zkhip_r1cs_domain_kind", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev", "zkhip_groth16_witness_h_domain_dev", "zkhip_fr_gather_dev", "zkhip_poly_resize_dev", "zkhip_fri_fold_dev", "zkhip_fri_leaves_dev", "zkhip_ec_ntt_dev",
@@ -442,6 +442,13 @@ class Bases:
         self.ctx._check(self.ctx.lib.zkhip_bases_download(self.ctx.h, self.h, ctypes.c_size_t(offset), ctypes.c_size_t(n), _p(out), _p(inf)),
                         "zkhip_bases_download")
         return out, inf
+
+    def spread(self, n_total, d_rows=None, first=0):
+        """a bases object of n_total points with these at the rows d_rows[j] (device u32 array; None: first + j), infinity elsewhere"""
+        out = ctypes.c_void_p()
+        self.ctx._check(self.ctx.lib.zkhip_bases_spread(self.ctx.h, self.h, ctypes.c_void_p(d_rows) if d_rows else None, ctypes.c_size_t(first),
+                                                        ctypes.c_size_t(n_total), ctypes.byref(out)), "zkhip_bases_spread")
+        return Bases(self.ctx, out, self.curve, self.group, n_total)
 
     def free(self):
         if self.h is not None and self.ctx.h:

@@ -62,7 +62,8 @@ int zkhip_sync(zkhip_ctx *ctx);
  * any was set (the results computed meanwhile are then not to be used).  The shims call it once per proof. */
 int zkhip_device_status(zkhip_ctx *ctx, uint32_t *flags /* nullable */);
 /* Tunables: "msm_window_bits" (0 = auto), "msm_sets" (bucket sets with window tables, 0 = auto), "msm_segment_log" (tail: 2^k buckets
- * per lane, < 0 = auto), "msm_tail_quads" (1: the tail of bucket sets up to 2^18 runs the group law over lane quads, 0: pairs everywhere), "msm_sort_tile_log" (14: the MSM has the GPU to itself; 12: kernels of another context run alongside and
+ * per lane, < 0 = auto), "msm_tail_quads" (1: the tail of bucket sets up to 2^18 runs the group law over lane quads, 0: pairs everywhere), "msm_share_sort" (1: consecutive members of zkhip_msm_batch_dev with the same scalars pointer, range and
+ * table geometry share one digit extraction / sort / large-bucket plan; 0: every member sorts), "msm_sort_tile_log" (14: the MSM has the GPU to itself; 12: kernels of another context run alongside and
  * the sort's LDS tiles must fit next to them), "ntt_radix_log", "ntt_tile_log", "ec_ntt_table_lanes" (zkhip_ec_ntt_dev: points multiplied per launch = per-lane window tables held at
  * once; 0 = as many as fit 1 GiB), "msm_precompute" / "msm_precompute_min" (window
  * tables at upload), "msm_graphs" (HIP-graph replay of repeated MSM calls; off), "msm_shard_rank" / "msm_shard_world" (window
@@ -107,6 +108,13 @@ int zkhip_bases_upload(zkhip_ctx *ctx, int curve, int group, const uint64_t *aff
 int zkhip_bases_upload_compressed(zkhip_ctx *ctx, int curve, int group, const uint8_t *octets, size_t n, zkhip_bases **out);
 int zkhip_bases_from_scalars(zkhip_ctx *ctx, int curve, int group, const uint64_t *base_affine_xy /* nullable */,
                              const uint64_t *scalars, size_t n, zkhip_bases **out);
+/* A bases object of n_total points holding src's points at the rows d_rows[j] (a DEVICE array of src's size; NULL: the consecutive rows
+ * first + j) and the point at infinity everywhere else, with its own window tables.  What it is for: queries of one proof that are
+ * multiplied by the same assignment vector -- A_query, the B query's G1 half (sparse: its index list is d_rows), L_query (the auxiliary
+ * part: first = n + 1) -- laid out over the SAME rows share one digit extraction and sort in zkhip_msm_batch_dev ("msm_share_sort").
+ * A row beyond n_total raises the gather flag of zkhip_device_status. */
+int zkhip_bases_spread(zkhip_ctx *ctx, const zkhip_bases *src, const uint32_t *d_rows /* nullable */, size_t first, size_t n_total,
+                       zkhip_bases **out);
 int zkhip_bases_download(zkhip_ctx *ctx, const zkhip_bases *b, size_t offset, size_t n, uint64_t *affine_xy, uint8_t *is_infinity);
 size_t zkhip_bases_size(const zkhip_bases *b);
 void zkhip_bases_free(zkhip_ctx *ctx, zkhip_bases *b);

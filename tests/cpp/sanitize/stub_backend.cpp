@@ -107,6 +107,10 @@ int zkhip_bases_from_scalars(zkhip_ctx *, int curve, int group, const uint64_t *
     for (size_t i = 0; i < 4 * n; ++i) acc += scalars[i];
     return new_bases(curve, group, n, out);
 }
+int zkhip_bases_spread(zkhip_ctx *, const zkhip_bases *src, const uint32_t *, size_t first, size_t n_total, zkhip_bases **out) {
+    if (first > n_total) return ZKHIP_ERR_RANGE;
+    return new_bases(src->curve, src->group, n_total, out);
+}
 int zkhip_bases_download(zkhip_ctx *, const zkhip_bases *b, size_t offset, size_t n, uint64_t *xy, uint8_t *inf) {
     if (offset + n > b->n) return ZKHIP_ERR_RANGE;
     memset(xy, 0, n * 2 * coord_limbs(b->curve, b->group) * 8);

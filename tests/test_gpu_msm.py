@@ -288,6 +288,61 @@ def test_msm_large_other_configs(ctx, zk, curve, group, log_n):
     b.free()
 
 
+@pytest.mark.parametrize("curve,group,log_n", [(0, 1, 15), (1, 1, 13), (0, 2, 13)])
+def test_batch_members_over_the_same_scalars_share_one_sort(ctx, zk, curve, group, log_n):
+    """Queries laid out over the same rows (zkhip_bases_spread) and multiplied by the same vector -- A, the dense B.h, the padded L of
+    one proof -- share the digit extraction / sort / large-bucket plan of a batch ("msm_share_sort"): the results equal those of the
+    original objects over their own (gathered / offset) scalars, with the option on and off."""
+    n = 1 << log_n
+    rng = np.random.default_rng(5)
+    a = ctx.bases_from_scalars(curve, group, cp.random_fr(curve, 21, n))
+    rows = np.sort(rng.choice(n, size=n - n // 16, replace=False)).astype(np.uint32)    # a sparse query: its index list
+    sparse = ctx.bases_from_scalars(curve, group, cp.random_fr(curve, 22, len(rows)))
+    first = 11
+    tail = ctx.bases_from_scalars(curve, group, cp.random_fr(curve, 23, n - first))     # the auxiliary part
+    d_rows = ctx.malloc(rows.nbytes)
+    ctx.h2d(d_rows, rows)
+    sparse_rows, tail_rows = sparse.spread(n, d_rows=d_rows), tail.spread(n, first=first)
+    # the spread objects hold the same points at the named rows and infinity elsewhere
+    pts, inf = sparse_rows.download()
+    src, _ = sparse.download()
+    assert (pts[rows] == src).all() and not inf[rows].any() and inf.sum() == n - len(rows)
+    pts, inf = tail_rows.download()
+    src, _ = tail.download()
+    assert (pts[first:] == src).all() and inf[:first].all() and not inf[first:].any()
+    sc = cp.random_fr(curve, 24, n)
+    sc[: n // 4, :] = 0
+    sc[: n // 8, 0] = 1    # Groth16-like: zeros and ones (the large-bucket plan is shared, too)
+    jac = 3 * zk.coord_limbs(curve, group) * 8
+    d_s, d_g, d_out = ctx.malloc(n * 32), ctx.malloc(len(rows) * 32), ctx.malloc(6 * jac)
+    ctx.h2d(d_s, sc)
+    ctx.h2d(d_g, np.ascontiguousarray(sc[rows]))
+    # the reference arrangement: every object over its own scalars
+    ctx.msm_dev(a, d_s, d_out)
+    ctx.msm_dev(sparse, d_g, d_out + jac)
+    ctx.msm_dev(tail, d_s + 32 * first, d_out + 2 * jac)
+    want = np.zeros((3, jac // 8), dtype=np.uint64)
+    ctx.d2h(want, d_out)
+    want = [ctx.jacobian_to_affine(curve, group, w) for w in want]
+    for share in (1, 0):
+        ctx.set_option("msm_share_sort", share)
+        ctx.msm_batch_dev([a, sparse_rows, tail_rows], [d_s, d_s, d_s], [d_out + 3 * jac, d_out + 4 * jac, d_out + 5 * jac])
+        got = np.zeros((6, jac // 8), dtype=np.uint64)
+        ctx.d2h(got, d_out)
+        for k in range(3):
+            g_aff, g_inf = ctx.jacobian_to_affine(curve, group, got[3 + k])
+            assert g_inf == want[k][1] and (g_aff == want[k][0]).all(), (share, k)
+    ctx.set_option("msm_share_sort", 1)
+    if log_n <= 13:    # and against the oracle
+        p, _ = a.download()
+        exp, einf = cp.msm(curve, group, p, sc, chunks=2)
+        assert want[0][1] == einf and (want[0][0] == exp).all()
+    for d in (d_rows, d_s, d_g, d_out):
+        ctx.free(d)
+    for b in (a, sparse, tail, sparse_rows, tail_rows):
+        b.free()
+
+
 # M + n + 1: 2^4+3 -> step(20); 2^10+11 -> step(2^10+16); 54 -> basic(64); 4096 -> basic; 65 -> step(64 + 1);
 # 2^11+256 -> step, 256 columns; 2^12+1000 -> step(2^12 + 2^10): column tiles; 2^15+16 -> step
 @pytest.mark.parametrize("curve,M,n", [(0, 16, 2), (1, 1024, 10), (0, 1024, 10), (0, 50, 3), (0, 4085, 10), (1, 60, 4), (0, 2048 + 250, 5),
