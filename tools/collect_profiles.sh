@@ -29,4 +29,7 @@ python3 tools/bench_groth16.py --steps 6 --domain basic 2>/dev/null | tail -1 > 
 ./tools/lpc_shim_bench 20 16 16 > gpurun_out/${R}_lpc_shim_bench.txt 2>&1
 python3 tools/bench_kzg.py 2>/dev/null | tail -1 > gpurun_out/${R}_kzg_commit_50x2p20.json
 python3 tools/bench_ntt.py 2>/dev/null | tail -1 > gpurun_out/${R}_ntt_2p22x8.json
+( python3 tools/bench_ecntt.py 12 16 18 20; python3 tools/bench_ecntt.py 12 14 --g2; python3 tools/bench_ecntt.py 16 --curve1 ) > gpurun_out/${R}_ecntt.txt 2>/dev/null
+python3 tools/groth16_two_provers.py 2>/dev/null | tail -1 > gpurun_out/${R}_groth16_two_provers.json
+python3 tools/bench_groth16.py --steps 6 --curve 1 2>/dev/null | tail -1 > gpurun_out/${R}_groth16_2p20_bn254_shim.json
 ls -la gpurun_out | tail -20
