@@ -316,7 +316,7 @@ def main():
             valu = (traffic or {}).get("valu", {}).get("msm_bucket_acc")
             # BASELINE cfg 4's instance (M = 2^20, n = 10) over the domain the reference reduces over (step radix-2, 2^20 + 16 points),
             # the same instance over the basic domain of 2^21 points (round 2's figure), and the m = 2^20 variant (M = 2^20 - 11)
-            line["groth16"] = groth16_leg(np, steps=8, verify=not args.no_verify, valu=valu)
+            line["groth16"] = groth16_leg(np, steps=8, verify=not args.no_verify, valu=valu, lanes=2)
             line["groth16_basic_2p21"] = groth16_leg(np, steps=6, verify=not args.no_verify, domain="basic", valu=valu)
             line["groth16_m2p20"] = groth16_leg(np, constraints=(1 << 20) - 11, steps=6, verify=not args.no_verify, valu=valu)
         if g16_sharded is not None:
@@ -533,7 +533,7 @@ def _bench_lib():
     return ctypes.CDLL(so)
 
 
-def groth16_leg(np, constraints=1 << 20, inputs=10, steps=4, verify=True, domain="ref", valu=None):
+def groth16_leg(np, constraints=1 << 20, inputs=10, steps=4, verify=True, domain="ref", valu=None, lanes=1):
     """The other half of BASELINE.json's metric: Groth16 prove constraints/s on one GPU (config 4's single-GPU leg: M = 2^20,
     n = 10) through the header-only shim, assignment H2D and result D2H included.  domain = "ref": the evaluation domain the
     reference reduces over, make_evaluation_domain(M + n + 1) (r1cs_to_qap.hpp:229-230) -- for M = 2^20, n = 10 the step radix-2
@@ -555,14 +555,18 @@ def groth16_leg(np, constraints=1 << 20, inputs=10, steps=4, verify=True, domain
     verified = ctypes.c_int(-1)
     prof = ctypes.create_string_buffer(16384)
     lib.zkhip_bench_set_domain(0 if domain == "basic" else -1, ctypes.c_size_t(m if domain == "basic" else 0))
+    lib.zkhip_bench_set_lanes(int(lanes))
     try:
         rc = lib.zkhip_bench_groth16(0, 0, ctypes.c_size_t(M), ctypes.c_size_t(inputs), ctypes.c_uint64(1), steps, omega.ctypes.data_as(ctypes.c_void_p),
                                      coset.ctypes.data_as(ctypes.c_void_p), times.ctypes.data_as(ctypes.c_void_p), ctypes.byref(setup),
                                      ctypes.byref(verified) if verify else None, prof, ctypes.c_size_t(16384))
     finally:
         lib.zkhip_bench_set_domain(-1, ctypes.c_size_t(0))
+        lib.zkhip_bench_set_lanes(1)
     if rc != 0:
         return {"error": rc}
+    lane_info = np.zeros(4, dtype=np.float64)
+    lib.zkhip_bench_last_lanes(lane_info.ctypes.data_as(ctypes.c_void_p))
     info = np.zeros(8, dtype=np.uint64)
     lib.zkhip_bench_last_info(info.ctypes.data_as(ctypes.c_void_p))
     kind, dm, qa, qb, qh, ql = (int(x) for x in info[:6])
@@ -586,6 +590,13 @@ def groth16_leg(np, constraints=1 << 20, inputs=10, steps=4, verify=True, domain
                             (100 * sum(v for k, v in kern.items() if k.startswith("msm_bucket_acc")) / tot)}
     if valu:
         roof["valu"] = dict(valu, note="msm_bucket_acc<G1> as measured by this run's PMC child pass (the same kernel a proof spends most of its time in)")
+    lanes_obj = None
+    if lane_info[0] > 1:
+        lanes_obj = {"lanes": int(lane_info[0]), "proofs_per_s": round(float(lane_info[1]), 2), "constraints_per_s": round(float(lane_info[1]) * M, 1),
+                     "ms_per_proof_seen_by_a_lane": round(float(lane_info[2]), 2), "every_proof_equals_the_verified_one": bool(lane_info[3] == 1),
+                     "what": "the THROUGHPUT arrangement, not the headline: %d provers at once on %d host threads over the SAME resident key "
+                             "(r1cs_gg_ppzksnark_proving_key_hip lane constructor: the queries are shared in HBM, each lane has its own streams and "
+                             "work buffers), %d proofs each; they fill each other's latency-bound phases" % (int(lane_info[0]), int(lane_info[0]), steps)}
     return {"metric": "Groth16 prove constraints/sec, BLS12-381, %d constraints, 1 GPU" % M, "value": round(M / mean * 1e3, 1),
             "unit": "constraints/s", "statistic": "mean of the proofs after the first", "ms_per_proof": [round(float(x), 2) for x in times],
             "domain": {"kind": ("basic_radix2", "extended_radix2", "step_radix2")[kind], "points": dm,
@@ -594,7 +605,7 @@ def groth16_leg(np, constraints=1 << 20, inputs=10, steps=4, verify=True, domain
             "key": "valid Groth16 key, generated on the device from a fixed trapdoor (r1cs_gg_ppzksnark_generator_hip), resident",
             "key_setup_ms": round(setup.value, 1), "verified": None if not verify else bool(verified.value == 1),
             "verification": "proof == (a G1, b G2, c G1) with a, b, c from the trapdoor identities (prover.hpp:141-153)",
-            "roofline": roof, "kernel_ms_last_proof": kern}
+            "roofline": roof, "kernel_ms_last_proof": kern, **({"lanes_over_one_key": lanes_obj} if lanes_obj else {})}
 
 
 def _last_domain(np, lib):

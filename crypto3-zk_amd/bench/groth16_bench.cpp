@@ -6,6 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <atomic>
+#include <memory>
 #include <vector>
 
 #include <nil/crypto3/zk/hip/r1cs_gg_ppzksnark_generator.hpp>
@@ -45,6 +48,8 @@ bool g_partial_only = false;
 // called between key generation and the timed proofs (tools/groth16_two_provers.py lines its threads up there)
 typedef void (*after_setup_fn)();
 after_setup_fn g_after_setup = nullptr;
+int g_lanes = 1;
+double g_lanes_info[4] = {0, 0, 0, 0};
 // the evaluation domain the next runs name (kind < 0: make_evaluation_domain's choice, the default) and what the last run used
 int g_dom_kind = -1;
 size_t g_dom_m = 0;
@@ -143,6 +148,36 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
         else if (!(proof.g_A == first.g_A && proof.g_B == first.g_B && proof.g_C == first.g_C)) ++differing;    // same (r, s): every proof is THE proof
     }
     if (prof && prof_cap) zkhip_profile_dump(ctx.get(), prof, prof_cap);    // per-kernel HIP-event ms of the last proof
+    zkhip_profile_enable(ctx.get(), 0);
+    /* the throughput arrangement: g_lanes provers at once over the SAME resident key (lane keys alias its queries), one host thread each */
+    g_lanes_info[0] = g_lanes_info[1] = g_lanes_info[2] = g_lanes_info[3] = 0;
+    if (g_lanes > 1 && world == 1 && !g_gather_dev) {
+        std::vector<std::unique_ptr<context>> lane_ctx;
+        std::vector<std::unique_ptr<typename prover::proving_key_type>> lane_key;
+        for (int l = 1; l < g_lanes; ++l) {
+            lane_ctx.emplace_back(new context(device));
+            lane_key.emplace_back(new typename prover::proving_key_type(*lane_ctx.back(), dpk));
+        }
+        std::atomic<int> lane_differing {0};
+        auto run = [&](const typename prover::proving_key_type &key, int count) {
+            for (int k = 0; k < count; ++k) {
+                auto pv = prover::process(key, primary, auxiliary, r, s);
+                if (!(pv.g_A == first.g_A && pv.g_B == first.g_B && pv.g_C == first.g_C)) ++lane_differing;
+            }
+        };
+        for (auto &k : lane_key) run(*k, 1);    // every lane allocates its work buffers outside the timed region
+        const auto w0 = std::chrono::steady_clock::now();
+        std::vector<std::thread> th;
+        for (auto &k : lane_key) th.emplace_back([&, kp = k.get()]() { run(*kp, steps); });
+        run(dpk, steps);
+        for (auto &t : th) t.join();
+        const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+        differing += lane_differing;
+        g_lanes_info[0] = g_lanes;
+        g_lanes_info[1] = (double)g_lanes * steps / wall;    // proofs per second, all lanes
+        g_lanes_info[2] = wall / steps * 1e3;                // ms per proof seen by one lane
+        g_lanes_info[3] = lane_differing == 0 ? 1 : 0;
+    }
     if (getenv("ZKHIP_G16_PHASES"))
         fprintf(stderr, "proof phases (host ms): stage+launch %.3f | host products %.3f | wait %.3f | assemble %.3f\n", dpk.last_phase_ms[0],
                 dpk.last_phase_ms[1], dpk.last_phase_ms[2], dpk.last_phase_ms[3]);
@@ -162,6 +197,10 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
 extern "C" {
 
 void zkhip_bench_set_after_setup(void (*fn)()) { g_after_setup = fn; }
+/* lanes > 1: after the one-at-a-time proofs, zkhip_bench_groth16 runs `lanes` provers at once over the same key (steps proofs each);
+   zkhip_bench_last_lanes: {lanes, proofs per second over all lanes, wall ms per proof of one lane, 1 if every proof equalled the verified one} */
+void zkhip_bench_set_lanes(int lanes) { g_lanes = lanes < 1 ? 1 : lanes; }
+void zkhip_bench_last_lanes(double *out4) { memcpy(out4, g_lanes_info, sizeof(g_lanes_info)); }
 /* kind < 0: make_evaluation_domain(M + n + 1)'s choice (r1cs_to_qap.hpp:229-230); 0 with m = 2^k: the basic domain of that size */
 void zkhip_bench_set_domain(int kind, size_t m) {
     g_dom_kind = kind;

@@ -255,16 +255,27 @@ public:
         check(zkhip_bases_download(ctx_->get(), b_, i, 1, xy.data(), &inf), "zkhip_bases_download", ctx_->get());
         return G::from_affine(xy.data(), inf != 0);
     }
-    ~device_bases() {
-        if (b_) zkhip_bases_free(ctx_ ? ctx_->get() : nullptr, b_);
+    /// a second handle on the SAME resident points (they are read-only once built): for another prover lane on the same GPU
+    /// (its own context / stream); `o` keeps the ownership and must outlive the alias
+    static device_bases alias(const device_bases &o) {
+        device_bases r;
+        r.ctx_ = o.ctx_;
+        r.b_ = o.b_;
+        r.size_ = o.size_;
+        r.owner_ = false;
+        return r;
     }
-    device_bases(device_bases &&o) noexcept : ctx_(o.ctx_), b_(o.b_), size_(o.size_) { o.b_ = nullptr; }
+    ~device_bases() {
+        if (b_ && owner_) zkhip_bases_free(ctx_ ? ctx_->get() : nullptr, b_);
+    }
+    device_bases(device_bases &&o) noexcept : ctx_(o.ctx_), b_(o.b_), size_(o.size_), owner_(o.owner_) { o.b_ = nullptr; }
     device_bases &operator=(device_bases &&o) noexcept {
         if (this != &o) {
-            if (b_) zkhip_bases_free(ctx_ ? ctx_->get() : nullptr, b_);
+            if (b_ && owner_) zkhip_bases_free(ctx_ ? ctx_->get() : nullptr, b_);
             ctx_ = o.ctx_;
             b_ = o.b_;
             size_ = o.size_;
+            owner_ = o.owner_;
             o.b_ = nullptr;
         }
         return *this;
@@ -278,6 +289,7 @@ private:
     const context *ctx_ = nullptr;
     zkhip_bases *b_ = nullptr;
     std::size_t size_ = 0;
+    bool owner_ = true;
 };
 
 }    // namespace hip

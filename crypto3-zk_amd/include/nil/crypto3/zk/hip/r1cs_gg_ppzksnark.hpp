@@ -143,7 +143,12 @@ public:
                                 cf[0].data(), rp[1].data(), cl[1].data(), cf[1].data(), rp[2].data(), cl[2].data(), cf[2].data(), &r_),
               "zkhip_r1cs_upload", ctx.get());
     }
-    ~device_r1cs() { zkhip_r1cs_free(ctx_->get(), r_); }
+    /// a second handle on the same resident matrices (read-only after construction and set_domain), for another prover lane
+    struct alias_tag { };
+    device_r1cs(alias_tag, const device_r1cs &o) : ctx_(o.ctx_), min_size_(o.min_size_), r_(o.r_), owner_(false) { }
+    ~device_r1cs() {
+        if (owner_) zkhip_r1cs_free(ctx_->get(), r_);
+    }
     device_r1cs(const device_r1cs &) = delete;
     device_r1cs &operator=(const device_r1cs &) = delete;
     const zkhip_r1cs *get() const { return r_; }
@@ -159,6 +164,7 @@ private:
     const context *ctx_;
     std::size_t min_size_ = 0;
     zkhip_r1cs *r_ = nullptr;
+    bool owner_ = true;
 };
 
 // ---- reductions::r1cs_to_qap<F>::witness_map on the device ---------------------------------------------------
@@ -284,6 +290,23 @@ public:
         if (A_query.size() != shard.A_n || H_query.size() != shard.H_n || L_query.size() != shard.L_n) throw_query_sizes();
     }
 
+    /// A second prover LANE over the same key: the queries and the constraint system of `other` are shared where they lie in HBM
+    /// (nothing is copied; they are read-only), the lane has its own context / stream, work buffers and G2 stream.  Two host threads,
+    /// one proving over `other` and one over the lane, fill each other's latency-bound phases: 2^20 constraints, one MI355X:
+    /// 51-52 proofs/s against 44-45 one at a time (tools/groth16_two_provers.py).  `other` must outlive the lane and must not be
+    /// proving while the lane is constructed.
+    r1cs_gg_ppzksnark_proving_key_hip(const context &lane_ctx, const r1cs_gg_ppzksnark_proving_key_hip &other) :
+        ctx(lane_ctx), host(other.host), domain(other.domain), evaluation_domain(other.evaluation_domain),
+        A_query((other.align_rows(), device_bases<CurveType, ZKHIP_G1>::alias(other.A_query))),
+        H_query(device_bases<CurveType, ZKHIP_G1>::alias(other.H_query)), L_query(device_bases<CurveType, ZKHIP_G1>::alias(other.L_query)),
+        B_query_h(device_bases<CurveType, ZKHIP_G1>::alias(other.B_query_h)), B_query_g(device_bases<CurveType, ZKHIP_G2>::alias(other.B_query_g)),
+        constraint_system(typename device_r1cs<CurveType>::alias_tag(), other.constraint_system), d_B_indices(other.d_B_indices),
+        B_count(other.B_count), shard(other.shard), share_sorts(other.share_sorts), L_rows_aligned(other.L_rows_aligned),
+        B_rows_aligned(other.B_rows_aligned), overlap_g2(other.overlap_g2), side_stream_priority(other.side_stream_priority),
+        direct_assignment_upload(other.direct_assignment_upload) {
+        if (lane_ctx.device() != other.ctx.device()) throw std::invalid_argument("proving key lane: the lane's context is on another GPU than the key");
+    }
+
     const context &ctx;
     const host_key_type &host;
     domain_params<CurveType> domain;
@@ -324,19 +347,21 @@ public:
     mutable double last_phase_ms[4] = {0, 0, 0, 0};
     mutable std::unique_ptr<context> side;
     mutable std::int64_t saved_sort_tile_log = 14;    // the caller's "msm_sort_tile_log", set aside for the duration of a proof
+    /// lays L_query and (when dense) the B query's G1 half out over A_query's rows -- see share_sorts; once, before the first proof
+    void align_rows() const {
+        if (!share_sorts || shard.world != 1 || L_rows_aligned) return;
+        const std::size_t N = host.constraint_system.num_variables(), n = host.constraint_system.num_inputs();
+        if (L_query.size() != N - n || A_query.size() != N + 1) return;
+        L_query = L_query.spread(nullptr, n + 1, N + 1);
+        L_rows_aligned = true;
+        if (B_count == B_query_h.size() && (B_count + 64 >= N + 1 || B_count * 64 >= (N + 1) * 63)) {
+            B_query_h = B_query_h.spread(d_B_indices.get(), 0, N + 1);
+            B_rows_aligned = true;
+        }
+    }
     void reserve_work(std::size_t cpa_elems, std::size_t degree, std::size_t result_bytes) const {
         if (d_cpa && work_cpa_ >= cpa_elems) return;
-        if (share_sorts && shard.world == 1 && !L_rows_aligned) {
-            const std::size_t N = host.constraint_system.num_variables(), n = host.constraint_system.num_inputs();
-            if (L_query.size() == N - n && A_query.size() == N + 1) {
-                L_query = L_query.spread(nullptr, n + 1, N + 1);
-                L_rows_aligned = true;
-                if (B_count == B_query_h.size() && (B_count + 64 >= N + 1 || B_count * 64 >= (N + 1) * 63)) {
-                    B_query_h = B_query_h.spread(d_B_indices.get(), 0, N + 1);
-                    B_rows_aligned = true;
-                }
-            }
-        }
+        align_rows();
         d_cpa = ctx.alloc(cpa_elems * 32);
         {
             void *hp = nullptr;

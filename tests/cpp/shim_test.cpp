@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <thread>
+#include <atomic>
 #include <vector>
 
 #include <nil/crypto3/zk/hip/kzg.hpp>
@@ -172,6 +174,22 @@ int groth16_prove_t(size_t M, size_t n, size_t N, const uint32_t *const rowptr[3
     // the randomised overload must run too (its output is not comparable)
     auto p2 = r1cs_gg_ppzksnark_prover_hip<Curve>::process(dpk, primary, auxiliary);
     if (p2.g_A.is_zero()) return -101;
+    // a second prover lane over the same resident key (own context / stream / work buffers), both proving at once from two threads
+    {
+        context ctx2(0);
+        r1cs_gg_ppzksnark_proving_key_hip<Curve> lane(ctx2, dpk);
+        std::atomic<int> bad {0};
+        auto prove = [&](const r1cs_gg_ppzksnark_proving_key_hip<Curve> &key) {
+            for (int k = 0; k < 3; ++k) {
+                auto pv = r1cs_gg_ppzksnark_prover_hip<Curve>::process(key, primary, auxiliary, A::scalar_from_limbs(r), A::scalar_from_limbs(s));
+                if (!(pv.g_A == proof_v.g_A) || !(pv.g_B == proof_v.g_B) || !(pv.g_C == proof_v.g_C)) ++bad;
+            }
+        };
+        std::thread other([&]() { prove(lane); });
+        prove(dpk);
+        other.join();
+        if (bad) return -105;
+    }
     // the same key held in structs declared like the reference's own (distinct types, same member names): consumed in place
     {
         ref_like::r1cs_gg_ppzksnark_proving_key<A> rk;
