@@ -10,6 +10,7 @@
 #include <functional>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <nil/crypto3/zk/hip/lpc.hpp>
@@ -107,6 +108,16 @@ void groth16_host_paths(std::size_t M) {
     pk.B_query.domain_size_ = N + 1;
     r1cs_gg_ppzksnark_proving_key_hip<Curve> whole(ctx, pk, dom);
     (void)prover::process(whole, primary, auxiliary, Fr(3), Fr(4));
+    {
+        /* two prover lanes over one key, proving at once on two threads (TSan: what the lanes share is read-only) */
+        context ctx2(0);
+        r1cs_gg_ppzksnark_proving_key_hip<Curve> lane(ctx2, whole);
+        std::thread other([&]() {
+            for (int k = 0; k < 2; ++k) (void)prover::process(lane, primary, auxiliary, Fr(3), Fr(4));
+        });
+        for (int k = 0; k < 2; ++k) (void)prover::process(whole, primary, auxiliary);
+        other.join();
+    }
     std::vector<std::uint64_t> gathered;
     for (std::size_t rank = 0; rank < 2; ++rank) {
         r1cs_gg_ppzksnark_proving_key_hip<Curve> part(ctx, pk, dom, rank, 2);
