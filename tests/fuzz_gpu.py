@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Randomised differential run of the device path against the CPU oracle (checker only), for a time budget:
+    python tests/fuzz_gpu.py [--seconds 300] [--seed 1]        (test infrastructure: it calls the oracle, so it lives under tests/)
+Every iteration draws a shape the fixed tests do not enumerate -- curve, group, size (1 .. 6000, not only powers of two), offset,
+scalar pattern (uniform, zeros / ones heavy, r - 1, few distinct values = large buckets, tiny values), MSM one by one / as a batch /
+as a batch whose members share a sort, NTT size / batch / direction / coset, evaluation domain of any kind, Groth16 witness map over the
+domain make_evaluation_domain picks -- and compares bit for bit.  Exit code 0 and a JSON line with the counts = no difference."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench  # noqa: E402
+import cport as cp  # noqa: E402
+import pyoracle as po  # noqa: E402
+from util import CURVES, limbs, qap_domains  # noqa: E402
+
+
+def scalars(rng, curve, n, pattern):
+    r = CURVES[curve].r
+    s = cp.random_fr(curve, int(rng.integers(1, 1 << 30)), n)
+    if pattern == "zeros_ones":
+        k = rng.integers(0, 3, size=n)
+        s[k == 0] = 0
+        s[k == 1] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    elif pattern == "minus_one":
+        idx = rng.random(n) < 0.3
+        s[idx] = np.array(po.to_limbs(r - 1, 4), dtype=np.uint64)
+    elif pattern == "few_values":
+        vals = cp.random_fr(curve, int(rng.integers(1, 1 << 30)), 3)
+        s = vals[rng.integers(0, 3, size=n)]
+    elif pattern == "tiny":
+        s[:, 1:] = 0
+        s[:, 0] &= np.uint64(0xFFFF)
+    return np.ascontiguousarray(s)
+
+
+def fuzz_msm(zk, ctx, rng, stats):
+    curve, group = int(rng.integers(0, 2)), int(rng.integers(1, 3))
+    n = int(rng.integers(1, 6000 if group == 1 else 1500))
+    b = ctx.bases_from_scalars(curve, group, cp.random_fr(curve, int(rng.integers(1, 1 << 30)), n))
+    pts, inf = b.download()
+    off = int(rng.integers(0, n)) if rng.random() < 0.3 else 0
+    cnt = n - off
+    pattern = ["uniform", "zeros_ones", "minus_one", "few_values", "tiny"][int(rng.integers(0, 5))]
+    sc = scalars(rng, curve, cnt, pattern)
+    jac = 3 * zk.coord_limbs(curve, group) * 8
+    d_s, d_o = ctx.malloc(max(1, cnt) * 32), ctx.malloc(3 * jac)
+    ctx.h2d(d_s, sc)
+    mode = int(rng.integers(0, 3))
+    res = np.zeros((3, jac // 8), dtype=np.uint64)
+    if mode == 0:
+        ctx.msm_dev(b, d_s, d_o, offset=off, n=cnt)
+        ctx.d2h(res, d_o)
+        got = [res[0]]
+        want = [(pts[off:], inf[off:], sc)]
+    else:
+        # a batch of three members over the same bases: mode 1 different scalars (rotations), mode 2 the SAME scalars (shared sort)
+        d_s2, d_s3 = ctx.malloc(max(1, cnt) * 32), ctx.malloc(max(1, cnt) * 32)
+        sc2, sc3 = (np.roll(sc, 1, axis=0), np.roll(sc, 2, axis=0)) if mode == 1 else (sc, sc)
+        ctx.h2d(d_s2, sc2)
+        ctx.h2d(d_s3, sc3)
+        ptrs = [d_s, d_s2, d_s3] if mode == 1 else [d_s, d_s, d_s]
+        ctx.set_option("msm_share_sort", int(rng.integers(0, 2)))
+        ctx.msm_batch_dev([b, b, b], ptrs, [d_o, d_o + jac, d_o + 2 * jac], offsets=[off] * 3, ns=[cnt] * 3)
+        ctx.set_option("msm_share_sort", 1)
+        ctx.d2h(res, d_o)
+        got = [res[0], res[1], res[2]]
+        want = [(pts[off:], inf[off:], x) for x in (sc, sc2, sc3)]
+        ctx.free(d_s2)
+        ctx.free(d_s3)
+    for g, (p, i, s) in zip(got, want):
+        aff, ginf = ctx.jacobian_to_affine(curve, group, g)
+        exp, einf = cp.msm(curve, group, p, s, inf=i, chunks=1 + int(rng.integers(0, 3)))
+        if bool(ginf) != bool(einf) or (not einf and not (aff == exp).all()):
+            raise SystemExit("MSM differs: curve %d group %d n %d off %d pattern %s mode %d" % (curve, group, n, off, pattern, mode))
+    ctx.free(d_s)
+    ctx.free(d_o)
+    b.free()
+    stats["msm"] += len(got)
+
+
+def fuzz_ntt(zk, ctx, rng, stats):
+    curve = int(rng.integers(0, 2))
+    C = CURVES[curve]
+    log_m, batch = int(rng.integers(0, 15)), int(rng.integers(1, 5))
+    w = limbs(C.root_of_unity(log_m), 4)
+    a = cp.random_fr(curve, int(rng.integers(1, 1 << 30)), batch << log_m).reshape(batch, 1 << log_m, 4)
+    inverse, coset = bool(rng.integers(0, 2)), (limbs(C.fr_generator, 4) if rng.random() < 0.5 else None)
+    got = ctx.ntt(curve, a, log_m, w, inverse=inverse, coset=coset)
+    exp = cp.ntt(curve, a, log_m, w, inverse=inverse, coset=coset)
+    if not (got == exp).all():
+        raise SystemExit("NTT differs: curve %d log_m %d batch %d inverse %d coset %d" % (curve, log_m, batch, inverse, coset is not None))
+    stats["ntt"] += 1
+
+
+def fuzz_domain(zk, ctx, rng, stats):
+    curve = int(rng.integers(0, 2))
+    n = int(rng.integers(2, 20000))
+    two_adicity = int(rng.integers(2, 12)) if rng.random() < 0.25 else None
+    try:
+        dom, zd = qap_domains(zk, curve, n, two_adicity=two_adicity)
+    except Exception:
+        stats["domain_skipped"] += 1  # no radix-2 domain of that size under the pretended two-adicity
+        return
+    m = dom.m
+    batch = int(rng.integers(1, 4))
+    a = cp.random_fr(curve, int(rng.integers(1, 1 << 30)), batch * m).reshape(batch, m, 4)
+    sh = limbs(dom.shift, 4)
+    exp = np.stack([cp.domain_fft(curve, dom.kind, a[b], limbs(dom.omega, 4), sh) for b in range(batch)])
+    got = ctx.domain_fft(curve, zd, a)
+    if not (got == exp).all() or not (ctx.domain_fft(curve, zd, got, inverse=True) == a).all():
+        raise SystemExit("domain transform differs: curve %d %s" % (curve, dom.describe()))
+    stats["domain"] += 1
+
+
+def fuzz_witness(zk, ctx, rng, stats):
+    curve = int(rng.integers(0, 2))
+    C = CURVES[curve]
+    M, nin = int(rng.integers(3, 5000)), int(rng.integers(1, 12))
+    g16 = cp.Groth16(curve, M, nin, seed=int(rng.integers(1, 1000)))
+    kind, m = cp.domain_choice(M + nin + 1, C.two_adicity)
+    wd = limbs(C.root_of_unity((M + nin).bit_length()), 4)
+    gen = limbs(C.fr_generator, 4)
+    g16.set_domain(kind, m, wd)
+    r1cs = ctx.upload_r1cs(curve, g16.M, g16.n, g16.N, g16.csr(0), g16.csr(1), g16.csr(2))
+    z = np.concatenate([np.array([[1, 0, 0, 0]], dtype=np.uint64), g16.assignment()])
+    if (r1cs.kind, r1cs.m) != (kind, m) or not (ctx.groth16_witness_h(r1cs, z, wd, gen) == g16.witness_map(wd, gen)).all():
+        raise SystemExit("witness map differs: curve %d M %d n %d" % (curve, M, nin))
+    r1cs.free()
+    stats["witness_map"] += 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    zk = bench.load_pkg()
+    ctx = zk.Context(0)
+    rng = np.random.default_rng(a.seed)
+    stats = {"msm": 0, "ntt": 0, "domain": 0, "domain_skipped": 0, "witness_map": 0}
+    legs = [fuzz_msm, fuzz_msm, fuzz_ntt, fuzz_domain, fuzz_witness]
+    t0 = time.time()
+    while time.time() - t0 < a.seconds:
+        legs[int(rng.integers(0, len(legs)))](zk, ctx, rng, stats)
+    ctx.close()
+    print(json.dumps({"fuzz": "device path against the CPU oracle, bit for bit", "seed": a.seed, "seconds": round(time.time() - t0, 1), "compared": stats,
+                      "differences": 0}))
+
+
+if __name__ == "__main__":
+    main()
