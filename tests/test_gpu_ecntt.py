@@ -23,7 +23,7 @@ def _jac_of(curve, group, scalars):
     return out
 
 
-@pytest.mark.parametrize("curve,group,log_m", [(0, 1, 0), (0, 1, 1), (0, 1, 4), (1, 1, 6), (0, 2, 3), (1, 2, 2), (0, 1, 8), (0, 1, 11), (1, 2, 7), (1, 1, 9)])
+@pytest.mark.parametrize("curve,group,log_m", [(0, 1, 0), (0, 1, 1), (0, 1, 4), (1, 1, 6), (0, 2, 3), (1, 2, 2), (0, 1, 8), (0, 1, 11), (1, 2, 7), (1, 1, 9), (0, 1, 13), (1, 1, 14), (0, 2, 9)])
 def test_ec_ntt_lagrange_basis(ctx, curve, group, log_m):
     C = CURVES[curve]
     r, m = C.r, 1 << log_m
