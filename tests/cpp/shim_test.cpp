@@ -14,6 +14,7 @@
 #include <nil/crypto3/zk/hip/fri.hpp>
 #include <nil/crypto3/zk/hip/knowledge_commitment_multiexp.hpp>
 #include <nil/crypto3/zk/hip/kzg_v2.hpp>
+#include <nil/crypto3/zk/hip/kzg_batched.hpp>
 #include <nil/crypto3/zk/hip/lpc.hpp>
 #include <nil/crypto3/zk/hip/marshalling.hpp>
 #include <nil/crypto3/zk/hip/powers_of_tau.hpp>
@@ -428,6 +429,43 @@ int kzg_v1_t(const uint64_t *srs, size_t n_srs, const uint64_t *vk, size_t n_vk,
     scripted_transcript<Curve> tr2;
     tr2.challenges = tr.challenges;
     if (!scheme.verify_eval(proof, scheme.packed_commitments(), tr2) || verify_calls != 1) return -9;
+    return 0;
+}
+
+/// The free-function batched scheme (batched_kzg, kzg.hpp:223-630) as the reference's batched_kzg_basic_test drives it
+/// (test/commitment/kzg.cpp:535-572): merge_eval_points, create_evals_polys, commit, public key, proof_eval.
+template <typename Curve>
+int kzg_batched_t(const uint64_t *srs, size_t n_srs, size_t npolys, const uint64_t *lens, const uint64_t *coeffs, const uint64_t *npts, const uint64_t *points,
+                  const uint64_t *gamma, uint64_t *commits, uint64_t *merged, uint64_t *n_merged, uint64_t *proof_out, uint64_t *absorbed) {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::g1_value_type G1;
+    typedef typename A::scalar_value_type Fr;
+    const size_t L1 = 2 * A::g1_coord_limbs;
+    context ctx(0);
+    std::vector<G1> ck;
+    for (size_t i = 0; i < n_srs; ++i) ck.push_back(G1::from_affine(srs + i * L1));
+    kzg_params_hip<Curve> params(ctx, ck.begin(), ck.end());
+    std::vector<std::vector<Fr>> polys(npolys), eval_points(npolys);
+    size_t at = 0, pt = 0;
+    for (size_t p = 0; p < npolys; ++p) {
+        for (size_t i = 0; i < lens[p]; ++i) polys[p].push_back(A::scalar_from_limbs(coeffs + 4 * at++));
+        for (size_t q = 0; q < npts[p]; ++q) eval_points[p].push_back(A::scalar_from_limbs(points + 4 * pt++));
+    }
+    const std::vector<Fr> merged_eval_points = kzg_batched_merge_eval_points<Curve>(eval_points);
+    const auto rs = kzg_batched_create_evals_polys<Curve>(polys, eval_points);
+    if (rs.size() != npolys) return -2;
+    for (size_t p = 0; p < npolys; ++p)    // BOOST_CHECK(polys[i].evaluate(s) == rs[i].evaluate(s)) (kzg.cpp:556-561)
+        for (const auto &sp : eval_points[p])
+            if (!(detail::small_poly<Fr>::evaluate(polys[p], sp) == detail::small_poly<Fr>::evaluate(rs[p], sp))) return -3;
+    kzg_batched_public_key_hip<Curve> pk {kzg_batched_commit<Curve>(params, polys), merged_eval_points, eval_points, rs};
+    for (size_t p = 0; p < npolys; ++p) pk.commits[p].to_affine(commits + p * L1);
+    *n_merged = merged_eval_points.size();
+    for (size_t i = 0; i < merged_eval_points.size(); ++i) A::scalar_to_limbs(merged_eval_points[i], merged + 4 * i);
+    scripted_transcript<Curve> tr;
+    tr.challenges = {A::scalar_from_limbs(gamma)};
+    kzg_batched_proof_eval<Curve>(params, polys, pk, tr).to_affine(proof_out);
+    absorbed[0] = tr.absorbed_points;
+    absorbed[1] = tr.absorbed_scalars;
     return 0;
 }
 
@@ -1051,6 +1089,18 @@ int shim_kzg_v1_proof_eval(int curve, const uint64_t *srs, size_t n_srs, const u
                                        proof_out, g2_out, absorbed);
     } catch (const std::exception &e) {
         fprintf(stderr, "shim_kzg_v1_proof_eval: %s\n", e.what());
+        return -1;
+    }
+}
+
+int shim_kzg_batched(int curve, const uint64_t *srs, size_t n_srs, size_t npolys, const uint64_t *lens, const uint64_t *coeffs, const uint64_t *npts,
+                     const uint64_t *points, const uint64_t *gamma, uint64_t *commits, uint64_t *merged, uint64_t *n_merged, uint64_t *proof_out,
+                     uint64_t *absorbed) {
+    try {
+        if (curve == ZKHIP_BLS12_381) return kzg_batched_t<bls12_381>(srs, n_srs, npolys, lens, coeffs, npts, points, gamma, commits, merged, n_merged, proof_out, absorbed);
+        return kzg_batched_t<alt_bn128_254>(srs, n_srs, npolys, lens, coeffs, npts, points, gamma, commits, merged, n_merged, proof_out, absorbed);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "shim_kzg_batched: %s\n", e.what());
         return -1;
     }
 }

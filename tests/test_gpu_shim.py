@@ -229,6 +229,52 @@ def _vk(curve, alpha, n):
 
 
 @pytest.mark.parametrize("curve", [0, 1])
+def test_kzg_batched_free_functions_shim(shim, curve):
+    """batched_kzg's algorithms (kzg.hpp:322-630) as free functions over coefficient-form polynomials: first the reference's own
+    batched_kzg_basic_test inputs (test/commitment/kzg.cpp:535-572: f = 1 + 2X + ... + 8X^7, alpha = 7, S = {101, 2, 3}), then a
+    ragged batch (different lengths and point sets, a polynomial shorter than its point set, shared points): commitments,
+    merged points, the transcript walk and the single quotient commitment against the oracle's restatement of proof_eval."""
+    C = CURVES[curve]
+    r = C.r
+    alpha = 7
+    rng = po.SplitMix64(311 + curve)
+    x1, x2, x3 = (rng.next_mod(r) for _ in range(3))
+    cases = [[([1, 2, 3, 4, 5, 6, 7, 8], [101, 2, 3])],
+             [([rng.next_mod(r) for _ in range(300)], [x1, x2]), ([rng.next_mod(r) for _ in range(77)], [x2]),
+              ([rng.next_mod(r) for _ in range(2)], [x3, x1, x2]), ([rng.next_mod(r) for _ in range(1024)], [x1, x2, x3]),
+              ([rng.next_mod(r) for _ in range(5)], [])]]
+    g = lambda v: cp.batch_mul(curve, 1, fr_arr([v % r]))[0][0]
+    u64 = lambda v: np.array(v, dtype=np.uint64)
+    for case in cases:
+        npolys = len(case)
+        n_srs = max(len(f) for f, _ in case)
+        srs = _srs(curve, alpha, n_srs)
+        gamma = rng.next_mod(r)
+        _, accum = po.kzg_v1_proof_eval(r, {0: [f for f, _ in case]}, {0: [pts for _, pts in case]}, gamma)
+        merged_exp = sorted({x for _, pts in case for x in pts})
+        commits = np.zeros((npolys, srs.shape[1]), dtype=np.uint64)
+        merged = np.zeros((max(1, len(merged_exp)) + 4, 4), dtype=np.uint64)
+        n_merged = np.zeros(1, dtype=np.uint64)
+        proof = np.zeros(srs.shape[1], dtype=np.uint64)
+        absorbed = np.zeros(2, dtype=np.uint64)
+        allpts = fr_arr([x for _, pts in case for x in pts]) if any(pts for _, pts in case) else np.zeros((1, 4), dtype=np.uint64)
+        rc = shim.shim_kzg_batched(curve, P(srs), ctypes.c_size_t(n_srs), ctypes.c_size_t(npolys), P(u64([len(f) for f, _ in case])),
+                                   P(fr_arr([c for f, _ in case for c in f])), P(u64([len(pts) for _, pts in case])), P(allpts), P(limbs(gamma, 4)),
+                                   P(commits), P(merged), P(n_merged), P(proof), P(absorbed))
+        assert rc == 0
+        for p, (f, _) in enumerate(case):
+            assert (commits[p] == g(po.poly_eval(f, alpha, r))).all(), p
+        assert int(n_merged[0]) == len(merged_exp) and [po.from_limbs(x) for x in merged[: len(merged_exp)]] == merged_exp
+        # update_transcript: every commitment, every point of every S, every coefficient of every r (:323-372)
+        # (r_i has |S_i| coefficients)
+        assert int(absorbed[0]) == npolys and int(absorbed[1]) == 2 * sum(len(pts) for _, pts in case)
+        assert any(accum)
+        e1, i1 = cp.msm(curve, 1, srs[: len(accum)], fr_arr(accum), chunks=2)
+        assert i1 == 0 and (proof == e1).all()
+        assert (proof == g(po.poly_eval(accum, alpha, r))).all()
+
+
+@pytest.mark.parametrize("curve", [0, 1])
 def test_kzg_v1_proof_eval_shim(shim, curve):
     """kzg_commitment_scheme (the first batched scheme, kzg.hpp:636-873): commit + proof_eval through the shim class against the
     oracle's restatement of :782-807 -- evaluations z, the single quotient commitment kzg_proof, the verifier's equation in
