@@ -4,7 +4,7 @@
 Every iteration draws a shape the fixed tests do not enumerate -- curve, group, size (1 .. 6000, not only powers of two), offset,
 scalar pattern (uniform, zeros / ones heavy, r - 1, few distinct values = large buckets, tiny values), MSM one by one / as a batch /
 as a batch whose members share a sort, NTT size / batch / direction / coset, evaluation domain of any kind, Groth16 witness map over the
-domain make_evaluation_domain picks -- and compares bit for bit.  Exit code 0 and a JSON line with the counts = no difference."""
+domain make_evaluation_domain picks, whole Groth16 proofs through the C++ shim -- and compares bit for bit.  Exit code 0 and a JSON line with the counts = no difference."""
 import argparse
 import json
 import os
@@ -138,6 +138,27 @@ def fuzz_witness(zk, ctx, rng, stats):
     stats["witness_map"] += 1
 
 
+_SHIM = {}
+
+
+def fuzz_proof(zk, ctx, rng, stats):
+    """one whole Groth16 proof through the header-only shim (key from the oracle's generator, uploaded; prover on the device) against the
+    oracle's prover -- random constraint count, input count, curve, evaluation domain (the reference's choice or the basic one)"""
+    import ctypes
+    import test_gpu_shim as tgs
+
+    if "lib" not in _SHIM:
+        _SHIM["lib"] = ctypes.CDLL(os.path.join(ROOT, "tests", "cpp", "libshimtest.so"))
+    curve, M, nin = int(rng.integers(0, 2)), int(rng.integers(13, 3000)), int(rng.integers(1, 12))
+    domain = "ref" if rng.random() < 0.7 else "basic"
+    try:
+        tgs._groth16_prover_shim(_SHIM["lib"], curve, M, nin, domain)
+    except AssertionError:
+        raise SystemExit("Groth16 proof differs: curve %d M %d n %d domain %s" % (curve, M, nin, domain))
+    del tgs._KEEP[:]
+    stats["groth16_proof"] += 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
@@ -146,8 +167,8 @@ def main():
     zk = bench.load_pkg()
     ctx = zk.Context(0)
     rng = np.random.default_rng(a.seed)
-    stats = {"msm": 0, "ntt": 0, "domain": 0, "domain_skipped": 0, "witness_map": 0}
-    legs = [fuzz_msm, fuzz_msm, fuzz_ntt, fuzz_domain, fuzz_witness]
+    stats = {"msm": 0, "ntt": 0, "domain": 0, "domain_skipped": 0, "witness_map": 0, "groth16_proof": 0}
+    legs = [fuzz_msm, fuzz_msm, fuzz_ntt, fuzz_domain, fuzz_witness, fuzz_proof]
     t0 = time.time()
     while time.time() - t0 < a.seconds:
         legs[int(rng.integers(0, len(legs)))](zk, ctx, rng, stats)
