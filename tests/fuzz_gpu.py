@@ -44,7 +44,7 @@ def scalars(rng, curve, n, pattern):
 
 def fuzz_msm(zk, ctx, rng, stats):
     curve, group = int(rng.integers(0, 2)), int(rng.integers(1, 3))
-    n = int(rng.integers(1, 6000 if group == 1 else 1500))
+    n = int(rng.integers(1, (6000 if group == 1 else 1500) * SCALE))
     b = ctx.bases_from_scalars(curve, group, cp.random_fr(curve, int(rng.integers(1, 1 << 30)), n))
     pts, inf = b.download()
     off = int(rng.integers(0, n)) if rng.random() < 0.3 else 0
@@ -90,7 +90,7 @@ def fuzz_msm(zk, ctx, rng, stats):
 def fuzz_ntt(zk, ctx, rng, stats):
     curve = int(rng.integers(0, 2))
     C = CURVES[curve]
-    log_m, batch = int(rng.integers(0, 15)), int(rng.integers(1, 5))
+    log_m, batch = int(rng.integers(0, 15 + (3 if SCALE > 1 else 0))), int(rng.integers(1, 5))
     w = limbs(C.root_of_unity(log_m), 4)
     a = cp.random_fr(curve, int(rng.integers(1, 1 << 30)), batch << log_m).reshape(batch, 1 << log_m, 4)
     inverse, coset = bool(rng.integers(0, 2)), (limbs(C.fr_generator, 4) if rng.random() < 0.5 else None)
@@ -103,7 +103,7 @@ def fuzz_ntt(zk, ctx, rng, stats):
 
 def fuzz_domain(zk, ctx, rng, stats):
     curve = int(rng.integers(0, 2))
-    n = int(rng.integers(2, 20000))
+    n = int(rng.integers(2, 20000 * SCALE))
     two_adicity = int(rng.integers(2, 12)) if rng.random() < 0.25 else None
     try:
         dom, zd = qap_domains(zk, curve, n, two_adicity=two_adicity)
@@ -124,7 +124,7 @@ def fuzz_domain(zk, ctx, rng, stats):
 def fuzz_witness(zk, ctx, rng, stats):
     curve = int(rng.integers(0, 2))
     C = CURVES[curve]
-    M, nin = int(rng.integers(3, 5000)), int(rng.integers(1, 12))
+    M, nin = int(rng.integers(3, 5000 * SCALE)), int(rng.integers(1, 12))
     g16 = cp.Groth16(curve, M, nin, seed=int(rng.integers(1, 1000)))
     kind, m = cp.domain_choice(M + nin + 1, C.two_adicity)
     wd = limbs(C.root_of_unity((M + nin).bit_length()), 4)
@@ -139,6 +139,7 @@ def fuzz_witness(zk, ctx, rng, stats):
 
 
 _SHIM = {}
+SCALE = 1    # --scale: multiplies the size ranges (16: MSMs up to 96 000 points, NTTs up to 2^17, domains up to 320 000, witness maps up to 80 000 constraints)
 
 
 def fuzz_proof(zk, ctx, rng, stats):
@@ -163,7 +164,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--scale", type=int, default=1, help="multiply the size ranges (larger, fewer cases)")
     a = ap.parse_args()
+    global SCALE
+    SCALE = max(1, a.scale)
     zk = bench.load_pkg()
     ctx = zk.Context(0)
     rng = np.random.default_rng(a.seed)
@@ -173,7 +177,7 @@ def main():
     while time.time() - t0 < a.seconds:
         legs[int(rng.integers(0, len(legs)))](zk, ctx, rng, stats)
     ctx.close()
-    print(json.dumps({"fuzz": "device path against the CPU oracle, bit for bit", "seed": a.seed, "seconds": round(time.time() - t0, 1), "compared": stats,
+    print(json.dumps({"fuzz": "device path against the CPU oracle, bit for bit", "seed": a.seed, "scale": SCALE, "seconds": round(time.time() - t0, 1), "compared": stats,
                       "differences": 0}))
 
 
