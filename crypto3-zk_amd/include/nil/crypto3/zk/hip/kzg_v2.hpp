@@ -231,7 +231,9 @@ public:
         const context &up = pipelined ? upload_context() : ctx;
         for (std::size_t i = 0; i < count;) {
             std::size_t j = i;
-            while (j < count && db.len[j] == db.len[i] && (upload_chunk == 0 || j - i < upload_chunk)) ++j;
+            /* the first chunk is a short one: nothing runs on the device until it has arrived */
+            const std::size_t limit = (pipelined && i == 0) ? std::max<std::size_t>(1, upload_chunk / 4) : upload_chunk;
+            while (j < count && db.len[j] == db.len[i] && (limit == 0 || j - i < limit)) ++j;
             for (std::size_t p = i; p < j; ++p) upload_scalars<adapter>(up, db.at(p), polys[p]->values.data(), polys[p]->size());
             if (pipelined) ctx.wait_for(up);
             std::size_t log_n = 0;
