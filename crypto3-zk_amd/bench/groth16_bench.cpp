@@ -108,6 +108,7 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
     std::vector<Fr> primary(full.begin(), full.begin() + n), auxiliary(full.begin() + n, full.end());
 
     context ctx(device);
+    if (const char *e = getenv("ZKHIP_G16_SEGMENT_LOG")) ctx.set_option("msm_segment_log", atoi(e));    // experiments: buckets per lane of the shared reduction
     if (const char *e = getenv("ZKHIP_G16_MAIN_PRIORITY")) ctx.set_option("stream_priority", atoi(e));    // experiments
     domain_params<Curve> dom {A::scalar_from_limbs(omega), A::scalar_from_limbs(coset)};
     dom.kind = g_dom_kind;
