@@ -282,6 +282,21 @@ struct curve_adapter<native_curve<Curve>> {
     }
     /// the scalar-field modulus r, canonical little-endian limbs (what rejection sampling of the blinders compares against)
     static void scalar_modulus(std::uint64_t *out) { scalar_value_type::modulus(out); }
+    /// fields::arithmetic_params<scalar_field_type>: multiplicative_generator, two-adicity s and the primitive 2^n-th root of unity
+    /// math::unity_root<F>(2^n) = generator^((r - 1) / 2^n) -- what the reference's domain classes read from crypto3-algebra / -math.
+    /// With them the shim offers the reference's own ARITIES (no domain constants, no context in the call): standard_domain_params,
+    /// the (pk) key constructor, witness_map(cs, x, w), the scheme classes' default roots.
+    static constexpr bool has_field_constants = true;
+    static constexpr unsigned two_adicity = Curve == ZKHIP_BLS12_381 ? 32 : 28;
+    static scalar_value_type multiplicative_generator() { return scalar_value_type(Curve == ZKHIP_BLS12_381 ? 7 : 5); }
+    static scalar_value_type root_of_unity(std::size_t log_n) {
+        if (log_n > two_adicity) throw std::invalid_argument("root_of_unity: the scalar field has no 2^n-th root of unity for this n");
+        const std::uint64_t top[2][4] = {{0x3829971f439f0d2bULL, 0xb63683508c2280b9ULL, 0xd09b681922c813b4ULL, 0x16a2a19edfe81f20ULL},
+                                         {0x9bd61b6e725b19f0ULL, 0x402d111e41112ed4ULL, 0x00e0a7eb8ef62abcULL, 0x2a3c09f0a58a7e85ULL}};
+        scalar_value_type w = scalar_from_limbs(top[Curve == ZKHIP_BLS12_381 ? 0 : 1]);    // generator^((r - 1) / 2^s)
+        for (std::size_t k = log_n; k < two_adicity; ++k) w = w * w;
+        return w;
+    }
     template <typename G>
     static bool point_to_affine_limbs(const G &p, std::uint64_t *out) { return p.to_affine(out); }
     static g1_value_type g1_from_jacobian(const std::uint64_t *xyz) { return g1_value_type::from_jacobian(xyz); }

@@ -68,6 +68,21 @@ struct domain_params {
     typename curve_adapter<CurveType>::scalar_value_type shift;              // extended radix-2: detail::coset_shift<F>()
 };
 
+/// The constants of the domain make_evaluation_domain(min_size) returns, from the adapter's field constants (curve_adapter::
+/// multiplicative_generator / root_of_unity: for the reference's curve types they forward to arithmetic_params<F> and math::unity_root,
+/// INTEGRATION.md): kind "auto", omega the primitive 2^ceil(log2 min_size)-th root, the extended domain's shift generator^2
+/// (detail::coset_shift<F>()).  What lets the entry points below take the reference's own argument lists.
+template <typename CurveType>
+domain_params<CurveType> standard_domain_params(std::size_t min_size) {
+    typedef curve_adapter<CurveType> adapter;
+    static_assert(adapter::has_field_constants, "this curve adapter does not provide multiplicative_generator() / root_of_unity()");
+    domain_params<CurveType> d;
+    d.omega = adapter::root_of_unity(detail::ceil_log2(min_size));
+    d.coset_generator = adapter::multiplicative_generator();
+    d.shift = d.coset_generator * d.coset_generator;
+    return d;
+}
+
 template <typename CurveType>
 class evaluation_domain_hip {
 public:

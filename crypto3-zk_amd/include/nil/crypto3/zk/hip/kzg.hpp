@@ -43,9 +43,23 @@ struct kzg_params_hip {
         ctx(ctx), commitment_key(ctx, ck_first, ck_last), verification_key(ctx, vk_first, vk_last) { }
     kzg_params_hip(const context &ctx, device_bases<CurveType, ZKHIP_G1> &&key, device_bases<CurveType, ZKHIP_G2> &&vkey) :
         ctx(ctx), commitment_key(std::move(key)), verification_key(std::move(vkey)) { }
+    /// params_type(d, t, alpha) (kzg.hpp:262-275, what the reference's tests construct): the powers alpha^i G1, i < d, and alpha^i G2,
+    /// i <= t, computed on the device (fixed-base batch exponentiation) on the calling thread's default context
+    kzg_params_hip(std::size_t d, std::size_t t, const typename curve_adapter<CurveType>::scalar_value_type &alpha) :
+        ctx(default_context()), commitment_key(powers_of<ZKHIP_G1>(default_context(), d, alpha)),
+        verification_key(powers_of<ZKHIP_G2>(default_context(), t + 1, alpha)) { }
     const context &ctx;
     device_bases<CurveType, ZKHIP_G1> commitment_key;
     device_bases<CurveType, ZKHIP_G2> verification_key;    // empty unless given: only commit_g2 reads it
+
+private:
+    template <int Group>
+    static device_bases<CurveType, Group> powers_of(const context &c, std::size_t count, const typename curve_adapter<CurveType>::scalar_value_type &alpha) {
+        typedef typename curve_adapter<CurveType>::scalar_value_type Fr;
+        std::vector<Fr> p(count, Fr::one());
+        for (std::size_t i = 1; i < count; ++i) p[i] = p[i - 1] * alpha;
+        return device_bases<CurveType, Group>::from_scalars(c, p.begin(), p.end());
+    }
 };
 
 /// commit(batch): one commitment per polynomial; all polynomials must have the same power-of-two size

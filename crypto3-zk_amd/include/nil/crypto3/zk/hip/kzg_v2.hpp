@@ -166,6 +166,9 @@ public:
 
     kzg_polys_evaluator_hip(const params_type &kzg_params, root_of_unity_type root_of_unity) :
         _params(kzg_params), _root_of_unity(std::move(root_of_unity)) { }
+    /// the reference's constructor argument list (kzg.hpp:667, kzg_v2.hpp:94: the parameters alone): the roots of unity from the curve adapter
+    explicit kzg_polys_evaluator_hip(const params_type &kzg_params) :
+        _params(kzg_params), _root_of_unity([](std::size_t log_n) { return adapter::root_of_unity(log_n); }) { }
 
     const params_type &get_commitment_params() const { return _params; }
     preprocessed_data_type preprocess(transcript_type &) const { return true; }
@@ -425,6 +428,7 @@ public:
     };
 
     kzg_commitment_scheme_v2_hip(const params_type &kzg_params, root_of_unity_type root_of_unity) : base(kzg_params, std::move(root_of_unity)) { }
+    explicit kzg_commitment_scheme_v2_hip(const params_type &kzg_params) : base(kzg_params) { }    // kzg_v2.hpp:94
 
     /// proof_eval (kzg_v2.hpp:236-305)
     proof_type proof_eval(transcript_type &transcript) {
@@ -564,6 +568,7 @@ public:
     };
 
     kzg_commitment_scheme_hip(const params_type &kzg_params, root_of_unity_type root_of_unity) : base(kzg_params, std::move(root_of_unity)) { }
+    explicit kzg_commitment_scheme_hip(const params_type &kzg_params) : base(kzg_params) { }    // kzg.hpp:667
 
     /// proof_eval (kzg.hpp:782-807)
     proof_type proof_eval(transcript_type &transcript) {

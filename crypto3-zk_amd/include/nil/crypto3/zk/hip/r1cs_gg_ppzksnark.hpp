@@ -198,6 +198,15 @@ struct r1cs_to_qap_hip {
         ctx.sync();    // d_scratch is released on return
         return d_h;
     }
+    /// r1cs_to_qap<F>::witness_map(cs, primary_input, auxiliary_input, d1 = d2 = d3 = 0) (r1cs_to_qap.hpp:219-225) with the reference's
+    /// argument list: the calling thread's default context, the domain make_evaluation_domain(M + n + 1) returns; -> coefficients_for_H
+    template <typename ConstraintSystem>
+    static std::vector<value_type> witness_map(const ConstraintSystem &cs, const std::vector<value_type> &primary_input,
+                                               const std::vector<value_type> &auxiliary_input) {
+        const context &ctx = default_context();
+        device_r1cs<CurveType> dcs(ctx, cs);
+        return witness_map_host(ctx, dcs, standard_domain_params<CurveType>(cs.num_constraints() + cs.num_inputs() + 1), primary_input, auxiliary_input);
+    }
     /// host copy of the same (the reference's return value, qap_witness::coefficients_for_H)
     static std::vector<value_type> witness_map_host(const context &ctx, device_r1cs<CurveType> &cs, const domain_params<CurveType> &dom,
                                                     const std::vector<value_type> &primary_input,
@@ -267,6 +276,14 @@ public:
     /// Uploads the four queries and the constraint system once; proofs then only move the assignment.
     r1cs_gg_ppzksnark_proving_key_hip(const context &ctx, const host_key_type &pk, const domain_params<CurveType> &dom) :
         r1cs_gg_ppzksnark_proving_key_hip(ctx, pk, dom, 0, 1) {}
+    /// The reference's own argument list -- a proving key, nothing else: the calling thread's default context (multiexp.hpp) and the
+    /// domain make_evaluation_domain(M + n + 1) returns, its constants from the curve adapter (standard_domain_params).  With it
+    ///     r1cs_gg_ppzksnark_proving_key_hip<curve> dpk(pk);  proof = r1cs_gg_ppzksnark_prover_hip<curve>::process(dpk, x, w);
+    /// is the whole change at a call site of r1cs_gg_ppzksnark_prover::process(pk, x, w) (prover.hpp:73-75).
+    explicit r1cs_gg_ppzksnark_proving_key_hip(const host_key_type &pk) :
+        r1cs_gg_ppzksnark_proving_key_hip(default_context(), pk,
+                                          standard_domain_params<CurveType>(pk.constraint_system.num_constraints() + pk.constraint_system.num_inputs() + 1), 0,
+                                          1) {}
 
     /// Adopts queries that already live on the device (e.g. produced by device_bases::from_scalars or decoded from the
     /// wire form); `pk` supplies the five single group elements and the constraint system, its query vectors are not read.

@@ -175,6 +175,21 @@ int groth16_prove_t(size_t M, size_t n, size_t N, const uint32_t *const rowptr[3
     // the randomised overload must run too (its output is not comparable)
     auto p2 = r1cs_gg_ppzksnark_prover_hip<Curve>::process(dpk, primary, auxiliary);
     if (p2.g_A.is_zero()) return -101;
+    if (g_dom_kind < 0) {
+        /* the reference's own argument lists: a key from (pk) alone, witness_map(cs, x, w) -- default context, the domain's constants from
+           the curve adapter; the test's omega must be the adapter's root */
+        const domain_params<Curve> std_dom = standard_domain_params<Curve>(M + n + 1);
+        if (!(std_dom.omega == dom.omega) || (coset && !(std_dom.coset_generator == dom.coset_generator))) return -106;
+        r1cs_gg_ppzksnark_proving_key_hip<Curve> plain(pk);
+        auto pv = r1cs_gg_ppzksnark_prover_hip<Curve>::process(plain, primary, auxiliary, A::scalar_from_limbs(r), A::scalar_from_limbs(s));
+        if (!(pv.g_A == proof_v.g_A) || !(pv.g_B == proof_v.g_B) || !(pv.g_C == proof_v.g_C)) return -107;
+        const auto h_plain = r1cs_to_qap_hip<Curve>::witness_map(pk.constraint_system, primary, auxiliary);
+        device_r1cs<Curve> dcs(ctx, pk.constraint_system);
+        const auto h_ctx = r1cs_to_qap_hip<Curve>::witness_map_host(ctx, dcs, dom, primary, auxiliary);
+        if (h_plain.size() != h_ctx.size()) return -108;
+        for (size_t i = 0; i < h_plain.size(); ++i)
+            if (!(h_plain[i] == h_ctx[i])) return -108;
+    }
     // a second prover lane over the same resident key (own context / stream / work buffers), both proving at once from two threads
     {
         context ctx2(0);
@@ -457,6 +472,29 @@ int kzg_batched_t(const uint64_t *srs, size_t n_srs, size_t npolys, const uint64
     for (size_t p = 0; p < npolys; ++p)    // BOOST_CHECK(polys[i].evaluate(s) == rs[i].evaluate(s)) (kzg.cpp:556-561)
         for (const auto &sp : eval_points[p])
             if (!(detail::small_poly<Fr>::evaluate(polys[p], sp) == detail::small_poly<Fr>::evaluate(rs[p], sp))) return -3;
+    {
+        /* params_type(d, t, alpha) as the reference's tests construct it (alpha = 7 in every caller of this harness): the same key */
+        kzg_params_hip<Curve> generated(n_srs, 2, Fr(7));
+        for (size_t i : {(size_t)0, n_srs / 2, n_srs - 1})
+            if (!(generated.commitment_key.at(i) == ck[i])) return -4;
+        if (generated.verification_key.size() != 3) return -4;
+        /* and the scheme classes from the parameters alone (kzg.hpp:667, kzg_v2.hpp:94): roots of unity from the curve adapter */
+        kzg_commitment_scheme_v2_hip<Curve, scripted_transcript<Curve>> scheme(generated);
+        polynomial_dfs<Curve> dfs;
+        for (size_t i = 0; i < 8; ++i) dfs.values.push_back(Fr(i + 1));
+        scheme.append_to_batch(0, dfs);
+        const auto c = scheme.commit(0);
+        /* the committed polynomial interpolates 1..8 on the 8th roots of unity: its value at alpha = 7 by barycentric evaluation */
+        const Fr w8 = A::root_of_unity(3);
+        Fr num = Fr::zero(), wi = Fr::one(), a8 = Fr(7);
+        for (int k = 0; k < 3; ++k) a8 = a8 * a8;    // 7^8
+        for (size_t i = 0; i < 8; ++i) {
+            num = num + dfs.values[i] * wi * (Fr(7) - wi).inversed();
+            wi = wi * w8;
+        }
+        const Fr f_alpha = (a8 - Fr::one()) * Fr(8).inversed() * num;
+        if (n_srs >= 8 && !(c.at(0) == f_alpha * ck[0])) return -5;
+    }
     kzg_batched_public_key_hip<Curve> pk {kzg_batched_commit<Curve>(params, polys), merged_eval_points, eval_points, rs};
     for (size_t p = 0; p < npolys; ++p) pk.commits[p].to_affine(commits + p * L1);
     *n_merged = merged_eval_points.size();
