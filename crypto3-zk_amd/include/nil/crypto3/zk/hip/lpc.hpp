@@ -58,6 +58,11 @@ struct fri_params_hip {
     std::size_t log_domain = 0;
     std::vector<std::size_t> step_list;
     std::function<value_type(std::size_t log_n)> root_of_unity;
+    /// the roots the reference's domains D[i] = make_evaluation_domain(2^(log_domain - i)) carry (fri params, basic_fri.hpp:84-118),
+    /// from the curve adapter's field constants
+    static fri_params_hip standard(std::size_t log_domain, std::vector<std::size_t> step_list) {
+        return {log_domain, std::move(step_list), [](std::size_t log_n) { return curve_adapter<CurveType>::root_of_unity(log_n); }};
+    }
 };
 
 namespace detail {

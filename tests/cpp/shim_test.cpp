@@ -857,6 +857,12 @@ int lpc_scheme_run(const uint64_t *evals, size_t npolys, const uint64_t *log_n, 
     fp.log_domain = log_domain;
     for (size_t i = 0; i < nsteps; ++i) fp.step_list.push_back(steps[i]);
     fp.root_of_unity = [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); };
+    {    // the adapter's field constants give the same parameters (fri_params_hip::standard): the test's roots are the adapter's
+        const auto std_fp = fri_params_hip<Curve>::standard(log_domain, fp.step_list);
+        for (size_t l = 0; l <= log_domain; ++l)
+            if (!(std_fp.root_of_unity(l) == fp.root_of_unity(l))) return -20;
+        if (g_lpc_builder == 0) fp = std_fp;
+    }
     typedef lpc_commitment_scheme_hip<Curve, scripted_any_transcript<Curve>, Builder> scheme_type;
     static_assert(scheme_type::is_lpc(), "placeholder branches on is_lpc()");
     scheme_type scheme(ctx, fp, Builder());
