@@ -172,6 +172,22 @@ public:
                                            prover::random_scalar(), prover::random_scalar());
     }
 
+    /// r1cs_gg_ppzksnark_generator<CurveType>::process(constraint_system) (generator.hpp:84-86) with the reference's argument list: the
+    /// calling thread's default context, the domain make_evaluation_domain(M + n + 1) returns (constants from the curve adapter)
+    static std::unique_ptr<generated_proving_key<CurveType>> process(const constraint_system_type &constraint_system) {
+        return basic_process(default_context(), constraint_system,
+                             standard_domain_params<CurveType>(constraint_system.num_constraints() + constraint_system.num_inputs() + 1));
+    }
+    /// ... and the testing entry point (generator.hpp:240-247): the toxic waste as arguments
+    static std::unique_ptr<generated_proving_key<CurveType>> deterministic_basic_process(const constraint_system_type &constraint_system,
+                                                                                         const scalar_value_type &t, const scalar_value_type &alpha,
+                                                                                         const scalar_value_type &beta, const scalar_value_type &gamma,
+                                                                                         const scalar_value_type &delta) {
+        return deterministic_basic_process(default_context(), constraint_system,
+                                           standard_domain_params<CurveType>(constraint_system.num_constraints() + constraint_system.num_inputs() + 1), t,
+                                           alpha, beta, gamma, delta);
+    }
+
     /// r1cs.hpp:192-215
     static void swap_AB_if_beneficial(constraint_system_type &cs) {
         std::vector<bool> touched_by_A(cs.num_variables() + 1, false), touched_by_B(cs.num_variables() + 1, false);

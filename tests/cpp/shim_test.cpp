@@ -1028,6 +1028,18 @@ int groth16_generate_prove_t(size_t M, size_t n, size_t N, const uint32_t *const
     pv.g_A.to_affine(proof);
     pv.g_B.to_affine(proof + L1);
     pv.g_C.to_affine(proof + L1 + L2);
+    if (g_dom_kind < 0 && M <= 4096) {
+        /* the generator with the reference's argument lists (generator.hpp:84-86, 240-247): the same key, so the same proof; and one
+           from fresh toxic waste, which must at least prove */
+        auto key2 = r1cs_gg_ppzksnark_generator_hip<Curve>::deterministic_basic_process(cs, A::scalar_from_limbs(trap), A::scalar_from_limbs(trap + 4),
+                                                                                        A::scalar_from_limbs(trap + 8), A::scalar_from_limbs(trap + 12),
+                                                                                        A::scalar_from_limbs(trap + 16));
+        auto pv2 = r1cs_gg_ppzksnark_prover_hip<Curve>::process(*key2->device, primary, auxiliary, A::scalar_from_limbs(r), A::scalar_from_limbs(s));
+        if (!(pv2.g_A == pv.g_A) || !(pv2.g_B == pv.g_B) || !(pv2.g_C == pv.g_C)) return -110;
+        auto key3 = r1cs_gg_ppzksnark_generator_hip<Curve>::process(cs);
+        auto pv3 = r1cs_gg_ppzksnark_prover_hip<Curve>::process(*key3->device, primary, auxiliary);
+        if (pv3.g_A.is_zero() || pv3.g_A == pv.g_A) return -111;
+    }
     if (ms) {
         ms[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
         ms[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
