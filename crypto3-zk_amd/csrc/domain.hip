@@ -263,7 +263,24 @@ static int dom_get_tables(zkhip_ctx *ctx, int curve, const ZkDomain &d, const ui
         delete old;
         ctx->dom_tables.erase(ctx->dom_tables.begin());
     }
-    DomTables *t = new DomTables();
+    // Built in a local owner and PUBLISHED only after the last launch has completed: an allocation, copy or launch that fails on
+    // the way (out of memory on d_T, say) must not leave a half-built entry in the cache for the next call to hit.
+    struct Building {
+        DomTables *t = new DomTables();
+        uint32_t *d_in = nullptr;
+        ~Building() {
+            (void)hipFree(d_in);
+            if (t) {
+                (void)hipFree(t->d_T);
+                (void)hipFree(t->d_Tinv);
+                (void)hipFree(t->d_consts);
+                (void)hipFree(t->d_zinv);
+                delete t;
+            }
+        }
+    } building;
+    DomTables *t = building.t;
+    uint32_t *&d_in = building.d_in;
     t->curve = curve;
     t->kind = d.kind;
     t->m = d.m;
@@ -273,9 +290,7 @@ static int dom_get_tables(zkhip_ctx *ctx, int curve, const ZkDomain &d, const ui
     memcpy(t->shift, d.shift, 32);
     t->has_coset = coset != nullptr;
     if (coset) memcpy(t->coset, coset, 32);
-    ctx->dom_tables.push_back(t);
     const uint64_t one[4] = {1, 0, 0, 0};
-    uint32_t *d_in = nullptr;
     ZK_HIP_CHECK(ctx, hipMalloc((void **)&d_in, 96));
     ZK_HIP_CHECK(ctx, hipMalloc((void **)&t->d_consts, DC_COUNT * 32));
     ZK_HIP_CHECK(ctx, hipMemsetAsync(t->d_consts, 0, DC_COUNT * 32, ctx->stream));
@@ -304,7 +319,8 @@ static int dom_get_tables(zkhip_ctx *ctx, int curve, const ZkDomain &d, const ui
         ZK_LAUNCH(ctx, "dom_setup", dom_zinv_table<U>, dim3((unsigned)((t->nz + 1 + 63) / 64)), dim3(64), 0, d.kind, t->d_consts, (uint64_t)t->nz, t->d_zinv);
     }
     ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(d_in);
+    ctx->dom_tables.push_back(t);
+    building.t = nullptr;  // the cache owns it now; d_in goes with `building`
     *out = t;
     return 0;
 }

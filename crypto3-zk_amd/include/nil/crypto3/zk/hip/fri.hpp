@@ -39,8 +39,9 @@ public:
         ctx_(&ctx), size_(size), degree_(size ? size - 1 : 0), d_(ctx.alloc(std::max<std::size_t>(1, size) * 32)) { }
     /// `degree`: polynomial_dfs carries its degree next to the evaluations (polynomial_product sizes its result from
     /// it); without one the vector is taken to be full (size - 1)
-    device_polynomial_dfs(const context &ctx, const polynomial_dfs<CurveType> &p, std::size_t degree = (std::size_t)-1) : device_polynomial_dfs(ctx, p.size()) {
-        upload_scalars<adapter>(ctx, d_.get(), p.values.data(), size_);
+    template <typename PolynomialType, typename = decltype(std::declval<const PolynomialType &>()[0])>
+    device_polynomial_dfs(const context &ctx, const PolynomialType &p, std::size_t degree = (std::size_t)-1) : device_polynomial_dfs(ctx, p.size()) {
+        upload_scalars<adapter>(ctx, d_.get(), detail::poly_data<adapter>(p), size_);
         if (degree != (std::size_t)-1) degree_ = degree;
     }
     std::size_t size() const { return size_; }
@@ -187,9 +188,9 @@ device_polynomial_dfs<CurveType> fold_polynomial(const device_polynomial_dfs<Cur
 /// extended to the 2^log_domain-point domain D (`poly[i].resize(D->size())`, :452-455) and the leaves are laid out
 /// in the reference's coset order; returns the leaf data (2^log_domain / 2^fri_step leaves of
 /// polys.size() * 2^fri_step canonical elements each) on the host for the caller's Merkle tree.
-template <typename CurveType>
+template <typename CurveType, typename PolynomialType = polynomial_dfs<CurveType>>
 std::vector<typename curve_adapter<CurveType>::scalar_value_type>
-    precommit_leaves(const context &ctx, const std::vector<polynomial_dfs<CurveType>> &polys, std::size_t log_domain, std::size_t fri_step,
+    precommit_leaves(const context &ctx, const std::vector<PolynomialType> &polys, std::size_t log_domain, std::size_t fri_step,
                      const typename device_polynomial_dfs<CurveType>::root_of_unity_type &root) {
     typedef curve_adapter<CurveType> adapter;
     ZKHIP_PROFILE_SCOPE("Basic FRI Precommit time");    // basic_fri.hpp:449
@@ -209,10 +210,10 @@ std::vector<typename curve_adapter<CurveType>::scalar_value_type>
         if (n == 0 || ((std::size_t)1 << log_n) != n || log_n > log_domain) throw std::runtime_error("precommit: bad polynomial size");
         char *dst = static_cast<char *>(d_ext.get()) + 32 * i * D;
         if (log_n == log_domain) {
-            for (std::size_t p = i; p < j; ++p) upload_scalars<adapter>(ctx, dst + 32 * (p - i) * n, polys[p].values.data(), n);
+            for (std::size_t p = i; p < j; ++p) upload_scalars<adapter>(ctx, dst + 32 * (p - i) * n, detail::poly_data<adapter>(polys[p]), n);
         } else {
             auto d_in = ctx.alloc(n * (j - i) * 32);
-            for (std::size_t p = i; p < j; ++p) upload_scalars<adapter>(ctx, static_cast<char *>(d_in.get()) + 32 * (p - i) * n, polys[p].values.data(), n);
+            for (std::size_t p = i; p < j; ++p) upload_scalars<adapter>(ctx, static_cast<char *>(d_in.get()) + 32 * (p - i) * n, detail::poly_data<adapter>(polys[p]), n);
             std::uint64_t wn[4];
             adapter::scalar_to_limbs(root(log_n), wn);
             check(zkhip_poly_resize_dev(ctx.get(), adapter::id, d_in.get(), log_n, j - i, wn, dst, log_domain, wd), "zkhip_poly_resize_dev", ctx.get());

@@ -22,12 +22,31 @@ namespace crypto3 {
 namespace zk {
 namespace hip {
 
-/// math::polynomial_dfs as far as the commitment layer reads it: evaluations over the size()-point domain.
+/// math::polynomial_dfs as far as the commitment layer reads it: evaluations over the size()-point domain.  This is only the
+/// DEFAULT polynomial type of the schemes: they are templated on `PolynomialType` exactly as the reference's polys_evaluator is
+/// (batched_commitment.hpp:56-64) and read a polynomial through size() and operator[] alone (detail::poly_data below), so
+/// crypto3-math's own math::polynomial_dfs -- private storage, begin / end / size / operator[] -- is consumed where it lies.
 template <typename CurveType>
 struct polynomial_dfs {
-    std::vector<typename curve_adapter<CurveType>::scalar_value_type> values;
+    typedef typename curve_adapter<CurveType>::scalar_value_type value_type;
+    std::vector<value_type> values;
     std::size_t size() const { return values.size(); }
+    const value_type &operator[](std::size_t i) const { return values[i]; }
+    value_type &operator[](std::size_t i) { return values[i]; }
+    typename std::vector<value_type>::const_iterator begin() const { return values.begin(); }
+    typename std::vector<value_type>::const_iterator end() const { return values.end(); }
 };
+
+namespace detail {
+    /// the contiguous evaluations of a polynomial_dfs-like object (what the uploads read): its element type must be the
+    /// adapter's scalar type, its storage contiguous (std::vector inside math::polynomial_dfs)
+    template <typename Adapter, typename PolynomialType>
+    const typename Adapter::scalar_value_type *poly_data(const PolynomialType &p) {
+        static_assert(std::is_same<typename std::decay<decltype(p[0])>::type, typename Adapter::scalar_value_type>::value,
+                      "PolynomialType's elements must be the curve adapter's scalar_value_type");
+        return p.size() ? &p[0] : nullptr;
+    }
+}    // namespace detail
 
 /// kzg::params_type with the commitment key resident on the device.
 template <typename CurveType>
@@ -64,9 +83,9 @@ private:
 
 /// commit(batch): one commitment per polynomial; all polynomials must have the same power-of-two size
 /// n <= commitment_key.size().  `omega` is the primitive n-th root of the polynomials' evaluation domain.
-template <typename CurveType>
+template <typename CurveType, typename PolynomialType = polynomial_dfs<CurveType>>
 std::vector<typename curve_adapter<CurveType>::g1_value_type>
-    kzg_commit_batch(const kzg_params_hip<CurveType> &params, const std::vector<polynomial_dfs<CurveType>> &polys,
+    kzg_commit_batch(const kzg_params_hip<CurveType> &params, const std::vector<PolynomialType> &polys,
                      const typename curve_adapter<CurveType>::scalar_value_type &omega) {
     typedef curve_adapter<CurveType> adapter;
     std::vector<typename adapter::g1_value_type> out;
@@ -79,7 +98,7 @@ std::vector<typename curve_adapter<CurveType>::g1_value_type>
     for (std::size_t b = 0; b < batch; ++b)
         if (polys[b].size() != n) throw std::runtime_error("kzg_commit_batch: ragged batch");
     auto d = ctx.alloc(n * batch * 32);
-    for (std::size_t b = 0; b < batch; ++b) upload_scalars<adapter>(ctx, static_cast<char *>(d.get()) + 32 * b * n, polys[b].values.data(), n);
+    for (std::size_t b = 0; b < batch; ++b) upload_scalars<adapter>(ctx, static_cast<char *>(d.get()) + 32 * b * n, detail::poly_data<adapter>(polys[b]), n);
     std::uint64_t w[4];
     adapter::scalar_to_limbs(omega, w);
     /* p.coefficients() for every polynomial of the batch (kzg.hpp:431) */
@@ -104,10 +123,11 @@ std::vector<typename curve_adapter<CurveType>::g1_value_type>
 }
 
 /// commit_one<KZG>(params, polynomial_dfs)
-template <typename CurveType>
-typename curve_adapter<CurveType>::g1_value_type commit_one(const kzg_params_hip<CurveType> &params, const polynomial_dfs<CurveType> &poly,
+template <typename CurveType, typename PolynomialType = polynomial_dfs<CurveType>,
+          typename std::enable_if<!std::is_same<PolynomialType, std::vector<typename curve_adapter<CurveType>::scalar_value_type>>::value, bool>::type = true>
+typename curve_adapter<CurveType>::g1_value_type commit_one(const kzg_params_hip<CurveType> &params, const PolynomialType &poly,
                                                             const typename curve_adapter<CurveType>::scalar_value_type &omega) {
-    return kzg_commit_batch<CurveType>(params, std::vector<polynomial_dfs<CurveType>> {poly}, omega)[0];
+    return kzg_commit_batch<CurveType, PolynomialType>(params, std::vector<PolynomialType> {poly}, omega)[0];
 }
 
 /// commit_one<KZG>(params, math::polynomial) (kzg.hpp:409-420): the polynomial given by its coefficients

@@ -146,7 +146,10 @@ typename curve_adapter<CurveType>::g1_value_type kzg_proof_eval(const kzg_params
 /// What kzg_commitment_scheme (kzg.hpp:636-873) and kzg_commitment_scheme_v2 (kzg_v2.hpp:56-360) share: the polys_evaluator
 /// state (batched_commitment.hpp:58-249), commit(batch) with the coefficient forms left resident, eval_polys, get_U,
 /// the transcript update and the device helpers of the opening proofs.
-template <typename CurveType, typename TranscriptType>
+/// `PolynomialType` as in the reference's polys_evaluator (batched_commitment.hpp:56-64; default: the shim's own polynomial_dfs):
+/// anything with size() and operator[] over contiguous scalar_value_type -- math::polynomial_dfs as placeholder_prover hands it
+/// over (prover.hpp:137-138, 316) included.
+template <typename CurveType, typename TranscriptType, typename PolynomialType = polynomial_dfs<CurveType>>
 class kzg_polys_evaluator_hip {
 public:
     typedef curve_adapter<CurveType> adapter;
@@ -156,7 +159,7 @@ public:
     typedef std::vector<single_commitment_type> commitment_type;
     typedef TranscriptType transcript_type;
     typedef kzg_params_hip<CurveType> params_type;
-    typedef polynomial_dfs<CurveType> poly_type;
+    typedef PolynomialType poly_type;
     typedef eval_storage_hip<CurveType> eval_storage_type;
     typedef bool preprocessed_data_type;
     /// primitive 2^log_n-th root of unity of the evaluation domains (math::make_evaluation_domain's choice)
@@ -237,7 +240,7 @@ public:
             /* the first chunk is a short one: nothing runs on the device until it has arrived */
             const std::size_t limit = (pipelined && i == 0) ? std::max<std::size_t>(1, upload_chunk / 4) : upload_chunk;
             while (j < count && db.len[j] == db.len[i] && (limit == 0 || j - i < limit)) ++j;
-            for (std::size_t p = i; p < j; ++p) upload_scalars<adapter>(up, db.at(p), polys[p]->values.data(), polys[p]->size());
+            for (std::size_t p = i; p < j; ++p) upload_scalars<adapter>(up, db.at(p), detail::poly_data<adapter>(*polys[p]), polys[p]->size());
             if (pipelined) ctx.wait_for(up);
             std::size_t log_n = 0;
             while (((std::size_t)1 << log_n) < db.len[i]) ++log_n;
@@ -405,9 +408,9 @@ protected:
 };
 
 /// kzg_commitment_scheme_v2 (kzg_v2.hpp:56-360): two quotient commitments (pi_1, pi_2)
-template <typename CurveType, typename TranscriptType>
-class kzg_commitment_scheme_v2_hip : public kzg_polys_evaluator_hip<CurveType, TranscriptType> {
-    typedef kzg_polys_evaluator_hip<CurveType, TranscriptType> base;
+template <typename CurveType, typename TranscriptType, typename PolynomialType = polynomial_dfs<CurveType>>
+class kzg_commitment_scheme_v2_hip : public kzg_polys_evaluator_hip<CurveType, TranscriptType, PolynomialType> {
+    typedef kzg_polys_evaluator_hip<CurveType, TranscriptType, PolynomialType> base;
 
 public:
     typedef typename base::adapter adapter;
@@ -544,9 +547,9 @@ protected:
 /// evaluation-point set S are combined first (one pass over their resident coefficients), the few coefficients of their U_j
 /// are subtracted, and the group is divided by V(S) root by root -- |S| synthetic divisions per GROUP instead of per polynomial.
 /// verify_eval (:809-868) is pairings: the caller's, like v2's; commit_g2 (:659-664, 497-510) is provided for it.
-template <typename CurveType, typename TranscriptType>
-class kzg_commitment_scheme_hip : public kzg_polys_evaluator_hip<CurveType, TranscriptType> {
-    typedef kzg_polys_evaluator_hip<CurveType, TranscriptType> base;
+template <typename CurveType, typename TranscriptType, typename PolynomialType = polynomial_dfs<CurveType>>
+class kzg_commitment_scheme_hip : public kzg_polys_evaluator_hip<CurveType, TranscriptType, PolynomialType> {
+    typedef kzg_polys_evaluator_hip<CurveType, TranscriptType, PolynomialType> base;
 
 public:
     typedef typename base::adapter adapter;
@@ -664,9 +667,9 @@ protected:
 /// (a byte blob) and a verify_eval.
 ///   Packer:   std::vector<std::uint8_t>(const single_commitment_type &)   -- nil::marshalling::pack<endianness>(point, status)
 ///   Verifier: bool(scheme &, const proof_type &, const std::map<std::size_t, commitment_type> &, transcript_type &)
-template <typename CurveType, typename TranscriptType, typename Packer, typename Verifier>
-class kzg_commitment_scheme_v2_placeholder_hip : public kzg_commitment_scheme_v2_hip<CurveType, TranscriptType> {
-    typedef kzg_commitment_scheme_v2_hip<CurveType, TranscriptType> base;
+template <typename CurveType, typename TranscriptType, typename Packer, typename Verifier, typename PolynomialType = polynomial_dfs<CurveType>>
+class kzg_commitment_scheme_v2_placeholder_hip : public kzg_commitment_scheme_v2_hip<CurveType, TranscriptType, PolynomialType> {
+    typedef kzg_commitment_scheme_v2_hip<CurveType, TranscriptType, PolynomialType> base;
 
 public:
     typedef std::vector<std::uint8_t> commitment_type;
@@ -705,9 +708,9 @@ private:
 /// The same for the FIRST batched scheme (kzg_commitment_scheme, kzg.hpp:636-873): `commit` packs the single commitments into the
 /// reference's byte blob (:748-765), `verify_eval` (:809-868) goes to the caller's pairing check, which finds commit_g2, the
 /// evaluation points and the per-polynomial commitments on this object.
-template <typename CurveType, typename TranscriptType, typename Packer, typename Verifier>
-class kzg_commitment_scheme_placeholder_hip : public kzg_commitment_scheme_hip<CurveType, TranscriptType> {
-    typedef kzg_commitment_scheme_hip<CurveType, TranscriptType> base;
+template <typename CurveType, typename TranscriptType, typename Packer, typename Verifier, typename PolynomialType = polynomial_dfs<CurveType>>
+class kzg_commitment_scheme_placeholder_hip : public kzg_commitment_scheme_hip<CurveType, TranscriptType, PolynomialType> {
+    typedef kzg_commitment_scheme_hip<CurveType, TranscriptType, PolynomialType> base;
 
 public:
     typedef std::vector<std::uint8_t> commitment_type;

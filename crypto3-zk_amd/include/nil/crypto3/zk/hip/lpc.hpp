@@ -95,7 +95,8 @@ namespace detail {
     };
 }    // namespace detail
 
-template <typename CurveType, typename TranscriptType, typename TreeBuilder>
+/// `PolynomialType`: as for the KZG schemes (batched_commitment.hpp:56-64) -- size() and operator[] over contiguous scalars.
+template <typename CurveType, typename TranscriptType, typename TreeBuilder, typename PolynomialType = polynomial_dfs<CurveType>>
 class lpc_commitment_scheme_hip {
 public:
     static constexpr bool is_lpc() { return true; }
@@ -105,7 +106,7 @@ public:
     typedef typename adapter::scalar_value_type value_type;
     typedef fri_params_hip<CurveType> params_type;
     typedef TranscriptType transcript_type;
-    typedef polynomial_dfs<CurveType> poly_type;
+    typedef PolynomialType poly_type;
     typedef eval_storage_hip<CurveType> eval_storage_type;
     static constexpr detail::tree_builder_kind builder_kind =
         detail::is_streaming_builder<TreeBuilder, value_type>::value
@@ -212,7 +213,7 @@ public:
         for (std::size_t i = 0; i < count;) {
             std::size_t j = i;
             while (j < count && db.len[j] == db.len[i] && (upload_chunk == 0 || j - i < upload_chunk)) ++j;
-            for (std::size_t p = i; p < j; ++p) upload_scalars<adapter>(up, db.at(p), polys[p]->values.data(), polys[p]->size());
+            for (std::size_t p = i; p < j; ++p) upload_scalars<adapter>(up, db.at(p), detail::poly_data<adapter>(*polys[p]), polys[p]->size());
             if (pipelined) _ctx.wait_for(up);
             const std::size_t log_n = log2_of(db.len[i]);
             std::uint64_t wn[4];

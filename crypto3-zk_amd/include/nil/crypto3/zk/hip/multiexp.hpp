@@ -5,11 +5,15 @@
 //   zk/commitments/polynomial/kzg.hpp:143-148, 409-435, 505-508
 //   zk/commitments/polynomial/knowledge_commitment_multiexp.hpp:107
 // Same argument order and meaning; `chunks` is accepted and ignored (the device splits the work itself).
-// `multiexp_method_hip` is the policy tag a KZG parameter struct shadows `multiexp_method` with
-// (kzg.hpp:82,231 declare `using multiexp_method = ...BDLO12` and use it as `typename KZG::multiexp_method`): the
-// REFERENCE-ARITY overloads at the end of this file -- multiexp<multiexp_method_hip>(b0, b1, s0, s1, chunks), no context
-// argument, the group read off the bases' value type -- are what such a struct's call sites (kzg.hpp:146, 417, 434, 505)
-// resolve to; they run on the calling thread's default context (default_context()).
+// `multiexp_method_hip` is the POLICY a KZG parameter struct shadows `multiexp_method` with (kzg.hpp:82, 231 declare
+// `using multiexp_method = ...BDLO12`).  The reference's call sites are QUALIFIED calls of crypto3-algebra's dispatcher,
+//   algebra::multiexp<typename KZG::multiexp_method>(b0, b1, s0, s1, 1)          (kzg.hpp:146-147, 414-418, 433-434, 505-508, 661-662)
+// which hands the range to the policy as `MultiexpMethod::process(b0, b1, s0, s1)` (one call when chunks == 1, one per chunk
+// otherwise).  So the seam is the policy's static `process`: no context argument, the group read off the
+// bases' value type, run on the calling thread's default context (default_context()).  tests/cpp/shim_test.cpp drives it
+// through a dispatcher declared in ANOTHER namespace and called qualified, as kzg.hpp does.  The free functions
+// multiexp<multiexp_method_hip>(b0, b1, s0, s1, chunks) at the end of this file are the same call for code that lives inside
+// zk::hip (the shim's own schemes).
 //---------------------------------------------------------------------------//
 #ifndef ZKHIP_SHIM_MULTIEXP_HPP
 #define ZKHIP_SHIM_MULTIEXP_HPP
@@ -27,7 +31,13 @@ namespace crypto3 {
 namespace zk {
 namespace hip {
 
-struct multiexp_method_hip { };
+/// The device multiexp as a crypto3-algebra multiexp policy: `process(bases_begin, bases_end, scalars_begin, scalars_end)`
+/// returns the sum as the bases' value type (defined below, after group_traits / default_context).
+struct multiexp_method_hip {
+    template <typename BaseIt, typename ScalarIt>
+    static typename std::iterator_traits<BaseIt>::value_type process(BaseIt bases_begin, BaseIt bases_end, ScalarIt scalars_begin,
+                                                                     ScalarIt scalars_end);
+};
 
 namespace detail {
     template <typename CurveType, typename ScalarIt>
@@ -126,12 +136,19 @@ inline const context &default_context() {
 /// make `ctx` the calling thread's default context (nullptr: back to the thread's own); the caller keeps it alive
 inline void set_default_context(context *ctx) { detail::default_context_override() = ctx; }
 
-/// algebra::multiexp<Method>(bases_begin, bases_end, scalars_begin, scalars_end, chunks) with Method = multiexp_method_hip
+template <typename BaseIt, typename ScalarIt>
+typename std::iterator_traits<BaseIt>::value_type multiexp_method_hip::process(BaseIt bases_begin, BaseIt bases_end, ScalarIt scalars_begin,
+                                                                               ScalarIt scalars_end) {
+    typedef group_traits<typename std::iterator_traits<BaseIt>::value_type> T;
+    return multiexp<multiexp_method_hip, typename T::curve_type, T::group>(default_context(), bases_begin, bases_end, scalars_begin, scalars_end, 1);
+}
+
+/// algebra::multiexp<Method>(bases_begin, bases_end, scalars_begin, scalars_end, chunks) with Method = multiexp_method_hip, for
+/// callers inside zk::hip; `chunks` is ignored (the device splits the work itself), so this is ONE `process` call.
 template <typename Method, typename BaseIt, typename ScalarIt, typename std::enable_if<std::is_same<Method, multiexp_method_hip>::value, bool>::type = true>
 typename std::iterator_traits<BaseIt>::value_type multiexp(BaseIt bases_begin, BaseIt bases_end, ScalarIt scalars_begin, ScalarIt scalars_end,
-                                                           std::size_t chunks) {
-    typedef group_traits<typename std::iterator_traits<BaseIt>::value_type> T;
-    return multiexp<Method, typename T::curve_type, T::group>(default_context(), bases_begin, bases_end, scalars_begin, scalars_end, chunks);
+                                                           std::size_t /*chunks*/) {
+    return Method::process(bases_begin, bases_end, scalars_begin, scalars_end);
 }
 template <typename Method, typename BaseIt, typename ScalarIt, typename std::enable_if<std::is_same<Method, multiexp_method_hip>::value, bool>::type = true>
 typename std::iterator_traits<BaseIt>::value_type multiexp_with_mixed_addition(BaseIt bases_begin, BaseIt bases_end, ScalarIt scalars_begin,

@@ -49,3 +49,18 @@ def test_product_does_not_reference_oracle():
     import subprocess
     out = subprocess.run(["ldd", os.path.join(pkg, "libzkhip.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_generated_asm_products_are_current(tmp_path):
+    """crypto3-zk_amd/csrc/mont_asm.hpp (the device's Montgomery products as inline-asm blocks) is GENERATED from
+    tools/gen_mont_asm.py; the committed file must be what the generator writes.  The blocks restate fu.hpp's C++ bodies term by
+    term (the -m gpu suite holds them against the oracle; the host tests run the C++ bodies)."""
+    import subprocess
+    import sys
+    out = tmp_path / "mont_asm.hpp"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_mont_asm.py"), "--product", str(out)], check=True)
+    assert out.read_text() == open(os.path.join(ROOT, "crypto3-zk_amd", "csrc", "mont_asm.hpp")).read()
+    text = out.read_text()
+    # 14-limb product: 2 L^2 multiply-adds, L mul_lo, 2 L masks, 2 L - 1 shifts, one move
+    body = text.split("struct MontAsm<14>")[1].split("static __device__")[1]
+    assert body.count("v_mad_u64_u32") == 2 * 14 * 14 and body.count("v_lshrrev_b64") == 27 and body.count("v_mul_lo_u32") == 14
