@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--split", choices=("points", "windows"), default="points",
                     help="N > 1: partition of the N x 2^log_n-point MSM over the ranks (see the module docstring)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-groth16-log", type=int, default=20, help="constraints of the CPU prover sample = 2^k (default: the headline instance; 17 = quick)")
     ap.add_argument("--no-groth16", action="store_true", help="skip the Groth16 constraints/s leg")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL all-gather + fold at N = 1 too (checks the N > 1 path on one GPU)")
     ap.add_argument("--no-kzg", action="store_true", help="skip the KZG commit / opening-proof leg (BASELINE config 5's commitment layer, N = 1 only)")
@@ -114,6 +115,7 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="every rank uses GPU 0 (two ranks sharing the one GPU of a test box)")
     ap.add_argument("--log-constraints", type=int, default=20, help="constraints of the sharded Groth16 leg = 2^k (tests use a smaller instance)")
     ap.add_argument("--kzg-log-rows", type=int, default=20, help="rows of the sharded KZG leg's columns = 2^k")
+    ap.add_argument("--ntt-log-m", type=int, default=22, help="domain of the sharded NTT leg = 2^k (tests use a smaller one)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: launch the ranks, run the all-gather + fold plumbing over gloo with stand-in partial sums, print the line's frame")
     args = ap.parse_args()
@@ -262,6 +264,10 @@ def main():
     if use_dist and not args.no_groth16:
         # BASELINE config 4: ONE 2^20-constraint proof sharded over all ranks (every rank takes part in the exchange)
         g16_sharded = groth16_sharded_leg(np, torch, dist, rank, world, local_rank, log_constraints=args.log_constraints, verify=not args.no_verify)
+    ntt_sharded = None
+    if use_dist and not args.no_ntt:
+        # BASELINE config 3: the 8 polynomials of 2^22 dealt over the ranks, no collective
+        ntt_sharded = ntt_sharded_leg(np, torch, dist, zk, ctx, rank, world, local_rank, log_m=args.ntt_log_m, verify=not args.no_verify)
     kzg_sharded = None
     if use_dist and not args.no_kzg:
         # BASELINE config 5's commitment leg: the 50 columns dealt over the ranks, one all-gather of the commitments
@@ -305,7 +311,7 @@ def main():
             line["roofline"]["traffic"] = traffic["msm_bucket_acc"]
             line["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run (2 x FETCH_SIZE + WRITE_SIZE, KiB -> B)"
             if traffic.get("valu", {}).get("msm_bucket_acc"):
-                line["roofline"]["valu"] = dict(traffic["valu"]["msm_bucket_acc"], bound="VALU issue: 4 cycles per wave instruction on 1024 SIMDs",
+                line["roofline"]["valu"] = dict(traffic["valu"]["msm_bucket_acc"], bound="VALU issue on 1024 SIMDs: issue_frac prices every wave instruction at 4 cycles; issue_frac_of_hw prices this kernel's mix (multiply-adds / VOP3 4 cycles, VOP2 2)",
                                                 source="SQ_INSTS_VALU, GRBM_GUI_ACTIVE / 8 of a third child pass")
         else:
             line["roofline"]["traffic_source"] = ("not collected: bench.py itself runs under a profiler (no nested rocprofv3)" if under_profiler() else
@@ -323,10 +329,15 @@ def main():
             line["groth16_sharded"] = g16_sharded
         if kzg_sharded is not None:
             line["kzg_sharded"] = kzg_sharded
+        if ntt_sharded is not None:
+            line["ntt_sharded"] = ntt_sharded
         if world == 1 and not args.no_kzg:
             line["kzg"] = kzg_leg(np, zk, ctx, verify=not args.no_verify, valu=(traffic or {}).get("valu", {}).get("msm_bucket_acc"))
             line["lpc"] = lpc_leg(np)
+            line["quotient_chain"] = quotient_leg(np, verify=not args.no_verify)
         if world == 1 and not args.no_cpu_baseline:
+            global CPU_GROTH16_LOG
+            CPU_GROTH16_LOG = args.cpu_groth16_log
             line["cpu_baseline"] = cpu_baseline(np, bases)
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     fence()
@@ -456,15 +467,38 @@ def pmc_traffic_live(log_n):
                 sums.setdefault(key, {})[counter] = tot / max(1, len(ids))
         res = {k: int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024) for k, v in sums.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
         valu = {}
+        mix = isa_mix()
         for k, v in sums.items():
             if v.get("SQ_INSTS_VALU") and v.get("GRBM_GUI_ACTIVE"):
                 cycles = v["GRBM_GUI_ACTIVE"] / 8  # summed over the 8 XCDs
                 valu[k] = {"wave_insts_per_launch": int(v["SQ_INSTS_VALU"]), "gpu_cycles_per_launch": int(cycles),
-                           "issue_frac": round(v["SQ_INSTS_VALU"] * 4 / 1024 / cycles, 4)}
+                           "issue_frac": round(v["SQ_INSTS_VALU"] * 4 / 1024 / cycles, 4),
+                           "issue_frac_convention": "every wave instruction priced at 4 cycles (what SQ_ACTIVE_INST_VALU counts)"}
+                if mix and k in mix:
+                    # price the kernel's OWN instruction mix with the measured issue costs (tools/microbench2.hip,
+                    # tools/mulbench4.hip): 64-bit-encoded instructions (multiply-adds, 64-bit shifts / adds) 4 cycles, VOP2 2
+                    # cycles when a second wave is resident (both kernels run 3+ waves per SIMD), 4 for a lone wave
+                    fr, cost = mix[k]["fractions"], mix["cycles_per_wave_instruction"]
+                    per_inst = sum(fr[c] * cost[c] for c in ("mad64", "vop3", "vop2"))
+                    lone = sum(fr[c] * (cost["vop2_lone_wave"] if c == "vop2" else cost[c]) for c in ("mad64", "vop3", "vop2"))
+                    valu[k].update({"issue_frac_of_hw": round(v["SQ_INSTS_VALU"] * per_inst / 1024 / cycles, 4),
+                                    "issue_frac_at_occupancy": round(v["SQ_INSTS_VALU"] * per_inst / 1024 / cycles, 4),
+                                    "issue_frac_if_lone_wave": round(v["SQ_INSTS_VALU"] * lone / 1024 / cycles, 4),
+                                    "priced_cycles_per_wave_instruction": round(per_inst, 3), "mix": fr,
+                                    "mix_source": "profiles/r04_isa_mix.json (tools/isa_mix.py: static ISA of the shipped kernel)",
+                                    "cost_source": cost["source"]})
         res["valu"] = valu
         return res
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def isa_mix():
+    """{kernel: {"fractions": {mad64, vop3, vop2}}, "cycles_per_wave_instruction": {...}} from profiles/r04_isa_mix.json, or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r04_isa_mix.json")))
+    except Exception:
+        return None
 
 
 def ntt_leg(np, zk, ctx, log_m=22, batch=8, steps=5, verify=True, traffic=None):
@@ -605,7 +639,9 @@ def groth16_leg(np, constraints=1 << 20, inputs=10, steps=4, verify=True, domain
             "key": "valid Groth16 key, generated on the device from a fixed trapdoor (r1cs_gg_ppzksnark_generator_hip), resident",
             "key_setup_ms": round(setup.value, 1), "verified": None if not verify else bool(verified.value == 1),
             "verification": "proof == (a G1, b G2, c G1) with a, b, c from the trapdoor identities (prover.hpp:141-153)",
-            "roofline": roof, "kernel_ms_last_proof": kern, **({"lanes_over_one_key": lanes_obj} if lanes_obj else {})}
+            "roofline": roof, "kernel_ms_serial_proof": kern,
+            "kernel_ms_source": "HIP events around every launch of ONE extra, untimed proof with the G2 multiexp on the main stream: a single in-order "
+                                "stream makes the event pairs exact kernel durations (the timed proofs run the G2 multiexp on a second stream and carry no events)", **({"lanes_over_one_key": lanes_obj} if lanes_obj else {})}
 
 
 def _last_domain(np, lib):
@@ -859,6 +895,100 @@ def lpc_leg(np, log_n=20, cols=16, steps=4):
             "verification": "the streaming and the vector builder fold the same leaves (bit-exact parity of the layout: tests/test_gpu_shim.py)"}
 
 
+def quotient_leg(np, log_n=20, steps=4, verify=True):
+    """placeholder's quotient-polynomial chain at BASELINE config 5's row count (hip/placeholder_quotient.hpp mirrors
+    prover.hpp:220-277, 314-317 and the polynomial_dfs side of gates_argument.hpp:203-216), every column resident: one gate of four
+    factors over the 4n-point extended domain, a second part over 2n points, F / (X^n - 1), the split into 4 parts and
+    commit(QUOTIENT_BATCH) through kzg_commitment_scheme_v2_hip from the resident parts (bench/scheme_bench.cpp)."""
+    import ctypes
+
+    lib = _bench_lib()
+    ms = np.zeros(5 * steps, dtype=np.float64)
+    verified = ctypes.c_int(-1)
+    rc = lib.zkhip_bench_quotient(0, ctypes.c_size_t(log_n), steps, ms.ctypes.data_as(ctypes.c_void_p), ctypes.byref(verified) if verify else None)
+    if rc != 0:
+        return {"error": rc}
+    ms = ms.reshape(steps, 5)
+    timed = ms[1:] if steps > 1 else ms
+    mean = timed.mean(axis=0)
+    total = float(mean.sum())
+    n = 1 << log_n
+    # SURVEY 8d's accounting, 64 B per element per transform + 128 B per (base, scalar) of a multiexp:
+    #   gate argument   4 factors + the mask, each iNTT(n) + NTT(4n)                      25 n
+    #   second part     w1, w2, w3: iNTT(n) + NTT(2n)                                      9 n
+    #   quotient        F1 2n -> 4n: iNTT(2n) + NTT(4n); coefficients(): iNTT(4n)         10 n
+    #   split           4 x from_coefficients: NTT(n)                                      4 n
+    #   commit          4 x coefficients(): iNTT(n); 4 multiexps of n points               4 n   (+ 4 n x 128 B)
+    alg = 52 * n * 64 + 4 * n * 128
+    ach = alg / (total * 1e-3) / 1e9
+    names = ("gate_argument", "second_part", "quotient_polynomial", "split_from_coefficients", "commit_quotient_batch")
+    return {"metric": "placeholder quotient chain, BLS12-381, 2^%d rows (one 4-factor gate over the 4x extended domain + one part over 2x), columns resident" % log_n,
+            "value": round(total, 3), "unit": "ms per chain", "higher_is_better": False, "statistic": "mean of the runs after the first",
+            "ms_by_phase": {k: round(float(v), 3) for k, v in zip(names, mean)}, "ms_per_run": [round(float(x), 2) for x in ms.sum(axis=1)],
+            "verified": None if not verify else bool(verified.value == 1),
+            "verification": "T(y) (y^n - 1) == alpha_0 G(y) + alpha_1 F1(y) at a random y; every commitment == part_k(alpha) G1",
+            "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                         "algorithmic_bytes_per_chain": alg, "per": "whole chain: 52 n transform elements x 64 B + 4 multiexps x n x 128 B (list in bench.py)",
+                         "dominant_kernels": "ntt_pass (the resizes to the extended domains) and msm_bucket_acc (the three non-zero parts' commitments)"}}
+
+
+def ntt_sharded_leg(np, torch, dist, zk, ctx, rank, world, local_rank, log_m=22, batch=8, steps=5, verify=True):
+    """BASELINE config 3 over N GPUs (north_star: "independent polynomial NTT batches shard across the 8 GPUs"): the 8
+    polynomials of 2^22 are dealt round-robin over the ranks (dist.shard_polys); every rank transforms its own polynomials in place --
+    NO collective in the data path --; the timed region is bracketed by barriers and the slowest rank counts (strong scaling: the
+    job is fixed).  Every rank checks its own outputs at sampled indices against the block-Horner evaluation of its inputs and the
+    verdicts are gathered."""
+    from crypto3_zk_amd import dist as zd
+
+    r = R_BLS
+    w = pow(7, (r - 1) >> log_m, r)
+    omega = lim(np, w)
+    m = 1 << log_m
+    mine = zd.shard_polys(batch, rank, world)
+    cnt = len(mine)
+    dev = f"cuda:{local_rank}"
+    data = np.concatenate([random_scalars(np, m, 300 + c) for c in mine]) if cnt else np.zeros((0, 4), dtype=np.uint64)
+    d = ctx.malloc(max(1, cnt) * m * 32)
+    ok = True
+    if cnt:
+        ctx.h2d(d, data)
+        if verify:
+            idx = [0, 1, m // 2 + 3, m - 1, 123457 % m, (7 * m) // 9]
+            pts = np.stack([lim(np, pow(w, i, r)) for i in idx])
+            want = ctx.poly_eval_dev(zk.BLS12_381, d, m, cnt, pts)
+            ctx.ntt_dev(zk.BLS12_381, d, log_m, cnt, omega)
+            got = np.zeros((cnt, m, 4), dtype=np.uint64)
+            ctx.d2h(got, d)
+            ok = bool(all((got[b, i] == want[b, k]).all() for b in range(cnt) for k, i in enumerate(idx)))
+        else:
+            ctx.ntt_dev(zk.BLS12_381, d, log_m, cnt, omega)
+        ctx.ntt_dev(zk.BLS12_381, d, log_m, cnt, omega)
+    times = []
+    for _ in range(steps + 1):
+        dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if cnt:
+            ctx.ntt_dev(zk.BLS12_381, d, log_m, cnt, omega)
+            ctx.sync()
+        dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        times.append(float(t.item()) * 1e3)
+    ctx.free(d)
+    verified = None
+    if verify:
+        parts = [None] * world
+        dist.all_gather_object(parts, bool(ok))
+        verified = bool(all(parts))
+    mean = sum(times[1:]) / len(times[1:])
+    return {"metric": "NTT elements/sec, BLS12-381 Fr, 2^%d x %d dealt over %d GPU(s)" % (log_m, batch, world),
+            "value": round(batch * m / mean / 1e3, 2), "unit": "Melements/s", "scaling": "strong", "statistic": "mean of the transforms after the first, slowest rank",
+            "ms_per_transform_batch": [round(t, 3) for t in times], "polynomials_per_rank": (batch + world - 1) // world,
+            "exchange": "none: the polynomials are independent (SURVEY 8e); two barriers bracket the timed region", "verified": verified}
+
+
 def kzg_sharded_leg(np, torch, dist, zk, ctx, rank, world, local_rank, log_n=20, cols=50, steps=2, verify=True):
     """BASELINE config 5's commitment leg over N GPUs: the 50 columns are dealt round-robin over the ranks
     (dist.shard_polys), every rank holds the whole SRS, commits its own columns (one batched inverse NTT + one MSM batch, no
@@ -922,6 +1052,9 @@ def kzg_sharded_leg(np, torch, dist, zk, ctx, rank, world, local_rank, log_n=20,
             "ms_per_commit": [round(t, 2) for t in times], "columns_per_rank": slots,
             "exchange": "one RCCL all-gather of %d B per rank per commit (the commitments); SRS replicated, no collective in the transforms or the multiexps" % (slots * 144),
             "verified": verified}
+
+
+CPU_GROTH16_LOG = 20  # --cpu-groth16-log: size of the CPU prover sample next to the 2^17 one (20 = the headline instance)
 
 
 def cpu_baseline(np, bases):
@@ -1003,20 +1136,28 @@ def cpu_baseline(np, bases):
     out["ntt"] = {"value": round((8 << 22) / dtn / 1e6, 3), "unit": "Melements/s", "cores": min(8, cores),
                   "sample": "all 8 polynomials of 2^22 (config 3), one thread per polynomial, %.1f s" % dtn}
     del a
-    # Groth16: the oracle's prover at 2^17 constraints over the domain the reference reduces over (its CPU key generation at 2^20
-    # would take minutes); keygen is outside the timing
-    Mg, ng = 1 << 17, 10
-    g = cp.Groth16(0, Mg, ng, seed=1)
-    kind, m = cp.domain_choice(Mg + ng + 1, 32)
-    wq = lim(np, pow(7, (r - 1) >> ((Mg + ng).bit_length()), r))
-    g.set_domain(kind, m, wq)
-    g.keygen(random_scalars(np, 5, 79), wq)
-    t0 = time.perf_counter()
-    cp.set_threads(best)
-    g.prove(lim(np, 5), lim(np, 6), wq, lim(np, 7), chunks=best)
-    dtg = time.perf_counter() - t0
-    out["groth16"] = {"value": round(Mg / dtg, 1), "unit": "constraints/s", "cores": best,
-                      "sample": "one proof at 2^17 constraints (2^20 needs minutes of CPU key generation), domain of %d points, %.1f s" % (m, dtg)}
+    # Groth16: the oracle's prover over the domain the reference reduces over, at 2^17 constraints (rounds 2-3's figure) and AT THE
+    # SIZE OF THE HEADLINE METRIC, 2^20: the oracle generates its own valid key from a fixed trapdoor (batched
+    # inversions: tens of seconds at 2^20; outside the timing) and ONE proof is timed on the best thread count of the MSM sweep
+    def cpu_proof(log_m):
+        Mg, ng = 1 << log_m, 10
+        g = cp.Groth16(0, Mg, ng, seed=1)
+        kind, m = cp.domain_choice(Mg + ng + 1, 32)
+        wq = lim(np, pow(7, (r - 1) >> ((Mg + ng).bit_length()), r))
+        g.set_domain(kind, m, wq)
+        cp.set_threads(cores)
+        tk = time.perf_counter()
+        g.keygen(random_scalars(np, 5, 79), wq)
+        tk = time.perf_counter() - tk
+        cp.set_threads(best)
+        t0 = time.perf_counter()
+        g.prove(lim(np, 5), lim(np, 6), wq, lim(np, 7), chunks=best)
+        dtg = time.perf_counter() - t0
+        return {"value": round(Mg / dtg, 1), "unit": "constraints/s", "cores": best, "constraints": Mg, "seconds_per_proof": round(dtg, 2),
+                "sample": "one proof at 2^%d constraints, domain of %d points (make_evaluation_domain's choice), chunks = %d threads, %.1f s; "
+                          "the oracle's own key generation took %.1f s on %d threads (not timed as proving)" % (log_m, m, best, dtg, tk, cores)}
+    out["groth16_2p17"] = cpu_proof(17)
+    out["groth16"] = cpu_proof(CPU_GROTH16_LOG) if CPU_GROTH16_LOG != 17 else out["groth16_2p17"]
     return out
 
 

@@ -139,7 +139,6 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
     typename prover::proof_type proof, first;
     int differing = 0;
     for (int k = 0; k < steps; ++k) {
-        if (k == steps - 1) zkhip_profile_enable(ctx.get(), 1);    // per-kernel HIP-event times of the last proof
         auto t1 = std::chrono::steady_clock::now();
         if (g_partial_only && world > 1) (void)prover::process_partial(dpk, primary, auxiliary);
         else if (g_gather_dev) proof = prover::process_device_gather(dpk, primary, auxiliary, r, s, g_d_mine, g_d_all, g_gather_dev);
@@ -148,8 +147,23 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
         if (k == 0) first = proof;
         else if (!(proof.g_A == first.g_A && proof.g_B == first.g_B && proof.g_C == first.g_C)) ++differing;    // same (r, s): every proof is THE proof
     }
-    if (prof && prof_cap) zkhip_profile_dump(ctx.get(), prof, prof_cap);    // per-kernel HIP-event ms of the last proof
-    zkhip_profile_enable(ctx.get(), 0);
+    /* Per-kernel durations for the roofline objects: ONE more, untimed proof with the G2 multiexp on the MAIN stream.  HIP events
+       around the launches of a single in-order stream bracket exactly each kernel's execution; with the G2 multiexp on its own
+       stream (the timed arrangement) an event pair also counts the time a launch queues behind the other stream's workgroups
+       (msm_bucket_large 2.98 ms for empty launches), which distorted every share computed from it. */
+    if (prof && prof_cap && !(g_partial_only && world > 1) && !g_gather_dev && !all_gather) {
+        const bool was = dpk.overlap_g2;
+        auto side = std::move(dpk.side);    // without its second context the key's G2 multiexp runs on the main stream (process() looks at `side`)
+        dpk.overlap_g2 = false;
+        (void)prover::process(dpk, primary, auxiliary, r, s);    // settle the serial arrangement, unprofiled
+        zkhip_profile_enable(ctx.get(), 1);
+        auto pv = prover::process(dpk, primary, auxiliary, r, s);
+        zkhip_profile_dump(ctx.get(), prof, prof_cap);
+        zkhip_profile_enable(ctx.get(), 0);
+        dpk.overlap_g2 = was;
+        dpk.side = std::move(side);
+        if (!(pv.g_A == first.g_A && pv.g_B == first.g_B && pv.g_C == first.g_C)) ++differing;
+    }
     /* the throughput arrangement: g_lanes provers at once over the SAME resident key (lane keys alias its queries), one host thread each */
     g_lanes_info[0] = g_lanes_info[1] = g_lanes_info[2] = g_lanes_info[3] = 0;
     if (g_lanes > 1 && world == 1 && !g_gather_dev) {

@@ -6,10 +6,12 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 
 #include <nil/crypto3/zk/hip/lpc.hpp>
+#include <nil/crypto3/zk/hip/placeholder_quotient.hpp>
 
 using namespace nil::crypto3::zk::hip;
 
@@ -184,6 +186,118 @@ int zkhip_bench_lpc_scheme(int device, size_t log_n, size_t cols, size_t expand,
         return 0;
     } catch (const std::exception &e) {
         fprintf(stderr, "zkhip_bench_lpc_scheme: %s\n", e.what());
+        return -1;
+    }
+}
+
+/* placeholder's quotient chain at size (hip/placeholder_quotient.hpp; prover.hpp:220-277, 314-317, gates_argument.hpp:203-216), every
+ * column RESIDENT: a gate theta * q * w0 * w1(next row) * w2 over the 4n-point extended domain (4 resizes + one 4-way product + the
+ * mask), a second part w1 * w2 - w3 over 2n points, F_consolidated = alpha_0 G + alpha_1 F1, its coefficients, the division by
+ * X^n - 1, the split into 4 parts of n coefficients, from_coefficients, and commit(QUOTIENT_BATCH) through the KZG scheme class from
+ * the resident parts.  ms: steps x {gate argument, second part, quotient_polynomial, split + from_coefficients, commit}.
+ * *verified: T(y) (y^n - 1) == alpha_0 G(y) + alpha_1 F1(y) at a random y (evaluations from the coefficient forms) and every
+ * commitment == part_k(alpha) G1. */
+int zkhip_bench_quotient(int device, size_t log_n, int steps, double *ms, int *verified) {
+    try {
+        typedef placeholder_quotient_hip<C> Q;
+        typedef device_polynomial_dfs<C> dfs;
+        const size_t n = (size_t)1 << log_n;
+        context ctx(device);
+        uint64_t seed = 77;
+        auto sm = [&seed]() {
+            uint64_t z = (seed += 0x9E3779B97F4A7C15ull);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return z ^ (z >> 31);
+        };
+        auto rnd = [&]() {
+            uint64_t w[4] = {sm(), sm(), sm(), sm() & 0x0fffffffffffffffull};
+            return A::scalar_from_limbs(w);
+        };
+        std::vector<polynomial_dfs<C>> h(6);
+        for (auto &p : h) p.values.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            const bool on = (i & 1) == 0;
+            h[4].values[i] = on ? rnd() : Fr::zero();            // selector
+            h[0].values[i] = on ? Fr::zero() : rnd();            // the gate holds on every selected row
+            h[1].values[i] = rnd();
+            h[2].values[i] = rnd();
+            h[5].values[i] = Fr::one();                          // mask
+        }
+        for (size_t i = 0; i < n; ++i) h[3].values[i] = h[1].values[i] * h[2].values[i];
+        std::vector<dfs> col;
+        for (size_t c = 0; c < 6; ++c) col.emplace_back(ctx, h[c], c == 5 ? 0 : n - 1);
+        std::vector<polynomial_dfs<C>>().swap(h);
+        std::vector<Fr> pw(n);
+        Fr x = Fr::one(), alpha(7);
+        for (size_t i = 0; i < n; ++i) pw[i] = x, x = x * alpha;
+        kzg_params_hip<C> params(ctx, device_bases<C, ZKHIP_G1>::from_scalars(ctx, pw.begin(), pw.end()));
+        std::vector<Fr>().swap(pw);
+        const Fr theta = rnd(), a0 = rnd(), a1 = rnd();
+        typename Q::device_coefficients T;
+        std::vector<dfs> parts;
+        std::vector<A::g1_value_type> commits;
+        std::unique_ptr<dfs> Gk, F1k;
+        for (int rep = 0; rep < steps; ++rep) {
+            auto t0 = std::chrono::steady_clock::now();
+            gate_product_hip<C> g;
+            g.factors = {&col[4], &col[0], &col[1], &col[2]};
+            g.rotations = {0, 0, 1, 0};
+            g.coefficient = theta;
+            dfs G = Q::gate_argument(ctx, {g}, col[5], 4 * n, bls_root);
+            ms[5 * rep] = ms_since(t0);
+            t0 = std::chrono::steady_clock::now();
+            dfs F1 = polynomial_product<C>({col[1], col[2]}, bls_root);
+            dfs w3 = col[3];
+            w3.resize(2 * n, bls_root);
+            F1 -= w3;
+            ctx.sync();
+            ms[5 * rep + 1] = ms_since(t0);
+            t0 = std::chrono::steady_clock::now();
+            T = Q::quotient_polynomial(ctx, {G, F1}, {a0, a1}, n, bls_root);
+            ms[5 * rep + 2] = ms_since(t0);
+            t0 = std::chrono::steady_clock::now();
+            parts = Q::quotient_polynomial_split_dfs(ctx, T, n, 4, n, bls_root);
+            ms[5 * rep + 3] = ms_since(t0);
+            t0 = std::chrono::steady_clock::now();
+            kzg_commitment_scheme_v2_hip<C, counting_transcript> scheme(params, bls_root);
+            scheme.append_to_batch(3, parts);    // QUOTIENT_BATCH (proof.hpp:40)
+            commits = scheme.commit(3);
+            ms[5 * rep + 4] = ms_since(t0);
+            if (rep == steps - 1) {
+                Gk.reset(new dfs(G));
+                F1k.reset(new dfs(F1));
+            }
+        }
+        if (verified) {
+            const Fr y = rnd();
+            uint64_t yl[4], v[4];
+            A::scalar_to_limbs(y, yl);
+            auto eval = [&](const void *d, size_t len) {
+                check(zkhip_poly_eval_dev(ctx.get(), A::id, d, len, len, 1, yl, 1, v), "zkhip_poly_eval_dev", ctx.get());
+                return A::scalar_from_limbs(v);
+            };
+            auto gc = Gk->coefficients(bls_root), fc = F1k->coefficients(bls_root);
+            Fr yn = y;
+            for (size_t k = 0; k < log_n; ++k) yn = yn * yn;
+            bool ok = eval(T.data.get(), T.size) * (yn - Fr::one()) == a0 * eval(gc.get(), Gk->size()) + a1 * eval(fc.get(), F1k->size());
+            uint64_t al[4];
+            A::scalar_to_limbs(alpha, al);
+            for (size_t k = 0; k < 4 && ok; ++k) {
+                const size_t lo = k * n, len = lo < T.size ? std::min(n, T.size - lo) : 0;
+                Fr e = Fr::zero();
+                if (len) {
+                    check(zkhip_poly_eval_dev(ctx.get(), A::id, T.at(lo), len, len, 1, al, 1, v), "zkhip_poly_eval_dev", ctx.get());
+                    e = A::scalar_from_limbs(v);
+                }
+                std::vector<Fr> one = {e};
+                ok = commits[k] == device_bases<C, ZKHIP_G1>::from_scalars(ctx, one.begin(), one.end()).at(0);
+            }
+            *verified = ok ? 1 : 0;
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkhip_bench_quotient: %s\n", e.what());
         return -1;
     }
 }

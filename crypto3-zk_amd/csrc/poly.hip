@@ -121,6 +121,25 @@ __global__ __launch_bounds__(256) void fr_vec_prod(const uint32_t *const *__rest
     fu_pack<U>(out + i * U::NL, fu_cond_sub_p(fu_mul(acc, one)));
 }
 
+// f / (X^n - 1) in coefficient form: the quotient of placeholder's `F_consolidated_normal / common_data.Z` (prover.hpp:273-275; Z is the
+// vanishing polynomial X^n - 1 of the basic n-row domain).  With f = sum_k X^(k n) f_k (blocks of n coefficients) the long division
+// gives q_(k-1) = f_k + q_k, i.e. quot[i + (k - 1) n] = sum_{j >= k} f[i + j n]: one lane per residue i < n walks its column top down.
+// The remainder f[i] + quot[i] must vanish for an exact division; lanes that see a non-zero one count into *bad.
+template <class U>
+__global__ __launch_bounds__(256) void poly_div_vanishing(const uint32_t *__restrict__ f, size_t len, size_t n, uint32_t *__restrict__ quot,
+                                                          uint32_t *__restrict__ bad) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || i >= len) return;
+    const size_t top = (len - 1 - i) / n;  // f[i + top n] is the column's last coefficient
+    Fu<U> s = Fu<U>::zero();
+    for (size_t k = top; k >= 1; --k) {
+        s = fu_cond_sub_p(fu_add(s, fu_unpack<U>(f + (i + k * n) * U::NL)));
+        fu_pack<U>(quot + (i + (k - 1) * n) * U::NL, s);
+    }
+    const Fu<U> r = fu_cond_sub_p(fu_add(s, fu_unpack<U>(f + i * U::NL)));
+    if (!r.limbs_zero()) atomicAdd(bad, 1u);
+}
+
 // out[i] = in[(i + rot) mod 2^log_n] on 32-byte elements: math::polynomial_shift (f(X) -> f(omega^shift X) on the
 // evaluation vector: index i reads i + shift * (size / domain_size)), permutation_argument.hpp:148, lookup_argument.hpp:232
 __global__ __launch_bounds__(256) void poly_rotate(const uint4 *__restrict__ in, uint32_t log_n, size_t rot, uint4 *__restrict__ out) {
@@ -381,6 +400,29 @@ int zkhip_fr_vec_op_dev(zkhip_ctx *ctx, int curve, int op, const void *d_a, cons
     ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     ZK_FR_DISPATCH(curve, ZK_LAUNCH(ctx, "fr_vec_op", fr_vec_op<U>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (const uint32_t *)d_a,
                                     (const uint32_t *)d_b, count, op, (uint32_t *)d_out));
+    return ZKHIP_OK;
+}
+
+int zkhip_poly_div_vanishing_dev(zkhip_ctx *ctx, int curve, const void *d_f, size_t len, size_t n, void *d_quot, uint64_t *nonzero_remainders) {
+    if (!ctx || n == 0 || (len && !d_f) || (len > n && !d_quot)) return ZKHIP_ERR_INVALID;
+    if (curve != CURVE_BLS12_381 && curve != CURVE_BN254) return ZKHIP_ERR_INVALID;
+    if (n >= ((size_t)1 << 39) || len >= ((size_t)1 << 40)) return ZKHIP_ERR_RANGE;
+    if (nonzero_remainders) *nonzero_remainders = 0;
+    if (len == 0) return ZKHIP_OK;
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ZK_TRY(ctx->ws_reserve(zkhip_ctx::ws_round(4)));
+    ctx->ws_reset();
+    uint32_t *d_bad = ctx->ws_take<uint32_t>(1);
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    const size_t lanes = std::min(n, len);
+    ZK_FR_DISPATCH(curve, ZK_LAUNCH(ctx, "poly_div_vanishing", poly_div_vanishing<U>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0,
+                                    (const uint32_t *)d_f, len, n, (uint32_t *)d_quot, d_bad));
+    if (nonzero_remainders) {
+        uint32_t bad = 0;
+        ZK_HIP_CHECK(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        *nonzero_remainders = bad;
+    }
     return ZKHIP_OK;
 }
 

@@ -439,9 +439,11 @@ __global__ void bases_spread_rows(const uint32_t *__restrict__ src, size_t count
     if (g >= count * stride) return;
     const size_t j = g / stride;
     const uint32_t w = (uint32_t)(g % stride), row = d_rows ? d_rows[j] : first + (uint32_t)j;
-    if (row >= n_total) {
+    // rows must be in range AND strictly increasing (the sparse B query's index list, r1cs_gg_ppzksnark.hpp check_b_indices): a
+    // repeated row would silently overwrite a point, so it raises the same sticky flag as a row beyond the end
+    if (row >= n_total || (d_rows && j + 1 < count && d_rows[j + 1] <= row)) {
         if (w == 0) atomicOr(status, ZK_STATUS_GATHER_RANGE);
-        return;
+        if (row >= n_total) return;
     }
     out[(size_t)row * stride + w] = src[g];
 }
@@ -449,6 +451,7 @@ __global__ void bases_spread_rows(const uint32_t *__restrict__ src, size_t count
 int zkhip_bases_spread(zkhip_ctx *ctx, const zkhip_bases *src, const uint32_t *d_rows, size_t first, size_t n_total, zkhip_bases **out) {
     if (!ctx || !src || !out) return ZKHIP_ERR_INVALID;
     if (n_total >= ((size_t)1 << 32) || (!d_rows && first + src->n > n_total)) return ZKHIP_ERR_RANGE;
+    if (src->n * src->stride_u32 >= ((size_t)1 << 39)) return ZKHIP_ERR_RANGE;  // one lane per word: the grid must fit 32 bits
     ZK_TRY(check_device(ctx));
     zkhip_bases *b = nullptr;
     ZK_TRY(bases_alloc(ctx, src->curve, src->group, n_total, &b));
@@ -462,9 +465,13 @@ int zkhip_bases_spread(zkhip_ctx *ctx, const zkhip_bases *src, const uint32_t *d
         }
         if (src->n) {
             const size_t lanes = src->n * src->stride_u32;
+            ctx->prof_begin("bases_spread_rows");
             hipLaunchKernelGGL(bases_spread_rows, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, ctx->stream, src->d, src->n, (uint32_t)src->stride_u32,
                                d_rows, (uint32_t)first, (uint32_t)n_total, b->d, ctx->d_status);
-            if (hipGetLastError() != hipSuccess) {
+            ctx->prof_end();
+            const hipError_t le = hipGetLastError();
+            if (le != hipSuccess) {
+                ctx->last_error = std::string("bases_spread_rows: ") + hipGetErrorString(le);
                 rc = ZKHIP_ERR_HIP;
                 break;
             }

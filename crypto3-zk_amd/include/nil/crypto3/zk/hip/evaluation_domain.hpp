@@ -57,7 +57,8 @@ namespace detail {
 
 /// The evaluation-domain constants the reference takes from crypto3-algebra / crypto3-math.
 ///   kind < 0 ("auto"): the domain make_evaluation_domain(num_constraints + num_inputs + 1) picks -- or, for a key whose
-///   H_query says so, the basic domain of the next power of two (both use the SAME omega: the primitive 2^ceil(log2)-th root);
+///   H_query says so, the basic domain of the next power of two (basic and step radix-2 use the SAME omega: the primitive
+///   2^ceil(log2)-th root; the extended domain's is the primitive 2^s-th root, s the field's two-adicity);
 ///   kind >= 0: exactly this domain (m points).
 template <typename CurveType>
 struct domain_params {
@@ -77,7 +78,13 @@ domain_params<CurveType> standard_domain_params(std::size_t min_size) {
     typedef curve_adapter<CurveType> adapter;
     static_assert(adapter::has_field_constants, "this curve adapter does not provide multiplicative_generator() / root_of_unity()");
     domain_params<CurveType> d;
-    d.omega = adapter::root_of_unity(detail::ceil_log2(min_size));
+    /* basic and step radix-2 use the primitive 2^ceil(log2 min_size)-th root; the EXTENDED domain (2^(s + 1) points for a field of
+       two-adicity s: two cosets of the largest radix-2 subgroup) uses the primitive 2^s-th root -- a 2^(s + 1)-th one does not
+       exist.  Ask the selection first. */
+    int kind = ZKHIP_DOMAIN_BASIC_RADIX2;
+    std::size_t m = 0;
+    check(zkhip_domain_choice(adapter::id, min_size, &kind, &m), "zkhip_domain_choice");
+    d.omega = adapter::root_of_unity(kind == ZKHIP_DOMAIN_EXTENDED_RADIX2 ? detail::ceil_log2(m) - 1 : detail::ceil_log2(min_size));
     d.coset_generator = adapter::multiplicative_generator();
     d.shift = d.coset_generator * d.coset_generator;
     return d;

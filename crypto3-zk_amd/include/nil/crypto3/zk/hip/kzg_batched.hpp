@@ -97,8 +97,24 @@ kzg_batched_proof_eval(const kzg_params_hip<CurveType> &params, const std::vecto
     const Fr gamma = transcript.challenge();
 
     std::size_t acc_len = 0;
-    for (std::size_t i = 0; i < polys.size(); ++i)
-        if (polys[i].size() > public_key.S[i].size()) acc_len = std::max(acc_len, polys[i].size() - public_key.S[i].size());
+    /* the reference asserts (f_i - r_i) % Z_{S_i} == 0 for EVERY polynomial (kzg.hpp:569-580); a public key whose r_i is not the
+       interpolation of f_i over S_i must not yield a proof here either.  f - r spans max(|f|, |r|) coefficients (a longer r_i makes
+       a non-vanishing remainder, caught by the divisions below); a short polynomial (deg f < |S|) passes only with f == r. */
+    auto coeff = [](const std::vector<Fr> &v, std::size_t j) { return j < v.size() ? v[j] : Fr::zero(); };
+    for (std::size_t i = 0; i < polys.size(); ++i) {
+        const std::size_t span = std::max(polys[i].size(), public_key.r[i].size());
+        std::size_t deg_p1 = 0;    // 1 + degree of f - r
+        for (std::size_t j = span; j-- > 0;)
+            if (!(coeff(polys[i], j) == coeff(public_key.r[i], j))) {
+                deg_p1 = j + 1;
+                break;
+            }
+        if (deg_p1 != 0 && deg_p1 <= public_key.S[i].size()) throw std::runtime_error("proof_eval: (f - r) does not vanish on S");
+    }
+    for (std::size_t i = 0; i < polys.size(); ++i) {
+        const std::size_t span = std::max(polys[i].size(), public_key.r[i].size());
+        if (span > public_key.S[i].size()) acc_len = std::max(acc_len, span - public_key.S[i].size());
+    }
     if (acc_len == 0) return adapter::g1_value_type::zero();    // every f_i = r_i: all quotients vanish
     if (acc_len > params.commitment_key.size()) throw std::runtime_error("proof_eval: quotient longer than the commitment key");
     auto d_acc = ctx.alloc(acc_len * 32);
@@ -106,10 +122,11 @@ kzg_batched_proof_eval(const kzg_params_hip<CurveType> &params, const std::vecto
     bool first = true;
     for (std::size_t i = 0; i < polys.size(); ++i, factor = factor * gamma) {
         const auto &f = polys[i];
-        if (f.size() <= public_key.S[i].size()) continue;    // deg f < |S|: the quotient is zero (f = r)
-        /* spare_poly = f - r (:571) */
-        std::vector<Fr> spare(f);
-        for (std::size_t j = 0; j < public_key.r[i].size() && j < spare.size(); ++j) spare[j] = spare[j] - public_key.r[i][j];
+        const std::size_t span = std::max(f.size(), public_key.r[i].size());
+        if (span <= public_key.S[i].size()) continue;    // deg (f - r) < |S| and f == r (checked above): the quotient is zero
+        /* spare_poly = f - r (:571), over the longer of the two */
+        std::vector<Fr> spare(span, Fr::zero());
+        for (std::size_t j = 0; j < span; ++j) spare[j] = coeff(f, j) - coeff(public_key.r[i], j);
         auto d_q = ctx.alloc(spare.size() * 32);
         upload_scalars<adapter>(ctx, d_q.get(), spare.data(), spare.size());
         /* spare_poly /= create_polynom_by_zeros(S_i) (:572-580): one root at a time, every remainder must vanish */

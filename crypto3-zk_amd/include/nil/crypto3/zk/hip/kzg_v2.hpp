@@ -33,6 +33,7 @@
 #include <set>
 #include <vector>
 
+#include "fri.hpp"
 #include "kzg.hpp"
 
 namespace nil {
@@ -197,6 +198,17 @@ public:
         if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
         _polys[index].push_back(&poly.get());
     }
+    /// A polynomial that is ALREADY resident (device_polynomial_dfs, fri.hpp: the quotient parts of placeholder_quotient.hpp, a
+    /// witness column built on the device) joins the batch where it lies: commit copies it device-to-device instead of crossing PCIe.
+    /// Not in the reference's interface -- an addition for callers that keep their columns on the GPU.
+    void append_to_batch(std::size_t index, const device_polynomial_dfs<CurveType> &poly) {
+        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
+        _resident[index].emplace(_polys[index].size(), poly);
+        _polys[index].push_back(nullptr);
+    }
+    void append_to_batch(std::size_t index, const std::vector<device_polynomial_dfs<CurveType>> &polys) {
+        for (const auto &p : polys) append_to_batch(index, p);
+    }
     void append_eval_point(std::size_t batch_id, const scalar_value_type &point) {
         for (auto &pts : _points.at(batch_id)) pts.push_back(point);
     }
@@ -218,14 +230,16 @@ public:
     commitment_type commit(std::size_t index) {
         const context &ctx = _params.ctx;
         const std::vector<const poly_type *> &polys = _polys[index];
+        const auto &resident = _resident[index];    // position -> a polynomial that is already on the device (polys[position] == nullptr)
         device_batch db;
         std::size_t total = 0;
-        for (const poly_type *p : polys) {
-            if (p->size() == 0 || (p->size() & (p->size() - 1))) throw std::runtime_error("commit: polynomial_dfs size must be a power of two");
-            if (p->size() > _params.commitment_key.size()) throw std::runtime_error("commit: polynomial longer than the commitment key");
+        for (std::size_t i = 0; i < polys.size(); ++i) {
+            const std::size_t sz = polys[i] ? polys[i]->size() : resident.at(i).size();
+            if (sz == 0 || (sz & (sz - 1))) throw std::runtime_error("commit: polynomial_dfs size must be a power of two");
+            if (sz > _params.commitment_key.size()) throw std::runtime_error("commit: polynomial longer than the commitment key");
             db.offset.push_back(total);
-            db.len.push_back(p->size());
-            total += p->size();
+            db.len.push_back(sz);
+            total += sz;
         }
         db.data = ctx.alloc(std::max<std::size_t>(1, total) * 32);
         const std::size_t count = polys.size(), jl = 3 * adapter::g1_coord_limbs;
@@ -240,7 +254,10 @@ public:
             /* the first chunk is a short one: nothing runs on the device until it has arrived */
             const std::size_t limit = (pipelined && i == 0) ? std::max<std::size_t>(1, upload_chunk / 4) : upload_chunk;
             while (j < count && db.len[j] == db.len[i] && (limit == 0 || j - i < limit)) ++j;
-            for (std::size_t p = i; p < j; ++p) upload_scalars<adapter>(up, db.at(p), detail::poly_data<adapter>(*polys[p]), polys[p]->size());
+            for (std::size_t p = i; p < j; ++p) {
+                if (polys[p]) upload_scalars<adapter>(up, db.at(p), detail::poly_data<adapter>(*polys[p]), polys[p]->size());
+                else check(zkhip_memcpy_d2d_async(up.get(), db.at(p), resident.at(p).data(), db.len[p] * 32), "zkhip_memcpy_d2d_async", up.get());
+            }
             if (pipelined) ctx.wait_for(up);
             std::size_t log_n = 0;
             while (((std::size_t)1 << log_n) < db.len[i]) ++log_n;
@@ -263,6 +280,7 @@ public:
         _locked[index] = true;
         _points[index].resize(polys.size());
         _polys[index].clear();    // no pointer to a lent polynomial outlives the call
+        _resident[index].clear();
         return _ind_commitments[index];
     }
 
@@ -399,6 +417,7 @@ protected:
     root_of_unity_type _root_of_unity;
     std::map<std::size_t, std::vector<const poly_type *>> _polys;    // in append order: copies held in _owned, or the caller's (lent)
     std::map<std::size_t, std::deque<poly_type>> _owned;             // a deque: references stay valid as it grows
+    std::map<std::size_t, std::map<std::size_t, device_polynomial_dfs<CurveType>>> _resident;    // batch -> position -> resident polynomial
     std::map<std::size_t, bool> _locked;
     std::map<std::size_t, std::vector<std::vector<scalar_value_type>>> _points;
     std::map<std::size_t, device_batch> _dev;

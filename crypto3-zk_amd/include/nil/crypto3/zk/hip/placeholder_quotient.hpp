@@ -1,0 +1,175 @@
+//---------------------------------------------------------------------------//
+// zkhip shim: placeholder's quotient-polynomial chain on the device -- the NTT consumers SURVEY section 2 stars next to the
+// commitment schemes (#10-12):
+//   placeholder_prover::quotient_polynomial            zk/snark/systems/plonk/placeholder/prover.hpp:262-277
+//   placeholder_prover::quotient_polynomial_split_dfs  prover.hpp:220-259   (detail::split_polynomial, prover.hpp:55-69)
+//   placeholder_prover::T_commit                       prover.hpp:314-317
+//   the polynomial_dfs side of the gates argument      gates_argument.hpp:93-121, 203-216 (polynomial_shift, resize to the extended
+//        domain, pointwise products and sums, `F[0] *= mask_polynomial`)
+// What stays the reference's: the symbolic expression machinery that decides WHICH products a circuit's gates are
+// (math::expression, the visitors; SURVEY section 2 out of scope) -- here the caller names the factors.
+//
+// Everything below works on device_polynomial_dfs (fri.hpp): the columns stay resident from the table to the commitment
+// (kzg_polys_evaluator_hip::append_to_batch(index, device_polynomial_dfs) takes them where they lie).
+//---------------------------------------------------------------------------//
+#ifndef ZKHIP_SHIM_PLACEHOLDER_QUOTIENT_HPP
+#define ZKHIP_SHIM_PLACEHOLDER_QUOTIENT_HPP
+
+#include <algorithm>
+#include <stdexcept>
+#include <vector>
+
+#include "fri.hpp"
+
+namespace nil {
+namespace crypto3 {
+namespace zk {
+namespace hip {
+
+/// One gate's contribution as gates_argument.hpp:203-216 evaluates it once the expression is a product: selector x factors, every
+/// factor first moved by its rotation (math::polynomial_shift over the ORIGINAL domain, gates_argument.hpp:108-110) and resized to
+/// the extended domain (`assignment.resize(extended_domain_size, ...)`, :111-113), times theta^k.
+template <typename CurveType>
+struct gate_product_hip {
+    std::vector<const device_polynomial_dfs<CurveType> *> factors;    // selector first, then the columns
+    std::vector<int> rotations;                                       // one per factor (0: none)
+    typename curve_adapter<CurveType>::scalar_value_type coefficient; // theta_acc of the constraint
+};
+
+template <typename CurveType>
+struct placeholder_quotient_hip {
+    typedef curve_adapter<CurveType> adapter;
+    typedef typename adapter::scalar_value_type value_type;
+    typedef device_polynomial_dfs<CurveType> dfs_type;
+    typedef typename dfs_type::root_of_unity_type root_of_unity_type;
+
+    /// A coefficient vector resident on the device (math::polynomial as far as this chain needs it)
+    struct device_coefficients {
+        std::shared_ptr<void> data;
+        std::size_t size = 0;    // coefficients (the top ones may be zero: nothing here condenses)
+        const void *at(std::size_t i) const { return static_cast<const char *>(data.get()) + 32 * i; }
+    };
+
+    /// gates_argument.hpp:203-216: F = (sum over the gates' products) * mask_polynomial on the extended domain of `extended_size`
+    /// points (original_domain->m * 2^ceil(log2(max_gates_degree + 1)), :149-150).
+    static dfs_type gate_argument(const context &ctx, const std::vector<gate_product_hip<CurveType>> &products, const dfs_type &mask_polynomial,
+                                  std::size_t extended_size, const root_of_unity_type &root) {
+        if (products.empty()) throw std::invalid_argument("gate_argument: no products");
+        dfs_type F(ctx, extended_size);
+        bool first = true;
+        for (const auto &g : products) {
+            if (g.factors.empty() || g.rotations.size() != g.factors.size()) throw std::invalid_argument("gate_argument: factors / rotations");
+            std::vector<dfs_type> moved;
+            std::vector<const void *> ptrs;
+            std::size_t degree = 0;
+            for (std::size_t k = 0; k < g.factors.size(); ++k) {
+                dfs_type f = g.rotations[k] ? polynomial_shift(*g.factors[k], g.rotations[k]) : *g.factors[k];
+                degree += f.degree();
+                f.resize(extended_size, root);
+                moved.push_back(std::move(f));
+            }
+            if (degree >= extended_size) throw std::invalid_argument("gate_argument: the product's degree does not fit the extended domain");
+            for (const auto &f : moved) ptrs.push_back(f.data());
+            dfs_type term(ctx, extended_size);
+            term.set_degree(degree);
+            check(zkhip_fr_vec_prod_dev(ctx.get(), adapter::id, ptrs.size(), ptrs.data(), term.data(), extended_size), "zkhip_fr_vec_prod_dev", ctx.get());
+            /* F (+)= coefficient * term */
+            std::uint64_t c[4];
+            adapter::scalar_to_limbs(g.coefficient, c);
+            const void *tp = term.data();
+            check(zkhip_poly_lincomb_dev(ctx.get(), adapter::id, 1, &tp, &extended_size, c, 1, F.data(), extended_size, first ? 0 : 1), "zkhip_poly_lincomb_dev",
+                  ctx.get());
+            F.set_degree(first ? degree : std::max(F.degree(), degree));
+            first = false;
+            ctx.sync();    // `moved` and `term` are released at the end of the iteration
+        }
+        dfs_type mask = mask_polynomial;
+        if (F.degree() + mask.degree() >= extended_size) throw std::invalid_argument("gate_argument: mask * F does not fit the extended domain");
+        mask.resize(extended_size, root);
+        F *= mask;    // gates_argument.hpp:215
+        ctx.sync();
+        return F;
+    }
+
+    /// prover.hpp:262-277: F_consolidated = sum_i alphas[i] * F_dfs[i] (math::polynomial_sum: on the largest of the domains; a part that
+    /// is_zero() -- size 0 here -- is skipped as :267-269 does), its coefficients, and the exact quotient by Z = X^rows_amount - 1.
+    /// Throws when the division leaves a remainder (the circuit is not satisfied): the reference would commit to a wrong quotient.
+    static device_coefficients quotient_polynomial(const context &ctx, const std::vector<dfs_type> &F_dfs, const std::vector<value_type> &alphas,
+                                                   std::size_t rows_amount, const root_of_unity_type &root) {
+        if (F_dfs.size() != alphas.size() || F_dfs.empty()) throw std::invalid_argument("quotient_polynomial: one alpha per part");
+        std::size_t size = 0;
+        for (const auto &f : F_dfs) size = std::max(size, f.size());
+        if (size < 2 * rows_amount) size = 2 * rows_amount;    // at least one quotient coefficient block
+        std::vector<dfs_type> parts;
+        std::vector<const void *> ptrs;
+        std::vector<std::size_t> lens;
+        std::vector<std::uint64_t> coeffs;
+        for (std::size_t i = 0; i < F_dfs.size(); ++i) {
+            if (F_dfs[i].size() == 0) continue;
+            dfs_type p = F_dfs[i];
+            p.resize(size, root);
+            parts.push_back(std::move(p));
+            std::uint64_t a[4];
+            adapter::scalar_to_limbs(alphas[i], a);
+            coeffs.insert(coeffs.end(), a, a + 4);
+        }
+        for (const auto &p : parts) {
+            ptrs.push_back(p.data());
+            lens.push_back(size);
+        }
+        dfs_type F(ctx, size);
+        check(zkhip_poly_lincomb_dev(ctx.get(), adapter::id, ptrs.size(), ptrs.data(), lens.data(), coeffs.data(), 1, F.data(), size, 0), "zkhip_poly_lincomb_dev",
+              ctx.get());
+        /* F_consolidated_dfs.coefficients() (:273), in place: F is a temporary */
+        std::size_t log_size = 0;
+        while (((std::size_t)1 << log_size) < size) ++log_size;
+        std::uint64_t w[4];
+        adapter::scalar_to_limbs(root(log_size), w);
+        check(zkhip_ntt_dev(ctx.get(), adapter::id, F.data(), log_size, 1, w, 1, nullptr), "zkhip_ntt_dev", ctx.get());
+        /* T_consolidated = F_consolidated_normal / common_data.Z (:275) */
+        device_coefficients T;
+        T.size = size - rows_amount;
+        T.data = ctx.alloc(T.size * 32);
+        std::uint64_t bad = 0;
+        check(zkhip_poly_div_vanishing_dev(ctx.get(), adapter::id, F.data(), size, rows_amount, T.data.get(), &bad), "zkhip_poly_div_vanishing_dev", ctx.get());
+        if (bad) throw std::runtime_error("quotient_polynomial: F_consolidated is not divisible by the vanishing polynomial");
+        return T;
+    }
+
+    /// prover.hpp:220-259: detail::split_polynomial(T, rows_amount - 1) -- chunks of rows_amount coefficients (:55-69) -- and
+    /// `T_splitted_dfs[k].from_coefficients(T_splitted[k])` over the `dfs_size`-point domain (|_F_dfs[0]|, :251-252) for
+    /// `split_polynomial_size` parts; parts beyond the quotient's length are the zero polynomial, as the reference initialises them.
+    static std::vector<dfs_type> quotient_polynomial_split_dfs(const context &ctx, const device_coefficients &T, std::size_t rows_amount,
+                                                               std::size_t split_polynomial_size, std::size_t dfs_size, const root_of_unity_type &root) {
+        const std::size_t chunks = (T.size + rows_amount - 1) / rows_amount;
+        /* the reference writes T_splitted_dfs[k] for EVERY chunk (:255-257): more chunks than parts is out of bounds there -- refused here */
+        if (chunks > split_polynomial_size) throw std::invalid_argument("quotient_polynomial_split_dfs: the quotient needs more parts than split_polynomial_size");
+        if (dfs_size < rows_amount) throw std::invalid_argument("quotient_polynomial_split_dfs: dfs_size < rows_amount");
+        std::vector<dfs_type> out;
+        std::size_t log_size = 0;
+        while (((std::size_t)1 << log_size) < dfs_size) ++log_size;
+        std::uint64_t w[4];
+        adapter::scalar_to_limbs(root(log_size), w);
+        for (std::size_t k = 0; k < split_polynomial_size; ++k) {
+            dfs_type p(ctx, dfs_size);
+            const std::size_t lo = k * rows_amount, len = lo < T.size ? std::min(rows_amount, T.size - lo) : 0;
+            /* zero-padded chunk -> evaluations (from_coefficients) */
+            const void *src = len ? T.at(lo) : nullptr;
+            std::uint64_t one[4];
+            adapter::scalar_to_limbs(value_type::one(), one);
+            check(zkhip_poly_lincomb_dev(ctx.get(), adapter::id, len ? 1 : 0, &src, &len, one, 1, p.data(), dfs_size, 0), "zkhip_poly_lincomb_dev", ctx.get());
+            check(zkhip_ntt_dev(ctx.get(), adapter::id, p.data(), log_size, 1, w, 0, nullptr), "zkhip_ntt_dev", ctx.get());
+            p.set_degree(len ? len - 1 : 0);
+            out.push_back(std::move(p));
+        }
+        ctx.sync();
+        return out;
+    }
+};
+
+}    // namespace hip
+}    // namespace zk
+}    // namespace crypto3
+}    // namespace nil
+
+#endif    // ZKHIP_SHIM_PLACEHOLDER_QUOTIENT_HPP

@@ -145,7 +145,7 @@ public:
     }
     /// a second handle on the same resident matrices (read-only after construction and set_domain), for another prover lane
     struct alias_tag { };
-    device_r1cs(alias_tag, const device_r1cs &o) : ctx_(o.ctx_), min_size_(o.min_size_), r_(o.r_), owner_(false) { }
+    device_r1cs(alias_tag, const device_r1cs &o) : ctx_(o.ctx_), min_size_(o.min_size_), r_(o.r_), owner_(false), aliases_(o.aliases_) { ++*aliases_; }
     ~device_r1cs() {
         if (owner_) zkhip_r1cs_free(ctx_->get(), r_);
     }
@@ -156,7 +156,13 @@ public:
     /// (r1cs_to_qap.hpp:229-230), until set_domain installs another (e.g. the basic one a key was generated over)
     std::size_t domain_size() const { return zkhip_r1cs_domain_size(r_); }
     int domain_kind() const { return zkhip_r1cs_domain_kind(r_); }
-    void set_domain(int kind, std::size_t m) { check(zkhip_r1cs_set_domain(r_, kind, m), "zkhip_r1cs_set_domain", ctx_->get()); }
+    /// The domain lives in the resident object every alias handle shares: installing the domain it already has is a no-op, and a
+    /// CHANGE is refused once another lane holds an alias (it may be reading kind / n0 / n1 in the middle of a proof).
+    void set_domain(int kind, std::size_t m) {
+        if (domain_kind() == kind && domain_size() == m) return;
+        if (*aliases_ != 0) throw std::logic_error("device_r1cs::set_domain: the constraint system is shared with other prover lanes");
+        check(zkhip_r1cs_set_domain(r_, kind, m), "zkhip_r1cs_set_domain", ctx_->get());
+    }
     void set_domain(const evaluation_domain_hip<CurveType> &d) { set_domain(d.kind, d.m); }
     std::size_t min_domain_size() const { return min_size_; }
 
@@ -165,6 +171,7 @@ private:
     std::size_t min_size_ = 0;
     zkhip_r1cs *r_ = nullptr;
     bool owner_ = true;
+    std::shared_ptr<std::size_t> aliases_ = std::make_shared<std::size_t>(0);    // alias handles ever taken on r_ (shared with them)
 };
 
 // ---- reductions::r1cs_to_qap<F>::witness_map on the device ---------------------------------------------------
@@ -322,6 +329,7 @@ public:
         B_rows_aligned(other.B_rows_aligned), overlap_g2(other.overlap_g2), side_stream_priority(other.side_stream_priority),
         direct_assignment_upload(other.direct_assignment_upload) {
         if (lane_ctx.device() != other.ctx.device()) throw std::invalid_argument("proving key lane: the lane's context is on another GPU than the key");
+        other.lanes_taken_ = true;    // from here on `other` keeps its queries where they are (align_rows)
     }
 
     const context &ctx;
@@ -352,6 +360,7 @@ public:
     /// it removes used to run under the G2 accumulation's multiply-adds), two provers sharing the GPU 51.3 -> 51.8 proofs/s.
     bool share_sorts = true;
     mutable bool L_rows_aligned = false, B_rows_aligned = false;
+    mutable bool lanes_taken_ = false;    // a lane key aliases this key's queries
     /// second in-order stream on the same GPU for the G2 multiexp (its own workspace); false: everything on `ctx`
     bool overlap_g2 = true;
     /// scheduling priority of that second stream (< 0: above, > 0: below the main stream's; "stream_priority" in include/zkhip.h)
@@ -366,7 +375,9 @@ public:
     mutable std::int64_t saved_sort_tile_log = 14;    // the caller's "msm_sort_tile_log", set aside for the duration of a proof
     /// lays L_query and (when dense) the B query's G1 half out over A_query's rows -- see share_sorts; once, before the first proof
     void align_rows() const {
-        if (!share_sorts || shard.world != 1 || L_rows_aligned) return;
+        /* a lane aliases L_query / B_query_h by their device pointers: once one exists the layout is frozen -- a share_sorts switched
+           on afterwards must not move (and free) what the lanes read */
+        if (!share_sorts || shard.world != 1 || L_rows_aligned || lanes_taken_) return;
         const std::size_t N = host.constraint_system.num_variables(), n = host.constraint_system.num_inputs();
         if (L_query.size() != N - n || A_query.size() != N + 1) return;
         L_query = L_query.spread(nullptr, n + 1, N + 1);

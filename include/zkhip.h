@@ -112,7 +112,8 @@ int zkhip_bases_from_scalars(zkhip_ctx *ctx, int curve, int group, const uint64_
  * first + j) and the point at infinity everywhere else, with its own window tables.  What it is for: queries of one proof that are
  * multiplied by the same assignment vector -- A_query, the B query's G1 half (sparse: its index list is d_rows), L_query (the auxiliary
  * part: first = n + 1) -- laid out over the SAME rows share one digit extraction and sort in zkhip_msm_batch_dev ("msm_share_sort").
- * A row beyond n_total raises the gather flag of zkhip_device_status. */
+ * d_rows must be STRICTLY INCREASING; a row beyond n_total or a repeated / out-of-order row raises the gather flag of
+ * zkhip_device_status (a repeated row would overwrite a point). */
 int zkhip_bases_spread(zkhip_ctx *ctx, const zkhip_bases *src, const uint32_t *d_rows /* nullable */, size_t first, size_t n_total,
                        zkhip_bases **out);
 int zkhip_bases_download(zkhip_ctx *ctx, const zkhip_bases *b, size_t offset, size_t n, uint64_t *affine_xy, uint8_t *is_infinity);
@@ -272,6 +273,12 @@ int zkhip_poly_eval_dev(zkhip_ctx *ctx, int curve, const void *d_polys, size_t n
  * d_out[0] = f(z) (the remainder), d_out[1 .. n) = the quotient's n - 1 coefficients.  d_out may equal d_f.
  * `remainder` (nullable, host) receives f(z); passing it synchronises the stream. */
 int zkhip_poly_div_linear_dev(zkhip_ctx *ctx, int curve, const void *d_f, size_t n, const uint64_t *z, void *d_out, uint64_t *remainder);
+/* Exact division by the vanishing polynomial X^n - 1 of the basic n-point domain, in coefficient form: placeholder's
+ * `T_consolidated = F_consolidated_normal / common_data.Z` (ph/prover.hpp:273-275).  d_f: len coefficients; d_quot receives the
+ * len - n coefficients of the quotient (nothing when len <= n); d_quot must not overlap d_f.  nonzero_remainders (nullable, host;
+ * passing it synchronises the stream) receives the number of non-zero coefficients of the remainder -- 0 for the exact division
+ * a satisfied circuit gives. */
+int zkhip_poly_div_vanishing_dev(zkhip_ctx *ctx, int curve, const void *d_f, size_t len, size_t n, void *d_quot, uint64_t *nonzero_remainders);
 /* d_acc[j] (+)= sum_i sum_{t < taps} coeffs[i * taps + t] * poly_i[j - t] for j < acc_len (poly_i is zero outside
  * [0, lens[i])): the accumulation `f += theta_i * (f_i - U) * diffpoly` (kzg_v2.hpp:258-263) for every committed
  * polynomial in ONE pass (coeffs[i] = theta_i * diffpoly_i, a few taps), and `L += ...` (:281-288) with taps = 1.

@@ -1087,6 +1087,72 @@ def polynomial_shift(evals: Sequence[int], shift: int, domain_size: int = 0) -> 
     return [evals[(i + shift * step) % n] for i in range(n)]
 
 
+# --------------------------------------------------------------------------------------
+# placeholder's quotient-polynomial chain (the NTT consumers next to the commitment schemes); restates
+#   zk/snark/systems/plonk/placeholder/prover.hpp:55-69       detail::split_polynomial
+#   zk/snark/systems/plonk/placeholder/prover.hpp:220-259     quotient_polynomial_split_dfs
+#   zk/snark/systems/plonk/placeholder/prover.hpp:262-277     quotient_polynomial
+#   zk/snark/systems/plonk/placeholder/gates_argument.hpp:93-121, 203-216   the polynomial_dfs arithmetic of the gate argument
+# PINNED: split_polynomial to the reference's own literals (test/systems/plonk/placeholder/placeholder.cpp:513-532) and its
+# identity f(y) = sum_i f_i(y) y^((max_degree + 1) i); the rest to the definitions (dense big-integer polynomial arithmetic:
+# poly_mul / poly_divmod below), in tests/test_oracle_kat.py::test_placeholder_quotient_chain_definitions.
+# --------------------------------------------------------------------------------------
+def split_polynomial(f: Sequence[int], max_degree: int) -> List[List[int]]:
+    """prover.hpp:55-69: chunks of max_degree + 1 coefficients"""
+    chunk = max_degree + 1
+    return [list(f[i:i + chunk]) for i in range(0, len(f), chunk)]
+
+
+def gate_argument_dfs(products, mask: Sequence[int], extended_size: int, root_of_unity, r: int) -> List[int]:
+    """gates_argument.hpp:203-216 for gates that are products: products = [(coefficient, [(evals, rotation), ...]), ...] over the
+    ORIGINAL n-point domain; every factor is shifted over that domain (:108-110), resized to the extended domain (:111-113),
+    multiplied pointwise; the weighted sum is multiplied by the mask polynomial (:215)."""
+    F = [0] * extended_size
+    for coeff, factors in products:
+        term = [1] * extended_size
+        for evals, rot in factors:
+            e = polynomial_shift(evals, rot) if rot else list(evals)
+            e = dfs_resize(e, extended_size, root_of_unity, r) if len(e) != extended_size else e
+            term = [a * b % r for a, b in zip(term, e)]
+        F = [(a + coeff * b) % r for a, b in zip(F, term)]
+    m = dfs_resize(list(mask), extended_size, root_of_unity, r) if len(mask) != extended_size else list(mask)
+    return [a * b % r for a, b in zip(F, m)]
+
+
+def quotient_polynomial(F_dfs: Sequence[Sequence[int]], alphas: Sequence[int], rows_amount: int, root_of_unity, r: int) -> List[int]:
+    """prover.hpp:262-277: coefficients of (sum_i alphas[i] F_dfs[i]) / (X^rows_amount - 1); parts live on different power-of-two
+    domains, math::polynomial_sum adds them on the largest.  NOT condensed: len = size - rows_amount.  Asserts exactness."""
+    size = max(max(len(f) for f in F_dfs), 2 * rows_amount)
+    acc = [0] * size
+    for f, a in zip(F_dfs, alphas):
+        if len(f) == 0:
+            continue
+        e = dfs_resize(list(f), size, root_of_unity, r) if len(f) != size else list(f)
+        acc = [(x + a * y) % r for x, y in zip(acc, e)]
+    coeffs = intt(acc, root_of_unity(size.bit_length() - 1), r)
+    # long division by Z = X^n - 1, column by column: q[i] = f[i + n] + q[i + n] (checked against q Z == f in the tests)
+    n = rows_amount
+    q = [0] * (size - n)
+    for i in range(size - n - 1, -1, -1):
+        q[i] = (coeffs[i + n] + (q[i + n] if i + n < size - n else 0)) % r
+    assert all((coeffs[i] + q[i]) % r == 0 for i in range(min(n, size - n))) and all(coeffs[i] == 0 for i in range(size - n, n)), \
+        "F_consolidated is not divisible by Z"
+    return q
+
+
+def quotient_polynomial_split_dfs(T: Sequence[int], rows_amount: int, split_polynomial_size: int, dfs_size: int, root_of_unity, r: int) -> List[List[int]]:
+    """prover.hpp:220-259: split into chunks of rows_amount coefficients, each from_coefficients over the dfs_size-point domain; parts
+    the quotient does not reach are the zero polynomial"""
+    parts = split_polynomial(poly_trim(T), rows_amount - 1)
+    assert len(parts) <= split_polynomial_size
+    w = root_of_unity(dfs_size.bit_length() - 1)
+    out = []
+    for k in range(split_polynomial_size):
+        c = parts[k] if k < len(parts) else []
+        out.append(ntt(list(c) + [0] * (dfs_size - len(c)), w, r))
+    return out
+
+
 def lpc_proof_eval(r: int, batches: dict, points: dict, fixed: Sequence[int], log_domain: int, step_list: Sequence[int], root_of_unity,
                    challenges: Sequence[int], tree_root):
     """batches[k] = list of DFS polynomials (lists of ints); points[k][i] = evaluation points of polynomial i of batch k;

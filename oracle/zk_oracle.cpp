@@ -493,14 +493,37 @@ static void batch_mul(const Affine<F> &base, const uint64_t *scalars, size_t n, 
         for (int i = 1; i < (1 << W); ++i) row[i] = row[i - 1].add(b);
         for (int i = 0; i < W; ++i) b = b.dbl();
     }
-#pragma omp parallel for schedule(dynamic, 64)
-    for (size_t i = 0; i < n; ++i) {
-        Jac<F> acc = Jac<F>::infinity();
-        for (int w = 0; w < NW; ++w) {
-            unsigned d = get_bits(scalars + 4 * i, 4, w * W, W);
-            if (d) acc = acc.add(table[((size_t)w << W) + d]);
+    // chunks of 256 results share ONE inversion (Montgomery's trick; batch_to_special in generator.hpp:190-192 does the same):
+    // a 2^20-constraint key (5.2 M G1 + 1 M G2 points) takes tens of seconds instead of minutes, which is what lets bench.py time
+    // the CPU prover at the size of the headline metric.  Same affine points as one inversion each.
+    const size_t CH = 256, nch = (n + CH - 1) / CH;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (size_t c = 0; c < nch; ++c) {
+        const size_t lo = c * CH, hi = std::min(n, lo + CH);
+        std::vector<Jac<F>> acc(hi - lo);
+        std::vector<F> pre(hi - lo);
+        F run = F::one();
+        for (size_t i = lo; i < hi; ++i) {
+            Jac<F> a = Jac<F>::infinity();
+            for (int w = 0; w < NW; ++w) {
+                unsigned d = get_bits(scalars + 4 * i, 4, w * W, W);
+                if (d) a = a.add(table[((size_t)w << W) + d]);
+            }
+            acc[i - lo] = a;
+            pre[i - lo] = run;  // product of the non-zero Z before this one
+            if (!a.is_inf()) run = run * a.Z;
         }
-        out[i] = acc.to_affine();
+        F inv = run.inv();
+        for (size_t i = hi; i-- > lo;) {
+            const Jac<F> &a = acc[i - lo];
+            if (a.is_inf()) {
+                out[i] = {F::zero(), F::zero(), true};
+                continue;
+            }
+            F zi = inv * pre[i - lo], zi2 = zi.sqr();
+            inv = inv * a.Z;
+            out[i] = {a.X * zi2, a.Y * zi2 * zi, false};
+        }
     }
 }
 

@@ -18,6 +18,7 @@
 #include <nil/crypto3/zk/hip/lpc.hpp>
 #include <nil/crypto3/zk/hip/marshalling.hpp>
 #include <array>
+#include <nil/crypto3/zk/hip/placeholder_quotient.hpp>
 #include <nil/crypto3/zk/hip/powers_of_tau.hpp>
 #include <nil/crypto3/zk/hip/r1cs_gg_ppzksnark.hpp>
 #include <nil/crypto3/zk/hip/r1cs_gg_ppzksnark_generator.hpp>
@@ -1232,15 +1233,76 @@ int placeholder_sequence_t(const uint64_t *srs, size_t n_srs, const uint64_t *ev
     if (a.size() > out_cap) return -32;
     std::copy(a.begin(), a.end(), out);
     *out_len = a.size();
-    /* LPC: theta, then one alpha per FRI round */
+    /* LPC: etha twice (the preprocessor's transcript and the prover's derive the SAME etha: preprocess, then setup -- lpc.hpp:82-107),
+       theta, then one alpha per FRI round */
     std::vector<uint64_t> ch;
-    for (int i = 0; i < 6; ++i) ch.insert(ch.end(), thetas + 4 * (i & 1), thetas + 4 * (i & 1) + 4);
+    for (int i : {0, 0, 1, 0, 1, 0, 1, 0}) ch.insert(ch.end(), thetas + 4 * i, thetas + 4 * i + 4);
     std::vector<uint64_t> la, lb;
-    rc = placeholder_sequence_lpc_run<Curve, polynomial_dfs<Curve>>(evals, npolys, log_n, nw, roots, challenge, ch.data(), 6, la);
+    rc = placeholder_sequence_lpc_run<Curve, polynomial_dfs<Curve>>(evals, npolys, log_n, nw, roots, challenge, ch.data(), 8, la);
     if (rc) return rc;
-    rc = placeholder_sequence_lpc_run<Curve, foreign>(evals, npolys, log_n, nw, roots, challenge, ch.data(), 6, lb);
+    rc = placeholder_sequence_lpc_run<Curve, foreign>(evals, npolys, log_n, nw, roots, challenge, ch.data(), 8, lb);
     if (rc) return rc;
     if (la != lb || la.empty()) return -33;
+    return 0;
+}
+
+// ---- placeholder's quotient chain on the device (placeholder_quotient.hpp; prover.hpp:220-277, 314-317, gates_argument.hpp:203-216) ----
+/// columns: w0, w1, w2, w3, q, mask (6 x 2^log_n evaluations).  Gate: theta * q * w0 * w1(next row) * w2, masked; second part
+/// w1 * w2 - w3 on the 2n-point domain (polynomial_product + resize + -=).  out: T (4n - n coefficients) | 4 parts x n evaluations |
+/// 4 commitments (affine limbs).  The quotient parts go to the KZG scheme's QUOTIENT batch WITHOUT leaving the device.
+template <typename Curve>
+int placeholder_quotient_t(const uint64_t *srs, size_t n_srs, const uint64_t *evals, size_t log_n, const uint64_t *roots, const uint64_t *theta,
+                           const uint64_t *alphas, uint64_t *out_T, uint64_t *out_parts, uint64_t *out_commits) {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::g1_value_type G1;
+    typedef typename A::scalar_value_type Fr;
+    typedef placeholder_quotient_hip<Curve> Q;
+    typedef device_polynomial_dfs<Curve> dfs;
+    const size_t n = (size_t)1 << log_n, L1 = 2 * A::g1_coord_limbs;
+    context ctx(0);
+    auto root = [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); };
+    std::vector<dfs> col;
+    for (size_t c = 0; c < 6; ++c) {
+        polynomial_dfs<Curve> h;
+        for (size_t i = 0; i < n; ++i) h.values.push_back(A::scalar_from_limbs(evals + 4 * (c * n + i)));
+        col.emplace_back(ctx, h, c == 5 ? 0 : n - 1);    // the mask is the constant 1 (degree 0)
+    }
+    gate_product_hip<Curve> g;
+    g.factors = {&col[4], &col[0], &col[1], &col[2]};
+    g.rotations = {0, 0, 1, 0};
+    g.coefficient = A::scalar_from_limbs(theta);
+    dfs G = Q::gate_argument(ctx, {g}, col[5], 4 * n, root);
+    dfs F1 = polynomial_product<Curve>({col[1], col[2]}, root);    // on the 2n-point domain
+    dfs w3 = col[3];
+    w3.resize(2 * n, root);
+    F1 -= w3;
+    auto T = Q::quotient_polynomial(ctx, {G, F1}, {A::scalar_from_limbs(alphas), A::scalar_from_limbs(alphas + 4)}, n, root);
+    if (T.size != 3 * n) return -41;
+    ctx.d2h(out_T, T.data.get(), T.size * 32);
+    auto parts = Q::quotient_polynomial_split_dfs(ctx, T, n, 4, n, root);
+    for (size_t k = 0; k < parts.size(); ++k) ctx.d2h(out_parts + 4 * k * n, parts[k].data(), n * 32);
+    /* T_commit (prover.hpp:314-317) */
+    std::vector<G1> ck;
+    for (size_t i = 0; i < n_srs; ++i) ck.push_back(G1::from_affine(srs + i * L1));
+    kzg_params_hip<Curve> params(ctx, ck.begin(), ck.end());
+    kzg_commitment_scheme_v2_hip<Curve, scripted_any_transcript<Curve>> scheme(params, root);
+    constexpr std::size_t QUOTIENT_BATCH = 3;
+    scheme.append_to_batch(QUOTIENT_BATCH, parts);
+    auto commits = scheme.commit(QUOTIENT_BATCH);
+    if (commits.size() != 4) return -42;
+    for (size_t k = 0; k < 4; ++k) commits[k].to_affine(out_commits + k * L1);
+    /* an unsatisfied row must be refused, not committed to */
+    polynomial_dfs<Curve> hb = col[3].to_host();
+    hb.values[3] = hb.values[3] + Fr::one();
+    dfs w3b(ctx, hb, n - 1);
+    w3b.resize(2 * n, root);
+    dfs F1b = polynomial_product<Curve>({col[1], col[2]}, root);
+    F1b -= w3b;
+    try {
+        (void)Q::quotient_polynomial(ctx, {G, F1b}, {A::scalar_from_limbs(alphas), A::scalar_from_limbs(alphas + 4)}, n, root);
+        return -43;
+    } catch (const std::runtime_error &) {
+    }
     return 0;
 }
 
@@ -1512,6 +1574,16 @@ int shim_placeholder_sequence(int curve, const uint64_t *srs, size_t n_srs, cons
         return placeholder_sequence_t<alt_bn128_254>(srs, n_srs, evals, npolys, log_n, nw, roots, challenge, thetas, out, out_cap, out_len);
     } catch (const std::exception &e) {
         fprintf(stderr, "shim_placeholder_sequence: %s\n", e.what());
+        return -1;
+    }
+}
+int shim_placeholder_quotient(int curve, const uint64_t *srs, size_t n_srs, const uint64_t *evals, size_t log_n, const uint64_t *roots, const uint64_t *theta,
+                              const uint64_t *alphas, uint64_t *out_T, uint64_t *out_parts, uint64_t *out_commits) {
+    try {
+        if (curve == ZKHIP_BLS12_381) return placeholder_quotient_t<bls12_381>(srs, n_srs, evals, log_n, roots, theta, alphas, out_T, out_parts, out_commits);
+        return placeholder_quotient_t<alt_bn128_254>(srs, n_srs, evals, log_n, roots, theta, alphas, out_T, out_parts, out_commits);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "shim_placeholder_quotient: %s\n", e.what());
         return -1;
     }
 }

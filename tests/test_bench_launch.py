@@ -40,7 +40,7 @@ def test_bench_rccl_path_on_one_gpu():
     all-gather) and the KZG commit with its columns dealt over the ranks (all-gather of the commitments) at world = 1.  stdout must carry exactly one JSON line, every leg verified."""
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                           "--master-port", "29619", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--force-dist",
-                          "--no-ntt", "--no-pmc", "--no-cpu-baseline"],
+                          "--ntt-log-m", "20", "--no-pmc", "--no-cpu-baseline"],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -49,4 +49,5 @@ def test_bench_rccl_path_on_one_gpu():
     assert line["n_gpus"] == 1 and line["verified"] is True and line["scaling"] == "weak"
     assert line["groth16_sharded"]["verified"] is True and line["groth16"]["verified"] is True
     assert line["kzg_sharded"]["verified"] is True and line["kzg"]["verified"] is True
+    assert line["ntt_sharded"]["verified"] is True and line["ntt"]["verified"] is True
     assert line["roofline"]["bound"] == "hbm" and line["roofline"]["achieved"] > 0

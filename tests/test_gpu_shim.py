@@ -422,6 +422,45 @@ def test_placeholder_call_sequence_with_foreign_polynomial_type(shim, curve):
     assert at + 2 * L1 + 1 == len(out)
 
 
+@pytest.mark.parametrize("curve,log_n", [(0, 8), (1, 8), (0, 12)])
+def test_placeholder_quotient_chain_shim(shim, curve, log_n):
+    """placeholder's quotient chain on the device (hip/placeholder_quotient.hpp; prover.hpp:220-277, 314-317, gates_argument.hpp:
+    203-216) against the oracle's restatement (itself pinned to the reference's split_polynomial test and to dense polynomial
+    arithmetic, tests/test_oracle_kat.py): gate product over the 4x extended domain with a rotated column, a second part on the 2x
+    domain, F / (X^n - 1), the split into parts, and the QUOTIENT batch committed from device-resident parts = part(alpha) G."""
+    C = CURVES[curve]
+    r, alpha = C.r, 7
+    n = 1 << log_n
+    rng = po.SplitMix64(5100 + curve + log_n)
+    cols = [[rng.next_mod(r) for _ in range(n)] for _ in range(3)]
+    q = [1 + rng.next_mod(r - 1) if i % 2 == 0 else 0 for i in range(n)]
+    cols[0] = [0 if q[i] else cols[0][i] for i in range(n)]
+    w3 = [cols[1][i] * cols[2][i] % r for i in range(n)]
+    mask = [1] * n
+    theta, a0, a1 = (rng.next_mod(r) for _ in range(3))
+    root = C.root_of_unity
+    G = po.gate_argument_dfs([(theta, [(q, 0), (cols[0], 0), (cols[1], 1), (cols[2], 0)])], mask, 4 * n, root, r)
+    e1, e2, e3 = (po.dfs_resize(x, 2 * n, root, r) for x in (cols[1], cols[2], w3))
+    F1 = [(x * y - z) % r for x, y, z in zip(e1, e2, e3)]
+    T = po.quotient_polynomial([G, F1], [a0, a1], n, root, r)
+    parts = po.quotient_polynomial_split_dfs(T, n, 4, n, root, r)
+    srs = _srs(curve, alpha, n)
+    L1 = srs.shape[1]
+    evals = fr_arr(cols[0] + cols[1] + cols[2] + w3 + q + mask)
+    roots = np.stack([limbs(root(l), 4) for l in range(log_n + 3)])
+    out_T = np.zeros((3 * n, 4), dtype=np.uint64)
+    out_parts = np.zeros((4, n, 4), dtype=np.uint64)
+    out_commits = np.zeros((4, L1), dtype=np.uint64)
+    rc = shim.shim_placeholder_quotient(curve, P(srs), ctypes.c_size_t(n), P(evals), ctypes.c_size_t(log_n), P(roots), P(limbs(theta, 4)),
+                                        P(np.concatenate([limbs(a0, 4), limbs(a1, 4)])), P(out_T), P(out_parts), P(out_commits))
+    assert rc == 0
+    assert fr_ints(out_T) == T
+    for k in range(4):
+        assert fr_ints(out_parts[k]) == parts[k], k
+        chunk = T[k * n:(k + 1) * n]
+        assert (out_commits[k] == cp.batch_mul(curve, 1, fr_arr([po.poly_eval(chunk, alpha, r)]))[0][0]).all(), k
+
+
 @pytest.mark.parametrize("curve", [0, 1])
 def test_kzg_v2_proof_eval_shim(shim, curve):
     """kzg_commitment_scheme_v2::commit + proof_eval (kzg_v2.hpp:208-305) through the shim class against the oracle's

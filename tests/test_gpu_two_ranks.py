@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _run(port, extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--same-device", "--steps", "3", "--warmup", "1", "--log-n", "18",
-           "--no-cpu-baseline", "--no-pmc"] + extra
+           "--no-cpu-baseline", "--no-pmc", "--ntt-log-m", "18"] + extra
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
@@ -36,6 +36,8 @@ def test_two_ranks_point_split_and_sharded_legs():
     assert g["verified"] is True and len(g["ms_per_proof"]) >= 2
     k = line["kzg_sharded"]
     assert k["verified"] is True and k["columns_per_rank"] == 25
+    t = line["ntt_sharded"]    # BASELINE config 3's split: 8 polynomials dealt 4 / 4, no collective in the data path
+    assert t["verified"] is True and t["polynomials_per_rank"] == 4 and t["scaling"] == "strong"
 
 
 def test_two_ranks_window_split():

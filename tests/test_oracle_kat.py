@@ -323,3 +323,57 @@ def test_kzg_v1_oracle_identity():
             fac = fac * gamma % r
     assert lhs == po.poly_eval(accum, alpha, r) * po.poly_eval(po.vanishing_poly(merged, r), alpha, r) % r
     assert len(accum) == 32 - 3
+
+
+def test_placeholder_quotient_chain_definitions():
+    """The oracle's restatement of placeholder's quotient chain (prover.hpp:55-69, 220-277; gates_argument.hpp:203-216).
+    split_polynomial is PINNED to the reference's own test (test/systems/plonk/placeholder/placeholder.cpp:513-532: the literal
+    polynomial, max_degree 3 -> 4 parts, f(y) = sum_i f_i(y) y^(4 i)); the DFS arithmetic to its definition in dense coefficient
+    form: the product of the factors, the division by X^n - 1 and the split, all by big-integer polynomial arithmetic."""
+    C = CURVES[0]
+    r = C.r
+    f = [1, 3, 4, 1, 5, 6, 7, 2, 8, 7, 5, 6, 1, 2, 1, 1]            # placeholder.cpp:514
+    parts = po.split_polynomial(f, 3)
+    assert len(parts) == 4                                          # :515, 521
+    rng = random.Random(11)
+    y = rng.randrange(r)
+    assert po.poly_eval(f, y, r) == sum(po.poly_eval(p, y, r) * pow(y, 4 * i, r) for i, p in enumerate(parts)) % r   # :525-531
+    # a satisfied toy circuit over n = 16 rows: gate q * (w0 * w1(shifted by one row) * w2) with q != 0 only where w0 == 0, and a
+    # second part w1 * w2 - w3 with w3 := w1 o w2 on the domain; both vanish on the domain, so F / Z is exact
+    n, log_n = 16, 4
+    root = C.root_of_unity
+    w = root(log_n)
+    cols = [[rng.randrange(r) for _ in range(n)] for _ in range(3)]
+    q = [rng.randrange(1, r) if i % 2 == 0 else 0 for i in range(n)]
+    cols[0] = [0 if q[i] else cols[0][i] for i in range(n)]
+    w3 = [cols[1][i] * cols[2][i] % r for i in range(n)]
+    mask = [1] * n
+    theta = rng.randrange(r)
+    ext = 4 * n                                                    # degree of q w0 w1 w2 <= 4 (n - 1) < 4 n
+    G = po.gate_argument_dfs([(theta, [(q, 0), (cols[0], 0), (cols[1], 1), (cols[2], 0)])], mask, ext, root, r)
+    # definition: coefficients of every factor, dense product, evaluation on the extended domain
+    def coeffs(e):
+        return po.intt(list(e), root(len(e).bit_length() - 1), r)
+    shifted = [cols[1][(i + 1) % n] for i in range(n)]
+    dense = po.poly_scale(po.poly_mul(po.poly_mul(coeffs(q), coeffs(cols[0]), r), po.poly_mul(coeffs(shifted), coeffs(cols[2]), r), r), theta, r)
+    dense = po.poly_trim(po.poly_mul(dense, coeffs(mask), r))
+    assert G == po.ntt(dense + [0] * (ext - len(dense)), root(ext.bit_length() - 1), r)
+    F1_dense = po.poly_trim(po.poly_sub(po.poly_mul(coeffs(cols[1]), coeffs(cols[2]), r), coeffs(w3), r))
+    F1 = po.ntt(F1_dense + [0] * (2 * n - len(F1_dense)), root(5), r)
+    alphas = [rng.randrange(r), rng.randrange(r)]
+    T = po.quotient_polynomial([G, F1], alphas, n, root, r)
+    assert len(T) == ext - n
+    total = po.poly_add(po.poly_scale(dense, alphas[0], r), po.poly_scale(F1_dense, alphas[1], r), r)
+    Z = [r - 1] + [0] * (n - 1) + [1]
+    assert po.poly_trim(po.poly_mul(po.poly_trim(T), Z, r)) == po.poly_trim(total)
+    parts = po.quotient_polynomial_split_dfs(T, n, 4, n, root, r)
+    assert len(parts) == 4
+    back = []
+    for p in parts:
+        back += po.intt(p, w, r)
+    assert po.poly_trim(back) == po.poly_trim(T)
+    # an unsatisfied row is caught: the division is no longer exact
+    bad = list(G)
+    bad[4] = (bad[4] + 1) % r    # index 4 of the 4x extended domain IS a row of the original domain
+    with pytest.raises(AssertionError):
+        po.quotient_polynomial([bad, F1], alphas, n, root, r)
