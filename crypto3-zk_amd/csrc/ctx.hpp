@@ -79,6 +79,7 @@ struct zkhip_ctx {
     bool own_stream = false;
     hipEvent_t order_event = nullptr;  // zkhip_stream_wait: marks this context's stream for another context to wait on
     std::string last_error;
+    std::vector<uint32_t> lagrange_stage;  // host constants of zkhip_domain_lagrange_dev, alive until its copies ran
     uint32_t *d_status = nullptr;  // sticky device-side error flags (ZK_STATUS_*), read and cleared by zkhip_device_status
     // bump-allocated workspace, grown on demand, reused across calls
     char *ws = nullptr;

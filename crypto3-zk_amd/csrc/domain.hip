@@ -608,6 +608,138 @@ int zk_dom_zinv(zkhip_ctx *ctx, int curve, const ZkDomain &d, const uint64_t *co
     return ZKHIP_ERR_INVALID;
 }
 
+// ---- every Lagrange polynomial of a domain at one point (key generation: r1cs_to_qap.hpp:152-153) ----------------------------------
+// out[i] = c w^i / (t - w^i)   (unit == 0: c l_i(t) n / (t^n - 1) folded into c by the host)
+// out[i] = c / (w^i - t)       (unit == 1: the step domain's denominators x^small - omega^small)
+// consts: w, w^-1, t, c in Montgomery form.  A lane takes LAG_CHUNK consecutive i: one power, running products, ONE inversion
+// (Montgomery's trick), then back down the chunk.  Canonical output.
+static constexpr uint32_t LAG_CHUNK = 16;
+template <class U>
+__global__ __launch_bounds__(64) void dom_lagrange(const uint32_t *__restrict__ consts, uint64_t n, int unit, uint32_t *__restrict__ out, uint64_t out_off) {
+    const uint64_t lo = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * LAG_CHUNK;
+    if (lo >= n) return;
+    const uint32_t cnt = (uint32_t)(n - lo < LAG_CHUNK ? n - lo : LAG_CHUNK);
+    const Fu<U> w = e_load<U>(consts, 0), winv = e_load<U>(consts, 1), t = e_load<U>(consts, 2), c = e_load<U>(consts, 3);
+    Fu<U> x = Fu<U>::one(), b = w;
+    for (uint64_t e = lo; e; e >>= 1) {
+        if (e & 1) x = fu_mul_call(x, b);
+        b = fu_mul_call(b, b);
+    }
+    x = fu_cond_sub_p(x);
+    Fu<U> pre[LAG_CHUNK];
+    Fu<U> acc = Fu<U>::one();
+    for (uint32_t k = 0; k < cnt; ++k) {
+        pre[k] = acc;
+        const Fu<U> den = unit ? fu_sub<2>(x, t) : fu_sub<2>(t, x);
+        acc = fu_mul_call(acc, den);
+        if (k + 1 < cnt) x = fu_cond_sub_p(fu_mul_call(x, w));
+    }
+    Fu<U> inv = fu_inv(acc);  // x is now w^(lo + cnt - 1)
+    Fu<U> plain = Fu<U>::zero();
+    plain.v[0] = 1;
+    for (uint32_t k = cnt; k-- > 0;) {
+        const Fu<U> den = unit ? fu_sub<2>(x, t) : fu_sub<2>(t, x);
+        Fu<U> r = fu_mul_call(fu_mul_call(inv, pre[k]), c);  // c / den_k
+        if (!unit) r = fu_mul_call(r, x);
+        e_store<U>(out, out_off + lo + k, fu_cond_sub_p(fu_mul_call(r, plain)));  // out of Montgomery form
+        inv = fu_mul_call(inv, den);
+        x = fu_cond_sub_p(fu_mul_call(x, winv));
+    }
+}
+// out[i] *= tab[i mod nz]  (canonical x canonical -> canonical), i < n
+template <class U>
+__global__ __launch_bounds__(256) void dom_scale_by_table(uint32_t *__restrict__ out, uint64_t n, const uint32_t *__restrict__ tab, uint64_t nz) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    e_store<U>(out, i, fu_cond_sub_p(fu_mul(fu_mul(e_load<U>(out, i), e_load<U>(tab, i % nz)), Fu<U>::r2())));
+}
+
+// host side of zkhip_domain_lagrange_dev: field arithmetic on canonical limbs with the kernels' own code
+template <class U>
+struct HF {
+    Fu<U> v;  // Montgomery
+    static HF from(const uint64_t *c) { return {fu_from_canonical<U>(reinterpret_cast<const uint32_t *>(c))}; }
+    static HF one() { return {Fu<U>::one()}; }
+    static HF u64(uint64_t x) {
+        const uint64_t c[4] = {x, 0, 0, 0};
+        return from(c);
+    }
+    HF operator*(const HF &o) const { return {fu_cond_sub_p(fu_mul(v, o.v))}; }
+    HF operator-(const HF &o) const { return {fu_canon(fu_sub<4>(v, o.v))}; }
+    HF inv() const { return {fu_cond_sub_p(fu_inv(v))}; }
+    HF pow(uint64_t e) const {
+        HF r = one(), b = *this;
+        for (; e; e >>= 1) {
+            if (e & 1) r = r * b;
+            b = b * b;
+        }
+        return r;
+    }
+    bool is_zero() const { return fu_canon(v).limbs_zero(); }
+    void store_mont(uint32_t *dst) const {  // 8 words, canonical representative of the Montgomery form
+        fu_pack<U>(dst, fu_canon(v));
+    }
+};
+
+// one dom_lagrange launch: out[off + i] = c w^i / (t - w^i) or c / (w^i - t)
+template <class U>
+static int lagrange_launch(zkhip_ctx *ctx, uint32_t *d_consts, uint32_t *h_consts, int slot, const HF<U> &w, const HF<U> &t, const HF<U> &c, size_t n, int unit,
+                           uint32_t *d_out, size_t off) {
+    uint32_t *h = h_consts + slot * 32, *d = d_consts + slot * 32;
+    w.store_mont(h);
+    w.inv().store_mont(h + 8);
+    t.store_mont(h + 16);
+    c.store_mont(h + 24);
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(d, h, 128, hipMemcpyHostToDevice, ctx->stream));
+    const size_t lanes = (n + LAG_CHUNK - 1) / LAG_CHUNK;
+    ZK_LAUNCH(ctx, "dom_lagrange", dom_lagrange<U>, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, d, (uint64_t)n, unit, d_out, (uint64_t)off);
+    return ZKHIP_OK;
+}
+
+template <class U>
+static int dom_lagrange_t(zkhip_ctx *ctx, const ZkDomain &d, const uint64_t *t_c, uint32_t *d_out) {
+    typedef HF<U> F;
+    const F one = F::one(), t = F::from(t_c), w = F::from(d.omega);
+    // constants of up to four launches, staged in page-able host memory that must outlive the copies: kept in the context
+    ctx->lagrange_stage.assign(4 * 32, 0u);
+    uint32_t *h = ctx->lagrange_stage.data(), *dc = nullptr;
+    ZK_TRY(ctx->ws_reserve(zkhip_ctx::ws_round(4 * 128) + zkhip_ctx::ws_round((d.n1 ? d.n0 / d.n1 : 1) * 32)));
+    ctx->ws_reset();
+    dc = ctx->ws_take<uint32_t>(4 * 32);
+    auto basic = [&](int slot, const F &root, const F &at, const F &scale, size_t n, size_t off) {
+        // scale * l_i(at) over <root>: l_i = (at^n - 1) root^i / (n (at - root^i))
+        const F c = (at.pow(n) - one) * F::u64(n).inv() * scale;
+        return lagrange_launch<U>(ctx, dc, h, slot, root, at, c, n, 0, d_out, off);
+    };
+    int rc = ZKHIP_OK;
+    if (d.kind == ZKHIP_DOMAIN_BASIC_RADIX2) {
+        if ((t.pow(d.m) - one).is_zero()) return ZKHIP_ERR_INVALID;
+        rc = basic(0, w, t, one, d.m, 0);
+    } else if (d.kind == ZKHIP_DOMAIN_EXTENDED_RADIX2) {
+        const size_t n = d.n0;
+        const F sh = F::from(d.shift), t_n = t.pow(n), s_n = sh.pow(n), ood = (s_n - one).inv();
+        if ((t_n - one).is_zero() || (t_n - s_n).is_zero()) return ZKHIP_ERR_INVALID;
+        rc = basic(0, w, t, (s_n - t_n) * ood, n, 0);
+        if (rc == ZKHIP_OK) rc = basic(1, w, t * sh.inv(), (t_n - one) * ood, n, n);
+    } else {
+        // big part: l_i(t) over <omega^2> times (t^small - omega^small) / (x_i^small - omega^small): the denominator takes big / small
+        // distinct values; small part: l_i(t / omega) over <omega^(2 big / small)> times (t^big - 1) / (omega^big - 1)
+        const size_t big = d.n0, small = d.n1, compr = big / small;
+        const F big_w = w * w, small_w = w.pow(2 * compr), w_sm = w.pow(small), L0 = t.pow(small) - w_sm;
+        if ((t.pow(big) - one).is_zero() || L0.is_zero()) return ZKHIP_ERR_INVALID;
+        uint32_t *d_dinv = ctx->ws_take<uint32_t>(compr * 8);
+        rc = lagrange_launch<U>(ctx, dc, h, 0, big_w.pow(small), w_sm, one, compr, 1, d_dinv, 0);  // 1 / (step^j - omega^small)
+        if (rc == ZKHIP_OK) rc = basic(1, big_w, t, L0, big, 0);
+        if (rc == ZKHIP_OK)
+            ZK_LAUNCH(ctx, "dom_lagrange", dom_scale_by_table<U>, dim3((unsigned)((big + 255) / 256)), dim3(256), 0, d_out, (uint64_t)big, d_dinv, (uint64_t)compr);
+        const F L1 = (t.pow(big) - one) * (w.pow(big) - one).inv();
+        if (rc == ZKHIP_OK) rc = basic(2, small_w, t * w.inv(), L1, small, big);
+    }
+    if (rc != ZKHIP_OK) return rc;
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the staged constants and the workspace table may be reused after return
+    return ZKHIP_OK;
+}
+
 extern "C" {
 
 int zkhip_domain_choice(int curve, size_t min_size, int *kind, size_t *m) {
@@ -615,6 +747,15 @@ int zkhip_domain_choice(int curve, size_t min_size, int *kind, size_t *m) {
     const int s = zk_dom_two_adicity(curve);
     if (s < 0) return ZKHIP_ERR_INVALID;
     return zk_dom_choice(min_size, (size_t)s, kind, m) ? ZKHIP_OK : ZKHIP_ERR_RANGE;
+}
+
+int zkhip_domain_lagrange_dev(zkhip_ctx *ctx, int curve, const zkhip_domain *dom, const uint64_t *t, void *d_out) {
+    if (!ctx || !dom || !t || !d_out) return ZKHIP_ERR_INVALID;
+    ZkDomain d;
+    ZK_TRY(zk_dom_parse(curve, dom, &d));
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (curve == CURVE_BLS12_381) return dom_lagrange_t<BlsFrU>(ctx, d, t, (uint32_t *)d_out);
+    return dom_lagrange_t<BnFrU>(ctx, d, t, (uint32_t *)d_out);
 }
 
 int zkhip_domain_fft_dev(zkhip_ctx *ctx, int curve, const zkhip_domain *dom, void *d_data, size_t batch, int inverse, const uint64_t *coset_gen) {

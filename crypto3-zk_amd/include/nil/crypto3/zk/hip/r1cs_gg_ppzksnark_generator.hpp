@@ -44,9 +44,10 @@ struct qap_instance_evaluation_hip {
 /// r1cs_to_qap<F>::instance_map_with_evaluation(cs, t) (r1cs_to_qap.hpp:138-187) over the evaluation domain `dom` describes:
 /// make_evaluation_domain(num_constraints + num_inputs + 1)'s choice unless it names another.  `ConstraintSystem` is
 /// duck-typed like device_r1cs.
+/// `ctx` (nullable): evaluate the Lagrange basis at t on the device (the dominant cost of this function at 2^20 points on the host).
 template <typename CurveType, typename ConstraintSystem>
 qap_instance_evaluation_hip<CurveType> instance_map_with_evaluation(const ConstraintSystem &cs, const typename curve_adapter<CurveType>::scalar_value_type &t,
-                                                                    const domain_params<CurveType> &dom) {
+                                                                    const domain_params<CurveType> &dom, const context *ctx = nullptr) {
     typedef typename curve_adapter<CurveType>::scalar_value_type Fr;
     const std::size_t M = cs.num_constraints(), n = cs.num_inputs(), N = cs.num_variables();
     const evaluation_domain_hip<CurveType> domain = evaluation_domain_hip<CurveType>::make(dom, M + n + 1);
@@ -57,7 +58,7 @@ qap_instance_evaluation_hip<CurveType> instance_map_with_evaluation(const Constr
     q.num_inputs = n;
     q.t = t;
     q.Zt = domain.compute_vanishing_polynomial(t);
-    const std::vector<Fr> u = domain.evaluate_all_lagrange_polynomials(t);
+    const std::vector<Fr> u = ctx ? domain.evaluate_all_lagrange_polynomials(*ctx, t) : domain.evaluate_all_lagrange_polynomials(t);
     q.At.assign(N + 1, Fr::zero());
     q.Bt.assign(N + 1, Fr::zero());
     q.Ct.assign(N + 1, Fr::zero());
@@ -110,7 +111,7 @@ public:
         swap_AB_if_beneficial(pk.constraint_system);
         const Fr delta_inverse = delta.inversed();
         /* A quadratic arithmetic program evaluated at t. */
-        const auto qap = instance_map_with_evaluation<CurveType>(pk.constraint_system, t, dom);
+        const auto qap = instance_map_with_evaluation<CurveType>(pk.constraint_system, t, dom, &ctx);
         const std::size_t N = qap.num_variables, n = qap.num_inputs, m = qap.degree;
         /* The delta inverse product component: (beta*A_i(t) + alpha*B_i(t) + C_i(t)) * delta^{-1} (generator.hpp:296-304) */
         std::vector<Fr> Lt(N - n);

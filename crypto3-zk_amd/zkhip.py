@@ -17,7 +17,7 @@ EXPORTS = [
     "zkhip_set_option", "zkhip_get_option", "zkhip_malloc", "zkhip_free", "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_memcpy_h2d_async", "zkhip_memcpy_d2h_async", "zkhip_memcpy_d2d_async", "zkhip_host_alloc", "zkhip_host_free",
     "zkhip_bases_upload", "zkhip_bases_upload_compressed", "zkhip_bases_from_scalars", "zkhip_bases_spread", "zkhip_bases_download", "zkhip_bases_size",
     "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_batch_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
-    "zkhip_domain_choice", "zkhip_domain_fft_dev",
+    "zkhip_domain_choice", "zkhip_domain_fft_dev", "zkhip_domain_lagrange_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_set_domain", "zkhip_r1cs_domain_size", "zkhip_r1cs_domain_kind", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev", "zkhip_groth16_witness_h_domain_dev", "zkhip_fr_gather_dev", "zkhip_poly_resize_dev", "zkhip_fri_fold_dev", "zkhip_fri_leaves_dev", "zkhip_ec_ntt_dev",
     "zkhip_fr_vec_op_dev", "zkhip_fr_vec_prod_dev", "zkhip_poly_shift_dev", "zkhip_poly_eval_dev", "zkhip_poly_div_linear_dev", "zkhip_poly_div_vanishing_dev", "zkhip_poly_lincomb_dev",
     "zkhip_profile_enable", "zkhip_profile_reset", "zkhip_profile_filter", "zkhip_profile_get", "zkhip_profile_dump",
@@ -289,6 +289,17 @@ class Context:
     def domain_fft_dev(self, curve: int, dom: Domain, d_data: int, batch: int, inverse=False, coset=None):
         self._check(self.lib.zkhip_domain_fft_dev(self.h, curve, ctypes.byref(dom), ctypes.c_void_p(d_data), ctypes.c_size_t(batch), 1 if inverse else 0,
                                                   _p(_u64(coset)) if coset is not None else None), "zkhip_domain_fft_dev")
+
+    def domain_lagrange(self, curve: int, dom: Domain, t) -> np.ndarray:
+        """evaluate_all_lagrange_polynomials(t): (m, 4) canonical, in get_domain_element order"""
+        out = np.zeros((int(dom.m), 4), dtype=np.uint64)
+        dp = self.malloc(out.nbytes)
+        try:
+            self._check(self.lib.zkhip_domain_lagrange_dev(self.h, curve, ctypes.byref(dom), _p(_u64(t).reshape(4)), ctypes.c_void_p(dp)), "zkhip_domain_lagrange_dev")
+            self.d2h(out, dp)
+        finally:
+            self.free(dp)
+        return out
 
     def domain_fft(self, curve: int, dom: Domain, data: np.ndarray, inverse=False, coset=None) -> np.ndarray:
         """host convenience: (batch, m, 4) canonical -> transformed copy"""

@@ -178,6 +178,11 @@ typedef struct zkhip_domain {
 /* (kind, m) make_evaluation_domain(min_size) picks over the curve's scalar field (two-adicity 32 for BLS12-381, 28 for BN254).
  * ZKHIP_ERR_RANGE when only a geometric / arithmetic sequence domain would do (beyond 2^(s+1) points: out of scope). */
 int zkhip_domain_choice(int curve, size_t min_size, int *kind, size_t *m);
+/* evaluation_domain::evaluate_all_lagrange_polynomials(t) (reductions/r1cs_to_qap.hpp:152-153, the key generator's QAP evaluation
+ * at the trapdoor): d_out[i] = L_i(t) for every point of the domain, in get_domain_element order (m canonical Fr elements,
+ * device), by the closed forms of the three radix-2 kinds with one batched inversion per 16 points.  ZKHIP_ERR_INVALID when t lies
+ * in the domain (the closed forms do not cover it; a trapdoor must not lie there anyway). */
+int zkhip_domain_lagrange_dev(zkhip_ctx *ctx, int curve, const zkhip_domain *dom, const uint64_t *t, void *d_out);
 /* evaluation_domain<F>::fft / inverse_fft over any of the three domains, in place on `batch` vectors of dom->m Fr elements:
  *   forward:  [coset != NULL: v[j] *= coset^j;]  out[i] = sum_j v[j] x_i^j        (x_i = get_domain_element(i))
  *   inverse:  the interpolation;  [coset != NULL: out[j] *= coset^(-j)]

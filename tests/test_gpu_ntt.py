@@ -210,3 +210,24 @@ def test_domain_fft_all_kinds(ctx, zk, curve):
     bad = zk.zkhip.Domain.make(dom.kind, dom.m, limbs(C.root_of_unity(4), 4))
     with pytest.raises(zk.zkhip.ZkhipError):
         ctx.domain_fft(curve, bad, cp.random_fr(curve, 1, 20).reshape(1, 20, 4))
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_domain_lagrange_all_kinds(ctx, zk, curve):
+    """evaluation_domain::evaluate_all_lagrange_polynomials(t) on the device (zkhip_domain_lagrange_dev: the key generator's QAP
+    evaluation, r1cs_to_qap.hpp:152-153) against the oracle's domains -- pinned to the product definition of the Lagrange
+    polynomials over each point set (tests/test_oracle_kat.py) --: basic, step (1 ... 1024 columns, every chunk boundary of the
+    16-point batched inversion) and extended radix-2 (over a pretended small two-adicity); sum_i L_i(t) = 1; t on the domain refused."""
+    C = CURVES[curve]
+    r = C.r
+    rng = po.SplitMix64(91 + curve)
+    for n, s in [(2, None), (3, None), (5, None), (16, None), (17, None), (20, None), (33, None), (48, None), (65, None), (1040, None), (2048 + 256, None),
+                 (4096 + 2048, None), (32768 + 16, None), (8, 2), (64, 5), (2048, 10), (1 << 13, None)]:
+        dom, zd = qap_domains(zk, curve, n, two_adicity=s)
+        t = rng.next_mod(r)
+        got = fr_ints(ctx.domain_lagrange(curve, zd, limbs(t, 4)))
+        assert got == dom.evaluate_all_lagrange_polynomials(t), (curve, dom.describe())
+        assert sum(got) % r == 1
+    dom, zd = qap_domains(zk, curve, 20)
+    with pytest.raises(zk.zkhip.ZkhipError):
+        ctx.domain_lagrange(curve, zd, limbs(dom.elements()[7], 4))
