@@ -577,6 +577,7 @@ def groth16_leg(np, constraints=1 << 20, inputs=10, steps=4, verify=True, domain
     import ctypes
 
     lib = _bench_lib()
+    lib.zkhip_bench_last_instance_ms.restype = ctypes.c_double
     r, g = R_BLS, 7
     M = constraints
     m = 1
@@ -637,7 +638,11 @@ def groth16_leg(np, constraints=1 << 20, inputs=10, steps=4, verify=True, domain
                        "chosen_by": "make_evaluation_domain(M + n + 1), as the reference (r1cs_to_qap.hpp:229-230)" if domain == "ref" else "named: next power of two"},
             "query_sizes": {"A": qa, "B": qb, "H": qh, "L": ql},
             "key": "valid Groth16 key, generated on the device from a fixed trapdoor (r1cs_gg_ppzksnark_generator_hip), resident",
-            "key_setup_ms": round(setup.value, 1), "verified": None if not verify else bool(verified.value == 1),
+            "key_setup_ms": round(setup.value, 1),
+            "key_setup_what": "r1cs_gg_ppzksnark_generator_hip::deterministic_basic_process alone (generator.hpp:240-377: QAP at the trapdoor with the "
+                              "Lagrange basis on the device, five batch exponentiations, window tables); building the synthetic circuit took instance_build_ms",
+            "instance_build_ms": round(float(lib.zkhip_bench_last_instance_ms()), 1),
+            "verified": None if not verify else bool(verified.value == 1),
             "verification": "proof == (a G1, b G2, c G1) with a, b, c from the trapdoor identities (prover.hpp:141-153)",
             "roofline": roof, "kernel_ms_serial_proof": kern,
             "kernel_ms_source": "HIP events around every launch of ONE extra, untimed proof with the G2 multiexp on the main stream: a single in-order "

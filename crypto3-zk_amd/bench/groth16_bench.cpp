@@ -54,6 +54,7 @@ double g_lanes_info[4] = {0, 0, 0, 0};
 int g_dom_kind = -1;
 size_t g_dom_m = 0;
 uint64_t g_last_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // domain kind, domain points, A / B / H / L query sizes of this rank, N, n
+double g_last_instance_ms = 0;    // building the synthetic constraint system + assignment of the last run (not part of *setup_ms)
 
 template <typename Curve>
 int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gather, size_t M, size_t n, uint64_t seed, int steps, const uint64_t *omega,
@@ -120,6 +121,9 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
         return A::scalar_from_limbs(w);
     };
     const Fr t = rnd_key(), alpha = rnd_key(), beta = rnd_key(), gamma = rnd_key(), delta = rnd_key();
+    ctx.sync();
+    g_last_instance_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();    // the synthetic circuit + context
+    t0 = std::chrono::steady_clock::now();    // from here: key generation proper (generator.hpp:240-377)
     auto key = r1cs_gg_ppzksnark_generator_hip<Curve>::deterministic_basic_process(ctx, cs, dom, t, alpha, beta, gamma, delta, rank, world);
     auto &dpk = *key->device;
     {
@@ -222,6 +226,7 @@ void zkhip_bench_set_domain(int kind, size_t m) {
     g_dom_m = m;
 }
 void zkhip_bench_last_info(uint64_t *out) { memcpy(out, g_last_info, sizeof(g_last_info)); }
+double zkhip_bench_last_instance_ms() { return g_last_instance_ms; }
 /* the sharded proof's exchange on device buffers (see all_gather_dev_fn); fn == NULL: back to the host-buffer callback */
 void zkhip_bench_set_device_gather(all_gather_dev_fn fn, void *d_mine, void *d_all) {
     g_gather_dev = fn;

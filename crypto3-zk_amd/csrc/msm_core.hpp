@@ -690,6 +690,80 @@ __global__ __launch_bounds__(64) void bases_mul(uint32_t *__restrict__ pts, cons
     affine_store<F>(pts + (size_t)i * (2 * NL), xyzz_to_affine(acc));
 }
 
+// ---- fixed-base batch exponentiation (batch_exp of generator.hpp:187-214: every point is a multiple of ONE base) --------------------
+// tab[(w << 8) + d] = d 2^(8 w) base, affine, d in [1, 256), w < 32.  One lane per window: 8 w doublings, 254 mixed additions in
+// XYZZ parked in `tmp` (5 field elements per entry: X, Y, ZZ, ZZZ, prefix product), ONE inversion (Montgomery's trick), back down.
+constexpr int FIXED_WBITS = 8, FIXED_NW = 32, FIXED_ROW = 1 << FIXED_WBITS;
+template <class F>
+__global__ __launch_bounds__(64) void bases_fixed_table(const uint32_t *__restrict__ base_canonical, uint32_t *__restrict__ tab, uint32_t *__restrict__ tmp) {
+    typedef FieldOps<F> O;
+    constexpr int NL = O::WORDS;
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= FIXED_NW) return;
+    Affine<F> g = {O::from_canonical(base_canonical), O::from_canonical(base_canonical + O::CANON_WORDS)};
+    XYZZ<F> P = XYZZ<F>::from_affine(g);
+    for (uint32_t k = 0; k < w * FIXED_WBITS; ++k) P = xyzz_dbl(P);
+    uint32_t *mine = tmp + (size_t)w * FIXED_ROW * (5 * NL);
+    XYZZ<F> acc = P;
+    F pre = F::one();
+    for (uint32_t d = 1; d < FIXED_ROW; ++d) {  // entry d: d P (P is not affine: full additions; the table is built once per call)
+        if (d > 1) acc = xyzz_add(acc, P);
+        uint32_t *slot = mine + (size_t)d * (5 * NL);
+        xyzz_store<F>(slot, acc);
+        pre = O::mul(pre, O::mul(acc.ZZ, acc.ZZZ));
+        O::store(slot + 4 * NL, pre);
+    }
+    F inv = O::inv(pre);
+    for (uint32_t d = FIXED_ROW; d-- > 1;) {
+        const uint32_t *slot = mine + (size_t)d * (5 * NL);
+        XYZZ<F> q = xyzz_load<F>(slot);
+        F before = d > 1 ? O::load(mine + (size_t)(d - 1) * (5 * NL) + 4 * NL) : F::one();
+        F dinv = O::mul(inv, before);
+        inv = O::mul(inv, O::mul(q.ZZ, q.ZZZ));
+        Affine<F> a = {O::mul(q.X, O::mul(dinv, q.ZZZ)), O::mul(q.Y, O::mul(dinv, q.ZZ))};
+        affine_store<F>(tab + ((size_t)w * FIXED_ROW + d) * (2 * NL), a);
+    }
+}
+// pts[i] = scalars[i] * base = sum_w tab[w][byte w of the scalar]: at most 32 mixed additions per point instead of 256 doublings + ~128
+// additions.  A lane takes FIXED_CHUNK consecutive points, parks their XYZZ sums in `tmp` and shares ONE inversion among them.
+constexpr uint32_t FIXED_CHUNK = 8;
+template <class F>
+__global__ __launch_bounds__(64) void bases_mul_fixed(uint32_t *__restrict__ pts, const uint32_t *__restrict__ tab, const uint32_t *__restrict__ scalars,
+                                                      uint32_t n, uint32_t *__restrict__ tmp) {
+    typedef FieldOps<F> O;
+    constexpr int NL = O::WORDS;
+    const uint32_t lo = (blockIdx.x * blockDim.x + threadIdx.x) * FIXED_CHUNK;
+    if (lo >= n) return;
+    const uint32_t cnt = n - lo < FIXED_CHUNK ? n - lo : FIXED_CHUNK;
+    F pre = F::one();
+    for (uint32_t k = 0; k < cnt; ++k) {
+        const uint32_t *s = scalars + (size_t)(lo + k) * 8;
+        XYZZ<F> acc = XYZZ<F>::infinity();
+        for (uint32_t w = 0; w < FIXED_NW; ++w) {
+            const uint32_t d = (s[w >> 2] >> ((w & 3) * 8)) & 0xFFu;
+            if (d) acc = xyzz_madd(acc, affine_load<F>(tab + ((size_t)w * FIXED_ROW + d) * (2 * NL)));
+        }
+        uint32_t *slot = tmp + (size_t)(lo + k) * (5 * NL);
+        xyzz_store<F>(slot, acc);
+        if (!acc.is_inf()) pre = O::mul(pre, O::mul(acc.ZZ, acc.ZZZ));
+        O::store(slot + 4 * NL, pre);
+    }
+    F inv = O::inv(pre);
+    for (uint32_t k = cnt; k-- > 0;) {
+        const uint32_t *slot = tmp + (size_t)(lo + k) * (5 * NL);
+        XYZZ<F> q = xyzz_load<F>(slot);
+        if (q.is_inf()) {
+            affine_store<F>(pts + (size_t)(lo + k) * (2 * NL), Affine<F>::infinity());
+            continue;
+        }
+        F before = k > 0 ? O::load(tmp + (size_t)(lo + k - 1) * (5 * NL) + 4 * NL) : F::one();
+        F dinv = O::mul(inv, before);
+        inv = O::mul(inv, O::mul(q.ZZ, q.ZZZ));
+        Affine<F> a = {O::mul(q.X, O::mul(dinv, q.ZZZ)), O::mul(q.Y, O::mul(dinv, q.ZZ))};
+        affine_store<F>(pts + (size_t)(lo + k) * (2 * NL), a);
+    }
+}
+
 // Window tables: the table of window w holds 2^off(w) P_i in affine form.  One lane per point: width(w - 1) doublings
 // per window in XYZZ, the intermediate points of the windows THIS object keeps parked in `tmp`, one shared inversion
 // (Montgomery's trick over the lane's own denominators ZZ*ZZZ), then the affine results are written to their slots.
@@ -1172,7 +1246,20 @@ int op_from_mont(zkhip_ctx *ctx, const zkhip_bases *b, size_t offset, size_t n, 
 }
 template <class F>
 int op_mul(zkhip_ctx *ctx, zkhip_bases *b, const uint32_t *d_base_canonical, const uint32_t *d_scalars) {
-    ZK_LAUNCH(ctx, "bases_mul", bases_mul<F>, dim3((unsigned)((b->n + 63) / 64)), dim3(64), 0, b->d, d_base_canonical, d_scalars, (uint32_t)b->n);
+    constexpr int NL = FieldOps<F>::WORDS;
+    if (b->n < 4096) {  // a handful of points: the table would cost more than it saves
+        ZK_LAUNCH(ctx, "bases_mul", bases_mul<F>, dim3((unsigned)((b->n + 63) / 64)), dim3(64), 0, b->d, d_base_canonical, d_scalars, (uint32_t)b->n);
+        return 0;
+    }
+    // fixed-base windows: a 32 x 256-entry affine table of the base, then <= 32 mixed additions per point (round 4: a 2^20-constraint
+    // key's batch exponentiations were 256 doublings + ~128 additions + one Fermat inversion PER POINT)
+    const size_t tab_words = (size_t)FIXED_NW * FIXED_ROW * 2 * NL, tmp_words = std::max<size_t>((size_t)FIXED_NW * FIXED_ROW, b->n) * 5 * NL;
+    ZK_TRY(ctx->ws_reserve(zkhip_ctx::ws_round(tab_words * 4) + zkhip_ctx::ws_round(tmp_words * 4)));
+    ctx->ws_reset();
+    uint32_t *tab = ctx->ws_take<uint32_t>(tab_words), *tmp = ctx->ws_take<uint32_t>(tmp_words);
+    ZK_LAUNCH(ctx, "bases_mul", bases_fixed_table<F>, dim3(1), dim3(64), 0, d_base_canonical, tab, tmp);
+    const size_t lanes = (b->n + FIXED_CHUNK - 1) / FIXED_CHUNK;
+    ZK_LAUNCH(ctx, "bases_mul", bases_mul_fixed<F>, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, b->d, tab, d_scalars, (uint32_t)b->n, tmp);
     return 0;
 }
 template <class F>

@@ -25,6 +25,10 @@
 #include <memory>
 #include <vector>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include "r1cs_gg_ppzksnark.hpp"
 
 namespace nil {
@@ -64,12 +68,24 @@ qap_instance_evaluation_hip<CurveType> instance_map_with_evaluation(const Constr
     q.Ct.assign(N + 1, Fr::zero());
     /* the constraints input_i * 0 = 0 that make the input consistent (r1cs_to_qap.hpp:160-162) */
     for (std::size_t i = 0; i <= n; ++i) q.At[i] = u[M + i];
-    for (std::size_t i = 0; i < M; ++i) {
-        const auto &c = cs.constraints[i];
-        for (const auto &term : c.a.terms) q.At[term.index] = q.At[term.index] + u[i] * term.coeff;
-        for (const auto &term : c.b.terms) q.Bt[term.index] = q.Bt[term.index] + u[i] * term.coeff;
-        for (const auto &term : c.c.terms) q.Ct[term.index] = q.Ct[term.index] + u[i] * term.coeff;
-    }
+    /* A_j(t) = sum_i u_i A_ij (r1cs_to_qap.hpp:164-178), split over host threads BY VARIABLE RANGE: every thread walks all the
+       constraints and takes the terms whose variable falls into its range -- no two threads write the same entry, and the field
+       products (the cost) are shared out; coefficients 1 (most of a circuit) need no product at all */
+    detail::parallel_chunks(N + 1, [&](std::size_t lo, std::size_t hi) {
+        const Fr one = Fr::one();
+        auto take = [&](std::vector<Fr> &dst, const decltype(cs.constraints[0].a.terms) &terms, const Fr &ui) {
+            for (const auto &term : terms) {
+                if (term.index < lo || term.index >= hi) continue;
+                dst[term.index] = dst[term.index] + (term.coeff == one ? ui : ui * term.coeff);
+            }
+        };
+        for (std::size_t i = 0; i < M; ++i) {
+            const auto &c = cs.constraints[i];
+            take(q.At, c.a.terms, u[i]);
+            take(q.Bt, c.b.terms, u[i]);
+            take(q.Ct, c.c.terms, u[i]);
+        }
+    });
     q.Ht.resize(m + 1);
     detail::parallel_chunks(m + 1, [&](std::size_t lo, std::size_t hi) {
         Fr ti = detail::pow_u64(t, lo);
@@ -106,13 +122,25 @@ public:
         typedef scalar_value_type Fr;
         std::unique_ptr<generated_proving_key<CurveType>> key(new generated_proving_key<CurveType>());
         auto &pk = key->host;
+        /* ZKHIP_GEN_PHASES=1: host wall time of the phases on stderr (where a 2^20-constraint key's seconds go) */
+        const bool phases = std::getenv("ZKHIP_GEN_PHASES") != nullptr;
+        auto tp = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!phases) return;
+            ctx.sync();
+            const auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "generator phase %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tp).count());
+            tp = now;
+        };
         /* Make the B_query "lighter" if possible (generator.hpp:250-252) */
         pk.constraint_system = constraint_system;
         swap_AB_if_beneficial(pk.constraint_system);
+        lap("copy + swap_AB");
         const Fr delta_inverse = delta.inversed();
         /* A quadratic arithmetic program evaluated at t. */
         const auto qap = instance_map_with_evaluation<CurveType>(pk.constraint_system, t, dom, &ctx);
         const std::size_t N = qap.num_variables, n = qap.num_inputs, m = qap.degree;
+        lap("instance_map_with_evaluation");
         /* The delta inverse product component: (beta*A_i(t) + alpha*B_i(t) + C_i(t)) * delta^{-1} (generator.hpp:296-304) */
         std::vector<Fr> Lt(N - n);
         detail::parallel_chunks(N - n, [&](std::size_t lo, std::size_t hi) {
@@ -133,6 +161,7 @@ public:
                 b_indices.push_back((std::uint32_t)i);
             }
         pk.B_query.domain_size_ = N + 1;
+        lap("Lt, Hs, B filter (host)");
         /* alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2 (:333-337): the same device path, read back */
         {
             std::vector<Fr> fx = {alpha, beta, delta};
@@ -147,11 +176,16 @@ public:
         /* the five batch exponentiations (:339-366), left resident as the key's queries.  rank / world > 1: this process
            generates (and will hold) only its slice of every query -- the point-range partition of a sharded proof. */
         const query_shard sh = query_shard::make(rank, world, N + 1, Bnz.size(), m - 1, N - n);
+        lap("fixed elements");
         auto a_query = device_bases<CurveType, ZKHIP_G1>::from_scalars(ctx, qap.At.begin() + sh.A_lo, qap.At.begin() + sh.A_lo + sh.A_n);
+        lap("A query");
         auto b_query_g = device_bases<CurveType, ZKHIP_G2>::from_scalars(ctx, Bnz.begin() + sh.B_lo, Bnz.begin() + sh.B_lo + sh.B_n);
         auto b_query_h = device_bases<CurveType, ZKHIP_G1>::from_scalars(ctx, Bnz.begin() + sh.B_lo, Bnz.begin() + sh.B_lo + sh.B_n);
+        lap("B query (G2 + G1)");
         auto h_query = device_bases<CurveType, ZKHIP_G1>::from_scalars(ctx, Hs.begin() + sh.H_lo, Hs.begin() + sh.H_lo + sh.H_n);
+        lap("H query");
         auto l_query = device_bases<CurveType, ZKHIP_G1>::from_scalars(ctx, Lt.begin() + sh.L_lo, Lt.begin() + sh.L_lo + sh.L_n);
+        lap("L query");
         b_indices = std::vector<std::uint32_t>(b_indices.begin() + sh.B_lo, b_indices.begin() + sh.B_lo + sh.B_n);
         /* the device key reduces over the very domain the queries were evaluated on (explicit: a rank's H slice does not tell) */
         domain_params<CurveType> key_dom = dom;
@@ -162,6 +196,7 @@ public:
         }
         key->device.reset(new r1cs_gg_ppzksnark_proving_key_hip<CurveType>(ctx, pk, key_dom, std::move(a_query), std::move(b_query_g), std::move(b_query_h),
                                                                           b_indices, std::move(h_query), std::move(l_query), world > 1 ? &sh : nullptr));
+        lap("device key (r1cs upload)");
         return key;
     }
 
