@@ -404,14 +404,27 @@ protected:
     std::vector<scalar_value_type> get_U(std::size_t b_ind, std::size_t poly_ind) const {
         return detail::small_poly<scalar_value_type>::lagrange(_points.at(b_ind)[poly_ind], _z.get(b_ind, poly_ind));
     }
-    /// update_transcript (kzg_v2.hpp:150-190): commitments, evaluations, U polynomials
+    /// update_transcript (kzg_v2.hpp:150-190, kzg.hpp:695-738): commitments, evaluations, U polynomials
     void update_transcript(std::size_t batch_ind, transcript_type &transcript) {
-        for (const auto &c : _ind_commitments.at(batch_ind)) transcript(c);
+        absorb_batch_commitments(batch_ind, transcript);
         for (std::size_t i = 0; i < _z.get_batch_size(batch_ind); ++i)
-            for (std::size_t j = 0; j < _z.get_poly_points_number(batch_ind, i); ++j) transcript(_z.get(batch_ind, i, j));
+            for (std::size_t j = 0; j < _z.get_poly_points_number(batch_ind, i); ++j) absorb_scalar(_z.get(batch_ind, i, j), transcript);
         for (std::size_t i = 0; i < _points.at(batch_ind).size(); ++i)
-            for (const auto &c : get_U(batch_ind, i)) transcript(c);
+            for (const auto &c : get_U(batch_ind, i)) absorb_scalar(c, transcript);
     }
+    /// WHAT the transcript absorbs.  These device schemes hand it VALUES (one call per commitment / scalar); the reference hands it
+    /// BYTES: the batch's commitment blob in one call, every scalar and pi_1 / pi_2 through nil::marshalling::pack (kzg_v2.hpp:153-189,
+    /// 265-272, 296-304).  The placeholder-facing wrappers below override the three hooks to reproduce exactly that.
+    virtual void absorb_batch_commitments(std::size_t batch_ind, transcript_type &transcript) {
+        for (const auto &c : _ind_commitments.at(batch_ind)) transcript(c);
+    }
+    virtual void absorb_scalar(const scalar_value_type &v, transcript_type &transcript) { transcript(v); }
+    virtual void absorb_point(const single_commitment_type &p, transcript_type &transcript) { transcript(p); }
+
+public:
+    virtual ~kzg_polys_evaluator_hip() = default;
+
+protected:
 
     const params_type &_params;
     root_of_unity_type _root_of_unity;
@@ -508,7 +521,7 @@ public:
             std::size_t f_len = acc_len;
             for (const auto &root : _merged_points) divide_in_place(f_ptr, f_len, root, "proof_eval: f is not divisible by V");
             pi_1 = commit_range(f_ptr, f_len);
-            transcript(pi_1);
+            this->absorb_point(pi_1, transcript);
 
             auto theta_2 = transcript.challenge();
             /* L = sum_i theta^i Z_{T\S_i}(theta_2) (f_i - U_i(theta_2)) - V(theta_2) f (kzg_v2.hpp:281-289) */
@@ -536,11 +549,11 @@ public:
             pi_2 = commit_range(l_ptr, ll);
             ctx.sync();    // d_f / d_l are released on return
         } else {
-            transcript(pi_1);
+            this->absorb_point(pi_1, transcript);
             (void)transcript.challenge();
         }
         /* TODO in the reference: "Review the necessity of sending pi_2 to transcript" (kzg_v2.hpp:295) -- kept */
-        transcript(pi_2);
+        this->absorb_point(pi_2, transcript);
         return proof_type {_z, pi_1, pi_2};
     }
 
@@ -680,13 +693,31 @@ protected:
 };
 
 
+/// nil::marshalling::pack<option::big_endian>(field element) as update_transcript applies it to evaluations and U coefficients
+/// (kzg_v2.hpp:163-165, 179-181): the canonical value as 32 big-endian bytes.  crypto3-marshalling is not vendored; the field
+/// encoding is the one the proving-key wire format states (g16/marshalling.hpp) with the transcript's big-endian option.
+template <typename CurveType>
+struct scalar_be_packer {
+    std::vector<std::uint8_t> operator()(const typename curve_adapter<CurveType>::scalar_value_type &v) const {
+        std::uint64_t l[4];
+        curve_adapter<CurveType>::scalar_to_limbs(v, l);
+        std::vector<std::uint8_t> b(32);
+        for (int i = 0; i < 32; ++i) b[31 - i] = (std::uint8_t)(l[i >> 3] >> (8 * (i & 7)));
+        return b;
+    }
+};
+
 /// The scheme object placeholder_prover / placeholder_verifier take as ParamsType::commitment_scheme_type
 /// (ph/params.hpp:50-63; the consumer contract is what dummy_commitment_scheme_type implements,
 /// test/systems/plonk/placeholder/placeholder.cpp:96-148): the device scheme above with the reference's commitment_type
 /// (a byte blob) and a verify_eval.
 ///   Packer:   std::vector<std::uint8_t>(const single_commitment_type &)   -- nil::marshalling::pack<endianness>(point, status)
 ///   Verifier: bool(scheme &, const proof_type &, const std::map<std::size_t, commitment_type> &, transcript_type &)
-template <typename CurveType, typename TranscriptType, typename Packer, typename Verifier, typename PolynomialType = polynomial_dfs<CurveType>>
+///   ScalarPacker: std::vector<std::uint8_t>(const scalar_value_type &)     -- nil::marshalling::pack<endianness>(field element, status)
+/// With them the TRANSCRIPT sees what the reference's sees, byte for byte: the batch's commitment blob in one call, every evaluation
+/// and U coefficient packed, pi_1 and pi_2 packed (kzg_v2.hpp:150-190, 265-272, 296-304; tests/cpp/shim_test.cpp records the calls).
+template <typename CurveType, typename TranscriptType, typename Packer, typename Verifier, typename PolynomialType = polynomial_dfs<CurveType>,
+          typename ScalarPacker = scalar_be_packer<CurveType>>
 class kzg_commitment_scheme_v2_placeholder_hip : public kzg_commitment_scheme_v2_hip<CurveType, TranscriptType, PolynomialType> {
     typedef kzg_commitment_scheme_v2_hip<CurveType, TranscriptType, PolynomialType> base;
 
@@ -697,8 +728,9 @@ public:
     typedef typename base::params_type params_type;
     typedef typename base::root_of_unity_type root_of_unity_type;
 
-    kzg_commitment_scheme_v2_placeholder_hip(const params_type &kzg_params, root_of_unity_type root_of_unity, Packer packer, Verifier verifier) :
-        base(kzg_params, std::move(root_of_unity)), _packer(std::move(packer)), _verifier(std::move(verifier)) { }
+    kzg_commitment_scheme_v2_placeholder_hip(const params_type &kzg_params, root_of_unity_type root_of_unity, Packer packer, Verifier verifier,
+                                             ScalarPacker scalar_packer = ScalarPacker()) :
+        base(kzg_params, std::move(root_of_unity)), _packer(std::move(packer)), _verifier(std::move(verifier)), _scalar_packer(std::move(scalar_packer)) { }
 
     /// kzg_v2.hpp:208-226: "Differs from static, because we pack the result into byte blob."
     commitment_type commit(std::size_t index) {
@@ -718,16 +750,24 @@ public:
     /// the evaluation points of (batch, polynomial), for the verifier's U / Z_{T \ S} polynomials
     const std::vector<typename base::scalar_value_type> &eval_points(std::size_t batch, std::size_t poly) const { return this->_points.at(batch).at(poly); }
 
+protected:
+    /* the reference's transcript traffic (see the class comment) */
+    void absorb_batch_commitments(std::size_t batch_ind, transcript_type &transcript) override { transcript(_commitments.at(batch_ind)); }
+    void absorb_scalar(const typename base::scalar_value_type &v, transcript_type &transcript) override { transcript(_scalar_packer(v)); }
+    void absorb_point(const typename base::single_commitment_type &p, transcript_type &transcript) override { transcript(_packer(p)); }
+
 private:
     Packer _packer;
     Verifier _verifier;
+    ScalarPacker _scalar_packer;
     std::map<std::size_t, commitment_type> _commitments;
 };
 
 /// The same for the FIRST batched scheme (kzg_commitment_scheme, kzg.hpp:636-873): `commit` packs the single commitments into the
 /// reference's byte blob (:748-765), `verify_eval` (:809-868) goes to the caller's pairing check, which finds commit_g2, the
 /// evaluation points and the per-polynomial commitments on this object.
-template <typename CurveType, typename TranscriptType, typename Packer, typename Verifier, typename PolynomialType = polynomial_dfs<CurveType>>
+template <typename CurveType, typename TranscriptType, typename Packer, typename Verifier, typename PolynomialType = polynomial_dfs<CurveType>,
+          typename ScalarPacker = scalar_be_packer<CurveType>>
 class kzg_commitment_scheme_placeholder_hip : public kzg_commitment_scheme_hip<CurveType, TranscriptType, PolynomialType> {
     typedef kzg_commitment_scheme_hip<CurveType, TranscriptType, PolynomialType> base;
 
@@ -738,8 +778,9 @@ public:
     typedef typename base::params_type params_type;
     typedef typename base::root_of_unity_type root_of_unity_type;
 
-    kzg_commitment_scheme_placeholder_hip(const params_type &kzg_params, root_of_unity_type root_of_unity, Packer packer, Verifier verifier) :
-        base(kzg_params, std::move(root_of_unity)), _packer(std::move(packer)), _verifier(std::move(verifier)) { }
+    kzg_commitment_scheme_placeholder_hip(const params_type &kzg_params, root_of_unity_type root_of_unity, Packer packer, Verifier verifier,
+                                          ScalarPacker scalar_packer = ScalarPacker()) :
+        base(kzg_params, std::move(root_of_unity)), _packer(std::move(packer)), _verifier(std::move(verifier)), _scalar_packer(std::move(scalar_packer)) { }
 
     commitment_type commit(std::size_t index) {
         commitment_type result;
@@ -756,9 +797,16 @@ public:
     const std::map<std::size_t, commitment_type> &packed_commitments() const { return _commitments; }
     const std::vector<typename base::scalar_value_type> &eval_points(std::size_t batch, std::size_t poly) const { return this->_points.at(batch).at(poly); }
 
+protected:
+    /* the reference's transcript traffic (kzg.hpp:695-738) */
+    void absorb_batch_commitments(std::size_t batch_ind, transcript_type &transcript) override { transcript(_commitments.at(batch_ind)); }
+    void absorb_scalar(const typename base::scalar_value_type &v, transcript_type &transcript) override { transcript(_scalar_packer(v)); }
+    void absorb_point(const typename base::single_commitment_type &p, transcript_type &transcript) override { transcript(_packer(p)); }
+
 private:
     Packer _packer;
     Verifier _verifier;
+    ScalarPacker _scalar_packer;
     std::map<std::size_t, commitment_type> _commitments;
 };
 

@@ -49,6 +49,44 @@ namespace detail {
     };
 }    // namespace detail
 
+/// nil::marshalling::pack<endianness>(G1 point) for BLS12-381 as the KZG schemes apply it to commitments (kzg_v2.hpp:217-221): the
+/// 48-byte compressed encoding (byte 0: 0x80 compressed | 0x40 infinity | 0x20 "y is the lexicographically larger root"; x big-endian)
+/// -- the encoding the reference's own byte vectors pin (aggregation test, r1cs_gg_ppzksnark_aggregation_conformity.cpp:932-1010; the
+/// oracle's bls12_381_compress reproduces them, tests/test_oracle_kat.py).  A ready-made `Packer` for the placeholder-facing schemes.
+template <typename CurveType>
+struct bls12_381_g1_packer {
+    typedef curve_adapter<CurveType> adapter;
+    std::vector<std::uint8_t> operator()(const typename adapter::g1_value_type &p) const {
+        static_assert(adapter::g1_coord_limbs == 6, "BLS12-381: 381-bit coordinates");
+        std::vector<std::uint8_t> b(48, 0);
+        std::uint64_t xy[12];
+        if (!p.to_affine(xy)) {
+            b[0] = 0xC0;
+            return b;
+        }
+        for (int i = 0; i < 48; ++i) b[47 - i] = (std::uint8_t)(xy[i >> 3] >> (8 * (i & 7)));
+        /* y > p - y  <=>  2 y > p (y < p): compare 2 y with the modulus, most significant limb first */
+        static const std::uint64_t P[6] = {0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull,
+                                           0x64774b84f38512bfull, 0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull};
+        std::uint64_t y2[7];
+        std::uint64_t carry = 0;
+        for (int i = 0; i < 6; ++i) {
+            y2[i] = (xy[6 + i] << 1) | carry;
+            carry = xy[6 + i] >> 63;
+        }
+        y2[6] = carry;
+        bool larger = y2[6] != 0;
+        if (!larger)
+            for (int i = 5; i >= 0; --i)
+                if (y2[i] != P[i]) {
+                    larger = y2[i] > P[i];
+                    break;
+                }
+        b[0] |= 0x80 | (larger ? 0x20 : 0);
+        return b;
+    }
+};
+
 /// proving_key_process: `blob` is the serialized proving key; `dom` the evaluation-domain constants (see domain_params)
 template <typename CurveType>
 std::unique_ptr<loaded_proving_key<CurveType>> proving_key_from_bytes(const context &ctx, const std::uint8_t *blob, std::size_t size,

@@ -324,6 +324,12 @@ struct scripted_transcript {
     std::size_t next = 0, absorbed_points = 0, absorbed_scalars = 0;
     void operator()(const typename A::g1_value_type &) { ++absorbed_points; }
     void operator()(const typename A::scalar_value_type &) { ++absorbed_scalars; }
+    /* the placeholder-facing wrappers hand over BYTES, as the reference does (kzg_v2.hpp:150-190): a 32-byte blob is a packed scalar,
+       anything else a run of packed points (this file's test packer writes the affine limbs: 16 * g1_coord_limbs bytes each) */
+    void operator()(const std::vector<std::uint8_t> &b) {
+        if (b.size() == 32) ++absorbed_scalars;
+        else absorbed_points += b.size() / (16 * A::g1_coord_limbs);
+    }
     typename A::scalar_value_type challenge() { return challenges.at(next++); }
 };
 
@@ -798,6 +804,25 @@ struct scripted_any_transcript {
     typename A::scalar_value_type challenge() { return challenges.at(next++); }
 };
 
+/// records WHAT is absorbed: every byte blob as it is (values the value-level schemes hand over are logged as empty blobs)
+template <typename Curve>
+struct recording_transcript {
+    typedef curve_adapter<Curve> A;
+    std::vector<typename A::scalar_value_type> challenges;
+    std::size_t next = 0, absorbed = 0;
+    std::vector<std::vector<std::uint8_t>> log;
+    void operator()(const std::vector<std::uint8_t> &b) {
+        ++absorbed;
+        log.push_back(b);
+    }
+    template <typename T>
+    void operator()(const T &) {
+        ++absorbed;
+        log.emplace_back();
+    }
+    typename A::scalar_value_type challenge() { return challenges.at(next++); }
+};
+
 /// toy Merkle stand-in: root = elements_per_leaf + sum_i (i + 1) leaves[i]  (the real tree + hash are the caller's)
 template <typename Curve>
 struct toy_tree {
@@ -1120,9 +1145,24 @@ struct make_poly<Curve, math_like::polynomial_dfs<typename curve_adapter<Curve>:
 
 /// the sequence above against kzg_commitment_scheme_v2_placeholder_hip<..., Poly>; outputs: blob sizes of the four batches, every
 /// evaluation in (batch, polynomial, point) order, pi_1, pi_2
-template <typename Curve, typename Poly>
+/// the test's stand-in packer: the affine limbs, little-endian bytes
+template <typename Curve>
+struct limb_packer {
+    std::vector<std::uint8_t> operator()(const typename curve_adapter<Curve>::g1_value_type &p) const {
+        const size_t L1 = 2 * curve_adapter<Curve>::g1_coord_limbs;
+        std::vector<std::uint64_t> xy(L1);
+        p.to_affine(xy.data());
+        std::vector<std::uint8_t> b(L1 * 8);
+        std::memcpy(b.data(), xy.data(), b.size());
+        return b;
+    }
+};
+
+/// `transcript_log` (nullable): every blob the transcript absorbed, as u64 words: count, then per blob its length and its bytes
+/// padded to 8.  PackerT: limb_packer, or the reference's encoding (bls12_381_g1_packer: 48-byte compressed points).
+template <typename Curve, typename Poly, typename PackerT>
 int placeholder_sequence_kzg_run(const uint64_t *srs, size_t n_srs, const uint64_t *evals, size_t npolys, size_t log_n, size_t nw, const uint64_t *roots,
-                                 const uint64_t *challenge, const uint64_t *thetas, std::vector<uint64_t> &out) {
+                                 const uint64_t *challenge, const uint64_t *thetas, std::vector<uint64_t> &out, std::vector<uint64_t> *transcript_log = nullptr) {
     typedef curve_adapter<Curve> A;
     typedef typename A::g1_value_type G1;
     typedef typename A::scalar_value_type Fr;
@@ -1131,16 +1171,10 @@ int placeholder_sequence_kzg_run(const uint64_t *srs, size_t n_srs, const uint64
     std::vector<G1> ck;
     for (size_t i = 0; i < n_srs; ++i) ck.push_back(G1::from_affine(srs + i * L1));
     kzg_params_hip<Curve> params(ctx, ck.begin(), ck.end());
-    auto packer = [L1](const G1 &p) {
-        std::vector<std::uint64_t> xy(L1);
-        p.to_affine(xy.data());
-        std::vector<std::uint8_t> b(L1 * 8);
-        std::memcpy(b.data(), xy.data(), b.size());
-        return b;
-    };
-    typedef scripted_any_transcript<Curve> tr_type;
+    PackerT packer;
+    typedef recording_transcript<Curve> tr_type;
     auto verifier = [](auto &, const auto &, const std::map<std::size_t, std::vector<std::uint8_t>> &, tr_type &) { return true; };
-    typedef kzg_commitment_scheme_v2_placeholder_hip<Curve, tr_type, decltype(packer), decltype(verifier), Poly> scheme_type;
+    typedef kzg_commitment_scheme_v2_placeholder_hip<Curve, tr_type, PackerT, decltype(verifier), Poly> scheme_type;
     static_assert(std::is_same<typename scheme_type::poly_type, Poly>::value, "poly_type is the template argument (batched_commitment.hpp:64)");
     scheme_type scheme(params, [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); }, packer, verifier);
     std::vector<Poly> polys;
@@ -1155,12 +1189,24 @@ int placeholder_sequence_kzg_run(const uint64_t *srs, size_t n_srs, const uint64
     std::map<std::size_t, typename scheme_type::commitment_type> commitments;
     auto proof = placeholder_prover_calls(scheme, tr, polys, nw, A::scalar_from_limbs(challenge), A::scalar_from_limbs(roots + 4 * log_n), commitments);
     out.clear();
-    for (std::size_t b = 0; b < 4; ++b) out.push_back(commitments.at(b).size());
-    for (std::size_t b = 0; b < 4; ++b)    // the blobs themselves: affine limbs of every single commitment
-        for (std::size_t i = 0; i < commitments.at(b).size(); i += 8) {
-            std::uint64_t w;
-            std::memcpy(&w, &commitments.at(b)[i], 8);
-            out.push_back(w);
+    if (transcript_log) {
+        transcript_log->clear();
+        transcript_log->push_back(tr.log.size());
+        for (const auto &b : tr.log) {
+            transcript_log->push_back(b.size());
+            for (std::size_t i = 0; i < b.size(); i += 8) {
+                std::uint64_t w = 0;
+                std::memcpy(&w, &b[i], std::min<std::size_t>(8, b.size() - i));
+                transcript_log->push_back(w);
+            }
+        }
+    }
+    for (std::size_t b = 0; b < 4; ++b) out.push_back(scheme.commitments().at(b).size() * L1 * 8);
+    for (std::size_t b = 0; b < 4; ++b)    // affine limbs of every single commitment
+        for (const auto &c : scheme.commitments().at(b)) {
+            std::vector<std::uint64_t> xy(L1);
+            c.to_affine(xy.data());
+            out.insert(out.end(), xy.begin(), xy.end());
         }
     for (std::size_t k : proof.z.get_batches())
         for (std::size_t i = 0; i < proof.z.get_batch_size(k); ++i)
@@ -1225,9 +1271,9 @@ int placeholder_sequence_t(const uint64_t *srs, size_t n_srs, const uint64_t *ev
                            const uint64_t *challenge, const uint64_t *thetas, uint64_t *out, size_t out_cap, uint64_t *out_len) {
     typedef math_like::polynomial_dfs<typename curve_adapter<Curve>::scalar_value_type> foreign;
     std::vector<uint64_t> a, b;
-    int rc = placeholder_sequence_kzg_run<Curve, polynomial_dfs<Curve>>(srs, n_srs, evals, npolys, log_n, nw, roots, challenge, thetas, a);
+    int rc = placeholder_sequence_kzg_run<Curve, polynomial_dfs<Curve>, limb_packer<Curve>>(srs, n_srs, evals, npolys, log_n, nw, roots, challenge, thetas, a);
     if (rc) return rc;
-    rc = placeholder_sequence_kzg_run<Curve, foreign>(srs, n_srs, evals, npolys, log_n, nw, roots, challenge, thetas, b);
+    rc = placeholder_sequence_kzg_run<Curve, foreign, limb_packer<Curve>>(srs, n_srs, evals, npolys, log_n, nw, roots, challenge, thetas, b);
     if (rc) return rc;
     if (a != b) return -31;
     if (a.size() > out_cap) return -32;
@@ -1243,6 +1289,21 @@ int placeholder_sequence_t(const uint64_t *srs, size_t n_srs, const uint64_t *ev
     rc = placeholder_sequence_lpc_run<Curve, foreign>(evals, npolys, log_n, nw, roots, challenge, ch.data(), 8, lb);
     if (rc) return rc;
     if (la != lb || la.empty()) return -33;
+    return 0;
+}
+
+/// The transcript traffic of the placeholder-facing KZG scheme with the REFERENCE's encodings (BLS12-381: 48-byte compressed points,
+/// 32-byte big-endian scalars): the log of every absorbed blob for the caller to hold against kzg_v2.hpp:150-190, 265-272, 296-304.
+int placeholder_transcript_bls(const uint64_t *srs, size_t n_srs, const uint64_t *evals, size_t npolys, size_t log_n, size_t nw, const uint64_t *roots,
+                               const uint64_t *challenge, const uint64_t *thetas, uint64_t *out, size_t out_cap, uint64_t *out_len) {
+    typedef bls12_381 Curve;
+    std::vector<uint64_t> a, log;
+    int rc = placeholder_sequence_kzg_run<Curve, polynomial_dfs<Curve>, bls12_381_g1_packer<Curve>>(srs, n_srs, evals, npolys, log_n, nw, roots, challenge, thetas,
+                                                                                                     a, &log);
+    if (rc) return rc;
+    if (log.size() > out_cap) return -32;
+    std::copy(log.begin(), log.end(), out);
+    *out_len = log.size();
     return 0;
 }
 
@@ -1584,6 +1645,15 @@ int shim_placeholder_quotient(int curve, const uint64_t *srs, size_t n_srs, cons
         return placeholder_quotient_t<alt_bn128_254>(srs, n_srs, evals, log_n, roots, theta, alphas, out_T, out_parts, out_commits);
     } catch (const std::exception &e) {
         fprintf(stderr, "shim_placeholder_quotient: %s\n", e.what());
+        return -1;
+    }
+}
+int shim_placeholder_transcript_bls(const uint64_t *srs, size_t n_srs, const uint64_t *evals, size_t npolys, size_t log_n, size_t nw, const uint64_t *roots,
+                                    const uint64_t *challenge, const uint64_t *thetas, uint64_t *out, size_t out_cap, uint64_t *out_len) {
+    try {
+        return placeholder_transcript_bls(srs, n_srs, evals, npolys, log_n, nw, roots, challenge, thetas, out, out_cap, out_len);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "shim_placeholder_transcript_bls: %s\n", e.what());
         return -1;
     }
 }

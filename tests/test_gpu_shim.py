@@ -422,6 +422,65 @@ def test_placeholder_call_sequence_with_foreign_polynomial_type(shim, curve):
     assert at + 2 * L1 + 1 == len(out)
 
 
+def test_placeholder_transcript_bytes_bls12_381(shim):
+    """a placeholder proof is bit-exact with the reference's only if the TRANSCRIPT absorbs the same bytes.  The
+    placeholder-facing KZG scheme with the reference's encodings -- commitments as 48-byte compressed BLS12-381 points (the
+    encoding pinned by the reference's own byte vectors, aggregation test :932-1010, through pyoracle.bls12_381_compress),
+    scalars as 32 big-endian bytes -- must hand the transcript exactly what kzg_v2.hpp does: the prover's transcript(commitment
+    blob) per batch (prover.hpp:142, 171, 207), then inside proof_eval per batch the blob in ONE call, every evaluation, every U
+    coefficient (:150-190), then pi_1 (:265-272) and pi_2 (:296-304)."""
+    curve = 0
+    C = CURVES[curve]
+    r, alpha, log_n, nw = C.r, 7, 5, 2
+    n = 1 << log_n
+    npolys = 8 + nw
+    rng = po.SplitMix64(4300)
+    ch, theta, theta2 = (rng.next_mod(r) for _ in range(3))
+    omega = C.root_of_unity(log_n)
+    evals, coeffs = [], []
+    for p in range(npolys):
+        e = cp.random_fr(curve, 4400 + p, n)
+        evals.append(e)
+        c = cp.ntt(curve, e.reshape(1, -1, 4), log_n, limbs(omega, 4), inverse=True)[0]
+        coeffs.append([po.from_limbs(x) for x in c])
+    srs = _srs(curve, alpha, n)
+    polys = {0: coeffs[0:4], 1: coeffs[4:5 + nw], 2: [coeffs[5 + nw]], 3: coeffs[6 + nw:]}
+    points = {0: [[ch], [ch], [ch, ch * omega % r], [ch, ch * omega % r]],
+              1: [[ch, ch * (omega * omega if i & 1 else omega) % r] for i in range(nw + 1)],
+              2: [[ch, ch * omega % r]], 3: [[ch], [ch]]}
+    z, f, Lq = po.kzg_v2_proof_eval(r, polys, points, theta, theta2)
+    G = C.g1
+    def commit_bytes(c):
+        return po.bls12_381_compress(1, G.mul(G.gen, po.poly_eval(c, alpha, r) % r))
+    be = lambda v: int(v).to_bytes(32, "big")
+    blobs = {b: b"".join(commit_bytes(c) for c in polys[b]) for b in range(4)}
+    expected = [blobs[0], blobs[1], blobs[2], blobs[3]]            # the prover's transcript(commitments[batch])
+    for b in range(4):                                             # update_transcript, batches ascending
+        expected.append(blobs[b])
+        expected += [be(v) for zl in z[b] for v in zl]
+        for i in range(len(polys[b])):
+            U = po.lagrange_interpolation(list(zip(points[b][i], z[b][i])), r)
+            expected += [be(c) for c in U]
+    expected += [commit_bytes(f), commit_bytes(Lq)]               # pi_1, pi_2
+    roots = np.stack([limbs(C.root_of_unity(l), 4) for l in range(log_n + 2)])
+    out = np.zeros(8192, dtype=np.uint64)
+    out_len = np.zeros(1, dtype=np.uint64)
+    rc = shim.shim_placeholder_transcript_bls(P(srs), ctypes.c_size_t(n), P(np.concatenate(evals)), ctypes.c_size_t(npolys), ctypes.c_size_t(log_n),
+                                              ctypes.c_size_t(nw), P(roots), P(limbs(ch, 4)), P(np.concatenate([limbs(theta, 4), limbs(theta2, 4)])), P(out),
+                                              ctypes.c_size_t(len(out)), P(out_len))
+    assert rc == 0
+    words = out[: int(out_len[0])]
+    got, at = [], 1
+    for _ in range(int(words[0])):
+        ln = int(words[at])
+        nwords = (ln + 7) // 8
+        got.append(words[at + 1: at + 1 + nwords].tobytes()[:ln])
+        at += 1 + nwords
+    assert len(got) == len(expected)
+    for i, (g, e) in enumerate(zip(got, expected)):
+        assert g == e, i
+
+
 @pytest.mark.parametrize("curve,log_n", [(0, 8), (1, 8), (0, 12)])
 def test_placeholder_quotient_chain_shim(shim, curve, log_n):
     """placeholder's quotient chain on the device (hip/placeholder_quotient.hpp; prover.hpp:220-277, 314-317, gates_argument.hpp:
