@@ -57,19 +57,42 @@ struct placeholder_quotient_hip {
         if (products.empty()) throw std::invalid_argument("gate_argument: no products");
         dfs_type F(ctx, extended_size);
         bool first = true;
+        const std::size_t n = mask_polynomial.size();
+        std::size_t log_n = 0, log_e = 0;
+        while (((std::size_t)1 << log_n) < n) ++log_n;
+        while (((std::size_t)1 << log_e) < extended_size) ++log_e;
+        if (((std::size_t)1 << log_n) != n || ((std::size_t)1 << log_e) != extended_size || extended_size < n)
+            throw std::invalid_argument("gate_argument: domain sizes must be powers of two, extended >= original");
+        std::uint64_t wn[4], we[4];
+        adapter::scalar_to_limbs(root(log_n), wn);
+        adapter::scalar_to_limbs(root(log_e), we);
+        /* ONE batched resize per gate: its factors (and, with the first gate, the mask) are laid side by side -- the rotation of a factor
+           writes straight into its slot -- and extended by one call (batched inverse NTT of n points + batched NTT of extended_size points:
+           the transforms then run their pairs-per-workgroup kernels) instead of one polynomial at a time */
+        std::shared_ptr<void> d_mask_ext;
         for (const auto &g : products) {
             if (g.factors.empty() || g.rotations.size() != g.factors.size()) throw std::invalid_argument("gate_argument: factors / rotations");
-            std::vector<dfs_type> moved;
-            std::vector<const void *> ptrs;
+            const std::size_t K = g.factors.size(), slots = K + (first ? 1 : 0);
+            auto d_in = ctx.alloc(slots * n * 32);
+            auto d_ext = ctx.alloc(slots * extended_size * 32);
             std::size_t degree = 0;
-            for (std::size_t k = 0; k < g.factors.size(); ++k) {
-                dfs_type f = g.rotations[k] ? polynomial_shift(*g.factors[k], g.rotations[k]) : *g.factors[k];
+            for (std::size_t k = 0; k < K; ++k) {
+                const dfs_type &f = *g.factors[k];
+                if (f.size() != n) throw std::invalid_argument("gate_argument: every factor lives on the original domain (the mask's size)");
                 degree += f.degree();
-                f.resize(extended_size, root);
-                moved.push_back(std::move(f));
+                char *slot = static_cast<char *>(d_in.get()) + k * n * 32;
+                if (g.rotations[k])
+                    check(zkhip_poly_shift_dev(ctx.get(), f.data(), log_n, (std::int64_t)g.rotations[k], slot), "zkhip_poly_shift_dev", ctx.get());
+                else check(zkhip_memcpy_d2d_async(ctx.get(), slot, f.data(), n * 32), "zkhip_memcpy_d2d_async", ctx.get());
             }
             if (degree >= extended_size) throw std::invalid_argument("gate_argument: the product's degree does not fit the extended domain");
-            for (const auto &f : moved) ptrs.push_back(f.data());
+            if (first)
+                check(zkhip_memcpy_d2d_async(ctx.get(), static_cast<char *>(d_in.get()) + K * n * 32, mask_polynomial.data(), n * 32), "zkhip_memcpy_d2d_async",
+                      ctx.get());
+            if (extended_size == n) check(zkhip_memcpy_d2d_async(ctx.get(), d_ext.get(), d_in.get(), slots * n * 32), "zkhip_memcpy_d2d_async", ctx.get());
+            else check(zkhip_poly_resize_dev(ctx.get(), adapter::id, d_in.get(), log_n, slots, wn, d_ext.get(), log_e, we), "zkhip_poly_resize_dev", ctx.get());
+            std::vector<const void *> ptrs;
+            for (std::size_t k = 0; k < K; ++k) ptrs.push_back(static_cast<const char *>(d_ext.get()) + k * extended_size * 32);
             dfs_type term(ctx, extended_size);
             term.set_degree(degree);
             check(zkhip_fr_vec_prod_dev(ctx.get(), adapter::id, ptrs.size(), ptrs.data(), term.data(), extended_size), "zkhip_fr_vec_prod_dev", ctx.get());
@@ -80,13 +103,17 @@ struct placeholder_quotient_hip {
             check(zkhip_poly_lincomb_dev(ctx.get(), adapter::id, 1, &tp, &extended_size, c, 1, F.data(), extended_size, first ? 0 : 1), "zkhip_poly_lincomb_dev",
                   ctx.get());
             F.set_degree(first ? degree : std::max(F.degree(), degree));
+            if (first) {    // keep the extended mask (the last slot) for the final product
+                d_mask_ext = ctx.alloc(extended_size * 32);
+                check(zkhip_memcpy_d2d_async(ctx.get(), d_mask_ext.get(), static_cast<const char *>(d_ext.get()) + K * extended_size * 32, extended_size * 32),
+                      "zkhip_memcpy_d2d_async", ctx.get());
+            }
             first = false;
-            ctx.sync();    // `moved` and `term` are released at the end of the iteration
+            ctx.sync();    // d_in, d_ext and `term` are released at the end of the iteration
         }
-        dfs_type mask = mask_polynomial;
-        if (F.degree() + mask.degree() >= extended_size) throw std::invalid_argument("gate_argument: mask * F does not fit the extended domain");
-        mask.resize(extended_size, root);
-        F *= mask;    // gates_argument.hpp:215
+        if (F.degree() + mask_polynomial.degree() >= extended_size) throw std::invalid_argument("gate_argument: mask * F does not fit the extended domain");
+        check(zkhip_fr_vec_op_dev(ctx.get(), adapter::id, 2, F.data(), d_mask_ext.get(), F.data(), extended_size), "zkhip_fr_vec_op_dev", ctx.get());    // gates_argument.hpp:215
+        F.set_degree(F.degree() + mask_polynomial.degree());
         ctx.sync();
         return F;
     }

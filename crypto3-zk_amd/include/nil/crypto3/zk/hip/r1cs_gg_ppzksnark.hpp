@@ -26,6 +26,8 @@
 #include <utility>
 #include <vector>
 
+#include <map>
+
 #include "evaluation_domain.hpp"
 #include "multiexp.hpp"
 
@@ -492,6 +494,47 @@ public:
         /* Choose two random field elements for prover zero-knowledge (prover.hpp:92-93). */
         return process(proving_key, primary_input, auxiliary_input, random_scalar(), random_scalar());
     }
+
+    /// THE REFERENCE'S STATIC SIGNATURE, argument for argument (prover.hpp:73-75):
+    ///     proof_type process(const proving_key_type &proving_key, const primary_input_type &, const auxiliary_input_type &)
+    /// with `proving_key` the reference's HOST key.  The device key the proof needs (queries in HBM, window tables) is built on the
+    /// first call with a given key object and kept in a per-thread cache for the later ones (keyed by the key's address and query
+    /// sizes; `forget(proving_key)` drops it when the host key goes away), on the calling thread's default context and over the
+    /// domain make_evaluation_domain(M + n + 1) returns.  A call site then changes by the class name alone; callers that manage
+    /// contexts / domains / shards themselves keep using the device-key overloads above.
+    template <typename K = KeyType, typename std::enable_if<std::is_same<K, KeyType>::value && curve_adapter<CurveType>::has_field_constants, bool>::type = true>
+    static proof_type process(const K &proving_key, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input) {
+        return process(cached_device_key(proving_key), primary_input, auxiliary_input);
+    }
+    template <typename K = KeyType, typename std::enable_if<std::is_same<K, KeyType>::value && curve_adapter<CurveType>::has_field_constants, bool>::type = true>
+    static proof_type process(const K &proving_key, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input,
+                              const scalar_value_type &r, const scalar_value_type &s) {
+        return process(cached_device_key(proving_key), primary_input, auxiliary_input, r, s);
+    }
+    /// drop the cached device key of `proving_key` (and with it the resident queries); true if there was one
+    static bool forget(const KeyType &proving_key) { return device_key_cache().erase(&proving_key) != 0; }
+
+private:
+    struct cached_key {
+        std::size_t a = 0, h = 0, l = 0;    // query sizes when the device key was built: a key object reused for another key is rebuilt
+        std::unique_ptr<proving_key_type> device;
+    };
+    static std::map<const KeyType *, cached_key> &device_key_cache() {
+        thread_local std::map<const KeyType *, cached_key> cache;    // per thread, like default_context(): a context is not thread-safe
+        return cache;
+    }
+    static const proving_key_type &cached_device_key(const KeyType &pk) {
+        cached_key &e = device_key_cache()[&pk];
+        if (!e.device || e.a != pk.A_query.size() || e.h != pk.H_query.size() || e.l != pk.L_query.size()) {
+            e.device.reset(new proving_key_type(pk));
+            e.a = pk.A_query.size();
+            e.h = pk.H_query.size();
+            e.l = pk.L_query.size();
+        }
+        return *e.device;
+    }
+
+public:
 
     static proof_type process(const proving_key_type &pk, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input,
                               const scalar_value_type &r, const scalar_value_type &s) {

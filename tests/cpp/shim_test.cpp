@@ -185,6 +185,19 @@ int groth16_prove_t(size_t M, size_t n, size_t N, const uint32_t *const rowptr[3
         r1cs_gg_ppzksnark_proving_key_hip<Curve> plain(pk);
         auto pv = r1cs_gg_ppzksnark_prover_hip<Curve>::process(plain, primary, auxiliary, A::scalar_from_limbs(r), A::scalar_from_limbs(s));
         if (!(pv.g_A == proof_v.g_A) || !(pv.g_B == proof_v.g_B) || !(pv.g_C == proof_v.g_C)) return -107;
+        /* THE REFERENCE'S STATIC SIGNATURE (prover.hpp:73-75): process(proving_key, primary_input, auxiliary_input) with the HOST key --
+           the device key is built on the first call and cached for the second */
+        {
+            typedef r1cs_gg_ppzksnark_prover_hip<Curve> prover;
+            const r1cs_gg_ppzksnark_proving_key<Curve> &proving_key = pk;
+            auto q1 = prover::process(proving_key, primary, auxiliary, A::scalar_from_limbs(r), A::scalar_from_limbs(s));
+            auto q2 = prover::process(proving_key, primary, auxiliary, A::scalar_from_limbs(r), A::scalar_from_limbs(s));
+            if (!(q1.g_A == proof_v.g_A) || !(q1.g_B == proof_v.g_B) || !(q1.g_C == proof_v.g_C)) return -109;
+            if (!(q2.g_A == proof_v.g_A) || !(q2.g_B == proof_v.g_B) || !(q2.g_C == proof_v.g_C)) return -109;
+            typename prover::proof_type q3 = prover::process(proving_key, primary, auxiliary);    // the three-argument form: fresh blinders
+            if (q3.g_A.is_zero()) return -109;
+            if (!prover::forget(proving_key) || prover::forget(proving_key)) return -110;
+        }
         const auto h_plain = r1cs_to_qap_hip<Curve>::witness_map(pk.constraint_system, primary, auxiliary);
         device_r1cs<Curve> dcs(ctx, pk.constraint_system);
         const auto h_ctx = r1cs_to_qap_hip<Curve>::witness_map_host(ctx, dcs, dom, primary, auxiliary);

@@ -1,15 +1,15 @@
 #!/bin/bash
-# Round-3 evidence run (on the GPU box, from the repository root): bench line, rocprofv3 kernel stats, PMC passes,
+# Round-4 evidence run (on the GPU box, from the repository root): bench line, rocprofv3 kernel stats, PMC passes,
 # sweeps.  Everything lands in gpurun_out/ (copied into profiles/ afterwards).
 set -u
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$root"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-R=r03
+R=r04
 python3 bench.py > gpurun_out/${R}_bench_final.json 2> gpurun_out/${R}_bench_final.err
 # kernel trace + stats of the MSM / NTT legs of the same command
-rm -rf /tmp/rp && ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rp -o msm --output-format csv -- python3 "$root/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-groth16 --no-kzg --no-pmc --no-verify --no-two-in-flight > /tmp/rp.log 2>&1 )
+rm -rf /tmp/rp && ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rp -o msm --output-format csv -- python3 "$root/bench.py" --no-cpu-baseline --no-groth16 --no-kzg --no-pmc --no-verify --no-two-in-flight > /tmp/rp.log 2>&1 )
 cp $(find /tmp/rp -name '*kernel_stats.csv' | head -1) gpurun_out/${R}_rocprofv3_kernel_stats_msm_bench.csv 2>/dev/null
 # the same for a whole Groth16 proof (both streams) and the 50-column KZG commit
 rm -rf /tmp/rp2 && ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rp2 -o g16 --output-format csv -- python3 "$root/tools/bench_groth16.py" --steps 4 > /tmp/rp2.log 2>&1 )
@@ -31,5 +31,9 @@ python3 tools/bench_kzg.py 2>/dev/null | tail -1 > gpurun_out/${R}_kzg_commit_50
 python3 tools/bench_ntt.py 2>/dev/null | tail -1 > gpurun_out/${R}_ntt_2p22x8.json
 ( python3 tools/bench_ecntt.py 12 16 18 20; python3 tools/bench_ecntt.py 12 14 --g2; python3 tools/bench_ecntt.py 16 --curve1 ) > gpurun_out/${R}_ecntt.txt 2>/dev/null
 python3 tools/groth16_two_provers.py 2>/dev/null | tail -1 > gpurun_out/${R}_groth16_two_provers.json
+( cd tools && ./microbench2 ) > gpurun_out/${R}_microbench2_valu_wallclock.txt 2>&1
+( cd tools && ./mulbench4 | grep -v "^CHECK" ) > gpurun_out/${R}_mulbench4_asm_vs_cpp_13x30.txt 2>&1
+ZKHIP_GEN_PHASES=1 python3 tools/bench_groth16.py --steps 2 2>&1 | grep "generator phase" > gpurun_out/${R}_generator_phases.txt
+for seed in 1 2; do timeout 400 python3 tests/fuzz_gpu.py --seconds 300 --seed $seed 2>&1 | tail -3; done > gpurun_out/${R}_fuzz.txt
 python3 tools/bench_groth16.py --steps 6 --curve 1 2>/dev/null | tail -1 > gpurun_out/${R}_groth16_2p20_bn254_shim.json
 ls -la gpurun_out | tail -20
