@@ -87,3 +87,40 @@ def test_ec_ntt_in_several_launches(ctx):
     assert outs[0] == outs[1]
     pts, inf = cp.batch_mul(curve, group, fr_arr(po.lagrange_at(m, w, tau, r)))
     assert outs[0] == [pt_from_limbs(curve, group, pts[j], inf[j]) for j in range(m)]
+
+
+@pytest.mark.parametrize("curve,group,log_m", [(0, 1, 17), (0, 2, 12), (1, 1, 16)])
+def test_ec_ntt_large_against_the_scalar_transform(ctx, zk, curve, group, log_m):
+    """Sizes beyond the closed-form test above: P_i = k_i G with random k_i generated on the device; the DFT over the
+    group of the P_i is the scalar DFT of the k_i in the exponent, out[j] = (sum_i omega^(ij) k_i) G -- 512 evenly spaced output points
+    against the oracle's scalar transform (pinned to the O(n^2) definition) and its fixed-base multiples; then the inverse transform
+    brings the inputs back (same sample + the point at infinity).  2^17 G1 points: every twiddle of 17 stages through the GLV split and the signed-window ladder."""
+    C = CURVES[curve]
+    r, m = C.r, 1 << log_m
+    w = C.root_of_unity(log_m)
+    ks = cp.random_fr(curve, 6000 + log_m, m)
+    ks[5] = 0  # a point at infinity among the inputs
+    bases = ctx.bases_from_scalars(curve, group, ks)
+    pts, inf = bases.download()
+    bases.free()
+    L = FQ_LIMBS[curve] * group
+    jac = np.zeros((m, 3 * L), dtype=np.uint64)
+    jac[:, : 2 * L] = pts
+    jac[:, 2 * L] = 1
+    jac[inf != 0] = 0
+    d = ctx.malloc(jac.nbytes)
+    ctx.h2d(d, jac)
+    ctx.ec_ntt_dev(curve, group, d, log_m, limbs(w, 4), inverse=False)
+    out = np.zeros_like(jac)
+    ctx.d2h(out, d)
+    exps = cp.ntt(curve, ks.reshape(1, m, 4), log_m, limbs(w, 4))[0]
+    exp_pts, exp_inf = cp.batch_mul(curve, group, exps)
+    # compare in affine (python normaliser: one inversion per point, hence a sample)
+    idx = list(range(0, m, m // 512))
+    for j in idx:
+        assert jac_to_affine_py(curve, group, out[j]) == pt_from_limbs(curve, group, exp_pts[j], exp_inf[j]), j
+    ctx.ec_ntt_dev(curve, group, d, log_m, limbs(w, 4), inverse=True)
+    ctx.d2h(out, d)
+    for j in idx + [5]:
+        assert jac_to_affine_py(curve, group, out[j]) == pt_from_limbs(curve, group, pts[j], inf[j]), j
+    ctx.free(d)
