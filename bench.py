@@ -335,6 +335,7 @@ def main():
             line["kzg"] = kzg_leg(np, zk, ctx, verify=not args.no_verify, valu=(traffic or {}).get("valu", {}).get("msm_bucket_acc"))
             line["lpc"] = lpc_leg(np)
             line["quotient_chain"] = quotient_leg(np, verify=not args.no_verify)
+            line["permutation_argument"] = permutation_leg(np, verify=not args.no_verify)
         if world == 1 and not args.no_cpu_baseline:
             global CPU_GROTH16_LOG
             CPU_GROTH16_LOG = args.cpu_groth16_log
@@ -935,6 +936,35 @@ def quotient_leg(np, log_n=20, steps=4, verify=True):
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
                          "algorithmic_bytes_per_chain": alg, "per": "whole chain: 52 n transform elements x 64 B + 4 multiexps x n x 128 B (list in bench.py)",
                          "dominant_kernels": "ntt_pass (the resizes to the extended domains) and msm_bucket_acc (the three non-zero parts' commitments)"}}
+
+
+def permutation_leg(np, log_n=20, k=4, steps=4, verify=True):
+    """placeholder's permutation argument, prover side, at BASELINE config 5's row count (hip/placeholder_permutation.hpp mirrors
+    permutation_argument.hpp:70-224): k permuted columns resident; the grand product V_P (one inversion per ROW in a serial loop in the
+    reference; chunks sharing an inversion + a three-level prefix-product scan here) and the three constraint polynomials."""
+    import ctypes
+
+    lib = _bench_lib()
+    ms = np.zeros(2 * steps, dtype=np.float64)
+    verified = ctypes.c_int(-1)
+    rc = lib.zkhip_bench_permutation(0, ctypes.c_size_t(log_n), ctypes.c_size_t(k), steps, ms.ctypes.data_as(ctypes.c_void_p), ctypes.byref(verified) if verify else None)
+    if rc != 0:
+        return {"error": rc}
+    ms = ms.reshape(steps, 2)
+    timed = ms[1:] if steps > 1 else ms
+    gp, whole = (float(x) for x in timed.mean(axis=0))
+    n = 1 << log_n
+    # the grand product reads 3 k vectors and writes 2 k + 1: 32 B per element each
+    alg_gp = (5 * k + 1) * n * 32
+    ach = alg_gp / (gp * 1e-3) / 1e9
+    return {"metric": "placeholder permutation argument (prover side), BLS12-381, %d permuted columns x 2^%d rows, resident" % (k, log_n),
+            "value": round(whole, 3), "unit": "ms per prove_eval", "higher_is_better": False, "statistic": "mean of the runs after the first",
+            "ms_grand_product": round(gp, 3), "ms_per_run": [round(float(x), 2) for x in ms[:, 1]],
+            "verified": None if not verify else bool(verified.value == 1),
+            "verification": "V_P[0] = 1 and the recurrence at 64 sampled rows; F_1(y) against its definition at a random y",
+            "roofline": {"bound": "hbm", "kernel": "perm_grand_product (3 launches: chunk ratios + workgroup scan, top scan, apply)", "achieved": round(ach, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None, "algorithmic_bytes": alg_gp,
+                         "per": "the grand product alone: 3 k input vectors read, 2 k + 1 written, 32 B per element"}}
 
 
 def ntt_sharded_leg(np, torch, dist, zk, ctx, rank, world, local_rank, log_m=22, batch=8, steps=5, verify=True):

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include <nil/crypto3/zk/hip/lpc.hpp>
+#include <nil/crypto3/zk/hip/placeholder_permutation.hpp>
 #include <nil/crypto3/zk/hip/placeholder_quotient.hpp>
 
 using namespace nil::crypto3::zk::hip;
@@ -298,6 +299,102 @@ int zkhip_bench_quotient(int device, size_t log_n, int steps, double *ms, int *v
         return 0;
     } catch (const std::exception &e) {
         fprintf(stderr, "zkhip_bench_quotient: %s\n", e.what());
+        return -1;
+    }
+}
+
+/* placeholder's permutation argument at size (hip/placeholder_permutation.hpp; permutation_argument.hpp:70-224): k permuted columns of
+ * 2^log_n rows, resident.  ms: steps x {grand product (g_v, h_v, V_P: zkhip_perm_grand_product_dev), whole prove_eval}.
+ * *verified: V_P[0] = 1 and V_P[j + 1] prod_i h_i[j] == V_P[j] prod_i g_i[j] at 64 sampled rows (host arithmetic over downloaded rows), and
+ * F_1(y) == (1 - q_last(y) - q_blind(y)) (V_P(omega y) h(y) - V_P(y) g(y)) at a random y, every polynomial evaluated from its coefficient form. */
+int zkhip_bench_permutation(int device, size_t log_n, size_t k, int steps, double *ms, int *verified) {
+    try {
+        typedef placeholder_permutation_hip<C> PA;
+        typedef device_polynomial_dfs<C> dfs;
+        const size_t n = (size_t)1 << log_n;
+        context ctx(device);
+        uint64_t seed = 99;
+        auto sm = [&seed]() {
+            uint64_t z = (seed += 0x9E3779B97F4A7C15ull);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return z ^ (z >> 31);
+        };
+        auto rnd = [&]() {
+            uint64_t w[4] = {sm(), sm(), sm(), sm() & 0x0fffffffffffffffull};
+            return A::scalar_from_limbs(w);
+        };
+        std::vector<polynomial_dfs<C>> h(3 * k + 3);
+        for (auto &p : h) {
+            p.values.resize(n);
+            for (auto &v : p.values) v = rnd();
+        }
+        for (size_t j = 0; j < n; ++j) {    // q_last, q_blind, lagrange_0 as placeholder shapes them
+            h[3 * k].values[j] = j == n - 4 ? Fr::one() : Fr::zero();
+            h[3 * k + 1].values[j] = j > n - 4 ? Fr::one() : Fr::zero();
+            h[3 * k + 2].values[j] = j == 0 ? Fr::one() : Fr::zero();
+        }
+        std::vector<dfs> all;
+        for (auto &p : h) all.emplace_back(ctx, p, n - 1);
+        std::vector<dfs> cols(all.begin(), all.begin() + k), sid(all.begin() + k, all.begin() + 2 * k), ssig(all.begin() + 2 * k, all.begin() + 3 * k);
+        const Fr beta = rnd(), gamma = rnd();
+        std::unique_ptr<PA::prover_result_type> last;
+        for (int rep = 0; rep < steps; ++rep) {
+            /* the grand product alone */
+            auto d_g = ctx.alloc(k * n * 32), d_h = ctx.alloc(k * n * 32), d_v = ctx.alloc(n * 32);
+            std::vector<const void *> pc, pi, ps;
+            for (size_t i = 0; i < k; ++i) pc.push_back(cols[i].data()), pi.push_back(sid[i].data()), ps.push_back(ssig[i].data());
+            uint64_t bl[4], gl[4];
+            A::scalar_to_limbs(beta, bl);
+            A::scalar_to_limbs(gamma, gl);
+            ctx.sync();
+            auto t0 = std::chrono::steady_clock::now();
+            check(zkhip_perm_grand_product_dev(ctx.get(), A::id, k, pc.data(), pi.data(), ps.data(), n, bl, gl, d_g.get(), d_h.get(), d_v.get()),
+                  "zkhip_perm_grand_product_dev", ctx.get());
+            ctx.sync();
+            ms[2 * rep] = ms_since(t0);
+            t0 = std::chrono::steady_clock::now();
+            last.reset(new PA::prover_result_type(PA::prove_eval(ctx, cols, sid, ssig, all[3 * k], all[3 * k + 1], all[3 * k + 2], beta, gamma, bls_root)));
+            ms[2 * rep + 1] = ms_since(t0);
+        }
+        if (verified) {
+            bool ok = true;
+            std::vector<uint64_t> vp(4 * n);
+            ctx.d2h(vp.data(), last->permutation_polynomial_dfs.data(), n * 32);
+            ok = A::scalar_from_limbs(vp.data()) == Fr::one();
+            for (int t = 0; t < 64 && ok; ++t) {
+                const size_t j = sm() % (n - 1);
+                Fr nom = Fr::one(), den = Fr::one();
+                for (size_t i = 0; i < k; ++i) {
+                    nom = nom * (h[i].values[j] + beta * h[k + i].values[j] + gamma);
+                    den = den * (h[i].values[j] + beta * h[2 * k + i].values[j] + gamma);
+                }
+                ok = A::scalar_from_limbs(&vp[4 * (j + 1)]) * den == A::scalar_from_limbs(&vp[4 * j]) * nom;
+            }
+            /* F_1 at a random point */
+            const Fr y = rnd();
+            uint64_t yl[4], v[4];
+            auto eval_at = [&](const dfs &p, const Fr &x) {
+                A::scalar_to_limbs(x, yl);
+                auto c = p.coefficients(bls_root);
+                check(zkhip_poly_eval_dev(ctx.get(), A::id, c.get(), p.size(), p.size(), 1, yl, 1, v), "zkhip_poly_eval_dev", ctx.get());
+                return A::scalar_from_limbs(v);
+            };
+            Fr gy = Fr::one(), hy = Fr::one();
+            for (size_t i = 0; i < k; ++i) {
+                const Fr c = eval_at(cols[i], y);
+                gy = gy * (c + beta * eval_at(sid[i], y) + gamma);
+                hy = hy * (c + beta * eval_at(ssig[i], y) + gamma);
+            }
+            const dfs &VP = last->permutation_polynomial_dfs;
+            const Fr lhs = eval_at(last->F_dfs[1], y);
+            const Fr rhs = (Fr::one() - eval_at(all[3 * k], y) - eval_at(all[3 * k + 1], y)) * (eval_at(VP, y * bls_root(log_n)) * hy - eval_at(VP, y) * gy);
+            ok = ok && lhs == rhs;
+            *verified = ok ? 1 : 0;
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkhip_bench_permutation: %s\n", e.what());
         return -1;
     }
 }

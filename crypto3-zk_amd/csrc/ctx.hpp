@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
@@ -79,6 +80,14 @@ struct zkhip_ctx {
     bool own_stream = false;
     hipEvent_t order_event = nullptr;  // zkhip_stream_wait: marks this context's stream for another context to wait on
     std::string last_error;
+    // zkhip_malloc / zkhip_free keep freed blocks for reuse (sizes rounded to 64 KiB; a request takes a cached block up to 1/8 larger):
+    // the polynomial-layer chains allocate the same GB-class temporaries again and again, and a raw hipMalloc / hipFree pair costs
+    // milliseconds -- at times hundreds (measured: a 20-ms quotient chain with 170-230 ms outliers every third run).  "alloc_cache_mb"
+    // caps what is kept (default 16 GiB of the 288; 0 turns the cache off); everything goes back at zkhip_destroy or when hipMalloc fails.
+    std::multimap<size_t, void *> alloc_free;
+    std::unordered_map<void *, size_t> alloc_live;
+    size_t alloc_cached_bytes = 0, opt_alloc_cache_bytes = (size_t)16 << 30;
+    std::mutex alloc_mutex;
     std::vector<uint32_t> lagrange_stage;  // host constants of zkhip_domain_lagrange_dev, alive until its copies ran
     uint32_t *d_status = nullptr;  // sticky device-side error flags (ZK_STATUS_*), read and cleared by zkhip_device_status
     // bump-allocated workspace, grown on demand, reused across calls

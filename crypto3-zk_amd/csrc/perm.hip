@@ -1,0 +1,234 @@
+// The grand product of placeholder's permutation argument (zk/snark/systems/plonk/placeholder/permutation_argument.hpp:103-136):
+//   g_i = column_i + beta S_id_i + gamma,   h_i = column_i + beta S_sigma_i + gamma          (pointwise over the n rows, i < k)
+//   V_P[0] = 1,   V_P[j] = V_P[j - 1] * prod_i g_i[j - 1] / prod_i h_i[j - 1]
+// The reference walks the rows one after the other with one field inversion per row.  Here: every lane takes PERM_CHUNK consecutive
+// rows, forms their numerators and denominators, inverts the denominators with ONE inversion (Montgomery's trick), and the exclusive
+// prefix PRODUCT over all rows is a three-level scan (lane chunk -> workgroup in LDS -> one workgroup over the workgroup totals).
+// Everything between the loads and the stores is in Montgomery form; HBM holds canonical Fr (4 x u64) as everywhere.
+#include <algorithm>
+
+#include "ctx.hpp"
+#include "fu.hpp"
+
+using namespace zkhip;
+
+namespace {
+
+constexpr uint32_t PERM_CHUNK = 8, PERM_THREADS = 256;
+
+template <class U>
+ZK_D Fu<U> p_load_mont(const uint32_t *p, size_t i) {  // canonical in memory -> Montgomery
+    const uint4 *q = reinterpret_cast<const uint4 *>(p) + 2 * i;
+    const uint4 a = q[0], b = q[1];
+    const uint32_t s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return fu_mul(fu_unpack<U>(s), Fu<U>::r2());
+}
+template <class U>
+ZK_D void p_store_raw(uint32_t *p, size_t i, const Fu<U> &x) {  // x normalised, < 2^256: stored as it is
+    uint32_t s[8];
+    fu_pack<U>(s, x);
+    uint4 *q = reinterpret_cast<uint4 *>(p) + 2 * i;
+    q[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    q[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+template <class U>
+ZK_D Fu<U> p_load_raw(const uint32_t *p, size_t i) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p) + 2 * i;
+    const uint4 a = q[0], b = q[1];
+    const uint32_t s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return fu_unpack<U>(s);
+}
+template <class U>
+ZK_D Fu<U> from_mont(const Fu<U> &x) {  // Montgomery -> canonical representative
+    Fu<U> one = Fu<U>::zero();
+    one.v[0] = 1;
+    return fu_cond_sub_p(fu_mul(x, one));
+}
+template <class U>
+ZK_D Fu<U> mmul(const Fu<U> &a, const Fu<U> &b) { return fu_cond_sub_p(fu_mul(a, b)); }
+
+// inclusive prefix product of one value per lane over the workgroup, in LDS (Hillis-Steele, log2(PERM_THREADS) rounds)
+template <class U>
+ZK_D Fu<U> block_scan_mul(uint32_t *lds, Fu<U> x, uint32_t t) {
+    constexpr int L = U::L;
+    auto put = [&](uint32_t i, const Fu<U> &v) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) lds[l * PERM_THREADS + i] = v.v[l];
+    };
+    auto get = [&](uint32_t i) {
+        Fu<U> v;
+#pragma unroll
+        for (int l = 0; l < L; ++l) v.v[l] = lds[l * PERM_THREADS + i];
+        return v;
+    };
+    put(t, x);
+    __syncthreads();
+    for (uint32_t d = 1; d < PERM_THREADS; d <<= 1) {
+        Fu<U> other;
+        const bool take = t >= d;
+        if (take) other = get(t - d);
+        __syncthreads();
+        if (take) {
+            x = mmul(x, other);
+            put(t, x);
+        }
+        __syncthreads();
+    }
+    return x;
+}
+
+// pass 1: ratios of the lane's rows (stored in Montgomery form), g / h vectors (canonical, optional), the lane's exclusive prefix
+// inside its workgroup and the workgroup's total
+template <class U>
+__global__ __launch_bounds__(PERM_THREADS) void perm_scan_local(const uint32_t *const *__restrict__ cols, const uint32_t *const *__restrict__ sid,
+                                                                const uint32_t *const *__restrict__ ssig, uint32_t k, size_t n,
+                                                                const uint32_t *__restrict__ consts, uint32_t *__restrict__ gv, uint32_t *__restrict__ hv,
+                                                                uint32_t *__restrict__ ratio, uint32_t *__restrict__ lane_prefix,
+                                                                uint32_t *__restrict__ block_tot) {
+    __shared__ uint32_t lds[U::L * PERM_THREADS];
+    const uint32_t t = threadIdx.x;
+    const size_t lane = (size_t)blockIdx.x * PERM_THREADS + t, lo = lane * PERM_CHUNK;
+    const Fu<U> beta = p_load_raw<U>(consts, 0), gamma = p_load_raw<U>(consts, 1);  // Montgomery
+    Fu<U> local = Fu<U>::one();
+    if (lo < n) {
+        const uint32_t cnt = (uint32_t)(n - lo < PERM_CHUNK ? n - lo : PERM_CHUNK);
+        Fu<U> nom[PERM_CHUNK], pre[PERM_CHUNK], den[PERM_CHUNK];
+        Fu<U> acc = Fu<U>::one();
+        for (uint32_t r = 0; r < cnt; ++r) {
+            const size_t row = lo + r;
+            Fu<U> nm = Fu<U>::one(), dn = Fu<U>::one();
+            for (uint32_t i = 0; i < k; ++i) {
+                const Fu<U> c = p_load_mont<U>(cols[i], row);
+                const Fu<U> cg = fu_cond_sub_p(fu_add(c, gamma));
+                const Fu<U> g = fu_cond_sub_p(fu_add(mmul(beta, p_load_mont<U>(sid[i], row)), cg));
+                const Fu<U> h = fu_cond_sub_p(fu_add(mmul(beta, p_load_mont<U>(ssig[i], row)), cg));
+                if (gv) p_store_raw<U>(gv, (size_t)i * n + row, from_mont(g));
+                if (hv) p_store_raw<U>(hv, (size_t)i * n + row, from_mont(h));
+                nm = mmul(nm, g);
+                dn = mmul(dn, h);
+            }
+            nom[r] = nm;
+            den[r] = dn;
+            pre[r] = acc;
+            acc = mmul(acc, dn);
+        }
+        Fu<U> inv = fu_cond_sub_p(fu_inv(acc));  // a zero denominator (probability ~ k n / r) leaves zeros behind, as 1 / 0 "=" 0 in the reference's field type
+        for (uint32_t r = cnt; r-- > 0;) {
+            const Fu<U> q = mmul(nom[r], mmul(inv, pre[r]));
+            inv = mmul(inv, den[r]);
+            nom[r] = q;
+        }
+        for (uint32_t r = 0; r < cnt; ++r) {
+            p_store_raw<U>(ratio, lo + r, nom[r]);
+            local = mmul(local, nom[r]);
+        }
+    }
+    const Fu<U> incl = block_scan_mul<U>(lds, local, t);
+    // exclusive prefix of this lane inside the workgroup = inclusive value of the lane before it
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < U::L; ++l) lds[l * PERM_THREADS + t] = incl.v[l];
+    __syncthreads();
+    Fu<U> excl = Fu<U>::one();
+    if (t > 0) {
+#pragma unroll
+        for (int l = 0; l < U::L; ++l) excl.v[l] = lds[l * PERM_THREADS + t - 1];
+    }
+    p_store_raw<U>(lane_prefix, lane, excl);
+    if (t == PERM_THREADS - 1) p_store_raw<U>(block_tot, blockIdx.x, incl);
+}
+
+// pass 2: exclusive prefix products of the workgroup totals (one workgroup; every lane takes `per` consecutive totals)
+template <class U>
+__global__ __launch_bounds__(PERM_THREADS) void perm_scan_top(uint32_t *__restrict__ block_tot, uint32_t nblk, uint32_t per) {
+    __shared__ uint32_t lds[U::L * PERM_THREADS];
+    const uint32_t t = threadIdx.x, lo = t * per;
+    Fu<U> local = Fu<U>::one();
+    for (uint32_t i = lo; i < lo + per && i < nblk; ++i) local = mmul(local, p_load_raw<U>(block_tot, i));
+    const Fu<U> incl = block_scan_mul<U>(lds, local, t);
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < U::L; ++l) lds[l * PERM_THREADS + t] = incl.v[l];
+    __syncthreads();
+    Fu<U> run = Fu<U>::one();
+    if (t > 0) {
+#pragma unroll
+        for (int l = 0; l < U::L; ++l) run.v[l] = lds[l * PERM_THREADS + t - 1];
+    }
+    for (uint32_t i = lo; i < lo + per && i < nblk; ++i) {
+        const Fu<U> mine = p_load_raw<U>(block_tot, i);
+        p_store_raw<U>(block_tot, i, run);  // exclusive
+        run = mmul(run, mine);
+    }
+}
+
+// pass 3: V_P[row] = (prefix of the workgroup) (prefix of the lane) (product of the lane's earlier ratios), canonical
+template <class U>
+__global__ __launch_bounds__(PERM_THREADS) void perm_scan_apply(const uint32_t *__restrict__ ratio, const uint32_t *__restrict__ lane_prefix,
+                                                                const uint32_t *__restrict__ block_pre, size_t n, uint32_t *__restrict__ vp) {
+    const size_t lane = (size_t)blockIdx.x * PERM_THREADS + threadIdx.x, lo = lane * PERM_CHUNK;
+    if (lo >= n) return;
+    Fu<U> run = mmul(p_load_raw<U>(block_pre, blockIdx.x), p_load_raw<U>(lane_prefix, lane));
+    const uint32_t cnt = (uint32_t)(n - lo < PERM_CHUNK ? n - lo : PERM_CHUNK);
+    for (uint32_t r = 0; r < cnt; ++r) {
+        p_store_raw<U>(vp, lo + r, from_mont(run));
+        run = mmul(run, p_load_raw<U>(ratio, lo + r));
+    }
+}
+
+// consts[0] = beta, consts[1] = gamma: canonical in, Montgomery out
+template <class U>
+__global__ void perm_setup(const uint32_t *__restrict__ in, uint32_t *__restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x >= 2) return;
+    p_store_raw<U>(out, threadIdx.x, fu_cond_sub_p(fu_mul(p_load_raw<U>(in, threadIdx.x), Fu<U>::r2())));
+}
+
+template <class U>
+int perm_run(zkhip_ctx *ctx, size_t k, const void *const *d_cols, const void *const *d_sid, const void *const *d_ssig, size_t n, const uint64_t *beta,
+             const uint64_t *gamma, uint32_t *d_gv, uint32_t *d_hv, uint32_t *d_vp) {
+    const size_t lanes = (n + PERM_CHUNK - 1) / PERM_CHUNK, nblk = (lanes + PERM_THREADS - 1) / PERM_THREADS;
+    if (nblk > (size_t)PERM_THREADS * 4096) return ZKHIP_ERR_RANGE;
+    const uint32_t per = (uint32_t)((nblk + PERM_THREADS - 1) / PERM_THREADS);
+    size_t need = zkhip_ctx::ws_round(3 * k * sizeof(void *)) + zkhip_ctx::ws_round(4 * 32) + zkhip_ctx::ws_round(n * 32) +
+                  zkhip_ctx::ws_round(nblk * PERM_THREADS * 32) + zkhip_ctx::ws_round(nblk * 32);
+    ZK_TRY(ctx->ws_reserve(need));
+    ctx->ws_reset();
+    const uint32_t **d_ptrs = ctx->ws_take<const uint32_t *>(3 * k);
+    uint32_t *d_consts = ctx->ws_take<uint32_t>(4 * 8);
+    uint32_t *d_ratio = ctx->ws_take<uint32_t>(n * 8);
+    uint32_t *d_lane = ctx->ws_take<uint32_t>(nblk * PERM_THREADS * 8);
+    uint32_t *d_blk = ctx->ws_take<uint32_t>(nblk * 8);
+    ctx->batch_ptrs.resize(3 * k);  // host copies alive until the asynchronous copies ran (synchronised below)
+    for (size_t i = 0; i < k; ++i) {
+        ctx->batch_ptrs[i] = (uint32_t *)d_cols[i];
+        ctx->batch_ptrs[k + i] = (uint32_t *)d_sid[i];
+        ctx->batch_ptrs[2 * k + i] = (uint32_t *)d_ssig[i];
+    }
+    ctx->lagrange_stage.assign(16, 0u);
+    memcpy(ctx->lagrange_stage.data(), beta, 32);
+    memcpy(ctx->lagrange_stage.data() + 8, gamma, 32);
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_ptrs, ctx->batch_ptrs.data(), 3 * k * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_consts + 16, ctx->lagrange_stage.data(), 64, hipMemcpyHostToDevice, ctx->stream));
+    ZK_LAUNCH(ctx, "perm_grand_product", perm_setup<U>, dim3(1), dim3(64), 0, d_consts + 16, d_consts);
+    ZK_LAUNCH(ctx, "perm_grand_product", perm_scan_local<U>, dim3((unsigned)nblk), dim3(PERM_THREADS), 0, d_ptrs, d_ptrs + k, d_ptrs + 2 * k, (uint32_t)k, n, d_consts,
+              d_gv, d_hv, d_ratio, d_lane, d_blk);
+    ZK_LAUNCH(ctx, "perm_grand_product", perm_scan_top<U>, dim3(1), dim3(PERM_THREADS), 0, d_blk, (uint32_t)nblk, per);
+    ZK_LAUNCH(ctx, "perm_grand_product", perm_scan_apply<U>, dim3((unsigned)nblk), dim3(PERM_THREADS), 0, d_ratio, d_lane, d_blk, n, d_vp);
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the staged pointers / constants may be reused after return
+    return ZKHIP_OK;
+}
+
+}  // namespace
+
+extern "C" int zkhip_perm_grand_product_dev(zkhip_ctx *ctx, int curve, size_t k, const void *const *d_cols, const void *const *d_sid, const void *const *d_ssigma,
+                                            size_t n, const uint64_t *beta, const uint64_t *gamma, void *d_g, void *d_h, void *d_vp) {
+    if (!ctx || k == 0 || !d_cols || !d_sid || !d_ssigma || !beta || !gamma || (n && !d_vp)) return ZKHIP_ERR_INVALID;
+    if (curve != CURVE_BLS12_381 && curve != CURVE_BN254) return ZKHIP_ERR_INVALID;
+    if (k >= 4096 || n >= ((size_t)1 << 32)) return ZKHIP_ERR_RANGE;
+    for (size_t i = 0; i < k; ++i)
+        if (n && (!d_cols[i] || !d_sid[i] || !d_ssigma[i])) return ZKHIP_ERR_INVALID;
+    if (n == 0) return ZKHIP_OK;
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (curve == CURVE_BLS12_381) return perm_run<BlsFrU>(ctx, k, d_cols, d_sid, d_ssigma, n, beta, gamma, (uint32_t *)d_g, (uint32_t *)d_h, (uint32_t *)d_vp);
+    return perm_run<BnFrU>(ctx, k, d_cols, d_sid, d_ssigma, n, beta, gamma, (uint32_t *)d_g, (uint32_t *)d_h, (uint32_t *)d_vp);
+}

@@ -51,6 +51,8 @@ int zkhip_init(int device_id, zkhip_ctx **out) {
     return ZKHIP_OK;
 }
 
+static void alloc_cache_flush(zkhip_ctx *ctx);
+
 void zkhip_destroy(zkhip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -67,6 +69,9 @@ void zkhip_destroy(zkhip_ctx *ctx) {
     }
     zk_graphs_clear(ctx);
     if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
+    alloc_cache_flush(ctx);
+    for (auto &e : ctx->alloc_live) (void)hipFree(e.first);  // blocks the caller never returned
+    ctx->alloc_live.clear();
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -143,6 +148,12 @@ int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value) {
         ctx->opt_msm_shard_rank = (int)value;
     }
     else if (n == "msm_graphs") ctx->opt_msm_graphs = (int)value;
+    else if (n == "alloc_cache_mb") {
+        if (value < 0) return ZKHIP_ERR_RANGE;
+        std::lock_guard<std::mutex> lock(ctx->alloc_mutex);
+        ctx->opt_alloc_cache_bytes = (size_t)value << 20;
+        if (ctx->alloc_cached_bytes > ctx->opt_alloc_cache_bytes) alloc_cache_flush(ctx);
+    }
     else if (n == "stream_priority") {
         // the context's OWN stream is recreated with a scheduling priority: < 0 the highest the device offers, > 0 the lowest, 0 the
         // default.  Two contexts on one GPU (the Groth16 shim's main and G2 streams) can so decide whose workgroups go first.
@@ -166,6 +177,7 @@ int zkhip_get_option(const zkhip_ctx *ctx, const char *name, int64_t *value) {
     if (!ctx || !name || !value) return ZKHIP_ERR_INVALID;
     std::string n(name);
     if (n == "msm_window_bits") *value = ctx->opt_msm_window_bits;
+    else if (n == "alloc_cache_mb") *value = (int64_t)(ctx->opt_alloc_cache_bytes >> 20);
     else if (n == "msm_segment_log") *value = ctx->opt_msm_segment_log;
     else if (n == "msm_sets") *value = ctx->opt_msm_sets;
     else if (n == "msm_tail_quads") *value = ctx->opt_msm_tail_quads;
@@ -185,15 +197,54 @@ int zkhip_get_option(const zkhip_ctx *ctx, const char *name, int64_t *value) {
     return ZKHIP_OK;
 }
 
+// give every cached block back to the driver
+static void alloc_cache_flush(zkhip_ctx *ctx) {
+    for (auto &e : ctx->alloc_free) (void)hipFree(e.second);
+    ctx->alloc_free.clear();
+    ctx->alloc_cached_bytes = 0;
+}
 int zkhip_malloc(zkhip_ctx *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) return ZKHIP_ERR_INVALID;
     ZK_TRY(check_device(ctx));
-    ZK_HIP_CHECK(ctx, hipMalloc(dptr, bytes ? bytes : 1));
+    const size_t want = ((bytes ? bytes : 1) + 0xFFFF) & ~(size_t)0xFFFF;
+    std::lock_guard<std::mutex> lock(ctx->alloc_mutex);
+    auto it = ctx->alloc_free.lower_bound(want);
+    if (it != ctx->alloc_free.end() && it->first <= want + (want >> 3)) {  // a cached block of this size class (blocks enter the cache after a stream sync)
+        *dptr = it->second;
+        ctx->alloc_cached_bytes -= it->first;
+        ctx->alloc_live[*dptr] = it->first;
+        ctx->alloc_free.erase(it);
+        return ZKHIP_OK;
+    }
+    hipError_t e = hipMalloc(dptr, want);
+    if (e != hipSuccess && !ctx->alloc_free.empty()) {  // out of memory with blocks in the cache: give them back and try once more
+        (void)hipGetLastError();
+        alloc_cache_flush(ctx);
+        e = hipMalloc(dptr, want);
+    }
+    ZK_HIP_CHECK(ctx, e);
+    ctx->alloc_live[*dptr] = want;
     return ZKHIP_OK;
 }
 int zkhip_free(zkhip_ctx *ctx, void *dptr) {
     if (!ctx) return ZKHIP_ERR_INVALID;
-    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!dptr) return ZKHIP_OK;
+    // hipFree used to synchronise the whole device before the block could be handed out again; a block entering the cache gets the same
+    // guarantee -- no stream of ANY context (a scheme's upload stream, the prover's G2 stream) still reads or writes it
+    ZK_HIP_CHECK(ctx, hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lock(ctx->alloc_mutex);
+    auto it = ctx->alloc_live.find(dptr);
+    if (it == ctx->alloc_live.end()) {  // not from zkhip_malloc of this context
+        ZK_HIP_CHECK(ctx, hipFree(dptr));
+        return ZKHIP_OK;
+    }
+    const size_t sz = it->second;
+    ctx->alloc_live.erase(it);
+    if (sz <= ctx->opt_alloc_cache_bytes && ctx->alloc_cached_bytes + sz <= ctx->opt_alloc_cache_bytes) {
+        ctx->alloc_free.emplace(sz, dptr);
+        ctx->alloc_cached_bytes += sz;
+        return ZKHIP_OK;
+    }
     ZK_HIP_CHECK(ctx, hipFree(dptr));
     return ZKHIP_OK;
 }

@@ -19,7 +19,7 @@ EXPORTS = [
     "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_batch_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_domain_choice", "zkhip_domain_fft_dev", "zkhip_domain_lagrange_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_set_domain", "zkhip_r1cs_domain_size", "zkhip_r1cs_domain_kind", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev", "zkhip_groth16_witness_h_domain_dev", "zkhip_fr_gather_dev", "zkhip_poly_resize_dev", "zkhip_fri_fold_dev", "zkhip_fri_leaves_dev", "zkhip_ec_ntt_dev",
-    "zkhip_fr_vec_op_dev", "zkhip_fr_vec_prod_dev", "zkhip_poly_shift_dev", "zkhip_poly_eval_dev", "zkhip_poly_div_linear_dev", "zkhip_poly_div_vanishing_dev", "zkhip_poly_lincomb_dev",
+    "zkhip_fr_vec_op_dev", "zkhip_fr_vec_prod_dev", "zkhip_poly_shift_dev", "zkhip_poly_eval_dev", "zkhip_poly_div_linear_dev", "zkhip_poly_div_vanishing_dev", "zkhip_poly_lincomb_dev", "zkhip_perm_grand_product_dev",
     "zkhip_profile_enable", "zkhip_profile_reset", "zkhip_profile_filter", "zkhip_profile_get", "zkhip_profile_dump",
 ]
 
@@ -382,6 +382,14 @@ class Context:
         self._check(self.lib.zkhip_poly_div_vanishing_dev(self.h, curve, ctypes.c_void_p(d_f), ctypes.c_size_t(length), ctypes.c_size_t(n), ctypes.c_void_p(d_quot),
                                                           ctypes.byref(bad)), "poly_div_vanishing_dev")
         return int(bad.value)
+
+    def perm_grand_product_dev(self, curve: int, d_cols, d_sid, d_ssigma, n: int, beta, gamma, d_g: int, d_h: int, d_vp: int):
+        """placeholder's permutation grand product: g / h vectors (k x n at d_g / d_h, 0 to skip) and V_P (n at d_vp)"""
+        k = len(d_cols)
+        arr = lambda ps: (ctypes.c_void_p * k)(*ps)
+        self._check(self.lib.zkhip_perm_grand_product_dev(self.h, curve, ctypes.c_size_t(k), arr(d_cols), arr(d_sid), arr(d_ssigma), ctypes.c_size_t(n),
+                                                          _p(_u64(beta).reshape(4)), _p(_u64(gamma).reshape(4)), ctypes.c_void_p(d_g or None),
+                                                          ctypes.c_void_p(d_h or None), ctypes.c_void_p(d_vp)), "perm_grand_product_dev")
 
     def poly_lincomb_dev(self, curve: int, d_polys, lens, coeffs: np.ndarray, taps: int, d_acc: int, acc_len: int, accumulate: bool):
         count = len(d_polys)

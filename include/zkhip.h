@@ -74,7 +74,10 @@ int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value);
  * of two contexts on one GPU the higher one's workgroups are dispatched first (set it before any work is enqueued). */
 int zkhip_get_option(const zkhip_ctx *ctx, const char *name, int64_t *value);
 
-/* ---- device memory (plumbing for callers that keep vectors resident) -------------------------- */
+/* ---- device memory (plumbing for callers that keep vectors resident) --------------------------
+ * zkhip_free synchronises the device and keeps the block for the next zkhip_malloc of its size class (option "alloc_cache_mb":
+ * megabytes kept per context, default 16384, 0 = hand every block back at once); the cache is emptied at zkhip_destroy and when
+ * the driver runs out of memory. */
 int zkhip_malloc(zkhip_ctx *ctx, size_t bytes, void **dptr);
 int zkhip_free(zkhip_ctx *ctx, void *dptr);
 int zkhip_memcpy_h2d(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes);
@@ -284,6 +287,14 @@ int zkhip_poly_div_linear_dev(zkhip_ctx *ctx, int curve, const void *d_f, size_t
  * passing it synchronises the stream) receives the number of non-zero coefficients of the remainder -- 0 for the exact division
  * a satisfied circuit gives. */
 int zkhip_poly_div_vanishing_dev(zkhip_ctx *ctx, int curve, const void *d_f, size_t len, size_t n, void *d_quot, uint64_t *nonzero_remainders);
+/* The grand product of placeholder's permutation argument (ph/permutation_argument.hpp:103-136): over n rows and k permuted columns
+ *   g_i = column_i + beta S_id_i + gamma,  h_i = column_i + beta S_sigma_i + gamma   (pointwise),
+ *   V_P[0] = 1,  V_P[j] = V_P[j - 1] prod_i g_i[j - 1] / prod_i h_i[j - 1].
+ * d_cols / d_sid / d_ssigma: HOST arrays of k device pointers to n canonical Fr each; d_g / d_h (nullable): k x n outputs, vector i at
+ * element offset i n (the g_v / h_v the argument multiplies up afterwards); d_vp: n outputs.  The reference pays one inversion per row
+ * in a serial loop; here rows are taken in chunks that share an inversion and the prefix product is a three-level scan. */
+int zkhip_perm_grand_product_dev(zkhip_ctx *ctx, int curve, size_t k, const void *const *d_cols, const void *const *d_sid, const void *const *d_ssigma,
+                                 size_t n, const uint64_t *beta, const uint64_t *gamma, void *d_g, void *d_h, void *d_vp);
 /* d_acc[j] (+)= sum_i sum_{t < taps} coeffs[i * taps + t] * poly_i[j - t] for j < acc_len (poly_i is zero outside
  * [0, lens[i])): the accumulation `f += theta_i * (f_i - U) * diffpoly` (kzg_v2.hpp:258-263) for every committed
  * polynomial in ONE pass (coeffs[i] = theta_i * diffpoly_i, a few taps), and `L += ...` (:281-288) with taps = 1.

@@ -1153,6 +1153,43 @@ def quotient_polynomial_split_dfs(T: Sequence[int], rows_amount: int, split_poly
     return out
 
 
+# placeholder's permutation argument, prover side (zk/snark/systems/plonk/placeholder/permutation_argument.hpp:70-224, the
+# permutation_parts == 1 form).  PINNED to its definition: V_P by the row-by-row recurrence of :126-136 (one inversion per row), the
+# three constraint polynomials as DENSE coefficient-form polynomial arithmetic of the comment formulas (:166, 175, 215) -- domain sizes
+# of the reference's intermediate polynomial_dfs objects are crypto3-math's business and do not show in the coefficients.
+def permutation_grand_product(cols, S_id, S_sigma, beta: int, gamma: int, r: int):
+    n = len(cols[0])
+    g = [[(c[j] + beta * s_[j] + gamma) % r for j in range(n)] for c, s_ in zip(cols, S_id)]
+    h = [[(c[j] + beta * s_[j] + gamma) % r for j in range(n)] for c, s_ in zip(cols, S_sigma)]
+    V = [1] * n
+    for j in range(1, n):
+        nom = den = 1
+        for gi, hi in zip(g, h):
+            nom = nom * gi[j - 1] % r
+            den = den * hi[j - 1] % r
+        V[j] = V[j - 1] * nom * pow(den, -1, r) % r
+    return g, h, V
+
+
+def permutation_argument(cols, S_id, S_sigma, q_last, q_blind, lagrange_0, beta: int, gamma: int, root_of_unity, r: int):
+    """-> (V_P evaluations, [F0, F1, F2] as trimmed coefficient lists):
+         F0 = L_0 (1 - V_P),  F1 = (1 - (q_last + q_blind)) (V_P(omega X) h - V_P g),  F2 = q_last V_P (V_P - 1),
+       g = prod_i g_i, h = prod_i h_i"""
+    n = len(cols[0])
+    w = root_of_unity(n.bit_length() - 1)
+    g, h, V = permutation_grand_product(cols, S_id, S_sigma, beta, gamma, r)
+    co = lambda e: poly_trim(intt(list(e), w, r))
+    G, H = [1], [1]
+    for gi, hi in zip(g, h):
+        G, H = poly_mul(G, co(gi), r), poly_mul(H, co(hi), r)
+    VP, VPs = co(V), co(polynomial_shift(V, 1))
+    one = [1]
+    F0 = poly_mul(co(lagrange_0), poly_sub(one, VP, r), r)
+    F1 = poly_mul(poly_sub(one, poly_add(co(q_last), co(q_blind), r), r), poly_sub(poly_mul(VPs, H, r), poly_mul(VP, G, r), r), r)
+    F2 = poly_mul(co(q_last), poly_mul(VP, poly_sub(VP, one, r), r), r)
+    return V, [poly_trim(F0), poly_trim(F1), poly_trim(F2)]
+
+
 def lpc_proof_eval(r: int, batches: dict, points: dict, fixed: Sequence[int], log_domain: int, step_list: Sequence[int], root_of_unity,
                    challenges: Sequence[int], tree_root):
     """batches[k] = list of DFS polynomials (lists of ints); points[k][i] = evaluation points of polynomial i of batch k;

@@ -18,6 +18,7 @@
 #include <nil/crypto3/zk/hip/lpc.hpp>
 #include <nil/crypto3/zk/hip/marshalling.hpp>
 #include <array>
+#include <nil/crypto3/zk/hip/placeholder_permutation.hpp>
 #include <nil/crypto3/zk/hip/placeholder_quotient.hpp>
 #include <nil/crypto3/zk/hip/powers_of_tau.hpp>
 #include <nil/crypto3/zk/hip/r1cs_gg_ppzksnark.hpp>
@@ -1380,6 +1381,43 @@ int placeholder_quotient_t(const uint64_t *srs, size_t n_srs, const uint64_t *ev
     return 0;
 }
 
+// ---- placeholder's permutation argument on the device (placeholder_permutation.hpp; permutation_argument.hpp:70-224) ----
+/// evals: k columns | k S_id | k S_sigma | q_last | q_blind | lagrange_0, each 2^log_n.  out_vp: V_P (n); out_F: the three F polynomials'
+/// COEFFICIENTS, each in a slot of 8 n elements (zero-padded), with their domain sizes in out_sizes.
+template <typename Curve>
+int placeholder_permutation_t(const uint64_t *evals, size_t k, size_t log_n, const uint64_t *roots, const uint64_t *beta, const uint64_t *gamma, uint64_t *out_vp,
+                              uint64_t *out_F, uint64_t *out_sizes) {
+    typedef curve_adapter<Curve> A;
+    typedef device_polynomial_dfs<Curve> dfs;
+    const size_t n = (size_t)1 << log_n;
+    context ctx(0);
+    auto root = [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); };
+    std::vector<dfs> all;
+    for (size_t c = 0; c < 3 * k + 3; ++c) {
+        polynomial_dfs<Curve> h;
+        for (size_t i = 0; i < n; ++i) h.values.push_back(A::scalar_from_limbs(evals + 4 * (c * n + i)));
+        all.emplace_back(ctx, h, n - 1);
+    }
+    std::vector<dfs> cols(all.begin(), all.begin() + k), sid(all.begin() + k, all.begin() + 2 * k), ssig(all.begin() + 2 * k, all.begin() + 3 * k);
+    auto res = placeholder_permutation_hip<Curve>::prove_eval(ctx, cols, sid, ssig, all[3 * k], all[3 * k + 1], all[3 * k + 2], A::scalar_from_limbs(beta),
+                                                             A::scalar_from_limbs(gamma), root);
+    ctx.d2h(out_vp, res.permutation_polynomial_dfs.data(), n * 32);
+    for (int f = 0; f < 3; ++f) {
+        const size_t sz = res.F_dfs[f].size();
+        if (sz > 8 * n) return -51;
+        out_sizes[f] = sz;
+        auto c = res.F_dfs[f].coefficients(root);
+        ctx.d2h(out_F + 4 * (size_t)f * 8 * n, c.get(), sz * 32);
+    }
+    /* the inputs must be untouched (the argument reads shared buffers) */
+    std::vector<uint64_t> back(4 * n);
+    ctx.d2h(back.data(), all[3 * k + 2].data(), n * 32);
+    if (std::memcmp(back.data(), evals + 4 * (3 * k + 2) * n, n * 32) != 0) return -52;
+    ctx.d2h(back.data(), all[3 * k].data(), n * 32);
+    if (std::memcmp(back.data(), evals + 4 * (3 * k) * n, n * 32) != 0) return -53;
+    return 0;
+}
+
 template <typename Curve>
 r1cs_constraint_system<Curve> cs_from_csr(size_t M, size_t n, size_t N, const uint32_t *const rowptr[3], const uint32_t *const col[3],
                                           const uint64_t *const coeff[3]) {
@@ -1667,6 +1705,16 @@ int shim_placeholder_transcript_bls(const uint64_t *srs, size_t n_srs, const uin
         return placeholder_transcript_bls(srs, n_srs, evals, npolys, log_n, nw, roots, challenge, thetas, out, out_cap, out_len);
     } catch (const std::exception &e) {
         fprintf(stderr, "shim_placeholder_transcript_bls: %s\n", e.what());
+        return -1;
+    }
+}
+int shim_placeholder_permutation(int curve, const uint64_t *evals, size_t k, size_t log_n, const uint64_t *roots, const uint64_t *beta, const uint64_t *gamma,
+                                 uint64_t *out_vp, uint64_t *out_F, uint64_t *out_sizes) {
+    try {
+        if (curve == ZKHIP_BLS12_381) return placeholder_permutation_t<bls12_381>(evals, k, log_n, roots, beta, gamma, out_vp, out_F, out_sizes);
+        return placeholder_permutation_t<alt_bn128_254>(evals, k, log_n, roots, beta, gamma, out_vp, out_F, out_sizes);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "shim_placeholder_permutation: %s\n", e.what());
         return -1;
     }
 }

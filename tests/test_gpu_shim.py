@@ -422,6 +422,63 @@ def test_placeholder_call_sequence_with_foreign_polynomial_type(shim, curve):
     assert at + 2 * L1 + 1 == len(out)
 
 
+@pytest.mark.parametrize("curve,log_n,k", [(0, 6, 3), (1, 6, 2), (0, 8, 4), (0, 5, 1)])
+def test_placeholder_permutation_argument_shim(shim, curve, log_n, k):
+    """placeholder's permutation argument, prover side, on the device (hip/placeholder_permutation.hpp; permutation_argument.hpp:70-224,
+    permutation_parts == 1): the grand product V_P -- a serial loop with one inversion per row in the reference; chunks sharing an inversion
+    + a three-level prefix-product scan on the device -- EXACTLY the oracle's row-by-row recurrence, and the three constraint polynomials
+    F_0, F_1, F_2 equal to the oracle's dense coefficient-form arithmetic.  A genuine copy-constraint instance: columns constant along the
+    cycles of a random permutation of the k n cells, so the product closes (V_P[n-1] g / h at the last row = 1)."""
+    C = CURVES[curve]
+    r = C.r
+    n = 1 << log_n
+    rng = po.SplitMix64(6100 + 10 * curve + log_n + k)
+    w = C.root_of_unity(log_n)
+    delta = C.fr_generator
+    labels = [[pow(delta, i, r) * pow(w, j, r) % r for j in range(n)] for i in range(k)]
+    cells = [(i, j) for i in range(k) for j in range(n)]
+    perm = list(cells)
+    for a in range(len(perm) - 1, 0, -1):            # Fisher-Yates with the test's generator
+        b = rng.next_mod(a + 1)
+        perm[a], perm[b] = perm[b], perm[a]
+    sigma = dict(zip(cells, perm))
+    val, seen = {}, set()
+    for c in cells:
+        if c in seen:
+            continue
+        v, x = rng.next_mod(r), c
+        while x not in seen:
+            seen.add(x)
+            val[x] = v
+            x = sigma[x]
+    cols = [[val[(i, j)] for j in range(n)] for i in range(k)]
+    S_id = labels
+    S_sigma = [[labels[sigma[(i, j)][0]][sigma[(i, j)][1]] for j in range(n)] for i in range(k)]
+    usable = n - 3
+    q_last = [1 if j == usable else 0 for j in range(n)]
+    q_blind = [1 if j > usable else 0 for j in range(n)]
+    L0 = [1] + [0] * (n - 1)
+    beta, gamma = rng.next_mod(r), rng.next_mod(r)
+    V, F = po.permutation_argument(cols, S_id, S_sigma, q_last, q_blind, L0, beta, gamma, C.root_of_unity, r)
+    g, h, _ = po.permutation_grand_product(cols, S_id, S_sigma, beta, gamma, r)
+    nom = den = 1
+    for gi, hi in zip(g, h):
+        nom, den = nom * gi[n - 1] % r, den * hi[n - 1] % r
+    assert V[n - 1] * nom * pow(den, -1, r) % r == 1        # the permutation is satisfied: the grand product closes
+    evals = fr_arr([x for v in cols + S_id + S_sigma + [q_last, q_blind, L0] for x in v])
+    roots = np.stack([limbs(C.root_of_unity(l), 4) for l in range(log_n + 4)])
+    out_vp = np.zeros((n, 4), dtype=np.uint64)
+    out_F = np.zeros((3, 8 * n, 4), dtype=np.uint64)
+    sizes = np.zeros(3, dtype=np.uint64)
+    rc = shim.shim_placeholder_permutation(curve, P(evals), ctypes.c_size_t(k), ctypes.c_size_t(log_n), P(roots), P(limbs(beta, 4)), P(limbs(gamma, 4)), P(out_vp),
+                                           P(out_F), P(sizes))
+    assert rc == 0
+    assert fr_ints(out_vp) == V
+    for f in range(3):
+        got = po.poly_trim(fr_ints(out_F[f][: int(sizes[f])]))
+        assert got == F[f], f
+
+
 def test_placeholder_transcript_bytes_bls12_381(shim):
     """a placeholder proof is bit-exact with the reference's only if the TRANSCRIPT absorbs the same bytes.  The
     placeholder-facing KZG scheme with the reference's encodings -- commitments as 48-byte compressed BLS12-381 points (the
