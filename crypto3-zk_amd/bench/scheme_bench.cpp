@@ -11,6 +11,7 @@
 #include <vector>
 
 #include <nil/crypto3/zk/hip/lpc.hpp>
+#include <nil/crypto3/zk/hip/placeholder_lookup.hpp>
 #include <nil/crypto3/zk/hip/placeholder_permutation.hpp>
 #include <nil/crypto3/zk/hip/placeholder_quotient.hpp>
 
@@ -395,6 +396,129 @@ int zkhip_bench_permutation(int device, size_t log_n, size_t k, int steps, doubl
         return 0;
     } catch (const std::exception &e) {
         fprintf(stderr, "zkhip_bench_permutation: %s\n", e.what());
+        return -1;
+    }
+}
+
+/* placeholder's lookup argument, prover side, from the sorted vectors on (hip/placeholder_lookup.hpp; lookup_argument.hpp:153-296): k_in inputs drawn
+ * from k_val table columns of 2^log_n rows, resident.  A GENUINE instance: table column i is zero at row 0, holds usable_rows / 2 distinct non-zero values
+ * behind it and zeros after them; the inputs take table values (or zero) in the usable rows; `sorted` is built on the host as sort_polynomials (:565-638)
+ * builds it.  ms: steps x {V_L alone (zkhip_lookup_grand_product_dev), whole prove_eval}.
+ * *verified: V_L[0] = 1, V_L[usable_rows] = 1 -- the product over all rows closes: the reference's own BOOST_CHECK (:217) --, zeros behind it, the
+ * recurrence at 64 sampled rows (host arithmetic), and F_2(y) == ((q_last + q_blind)(y) - 1)(V_L(y) g(y) - V_L(omega y) h(y)) at a random y, every
+ * polynomial evaluated from its coefficient form. */
+int zkhip_bench_lookup(int device, size_t log_n, size_t k_in, size_t k_val, int steps, double *ms, int *verified) {
+    try {
+        typedef placeholder_lookup_hip<C> LA;
+        typedef device_polynomial_dfs<C> dfs;
+        const size_t n = (size_t)1 << log_n, usable = n - 4, total = k_in + k_val, T = usable / 2;
+        context ctx(device);
+        uint64_t seed = 777;
+        auto sm = [&seed]() {
+            uint64_t z = (seed += 0x9E3779B97F4A7C15ull);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return z ^ (z >> 31);
+        };
+        auto rnd = [&]() {
+            uint64_t w[4] = {sm() | 1, sm(), sm(), sm() & 0x0fffffffffffffffull};    // never zero
+            return A::scalar_from_limbs(w);
+        };
+        std::vector<polynomial_dfs<C>> value(k_val), input(k_in), sorted(total);
+        std::vector<Fr> pool(1, Fr::zero());
+        for (auto &p : value) {
+            p.values.assign(n, Fr::zero());
+            for (size_t j = 1; j <= T; ++j) pool.push_back(p.values[j] = rnd());
+        }
+        std::vector<uint32_t> looked_up(pool.size(), 0);
+        for (auto &p : input) {
+            p.values.resize(n);
+            for (size_t j = 0; j < n; ++j) {
+                if (j < usable) {
+                    const size_t idx = sm() % pool.size();
+                    ++looked_up[idx];
+                    p.values[j] = pool[idx];
+                } else {
+                    p.values[j] = rnd();
+                }
+            }
+        }
+        {    // sort_polynomials: a zero at every 0 -> non-zero step of the table walk, then every value as often as it occurs in table + inputs
+            std::vector<Fr> flat;
+            size_t idx = 1;
+            for (size_t c = 0; c < k_val; ++c) {
+                flat.push_back(Fr::zero());
+                for (size_t j = 1; j <= T; ++j, ++idx) flat.insert(flat.end(), 1 + looked_up[idx], pool[idx]);
+            }
+            if (flat.size() > total * usable) throw std::runtime_error("lookup bench: instance does not fit");
+            for (auto &p : sorted) p.values.assign(n, Fr::zero());
+            for (size_t i = 0; i < flat.size(); ++i) sorted[i / usable].values[i % usable] = flat[i];
+            for (size_t i = 0; i + 1 < total; ++i) sorted[i].values[usable] = sorted[i + 1].values[0];
+        }
+        polynomial_dfs<C> hq_last, hq_blind, hl0;
+        hq_last.values.assign(n, Fr::zero());
+        hq_blind.values.assign(n, Fr::zero());
+        hl0.values.assign(n, Fr::zero());
+        hq_last.values[usable] = Fr::one();
+        for (size_t j = usable + 1; j < n; ++j) hq_blind.values[j] = Fr::one();
+        hl0.values[0] = Fr::one();
+        std::vector<dfs> d_in, d_val, d_sorted;
+        for (auto &p : input) d_in.emplace_back(ctx, p, n - 1);
+        for (auto &p : value) d_val.emplace_back(ctx, p, n - 1);
+        for (auto &p : sorted) d_sorted.emplace_back(ctx, p, n - 1);
+        dfs q_last(ctx, hq_last, n - 1), q_blind(ctx, hq_blind, n - 1), lagrange_0(ctx, hl0, n - 1);
+        const Fr beta = rnd(), gamma = rnd();
+        std::vector<Fr> alphas;
+        for (size_t i = 0; i + 1 < total; ++i) alphas.push_back(rnd());
+        std::unique_ptr<LA::prover_result_type> last;
+        for (int rep = 0; rep < steps; ++rep) {
+            ctx.sync();
+            auto t0 = std::chrono::steady_clock::now();
+            {
+                dfs v = LA::compute_V_L(ctx, d_sorted, d_in, d_val, beta, gamma, usable);
+                ctx.sync();
+            }
+            ms[2 * rep] = ms_since(t0);
+            t0 = std::chrono::steady_clock::now();
+            last.reset(new LA::prover_result_type(LA::prove_eval(ctx, d_in, d_val, d_sorted, q_last, q_blind, lagrange_0, beta, gamma, alphas, usable, bls_root)));
+            ms[2 * rep + 1] = ms_since(t0);
+        }
+        if (verified) {
+            std::vector<uint64_t> vl(4 * n);
+            ctx.d2h(vl.data(), last->V_L.data(), n * 32);
+            auto V = [&](size_t j) { return A::scalar_from_limbs(&vl[4 * j]); };
+            bool ok = V(0) == Fr::one() && V(usable) == Fr::one();
+            for (size_t j = usable + 1; j < n && ok; ++j) ok = V(j) == Fr::zero();
+            const Fr part1 = (Fr::one() + beta) * gamma;
+            for (int t = 0; t < 64 && ok; ++t) {
+                const size_t j = sm() % usable;
+                Fr g = Fr::one(), h = Fr::one();
+                for (auto &p : input) g = g * (Fr::one() + beta) * (gamma + p.values[j]);
+                for (auto &p : value) g = g * (part1 + p.values[j] + beta * p.values[j + 1]);
+                for (auto &p : sorted) h = h * (part1 + p.values[j] + beta * p.values[j + 1]);
+                ok = V(j + 1) * h == V(j) * g;
+            }
+            /* F_2 at a random point */
+            const Fr y = rnd(), w = bls_root(log_n);
+            uint64_t yl[4], v[4];
+            auto eval_at = [&](const dfs &p, const Fr &x) {
+                A::scalar_to_limbs(x, yl);
+                auto c = p.coefficients(bls_root);
+                check(zkhip_poly_eval_dev(ctx.get(), A::id, c.get(), p.size(), p.size(), 1, yl, 1, v), "zkhip_poly_eval_dev", ctx.get());
+                return A::scalar_from_limbs(v);
+            };
+            Fr gy = Fr::one(), hy = Fr::one();
+            for (auto &p : d_in) gy = gy * (Fr::one() + beta) * (gamma + eval_at(p, y));
+            for (auto &p : d_val) gy = gy * (part1 + eval_at(p, y) + beta * eval_at(p, y * w));
+            for (auto &p : d_sorted) hy = hy * (part1 + eval_at(p, y) + beta * eval_at(p, y * w));
+            const Fr lhs = eval_at(last->F_dfs[2], y);
+            const Fr rhs = (eval_at(q_last, y) + eval_at(q_blind, y) - Fr::one()) * (eval_at(last->V_L, y) * gy - eval_at(last->V_L, y * w) * hy);
+            ok = ok && lhs == rhs;
+            *verified = ok ? 1 : 0;
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkhip_bench_lookup: %s\n", e.what());
         return -1;
     }
 }

@@ -1,4 +1,4 @@
-// The grand product of placeholder's permutation argument (zk/snark/systems/plonk/placeholder/permutation_argument.hpp:103-136):
+// The grand products of placeholder's permutation and lookup arguments (the lookup's rows: LookupRows below).  The permutation argument's (zk/snark/systems/plonk/placeholder/permutation_argument.hpp:103-136):
 //   g_i = column_i + beta S_id_i + gamma,   h_i = column_i + beta S_sigma_i + gamma          (pointwise over the n rows, i < k)
 //   V_P[0] = 1,   V_P[j] = V_P[j - 1] * prod_i g_i[j - 1] / prod_i h_i[j - 1]
 // The reference walks the rows one after the other with one field inversion per row.  Here: every lane takes PERM_CHUNK consecutive
@@ -77,40 +77,72 @@ ZK_D Fu<U> block_scan_mul(uint32_t *lds, Fu<U> x, uint32_t t) {
     return x;
 }
 
-// pass 1: ratios of the lane's rows (stored in Montgomery form), g / h vectors (canonical, optional), the lane's exclusive prefix
-// inside its workgroup and the workgroup's total
+// the rows of the permutation argument: numerator prod_i (column_i + beta S_id_i + gamma), denominator the same over S_sigma
 template <class U>
-__global__ __launch_bounds__(PERM_THREADS) void perm_scan_local(const uint32_t *const *__restrict__ cols, const uint32_t *const *__restrict__ sid,
-                                                                const uint32_t *const *__restrict__ ssig, uint32_t k, size_t n,
-                                                                const uint32_t *__restrict__ consts, uint32_t *__restrict__ gv, uint32_t *__restrict__ hv,
-                                                                uint32_t *__restrict__ ratio, uint32_t *__restrict__ lane_prefix,
-                                                                uint32_t *__restrict__ block_tot) {
+struct PermRows {
+    const uint32_t *const *cols, *const *sid, *const *ssig;
+    uint32_t k;
+    size_t n;
+    uint32_t *gv, *hv;  // the g_v / h_v vectors (canonical, k x n), or null
+    ZK_D void operator()(size_t row, const uint32_t *consts, Fu<U> &nm, Fu<U> &dn) const {
+        const Fu<U> beta = p_load_raw<U>(consts, 0), gamma = p_load_raw<U>(consts, 1);  // Montgomery
+        nm = Fu<U>::one();
+        dn = Fu<U>::one();
+        for (uint32_t i = 0; i < k; ++i) {
+            const Fu<U> c = p_load_mont<U>(cols[i], row);
+            const Fu<U> cg = fu_cond_sub_p(fu_add(c, gamma));
+            const Fu<U> g = fu_cond_sub_p(fu_add(mmul(beta, p_load_mont<U>(sid[i], row)), cg));
+            const Fu<U> h = fu_cond_sub_p(fu_add(mmul(beta, p_load_mont<U>(ssig[i], row)), cg));
+            if (gv) p_store_raw<U>(gv, (size_t)i * n + row, from_mont(g));
+            if (hv) p_store_raw<U>(hv, (size_t)i * n + row, from_mont(h));
+            nm = mmul(nm, g);
+            dn = mmul(dn, h);
+        }
+    }
+};
+
+// the rows of the lookup argument (lookup_argument.hpp:387-407), row = k - 1 of the reference's loop:
+//   numerator (1 + beta)^k_in prod_i (gamma + input_i[row]) prod_i ((1 + beta) gamma + value_i[row] + beta value_i[row + 1]),
+//   denominator prod_i ((1 + beta) gamma + sorted_i[row] + beta sorted_i[row + 1]);   consts[2] = (1 + beta)^k_in, consts[3] = (1 + beta) gamma
+template <class U>
+struct LookupRows {
+    const uint32_t *const *in, *const *val, *const *sorted;
+    uint32_t k_in, k_val, k_sorted;
+    size_t n;
+    ZK_D void operator()(size_t row, const uint32_t *consts, Fu<U> &nm, Fu<U> &dn) const {
+        const Fu<U> beta = p_load_raw<U>(consts, 0), gamma = p_load_raw<U>(consts, 1), part1 = p_load_raw<U>(consts, 3);
+        const size_t next = row + 1 == n ? 0 : row + 1;
+        nm = p_load_raw<U>(consts, 2);
+        dn = Fu<U>::one();
+        for (uint32_t i = 0; i < k_in; ++i) nm = mmul(nm, fu_cond_sub_p(fu_add(gamma, p_load_mont<U>(in[i], row))));
+        for (uint32_t i = 0; i < k_val; ++i) {
+            const Fu<U> a = fu_cond_sub_p(fu_add(part1, p_load_mont<U>(val[i], row)));
+            nm = mmul(nm, fu_cond_sub_p(fu_add(a, mmul(beta, p_load_mont<U>(val[i], next)))));
+        }
+        for (uint32_t i = 0; i < k_sorted; ++i) {
+            const Fu<U> a = fu_cond_sub_p(fu_add(part1, p_load_mont<U>(sorted[i], row)));
+            dn = mmul(dn, fu_cond_sub_p(fu_add(a, mmul(beta, p_load_mont<U>(sorted[i], next)))));
+        }
+    }
+};
+
+// pass 1: ratios of the lane's rows (stored in Montgomery form; rows >= `rows` count as ratio 1), the lane's exclusive prefix inside its
+// workgroup and the workgroup's total
+template <class U, class Rows>
+__global__ __launch_bounds__(PERM_THREADS) void perm_scan_local(Rows rows_of, size_t rows, const uint32_t *__restrict__ consts, uint32_t *__restrict__ ratio,
+                                                                uint32_t *__restrict__ lane_prefix, uint32_t *__restrict__ block_tot) {
     __shared__ uint32_t lds[U::L * PERM_THREADS];
     const uint32_t t = threadIdx.x;
     const size_t lane = (size_t)blockIdx.x * PERM_THREADS + t, lo = lane * PERM_CHUNK;
-    const Fu<U> beta = p_load_raw<U>(consts, 0), gamma = p_load_raw<U>(consts, 1);  // Montgomery
     Fu<U> local = Fu<U>::one();
-    if (lo < n) {
-        const uint32_t cnt = (uint32_t)(n - lo < PERM_CHUNK ? n - lo : PERM_CHUNK);
+    if (lo < rows) {
+        const uint32_t cnt = (uint32_t)(rows - lo < PERM_CHUNK ? rows - lo : PERM_CHUNK);
         Fu<U> nom[PERM_CHUNK], pre[PERM_CHUNK], den[PERM_CHUNK];
         Fu<U> acc = Fu<U>::one();
         for (uint32_t r = 0; r < cnt; ++r) {
-            const size_t row = lo + r;
-            Fu<U> nm = Fu<U>::one(), dn = Fu<U>::one();
-            for (uint32_t i = 0; i < k; ++i) {
-                const Fu<U> c = p_load_mont<U>(cols[i], row);
-                const Fu<U> cg = fu_cond_sub_p(fu_add(c, gamma));
-                const Fu<U> g = fu_cond_sub_p(fu_add(mmul(beta, p_load_mont<U>(sid[i], row)), cg));
-                const Fu<U> h = fu_cond_sub_p(fu_add(mmul(beta, p_load_mont<U>(ssig[i], row)), cg));
-                if (gv) p_store_raw<U>(gv, (size_t)i * n + row, from_mont(g));
-                if (hv) p_store_raw<U>(hv, (size_t)i * n + row, from_mont(h));
-                nm = mmul(nm, g);
-                dn = mmul(dn, h);
-            }
-            nom[r] = nm;
-            den[r] = dn;
+            rows_of(lo + r, consts, nom[r], den[r]);
             pre[r] = acc;
-            acc = mmul(acc, dn);
+            acc = mmul(acc, den[r]);
         }
         Fu<U> inv = fu_cond_sub_p(fu_inv(acc));  // a zero denominator (probability ~ k n / r) leaves zeros behind, as 1 / 0 "=" 0 in the reference's field type
         for (uint32_t r = cnt; r-- > 0;) {
@@ -162,60 +194,97 @@ __global__ __launch_bounds__(PERM_THREADS) void perm_scan_top(uint32_t *__restri
     }
 }
 
-// pass 3: V_P[row] = (prefix of the workgroup) (prefix of the lane) (product of the lane's earlier ratios), canonical
+// pass 3: V[row] = (prefix of the workgroup) (prefix of the lane) (product of the lane's earlier ratios), canonical, for row <= rows;
+// the entries behind that are zero (the lookup argument's V_L, lookup_argument.hpp:382-383; the permutation argument has rows = n)
 template <class U>
 __global__ __launch_bounds__(PERM_THREADS) void perm_scan_apply(const uint32_t *__restrict__ ratio, const uint32_t *__restrict__ lane_prefix,
-                                                                const uint32_t *__restrict__ block_pre, size_t n, uint32_t *__restrict__ vp) {
+                                                                const uint32_t *__restrict__ block_pre, size_t n, size_t rows, uint32_t *__restrict__ vp) {
     const size_t lane = (size_t)blockIdx.x * PERM_THREADS + threadIdx.x, lo = lane * PERM_CHUNK;
     if (lo >= n) return;
-    Fu<U> run = mmul(p_load_raw<U>(block_pre, blockIdx.x), p_load_raw<U>(lane_prefix, lane));
     const uint32_t cnt = (uint32_t)(n - lo < PERM_CHUNK ? n - lo : PERM_CHUNK);
+    if (lo > rows) {
+        for (uint32_t r = 0; r < cnt; ++r) p_store_raw<U>(vp, lo + r, Fu<U>::zero());
+        return;
+    }
+    Fu<U> run = mmul(p_load_raw<U>(block_pre, blockIdx.x), p_load_raw<U>(lane_prefix, lane));
     for (uint32_t r = 0; r < cnt; ++r) {
-        p_store_raw<U>(vp, lo + r, from_mont(run));
-        run = mmul(run, p_load_raw<U>(ratio, lo + r));
+        if (lo + r <= rows) {
+            p_store_raw<U>(vp, lo + r, from_mont(run));
+            if (lo + r < rows) run = mmul(run, p_load_raw<U>(ratio, lo + r));
+        } else {
+            p_store_raw<U>(vp, lo + r, Fu<U>::zero());
+        }
     }
 }
 
-// consts[0] = beta, consts[1] = gamma: canonical in, Montgomery out
+// consts[0] = beta, consts[1] = gamma: canonical in, Montgomery out; consts[2] = (1 + beta)^k_in, consts[3] = (1 + beta) gamma (the lookup argument's)
 template <class U>
-__global__ void perm_setup(const uint32_t *__restrict__ in, uint32_t *__restrict__ out) {
-    if (blockIdx.x != 0 || threadIdx.x >= 2) return;
-    p_store_raw<U>(out, threadIdx.x, fu_cond_sub_p(fu_mul(p_load_raw<U>(in, threadIdx.x), Fu<U>::r2())));
+__global__ void perm_setup(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t k_in) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const Fu<U> beta = fu_cond_sub_p(fu_mul(p_load_raw<U>(in, 0), Fu<U>::r2())), gamma = fu_cond_sub_p(fu_mul(p_load_raw<U>(in, 1), Fu<U>::r2()));
+    const Fu<U> opb = fu_cond_sub_p(fu_add(Fu<U>::one(), beta));
+    Fu<U> pw = Fu<U>::one();
+    for (uint32_t i = 0; i < k_in; ++i) pw = mmul(pw, opb);
+    p_store_raw<U>(out, 0, beta);
+    p_store_raw<U>(out, 1, gamma);
+    p_store_raw<U>(out, 2, pw);
+    p_store_raw<U>(out, 3, mmul(opb, gamma));
+}
+
+// the three passes over `n` entries of which the first `rows` carry ratios; ptrs: the device pointer table of the row functor (count entries)
+template <class U, class MakeRows>
+int scan_run(zkhip_ctx *ctx, size_t count, MakeRows make_rows, size_t n, size_t rows, uint32_t k_in, const uint64_t *beta, const uint64_t *gamma, uint32_t *d_vp) {
+    const size_t lanes = (n + PERM_CHUNK - 1) / PERM_CHUNK, nblk = (lanes + PERM_THREADS - 1) / PERM_THREADS;
+    if (nblk > (size_t)PERM_THREADS * 4096) return ZKHIP_ERR_RANGE;
+    const uint32_t per = (uint32_t)((nblk + PERM_THREADS - 1) / PERM_THREADS);
+    size_t need = zkhip_ctx::ws_round(count * sizeof(void *)) + zkhip_ctx::ws_round(6 * 32) + zkhip_ctx::ws_round(n * 32) +
+                  zkhip_ctx::ws_round(nblk * PERM_THREADS * 32) + zkhip_ctx::ws_round(nblk * 32);
+    ZK_TRY(ctx->ws_reserve(need));
+    ctx->ws_reset();
+    const uint32_t **d_ptrs = ctx->ws_take<const uint32_t *>(count);
+    uint32_t *d_consts = ctx->ws_take<uint32_t>(6 * 8);
+    uint32_t *d_ratio = ctx->ws_take<uint32_t>(n * 8);
+    uint32_t *d_lane = ctx->ws_take<uint32_t>(nblk * PERM_THREADS * 8);
+    uint32_t *d_blk = ctx->ws_take<uint32_t>(nblk * 8);
+    ctx->lagrange_stage.assign(16, 0u);  // host copies alive until the asynchronous copies ran (synchronised below); batch_ptrs filled by the caller
+    memcpy(ctx->lagrange_stage.data(), beta, 32);
+    memcpy(ctx->lagrange_stage.data() + 8, gamma, 32);
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_ptrs, ctx->batch_ptrs.data(), count * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_consts + 32, ctx->lagrange_stage.data(), 64, hipMemcpyHostToDevice, ctx->stream));
+    ZK_LAUNCH(ctx, "perm_grand_product", perm_setup<U>, dim3(1), dim3(64), 0, d_consts + 32, d_consts, k_in);
+    auto rows_of = make_rows(d_ptrs);
+    ZK_LAUNCH(ctx, "perm_grand_product", (perm_scan_local<U, decltype(rows_of)>), dim3((unsigned)nblk), dim3(PERM_THREADS), 0, rows_of, rows, d_consts, d_ratio, d_lane,
+              d_blk);
+    ZK_LAUNCH(ctx, "perm_grand_product", perm_scan_top<U>, dim3(1), dim3(PERM_THREADS), 0, d_blk, (uint32_t)nblk, per);
+    ZK_LAUNCH(ctx, "perm_grand_product", perm_scan_apply<U>, dim3((unsigned)nblk), dim3(PERM_THREADS), 0, d_ratio, d_lane, d_blk, n, rows, d_vp);
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the staged pointers / constants may be reused after return
+    return ZKHIP_OK;
 }
 
 template <class U>
 int perm_run(zkhip_ctx *ctx, size_t k, const void *const *d_cols, const void *const *d_sid, const void *const *d_ssig, size_t n, const uint64_t *beta,
              const uint64_t *gamma, uint32_t *d_gv, uint32_t *d_hv, uint32_t *d_vp) {
-    const size_t lanes = (n + PERM_CHUNK - 1) / PERM_CHUNK, nblk = (lanes + PERM_THREADS - 1) / PERM_THREADS;
-    if (nblk > (size_t)PERM_THREADS * 4096) return ZKHIP_ERR_RANGE;
-    const uint32_t per = (uint32_t)((nblk + PERM_THREADS - 1) / PERM_THREADS);
-    size_t need = zkhip_ctx::ws_round(3 * k * sizeof(void *)) + zkhip_ctx::ws_round(4 * 32) + zkhip_ctx::ws_round(n * 32) +
-                  zkhip_ctx::ws_round(nblk * PERM_THREADS * 32) + zkhip_ctx::ws_round(nblk * 32);
-    ZK_TRY(ctx->ws_reserve(need));
-    ctx->ws_reset();
-    const uint32_t **d_ptrs = ctx->ws_take<const uint32_t *>(3 * k);
-    uint32_t *d_consts = ctx->ws_take<uint32_t>(4 * 8);
-    uint32_t *d_ratio = ctx->ws_take<uint32_t>(n * 8);
-    uint32_t *d_lane = ctx->ws_take<uint32_t>(nblk * PERM_THREADS * 8);
-    uint32_t *d_blk = ctx->ws_take<uint32_t>(nblk * 8);
-    ctx->batch_ptrs.resize(3 * k);  // host copies alive until the asynchronous copies ran (synchronised below)
+    ctx->batch_ptrs.resize(3 * k);
     for (size_t i = 0; i < k; ++i) {
         ctx->batch_ptrs[i] = (uint32_t *)d_cols[i];
         ctx->batch_ptrs[k + i] = (uint32_t *)d_sid[i];
         ctx->batch_ptrs[2 * k + i] = (uint32_t *)d_ssig[i];
     }
-    ctx->lagrange_stage.assign(16, 0u);
-    memcpy(ctx->lagrange_stage.data(), beta, 32);
-    memcpy(ctx->lagrange_stage.data() + 8, gamma, 32);
-    ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_ptrs, ctx->batch_ptrs.data(), 3 * k * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_consts + 16, ctx->lagrange_stage.data(), 64, hipMemcpyHostToDevice, ctx->stream));
-    ZK_LAUNCH(ctx, "perm_grand_product", perm_setup<U>, dim3(1), dim3(64), 0, d_consts + 16, d_consts);
-    ZK_LAUNCH(ctx, "perm_grand_product", perm_scan_local<U>, dim3((unsigned)nblk), dim3(PERM_THREADS), 0, d_ptrs, d_ptrs + k, d_ptrs + 2 * k, (uint32_t)k, n, d_consts,
-              d_gv, d_hv, d_ratio, d_lane, d_blk);
-    ZK_LAUNCH(ctx, "perm_grand_product", perm_scan_top<U>, dim3(1), dim3(PERM_THREADS), 0, d_blk, (uint32_t)nblk, per);
-    ZK_LAUNCH(ctx, "perm_grand_product", perm_scan_apply<U>, dim3((unsigned)nblk), dim3(PERM_THREADS), 0, d_ratio, d_lane, d_blk, n, d_vp);
-    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the staged pointers / constants may be reused after return
-    return ZKHIP_OK;
+    return scan_run<U>(
+        ctx, 3 * k, [&](const uint32_t **p) { return PermRows<U>{p, p + k, p + 2 * k, (uint32_t)k, n, d_gv, d_hv}; }, n, n, 0, beta, gamma, d_vp);
+}
+
+template <class U>
+int lookup_run(zkhip_ctx *ctx, size_t k_in, const void *const *d_in, size_t k_val, const void *const *d_val, size_t k_sorted, const void *const *d_sorted, size_t n,
+               size_t usable_rows, const uint64_t *beta, const uint64_t *gamma, uint32_t *d_vl) {
+    ctx->batch_ptrs.clear();
+    for (size_t i = 0; i < k_in; ++i) ctx->batch_ptrs.push_back((uint32_t *)d_in[i]);
+    for (size_t i = 0; i < k_val; ++i) ctx->batch_ptrs.push_back((uint32_t *)d_val[i]);
+    for (size_t i = 0; i < k_sorted; ++i) ctx->batch_ptrs.push_back((uint32_t *)d_sorted[i]);
+    return scan_run<U>(
+        ctx, k_in + k_val + k_sorted,
+        [&](const uint32_t **p) { return LookupRows<U>{p, p + k_in, p + k_in + k_val, (uint32_t)k_in, (uint32_t)k_val, (uint32_t)k_sorted, n}; }, n, usable_rows,
+        (uint32_t)k_in, beta, gamma, d_vl);
 }
 
 }  // namespace
@@ -231,4 +300,25 @@ extern "C" int zkhip_perm_grand_product_dev(zkhip_ctx *ctx, int curve, size_t k,
     ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (curve == CURVE_BLS12_381) return perm_run<BlsFrU>(ctx, k, d_cols, d_sid, d_ssigma, n, beta, gamma, (uint32_t *)d_g, (uint32_t *)d_h, (uint32_t *)d_vp);
     return perm_run<BnFrU>(ctx, k, d_cols, d_sid, d_ssigma, n, beta, gamma, (uint32_t *)d_g, (uint32_t *)d_h, (uint32_t *)d_vp);
+}
+
+/* V_L of the lookup argument (lookup_argument.hpp:375-409): V_L[0] = 1, V_L[k] = V_L[k - 1] g(k - 1) / h(k - 1) for k <= usable_rows, zero behind */
+extern "C" int zkhip_lookup_grand_product_dev(zkhip_ctx *ctx, int curve, size_t k_in, const void *const *d_input, size_t k_val, const void *const *d_value,
+                                              size_t k_sorted, const void *const *d_sorted, size_t n, size_t usable_rows, const uint64_t *beta, const uint64_t *gamma,
+                                              void *d_vl) {
+    if (!ctx || !beta || !gamma || (n && !d_vl) || (k_in && !d_input) || (k_val && !d_value) || (k_sorted && !d_sorted)) return ZKHIP_ERR_INVALID;
+    if (curve != CURVE_BLS12_381 && curve != CURVE_BN254) return ZKHIP_ERR_INVALID;
+    if (k_in >= 4096 || k_val >= 4096 || k_sorted >= 4096 || n >= ((size_t)1 << 32)) return ZKHIP_ERR_RANGE;
+    if (n && usable_rows >= n) return ZKHIP_ERR_RANGE;
+    for (size_t i = 0; n && i < k_in; ++i)
+        if (!d_input[i]) return ZKHIP_ERR_INVALID;
+    for (size_t i = 0; n && i < k_val; ++i)
+        if (!d_value[i]) return ZKHIP_ERR_INVALID;
+    for (size_t i = 0; n && i < k_sorted; ++i)
+        if (!d_sorted[i]) return ZKHIP_ERR_INVALID;
+    if (n == 0) return ZKHIP_OK;
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (curve == CURVE_BLS12_381)
+        return lookup_run<BlsFrU>(ctx, k_in, d_input, k_val, d_value, k_sorted, d_sorted, n, usable_rows, beta, gamma, (uint32_t *)d_vl);
+    return lookup_run<BnFrU>(ctx, k_in, d_input, k_val, d_value, k_sorted, d_sorted, n, usable_rows, beta, gamma, (uint32_t *)d_vl);
 }

@@ -106,6 +106,25 @@ __global__ __launch_bounds__(256) void fr_vec_op(const uint32_t *__restrict__ a,
     fu_pack<U>(out + i * U::NL, r);
 }
 
+// out[i] = a x[i] + b y[i] + c (y nullable): the linear factors placeholder's arguments multiply up, e.g. (1 + beta)(gamma + input) and
+// (1 + beta) gamma + value + beta value(omega X) (lookup_argument.hpp:313, 329, 361); a, b, c canonical, by value
+struct FrWords {
+    uint32_t w[8];
+};
+template <class U>
+__global__ __launch_bounds__(256) void fr_vec_affine(const uint32_t *__restrict__ x, const uint32_t *__restrict__ y, FrWords a, FrWords b, FrWords c, size_t count,
+                                                     uint32_t *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const Fu<U> am = fu_mul(fu_unpack<U>(a.w), Fu<U>::r2());  // a R: (a R) x / R = a x
+    Fu<U> r = fu_cond_sub_p(fu_add(fu_cond_sub_p(fu_mul(am, fu_unpack<U>(x + i * U::NL))), fu_unpack<U>(c.w)));
+    if (y) {
+        const Fu<U> bm = fu_mul(fu_unpack<U>(b.w), Fu<U>::r2());
+        r = fu_cond_sub_p(fu_add(r, fu_cond_sub_p(fu_mul(bm, fu_unpack<U>(y + i * U::NL)))));
+    }
+    fu_pack<U>(out + i * U::NL, r);
+}
+
 // out[i] = prod_k in_k[i]: math::polynomial_product on polynomials already brought to the product's domain
 // (placeholder/permutation_argument.hpp:148, gates_argument.hpp:117); `ptrs` is a device array of `count` pointers.
 template <class U>
@@ -400,6 +419,22 @@ int zkhip_fr_vec_op_dev(zkhip_ctx *ctx, int curve, int op, const void *d_a, cons
     ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     ZK_FR_DISPATCH(curve, ZK_LAUNCH(ctx, "fr_vec_op", fr_vec_op<U>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (const uint32_t *)d_a,
                                     (const uint32_t *)d_b, count, op, (uint32_t *)d_out));
+    return ZKHIP_OK;
+}
+
+int zkhip_fr_vec_affine_dev(zkhip_ctx *ctx, int curve, const void *d_x, const void *d_y, const uint64_t *a, const uint64_t *b, const uint64_t *c, void *d_out,
+                            size_t count) {
+    if (!ctx || !a || !c || (d_y && !b) || (count && (!d_x || !d_out))) return ZKHIP_ERR_INVALID;
+    if (curve != CURVE_BLS12_381 && curve != CURVE_BN254) return ZKHIP_ERR_INVALID;
+    if (count >= ((size_t)1 << 39)) return ZKHIP_ERR_RANGE;
+    if (count == 0) return ZKHIP_OK;
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    FrWords wa, wb = {}, wc;
+    memcpy(wa.w, a, 32);
+    if (b) memcpy(wb.w, b, 32);
+    memcpy(wc.w, c, 32);
+    ZK_FR_DISPATCH(curve, ZK_LAUNCH(ctx, "fr_vec_affine", fr_vec_affine<U>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (const uint32_t *)d_x,
+                                    (const uint32_t *)d_y, wa, wb, wc, count, (uint32_t *)d_out));
     return ZKHIP_OK;
 }
 

@@ -1,0 +1,180 @@
+//---------------------------------------------------------------------------//
+// zkhip shim: placeholder's lookup argument, prover side, from the sorted vectors on --
+//   placeholder_lookup_argument_prover::prove_eval   zk/snark/systems/plonk/placeholder/lookup_argument.hpp:153-296
+// (the one-part form: lookup_parts(max_quotient_chunks = 0) = { sorted_lookup_columns_number }, :56-62, as the reference's tests configure it).
+//   :175-186  reduce_dfs_polynomial_domain: every (size / n)-th evaluation (:498-517)                 -- reduce_dfs_polynomial_domain below
+//   :208-209  compute_V_L (:375-409): V_L[0] = 1, V_L[k] = V_L[k - 1] g(k - 1) / h(k - 1), k <= usable_rows, zero behind
+//             -- zkhip_lookup_grand_product_dev: a serial loop with one inversion per row in the reference; the permutation argument's scan here
+//   :223-229  compute_gs / compute_hs (:297-373): g = prod_i (1 + beta)(gamma + input_i) prod_i ((1 + beta) gamma + value_i + beta value_i(omega X)),
+//             h = prod_i ((1 + beta) gamma + sorted_i + beta sorted_i(omega X))    -- one zkhip_fr_vec_affine_dev pass per factor + polynomial_product
+//   :236-251  F_dfs[0] = lagrange_0 (1 - V_L),  F_dfs[1] = q_last (V_L V_L - V_L),  F_dfs[2] = ((q_last + q_blind) - 1)(V_L g - V_L(omega X) h)
+//   :278-288  F_dfs[3] = sum_i alpha_i lagrange_0 (sorted_(i + 1) - sorted_i(omega^usable_rows X))
+// What the caller keeps: the constraint system's side -- prepare_lookup_value / prepare_lookup_input (:411-496, a walk over the lookup tables and
+// gates with theta) and sort_polynomials (:565-638, a hash-map walk over the rows) --, the transcript (beta, gamma, the alphas are arguments) and the
+// two append_to_batch calls (LOOKUP_BATCH: sorted, PERMUTATION_BATCH: V_L): device_polynomial_dfs go to the KZG scheme where they lie.
+//---------------------------------------------------------------------------//
+#ifndef ZKHIP_SHIM_PLACEHOLDER_LOOKUP_HPP
+#define ZKHIP_SHIM_PLACEHOLDER_LOOKUP_HPP
+
+#include <array>
+#include <stdexcept>
+#include <vector>
+
+#include "fri.hpp"
+
+namespace nil {
+namespace crypto3 {
+namespace zk {
+namespace hip {
+
+template <typename CurveType>
+struct placeholder_lookup_hip {
+    typedef curve_adapter<CurveType> adapter;
+    typedef typename adapter::scalar_value_type value_type;
+    typedef device_polynomial_dfs<CurveType> dfs_type;
+    typedef typename dfs_type::root_of_unity_type root_of_unity_type;
+
+    struct prover_result_type {
+        std::array<dfs_type, 4> F_dfs;
+        dfs_type V_L;
+    };
+
+    /// lookup_argument.hpp:498-517 -- unlike resize() this does not look at the degree: the result is the vector of values on the smaller domain
+    static dfs_type reduce_dfs_polynomial_domain(const dfs_type &p, std::size_t new_domain_size) {
+        if (new_domain_size > p.size() || p.size() % new_domain_size) throw std::invalid_argument("reduce_dfs_polynomial_domain: not a sub-domain");
+        if (p.size() == new_domain_size) return p;
+        const context &ctx = p.ctx();
+        dfs_type out(ctx, new_domain_size);
+        std::uint64_t unused[4] = {1, 0, 0, 0};
+        check(zkhip_poly_resize_dev(ctx.get(), adapter::id, p.data(), log2_of(p.size()), 1, unused, out.data(), log2_of(new_domain_size), unused), "zkhip_poly_resize_dev",
+              ctx.get());
+        return out;
+    }
+
+    /// compute_V_L (:375-409) over the REDUCED vectors
+    static dfs_type compute_V_L(const context &ctx, const std::vector<dfs_type> &sorted, const std::vector<dfs_type> &reduced_input,
+                                const std::vector<dfs_type> &reduced_value, const value_type &beta, const value_type &gamma, std::size_t usable_rows) {
+        if (sorted.empty()) throw std::invalid_argument("lookup argument: no sorted vectors");
+        const std::size_t n = sorted[0].size();
+        auto ptrs = [n](const std::vector<dfs_type> &v) {
+            std::vector<const void *> p;
+            for (const auto &x : v) {
+                if (x.size() != n) throw std::invalid_argument("lookup argument: a reduced vector's size differs from the basic domain's");
+                p.push_back(x.data());
+            }
+            return p;
+        };
+        const auto pi = ptrs(reduced_input), pv = ptrs(reduced_value), ps = ptrs(sorted);
+        std::uint64_t bl[4], gl[4];
+        adapter::scalar_to_limbs(beta, bl);
+        adapter::scalar_to_limbs(gamma, gl);
+        dfs_type V_L(ctx, n);
+        check(zkhip_lookup_grand_product_dev(ctx.get(), adapter::id, pi.size(), pi.data(), pv.size(), pv.data(), ps.size(), ps.data(), n, usable_rows, bl, gl, V_L.data()),
+              "zkhip_lookup_grand_product_dev", ctx.get());
+        return V_L;
+    }
+
+    /// `lookup_input` / `lookup_value`: what prepare_lookup_input / prepare_lookup_value return (inputs may live on larger domains than the
+    /// n-row basic one), `sorted`: sort_polynomials' result, `alphas`: sorted.size() - 1 challenges in drawing order.
+    static prover_result_type prove_eval(const context &ctx, const std::vector<dfs_type> &lookup_input, const std::vector<dfs_type> &lookup_value,
+                                         const std::vector<dfs_type> &sorted, const dfs_type &q_last, const dfs_type &q_blind, const dfs_type &lagrange_0,
+                                         const value_type &beta, const value_type &gamma, const std::vector<value_type> &alphas, std::size_t usable_rows,
+                                         const root_of_unity_type &root) {
+        if (sorted.empty() || sorted.size() != lookup_input.size() + lookup_value.size())
+            throw std::invalid_argument("lookup argument: one sorted vector per input and value vector");
+        if (alphas.size() + 1 != sorted.size()) throw std::invalid_argument("lookup argument: one alpha per sorted vector but the first");
+        const std::size_t n = sorted[0].size();
+        if (q_last.size() != n || q_blind.size() != n || lagrange_0.size() != n) throw std::invalid_argument("lookup argument: selector sizes differ from the basic domain's");
+        if (usable_rows >= n) throw std::invalid_argument("lookup argument: usable_rows must be below the domain size");
+        const value_type one = value_type::one(), zero = value_type::zero(), part1 = (one + beta) * gamma;
+        /* 3., 5.: reduce, then V_L in one device call */
+        std::vector<dfs_type> reduced_input, reduced_value;
+        for (const auto &p : lookup_input) reduced_input.push_back(reduce_dfs_polynomial_domain(p, n));
+        for (const auto &p : lookup_value) reduced_value.push_back(reduce_dfs_polynomial_domain(p, n));
+        dfs_type V_L = compute_V_L(ctx, sorted, reduced_input, reduced_value, beta, gamma, usable_rows);
+        reduced_input.clear();
+        reduced_value.clear();
+        /* compute_gs / compute_hs */
+        std::vector<dfs_type> g_multipliers, h_multipliers;
+        for (const auto &p : lookup_input) g_multipliers.push_back(affine(p, nullptr, one + beta, zero, part1));
+        for (const auto &p : lookup_value) {
+            dfs_type shifted = polynomial_shift(p, 1, n);
+            g_multipliers.push_back(affine(p, &shifted, one, beta, part1));
+        }
+        for (const auto &p : sorted) {
+            dfs_type shifted = polynomial_shift(p, 1, n);
+            h_multipliers.push_back(affine(p, &shifted, one, beta, part1));
+        }
+        dfs_type g = polynomial_product<CurveType>(std::move(g_multipliers), root), h = polynomial_product<CurveType>(std::move(h_multipliers), root);
+        dfs_type V_L_shifted = polynomial_shift(V_L, 1, n);
+        prover_result_type res {{dfs_type(ctx, 1), dfs_type(ctx, 1), dfs_type(ctx, 1), dfs_type(ctx, 1)}, V_L};
+        /* F_dfs[0] = lagrange_0 (1 - V_L) = lagrange_0 - lagrange_0 V_L */
+        res.F_dfs[0] = minus(lagrange_0, polynomial_product<CurveType>({lagrange_0, V_L}, root), root);
+        /* F_dfs[1] = q_last (V_L V_L - V_L) */
+        res.F_dfs[1] = minus(polynomial_product<CurveType>({q_last, V_L, V_L}, root), polynomial_product<CurveType>({q_last, V_L}, root), root);
+        /* F_dfs[2] = ((q_last + q_blind) - 1) (V_L g - V_L_shifted h) = q T - T */
+        dfs_type T = minus(polynomial_product<CurveType>({V_L, g}, root), polynomial_product<CurveType>({V_L_shifted, h}, root), root);
+        dfs_type q = affine(q_last, &q_blind, one, one, zero);
+        q.set_degree(std::max(q_last.degree(), q_blind.degree()));
+        res.F_dfs[2] = minus(polynomial_product<CurveType>({q, T}, root), T, root);
+        /* F_dfs[3] = sum_i alpha_i lagrange_0 (sorted[i + 1] - sorted[i](omega^usable_rows X)) */
+        if (sorted.size() > 1) {
+            dfs_type sum(ctx, n);
+            for (std::size_t i = 0; i + 1 < sorted.size(); ++i) {
+                dfs_type shifted = polynomial_shift(sorted[i], (int)usable_rows, n);
+                dfs_type part = affine(sorted[i + 1], &shifted, alphas[i], zero - alphas[i], zero);
+                if (i == 0)
+                    sum = part;
+                else
+                    sum += part;
+            }
+            sum.set_degree(n - 1);
+            res.F_dfs[3] = polynomial_product<CurveType>({sum, lagrange_0}, root);
+        } else {
+            res.F_dfs[3] = affine(lagrange_0, nullptr, zero, zero, zero);    // zero_polynomial
+            res.F_dfs[3].set_degree(0);
+        }
+        ctx.sync();
+        return res;
+    }
+
+    /// a x + b y + c over x's domain, into a buffer of its own
+    static dfs_type affine(const dfs_type &x, const dfs_type *y, const value_type &a, const value_type &b, const value_type &c) {
+        if (y && y->size() != x.size()) throw std::invalid_argument("lookup argument: operands must share the domain");
+        dfs_type out(x.ctx(), x.size());
+        out.set_degree(y ? std::max(x.degree(), y->degree()) : x.degree());
+        std::uint64_t al[4], bl[4], cl[4];
+        adapter::scalar_to_limbs(a, al);
+        adapter::scalar_to_limbs(b, bl);
+        adapter::scalar_to_limbs(c, cl);
+        check(zkhip_fr_vec_affine_dev(x.ctx().get(), adapter::id, x.data(), y ? y->data() : nullptr, al, y ? bl : nullptr, cl, out.data(), x.size()),
+              "zkhip_fr_vec_affine_dev", x.ctx().get());
+        return out;
+    }
+
+private:
+    static std::size_t log2_of(std::size_t n) {
+        std::size_t l = 0;
+        while (((std::size_t)1 << l) < n) ++l;
+        if (n == 0 || ((std::size_t)1 << l) != n) throw std::invalid_argument("lookup argument: sizes must be powers of two");
+        return l;
+    }
+    /// a - b on the larger of the two domains, into a buffer of its own (copies of a device_polynomial_dfs share their buffer)
+    static dfs_type minus(dfs_type a, dfs_type b, const root_of_unity_type &root) {
+        const std::size_t size = std::max(a.size(), b.size());
+        a.resize(size, root);
+        b.resize(size, root);
+        dfs_type out(a.ctx(), size);
+        out.set_degree(std::max(a.degree(), b.degree()));
+        check(zkhip_fr_vec_op_dev(a.ctx().get(), adapter::id, 1, a.data(), b.data(), out.data(), size), "zkhip_fr_vec_op_dev", a.ctx().get());
+        a.ctx().sync();    // a and b are released on return
+        return out;
+    }
+};
+
+}    // namespace hip
+}    // namespace zk
+}    // namespace crypto3
+}    // namespace nil
+
+#endif    // ZKHIP_SHIM_PLACEHOLDER_LOOKUP_HPP

@@ -19,7 +19,7 @@ EXPORTS = [
     "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_batch_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_domain_choice", "zkhip_domain_fft_dev", "zkhip_domain_lagrange_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_set_domain", "zkhip_r1cs_domain_size", "zkhip_r1cs_domain_kind", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev", "zkhip_groth16_witness_h_domain_dev", "zkhip_fr_gather_dev", "zkhip_poly_resize_dev", "zkhip_fri_fold_dev", "zkhip_fri_leaves_dev", "zkhip_ec_ntt_dev",
-    "zkhip_fr_vec_op_dev", "zkhip_fr_vec_prod_dev", "zkhip_poly_shift_dev", "zkhip_poly_eval_dev", "zkhip_poly_div_linear_dev", "zkhip_poly_div_vanishing_dev", "zkhip_poly_lincomb_dev", "zkhip_perm_grand_product_dev",
+    "zkhip_fr_vec_op_dev", "zkhip_fr_vec_affine_dev", "zkhip_fr_vec_prod_dev", "zkhip_poly_shift_dev", "zkhip_poly_eval_dev", "zkhip_poly_div_linear_dev", "zkhip_poly_div_vanishing_dev", "zkhip_poly_lincomb_dev", "zkhip_perm_grand_product_dev", "zkhip_lookup_grand_product_dev",
     "zkhip_profile_enable", "zkhip_profile_reset", "zkhip_profile_filter", "zkhip_profile_get", "zkhip_profile_dump",
 ]
 
@@ -390,6 +390,19 @@ class Context:
         self._check(self.lib.zkhip_perm_grand_product_dev(self.h, curve, ctypes.c_size_t(k), arr(d_cols), arr(d_sid), arr(d_ssigma), ctypes.c_size_t(n),
                                                           _p(_u64(beta).reshape(4)), _p(_u64(gamma).reshape(4)), ctypes.c_void_p(d_g or None),
                                                           ctypes.c_void_p(d_h or None), ctypes.c_void_p(d_vp)), "perm_grand_product_dev")
+
+    def fr_vec_affine_dev(self, curve: int, d_x: int, d_y: int, a, b, c, d_out: int, count: int):
+        """d_out[i] = a d_x[i] + b d_y[i] + c (d_y = 0: no second operand)"""
+        self._check(self.lib.zkhip_fr_vec_affine_dev(self.h, curve, ctypes.c_void_p(d_x), ctypes.c_void_p(d_y or None), _p(_u64(a).reshape(4)),
+                                                     _p(_u64(b).reshape(4)) if d_y else None, _p(_u64(c).reshape(4)), ctypes.c_void_p(d_out), ctypes.c_size_t(count)),
+                    "fr_vec_affine_dev")
+
+    def lookup_grand_product_dev(self, curve: int, d_input, d_value, d_sorted, n: int, usable_rows: int, beta, gamma, d_vl: int):
+        """placeholder's lookup grand product V_L (n at d_vl) from the reduced input / value / sorted vectors"""
+        arr = lambda ps: (ctypes.c_void_p * max(len(ps), 1))(*ps)
+        self._check(self.lib.zkhip_lookup_grand_product_dev(self.h, curve, ctypes.c_size_t(len(d_input)), arr(d_input), ctypes.c_size_t(len(d_value)), arr(d_value),
+                                                            ctypes.c_size_t(len(d_sorted)), arr(d_sorted), ctypes.c_size_t(n), ctypes.c_size_t(usable_rows),
+                                                            _p(_u64(beta).reshape(4)), _p(_u64(gamma).reshape(4)), ctypes.c_void_p(d_vl)), "lookup_grand_product_dev")
 
     def poly_lincomb_dev(self, curve: int, d_polys, lens, coeffs: np.ndarray, taps: int, d_acc: int, acc_len: int, accumulate: bool):
         count = len(d_polys)

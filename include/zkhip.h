@@ -273,6 +273,11 @@ int zkhip_ec_ntt_dev(zkhip_ctx *ctx, int curve, int group, void *d_jacobian, siz
  * polynomial_dfs::operator+= / -= / *= on equal domains (ph/gates_argument.hpp:119-121,
  * ph/permutation_argument.hpp:148-167): d_out[i] = d_a[i] op d_b[i], op 0 add, 1 sub, 2 mul; in place allowed. */
 int zkhip_fr_vec_op_dev(zkhip_ctx *ctx, int curve, int op, const void *d_a, const void *d_b, void *d_out, size_t count);
+/* d_out[i] = a d_x[i] + b d_y[i] + c (d_y and b nullable together; a, b, c canonical Fr on the host; in place allowed): the linear
+ * factors the arguments multiply up -- (1 + beta)(gamma + input), (1 + beta) gamma + value + beta value(omega X)
+ * (ph/lookup_argument.hpp:313, 329, 361), mask = 1 - q_last - q_blind (:161-162) -- in one pass each. */
+int zkhip_fr_vec_affine_dev(zkhip_ctx *ctx, int curve, const void *d_x, const void *d_y, const uint64_t *a, const uint64_t *b, const uint64_t *c, void *d_out,
+                            size_t count);
 /* polynomial::evaluate for `batch` polynomials (n coefficients each, `stride` elements apart) at `npoints` points
  * given on the host (eval_polys, batched_commitment.hpp:168-183): out[b * npoints + p] = poly_b(points[p]), host. */
 int zkhip_poly_eval_dev(zkhip_ctx *ctx, int curve, const void *d_polys, size_t n, size_t stride, size_t batch, const uint64_t *points,
@@ -295,6 +300,14 @@ int zkhip_poly_div_vanishing_dev(zkhip_ctx *ctx, int curve, const void *d_f, siz
  * in a serial loop; here rows are taken in chunks that share an inversion and the prefix product is a three-level scan. */
 int zkhip_perm_grand_product_dev(zkhip_ctx *ctx, int curve, size_t k, const void *const *d_cols, const void *const *d_sid, const void *const *d_ssigma,
                                  size_t n, const uint64_t *beta, const uint64_t *gamma, void *d_g, void *d_h, void *d_vp);
+/* V_L of placeholder's lookup argument (ph/lookup_argument.hpp:375-409, `compute_V_L`), the same scan over other rows:
+ *   V_L[0] = 1,  V_L[k] = V_L[k - 1] g(k - 1) / h(k - 1) for 1 <= k <= usable_rows,  V_L[k] = 0 behind,
+ *   g(j) = (1 + beta)^k_in prod_i (gamma + input_i[j]) prod_i ((1 + beta) gamma + value_i[j] + beta value_i[j + 1]),
+ *   h(j) = prod_i ((1 + beta) gamma + sorted_i[j] + beta sorted_i[j + 1]).
+ * d_input / d_value / d_sorted: HOST arrays of device pointers to n canonical Fr each (the REDUCED vectors: on the basic domain);
+ * usable_rows < n (ZKHIP_ERR_RANGE otherwise); d_vl: n outputs. */
+int zkhip_lookup_grand_product_dev(zkhip_ctx *ctx, int curve, size_t k_in, const void *const *d_input, size_t k_val, const void *const *d_value, size_t k_sorted,
+                                   const void *const *d_sorted, size_t n, size_t usable_rows, const uint64_t *beta, const uint64_t *gamma, void *d_vl);
 /* d_acc[j] (+)= sum_i sum_{t < taps} coeffs[i * taps + t] * poly_i[j - t] for j < acc_len (poly_i is zero outside
  * [0, lens[i])): the accumulation `f += theta_i * (f_i - U) * diffpoly` (kzg_v2.hpp:258-263) for every committed
  * polynomial in ONE pass (coeffs[i] = theta_i * diffpoly_i, a few taps), and `L += ...` (:281-288) with taps = 1.

@@ -1190,6 +1190,99 @@ def permutation_argument(cols, S_id, S_sigma, q_last, q_blind, lagrange_0, beta:
     return V, [poly_trim(F0), poly_trim(F1), poly_trim(F2)]
 
 
+def reduce_dfs_polynomial_domain(evals: Sequence[int], new_size: int) -> List[int]:
+    """lookup_argument.hpp:498-517: every (size / new_size)-th evaluation"""
+    assert len(evals) % new_size == 0
+    step = len(evals) // new_size
+    return [evals[i * step] for i in range(new_size)]
+
+
+def lookup_sort_polynomials(reduced_input, reduced_value, domain_size: int, usable_rows: int) -> List[List[int]]:
+    """lookup_argument.hpp:565-638: the values of the table columns in their order, each repeated as often as it is looked up
+    (+ once per table occurrence), dealt over |input| + |value| vectors of usable_rows entries; entry usable_rows of every vector
+    but the last repeats the next vector's head."""
+    count = {}
+    for v in reduced_value:
+        for j in range(usable_rows):
+            count[v[j]] = count.get(v[j], 0) + 1
+    for v in reduced_input:
+        for j in range(usable_rows):
+            assert v[j] in count, "a looked-up value that is in no table"
+            count[v[j]] += 1
+    total = len(reduced_input) + len(reduced_value)
+    flat = []
+    prev = 0
+    for v in reduced_value:
+        for j in range(usable_rows):
+            if v[j] != prev:
+                flat.extend([prev] if prev == 0 else [prev] * count[prev])
+                prev = v[j]
+    if prev != 0:
+        flat.extend([prev] * count[prev])
+    assert len(flat) <= total * usable_rows
+    out = [[0] * domain_size for _ in range(total)]
+    for idx, val in enumerate(flat):
+        out[idx // usable_rows][idx % usable_rows] = val
+    for i in range(total - 1):
+        out[i][usable_rows] = out[i + 1][0]
+    return out
+
+
+def lookup_grand_product(reduced_input, reduced_value, sorted_, beta: int, gamma: int, usable_rows: int, r: int) -> List[int]:
+    """compute_V_L, lookup_argument.hpp:375-409 (the row-by-row recurrence, one inversion per row)"""
+    n = len(sorted_[0])
+    V = [0] * n
+    V[0] = 1
+    part1 = (1 + beta) * gamma % r
+    for k in range(1, usable_rows + 1):
+        g = pow(1 + beta, len(reduced_input), r)
+        for v in reduced_input:
+            g = g * (gamma + v[k - 1]) % r
+        for v in reduced_value:
+            g = g * (part1 + v[k - 1] + beta * v[k]) % r
+        h = 1
+        for v in sorted_:
+            h = h * (part1 + v[k - 1] + beta * v[k]) % r
+        V[k] = V[k - 1] * g % r * pow(h, -1, r) % r
+    return V
+
+
+def lookup_argument(lookup_input, lookup_value, sorted_, q_last, q_blind, lagrange_0, beta: int, gamma: int, alphas: Sequence[int], usable_rows: int,
+                    root_of_unity, r: int):
+    """placeholder_lookup_argument_prover::prove_eval from `sorted` on (lookup_argument.hpp:198-296), one part (max_quotient_chunks = 0):
+    -> (V_L evaluations, [F0, F1, F2, F3] as trimmed coefficient lists):
+         F0 = L_0 (1 - V_L),  F1 = q_last (V_L^2 - V_L),
+         F2 = ((q_last + q_blind) - 1) (V_L g - V_L(omega X) h),   g = prod_i (1 + beta)(gamma + input_i) prod_i ((1 + beta) gamma + value_i + beta value_i(omega X)),
+                                                                   h = prod_i ((1 + beta) gamma + sorted_i + beta sorted_i(omega X)),
+         F3 = sum_{i >= 1} alpha_{i - 1} L_0 (sorted_i - sorted_{i-1}... shifted by usable_rows): alpha L_0 (sorted_i - sorted_{i - 1}(omega^usable_rows X))
+    lookup_input may live on larger domains than n (expressions of degree > 1); everything is dense coefficient arithmetic here."""
+    n = len(sorted_[0])
+    co = lambda e: poly_trim(intt(list(e), root_of_unity(len(e).bit_length() - 1), r))
+    red_in = [reduce_dfs_polynomial_domain(v, n) for v in lookup_input]
+    red_val = [reduce_dfs_polynomial_domain(v, n) for v in lookup_value]
+    V = lookup_grand_product(red_in, red_val, sorted_, beta, gamma, usable_rows, r)
+    part1 = (1 + beta) * gamma % r
+    G, H = [1], [1]
+    for v in lookup_input:
+        G = poly_mul(G, poly_scale(poly_add([gamma], co(v), r), (1 + beta) % r, r), r)
+    for v in lookup_value:
+        G = poly_mul(G, poly_add(poly_add([part1], co(v), r), poly_scale(co(polynomial_shift(v, 1, n)), beta, r), r), r)
+    for v in sorted_:
+        H = poly_mul(H, poly_add(poly_add([part1], co(v), r), poly_scale(co(polynomial_shift(v, 1, n)), beta, r), r), r)
+    VL, VLs = co(V), co(polynomial_shift(V, 1))
+    one = [1]
+    L0 = co(lagrange_0)
+    F0 = poly_mul(L0, poly_sub(one, VL, r), r)
+    F1 = poly_mul(co(q_last), poly_sub(poly_mul(VL, VL, r), VL, r), r)
+    F2 = poly_mul(poly_sub(poly_add(co(q_last), co(q_blind), r), one, r), poly_sub(poly_mul(VL, G, r), poly_mul(VLs, H, r), r), r)
+    F3 = []
+    # F_dfs_3_parts = sorted[1:], part i (0-based) subtracts sorted[i] shifted by usable_rows   (lookup_argument.hpp:281-288)
+    for i in range(len(sorted_) - 1):
+        d = poly_sub(co(sorted_[i + 1]), co(polynomial_shift(sorted_[i], usable_rows, n)), r)
+        F3 = poly_add(F3, poly_scale(poly_mul(d, L0, r), alphas[i], r), r)
+    return V, [poly_trim(F0), poly_trim(F1), poly_trim(F2), poly_trim(F3)]
+
+
 def lpc_proof_eval(r: int, batches: dict, points: dict, fixed: Sequence[int], log_domain: int, step_list: Sequence[int], root_of_unity,
                    challenges: Sequence[int], tree_root):
     """batches[k] = list of DFS polynomials (lists of ints); points[k][i] = evaluation points of polynomial i of batch k;

@@ -18,6 +18,7 @@
 #include <nil/crypto3/zk/hip/lpc.hpp>
 #include <nil/crypto3/zk/hip/marshalling.hpp>
 #include <array>
+#include <nil/crypto3/zk/hip/placeholder_lookup.hpp>
 #include <nil/crypto3/zk/hip/placeholder_permutation.hpp>
 #include <nil/crypto3/zk/hip/placeholder_quotient.hpp>
 #include <nil/crypto3/zk/hip/powers_of_tau.hpp>
@@ -1418,6 +1419,51 @@ int placeholder_permutation_t(const uint64_t *evals, size_t k, size_t log_n, con
     return 0;
 }
 
+// ---- placeholder's lookup argument on the device (placeholder_lookup.hpp; lookup_argument.hpp:153-296) ----
+/// evals: k_in inputs (input i on 2^in_logs[i] points) | k_val values | k_in + k_val sorted | q_last | q_blind | lagrange_0 (2^log_n each).
+/// out_vl: V_L (n); out_F: the four F polynomials' COEFFICIENTS, each in a slot of 16 n elements, with their domain sizes in out_sizes.
+template <typename Curve>
+int placeholder_lookup_t(const uint64_t *evals, size_t k_in, const uint64_t *in_logs, size_t k_val, size_t log_n, size_t usable_rows, const uint64_t *roots,
+                         const uint64_t *beta, const uint64_t *gamma, const uint64_t *alphas, uint64_t *out_vl, uint64_t *out_F, uint64_t *out_sizes) {
+    typedef curve_adapter<Curve> A;
+    typedef device_polynomial_dfs<Curve> dfs;
+    const size_t n = (size_t)1 << log_n, total = k_in + k_val;
+    context ctx(0);
+    auto root = [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); };
+    const uint64_t *at = evals;
+    auto take = [&](size_t size) {
+        polynomial_dfs<Curve> h;
+        for (size_t i = 0; i < size; ++i) h.values.push_back(A::scalar_from_limbs(at + 4 * i));
+        at += 4 * size;
+        return dfs(ctx, h, size - 1);
+    };
+    std::vector<dfs> input, value, sorted;
+    for (size_t i = 0; i < k_in; ++i) input.push_back(take((size_t)1 << in_logs[i]));
+    for (size_t i = 0; i < k_val; ++i) value.push_back(take(n));
+    for (size_t i = 0; i < total; ++i) sorted.push_back(take(n));
+    const uint64_t *q_last_words = at;
+    dfs q_last = take(n), q_blind = take(n), lagrange_0 = take(n);
+    std::vector<typename A::scalar_value_type> al;
+    for (size_t i = 0; i + 1 < total; ++i) al.push_back(A::scalar_from_limbs(alphas + 4 * i));
+    auto res = placeholder_lookup_hip<Curve>::prove_eval(ctx, input, value, sorted, q_last, q_blind, lagrange_0, A::scalar_from_limbs(beta), A::scalar_from_limbs(gamma), al,
+                                                         usable_rows, root);
+    ctx.d2h(out_vl, res.V_L.data(), n * 32);
+    for (int f = 0; f < 4; ++f) {
+        const size_t sz = res.F_dfs[f].size();
+        if (sz > 16 * n) return -61;
+        out_sizes[f] = sz;
+        auto c = res.F_dfs[f].coefficients(root);
+        ctx.d2h(out_F + 4 * (size_t)f * 16 * n, c.get(), sz * 32);
+    }
+    /* the inputs must be untouched (the argument reads shared buffers) */
+    std::vector<uint64_t> back(4 * n);
+    ctx.d2h(back.data(), q_last.data(), n * 32);
+    if (std::memcmp(back.data(), q_last_words, n * 32) != 0) return -62;
+    ctx.d2h(back.data(), sorted[0].data(), n * 32);
+    if (std::memcmp(back.data(), q_last_words - 4 * total * n, n * 32) != 0) return -63;
+    return 0;
+}
+
 template <typename Curve>
 r1cs_constraint_system<Curve> cs_from_csr(size_t M, size_t n, size_t N, const uint32_t *const rowptr[3], const uint32_t *const col[3],
                                           const uint64_t *const coeff[3]) {
@@ -1715,6 +1761,17 @@ int shim_placeholder_permutation(int curve, const uint64_t *evals, size_t k, siz
         return placeholder_permutation_t<alt_bn128_254>(evals, k, log_n, roots, beta, gamma, out_vp, out_F, out_sizes);
     } catch (const std::exception &e) {
         fprintf(stderr, "shim_placeholder_permutation: %s\n", e.what());
+        return -1;
+    }
+}
+int shim_placeholder_lookup(int curve, const uint64_t *evals, size_t k_in, const uint64_t *in_logs, size_t k_val, size_t log_n, size_t usable_rows, const uint64_t *roots,
+                            const uint64_t *beta, const uint64_t *gamma, const uint64_t *alphas, uint64_t *out_vl, uint64_t *out_F, uint64_t *out_sizes) {
+    try {
+        if (curve == ZKHIP_BLS12_381)
+            return placeholder_lookup_t<bls12_381>(evals, k_in, in_logs, k_val, log_n, usable_rows, roots, beta, gamma, alphas, out_vl, out_F, out_sizes);
+        return placeholder_lookup_t<alt_bn128_254>(evals, k_in, in_logs, k_val, log_n, usable_rows, roots, beta, gamma, alphas, out_vl, out_F, out_sizes);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "shim_placeholder_lookup: %s\n", e.what());
         return -1;
     }
 }

@@ -11,7 +11,7 @@ import pytest
 
 import cport as cp
 import pyoracle as po
-from util import CURVES, FQ_LIMBS, fr_arr, fr_ints, limbs, pt_limbs
+from util import CURVES, FQ_LIMBS, fr_arr, fr_ints, limbs, lookup_instance, pt_limbs
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -475,6 +475,43 @@ def test_placeholder_permutation_argument_shim(shim, curve, log_n, k):
     assert rc == 0
     assert fr_ints(out_vp) == V
     for f in range(3):
+        got = po.poly_trim(fr_ints(out_F[f][: int(sizes[f])]))
+        assert got == F[f], f
+
+
+@pytest.mark.parametrize("curve,log_n,k_in,k_val,big", [(0, 6, 1, 1, ()), (1, 6, 2, 1, (1,)), (0, 7, 3, 2, (0,)), (0, 5, 1, 2, ())])
+def test_placeholder_lookup_argument_shim(shim, curve, log_n, k_in, k_val, big):
+    """placeholder's lookup argument, prover side, from the sorted vectors on (hip/placeholder_lookup.hpp; lookup_argument.hpp:153-296, one part):
+    V_L -- a serial loop with one inversion per row in the reference (compute_V_L, :375-409); the permutation argument's scan on the device --
+    EXACTLY the oracle's row-by-row recurrence (zero behind usable_rows), and the four constraint polynomials equal to the oracle's dense
+    coefficient-form arithmetic.  A genuine instance (inputs drawn from the tables, `sorted` by the oracle's restatement of
+    sort_polynomials, :565-638): the product closes, V_L[usable_rows] = 1 -- the reference's own BOOST_CHECK (:217)."""
+    C = CURVES[curve]
+    r = C.r
+    n = 1 << log_n
+    rng = po.SplitMix64(6400 + 10 * curve + log_n + k_in + 3 * k_val)
+    inputs, values, usable = lookup_instance(C, rng, log_n, k_in, k_val, big)
+    red_in = [po.reduce_dfs_polynomial_domain(f, n) for f in inputs]
+    sorted_ = po.lookup_sort_polynomials(red_in, values, n, usable)
+    q_last = [1 if j == usable else 0 for j in range(n)]
+    q_blind = [1 if j > usable else 0 for j in range(n)]
+    L0 = [1] + [0] * (n - 1)
+    beta, gamma = rng.next_mod(r), rng.next_mod(r)
+    alphas = [rng.next_mod(r) for _ in range(k_in + k_val - 1)]
+    V, F = po.lookup_argument(inputs, values, sorted_, q_last, q_blind, L0, beta, gamma, alphas, usable, C.root_of_unity, r)
+    assert V[usable] == 1 and all(v == 0 for v in V[usable + 1:])
+    evals = fr_arr([x for v in inputs + values + sorted_ + [q_last, q_blind, L0] for x in v])
+    in_logs = np.array([len(f).bit_length() - 1 for f in inputs], dtype=np.uint64)
+    roots = np.stack([limbs(C.root_of_unity(l), 4) for l in range(log_n + 5)])
+    out_vl = np.zeros((n, 4), dtype=np.uint64)
+    out_F = np.zeros((4, 16 * n, 4), dtype=np.uint64)
+    sizes = np.zeros(4, dtype=np.uint64)
+    al = np.stack([limbs(a, 4) for a in alphas] + [limbs(0, 4)])
+    rc = shim.shim_placeholder_lookup(curve, P(evals), ctypes.c_size_t(k_in), P(in_logs), ctypes.c_size_t(k_val), ctypes.c_size_t(log_n), ctypes.c_size_t(usable),
+                                      P(roots), P(limbs(beta, 4)), P(limbs(gamma, 4)), P(al), P(out_vl), P(out_F), P(sizes))
+    assert rc == 0
+    assert fr_ints(out_vl) == V
+    for f in range(4):
         got = po.poly_trim(fr_ints(out_F[f][: int(sizes[f])]))
         assert got == F[f], f
 

@@ -377,3 +377,43 @@ def test_placeholder_quotient_chain_definitions():
     bad[4] = (bad[4] + 1) % r    # index 4 of the 4x extended domain IS a row of the original domain
     with pytest.raises(AssertionError):
         po.quotient_polynomial([bad, F1], alphas, n, root, r)
+
+
+@pytest.mark.parametrize("curve,log_n,k_in,k_val,big", [(0, 5, 1, 1, ()), (1, 5, 2, 1, (1,)), (0, 6, 3, 2, (0,))])
+def test_placeholder_lookup_argument_definitions(curve, log_n, k_in, k_val, big):
+    """The oracle's restatement of placeholder's lookup argument (lookup_argument.hpp:153-296, 375-409, 565-638) against what the
+    argument is FOR: on a genuine instance (every input drawn from the tables) sort_polynomials' result makes the grand product close,
+    V_L[usable_rows] = 1 -- the reference's own BOOST_CHECK (:217) --, and every constraint polynomial F_0 .. F_3 vanishes on the rows
+    (divisible by X^n - 1), by big-integer polynomial arithmetic.  An input that is in no table breaks both."""
+    from util import lookup_instance
+    C = CURVES[curve]
+    r = C.r
+    n = 1 << log_n
+    rng = po.SplitMix64(7700 + 10 * curve + log_n + k_in)
+    inputs, values, usable = lookup_instance(C, rng, log_n, k_in, k_val, big)
+    red_in = [po.reduce_dfs_polynomial_domain(f, n) for f in inputs]
+    assert all(len(v) == n for v in red_in)
+    sorted_ = po.lookup_sort_polynomials(red_in, values, n, usable)
+    assert len(sorted_) == k_in + k_val and all(sorted_[i][usable] == sorted_[i + 1][0] for i in range(len(sorted_) - 1))
+    q_last = [1 if j == usable else 0 for j in range(n)]
+    q_blind = [1 if j > usable else 0 for j in range(n)]
+    L0 = [1] + [0] * (n - 1)
+    beta, gamma = rng.next_mod(r), rng.next_mod(r)
+    alphas = [rng.next_mod(r) for _ in range(k_in + k_val - 1)]
+    V, F = po.lookup_argument(inputs, values, sorted_, q_last, q_blind, L0, beta, gamma, alphas, usable, C.root_of_unity, r)
+    assert V[0] == 1 and V[usable] == 1 and all(v == 0 for v in V[usable + 1:])
+
+    def on_rows(f):  # f mod (X^n - 1)
+        out = [0] * n
+        for i, c in enumerate(f):
+            out[i % n] = (out[i % n] + c) % r
+        return out
+    for f in F:
+        assert not any(on_rows(f))
+    assert any(F[2])                                                # not the zero polynomial: the blinding rows carry junk
+    # a looked-up value that is in the table but one time too few in `sorted`: the product no longer closes
+    bad = [list(v) for v in sorted_]
+    j = next(j for j in range(1, usable - 1) if bad[0][j] != bad[0][j + 1] and bad[0][j] != 0)
+    bad[0][j] = bad[0][j + 1]
+    Vb, Fb = po.lookup_argument(inputs, values, bad, q_last, q_blind, L0, beta, gamma, alphas, usable, C.root_of_unity, r)
+    assert Vb[usable] != 1 and any(on_rows(Fb[1]))

@@ -69,3 +69,32 @@ def qap_domains(zkmod, curve, min_size, two_adicity=None):
     dom = po.make_evaluation_domain(C, min_size, two_adicity=two_adicity)
     zd = zkmod.zkhip.Domain.make(dom.kind, dom.m, limbs(dom.omega, 4), limbs(dom.shift, 4))
     return dom, zd
+
+
+def lookup_instance(C, rng, log_n, k_in, k_val, big_inputs=()):
+    """A genuine lookup instance in the shape prepare_lookup_value / prepare_lookup_input leave behind: every (theta-compressed) table
+    column is zero at row 0, holds distinct non-zero values (one of them repeated in adjacent rows) in the rows after it, zero behind and
+    zero from usable_rows on (the mask); every input takes table values (or zero) in the usable rows and anything behind them.  Inputs
+    listed in big_inputs live on the 2n-point domain (an expression of degree > 1): f + c (X^n - 1), which reduces to f."""
+    r = C.r
+    n = 1 << log_n
+    usable = n - 3
+    values, pool = [], [0]
+    for i in range(k_val):
+        T = usable // 2 + i
+        col = [0] * n
+        prev = 0
+        for j in range(1, T + 1):
+            prev = prev if (j == 3 and prev) else rng.next_mod(r - 1) + 1
+            col[j] = prev
+            pool.append(prev)
+        values.append(col)
+    inputs = []
+    for i in range(k_in):
+        f = [pool[rng.next_mod(len(pool))] for _ in range(usable)] + [rng.next_mod(r) for _ in range(n - usable)]
+        if i in big_inputs:
+            big = po.dfs_resize(f, 2 * n, C.root_of_unity, r)
+            c = rng.next_mod(r)
+            f = [(v - 2 * c * (j & 1)) % r for j, v in enumerate(big)]
+        inputs.append(f)
+    return inputs, values, usable
