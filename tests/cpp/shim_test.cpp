@@ -1464,6 +1464,82 @@ int placeholder_lookup_t(const uint64_t *evals, size_t k_in, const uint64_t *in_
     return 0;
 }
 
+// ---- the pieces composed as placeholder_prover::process strings them (prover.hpp:170-213 permutation + lookup arguments, :215-218 gate
+// argument, :262-277 quotient, :220-259 split, :314-317 T_commit), every polynomial resident from the arguments to the commitments ----
+/// evals: k columns | k S_id | k S_sigma | lookup input | lookup value | 2 sorted | gate q, w0, w1, w2 | q_last | q_blind | lagrange_0 (2^log_n each).
+/// challenges: beta_p, gamma_p, beta_l, gamma_l, alpha_l (F_3 of the lookup), 8 alphas of the quotient.
+/// out_T: 3 n coefficients; out_commits: V_P, V_L | sorted_0, sorted_1 | 4 quotient parts (affine limbs).
+template <typename Curve>
+int placeholder_round_t(const uint64_t *srs, size_t n_srs, const uint64_t *evals, size_t k, size_t log_n, size_t usable_rows, const uint64_t *roots,
+                        const uint64_t *challenges, uint64_t *out_T, uint64_t *out_commits) {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::g1_value_type G1;
+    typedef typename A::scalar_value_type Fr;
+    typedef device_polynomial_dfs<Curve> dfs;
+    typedef placeholder_quotient_hip<Curve> Q;
+    const size_t n = (size_t)1 << log_n, L1 = 2 * A::g1_coord_limbs;
+    context ctx(0);
+    auto root = [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); };
+    auto ch = [challenges](size_t i) { return A::scalar_from_limbs(challenges + 4 * i); };
+    const uint64_t *at = evals;
+    auto take = [&]() {
+        polynomial_dfs<Curve> h;
+        for (size_t i = 0; i < n; ++i) h.values.push_back(A::scalar_from_limbs(at + 4 * i));
+        at += 4 * n;
+        return dfs(ctx, h, n - 1);
+    };
+    std::vector<dfs> cols, sid, ssig, l_in, l_val, sorted, gate;
+    for (size_t i = 0; i < k; ++i) cols.push_back(take());
+    for (size_t i = 0; i < k; ++i) sid.push_back(take());
+    for (size_t i = 0; i < k; ++i) ssig.push_back(take());
+    l_in.push_back(take());
+    l_val.push_back(take());
+    for (int i = 0; i < 2; ++i) sorted.push_back(take());
+    for (int i = 0; i < 4; ++i) gate.push_back(take());
+    dfs q_last = take(), q_blind = take(), lagrange_0 = take();
+    /* the commitment scheme: SRS resident, batches fed with device polynomials */
+    std::vector<G1> ck;
+    for (size_t i = 0; i < n_srs; ++i) ck.push_back(G1::from_affine(srs + i * L1));
+    kzg_params_hip<Curve> params(ctx, ck.begin(), ck.end());
+    kzg_commitment_scheme_v2_hip<Curve, scripted_any_transcript<Curve>> scheme(params, root);
+    constexpr std::size_t PERMUTATION_BATCH = 2, QUOTIENT_BATCH = 3, LOOKUP_BATCH = 4;
+    /* 4. permutation argument (prover.hpp:170-190) */
+    auto perm = placeholder_permutation_hip<Curve>::prove_eval(ctx, cols, sid, ssig, q_last, q_blind, lagrange_0, ch(0), ch(1), root);
+    scheme.append_to_batch(PERMUTATION_BATCH, perm.permutation_polynomial_dfs);
+    /* 5. lookup argument (:192-205): sorted -> LOOKUP_BATCH, V_L -> PERMUTATION_BATCH */
+    scheme.append_to_batch(LOOKUP_BATCH, sorted);
+    auto lookup_commit = scheme.commit(LOOKUP_BATCH);
+    auto look = placeholder_lookup_hip<Curve>::prove_eval(ctx, l_in, l_val, sorted, q_last, q_blind, lagrange_0, ch(2), ch(3), {ch(4)}, usable_rows, root);
+    scheme.append_to_batch(PERMUTATION_BATCH, look.V_L);
+    auto perm_commit = scheme.commit(PERMUTATION_BATCH);
+    /* 6. gate argument: q (w0 w1 - w2), masked by 1 - q_last - q_blind (gates_argument.hpp:203-216) */
+    dfs mask = placeholder_lookup_hip<Curve>::affine(q_last, &q_blind, Fr::zero() - Fr::one(), Fr::zero() - Fr::one(), Fr::one());
+    gate_product_hip<Curve> g1, g2;
+    g1.factors = {&gate[0], &gate[1], &gate[2]};
+    g1.rotations = {0, 0, 0};
+    g1.coefficient = Fr::one();
+    g2.factors = {&gate[0], &gate[3]};
+    g2.rotations = {0, 0};
+    g2.coefficient = Fr::zero() - Fr::one();
+    dfs G = Q::gate_argument(ctx, {g1, g2}, mask, 4 * n, root);
+    /* 7. quotient over all eight parts, split, T_commit */
+    std::vector<dfs> F = {perm.F_dfs[0], perm.F_dfs[1], perm.F_dfs[2], look.F_dfs[0], look.F_dfs[1], look.F_dfs[2], look.F_dfs[3], G};
+    std::vector<Fr> alphas;
+    for (size_t i = 0; i < F.size(); ++i) alphas.push_back(ch(5 + i));
+    auto T = Q::quotient_polynomial(ctx, F, alphas, n, root);
+    if (T.size != 3 * n) return -71;
+    ctx.d2h(out_T, T.data.get(), T.size * 32);
+    auto parts = Q::quotient_polynomial_split_dfs(ctx, T, n, 4, n, root);
+    scheme.append_to_batch(QUOTIENT_BATCH, parts);
+    auto t_commit = scheme.commit(QUOTIENT_BATCH);
+    if (perm_commit.size() != 2 || lookup_commit.size() != 2 || t_commit.size() != 4) return -72;
+    size_t o = 0;
+    for (auto &c : perm_commit) c.to_affine(out_commits + (o++) * L1);
+    for (auto &c : lookup_commit) c.to_affine(out_commits + (o++) * L1);
+    for (auto &c : t_commit) c.to_affine(out_commits + (o++) * L1);
+    return 0;
+}
+
 template <typename Curve>
 r1cs_constraint_system<Curve> cs_from_csr(size_t M, size_t n, size_t N, const uint32_t *const rowptr[3], const uint32_t *const col[3],
                                           const uint64_t *const coeff[3]) {
@@ -1761,6 +1837,16 @@ int shim_placeholder_permutation(int curve, const uint64_t *evals, size_t k, siz
         return placeholder_permutation_t<alt_bn128_254>(evals, k, log_n, roots, beta, gamma, out_vp, out_F, out_sizes);
     } catch (const std::exception &e) {
         fprintf(stderr, "shim_placeholder_permutation: %s\n", e.what());
+        return -1;
+    }
+}
+int shim_placeholder_round(int curve, const uint64_t *srs, size_t n_srs, const uint64_t *evals, size_t k, size_t log_n, size_t usable_rows, const uint64_t *roots,
+                           const uint64_t *challenges, uint64_t *out_T, uint64_t *out_commits) {
+    try {
+        if (curve == ZKHIP_BLS12_381) return placeholder_round_t<bls12_381>(srs, n_srs, evals, k, log_n, usable_rows, roots, challenges, out_T, out_commits);
+        return placeholder_round_t<alt_bn128_254>(srs, n_srs, evals, k, log_n, usable_rows, roots, challenges, out_T, out_commits);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "shim_placeholder_round: %s\n", e.what());
         return -1;
     }
 }

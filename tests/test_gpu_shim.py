@@ -11,7 +11,7 @@ import pytest
 
 import cport as cp
 import pyoracle as po
-from util import CURVES, FQ_LIMBS, fr_arr, fr_ints, limbs, lookup_instance, pt_limbs
+from util import CURVES, FQ_LIMBS, fr_arr, fr_ints, limbs, lookup_instance, permutation_instance, pt_limbs
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -514,6 +514,61 @@ def test_placeholder_lookup_argument_shim(shim, curve, log_n, k_in, k_val, big):
     for f in range(4):
         got = po.poly_trim(fr_ints(out_F[f][: int(sizes[f])]))
         assert got == F[f], f
+
+
+@pytest.mark.parametrize("curve,log_n", [(0, 6), (1, 5)])
+def test_placeholder_round_composed_shim(shim, curve, log_n):
+    """The pieces composed as placeholder_prover::process strings them (prover.hpp:170-218, 262-277, 220-259, 314-317): permutation
+    argument, lookup argument and a gate argument over GENUINE instances (copy constraints closed inside the usable rows, inputs drawn
+    from the table, w2 = w0 w1 where the selector is on), their eight constraint polynomials -- living on different domains -- consolidated
+    with eight alphas, divided by X^n - 1 (exactly: every part vanishes on the rows), split and committed; V_P, V_L, the sorted vectors
+    and the quotient parts go to the KZG scheme as device polynomials.  Against the oracle: T coefficient by coefficient, every
+    commitment = polynomial(alpha) G."""
+    C = CURVES[curve]
+    r, alpha, k = C.r, 7, 2
+    n = 1 << log_n
+    usable = n - 3
+    root = C.root_of_unity
+    rng = po.SplitMix64(8800 + curve + log_n)
+    cols, S_id, S_sigma = permutation_instance(C, rng, log_n, k, usable)
+    inputs, values, _ = lookup_instance(C, rng, log_n, 1, 1)
+    sorted_ = po.lookup_sort_polynomials(inputs, values, n, usable)
+    q = [1 if (j % 3 == 0 and j < usable) else 0 for j in range(n)]
+    w0, w1 = ([rng.next_mod(r) for _ in range(n)] for _ in range(2))
+    w2 = [w0[j] * w1[j] % r if q[j] else rng.next_mod(r) for j in range(n)]
+    q_last = [1 if j == usable else 0 for j in range(n)]
+    q_blind = [1 if j > usable else 0 for j in range(n)]
+    L0 = [1] + [0] * (n - 1)
+    ch = [rng.next_mod(r) for _ in range(13)]
+    bp, gp, bl, gl, al = ch[:5]
+    alphas = ch[5:]
+    VP, Fp = po.permutation_argument(cols, S_id, S_sigma, q_last, q_blind, L0, bp, gp, root, r)
+    VL, Fl = po.lookup_argument(inputs, values, sorted_, q_last, q_blind, L0, bl, gl, [al], usable, root, r)
+    assert VP[usable] == 1 and VL[usable] == 1
+    mask = [(1 - a - b) % r for a, b in zip(q_last, q_blind)]
+    G = po.gate_argument_dfs([(1, [(q, 0), (w0, 0), (w1, 0)]), (r - 1, [(q, 0), (w2, 0)])], mask, 4 * n, root, r)
+
+    def to_dfs(c, size=4 * n):
+        assert len(c) <= size
+        return po.ntt(list(c) + [0] * (size - len(c)), root(size.bit_length() - 1), r)
+    F = [to_dfs(f) for f in Fp + Fl] + [G]
+    T = po.quotient_polynomial(F, alphas, n, root, r)
+    parts = po.quotient_polynomial_split_dfs(T, n, 4, n, root, r)
+    srs = _srs(curve, alpha, n)
+    L1 = srs.shape[1]
+    evals = fr_arr([x for v in cols + S_id + S_sigma + inputs + values + sorted_ + [q, w0, w1, w2, q_last, q_blind, L0] for x in v])
+    roots = np.stack([limbs(root(l), 4) for l in range(log_n + 4)])
+    out_T = np.zeros((3 * n, 4), dtype=np.uint64)
+    out_commits = np.zeros((8, L1), dtype=np.uint64)
+    rc = shim.shim_placeholder_round(curve, P(srs), ctypes.c_size_t(n), P(evals), ctypes.c_size_t(k), ctypes.c_size_t(log_n), ctypes.c_size_t(usable), P(roots),
+                                     P(np.stack([limbs(c, 4) for c in ch])), P(out_T), P(out_commits))
+    assert rc == 0
+    assert fr_ints(out_T) == T
+    co = lambda e: po.intt(list(e), root(log_n), r)
+    g = lambda c: cp.batch_mul(curve, 1, fr_arr([po.poly_eval(c, alpha, r)]))[0][0]
+    expected = [co(VP), co(VL), co(sorted_[0]), co(sorted_[1])] + [T[i * n:(i + 1) * n] for i in range(4)]
+    for i, c in enumerate(expected):
+        assert (out_commits[i] == g(c)).all(), i
 
 
 def test_placeholder_transcript_bytes_bls12_381(shim):

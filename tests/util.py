@@ -98,3 +98,31 @@ def lookup_instance(C, rng, log_n, k_in, k_val, big_inputs=()):
             f = [(v - 2 * c * (j & 1)) % r for j, v in enumerate(big)]
         inputs.append(f)
     return inputs, values, usable
+
+
+def permutation_instance(C, rng, log_n, k, usable):
+    """A genuine copy-constraint instance in placeholder's shape: the k columns are constant along the cycles of a random permutation of
+    the k * usable cells of the usable rows; the rows behind them are blinding (random values, identity permutation), so the grand
+    product closes AT usable: V_P[usable] = 1.  -> (columns, S_id, S_sigma)"""
+    r = C.r
+    n = 1 << log_n
+    w, delta = C.root_of_unity(log_n), C.fr_generator
+    labels = [[pow(delta, i, r) * pow(w, j, r) % r for j in range(n)] for i in range(k)]
+    cells = [(i, j) for i in range(k) for j in range(usable)]
+    perm = list(cells)
+    for a in range(len(perm) - 1, 0, -1):            # Fisher-Yates with the test's generator
+        b = rng.next_mod(a + 1)
+        perm[a], perm[b] = perm[b], perm[a]
+    sigma = dict(zip(cells, perm))
+    val, seen = {}, set()
+    for c in cells:
+        if c in seen:
+            continue
+        v, x = rng.next_mod(r), c
+        while x not in seen:
+            seen.add(x)
+            val[x] = v
+            x = sigma[x]
+    cols = [[val[(i, j)] if j < usable else rng.next_mod(r) for j in range(n)] for i in range(k)]
+    S_sigma = [[labels[sigma[(i, j)][0]][sigma[(i, j)][1]] if j < usable else labels[i][j] for j in range(n)] for i in range(k)]
+    return cols, labels, S_sigma
