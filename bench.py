@@ -902,7 +902,7 @@ def lpc_leg(np, log_n=20, cols=16, steps=4):
             "verification": "the streaming and the vector builder fold the same leaves (bit-exact parity of the layout: tests/test_gpu_shim.py)"}
 
 
-def quotient_leg(np, log_n=20, steps=4, verify=True):
+def quotient_leg(np, log_n=20, steps=6, verify=True):
     """placeholder's quotient-polynomial chain at BASELINE config 5's row count (hip/placeholder_quotient.hpp mirrors
     prover.hpp:220-277, 314-317 and the polynomial_dfs side of gates_argument.hpp:203-216), every column resident: one gate of four
     factors over the 4n-point extended domain, a second part over 2n points, F / (X^n - 1), the split into 4 parts and
@@ -916,9 +916,9 @@ def quotient_leg(np, log_n=20, steps=4, verify=True):
     if rc != 0:
         return {"error": rc}
     ms = ms.reshape(steps, 5)
-    timed = ms[1:] if steps > 1 else ms
-    mean = timed.mean(axis=0)
-    total = float(mean.sum())
+    timed = ms[2:] if steps > 2 else ms    # the first two runs warm the transforms' tables and the context's block cache
+    mean = np.median(timed, axis=0)
+    total = float(np.median(timed.sum(axis=1)))
     n = 1 << log_n
     # SURVEY 8d's accounting, 64 B per element per transform + 128 B per (base, scalar) of a multiexp:
     #   gate argument   4 factors + the mask, each iNTT(n) + NTT(4n)                      25 n
@@ -930,7 +930,7 @@ def quotient_leg(np, log_n=20, steps=4, verify=True):
     ach = alg / (total * 1e-3) / 1e9
     names = ("gate_argument", "second_part", "quotient_polynomial", "split_from_coefficients", "commit_quotient_batch")
     return {"metric": "placeholder quotient chain, BLS12-381, 2^%d rows (one 4-factor gate over the 4x extended domain + one part over 2x), columns resident" % log_n,
-            "value": round(total, 3), "unit": "ms per chain", "higher_is_better": False, "statistic": "mean of the runs after the first",
+            "value": round(total, 3), "unit": "ms per chain", "higher_is_better": False, "statistic": "median of the runs after the first two",
             "ms_by_phase": {k: round(float(v), 3) for k, v in zip(names, mean)}, "ms_per_run": [round(float(x), 2) for x in ms.sum(axis=1)],
             "verified": None if not verify else bool(verified.value == 1),
             "verification": "T(y) (y^n - 1) == alpha_0 G(y) + alpha_1 F1(y) at a random y; every commitment == part_k(alpha) G1",
@@ -939,7 +939,7 @@ def quotient_leg(np, log_n=20, steps=4, verify=True):
                          "dominant_kernels": "ntt_pass (the resizes to the extended domains) and msm_bucket_acc (the three non-zero parts' commitments)"}}
 
 
-def permutation_leg(np, log_n=20, k=4, steps=4, verify=True):
+def permutation_leg(np, log_n=20, k=4, steps=6, verify=True):
     """placeholder's permutation argument, prover side, at BASELINE config 5's row count (hip/placeholder_permutation.hpp mirrors
     permutation_argument.hpp:70-224): k permuted columns resident; the grand product V_P (one inversion per ROW in a serial loop in the
     reference; chunks sharing an inversion + a three-level prefix-product scan here) and the three constraint polynomials."""
@@ -952,14 +952,14 @@ def permutation_leg(np, log_n=20, k=4, steps=4, verify=True):
     if rc != 0:
         return {"error": rc}
     ms = ms.reshape(steps, 2)
-    timed = ms[1:] if steps > 1 else ms
-    gp, whole = (float(x) for x in timed.mean(axis=0))
+    timed = ms[2:] if steps > 2 else ms    # the first two runs warm the transforms' tables and the context's block cache
+    gp, whole = (float(x) for x in np.median(timed, axis=0))
     n = 1 << log_n
     # the grand product reads 3 k vectors and writes 2 k + 1: 32 B per element each
     alg_gp = (5 * k + 1) * n * 32
     ach = alg_gp / (gp * 1e-3) / 1e9
     return {"metric": "placeholder permutation argument (prover side), BLS12-381, %d permuted columns x 2^%d rows, resident" % (k, log_n),
-            "value": round(whole, 3), "unit": "ms per prove_eval", "higher_is_better": False, "statistic": "mean of the runs after the first",
+            "value": round(whole, 3), "unit": "ms per prove_eval", "higher_is_better": False, "statistic": "median of the runs after the first two",
             "ms_grand_product": round(gp, 3), "ms_per_run": [round(float(x), 2) for x in ms[:, 1]],
             "verified": None if not verify else bool(verified.value == 1),
             "verification": "V_P[0] = 1 and the recurrence at 64 sampled rows; F_1(y) against its definition at a random y",
@@ -968,7 +968,7 @@ def permutation_leg(np, log_n=20, k=4, steps=4, verify=True):
                          "per": "the grand product alone: 3 k input vectors read, 2 k + 1 written, 32 B per element"}}
 
 
-def lookup_leg(np, log_n=20, k_in=2, k_val=1, steps=4, verify=True):
+def lookup_leg(np, log_n=20, k_in=2, k_val=1, steps=6, verify=True):
     """placeholder's lookup argument, prover side, from the sorted vectors on, at BASELINE config 5's row count (hip/placeholder_lookup.hpp mirrors
     lookup_argument.hpp:153-296): a genuine instance -- k_in inputs drawn from k_val table columns --, resident; V_L (compute_V_L: one inversion
     per ROW in a serial loop in the reference; the permutation argument's scan here) and the four constraint polynomials."""
@@ -982,15 +982,15 @@ def lookup_leg(np, log_n=20, k_in=2, k_val=1, steps=4, verify=True):
     if rc != 0:
         return {"error": rc}
     ms = ms.reshape(steps, 2)
-    timed = ms[1:] if steps > 1 else ms
-    gp, whole = (float(x) for x in timed.mean(axis=0))
+    timed = ms[2:] if steps > 2 else ms    # the first two runs warm the transforms' tables and the context's block cache
+    gp, whole = (float(x) for x in np.median(timed, axis=0))
     n = 1 << log_n
     # V_L reads the k_in + k_val + (k_in + k_val) reduced vectors and writes one: 32 B per element each
     alg_gp = (2 * (k_in + k_val) + 1) * n * 32
     ach = alg_gp / (gp * 1e-3) / 1e9
     return {"metric": "placeholder lookup argument (prover side, from the sorted vectors on), BLS12-381, %d inputs over %d table columns x 2^%d rows, resident"
                       % (k_in, k_val, log_n),
-            "value": round(whole, 3), "unit": "ms per prove_eval", "higher_is_better": False, "statistic": "mean of the runs after the first",
+            "value": round(whole, 3), "unit": "ms per prove_eval", "higher_is_better": False, "statistic": "median of the runs after the first two",
             "ms_grand_product": round(gp, 3), "ms_per_run": [round(float(x), 2) for x in ms[:, 1]],
             "verified": None if not verify else bool(verified.value == 1),
             "verification": "V_L[0] = 1, V_L[usable_rows] = 1 (the product over all rows closes: the reference's own check, lookup_argument.hpp:217), zeros behind, "
