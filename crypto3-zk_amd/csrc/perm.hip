@@ -287,7 +287,48 @@ int lookup_run(zkhip_ctx *ctx, size_t k_in, const void *const *d_in, size_t k_va
         (uint32_t)k_in, beta, gamma, d_vl);
 }
 
+// out[j] = a[j] b[j] / c[j] for j < count, PERM_CHUNK rows per lane sharing one inversion: the intermediate polynomials of the multi-part
+// permutation / lookup arguments (permutation_argument.hpp:196-198, lookup_argument.hpp:264-266: one inversion per row in the reference)
+template <class U>
+__global__ __launch_bounds__(PERM_THREADS) void fr_vec_mul_div(const uint32_t *a, const uint32_t *b, const uint32_t *c, size_t count, uint32_t *out) {  // out may alias an input
+    const size_t lane = (size_t)blockIdx.x * PERM_THREADS + threadIdx.x, lo = lane * PERM_CHUNK;
+    if (lo >= count) return;
+    const uint32_t cnt = (uint32_t)(count - lo < PERM_CHUNK ? count - lo : PERM_CHUNK);
+    Fu<U> nom[PERM_CHUNK], pre[PERM_CHUNK], den[PERM_CHUNK];
+    Fu<U> acc = Fu<U>::one();
+    for (uint32_t r = 0; r < cnt; ++r) {
+        nom[r] = mmul(p_load_mont<U>(a, lo + r), p_load_mont<U>(b, lo + r));
+        den[r] = p_load_mont<U>(c, lo + r);
+        pre[r] = acc;
+        acc = mmul(acc, den[r]);
+    }
+    Fu<U> inv = fu_cond_sub_p(fu_inv(acc));  // a zero among the chunk's denominators leaves zeros in the whole chunk
+    for (uint32_t r = cnt; r-- > 0;) {
+        const Fu<U> q = mmul(nom[r], mmul(inv, pre[r]));
+        inv = mmul(inv, den[r]);
+        nom[r] = q;
+    }
+    for (uint32_t r = 0; r < cnt; ++r) p_store_raw<U>(out, lo + r, from_mont(nom[r]));
+}
+
 }  // namespace
+
+extern "C" int zkhip_fr_vec_mul_div_dev(zkhip_ctx *ctx, int curve, const void *d_a, const void *d_b, const void *d_c, void *d_out, size_t count) {
+    if (!ctx || (count && (!d_a || !d_b || !d_c || !d_out))) return ZKHIP_ERR_INVALID;
+    if (curve != CURVE_BLS12_381 && curve != CURVE_BN254) return ZKHIP_ERR_INVALID;
+    if (count >= ((size_t)1 << 39)) return ZKHIP_ERR_RANGE;
+    if (count == 0) return ZKHIP_OK;
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t lanes = (count + PERM_CHUNK - 1) / PERM_CHUNK;
+    const dim3 grid((unsigned)((lanes + PERM_THREADS - 1) / PERM_THREADS));
+    if (curve == CURVE_BLS12_381)
+        ZK_LAUNCH(ctx, "fr_vec_mul_div", fr_vec_mul_div<BlsFrU>, grid, dim3(PERM_THREADS), 0, (const uint32_t *)d_a, (const uint32_t *)d_b, (const uint32_t *)d_c, count,
+                  (uint32_t *)d_out);
+    else
+        ZK_LAUNCH(ctx, "fr_vec_mul_div", fr_vec_mul_div<BnFrU>, grid, dim3(PERM_THREADS), 0, (const uint32_t *)d_a, (const uint32_t *)d_b, (const uint32_t *)d_c, count,
+                  (uint32_t *)d_out);
+    return ZKHIP_OK;
+}
 
 extern "C" int zkhip_perm_grand_product_dev(zkhip_ctx *ctx, int curve, size_t k, const void *const *d_cols, const void *const *d_sid, const void *const *d_ssigma,
                                             size_t n, const uint64_t *beta, const uint64_t *gamma, void *d_g, void *d_h, void *d_vp) {

@@ -1,13 +1,18 @@
 //---------------------------------------------------------------------------//
 // zkhip shim: placeholder's lookup argument, prover side, from the sorted vectors on --
 //   placeholder_lookup_argument_prover::prove_eval   zk/snark/systems/plonk/placeholder/lookup_argument.hpp:153-296
-// (the one-part form: lookup_parts(max_quotient_chunks = 0) = { sorted_lookup_columns_number }, :56-62, as the reference's tests configure it).
+// both forms: one part (lookup_parts(max_quotient_chunks = 0) = { sorted_lookup_columns_number }, :56-62) and the multi-part one the reference's
+// tests also run (test/systems/plonk/placeholder/placeholder.cpp:1287-1291: max_quotient_poly_chunks = 8, 10, 30, 50); the caller passes
+// lookup_parts(...)'s result, which is the constraint system's to compute (:63-107).
 //   :175-186  reduce_dfs_polynomial_domain: every (size / n)-th evaluation (:498-517)                 -- reduce_dfs_polynomial_domain below
 //   :208-209  compute_V_L (:375-409): V_L[0] = 1, V_L[k] = V_L[k - 1] g(k - 1) / h(k - 1), k <= usable_rows, zero behind
 //             -- zkhip_lookup_grand_product_dev: a serial loop with one inversion per row in the reference; the permutation argument's scan here
 //   :223-229  compute_gs / compute_hs (:297-373): g = prod_i (1 + beta)(gamma + input_i) prod_i ((1 + beta) gamma + value_i + beta value_i(omega X)),
 //             h = prod_i ((1 + beta) gamma + sorted_i + beta sorted_i(omega X))    -- one zkhip_fr_vec_affine_dev pass per factor + polynomial_product
 //   :236-251  F_dfs[0] = lagrange_0 (1 - V_L),  F_dfs[1] = q_last (V_L V_L - V_L),  F_dfs[2] = ((q_last + q_blind) - 1)(V_L g - V_L(omega X) h)
+//   :252-276  several parts: the g / h factors in groups of part_sizes[i]; every group but the last gives an intermediate polynomial
+//             current[j] = previous[j] g_i[j] / h_i[j] over the usable rows (zkhip_fr_vec_mul_div_dev), appended to PERMUTATION_BATCH after V_L, and
+//             F_dfs[2] = ((q_last + q_blind) - 1)(sum_i alpha_i (previous_i g_i - current_i h_i) + previous_last g_last - V_L(omega X) h_last)
 //   :278-288  F_dfs[3] = sum_i alpha_i lagrange_0 (sorted_(i + 1) - sorted_i(omega^usable_rows X))
 // What the caller keeps: the constraint system's side -- prepare_lookup_value / prepare_lookup_input (:411-496, a walk over the lookup tables and
 // gates with theta) and sort_polynomials (:565-638, a hash-map walk over the rows) --, the transcript (beta, gamma, the alphas are arguments) and the
@@ -20,7 +25,7 @@
 #include <stdexcept>
 #include <vector>
 
-#include "fri.hpp"
+#include "placeholder_permutation.hpp"
 
 namespace nil {
 namespace crypto3 {
@@ -37,6 +42,7 @@ struct placeholder_lookup_hip {
     struct prover_result_type {
         std::array<dfs_type, 4> F_dfs;
         dfs_type V_L;
+        std::vector<dfs_type> parts_dfs;    // the intermediate polynomials of the multi-part form, in PERMUTATION_BATCH order behind V_L
     };
 
     /// lookup_argument.hpp:498-517 -- unlike resize() this does not look at the degree: the result is the vector of values on the smaller domain
@@ -75,11 +81,21 @@ struct placeholder_lookup_hip {
     }
 
     /// `lookup_input` / `lookup_value`: what prepare_lookup_input / prepare_lookup_value return (inputs may live on larger domains than the
-    /// n-row basic one), `sorted`: sort_polynomials' result, `alphas`: sorted.size() - 1 challenges in drawing order.
+    /// n-row basic one), `sorted`: sort_polynomials' result, `alphas`: sorted.size() - 1 challenges in drawing order (F_dfs[3], :281-283).
+    /// part_sizes (empty: one part) / part_alphas (part_sizes.size() - 1 challenges, drawn BEFORE V_L is computed, :202-206): the multi-part form.
     static prover_result_type prove_eval(const context &ctx, const std::vector<dfs_type> &lookup_input, const std::vector<dfs_type> &lookup_value,
                                          const std::vector<dfs_type> &sorted, const dfs_type &q_last, const dfs_type &q_blind, const dfs_type &lagrange_0,
                                          const value_type &beta, const value_type &gamma, const std::vector<value_type> &alphas, std::size_t usable_rows,
-                                         const root_of_unity_type &root) {
+                                         const root_of_unity_type &root, std::vector<std::size_t> part_sizes = {}, const std::vector<value_type> &part_alphas = {}) {
+        typedef placeholder_permutation_hip<CurveType> PA;    // the shared helpers: plus / minus / scale / multiplied_up
+        if (part_sizes.empty()) part_sizes.push_back(sorted.size());
+        std::size_t covered = 0;
+        for (std::size_t sz : part_sizes) {
+            if (sz == 0) throw std::invalid_argument("lookup argument: an empty part");
+            covered += sz;
+        }
+        if (covered != sorted.size() || part_alphas.size() + 1 != part_sizes.size())
+            throw std::invalid_argument("lookup argument: part_sizes must add up to the sorted vectors, with one alpha per part but the last");
         if (sorted.empty() || sorted.size() != lookup_input.size() + lookup_value.size())
             throw std::invalid_argument("lookup argument: one sorted vector per input and value vector");
         if (alphas.size() + 1 != sorted.size()) throw std::invalid_argument("lookup argument: one alpha per sorted vector but the first");
@@ -105,15 +121,35 @@ struct placeholder_lookup_hip {
             dfs_type shifted = polynomial_shift(p, 1, n);
             h_multipliers.push_back(affine(p, &shifted, one, beta, part1));
         }
-        dfs_type g = polynomial_product<CurveType>(std::move(g_multipliers), root), h = polynomial_product<CurveType>(std::move(h_multipliers), root);
+        std::vector<dfs_type> gs, hs;
+        for (std::size_t p = 0, at = 0; p < part_sizes.size(); at += part_sizes[p++]) {
+            gs.push_back(polynomial_product<CurveType>(std::vector<dfs_type>(g_multipliers.begin() + at, g_multipliers.begin() + at + part_sizes[p]), root));
+            hs.push_back(polynomial_product<CurveType>(std::vector<dfs_type>(h_multipliers.begin() + at, h_multipliers.begin() + at + part_sizes[p]), root));
+        }
+        g_multipliers.clear();
+        h_multipliers.clear();
         dfs_type V_L_shifted = polynomial_shift(V_L, 1, n);
-        prover_result_type res {{dfs_type(ctx, 1), dfs_type(ctx, 1), dfs_type(ctx, 1), dfs_type(ctx, 1)}, V_L};
+        prover_result_type res {{dfs_type(ctx, 1), dfs_type(ctx, 1), dfs_type(ctx, 1), dfs_type(ctx, 1)}, V_L, {}};
         /* F_dfs[0] = lagrange_0 (1 - V_L) = lagrange_0 - lagrange_0 V_L */
         res.F_dfs[0] = minus(lagrange_0, polynomial_product<CurveType>({lagrange_0, V_L}, root), root);
         /* F_dfs[1] = q_last (V_L V_L - V_L) */
         res.F_dfs[1] = minus(polynomial_product<CurveType>({q_last, V_L, V_L}, root), polynomial_product<CurveType>({q_last, V_L}, root), root);
-        /* F_dfs[2] = ((q_last + q_blind) - 1) (V_L g - V_L_shifted h) = q T - T */
-        dfs_type T = minus(polynomial_product<CurveType>({V_L, g}, root), polynomial_product<CurveType>({V_L_shifted, h}, root), root);
+        /* F_dfs[2] = ((q_last + q_blind) - 1) T = q T - T,  T = V_L g - V_L_shifted h (one part),
+           T = sum_i alpha_i (previous g_i - current h_i) + previous g_last - V_L_shifted h_last (several) */
+        dfs_type T(ctx, 1), previous = V_L;
+        const std::size_t parts = part_sizes.size();
+        for (std::size_t p = 0; p + 1 < parts; ++p) {
+            dfs_type current = PA::multiplied_up(previous, V_L, gs[p], hs[p], n, usable_rows);
+            res.parts_dfs.push_back(current);
+            dfs_type part = minus(polynomial_product<CurveType>({previous, gs[p]}, root), polynomial_product<CurveType>({current, hs[p]}, root), root);
+            PA::scale(part, part_alphas[p]);
+            T = p == 0 ? part : PA::plus(T, part, root);
+            previous = current;
+        }
+        {
+            dfs_type last = minus(polynomial_product<CurveType>({previous, gs[parts - 1]}, root), polynomial_product<CurveType>({V_L_shifted, hs[parts - 1]}, root), root);
+            T = parts == 1 ? last : PA::plus(T, last, root);
+        }
         dfs_type q = affine(q_last, &q_blind, one, one, zero);
         q.set_degree(std::max(q_last.degree(), q_blind.degree()));
         res.F_dfs[2] = minus(polynomial_product<CurveType>({q, T}, root), T, root);
@@ -159,17 +195,7 @@ private:
         if (n == 0 || ((std::size_t)1 << l) != n) throw std::invalid_argument("lookup argument: sizes must be powers of two");
         return l;
     }
-    /// a - b on the larger of the two domains, into a buffer of its own (copies of a device_polynomial_dfs share their buffer)
-    static dfs_type minus(dfs_type a, dfs_type b, const root_of_unity_type &root) {
-        const std::size_t size = std::max(a.size(), b.size());
-        a.resize(size, root);
-        b.resize(size, root);
-        dfs_type out(a.ctx(), size);
-        out.set_degree(std::max(a.degree(), b.degree()));
-        check(zkhip_fr_vec_op_dev(a.ctx().get(), adapter::id, 1, a.data(), b.data(), out.data(), size), "zkhip_fr_vec_op_dev", a.ctx().get());
-        a.ctx().sync();    // a and b are released on return
-        return out;
-    }
+    static dfs_type minus(const dfs_type &a, const dfs_type &b, const root_of_unity_type &root) { return placeholder_permutation_hip<CurveType>::minus(a, b, root); }
 };
 
 }    // namespace hip

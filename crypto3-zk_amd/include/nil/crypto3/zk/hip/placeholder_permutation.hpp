@@ -1,12 +1,17 @@
 //---------------------------------------------------------------------------//
 // zkhip shim: placeholder's permutation argument, prover side, on the device --
 //   placeholder_permutation_argument::prove_eval   zk/snark/systems/plonk/placeholder/permutation_argument.hpp:70-224
-// (the permutation_parts == 1 form: common_data.max_quotient_chunks == 0, as the reference's tests configure it).
+// both forms: permutation_parts == 1 (common_data.max_quotient_chunks == 0) and the multi-part one the reference's tests also run
+// (test/systems/plonk/placeholder/placeholder.cpp:1245, 1287-1291: max_quotient_poly_chunks = 8, 10, 30, 50).
 //   :103-124  g_v[i] = column_i + beta S_id[i] + gamma,  h_v[i] = column_i + beta S_sigma[i] + gamma
 //   :126-136  V_P[0] = 1, V_P[j] = V_P[j - 1] prod_i g_v[i][j - 1] / prod_i h_v[i][j - 1]    -- zkhip_perm_grand_product_dev: a serial loop with
 //             one inversion per row in the reference; chunks sharing an inversion + a three-level prefix-product scan here
 //   :140-160  g = polynomial_product(g_v), h = polynomial_product(h_v)
 //   :163-218  F_dfs[0] = lagrange_0 (1 - V_P),  F_dfs[1] = (1 - (q_last + q_blind)) (V_P(omega X) h - V_P g),  F_dfs[2] = q_last V_P (V_P - 1)
+//   :147-160, 188-207  max_quotient_chunks = c != 0: the factors in groups of c - 1; every group but the last gives an intermediate polynomial
+//             current[j] = previous[j] g_i[j] / h_i[j] over the usable rows (zkhip_fr_vec_mul_div_dev: chunks sharing an inversion; one inversion per
+//             row in the reference), appended to PERMUTATION_BATCH after V_P, and
+//             F_dfs[1] = ((q_last + q_blind) - 1)(sum_i alpha_i (previous_i g_i - current_i h_i) + previous_last g_last - V_P(omega X) h_last)
 // What the caller keeps: the transcript (beta, gamma are arguments) and `commitment_scheme.append_to_batch(PERMUTATION_BATCH, V_P)` --
 // the returned V_P is a device_polynomial_dfs, which the KZG scheme takes where it lies.
 // Domain sizes of the three F polynomials follow their degrees (the smallest power of two that holds them), as polynomial_dfs's
@@ -36,19 +41,26 @@ struct placeholder_permutation_hip {
     struct prover_result_type {
         std::array<dfs_type, 3> F_dfs;
         dfs_type permutation_polynomial_dfs;    // V_P
+        std::vector<dfs_type> parts_dfs;        // the intermediate polynomials of the multi-part form, in PERMUTATION_BATCH order behind V_P
     };
 
     /// `columns[i]`: the i-th permuted column (column_polynomials[global_indices[i]], :93-97), S_id / S_sigma the preprocessed identity /
-    /// permutation polynomials, all over the n-row basic domain.
+    /// permutation polynomials, all over the n-row basic domain.  max_quotient_chunks / alphas / usable_rows: the multi-part form
+    /// (alphas: permutation_parts - 1 challenges in drawing order, :181-183).
     static prover_result_type prove_eval(const context &ctx, const std::vector<dfs_type> &columns, const std::vector<dfs_type> &S_id,
                                          const std::vector<dfs_type> &S_sigma, const dfs_type &q_last, const dfs_type &q_blind, const dfs_type &lagrange_0,
-                                         const value_type &beta, const value_type &gamma, const root_of_unity_type &root) {
+                                         const value_type &beta, const value_type &gamma, const root_of_unity_type &root, std::size_t max_quotient_chunks = 0,
+                                         const std::vector<value_type> &alphas = {}, std::size_t usable_rows = 0) {
         const std::size_t k = columns.size();
         if (k == 0 || S_id.size() != k || S_sigma.size() != k) throw std::invalid_argument("permutation argument: one S_id / S_sigma per permuted column");
         const std::size_t n = columns[0].size();
         for (std::size_t i = 0; i < k; ++i)
             if (columns[i].size() != n || S_id[i].size() != n || S_sigma[i].size() != n) throw std::invalid_argument("permutation argument: sizes differ from the basic domain's");
         if (q_last.size() != n || q_blind.size() != n || lagrange_0.size() != n) throw std::invalid_argument("permutation argument: selector sizes differ from the basic domain's");
+        if (max_quotient_chunks == 1) throw std::invalid_argument("permutation argument: max_quotient_chunks = 1 leaves no factor per part");
+        const std::size_t step = max_quotient_chunks ? max_quotient_chunks - 1 : k, parts = (k + step - 1) / step;    // preprocessor.hpp:80-87
+        if (alphas.size() + 1 != parts) throw std::invalid_argument("permutation argument: permutation_parts - 1 alphas");
+        if (parts > 1 && (usable_rows == 0 || usable_rows >= n)) throw std::invalid_argument("permutation argument: the multi-part form needs usable_rows");
         /* 2.-3.: g_v, h_v and V_P in one device call */
         auto d_g = ctx.alloc(k * n * 32), d_h = ctx.alloc(k * n * 32);
         dfs_type V_P(ctx, n);
@@ -63,40 +75,94 @@ struct placeholder_permutation_hip {
         adapter::scalar_to_limbs(gamma, gl);
         check(zkhip_perm_grand_product_dev(ctx.get(), adapter::id, k, pc.data(), pi.data(), ps.data(), n, bl, gl, d_g.get(), d_h.get(), V_P.data()),
               "zkhip_perm_grand_product_dev", ctx.get());
-        /* 5.: g = prod g_v[i], h = prod h_v[i] */
-        std::vector<dfs_type> g_v, h_v;
-        for (std::size_t i = 0; i < k; ++i) {
-            g_v.emplace_back(ctx, n);
-            h_v.emplace_back(ctx, n);
-            check(zkhip_memcpy_d2d_async(ctx.get(), g_v.back().data(), static_cast<const char *>(d_g.get()) + i * n * 32, n * 32), "zkhip_memcpy_d2d_async", ctx.get());
-            check(zkhip_memcpy_d2d_async(ctx.get(), h_v.back().data(), static_cast<const char *>(d_h.get()) + i * n * 32, n * 32), "zkhip_memcpy_d2d_async", ctx.get());
+        /* 5.: gs[p] = prod of the p-th group's g_v, hs[p] likewise */
+        std::vector<dfs_type> gs, hs;
+        for (std::size_t lo = 0; lo < k; lo += step) {
+            std::vector<dfs_type> g_v, h_v;
+            for (std::size_t i = lo; i < std::min(k, lo + step); ++i) {
+                g_v.emplace_back(ctx, n);
+                h_v.emplace_back(ctx, n);
+                check(zkhip_memcpy_d2d_async(ctx.get(), g_v.back().data(), static_cast<const char *>(d_g.get()) + i * n * 32, n * 32), "zkhip_memcpy_d2d_async", ctx.get());
+                check(zkhip_memcpy_d2d_async(ctx.get(), h_v.back().data(), static_cast<const char *>(d_h.get()) + i * n * 32, n * 32), "zkhip_memcpy_d2d_async", ctx.get());
+            }
+            gs.push_back(polynomial_product<CurveType>(std::move(g_v), root));
+            hs.push_back(polynomial_product<CurveType>(std::move(h_v), root));
         }
-        dfs_type g = polynomial_product<CurveType>(g_v, root), h = polynomial_product<CurveType>(h_v, root);
         dfs_type V_P_shifted = polynomial_shift(V_P, 1, n);
-        prover_result_type res {{dfs_type(ctx, 1), dfs_type(ctx, 1), dfs_type(ctx, 1)}, V_P};
+        prover_result_type res {{dfs_type(ctx, 1), dfs_type(ctx, 1), dfs_type(ctx, 1)}, V_P, {}};
         /* F_dfs[0] = lagrange_0 (1 - V_P) = lagrange_0 - lagrange_0 V_P */
         res.F_dfs[0] = minus(lagrange_0, polynomial_product<CurveType>({lagrange_0, V_P}, root), root);
-        /* F_dfs[1] = (1 - q)(V_P_shifted h - V_P g) = T - q T,  q = q_last + q_blind */
-        dfs_type T = minus(polynomial_product<CurveType>({V_P_shifted, h}, root), polynomial_product<CurveType>({V_P, g}, root), root);
         dfs_type q(ctx, n);    // q_last + q_blind, in a buffer of its own
         q.set_degree(std::max(q_last.degree(), q_blind.degree()));
         check(zkhip_fr_vec_op_dev(ctx.get(), adapter::id, 0, q_last.data(), q_blind.data(), q.data(), n), "zkhip_fr_vec_op_dev", ctx.get());
-        res.F_dfs[1] = minus(T, polynomial_product<CurveType>({q, T}, root), root);
+        if (parts == 1) {
+            /* F_dfs[1] = (1 - q)(V_P_shifted h - V_P g) = T - q T,  q = q_last + q_blind */
+            dfs_type T = minus(polynomial_product<CurveType>({V_P_shifted, hs[0]}, root), polynomial_product<CurveType>({V_P, gs[0]}, root), root);
+            res.F_dfs[1] = minus(T, polynomial_product<CurveType>({q, T}, root), root);
+        } else {
+            /* F_dfs[1] = (q - 1)(sum_i alpha_i (previous g_i - current h_i) + previous g_last - V_P_shifted h_last) = q S - S */
+            dfs_type previous = V_P, S(ctx, 1);
+            for (std::size_t p = 0; p + 1 < parts; ++p) {
+                dfs_type current = multiplied_up(previous, V_P, gs[p], hs[p], n, usable_rows);
+                res.parts_dfs.push_back(current);
+                dfs_type part = minus(polynomial_product<CurveType>({previous, gs[p]}, root), polynomial_product<CurveType>({current, hs[p]}, root), root);
+                scale(part, alphas[p]);
+                S = p == 0 ? part : plus(S, part, root);
+                previous = current;
+            }
+            dfs_type last = minus(polynomial_product<CurveType>({previous, gs[parts - 1]}, root), polynomial_product<CurveType>({V_P_shifted, hs[parts - 1]}, root), root);
+            S = plus(S, last, root);
+            res.F_dfs[1] = minus(polynomial_product<CurveType>({q, S}, root), S, root);
+        }
         /* F_dfs[2] = q_last V_P (V_P - 1) = q_last V_P V_P - q_last V_P */
         res.F_dfs[2] = minus(polynomial_product<CurveType>({q_last, V_P, V_P}, root), polynomial_product<CurveType>({q_last, V_P}, root), root);
         ctx.sync();
         return res;
     }
 
+    /// the intermediate polynomial of a part (:193-199): current[j] = previous[j] reduced_g[j] / reduced_h[j] for j < usable_rows, `fill`'s values
+    /// behind them (V_P's, which `current_poly` starts as); reduced = every (size / n)-th evaluation (reduce_dfs_polynomial_domain)
+    static dfs_type multiplied_up(const dfs_type &previous, const dfs_type &fill, const dfs_type &g, const dfs_type &h, std::size_t n, std::size_t usable_rows) {
+        const context &ctx = previous.ctx();
+        dfs_type current(ctx, n);
+        current.set_degree(n - 1);
+        check(zkhip_memcpy_d2d_async(ctx.get(), current.data(), fill.data(), n * 32), "zkhip_memcpy_d2d_async", ctx.get());
+        dfs_type rg = reduced(g, n), rh = reduced(h, n);
+        check(zkhip_fr_vec_mul_div_dev(ctx.get(), adapter::id, previous.data(), rg.data(), rh.data(), current.data(), usable_rows), "zkhip_fr_vec_mul_div_dev", ctx.get());
+        ctx.sync();    // rg, rh are released on return
+        return current;
+    }
+    static dfs_type reduced(const dfs_type &p, std::size_t n) {
+        if (p.size() == n) return p;
+        if (p.size() < n || p.size() % n) throw std::invalid_argument("permutation argument: not an extension of the basic domain");
+        dfs_type out(p.ctx(), n);
+        std::size_t lp = 0, ln = 0;
+        while (((std::size_t)1 << lp) < p.size()) ++lp;
+        while (((std::size_t)1 << ln) < n) ++ln;
+        std::uint64_t unused[4] = {1, 0, 0, 0};
+        check(zkhip_poly_resize_dev(p.ctx().get(), adapter::id, p.data(), lp, 1, unused, out.data(), ln, unused), "zkhip_poly_resize_dev", p.ctx().get());
+        return out;
+    }
+    /// a + b on the larger of the two domains, into a buffer of its own
+    static dfs_type plus(dfs_type a, dfs_type b, const root_of_unity_type &root) { return combine(0, a, b, root); }
+    /// a - b likewise (copies of a device_polynomial_dfs share their buffer: never in place)
+    static dfs_type minus(dfs_type a, dfs_type b, const root_of_unity_type &root) { return combine(1, a, b, root); }
+    /// p *= c, in place (p must own its buffer)
+    static void scale(dfs_type &p, const value_type &c) {
+        std::uint64_t cl[4], zl[4];
+        adapter::scalar_to_limbs(c, cl);
+        adapter::scalar_to_limbs(value_type::zero(), zl);
+        check(zkhip_fr_vec_affine_dev(p.ctx().get(), adapter::id, p.data(), nullptr, cl, nullptr, zl, p.data(), p.size()), "zkhip_fr_vec_affine_dev", p.ctx().get());
+    }
+
 private:
-    /// a - b on the larger of the two domains, into a buffer of its own (copies of a device_polynomial_dfs share their buffer)
-    static dfs_type minus(dfs_type a, dfs_type b, const root_of_unity_type &root) {
+    static dfs_type combine(int op, dfs_type a, dfs_type b, const root_of_unity_type &root) {
         const std::size_t size = std::max(a.size(), b.size());
         a.resize(size, root);
         b.resize(size, root);
         dfs_type out(a.ctx(), size);
         out.set_degree(std::max(a.degree(), b.degree()));
-        check(zkhip_fr_vec_op_dev(a.ctx().get(), adapter::id, 1, a.data(), b.data(), out.data(), size), "zkhip_fr_vec_op_dev", a.ctx().get());
+        check(zkhip_fr_vec_op_dev(a.ctx().get(), adapter::id, op, a.data(), b.data(), out.data(), size), "zkhip_fr_vec_op_dev", a.ctx().get());
         a.ctx().sync();    // a and b are released on return
         return out;
     }

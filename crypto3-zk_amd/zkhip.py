@@ -19,7 +19,7 @@ EXPORTS = [
     "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_batch_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_domain_choice", "zkhip_domain_fft_dev", "zkhip_domain_lagrange_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_set_domain", "zkhip_r1cs_domain_size", "zkhip_r1cs_domain_kind", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev", "zkhip_groth16_witness_h_domain_dev", "zkhip_fr_gather_dev", "zkhip_poly_resize_dev", "zkhip_fri_fold_dev", "zkhip_fri_leaves_dev", "zkhip_ec_ntt_dev",
-    "zkhip_fr_vec_op_dev", "zkhip_fr_vec_affine_dev", "zkhip_fr_vec_prod_dev", "zkhip_poly_shift_dev", "zkhip_poly_eval_dev", "zkhip_poly_div_linear_dev", "zkhip_poly_div_vanishing_dev", "zkhip_poly_lincomb_dev", "zkhip_perm_grand_product_dev", "zkhip_lookup_grand_product_dev",
+    "zkhip_fr_vec_op_dev", "zkhip_fr_vec_affine_dev", "zkhip_fr_vec_mul_div_dev", "zkhip_fr_vec_prod_dev", "zkhip_poly_shift_dev", "zkhip_poly_eval_dev", "zkhip_poly_div_linear_dev", "zkhip_poly_div_vanishing_dev", "zkhip_poly_lincomb_dev", "zkhip_perm_grand_product_dev", "zkhip_lookup_grand_product_dev",
     "zkhip_profile_enable", "zkhip_profile_reset", "zkhip_profile_filter", "zkhip_profile_get", "zkhip_profile_dump",
 ]
 
@@ -396,6 +396,11 @@ class Context:
         self._check(self.lib.zkhip_fr_vec_affine_dev(self.h, curve, ctypes.c_void_p(d_x), ctypes.c_void_p(d_y or None), _p(_u64(a).reshape(4)),
                                                      _p(_u64(b).reshape(4)) if d_y else None, _p(_u64(c).reshape(4)), ctypes.c_void_p(d_out), ctypes.c_size_t(count)),
                     "fr_vec_affine_dev")
+
+    def fr_vec_mul_div_dev(self, curve: int, d_a: int, d_b: int, d_c: int, d_out: int, count: int):
+        """d_out[j] = d_a[j] d_b[j] / d_c[j], j < count"""
+        self._check(self.lib.zkhip_fr_vec_mul_div_dev(self.h, curve, ctypes.c_void_p(d_a), ctypes.c_void_p(d_b), ctypes.c_void_p(d_c), ctypes.c_void_p(d_out),
+                                                      ctypes.c_size_t(count)), "fr_vec_mul_div_dev")
 
     def lookup_grand_product_dev(self, curve: int, d_input, d_value, d_sorted, n: int, usable_rows: int, beta, gamma, d_vl: int):
         """placeholder's lookup grand product V_L (n at d_vl) from the reduced input / value / sorted vectors"""

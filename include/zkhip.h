@@ -278,6 +278,11 @@ int zkhip_fr_vec_op_dev(zkhip_ctx *ctx, int curve, int op, const void *d_a, cons
  * (ph/lookup_argument.hpp:313, 329, 361), mask = 1 - q_last - q_blind (:161-162) -- in one pass each. */
 int zkhip_fr_vec_affine_dev(zkhip_ctx *ctx, int curve, const void *d_x, const void *d_y, const uint64_t *a, const uint64_t *b, const uint64_t *c, void *d_out,
                             size_t count);
+/* d_out[j] = d_a[j] d_b[j] / d_c[j] for j < count (in place allowed; entries from `count` on are not touched): the intermediate
+ * polynomials of the multi-part permutation / lookup arguments, current[j] = previous[j] g[j] / h[j] over the usable rows
+ * (ph/permutation_argument.hpp:196-198, lookup_argument.hpp:264-266) -- rows in chunks of 8 that share one inversion; a zero
+ * denominator zeroes its chunk. */
+int zkhip_fr_vec_mul_div_dev(zkhip_ctx *ctx, int curve, const void *d_a, const void *d_b, const void *d_c, void *d_out, size_t count);
 /* polynomial::evaluate for `batch` polynomials (n coefficients each, `stride` elements apart) at `npoints` points
  * given on the host (eval_polys, batched_commitment.hpp:168-183): out[b * npoints + p] = poly_b(points[p]), host. */
 int zkhip_poly_eval_dev(zkhip_ctx *ctx, int curve, const void *d_polys, size_t n, size_t stride, size_t batch, const uint64_t *points,

@@ -1171,23 +1171,53 @@ def permutation_grand_product(cols, S_id, S_sigma, beta: int, gamma: int, r: int
     return g, h, V
 
 
-def permutation_argument(cols, S_id, S_sigma, q_last, q_blind, lagrange_0, beta: int, gamma: int, root_of_unity, r: int):
+def permutation_argument(cols, S_id, S_sigma, q_last, q_blind, lagrange_0, beta: int, gamma: int, root_of_unity, r: int, max_quotient_chunks: int = 0,
+                         alphas: Sequence[int] = (), usable_rows: int = None):
     """-> (V_P evaluations, [F0, F1, F2] as trimmed coefficient lists):
          F0 = L_0 (1 - V_P),  F1 = (1 - (q_last + q_blind)) (V_P(omega X) h - V_P g),  F2 = q_last V_P (V_P - 1),
-       g = prod_i g_i, h = prod_i h_i"""
+       g = prod_i g_i, h = prod_i h_i.
+    max_quotient_chunks = c != 0 (permutation_argument.hpp:147-160, 188-207): the factors go in groups of c - 1 (g_0, h_0), (g_1, h_1), ...;
+    every group but the last gives an intermediate polynomial current[j] = previous[j] g_i[j] / h_i[j] over the usable rows (the rest keeps V_P's
+    values), previous starting as V_P, and
+         F1 = ((q_last + q_blind) - 1) (sum_i alphas[i] (previous_i g_i - current_i h_i) + previous_last g_last - V_P(omega X) h_last);
+    -> (V_P, [F0, F1, F2], [current_0, ...] evaluations)"""
     n = len(cols[0])
     w = root_of_unity(n.bit_length() - 1)
     g, h, V = permutation_grand_product(cols, S_id, S_sigma, beta, gamma, r)
     co = lambda e: poly_trim(intt(list(e), w, r))
-    G, H = [1], [1]
-    for gi, hi in zip(g, h):
-        G, H = poly_mul(G, co(gi), r), poly_mul(H, co(hi), r)
     VP, VPs = co(V), co(polynomial_shift(V, 1))
     one = [1]
     F0 = poly_mul(co(lagrange_0), poly_sub(one, VP, r), r)
-    F1 = poly_mul(poly_sub(one, poly_add(co(q_last), co(q_blind), r), r), poly_sub(poly_mul(VPs, H, r), poly_mul(VP, G, r), r), r)
     F2 = poly_mul(co(q_last), poly_mul(VP, poly_sub(VP, one, r), r), r)
-    return V, [poly_trim(F0), poly_trim(F1), poly_trim(F2)]
+    q = poly_add(co(q_last), co(q_blind), r)
+    if max_quotient_chunks == 0:
+        G, H = [1], [1]
+        for gi, hi in zip(g, h):
+            G, H = poly_mul(G, co(gi), r), poly_mul(H, co(hi), r)
+        F1 = poly_mul(poly_sub(one, q, r), poly_sub(poly_mul(VPs, H, r), poly_mul(VP, G, r), r), r)
+        return V, [poly_trim(F0), poly_trim(F1), poly_trim(F2)]
+    step = max_quotient_chunks - 1
+    groups = [(g[i:i + step], h[i:i + step]) for i in range(0, len(g), step)]
+    assert len(alphas) == len(groups) - 1
+    prev, currents, acc = list(V), [], []
+    for idx, (gg, hh) in enumerate(groups):
+        G, H = [1], [1]
+        for gi, hi in zip(gg, hh):
+            G, H = poly_mul(G, co(gi), r), poly_mul(H, co(hi), r)
+        if idx < len(groups) - 1:
+            cur = list(V)
+            for j in range(usable_rows):
+                nom = den = 1
+                for gi, hi in zip(gg, hh):
+                    nom, den = nom * gi[j] % r, den * hi[j] % r
+                cur[j] = prev[j] * nom % r * pow(den, -1, r) % r
+            currents.append(cur)
+            acc = poly_add(acc, poly_scale(poly_sub(poly_mul(co(prev), G, r), poly_mul(co(cur), H, r), r), alphas[idx], r), r)
+            prev = cur
+        else:
+            acc = poly_add(acc, poly_sub(poly_mul(co(prev), G, r), poly_mul(VPs, H, r), r), r)
+    F1 = poly_mul(poly_sub(q, one, r), acc, r)
+    return V, [poly_trim(F0), poly_trim(F1), poly_trim(F2)], currents
 
 
 def reduce_dfs_polynomial_domain(evals: Sequence[int], new_size: int) -> List[int]:
@@ -1248,13 +1278,17 @@ def lookup_grand_product(reduced_input, reduced_value, sorted_, beta: int, gamma
 
 
 def lookup_argument(lookup_input, lookup_value, sorted_, q_last, q_blind, lagrange_0, beta: int, gamma: int, alphas: Sequence[int], usable_rows: int,
-                    root_of_unity, r: int):
-    """placeholder_lookup_argument_prover::prove_eval from `sorted` on (lookup_argument.hpp:198-296), one part (max_quotient_chunks = 0):
-    -> (V_L evaluations, [F0, F1, F2, F3] as trimmed coefficient lists):
+                    root_of_unity, r: int, part_sizes: Sequence[int] = None, part_alphas: Sequence[int] = ()):
+    """placeholder_lookup_argument_prover::prove_eval from `sorted` on (lookup_argument.hpp:198-296):
+    -> (V_L evaluations, [F0, F1, F2, F3] as trimmed coefficient lists [, intermediate polynomials' evaluations]):
          F0 = L_0 (1 - V_L),  F1 = q_last (V_L^2 - V_L),
          F2 = ((q_last + q_blind) - 1) (V_L g - V_L(omega X) h),   g = prod_i (1 + beta)(gamma + input_i) prod_i ((1 + beta) gamma + value_i + beta value_i(omega X)),
                                                                    h = prod_i ((1 + beta) gamma + sorted_i + beta sorted_i(omega X)),
-         F3 = sum_{i >= 1} alpha_{i - 1} L_0 (sorted_i - sorted_{i-1}... shifted by usable_rows): alpha L_0 (sorted_i - sorted_{i - 1}(omega^usable_rows X))
+         F3 = sum_i alphas[i] L_0 (sorted_(i + 1) - sorted_i(omega^usable_rows X)).
+    part_sizes (lookup_parts(max_quotient_chunks), :56-107; None = one part): the g factors (inputs first, then values) and the h factors go in
+    groups of these sizes (:297-373); every group but the last gives an intermediate polynomial current[j] = previous[j] g_i[j] / h_i[j] over the
+    usable rows (the rest keeps V_L's values), and F2 = ((q_last + q_blind) - 1)(sum_i part_alphas[i] (previous_i g_i - current_i h_i) +
+    previous_last g_last - V_L(omega X) h_last) (:252-276).
     lookup_input may live on larger domains than n (expressions of degree > 1); everything is dense coefficient arithmetic here."""
     n = len(sorted_[0])
     co = lambda e: poly_trim(intt(list(e), root_of_unity(len(e).bit_length() - 1), r))
@@ -1262,25 +1296,44 @@ def lookup_argument(lookup_input, lookup_value, sorted_, q_last, q_blind, lagran
     red_val = [reduce_dfs_polynomial_domain(v, n) for v in lookup_value]
     V = lookup_grand_product(red_in, red_val, sorted_, beta, gamma, usable_rows, r)
     part1 = (1 + beta) * gamma % r
-    G, H = [1], [1]
-    for v in lookup_input:
-        G = poly_mul(G, poly_scale(poly_add([gamma], co(v), r), (1 + beta) % r, r), r)
-    for v in lookup_value:
-        G = poly_mul(G, poly_add(poly_add([part1], co(v), r), poly_scale(co(polynomial_shift(v, 1, n)), beta, r), r), r)
-    for v in sorted_:
-        H = poly_mul(H, poly_add(poly_add([part1], co(v), r), poly_scale(co(polynomial_shift(v, 1, n)), beta, r), r), r)
+    # the factors as (coefficients, values on the rows)
+    nxt = lambda v: polynomial_shift(v, 1, n)
+    g_f = [(poly_scale(poly_add([gamma], co(v), r), (1 + beta) % r, r), [(1 + beta) * (gamma + x) % r for x in rv]) for v, rv in zip(lookup_input, red_in)]
+    g_f += [(poly_add(poly_add([part1], co(v), r), poly_scale(co(nxt(v)), beta, r), r), [(part1 + a + beta * b) % r for a, b in zip(v, nxt(v))]) for v in lookup_value]
+    h_f = [(poly_add(poly_add([part1], co(v), r), poly_scale(co(nxt(v)), beta, r), r), [(part1 + a + beta * b) % r for a, b in zip(v, nxt(v))]) for v in sorted_]
     VL, VLs = co(V), co(polynomial_shift(V, 1))
     one = [1]
     L0 = co(lagrange_0)
     F0 = poly_mul(L0, poly_sub(one, VL, r), r)
     F1 = poly_mul(co(q_last), poly_sub(poly_mul(VL, VL, r), VL, r), r)
-    F2 = poly_mul(poly_sub(poly_add(co(q_last), co(q_blind), r), one, r), poly_sub(poly_mul(VL, G, r), poly_mul(VLs, H, r), r), r)
+    sizes = list(part_sizes) if part_sizes is not None else [len(sorted_)]
+    assert sum(sizes) == len(sorted_) == len(g_f) and len(part_alphas) == len(sizes) - 1
+    prev, currents, acc, at = list(V), [], [], 0
+    for idx, sz in enumerate(sizes):
+        G, H = [1], [1]
+        for (gc, _), (hc, _) in zip(g_f[at:at + sz], h_f[at:at + sz]):
+            G, H = poly_mul(G, gc, r), poly_mul(H, hc, r)
+        if idx < len(sizes) - 1:
+            cur = list(V)
+            for j in range(usable_rows):
+                nom = den = 1
+                for (_, gv), (_, hv) in zip(g_f[at:at + sz], h_f[at:at + sz]):
+                    nom, den = nom * gv[j] % r, den * hv[j] % r
+                cur[j] = prev[j] * nom % r * pow(den, -1, r) % r
+            currents.append(cur)
+            acc = poly_add(acc, poly_scale(poly_sub(poly_mul(co(prev), G, r), poly_mul(co(cur), H, r), r), part_alphas[idx], r), r)
+            prev = cur
+        else:
+            acc = poly_add(acc, poly_sub(poly_mul(co(prev), G, r), poly_mul(VLs, H, r), r), r)
+        at += sz
+    F2 = poly_mul(poly_sub(poly_add(co(q_last), co(q_blind), r), one, r), acc, r)
     F3 = []
     # F_dfs_3_parts = sorted[1:], part i (0-based) subtracts sorted[i] shifted by usable_rows   (lookup_argument.hpp:281-288)
     for i in range(len(sorted_) - 1):
         d = poly_sub(co(sorted_[i + 1]), co(polynomial_shift(sorted_[i], usable_rows, n)), r)
         F3 = poly_add(F3, poly_scale(poly_mul(d, L0, r), alphas[i], r), r)
-    return V, [poly_trim(F0), poly_trim(F1), poly_trim(F2), poly_trim(F3)]
+    F = [poly_trim(F0), poly_trim(F1), poly_trim(F2), poly_trim(F3)]
+    return (V, F) if part_sizes is None else (V, F, currents)
 
 
 def lpc_proof_eval(r: int, batches: dict, points: dict, fixed: Sequence[int], log_domain: int, step_list: Sequence[int], root_of_unity,

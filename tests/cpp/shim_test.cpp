@@ -18,6 +18,7 @@
 #include <nil/crypto3/zk/hip/lpc.hpp>
 #include <nil/crypto3/zk/hip/marshalling.hpp>
 #include <array>
+#include <nil/crypto3/zk/hip/column_polynomial.hpp>
 #include <nil/crypto3/zk/hip/placeholder_lookup.hpp>
 #include <nil/crypto3/zk/hip/placeholder_permutation.hpp>
 #include <nil/crypto3/zk/hip/placeholder_quotient.hpp>
@@ -1386,8 +1387,8 @@ int placeholder_quotient_t(const uint64_t *srs, size_t n_srs, const uint64_t *ev
 /// evals: k columns | k S_id | k S_sigma | q_last | q_blind | lagrange_0, each 2^log_n.  out_vp: V_P (n); out_F: the three F polynomials'
 /// COEFFICIENTS, each in a slot of 8 n elements (zero-padded), with their domain sizes in out_sizes.
 template <typename Curve>
-int placeholder_permutation_t(const uint64_t *evals, size_t k, size_t log_n, const uint64_t *roots, const uint64_t *beta, const uint64_t *gamma, uint64_t *out_vp,
-                              uint64_t *out_F, uint64_t *out_sizes) {
+int placeholder_permutation_t(const uint64_t *evals, size_t k, size_t log_n, const uint64_t *roots, const uint64_t *beta, const uint64_t *gamma, size_t chunks,
+                              const uint64_t *alphas, size_t n_alphas, size_t usable_rows, uint64_t *out_vp, uint64_t *out_F, uint64_t *out_sizes, uint64_t *out_parts) {
     typedef curve_adapter<Curve> A;
     typedef device_polynomial_dfs<Curve> dfs;
     const size_t n = (size_t)1 << log_n;
@@ -1400,9 +1401,13 @@ int placeholder_permutation_t(const uint64_t *evals, size_t k, size_t log_n, con
         all.emplace_back(ctx, h, n - 1);
     }
     std::vector<dfs> cols(all.begin(), all.begin() + k), sid(all.begin() + k, all.begin() + 2 * k), ssig(all.begin() + 2 * k, all.begin() + 3 * k);
+    std::vector<typename A::scalar_value_type> al;
+    for (size_t i = 0; i < n_alphas; ++i) al.push_back(A::scalar_from_limbs(alphas + 4 * i));
     auto res = placeholder_permutation_hip<Curve>::prove_eval(ctx, cols, sid, ssig, all[3 * k], all[3 * k + 1], all[3 * k + 2], A::scalar_from_limbs(beta),
-                                                             A::scalar_from_limbs(gamma), root);
+                                                             A::scalar_from_limbs(gamma), root, chunks, al, usable_rows);
     ctx.d2h(out_vp, res.permutation_polynomial_dfs.data(), n * 32);
+    if (res.parts_dfs.size() != n_alphas) return -54;
+    for (size_t i = 0; i < res.parts_dfs.size(); ++i) ctx.d2h(out_parts + 4 * i * n, res.parts_dfs[i].data(), n * 32);
     for (int f = 0; f < 3; ++f) {
         const size_t sz = res.F_dfs[f].size();
         if (sz > 8 * n) return -51;
@@ -1419,12 +1424,36 @@ int placeholder_permutation_t(const uint64_t *evals, size_t k, size_t log_n, con
     return 0;
 }
 
+// ---- plonk columns -> coefficient form (column_polynomial.hpp; arithmetization/plonk/detail/column_polynomial.hpp:43-72) ----
+/// `count` columns of m values over the (kind, m, omega, shift) domain; out: count x m coefficients.  The columns are std::vectors of field
+/// elements, as plonk_column is.
+template <typename Curve>
+int column_polynomials_t(const uint64_t *evals, size_t count, int kind, size_t m, const uint64_t *omega, const uint64_t *shift, uint64_t *out) {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::scalar_value_type Fr;
+    context ctx(0);
+    evaluation_domain_hip<Curve> domain(kind, m, A::scalar_from_limbs(omega), A::scalar_from_limbs(shift));
+    std::vector<std::vector<Fr>> columns(count);
+    for (size_t c = 0; c < count; ++c)
+        for (size_t i = 0; i < m; ++i) columns[c].push_back(A::scalar_from_limbs(evals + 4 * (c * m + i)));
+    auto polys = column_range_polynomials<Curve>(ctx, columns, domain);
+    if (polys.size() != count) return -81;
+    for (size_t c = 0; c < count; ++c) {
+        if (polys[c].size() != m) return -82;
+        for (size_t i = 0; i < m; ++i) A::scalar_to_limbs(polys[c][i], out + 4 * (c * m + i));
+    }
+    auto one = column_polynomial<Curve>(ctx, columns[count - 1], domain);
+    if (one != polys[count - 1]) return -83;
+    return 0;
+}
+
 // ---- placeholder's lookup argument on the device (placeholder_lookup.hpp; lookup_argument.hpp:153-296) ----
 /// evals: k_in inputs (input i on 2^in_logs[i] points) | k_val values | k_in + k_val sorted | q_last | q_blind | lagrange_0 (2^log_n each).
 /// out_vl: V_L (n); out_F: the four F polynomials' COEFFICIENTS, each in a slot of 16 n elements, with their domain sizes in out_sizes.
 template <typename Curve>
 int placeholder_lookup_t(const uint64_t *evals, size_t k_in, const uint64_t *in_logs, size_t k_val, size_t log_n, size_t usable_rows, const uint64_t *roots,
-                         const uint64_t *beta, const uint64_t *gamma, const uint64_t *alphas, uint64_t *out_vl, uint64_t *out_F, uint64_t *out_sizes) {
+                         const uint64_t *beta, const uint64_t *gamma, const uint64_t *alphas, const uint64_t *part_sizes, size_t n_parts, const uint64_t *part_alphas,
+                         uint64_t *out_vl, uint64_t *out_F, uint64_t *out_sizes, uint64_t *out_parts) {
     typedef curve_adapter<Curve> A;
     typedef device_polynomial_dfs<Curve> dfs;
     const size_t n = (size_t)1 << log_n, total = k_in + k_val;
@@ -1445,9 +1474,14 @@ int placeholder_lookup_t(const uint64_t *evals, size_t k_in, const uint64_t *in_
     dfs q_last = take(n), q_blind = take(n), lagrange_0 = take(n);
     std::vector<typename A::scalar_value_type> al;
     for (size_t i = 0; i + 1 < total; ++i) al.push_back(A::scalar_from_limbs(alphas + 4 * i));
+    std::vector<std::size_t> ps(part_sizes, part_sizes + n_parts);
+    std::vector<typename A::scalar_value_type> pa;
+    for (size_t i = 0; i + 1 < n_parts; ++i) pa.push_back(A::scalar_from_limbs(part_alphas + 4 * i));
     auto res = placeholder_lookup_hip<Curve>::prove_eval(ctx, input, value, sorted, q_last, q_blind, lagrange_0, A::scalar_from_limbs(beta), A::scalar_from_limbs(gamma), al,
-                                                         usable_rows, root);
+                                                         usable_rows, root, ps, pa);
     ctx.d2h(out_vl, res.V_L.data(), n * 32);
+    if (res.parts_dfs.size() != (n_parts ? n_parts - 1 : 0)) return -64;
+    for (size_t i = 0; i < res.parts_dfs.size(); ++i) ctx.d2h(out_parts + 4 * i * n, res.parts_dfs[i].data(), n * 32);
     for (int f = 0; f < 4; ++f) {
         const size_t sz = res.F_dfs[f].size();
         if (sz > 16 * n) return -61;
@@ -1831,14 +1865,19 @@ int shim_placeholder_transcript_bls(const uint64_t *srs, size_t n_srs, const uin
     }
 }
 int shim_placeholder_permutation(int curve, const uint64_t *evals, size_t k, size_t log_n, const uint64_t *roots, const uint64_t *beta, const uint64_t *gamma,
-                                 uint64_t *out_vp, uint64_t *out_F, uint64_t *out_sizes) {
+                                 size_t chunks, const uint64_t *alphas, size_t n_alphas, size_t usable_rows, uint64_t *out_vp, uint64_t *out_F, uint64_t *out_sizes,
+                                 uint64_t *out_parts) {
     try {
-        if (curve == ZKHIP_BLS12_381) return placeholder_permutation_t<bls12_381>(evals, k, log_n, roots, beta, gamma, out_vp, out_F, out_sizes);
-        return placeholder_permutation_t<alt_bn128_254>(evals, k, log_n, roots, beta, gamma, out_vp, out_F, out_sizes);
+        if (curve == ZKHIP_BLS12_381)
+            return placeholder_permutation_t<bls12_381>(evals, k, log_n, roots, beta, gamma, chunks, alphas, n_alphas, usable_rows, out_vp, out_F, out_sizes, out_parts);
+        return placeholder_permutation_t<alt_bn128_254>(evals, k, log_n, roots, beta, gamma, chunks, alphas, n_alphas, usable_rows, out_vp, out_F, out_sizes, out_parts);
     } catch (const std::exception &e) {
         fprintf(stderr, "shim_placeholder_permutation: %s\n", e.what());
         return -1;
     }
+}
+int shim_column_polynomials(int curve, const uint64_t *evals, size_t count, int kind, size_t m, const uint64_t *omega, const uint64_t *shift, uint64_t *out) {
+    CURVE_CALL("shim_column_polynomials", column_polynomials_t, evals, count, kind, m, omega, shift, out)
 }
 int shim_placeholder_round(int curve, const uint64_t *srs, size_t n_srs, const uint64_t *evals, size_t k, size_t log_n, size_t usable_rows, const uint64_t *roots,
                            const uint64_t *challenges, uint64_t *out_T, uint64_t *out_commits) {
@@ -1851,11 +1890,14 @@ int shim_placeholder_round(int curve, const uint64_t *srs, size_t n_srs, const u
     }
 }
 int shim_placeholder_lookup(int curve, const uint64_t *evals, size_t k_in, const uint64_t *in_logs, size_t k_val, size_t log_n, size_t usable_rows, const uint64_t *roots,
-                            const uint64_t *beta, const uint64_t *gamma, const uint64_t *alphas, uint64_t *out_vl, uint64_t *out_F, uint64_t *out_sizes) {
+                            const uint64_t *beta, const uint64_t *gamma, const uint64_t *alphas, const uint64_t *part_sizes, size_t n_parts, const uint64_t *part_alphas,
+                            uint64_t *out_vl, uint64_t *out_F, uint64_t *out_sizes, uint64_t *out_parts) {
     try {
         if (curve == ZKHIP_BLS12_381)
-            return placeholder_lookup_t<bls12_381>(evals, k_in, in_logs, k_val, log_n, usable_rows, roots, beta, gamma, alphas, out_vl, out_F, out_sizes);
-        return placeholder_lookup_t<alt_bn128_254>(evals, k_in, in_logs, k_val, log_n, usable_rows, roots, beta, gamma, alphas, out_vl, out_F, out_sizes);
+            return placeholder_lookup_t<bls12_381>(evals, k_in, in_logs, k_val, log_n, usable_rows, roots, beta, gamma, alphas, part_sizes, n_parts, part_alphas, out_vl,
+                                                   out_F, out_sizes, out_parts);
+        return placeholder_lookup_t<alt_bn128_254>(evals, k_in, in_logs, k_val, log_n, usable_rows, roots, beta, gamma, alphas, part_sizes, n_parts, part_alphas, out_vl,
+                                                   out_F, out_sizes, out_parts);
     } catch (const std::exception &e) {
         fprintf(stderr, "shim_placeholder_lookup: %s\n", e.what());
         return -1;

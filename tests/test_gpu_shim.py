@@ -422,65 +422,52 @@ def test_placeholder_call_sequence_with_foreign_polynomial_type(shim, curve):
     assert at + 2 * L1 + 1 == len(out)
 
 
-@pytest.mark.parametrize("curve,log_n,k", [(0, 6, 3), (1, 6, 2), (0, 8, 4), (0, 5, 1)])
-def test_placeholder_permutation_argument_shim(shim, curve, log_n, k):
-    """placeholder's permutation argument, prover side, on the device (hip/placeholder_permutation.hpp; permutation_argument.hpp:70-224,
-    permutation_parts == 1): the grand product V_P -- a serial loop with one inversion per row in the reference; chunks sharing an inversion
-    + a three-level prefix-product scan on the device -- EXACTLY the oracle's row-by-row recurrence, and the three constraint polynomials
-    F_0, F_1, F_2 equal to the oracle's dense coefficient-form arithmetic.  A genuine copy-constraint instance: columns constant along the
-    cycles of a random permutation of the k n cells, so the product closes (V_P[n-1] g / h at the last row = 1)."""
+@pytest.mark.parametrize("curve,log_n,k,chunks", [(0, 6, 3, 0), (1, 6, 2, 0), (0, 8, 4, 0), (0, 5, 1, 0), (0, 6, 3, 2), (1, 5, 4, 3), (0, 6, 5, 3), (0, 5, 2, 8)])
+def test_placeholder_permutation_argument_shim(shim, curve, log_n, k, chunks):
+    """placeholder's permutation argument, prover side, on the device (hip/placeholder_permutation.hpp; permutation_argument.hpp:70-224),
+    one-part (max_quotient_chunks = 0) and multi-part (the reference's tests run 8, 10, 30, 50): the grand product V_P -- a serial loop
+    with one inversion per row in the reference; chunks sharing an inversion + a three-level prefix-product scan on the device --
+    EXACTLY the oracle's row-by-row recurrence, the intermediate polynomials of the multi-part form value by value, and the three
+    constraint polynomials F_0, F_1, F_2 equal to the oracle's dense coefficient-form arithmetic.  A genuine copy-constraint instance
+    (tests/util.py permutation_instance): the product closes at usable_rows."""
     C = CURVES[curve]
     r = C.r
     n = 1 << log_n
-    rng = po.SplitMix64(6100 + 10 * curve + log_n + k)
-    w = C.root_of_unity(log_n)
-    delta = C.fr_generator
-    labels = [[pow(delta, i, r) * pow(w, j, r) % r for j in range(n)] for i in range(k)]
-    cells = [(i, j) for i in range(k) for j in range(n)]
-    perm = list(cells)
-    for a in range(len(perm) - 1, 0, -1):            # Fisher-Yates with the test's generator
-        b = rng.next_mod(a + 1)
-        perm[a], perm[b] = perm[b], perm[a]
-    sigma = dict(zip(cells, perm))
-    val, seen = {}, set()
-    for c in cells:
-        if c in seen:
-            continue
-        v, x = rng.next_mod(r), c
-        while x not in seen:
-            seen.add(x)
-            val[x] = v
-            x = sigma[x]
-    cols = [[val[(i, j)] for j in range(n)] for i in range(k)]
-    S_id = labels
-    S_sigma = [[labels[sigma[(i, j)][0]][sigma[(i, j)][1]] for j in range(n)] for i in range(k)]
     usable = n - 3
+    rng = po.SplitMix64(6100 + 10 * curve + log_n + k + 100 * chunks)
+    cols, S_id, S_sigma = permutation_instance(C, rng, log_n, k, usable)
     q_last = [1 if j == usable else 0 for j in range(n)]
     q_blind = [1 if j > usable else 0 for j in range(n)]
     L0 = [1] + [0] * (n - 1)
     beta, gamma = rng.next_mod(r), rng.next_mod(r)
-    V, F = po.permutation_argument(cols, S_id, S_sigma, q_last, q_blind, L0, beta, gamma, C.root_of_unity, r)
-    g, h, _ = po.permutation_grand_product(cols, S_id, S_sigma, beta, gamma, r)
-    nom = den = 1
-    for gi, hi in zip(g, h):
-        nom, den = nom * gi[n - 1] % r, den * hi[n - 1] % r
-    assert V[n - 1] * nom * pow(den, -1, r) % r == 1        # the permutation is satisfied: the grand product closes
+    parts = 1 if chunks == 0 else -(-k // (chunks - 1))
+    alphas = [rng.next_mod(r) for _ in range(parts - 1)]
+    res = po.permutation_argument(cols, S_id, S_sigma, q_last, q_blind, L0, beta, gamma, C.root_of_unity, r, chunks, alphas, usable)
+    V, F = res[0], res[1]
+    currents = res[2] if chunks else []
+    assert V[usable] == 1                                   # the permutation is satisfied: the grand product closes
     evals = fr_arr([x for v in cols + S_id + S_sigma + [q_last, q_blind, L0] for x in v])
     roots = np.stack([limbs(C.root_of_unity(l), 4) for l in range(log_n + 4)])
     out_vp = np.zeros((n, 4), dtype=np.uint64)
     out_F = np.zeros((3, 8 * n, 4), dtype=np.uint64)
     sizes = np.zeros(3, dtype=np.uint64)
-    rc = shim.shim_placeholder_permutation(curve, P(evals), ctypes.c_size_t(k), ctypes.c_size_t(log_n), P(roots), P(limbs(beta, 4)), P(limbs(gamma, 4)), P(out_vp),
-                                           P(out_F), P(sizes))
+    out_parts = np.zeros((max(1, parts - 1), n, 4), dtype=np.uint64)
+    al = np.stack([limbs(a, 4) for a in alphas] + [limbs(0, 4)])
+    rc = shim.shim_placeholder_permutation(curve, P(evals), ctypes.c_size_t(k), ctypes.c_size_t(log_n), P(roots), P(limbs(beta, 4)), P(limbs(gamma, 4)),
+                                           ctypes.c_size_t(chunks), P(al), ctypes.c_size_t(len(alphas)), ctypes.c_size_t(usable), P(out_vp), P(out_F), P(sizes),
+                                           P(out_parts))
     assert rc == 0
     assert fr_ints(out_vp) == V
+    for i, c in enumerate(currents):
+        assert fr_ints(out_parts[i]) == c, i
     for f in range(3):
         got = po.poly_trim(fr_ints(out_F[f][: int(sizes[f])]))
         assert got == F[f], f
 
 
-@pytest.mark.parametrize("curve,log_n,k_in,k_val,big", [(0, 6, 1, 1, ()), (1, 6, 2, 1, (1,)), (0, 7, 3, 2, (0,)), (0, 5, 1, 2, ())])
-def test_placeholder_lookup_argument_shim(shim, curve, log_n, k_in, k_val, big):
+@pytest.mark.parametrize("curve,log_n,k_in,k_val,big,part_sizes", [(0, 6, 1, 1, (), None), (1, 6, 2, 1, (1,), None), (0, 7, 3, 2, (0,), None), (0, 5, 1, 2, (), None),
+                                                                   (0, 6, 1, 1, (), [1, 1]), (1, 5, 2, 1, (1,), [2, 1]), (0, 6, 3, 2, (0,), [2, 1, 2])])
+def test_placeholder_lookup_argument_shim(shim, curve, log_n, k_in, k_val, big, part_sizes):
     """placeholder's lookup argument, prover side, from the sorted vectors on (hip/placeholder_lookup.hpp; lookup_argument.hpp:153-296, one part):
     V_L -- a serial loop with one inversion per row in the reference (compute_V_L, :375-409); the permutation argument's scan on the device --
     EXACTLY the oracle's row-by-row recurrence (zero behind usable_rows), and the four constraint polynomials equal to the oracle's dense
@@ -498,7 +485,10 @@ def test_placeholder_lookup_argument_shim(shim, curve, log_n, k_in, k_val, big):
     L0 = [1] + [0] * (n - 1)
     beta, gamma = rng.next_mod(r), rng.next_mod(r)
     alphas = [rng.next_mod(r) for _ in range(k_in + k_val - 1)]
-    V, F = po.lookup_argument(inputs, values, sorted_, q_last, q_blind, L0, beta, gamma, alphas, usable, C.root_of_unity, r)
+    part_alphas = [rng.next_mod(r) for _ in range(len(part_sizes) - 1)] if part_sizes else []
+    res = po.lookup_argument(inputs, values, sorted_, q_last, q_blind, L0, beta, gamma, alphas, usable, C.root_of_unity, r, part_sizes, part_alphas)
+    V, F = res[0], res[1]
+    currents = res[2] if part_sizes else []
     assert V[usable] == 1 and all(v == 0 for v in V[usable + 1:])
     evals = fr_arr([x for v in inputs + values + sorted_ + [q_last, q_blind, L0] for x in v])
     in_logs = np.array([len(f).bit_length() - 1 for f in inputs], dtype=np.uint64)
@@ -507,13 +497,39 @@ def test_placeholder_lookup_argument_shim(shim, curve, log_n, k_in, k_val, big):
     out_F = np.zeros((4, 16 * n, 4), dtype=np.uint64)
     sizes = np.zeros(4, dtype=np.uint64)
     al = np.stack([limbs(a, 4) for a in alphas] + [limbs(0, 4)])
+    ps = np.array(part_sizes or [], dtype=np.uint64)
+    pa = np.stack([limbs(a, 4) for a in part_alphas] + [limbs(0, 4)])
+    out_parts = np.zeros((max(1, len(currents)), n, 4), dtype=np.uint64)
     rc = shim.shim_placeholder_lookup(curve, P(evals), ctypes.c_size_t(k_in), P(in_logs), ctypes.c_size_t(k_val), ctypes.c_size_t(log_n), ctypes.c_size_t(usable),
-                                      P(roots), P(limbs(beta, 4)), P(limbs(gamma, 4)), P(al), P(out_vl), P(out_F), P(sizes))
+                                      P(roots), P(limbs(beta, 4)), P(limbs(gamma, 4)), P(al), P(ps) if len(ps) else None, ctypes.c_size_t(len(ps)), P(pa), P(out_vl),
+                                      P(out_F), P(sizes), P(out_parts))
     assert rc == 0
     assert fr_ints(out_vl) == V
+    for i, c in enumerate(currents):
+        assert fr_ints(out_parts[i]) == c, i
     for f in range(4):
         got = po.poly_trim(fr_ints(out_F[f][: int(sizes[f])]))
         assert got == F[f], f
+
+
+@pytest.mark.parametrize("curve,n", [(0, 64), (1, 48), (0, 1040), (1, 4096)])
+def test_column_range_polynomials_shim(shim, curve, n):
+    """detail::column_range_polynomials / column_polynomial (arithmetization/plonk/detail/column_polynomial.hpp:43-72): the columns of a
+    table to coefficient form by ONE batched inverse transform over the domain make_evaluation_domain returns for n rows (basic and
+    step radix-2 here), against the oracle's inverse transform over the same domain, column by column."""
+    C = CURVES[curve]
+    dom = po.make_evaluation_domain(C, n)
+    m, count = dom.m, 5
+    a = cp.random_fr(curve, 9100 + n, count * m).reshape(count, m, 4)
+    w, sh = limbs(dom.omega, 4), limbs(dom.shift, 4)
+    exp = np.stack([cp.domain_fft(curve, dom.kind, a[c], w, sh, inverse=True) for c in range(count)])
+    out = np.zeros((count, m, 4), dtype=np.uint64)
+    rc = shim.shim_column_polynomials(curve, P(a), ctypes.c_size_t(count), dom.kind, ctypes.c_size_t(m), P(w), P(sh), P(out))
+    assert rc == 0
+    assert (out == exp).all()
+    if m <= 64:
+        xs = dom.elements()
+        assert [po.poly_eval(fr_ints(out[0]), x, C.r) for x in xs] == fr_ints(a[0])
 
 
 @pytest.mark.parametrize("curve,log_n", [(0, 6), (1, 5)])

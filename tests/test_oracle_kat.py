@@ -411,9 +411,60 @@ def test_placeholder_lookup_argument_definitions(curve, log_n, k_in, k_val, big)
     for f in F:
         assert not any(on_rows(f))
     assert any(F[2])                                                # not the zero polynomial: the blinding rows carry junk
+    # the multi-part form (lookup_parts(max_quotient_chunks != 0), :243-276): F_2 is another polynomial that vanishes on the rows as well,
+    # the last intermediate polynomial times the last group's ratio is V_L one row on
+    if k_in + k_val > 1:
+        sizes = [1, k_in + k_val - 1] if k_in + k_val < 5 else [2, 1, 2]
+        pa = [rng.next_mod(r) for _ in range(len(sizes) - 1)]
+        V2, F2, cur = po.lookup_argument(inputs, values, sorted_, q_last, q_blind, L0, beta, gamma, alphas, usable, C.root_of_unity, r, part_sizes=sizes, part_alphas=pa)
+        assert V2 == V and F2[0] == F[0] and F2[1] == F[1] and F2[3] == F[3] and F2[2] != F[2]
+        assert not any(on_rows(F2[2])) and len(cur) == len(sizes) - 1 and all(c[usable:] == V[usable:] for c in cur)
     # a looked-up value that is in the table but one time too few in `sorted`: the product no longer closes
     bad = [list(v) for v in sorted_]
     j = next(j for j in range(1, usable - 1) if bad[0][j] != bad[0][j + 1] and bad[0][j] != 0)
     bad[0][j] = bad[0][j + 1]
     Vb, Fb = po.lookup_argument(inputs, values, bad, q_last, q_blind, L0, beta, gamma, alphas, usable, C.root_of_unity, r)
     assert Vb[usable] != 1 and any(on_rows(Fb[1]))
+
+
+@pytest.mark.parametrize("curve,log_n,k,chunks", [(0, 5, 3, 0), (0, 5, 3, 2), (1, 5, 4, 3), (0, 6, 5, 3)])
+def test_placeholder_permutation_argument_definitions(curve, log_n, k, chunks):
+    """The oracle's restatement of placeholder's permutation argument (permutation_argument.hpp:70-224), one-part and multi-part
+    (max_quotient_chunks != 0: groups of chunks - 1 factors, intermediate polynomials, :147-160, 188-207), against what the argument is FOR:
+    on a genuine copy-constraint instance (columns constant along the cycles of a permutation of the usable rows' cells, blinding rows
+    behind) the grand product closes at usable_rows and F_0, F_1, F_2 vanish on every row; a broken copy breaks F_2."""
+    from util import permutation_instance
+    C = CURVES[curve]
+    r = C.r
+    n = 1 << log_n
+    usable = n - 3
+    rng = po.SplitMix64(7900 + 10 * curve + log_n + k + chunks)
+    cols, S_id, S_sigma = permutation_instance(C, rng, log_n, k, usable)
+    q_last = [1 if j == usable else 0 for j in range(n)]
+    q_blind = [1 if j > usable else 0 for j in range(n)]
+    L0 = [1] + [0] * (n - 1)
+    beta, gamma = rng.next_mod(r), rng.next_mod(r)
+    parts = 1 if chunks == 0 else -(-k // (chunks - 1))
+    alphas = [rng.next_mod(r) for _ in range(parts - 1)]
+    res = po.permutation_argument(cols, S_id, S_sigma, q_last, q_blind, L0, beta, gamma, C.root_of_unity, r, chunks, alphas, usable)
+    V, F = res[0], res[1]
+    assert V[0] == 1 and V[usable] == 1
+
+    def on_rows(f):
+        out = [0] * n
+        for i, c in enumerate(f):
+            out[i % n] = (out[i % n] + c) % r
+        return out
+    for f in F:
+        assert not any(on_rows(f))
+    assert any(F[1])
+    if chunks:
+        assert len(res[2]) == parts - 1 and all(c[usable:] == V[usable:] for c in res[2])
+        V1, F1 = po.permutation_argument(cols, S_id, S_sigma, q_last, q_blind, L0, beta, gamma, C.root_of_unity, r)
+        assert V1 == V and F1[0] == F[0] and F1[2] == F[2]
+        # the multi-part F_1 has a lower degree than the one-part F_1: what the chunks are for
+        assert parts == 1 or len(F[1]) < len(F1[1])
+    bad = [list(c) for c in cols]
+    bad[0][1] = (bad[0][1] + 1) % r
+    Vb, Fb = po.permutation_argument(bad, S_id, S_sigma, q_last, q_blind, L0, beta, gamma, C.root_of_unity, r)[:2]
+    assert Vb[usable] != 1 and any(on_rows(Fb[2]))
