@@ -229,6 +229,7 @@ int zkhip_malloc(zkhip_ctx *ctx, size_t bytes, void **dptr) {
 int zkhip_free(zkhip_ctx *ctx, void *dptr) {
     if (!ctx) return ZKHIP_ERR_INVALID;
     if (!dptr) return ZKHIP_OK;
+    ZK_TRY(check_device(ctx));
     // hipFree used to synchronise the whole device before the block could be handed out again; a block entering the cache gets the same
     // guarantee -- no stream of ANY context (a scheme's upload stream, the prover's G2 stream) still reads or writes it
     ZK_HIP_CHECK(ctx, hipDeviceSynchronize());

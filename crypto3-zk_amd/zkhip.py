@@ -164,6 +164,11 @@ class Context:
     def set_option(self, name: str, value: int):
         self._check(self.lib.zkhip_set_option(self.h, name.encode(), ctypes.c_int64(value)), "zkhip_set_option")
 
+    def get_option(self, name: str) -> int:
+        v = ctypes.c_int64(0)
+        self._check(self.lib.zkhip_get_option(self.h, name.encode(), ctypes.byref(v)), "zkhip_get_option")
+        return int(v.value)
+
     # ---- device memory
     def malloc(self, nbytes: int) -> int:
         p = ctypes.c_void_p()

@@ -120,3 +120,104 @@ def test_poly_lincomb(ctx, curve):
     assert fr_ints(out) == [s * x % r for x in polys[0]]
     for d in ds + [d_acc]:
         ctx.free(d)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_fr_vec_affine_and_mul_div(ctx, curve):
+    """zkhip_fr_vec_affine_dev (a x + b y + c, y optional) and zkhip_fr_vec_mul_div_dev (a b / c over the first `count` entries, rows in
+    chunks of 8 sharing an inversion) through the C ABI against big-integer arithmetic: edge values, counts that are no multiple of the
+    chunk, in place, entries behind `count` untouched, empty."""
+    r = CURVES[curve].r
+    n = 1003
+    x = fr_ints(cp.random_fr(curve, 71, n))
+    y = fr_ints(cp.random_fr(curve, 72, n))
+    z = [v or 1 for v in fr_ints(cp.random_fr(curve, 73, n))]
+    x[:4] = [0, r - 1, 1, r - 1]
+    y[:4] = [0, r - 1, r - 1, 1]
+    z[:4] = [1, r - 1, 2, r - 2]
+    d_x, d_y, d_z, d_o = (ctx.malloc(n * 32) for _ in range(4))
+    ctx.h2d(d_x, fr_arr(x))
+    ctx.h2d(d_y, fr_arr(y))
+    ctx.h2d(d_z, fr_arr(z))
+    got = np.zeros((n, 4), dtype=np.uint64)
+    for a, b, c in ((3, 5, 7), (r - 1, r - 1, r - 1), (0, 1, 0), (1, 0, 0), (0, 0, r - 1), (12345678901234567890 % r, r - 2, 1)):
+        ctx.fr_vec_affine_dev(curve, d_x, d_y, limbs(a, 4), limbs(b, 4), limbs(c, 4), d_o, n)
+        ctx.d2h(got, d_o)
+        assert fr_ints(got) == [(a * u + b * v + c) % r for u, v in zip(x, y)], (a, b, c)
+        ctx.fr_vec_affine_dev(curve, d_x, 0, limbs(a, 4), None, limbs(c, 4), d_o, n)
+        ctx.d2h(got, d_o)
+        assert fr_ints(got) == [(a * u + c) % r for u in x], (a, c)
+    ctx.fr_vec_affine_dev(curve, d_x, 0, limbs(2, 4), None, limbs(1, 4), d_o, 0)     # empty
+    for count in (n, 1000, 9, 8, 7, 1):
+        ctx.h2d(d_o, fr_arr([7] * n))
+        ctx.fr_vec_mul_div_dev(curve, d_x, d_y, d_z, d_o, count)
+        ctx.d2h(got, d_o)
+        assert fr_ints(got) == [u * v % r * pow(w, -1, r) % r for u, v, w in zip(x[:count], y[:count], z[:count])] + [7] * (n - count), count
+    ctx.fr_vec_mul_div_dev(curve, d_x, d_y, d_z, d_x, n)                             # in place
+    ctx.d2h(got, d_x)
+    assert fr_ints(got) == [u * v % r * pow(w, -1, r) % r for u, v, w in zip(x, y, z)]
+    ctx.fr_vec_mul_div_dev(curve, d_x, d_y, d_z, d_o, 0)                             # empty
+    for p in (d_x, d_y, d_z, d_o):
+        ctx.free(p)
+
+
+@pytest.mark.parametrize("curve,n,usable,k_in,k_val", [(0, 64, 61, 1, 1), (1, 8, 4, 0, 2), (0, 2051, 2040, 2, 0), (0, 4096, 4095, 1, 2)])
+def test_lookup_grand_product_abi(ctx, curve, n, usable, k_in, k_val):
+    """zkhip_lookup_grand_product_dev through the C ABI on RANDOM vectors (no closing product needed: the recurrence is what is checked)
+    against the oracle's row-by-row loop (compute_V_L, lookup_argument.hpp:375-409): sizes that are no power of two or multiple of the
+    chunk, no inputs / no values, usable_rows = n - 1, zeros behind usable_rows; usable_rows >= n is refused."""
+    r = CURVES[curve].r
+    rng = po.SplitMix64(8300 + n + k_in)
+    vec = lambda: [rng.next_mod(r) for _ in range(n)]
+    inputs, values, sorted_ = [vec() for _ in range(k_in)], [vec() for _ in range(k_val)], [vec() for _ in range(k_in + k_val)]
+    beta, gamma = rng.next_mod(r), rng.next_mod(r)
+    exp = po.lookup_grand_product(inputs, values, sorted_, beta, gamma, usable, r)
+    ptrs = []
+    for v in inputs + values + sorted_:
+        d = ctx.malloc(n * 32)
+        ctx.h2d(d, fr_arr(v))
+        ptrs.append(d)
+    d_v = ctx.malloc(n * 32)
+    ctx.lookup_grand_product_dev(curve, ptrs[:k_in], ptrs[k_in:k_in + k_val], ptrs[k_in + k_val:], n, usable, limbs(beta, 4), limbs(gamma, 4), d_v)
+    got = np.zeros((n, 4), dtype=np.uint64)
+    ctx.d2h(got, d_v)
+    assert fr_ints(got) == exp
+    with pytest.raises(Exception):
+        ctx.lookup_grand_product_dev(curve, ptrs[:k_in], ptrs[k_in:k_in + k_val], ptrs[k_in + k_val:], n, n, limbs(beta, 4), limbs(gamma, 4), d_v)
+    for p in ptrs + [d_v]:
+        ctx.free(p)
+
+
+def test_block_cache_behind_malloc_free(ctx):
+    """zkhip_malloc / zkhip_free keep freed blocks for the next request of their size class (option alloc_cache_mb): a block
+    comes back for an equal or slightly smaller request, not for a much smaller or a larger one; its contents are whatever the last
+    owner left (no clearing promised, none relied on: every kernel writes what it reads back); alloc_cache_mb = 0 empties the cache and
+    turns it off; and the cache never hands out a block that is still live."""
+    assert ctx.get_option("alloc_cache_mb") == 16384
+    a = ctx.malloc(3 << 20)
+    ctx.free(a)
+    b = ctx.malloc(3 << 20)
+    assert b == a                                            # the cached block
+    c = ctx.malloc(3 << 20)
+    assert c != b                                            # b is live: a second block
+    ctx.free(b)
+    d = ctx.malloc((3 << 20) - 70000)                        # within an eighth of the block: taken
+    assert d == b
+    ctx.free(d)
+    e = ctx.malloc(1 << 20)                                  # a third of the block: not taken
+    assert e != b
+    f = ctx.malloc(4 << 20)                                  # larger: not taken
+    assert f not in (b, c, e)
+    data = np.arange(1 << 17, dtype=np.uint64)
+    ctx.h2d(f, data)
+    back = np.zeros_like(data)
+    ctx.d2h(back, f)
+    assert (back == data).all()
+    ctx.set_option("alloc_cache_mb", 0)                      # flush + off
+    assert ctx.get_option("alloc_cache_mb") == 0
+    for p in (c, e, f):
+        ctx.free(p)
+    g = ctx.malloc(3 << 20)
+    ctx.free(g)
+    ctx.set_option("alloc_cache_mb", 16384)
+    ctx.free(0)                                              # a null pointer is accepted
