@@ -337,6 +337,7 @@ def main():
             line["quotient_chain"] = quotient_leg(np, verify=not args.no_verify)
             line["permutation_argument"] = permutation_leg(np, verify=not args.no_verify)
             line["lookup_argument"] = lookup_leg(np, verify=not args.no_verify)
+            line["placeholder_round"] = placeholder_round_leg(np, verify=not args.no_verify)
         if world == 1 and not args.no_cpu_baseline:
             global CPU_GROTH16_LOG
             CPU_GROTH16_LOG = args.cpu_groth16_log
@@ -998,6 +999,34 @@ def lookup_leg(np, log_n=20, k_in=2, k_val=1, steps=6, verify=True):
             "roofline": {"bound": "hbm", "kernel": "perm_grand_product (3 launches: chunk ratios + workgroup scan, top scan, apply)", "achieved": round(ach, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None, "algorithmic_bytes": alg_gp,
                          "per": "V_L alone: 2 (k_in + k_val) input vectors read, 1 written, 32 B per element"}}
+
+
+def placeholder_round_leg(np, log_n=20, steps=5, verify=True):
+    """One placeholder-shaped prover round at BASELINE config 5's row count, the device pieces composed as placeholder_prover::process strings
+    them (prover.hpp:170-218, 262-277, 220-259, 314-317) over genuine instances: permutation argument (4 columns), lookup argument (2 inputs over
+    1 table), a gate argument, the quotient of their eight constraint polynomials, its split into 8 parts, and the commitments of V_P, V_L, the
+    sorted vectors and the quotient parts (13 MSMs of 2^20) -- every polynomial resident from the arguments to the KZG scheme."""
+    import ctypes
+
+    lib = _bench_lib()
+    ms = np.zeros(7 * steps, dtype=np.float64)
+    verified = ctypes.c_int(-1)
+    rc = lib.zkhip_bench_placeholder_round(0, ctypes.c_size_t(log_n), steps, ms.ctypes.data_as(ctypes.c_void_p), ctypes.byref(verified) if verify else None)
+    if rc != 0:
+        return {"error": rc}
+    ms = ms.reshape(steps, 7)
+    timed = ms[2:] if steps > 2 else ms    # the first two runs warm the transforms' tables and the context's block cache
+    names = ["permutation_argument", "lookup_argument_with_lookup_batch_commit", "permutation_batch_commit", "gate_argument", "quotient_polynomial", "split",
+             "quotient_batch_commit"]
+    return {"metric": "placeholder-shaped prover round, BLS12-381, 2^%d rows: permutation (4 columns) + lookup (2 inputs, 1 table) + gate arguments, quotient of 8 parts, "
+                      "split in 8, 13 commitments; resident" % log_n,
+            "value": round(float(np.median(timed.sum(axis=1))), 3), "unit": "ms per round", "higher_is_better": False,
+            "statistic": "median of the runs after the first two",
+            "ms_by_phase": {k: round(float(v), 3) for k, v in zip(names, np.median(timed, axis=0))},
+            "ms_per_run": [round(float(x), 2) for x in ms.sum(axis=1)],
+            "verified": None if not verify else bool(verified.value == 1),
+            "verification": "V_P[usable] = V_L[usable] = 1 (both grand products close over 2^20 rows), the division by X^n - 1 is exact, "
+                            "T(y)(y^n - 1) = sum_i alpha_i F_i(y) at a random y"}
 
 
 def ntt_sharded_leg(np, torch, dist, zk, ctx, rank, world, local_rank, log_m=22, batch=8, steps=5, verify=True):

@@ -81,6 +81,103 @@ struct vector_fold_builder {    // round 2's shape: the leaves materialised in a
 };
 }    // namespace
 
+namespace {
+
+struct splitmix {
+    uint64_t seed;
+    uint64_t operator()() {
+        uint64_t z = (seed += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    Fr nonzero() {
+        uint64_t w[4] = {(*this)() | 1, (*this)(), (*this)(), (*this)() & 0x0fffffffffffffffull};
+        return A::scalar_from_limbs(w);
+    }
+};
+
+/// a genuine lookup instance (see zkhip_bench_lookup): table columns, inputs drawn from them, `sorted` as sort_polynomials (:565-638) builds it
+void build_lookup_instance(splitmix &sm, size_t n, size_t usable, size_t k_in, size_t k_val, std::vector<polynomial_dfs<C>> &value, std::vector<polynomial_dfs<C>> &input,
+                           std::vector<polynomial_dfs<C>> &sorted) {
+    const size_t total = k_in + k_val, T = usable / 2;
+    value.assign(k_val, {});
+    input.assign(k_in, {});
+    sorted.assign(total, {});
+    std::vector<Fr> pool(1, Fr::zero());
+    for (auto &p : value) {
+        p.values.assign(n, Fr::zero());
+        for (size_t j = 1; j <= T; ++j) pool.push_back(p.values[j] = sm.nonzero());
+    }
+    std::vector<uint32_t> looked_up(pool.size(), 0);
+    for (auto &p : input) {
+        p.values.resize(n);
+        for (size_t j = 0; j < n; ++j) {
+            if (j < usable) {
+                const size_t idx = sm() % pool.size();
+                ++looked_up[idx];
+                p.values[j] = pool[idx];
+            } else {
+                p.values[j] = sm.nonzero();
+            }
+        }
+    }
+    // sort_polynomials: a zero at every 0 -> non-zero step of the table walk, then every value as often as it occurs in table + inputs
+    std::vector<Fr> flat;
+    size_t idx = 1;
+    for (size_t c = 0; c < k_val; ++c) {
+        flat.push_back(Fr::zero());
+        for (size_t j = 1; j <= T; ++j, ++idx) flat.insert(flat.end(), 1 + looked_up[idx], pool[idx]);
+    }
+    if (flat.size() > total * usable) throw std::runtime_error("lookup bench: instance does not fit");
+    for (auto &p : sorted) p.values.assign(n, Fr::zero());
+    for (size_t i = 0; i < flat.size(); ++i) sorted[i / usable].values[i % usable] = flat[i];
+    for (size_t i = 0; i + 1 < total; ++i) sorted[i].values[usable] = sorted[i + 1].values[0];
+}
+
+/// a genuine copy-constraint instance in placeholder's shape: k columns constant along the cycles of a random permutation of the k * usable cells of
+/// the usable rows, blinding rows (random values, identity permutation) behind; S_id[i][j] = delta^i omega^j
+void build_permutation_instance(splitmix &sm, size_t log_n, size_t usable, size_t k, std::vector<polynomial_dfs<C>> &cols, std::vector<polynomial_dfs<C>> &sid,
+                                std::vector<polynomial_dfs<C>> &ssig) {
+    const size_t n = (size_t)1 << log_n, cells = k * usable;
+    cols.assign(k, {});
+    sid.assign(k, {});
+    ssig.assign(k, {});
+    const Fr w = bls_root(log_n), delta(7);
+    Fr di = Fr::one();
+    for (size_t i = 0; i < k; ++i, di = di * delta) {
+        sid[i].values.resize(n);
+        Fr x = di;
+        for (size_t j = 0; j < n; ++j, x = x * w) sid[i].values[j] = x;
+    }
+    std::vector<uint32_t> perm(cells);
+    for (size_t c = 0; c < cells; ++c) perm[c] = (uint32_t)c;
+    for (size_t a = cells - 1; a > 0; --a) std::swap(perm[a], perm[sm() % (a + 1)]);
+    std::vector<uint8_t> seen(cells, 0);
+    for (size_t i = 0; i < k; ++i) {
+        cols[i].values.resize(n);
+        ssig[i].values.resize(n);
+    }
+    auto col_of = [usable](size_t c) { return c / usable; };
+    auto row_of = [usable](size_t c) { return c % usable; };
+    for (size_t c = 0; c < cells; ++c) {
+        if (seen[c]) continue;
+        const Fr v = sm.nonzero();
+        for (size_t x = c; !seen[x]; x = perm[x]) {
+            seen[x] = 1;
+            cols[col_of(x)].values[row_of(x)] = v;
+        }
+    }
+    for (size_t c = 0; c < cells; ++c) ssig[col_of(c)].values[row_of(c)] = sid[col_of(perm[c])].values[row_of(perm[c])];
+    for (size_t i = 0; i < k; ++i)
+        for (size_t j = usable; j < n; ++j) {
+            cols[i].values[j] = sm.nonzero();
+            ssig[i].values[j] = sid[i].values[j];
+        }
+}
+
+}    // namespace
+
 extern "C" {
 
 /* 50 (cols) polynomial_dfs of 2^log_n rows in HOST memory (evals: cols x n x 4 canonical limbs, row-major per column) ->
@@ -424,37 +521,10 @@ int zkhip_bench_lookup(int device, size_t log_n, size_t k_in, size_t k_val, int 
             uint64_t w[4] = {sm() | 1, sm(), sm(), sm() & 0x0fffffffffffffffull};    // never zero
             return A::scalar_from_limbs(w);
         };
-        std::vector<polynomial_dfs<C>> value(k_val), input(k_in), sorted(total);
-        std::vector<Fr> pool(1, Fr::zero());
-        for (auto &p : value) {
-            p.values.assign(n, Fr::zero());
-            for (size_t j = 1; j <= T; ++j) pool.push_back(p.values[j] = rnd());
-        }
-        std::vector<uint32_t> looked_up(pool.size(), 0);
-        for (auto &p : input) {
-            p.values.resize(n);
-            for (size_t j = 0; j < n; ++j) {
-                if (j < usable) {
-                    const size_t idx = sm() % pool.size();
-                    ++looked_up[idx];
-                    p.values[j] = pool[idx];
-                } else {
-                    p.values[j] = rnd();
-                }
-            }
-        }
-        {    // sort_polynomials: a zero at every 0 -> non-zero step of the table walk, then every value as often as it occurs in table + inputs
-            std::vector<Fr> flat;
-            size_t idx = 1;
-            for (size_t c = 0; c < k_val; ++c) {
-                flat.push_back(Fr::zero());
-                for (size_t j = 1; j <= T; ++j, ++idx) flat.insert(flat.end(), 1 + looked_up[idx], pool[idx]);
-            }
-            if (flat.size() > total * usable) throw std::runtime_error("lookup bench: instance does not fit");
-            for (auto &p : sorted) p.values.assign(n, Fr::zero());
-            for (size_t i = 0; i < flat.size(); ++i) sorted[i / usable].values[i % usable] = flat[i];
-            for (size_t i = 0; i + 1 < total; ++i) sorted[i].values[usable] = sorted[i + 1].values[0];
-        }
+        std::vector<polynomial_dfs<C>> value, input, sorted;
+        splitmix gen {seed};
+        build_lookup_instance(gen, n, usable, k_in, k_val, value, input, sorted);
+        seed = gen.seed;
         polynomial_dfs<C> hq_last, hq_blind, hl0;
         hq_last.values.assign(n, Fr::zero());
         hq_blind.values.assign(n, Fr::zero());
@@ -519,6 +589,135 @@ int zkhip_bench_lookup(int device, size_t log_n, size_t k_in, size_t k_val, int 
         return 0;
     } catch (const std::exception &e) {
         fprintf(stderr, "zkhip_bench_lookup: %s\n", e.what());
+        return -1;
+    }
+}
+
+/* One placeholder-shaped prover round at BASELINE config 5's row count, the pieces composed as placeholder_prover::process strings them
+ * (prover.hpp:170-218, 262-277, 220-259, 314-317) over GENUINE instances, every polynomial resident from the arguments to the commitments:
+ *   permutation argument (4 permuted columns, copy constraints closed inside the usable rows) -> V_P to PERMUTATION_BATCH,
+ *   lookup argument (2 inputs over 1 table column; sorted -> LOOKUP_BATCH + commit, V_L -> PERMUTATION_BATCH) + commit(PERMUTATION_BATCH),
+ *   gate argument q (w0 w1 - w2) masked by 1 - q_last - q_blind over the 4n-point domain,
+ *   quotient of the eight constraint polynomials (domains 2n .. 8n) by X^n - 1 -- exact: every part vanishes on the rows --, split into 8 parts,
+ *   commit(QUOTIENT_BATCH).
+ * ms: steps x {permutation, lookup (with its LOOKUP_BATCH commit), PERMUTATION_BATCH commit, gate argument, quotient, split, QUOTIENT_BATCH commit}.
+ * *verified: V_P[usable] = V_L[usable] = 1, the division left no remainder (quotient_polynomial throws otherwise) and
+ * T(y) (y^n - 1) == sum_i alpha_i F_i(y) at a random y, every polynomial evaluated from its coefficient form. */
+int zkhip_bench_placeholder_round(int device, size_t log_n, int steps, double *ms, int *verified) {
+    try {
+        typedef placeholder_quotient_hip<C> Q;
+        typedef placeholder_permutation_hip<C> PA;
+        typedef placeholder_lookup_hip<C> LA;
+        typedef device_polynomial_dfs<C> dfs;
+        const size_t n = (size_t)1 << log_n, usable = n - 4, k = 4;
+        context ctx(device);
+        splitmix sm {4242};
+        std::vector<polynomial_dfs<C>> h_cols, h_sid, h_ssig, h_val, h_in, h_sorted;
+        build_permutation_instance(sm, log_n, usable, k, h_cols, h_sid, h_ssig);
+        build_lookup_instance(sm, n, usable, 2, 1, h_val, h_in, h_sorted);
+        polynomial_dfs<C> hq, hw0, hw1, hw2, hq_last, hq_blind, hl0;
+        for (auto *p : {&hq, &hw0, &hw1, &hw2, &hq_last, &hq_blind, &hl0}) p->values.assign(n, Fr::zero());
+        for (size_t j = 0; j < n; ++j) {
+            hq.values[j] = (j % 3 == 0 && j < usable) ? Fr::one() : Fr::zero();
+            hw0.values[j] = sm.nonzero();
+            hw1.values[j] = sm.nonzero();
+            hw2.values[j] = hq.values[j] == Fr::one() ? hw0.values[j] * hw1.values[j] : sm.nonzero();
+        }
+        hq_last.values[usable] = Fr::one();
+        for (size_t j = usable + 1; j < n; ++j) hq_blind.values[j] = Fr::one();
+        hl0.values[0] = Fr::one();
+        auto up = [&](std::vector<polynomial_dfs<C>> &v) {
+            std::vector<dfs> out;
+            for (auto &p : v) out.emplace_back(ctx, p, n - 1);
+            std::vector<polynomial_dfs<C>>().swap(v);
+            return out;
+        };
+        std::vector<dfs> cols = up(h_cols), sid = up(h_sid), ssig = up(h_ssig), l_val = up(h_val), l_in = up(h_in), sorted = up(h_sorted);
+        dfs q(ctx, hq, n - 1), w0(ctx, hw0, n - 1), w1(ctx, hw1, n - 1), w2(ctx, hw2, n - 1), q_last(ctx, hq_last, n - 1), q_blind(ctx, hq_blind, n - 1),
+            lagrange_0(ctx, hl0, n - 1);
+        std::vector<Fr> pw(n);
+        Fr x = Fr::one(), alpha(7);
+        for (size_t i = 0; i < n; ++i) pw[i] = x, x = x * alpha;
+        kzg_params_hip<C> params(ctx, device_bases<C, ZKHIP_G1>::from_scalars(ctx, pw.begin(), pw.end()));
+        std::vector<Fr>().swap(pw);
+        const Fr bp = sm.nonzero(), gp = sm.nonzero(), bl = sm.nonzero(), gl = sm.nonzero();
+        const std::vector<Fr> l_alphas = {sm.nonzero(), sm.nonzero()};
+        std::vector<Fr> alphas;
+        for (int i = 0; i < 8; ++i) alphas.push_back(sm.nonzero());
+        std::vector<dfs> F;
+        typename Q::device_coefficients T;
+        std::unique_ptr<PA::prover_result_type> perm;
+        std::unique_ptr<LA::prover_result_type> look;
+        constexpr std::size_t PERMUTATION_BATCH = 2, QUOTIENT_BATCH = 3, LOOKUP_BATCH = 4;
+        for (int rep = 0; rep < steps; ++rep) {
+            double *t = ms + 7 * rep;
+            kzg_commitment_scheme_v2_hip<C, counting_transcript> scheme(params, bls_root);
+            ctx.sync();
+            auto t0 = std::chrono::steady_clock::now();
+            perm.reset(new PA::prover_result_type(PA::prove_eval(ctx, cols, sid, ssig, q_last, q_blind, lagrange_0, bp, gp, bls_root)));
+            scheme.append_to_batch(PERMUTATION_BATCH, perm->permutation_polynomial_dfs);
+            t[0] = ms_since(t0);
+            t0 = std::chrono::steady_clock::now();
+            scheme.append_to_batch(LOOKUP_BATCH, sorted);
+            auto lookup_commit = scheme.commit(LOOKUP_BATCH);
+            look.reset(new LA::prover_result_type(LA::prove_eval(ctx, l_in, l_val, sorted, q_last, q_blind, lagrange_0, bl, gl, l_alphas, usable, bls_root)));
+            scheme.append_to_batch(PERMUTATION_BATCH, look->V_L);
+            t[1] = ms_since(t0);
+            t0 = std::chrono::steady_clock::now();
+            auto perm_commit = scheme.commit(PERMUTATION_BATCH);
+            t[2] = ms_since(t0);
+            t0 = std::chrono::steady_clock::now();
+            dfs mask = LA::affine(q_last, &q_blind, Fr::zero() - Fr::one(), Fr::zero() - Fr::one(), Fr::one());
+            gate_product_hip<C> g1, g2;
+            g1.factors = {&q, &w0, &w1};
+            g1.rotations = {0, 0, 0};
+            g1.coefficient = Fr::one();
+            g2.factors = {&q, &w2};
+            g2.rotations = {0, 0};
+            g2.coefficient = Fr::zero() - Fr::one();
+            dfs G = Q::gate_argument(ctx, {g1, g2}, mask, 4 * n, bls_root);
+            ctx.sync();
+            t[3] = ms_since(t0);
+            t0 = std::chrono::steady_clock::now();
+            F = {perm->F_dfs[0], perm->F_dfs[1], perm->F_dfs[2], look->F_dfs[0], look->F_dfs[1], look->F_dfs[2], look->F_dfs[3], G};
+            T = Q::quotient_polynomial(ctx, F, alphas, n, bls_root);
+            t[4] = ms_since(t0);
+            t0 = std::chrono::steady_clock::now();
+            auto parts = Q::quotient_polynomial_split_dfs(ctx, T, n, 8, n, bls_root);
+            t[5] = ms_since(t0);
+            t0 = std::chrono::steady_clock::now();
+            scheme.append_to_batch(QUOTIENT_BATCH, parts);
+            auto t_commit = scheme.commit(QUOTIENT_BATCH);
+            t[6] = ms_since(t0);
+            if (lookup_commit.size() != 3 || perm_commit.size() != 2 || t_commit.size() != 8) throw std::runtime_error("placeholder round: batch sizes");
+        }
+        if (verified) {
+            uint64_t one_at[4];
+            auto at_row = [&](const dfs &p, size_t row) {
+                ctx.d2h(one_at, static_cast<const char *>(p.data()) + 32 * row, 32);
+                return A::scalar_from_limbs(one_at);
+            };
+            bool ok = at_row(perm->permutation_polynomial_dfs, usable) == Fr::one() && at_row(look->V_L, usable) == Fr::one();
+            const Fr y = sm.nonzero();
+            uint64_t yl[4], v[4];
+            A::scalar_to_limbs(y, yl);
+            auto eval = [&](const void *d, size_t len) {
+                check(zkhip_poly_eval_dev(ctx.get(), A::id, d, len, len, 1, yl, 1, v), "zkhip_poly_eval_dev", ctx.get());
+                return A::scalar_from_limbs(v);
+            };
+            Fr rhs = Fr::zero();
+            for (size_t i = 0; i < F.size(); ++i) {
+                auto c = F[i].coefficients(bls_root);
+                rhs = rhs + alphas[i] * eval(c.get(), F[i].size());
+            }
+            Fr yn = y;
+            for (size_t b = 0; b < log_n; ++b) yn = yn * yn;
+            ok = ok && eval(T.data.get(), T.size) * (yn - Fr::one()) == rhs;
+            *verified = ok ? 1 : 0;
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkhip_bench_placeholder_round: %s\n", e.what());
         return -1;
     }
 }
