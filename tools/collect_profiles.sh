@@ -16,6 +16,10 @@ rm -rf /tmp/rp2 && ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rp2 -o 
 cp $(find /tmp/rp2 -name '*kernel_stats.csv' | head -1) gpurun_out/${R}_rocprofv3_kernel_stats_groth16.csv 2>/dev/null
 rm -rf /tmp/rp3 && ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rp3 -o kzg --output-format csv -- python3 "$root/tools/bench_kzg.py" > /tmp/rp3.log 2>&1 )
 cp $(find /tmp/rp3 -name '*kernel_stats.csv' | head -1) gpurun_out/${R}_rocprofv3_kernel_stats_kzg.csv 2>/dev/null
+# the placeholder legs (round, lookup, permutation): the lines and their kernel table
+python3 tools/run_placeholder_legs.py > gpurun_out/${R}_placeholder_legs.json 2>/dev/null
+rm -rf /tmp/rp4 && ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rp4 -o ph --output-format csv -- python3 "$root/tools/run_placeholder_legs.py" > /tmp/rp4.log 2>&1 )
+cp $(find /tmp/rp4 -name '*kernel_stats.csv' | head -1) gpurun_out/${R}_rocprofv3_kernel_stats_placeholder_legs.csv 2>/dev/null
 # PMC: one counter group per pass (FETCH_SIZE / WRITE_SIZE in passes of their own), over the MSM + NTT workload of tools/pmc_child.py
 tools/pmc_collect.sh gpurun_out/${R}_pmc_msm_ntt.json tools/pmc_child.py 20 > /dev/null 2>&1
 PMC_GROUPS="GRBM_GUI_ACTIVE;SQ_BUSY_CYCLES SQ_WAVES" tools/pmc_collect.sh gpurun_out/${R}_pmc_clock.json tools/pmc_child.py 20 > /dev/null 2>&1
