@@ -4,7 +4,8 @@
 Every iteration draws a shape the fixed tests do not enumerate -- curve, group, size (1 .. 6000, not only powers of two), offset,
 scalar pattern (uniform, zeros / ones heavy, r - 1, few distinct values = large buckets, tiny values), MSM one by one / as a batch /
 as a batch whose members share a sort, NTT size / batch / direction / coset, evaluation domain of any kind, Groth16 witness map over the
-domain make_evaluation_domain picks, whole Groth16 proofs through the C++ shim -- and compares bit for bit.  Exit code 0 and a JSON line with the counts = no difference."""
+domain make_evaluation_domain picks, whole Groth16 proofs through the C++ shim, the grand products / pointwise kernels behind placeholder's
+permutation and lookup arguments on vectors of any length -- and compares bit for bit.  Exit code 0 and a JSON line with the counts = no difference."""
 import argparse
 import json
 import os
@@ -160,6 +161,76 @@ def fuzz_proof(zk, ctx, rng, stats):
     stats["groth16_proof"] += 1
 
 
+def _up(ctx, vals):
+    from util import fr_arr
+    d = ctx.malloc(max(1, len(vals)) * 32)
+    if len(vals):
+        ctx.h2d(d, fr_arr(vals))
+    return d
+
+
+def _down(ctx, d, n):
+    from util import fr_ints
+    out = np.zeros((n, 4), dtype=np.uint64)
+    if n:
+        ctx.d2h(out, d)
+    return fr_ints(out)
+
+
+def fuzz_arguments(zk, ctx, rng, stats):
+    """the kernels behind placeholder's permutation / lookup arguments through the C ABI on random vectors of any length (the recurrences are what
+    is compared, no closing product needed): the two grand products against the oracle's row-by-row loops, a x + b y + c and a b / c against
+    big integers"""
+    curve = int(rng.integers(0, 2))
+    r = CURVES[curve].r
+    n = int(rng.integers(1, 3000 * SCALE))
+    srng = po.SplitMix64(int(rng.integers(1, 1 << 30)))
+    vec = lambda: [srng.next_mod(r) if rng.random() < 0.97 else int(rng.integers(0, 2)) * (r - 1) for _ in range(n)]
+    beta, gamma = srng.next_mod(r), srng.next_mod(r)
+    which = int(rng.integers(0, 3))
+    if which == 0:
+        k = int(rng.integers(1, 5))
+        cols, sid, ssig = [vec() for _ in range(k)], [vec() for _ in range(k)], [vec() for _ in range(k)]
+        g, h, V = po.permutation_grand_product(cols, sid, ssig, beta, gamma, r)
+        ptrs = [_up(ctx, v) for v in cols + sid + ssig]
+        d_g, d_h, d_v = ctx.malloc(k * n * 32), ctx.malloc(k * n * 32), ctx.malloc(n * 32)
+        ctx.perm_grand_product_dev(curve, ptrs[:k], ptrs[k:2 * k], ptrs[2 * k:], n, limbs(beta, 4), limbs(gamma, 4), d_g, d_h, d_v)
+        ok = _down(ctx, d_v, n) == V and _down(ctx, d_g, k * n) == [x for v in g for x in v] and _down(ctx, d_h, k * n) == [x for v in h for x in v]
+        for p_ in ptrs + [d_g, d_h, d_v]:
+            ctx.free(p_)
+        if not ok:
+            raise SystemExit("permutation grand product differs: curve %d n %d k %d" % (curve, n, k))
+    elif which == 1:
+        if n < 2:
+            return
+        k_in, k_val = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+        usable = int(rng.integers(0, n))
+        inputs, values, sorted_ = [vec() for _ in range(k_in)], [vec() for _ in range(k_val)], [vec() for _ in range(max(1, k_in + k_val))]
+        V = po.lookup_grand_product(inputs, values, sorted_, beta, gamma, usable, r)
+        ptrs = [_up(ctx, v) for v in inputs + values + sorted_]
+        d_v = ctx.malloc(n * 32)
+        ctx.lookup_grand_product_dev(curve, ptrs[:k_in], ptrs[k_in:k_in + k_val], ptrs[k_in + k_val:], n, usable, limbs(beta, 4), limbs(gamma, 4), d_v)
+        ok = _down(ctx, d_v, n) == V
+        for p_ in ptrs + [d_v]:
+            ctx.free(p_)
+        if not ok:
+            raise SystemExit("lookup grand product differs: curve %d n %d k_in %d k_val %d usable %d" % (curve, n, k_in, k_val, usable))
+    else:
+        x, y, z = vec(), vec(), [v or 1 for v in vec()]
+        a, b, c = srng.next_mod(r), srng.next_mod(r), srng.next_mod(r)
+        count = int(rng.integers(0, n + 1))
+        d_x, d_y, d_z, d_o = _up(ctx, x), _up(ctx, y), _up(ctx, z), _up(ctx, [5] * n)
+        ctx.fr_vec_mul_div_dev(curve, d_x, d_y, d_z, d_o, count)
+        ok = _down(ctx, d_o, n) == [u * v % r * pow(w, -1, r) % r for u, v, w in zip(x[:count], y[:count], z[:count])] + [5] * (n - count)
+        ctx.fr_vec_affine_dev(curve, d_x, d_y, limbs(a, 4), limbs(b, 4), limbs(c, 4), d_o, n)
+        ok = ok and _down(ctx, d_o, n) == [(a * u + b * v + c) % r for u, v in zip(x, y)]
+        for p_ in (d_x, d_y, d_z, d_o):
+            ctx.free(p_)
+        if not ok:
+            raise SystemExit("vector affine / mul-div differs: curve %d n %d count %d" % (curve, n, count))
+    stats["argument_kernels"] += 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
@@ -171,8 +242,8 @@ def main():
     zk = bench.load_pkg()
     ctx = zk.Context(0)
     rng = np.random.default_rng(a.seed)
-    stats = {"msm": 0, "ntt": 0, "domain": 0, "domain_skipped": 0, "witness_map": 0, "groth16_proof": 0}
-    legs = [fuzz_msm, fuzz_msm, fuzz_ntt, fuzz_domain, fuzz_witness, fuzz_proof]
+    stats = {"msm": 0, "ntt": 0, "domain": 0, "domain_skipped": 0, "witness_map": 0, "groth16_proof": 0, "argument_kernels": 0}
+    legs = [fuzz_msm, fuzz_msm, fuzz_ntt, fuzz_domain, fuzz_witness, fuzz_proof, fuzz_arguments]
     t0 = time.time()
     while time.time() - t0 < a.seconds:
         legs[int(rng.integers(0, len(legs)))](zk, ctx, rng, stats)
