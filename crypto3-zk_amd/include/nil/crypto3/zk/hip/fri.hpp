@@ -130,16 +130,18 @@ private:
 
 /// math::polynomial_product(multipliers) (ph/permutation_argument.hpp:148, gates_argument.hpp:117): the product of k
 /// DFS polynomials on the smallest power-of-two domain that holds its degree (sum of the degrees): every factor is
-/// resized to it, then ONE k-way pointwise pass multiplies them.
+/// resized to it, then ONE k-way pointwise pass multiplies them.  A factor may arrive on a LARGER domain than the product's (a polynomial
+/// a caller extended once for several products): it is subsampled, which costs no transform.  `min_size`: a floor for the product's
+/// domain, for a result that is combined with polynomials living there afterwards.
 template <typename CurveType>
 device_polynomial_dfs<CurveType> polynomial_product(std::vector<device_polynomial_dfs<CurveType>> multipliers,
-                                                    const typename device_polynomial_dfs<CurveType>::root_of_unity_type &root) {
+                                                    const typename device_polynomial_dfs<CurveType>::root_of_unity_type &root, std::size_t min_size = 0) {
     typedef curve_adapter<CurveType> adapter;
     if (multipliers.empty()) throw std::invalid_argument("polynomial_product: no factors");
     const context &ctx = multipliers[0].ctx();
     std::size_t degree = 0, size = 1;
     for (const auto &m : multipliers) degree += m.degree();
-    while (size < degree + 1) size <<= 1;
+    while (size < degree + 1 || size < min_size) size <<= 1;
     std::vector<const void *> ptrs;
     for (auto &m : multipliers) {
         m.resize(size, root);

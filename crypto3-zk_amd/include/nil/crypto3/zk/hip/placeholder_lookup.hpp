@@ -128,26 +128,34 @@ struct placeholder_lookup_hip {
         }
         g_multipliers.clear();
         h_multipliers.clear();
-        dfs_type V_L_shifted = polynomial_shift(V_L, 1, n);
+        /* V_L takes part in five products on three domains: extended ONCE, to the largest of them (that of V_L g), subsampled for the others
+           inside polynomial_product; V_L(omega X) is a rotation of that extension; likewise lagrange_0 and q_last */
+        std::size_t deg_g = 0;
+        for (const auto &g : gs) deg_g = std::max(deg_g, g.degree());
+        const dfs_type V = PA::extended(V_L, PA::pow2_holding(V_L.degree() + deg_g), root);
+        const dfs_type V_shifted = polynomial_shift(V, 1, n);
+        const dfs_type L0 = PA::extended(lagrange_0, 2 * n, root), QL = PA::extended(q_last, 4 * n, root);
         prover_result_type res {{dfs_type(ctx, 1), dfs_type(ctx, 1), dfs_type(ctx, 1), dfs_type(ctx, 1)}, V_L, {}};
         /* F_dfs[0] = lagrange_0 (1 - V_L) = lagrange_0 - lagrange_0 V_L */
-        res.F_dfs[0] = minus(lagrange_0, polynomial_product<CurveType>({lagrange_0, V_L}, root), root);
-        /* F_dfs[1] = q_last (V_L V_L - V_L) */
-        res.F_dfs[1] = minus(polynomial_product<CurveType>({q_last, V_L, V_L}, root), polynomial_product<CurveType>({q_last, V_L}, root), root);
+        res.F_dfs[0] = minus(L0, polynomial_product<CurveType>({L0, V}, root, L0.size()), root);
+        /* F_dfs[1] = q_last (V_L V_L - V_L), both products on the first one's domain */
+        res.F_dfs[1] = minus(polynomial_product<CurveType>({QL, V, V}, root), polynomial_product<CurveType>({QL, V}, root, QL.size()), root);
         /* F_dfs[2] = ((q_last + q_blind) - 1) T = q T - T,  T = V_L g - V_L_shifted h (one part),
            T = sum_i alpha_i (previous g_i - current h_i) + previous g_last - V_L_shifted h_last (several) */
-        dfs_type T(ctx, 1), previous = V_L;
+        dfs_type T(ctx, 1), previous = V_L, previous_ext = V;
         const std::size_t parts = part_sizes.size();
         for (std::size_t p = 0; p + 1 < parts; ++p) {
             dfs_type current = PA::multiplied_up(previous, V_L, gs[p], hs[p], n, usable_rows);
             res.parts_dfs.push_back(current);
-            dfs_type part = minus(polynomial_product<CurveType>({previous, gs[p]}, root), polynomial_product<CurveType>({current, hs[p]}, root), root);
+            const dfs_type current_ext = PA::extended(current, V.size(), root);    // once for current h_p and, as the next previous, for previous g_(p + 1)
+            dfs_type part = minus(polynomial_product<CurveType>({previous_ext, gs[p]}, root), polynomial_product<CurveType>({current_ext, hs[p]}, root), root);
             PA::scale(part, part_alphas[p]);
             T = p == 0 ? part : PA::plus(T, part, root);
             previous = current;
+            previous_ext = current_ext;
         }
         {
-            dfs_type last = minus(polynomial_product<CurveType>({previous, gs[parts - 1]}, root), polynomial_product<CurveType>({V_L_shifted, hs[parts - 1]}, root), root);
+            dfs_type last = minus(polynomial_product<CurveType>({previous_ext, gs[parts - 1]}, root), polynomial_product<CurveType>({V_shifted, hs[parts - 1]}, root), root);
             T = parts == 1 ? last : PA::plus(T, last, root);
         }
         dfs_type q = affine(q_last, &q_blind, one, one, zero);
@@ -165,7 +173,7 @@ struct placeholder_lookup_hip {
                     sum += part;
             }
             sum.set_degree(n - 1);
-            res.F_dfs[3] = polynomial_product<CurveType>({sum, lagrange_0}, root);
+            res.F_dfs[3] = polynomial_product<CurveType>({sum, L0}, root);
         } else {
             res.F_dfs[3] = affine(lagrange_0, nullptr, zero, zero, zero);    // zero_polynomial
             res.F_dfs[3].set_degree(0);

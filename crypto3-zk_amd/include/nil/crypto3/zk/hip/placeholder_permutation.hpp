@@ -88,34 +88,42 @@ struct placeholder_permutation_hip {
             gs.push_back(polynomial_product<CurveType>(std::move(g_v), root));
             hs.push_back(polynomial_product<CurveType>(std::move(h_v), root));
         }
-        dfs_type V_P_shifted = polynomial_shift(V_P, 1, n);
+        /* V_P takes part in five products on three domains: it is extended ONCE, to the largest of them (that of V_P g), and subsampled for the
+           others inside polynomial_product; V_P(omega X) is a rotation of that extension; likewise lagrange_0 and q_last */
+        std::size_t deg_g = 0;
+        for (const auto &g : gs) deg_g = std::max(deg_g, g.degree());
+        const dfs_type V = extended(V_P, pow2_holding(V_P.degree() + deg_g), root);
+        const dfs_type V_shifted = polynomial_shift(V, 1, n);
+        const dfs_type L0 = extended(lagrange_0, 2 * n, root), QL = extended(q_last, 4 * n, root);
         prover_result_type res {{dfs_type(ctx, 1), dfs_type(ctx, 1), dfs_type(ctx, 1)}, V_P, {}};
         /* F_dfs[0] = lagrange_0 (1 - V_P) = lagrange_0 - lagrange_0 V_P */
-        res.F_dfs[0] = minus(lagrange_0, polynomial_product<CurveType>({lagrange_0, V_P}, root), root);
+        res.F_dfs[0] = minus(L0, polynomial_product<CurveType>({L0, V}, root, L0.size()), root);
         dfs_type q(ctx, n);    // q_last + q_blind, in a buffer of its own
         q.set_degree(std::max(q_last.degree(), q_blind.degree()));
         check(zkhip_fr_vec_op_dev(ctx.get(), adapter::id, 0, q_last.data(), q_blind.data(), q.data(), n), "zkhip_fr_vec_op_dev", ctx.get());
         if (parts == 1) {
             /* F_dfs[1] = (1 - q)(V_P_shifted h - V_P g) = T - q T,  q = q_last + q_blind */
-            dfs_type T = minus(polynomial_product<CurveType>({V_P_shifted, hs[0]}, root), polynomial_product<CurveType>({V_P, gs[0]}, root), root);
+            dfs_type T = minus(polynomial_product<CurveType>({V_shifted, hs[0]}, root), polynomial_product<CurveType>({V, gs[0]}, root), root);
             res.F_dfs[1] = minus(T, polynomial_product<CurveType>({q, T}, root), root);
         } else {
             /* F_dfs[1] = (q - 1)(sum_i alpha_i (previous g_i - current h_i) + previous g_last - V_P_shifted h_last) = q S - S */
-            dfs_type previous = V_P, S(ctx, 1);
+            dfs_type previous = V_P, previous_ext = V, S(ctx, 1);
             for (std::size_t p = 0; p + 1 < parts; ++p) {
                 dfs_type current = multiplied_up(previous, V_P, gs[p], hs[p], n, usable_rows);
                 res.parts_dfs.push_back(current);
-                dfs_type part = minus(polynomial_product<CurveType>({previous, gs[p]}, root), polynomial_product<CurveType>({current, hs[p]}, root), root);
+                const dfs_type current_ext = extended(current, V.size(), root);    // once for current h_p and, as the next previous, for previous g_(p + 1)
+                dfs_type part = minus(polynomial_product<CurveType>({previous_ext, gs[p]}, root), polynomial_product<CurveType>({current_ext, hs[p]}, root), root);
                 scale(part, alphas[p]);
                 S = p == 0 ? part : plus(S, part, root);
                 previous = current;
+                previous_ext = current_ext;
             }
-            dfs_type last = minus(polynomial_product<CurveType>({previous, gs[parts - 1]}, root), polynomial_product<CurveType>({V_P_shifted, hs[parts - 1]}, root), root);
+            dfs_type last = minus(polynomial_product<CurveType>({previous_ext, gs[parts - 1]}, root), polynomial_product<CurveType>({V_shifted, hs[parts - 1]}, root), root);
             S = plus(S, last, root);
             res.F_dfs[1] = minus(polynomial_product<CurveType>({q, S}, root), S, root);
         }
-        /* F_dfs[2] = q_last V_P (V_P - 1) = q_last V_P V_P - q_last V_P */
-        res.F_dfs[2] = minus(polynomial_product<CurveType>({q_last, V_P, V_P}, root), polynomial_product<CurveType>({q_last, V_P}, root), root);
+        /* F_dfs[2] = q_last V_P (V_P - 1) = q_last V_P V_P - q_last V_P, both products on the first one's domain */
+        res.F_dfs[2] = minus(polynomial_product<CurveType>({QL, V, V}, root), polynomial_product<CurveType>({QL, V}, root, QL.size()), root);
         ctx.sync();
         return res;
     }
@@ -131,6 +139,17 @@ struct placeholder_permutation_hip {
         check(zkhip_fr_vec_mul_div_dev(ctx.get(), adapter::id, previous.data(), rg.data(), rh.data(), current.data(), usable_rows), "zkhip_fr_vec_mul_div_dev", ctx.get());
         ctx.sync();    // rg, rh are released on return
         return current;
+    }
+    /// p on the `size`-point domain (a copy with a buffer of its own; p itself where it already lives there)
+    static dfs_type extended(const dfs_type &p, std::size_t size, const root_of_unity_type &root) {
+        dfs_type e = p;
+        if (size > p.size()) e.resize(size, root);
+        return e;
+    }
+    static std::size_t pow2_holding(std::size_t degree) {
+        std::size_t size = 1;
+        while (size < degree + 1) size <<= 1;
+        return size;
     }
     static dfs_type reduced(const dfs_type &p, std::size_t n) {
         if (p.size() == n) return p;

@@ -127,32 +127,25 @@ struct placeholder_quotient_hip {
         std::size_t size = 0;
         for (const auto &f : F_dfs) size = std::max(size, f.size());
         if (size < 2 * rows_amount) size = 2 * rows_amount;    // at least one quotient coefficient block
-        std::vector<dfs_type> parts;
+        /* The reference adds the parts in DFS form on the largest domain and inverts the sum (:262-273).  The coefficients of a sum are the sum
+           of the coefficients: every part is inverted on ITS OWN domain (an inverse transform of its size instead of an extension to the largest
+           one) and the weighted coefficient vectors are added in one pass -- the same field elements, about half the transform work */
+        std::vector<std::shared_ptr<void>> parts;
         std::vector<const void *> ptrs;
         std::vector<std::size_t> lens;
         std::vector<std::uint64_t> coeffs;
         for (std::size_t i = 0; i < F_dfs.size(); ++i) {
             if (F_dfs[i].size() == 0) continue;
-            dfs_type p = F_dfs[i];
-            p.resize(size, root);
-            parts.push_back(std::move(p));
+            parts.push_back(F_dfs[i].coefficients(root));
+            ptrs.push_back(parts.back().get());
+            lens.push_back(F_dfs[i].size());
             std::uint64_t a[4];
             adapter::scalar_to_limbs(alphas[i], a);
             coeffs.insert(coeffs.end(), a, a + 4);
         }
-        for (const auto &p : parts) {
-            ptrs.push_back(p.data());
-            lens.push_back(size);
-        }
-        dfs_type F(ctx, size);
+        dfs_type F(ctx, size);    // holds COEFFICIENTS from here on
         check(zkhip_poly_lincomb_dev(ctx.get(), adapter::id, ptrs.size(), ptrs.data(), lens.data(), coeffs.data(), 1, F.data(), size, 0), "zkhip_poly_lincomb_dev",
               ctx.get());
-        /* F_consolidated_dfs.coefficients() (:273), in place: F is a temporary */
-        std::size_t log_size = 0;
-        while (((std::size_t)1 << log_size) < size) ++log_size;
-        std::uint64_t w[4];
-        adapter::scalar_to_limbs(root(log_size), w);
-        check(zkhip_ntt_dev(ctx.get(), adapter::id, F.data(), log_size, 1, w, 1, nullptr), "zkhip_ntt_dev", ctx.get());
         /* T_consolidated = F_consolidated_normal / common_data.Z (:275) */
         device_coefficients T;
         T.size = size - rows_amount;
