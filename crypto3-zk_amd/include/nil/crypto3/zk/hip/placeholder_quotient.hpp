@@ -53,7 +53,7 @@ struct placeholder_quotient_hip {
     /// gates_argument.hpp:203-216: F = (sum over the gates' products) * mask_polynomial on the extended domain of `extended_size`
     /// points (original_domain->m * 2^ceil(log2(max_gates_degree + 1)), :149-150).
     static dfs_type gate_argument(const context &ctx, const std::vector<gate_product_hip<CurveType>> &products, const dfs_type &mask_polynomial,
-                                  std::size_t extended_size, const root_of_unity_type &root) {
+                                  std::size_t extended_size, const root_of_unity_type &root, std::size_t slot_budget = (std::size_t)16 << 30) {
         if (products.empty()) throw std::invalid_argument("gate_argument: no products");
         dfs_type F(ctx, extended_size);
         bool first = true;
@@ -66,49 +66,75 @@ struct placeholder_quotient_hip {
         std::uint64_t wn[4], we[4];
         adapter::scalar_to_limbs(root(log_n), wn);
         adapter::scalar_to_limbs(root(log_e), we);
-        /* ONE batched resize per gate: its factors (and, with the first gate, the mask) are laid side by side -- the rotation of a factor
-           writes straight into its slot -- and extended by one call (batched inverse NTT of n points + batched NTT of extended_size points:
-           the transforms then run their pairs-per-workgroup kernels) instead of one polynomial at a time */
+        /* Every DISTINCT (column, rotation) the gates name is extended ONCE (the reference's evaluator caches a variable's extension the same way):
+           the distinct factors of a group of gates -- and, with the first group, the mask -- are laid side by side (the rotation of a factor
+           writes straight into its slot) and extended by ONE call (a batched inverse NTT of n points + a batched NTT of extended_size points: the
+           transforms then run their pairs-per-workgroup kernels); every gate of the group is one k-way pointwise product over its slots.
+           A group ends where its extensions would pass `slot_budget` bytes. */
+        const std::size_t max_slots = std::max<std::size_t>(2, slot_budget / (extended_size * 32));
         std::shared_ptr<void> d_mask_ext;
-        for (const auto &g : products) {
-            if (g.factors.empty() || g.rotations.size() != g.factors.size()) throw std::invalid_argument("gate_argument: factors / rotations");
-            const std::size_t K = g.factors.size(), slots = K + (first ? 1 : 0);
+        for (std::size_t lo = 0; lo < products.size();) {
+            std::vector<std::pair<const dfs_type *, int>> unique;
+            auto slot_of = [&unique](const dfs_type *f, int rot) {
+                for (std::size_t u = 0; u < unique.size(); ++u)
+                    if (unique[u].first == f && unique[u].second == rot) return u;
+                return unique.size();
+            };
+            std::size_t hi = lo;
+            for (; hi < products.size(); ++hi) {
+                const auto &g = products[hi];
+                if (g.factors.empty() || g.rotations.size() != g.factors.size()) throw std::invalid_argument("gate_argument: factors / rotations");
+                std::vector<std::pair<const dfs_type *, int>> added;
+                for (std::size_t k = 0; k < g.factors.size(); ++k) {
+                    const std::pair<const dfs_type *, int> key(g.factors[k], g.rotations[k]);
+                    if (slot_of(key.first, key.second) == unique.size() && std::find(added.begin(), added.end(), key) == added.end()) added.push_back(key);
+                }
+                if (hi > lo && unique.size() + added.size() + (first ? 1 : 0) > max_slots) break;
+                unique.insert(unique.end(), added.begin(), added.end());
+            }
+            const std::size_t U = unique.size(), slots = U + (first ? 1 : 0);
             auto d_in = ctx.alloc(slots * n * 32);
             auto d_ext = ctx.alloc(slots * extended_size * 32);
-            std::size_t degree = 0;
-            for (std::size_t k = 0; k < K; ++k) {
-                const dfs_type &f = *g.factors[k];
+            for (std::size_t u = 0; u < U; ++u) {
+                const dfs_type &f = *unique[u].first;
                 if (f.size() != n) throw std::invalid_argument("gate_argument: every factor lives on the original domain (the mask's size)");
-                degree += f.degree();
-                char *slot = static_cast<char *>(d_in.get()) + k * n * 32;
-                if (g.rotations[k])
-                    check(zkhip_poly_shift_dev(ctx.get(), f.data(), log_n, (std::int64_t)g.rotations[k], slot), "zkhip_poly_shift_dev", ctx.get());
+                char *slot = static_cast<char *>(d_in.get()) + u * n * 32;
+                if (unique[u].second)
+                    check(zkhip_poly_shift_dev(ctx.get(), f.data(), log_n, (std::int64_t)unique[u].second, slot), "zkhip_poly_shift_dev", ctx.get());
                 else check(zkhip_memcpy_d2d_async(ctx.get(), slot, f.data(), n * 32), "zkhip_memcpy_d2d_async", ctx.get());
             }
-            if (degree >= extended_size) throw std::invalid_argument("gate_argument: the product's degree does not fit the extended domain");
             if (first)
-                check(zkhip_memcpy_d2d_async(ctx.get(), static_cast<char *>(d_in.get()) + K * n * 32, mask_polynomial.data(), n * 32), "zkhip_memcpy_d2d_async",
+                check(zkhip_memcpy_d2d_async(ctx.get(), static_cast<char *>(d_in.get()) + U * n * 32, mask_polynomial.data(), n * 32), "zkhip_memcpy_d2d_async",
                       ctx.get());
             if (extended_size == n) check(zkhip_memcpy_d2d_async(ctx.get(), d_ext.get(), d_in.get(), slots * n * 32), "zkhip_memcpy_d2d_async", ctx.get());
             else check(zkhip_poly_resize_dev(ctx.get(), adapter::id, d_in.get(), log_n, slots, wn, d_ext.get(), log_e, we), "zkhip_poly_resize_dev", ctx.get());
-            std::vector<const void *> ptrs;
-            for (std::size_t k = 0; k < K; ++k) ptrs.push_back(static_cast<const char *>(d_ext.get()) + k * extended_size * 32);
             dfs_type term(ctx, extended_size);
-            term.set_degree(degree);
-            check(zkhip_fr_vec_prod_dev(ctx.get(), adapter::id, ptrs.size(), ptrs.data(), term.data(), extended_size), "zkhip_fr_vec_prod_dev", ctx.get());
-            /* F (+)= coefficient * term */
-            std::uint64_t c[4];
-            adapter::scalar_to_limbs(g.coefficient, c);
-            const void *tp = term.data();
-            check(zkhip_poly_lincomb_dev(ctx.get(), adapter::id, 1, &tp, &extended_size, c, 1, F.data(), extended_size, first ? 0 : 1), "zkhip_poly_lincomb_dev",
-                  ctx.get());
-            F.set_degree(first ? degree : std::max(F.degree(), degree));
+            for (std::size_t gi = lo; gi < hi; ++gi) {
+                const auto &g = products[gi];
+                std::size_t degree = 0;
+                std::vector<const void *> ptrs;
+                for (std::size_t k = 0; k < g.factors.size(); ++k) {
+                    degree += g.factors[k]->degree();
+                    ptrs.push_back(static_cast<const char *>(d_ext.get()) + slot_of(g.factors[k], g.rotations[k]) * extended_size * 32);
+                }
+                if (degree >= extended_size) throw std::invalid_argument("gate_argument: the product's degree does not fit the extended domain");
+                check(zkhip_fr_vec_prod_dev(ctx.get(), adapter::id, ptrs.size(), ptrs.data(), term.data(), extended_size), "zkhip_fr_vec_prod_dev", ctx.get());
+                /* F (+)= coefficient * term */
+                std::uint64_t c[4];
+                adapter::scalar_to_limbs(g.coefficient, c);
+                const void *tp = term.data();
+                const bool very_first = first && gi == lo;
+                check(zkhip_poly_lincomb_dev(ctx.get(), adapter::id, 1, &tp, &extended_size, c, 1, F.data(), extended_size, very_first ? 0 : 1), "zkhip_poly_lincomb_dev",
+                      ctx.get());
+                F.set_degree(very_first ? degree : std::max(F.degree(), degree));
+            }
             if (first) {    // keep the extended mask (the last slot) for the final product
                 d_mask_ext = ctx.alloc(extended_size * 32);
-                check(zkhip_memcpy_d2d_async(ctx.get(), d_mask_ext.get(), static_cast<const char *>(d_ext.get()) + K * extended_size * 32, extended_size * 32),
+                check(zkhip_memcpy_d2d_async(ctx.get(), d_mask_ext.get(), static_cast<const char *>(d_ext.get()) + U * extended_size * 32, extended_size * 32),
                       "zkhip_memcpy_d2d_async", ctx.get());
             }
             first = false;
+            lo = hi;
             ctx.sync();    // d_in, d_ext and `term` are released at the end of the iteration
         }
         if (F.degree() + mask_polynomial.degree() >= extended_size) throw std::invalid_argument("gate_argument: mask * F does not fit the extended domain");

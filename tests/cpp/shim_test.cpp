@@ -1556,6 +1556,13 @@ int placeholder_round_t(const uint64_t *srs, size_t n_srs, const uint64_t *evals
     g2.rotations = {0, 0};
     g2.coefficient = Fr::zero() - Fr::one();
     dfs G = Q::gate_argument(ctx, {g1, g2}, mask, 4 * n, root);
+    {    // the same with a budget that forces one gate per group (q extended twice): identical evaluations
+        dfs G1 = Q::gate_argument(ctx, {g1, g2}, mask, 4 * n, root, 1);
+        std::vector<uint64_t> a(16 * n), b(16 * n);
+        ctx.d2h(a.data(), G.data(), 4 * n * 32);
+        ctx.d2h(b.data(), G1.data(), 4 * n * 32);
+        if (a != b || G.degree() != G1.degree()) return -73;
+    }
     /* 7. quotient over all eight parts, split, T_commit */
     std::vector<dfs> F = {perm.F_dfs[0], perm.F_dfs[1], perm.F_dfs[2], look.F_dfs[0], look.F_dfs[1], look.F_dfs[2], look.F_dfs[3], G};
     std::vector<Fr> alphas;
