@@ -13,8 +13,11 @@
 #include <thread>
 #include <vector>
 
+#include <nil/crypto3/zk/hip/column_polynomial.hpp>
 #include <nil/crypto3/zk/hip/lpc.hpp>
 #include <nil/crypto3/zk/hip/marshalling.hpp>
+#include <nil/crypto3/zk/hip/placeholder_lookup.hpp>
+#include <nil/crypto3/zk/hip/placeholder_quotient.hpp>
 #include <nil/crypto3/zk/hip/r1cs_gg_ppzksnark_generator.hpp>
 
 using namespace nil::crypto3::zk::hip;
@@ -241,6 +244,78 @@ void scheme_host_paths() {
     run_lpc(stream_builder<Fr>());
 }
 
+/// the host logic of placeholder's arguments and quotient chain over the stub backend (device buffers are host memory the stub only sizes and
+/// touches): buffer sizing, the grouping of gates and parts, slot indexing, the multi-part forms, argument checks
+template <typename Curve>
+void placeholder_host_paths() {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::scalar_value_type Fr;
+    typedef device_polynomial_dfs<Curve> dfs;
+    context ctx(0);
+    auto root = [](std::size_t l) { return Fr((std::uint64_t)(l + 2)); };
+    const std::size_t n = 64, usable = 60;
+    auto make = [&](std::size_t size, std::uint64_t seed) {
+        polynomial_dfs<Curve> h;
+        for (std::size_t i = 0; i < size; ++i) h.values.push_back(Fr(i * 3 + seed));
+        return dfs(ctx, h, size - 1);
+    };
+    std::vector<dfs> cols, sid, ssig;
+    for (std::uint64_t i = 0; i < 5; ++i) cols.push_back(make(n, i)), sid.push_back(make(n, 10 + i)), ssig.push_back(make(n, 20 + i));
+    dfs q_last = make(n, 31), q_blind = make(n, 32), l0 = make(n, 33);
+    typedef placeholder_permutation_hip<Curve> PA;
+    typedef placeholder_lookup_hip<Curve> LA;
+    typedef placeholder_quotient_hip<Curve> Q;
+    auto one = PA::prove_eval(ctx, cols, sid, ssig, q_last, q_blind, l0, Fr(3), Fr(5), root);
+    EXPECT(one.parts_dfs.empty() && one.F_dfs[1].size() >= 4 * n);
+    auto multi = PA::prove_eval(ctx, cols, sid, ssig, q_last, q_blind, l0, Fr(3), Fr(5), root, 3, {Fr(7), Fr(8)}, usable);    // 5 factors in groups of 2: 3 parts
+    EXPECT(multi.parts_dfs.size() == 2);
+    bool threw = false;
+    try {
+        (void)PA::prove_eval(ctx, cols, sid, ssig, q_last, q_blind, l0, Fr(3), Fr(5), root, 3, {Fr(7)}, usable);    // one alpha short
+    } catch (const std::invalid_argument &) {
+        threw = true;
+    }
+    EXPECT(threw);
+    std::vector<dfs> l_in = {make(2 * n, 40), make(n, 41)}, l_val = {make(n, 42)}, sorted = {make(n, 43), make(n, 44), make(n, 45)};
+    auto look = LA::prove_eval(ctx, l_in, l_val, sorted, q_last, q_blind, l0, Fr(3), Fr(5), {Fr(1), Fr(2)}, usable, root);
+    EXPECT(look.parts_dfs.empty());
+    auto look2 = LA::prove_eval(ctx, l_in, l_val, sorted, q_last, q_blind, l0, Fr(3), Fr(5), {Fr(1), Fr(2)}, usable, root, {1, 2}, {Fr(9)});
+    EXPECT(look2.parts_dfs.size() == 1);
+    threw = false;
+    try {
+        (void)LA::prove_eval(ctx, l_in, l_val, sorted, q_last, q_blind, l0, Fr(3), Fr(5), {Fr(1), Fr(2)}, usable, root, {1, 1}, {Fr(9)});    // parts do not cover
+    } catch (const std::invalid_argument &) {
+        threw = true;
+    }
+    EXPECT(threw);
+    /* gates sharing columns, with and without a budget that splits them into groups */
+    gate_product_hip<Curve> g1, g2, g3;
+    g1.factors = {&cols[0], &cols[1], &cols[2]};
+    g1.rotations = {0, 1, 0};
+    g1.coefficient = Fr(2);
+    g2.factors = {&cols[0], &cols[1]};
+    g2.rotations = {0, 0};
+    g2.coefficient = Fr(3);
+    g3.factors = {&cols[3], &cols[3], &cols[1]};
+    g3.rotations = {0, -1, 1};
+    g3.coefficient = Fr(4);
+    dfs mask = LA::affine(q_last, &q_blind, Fr(1), Fr(1), Fr(1));
+    dfs G = Q::gate_argument(ctx, {g1, g2, g3}, mask, 4 * n, root);
+    dfs Gs = Q::gate_argument(ctx, {g1, g2, g3}, mask, 4 * n, root, 1);
+    EXPECT(G.size() == 4 * n && Gs.size() == 4 * n && G.degree() == Gs.degree());
+    std::vector<dfs> F = {one.F_dfs[0], one.F_dfs[1], one.F_dfs[2], look.F_dfs[0], look.F_dfs[1], look.F_dfs[2], look.F_dfs[3], G};
+    std::vector<Fr> alphas(F.size(), Fr(6));
+    auto T = Q::quotient_polynomial(ctx, F, alphas, n, root);    // the stub reports no remainder
+    std::size_t largest = 0;
+    for (const auto &f : F) largest = std::max(largest, f.size());
+    EXPECT(T.size == largest - n);
+    auto parts = Q::quotient_polynomial_split_dfs(ctx, T, n, T.size / n + 1, n, root);
+    EXPECT(parts.size() == T.size / n + 1);
+    evaluation_domain_hip<Curve> dom(ZKHIP_DOMAIN_BASIC_RADIX2, n, Fr(2));
+    std::vector<std::vector<Fr>> columns(3, std::vector<Fr>(n, Fr(4)));
+    EXPECT(column_range_polynomials<Curve>(ctx, columns, dom).size() == 3);
+}
+
 template <typename Curve>
 void bulk_transfers() {
     typedef curve_adapter<Curve> A;
@@ -372,6 +447,8 @@ int main(int argc, char **argv) {
         groth16_host_paths<alt_bn128_254>(64);
         scheme_host_paths<bls12_381>();
         scheme_host_paths<converting_curve>();
+        placeholder_host_paths<bls12_381>();
+        placeholder_host_paths<converting_curve>();
         bulk_transfers<converting_curve>();
         bulk_transfers<bls12_381>();
     }
