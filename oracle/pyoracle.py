@@ -1154,7 +1154,8 @@ def quotient_polynomial_split_dfs(T: Sequence[int], rows_amount: int, split_poly
 
 
 # placeholder's permutation argument, prover side (zk/snark/systems/plonk/placeholder/permutation_argument.hpp:70-224, the
-# permutation_parts == 1 form).  PINNED to its definition: V_P by the row-by-row recurrence of :126-136 (one inversion per row), the
+# permutation_parts == 1 form and the multi-part one of max_quotient_chunks != 0).  PINNED to its definition and its purpose
+# (tests/test_oracle_kat.py: on a genuine instance the product closes and every F vanishes on the rows): V_P by the row-by-row recurrence of :126-136 (one inversion per row), the
 # three constraint polynomials as DENSE coefficient-form polynomial arithmetic of the comment formulas (:166, 175, 215) -- domain sizes
 # of the reference's intermediate polynomial_dfs objects are crypto3-math's business and do not show in the coefficients.
 def permutation_grand_product(cols, S_id, S_sigma, beta: int, gamma: int, r: int):
