@@ -589,7 +589,10 @@ ZK_D XYZZ<F> block_tree_sum(uint32_t *lds, XYZZ<F> acc, uint32_t t, uint32_t nth
 // measures the same for a single MSM (0.699 against 0.716 ms at 2^19 buckets) but worse for batches, whose many waves want
 // the second slot (50 x 2^19 buckets: 17.4 against 13.7 ms).
 template <class F, int LPB>
-__global__ __launch_bounds__(MSM_TAIL_THREADS, 2) void msm_bucket_red(const uint32_t *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t nseg,
+#ifndef ZK_TAIL_WAVES
+#define ZK_TAIL_WAVES 2  // workgroups of the reduction per CU the register allocation leaves room for (1: no spills; measured)
+#endif
+__global__ __launch_bounds__(MSM_TAIL_THREADS, ZK_TAIL_WAVES) void msm_bucket_red(const uint32_t *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t nseg,
                                                                    uint32_t nblk, uint32_t *__restrict__ partial) {
     constexpr int NL = FieldOps<F>::WORDS;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
