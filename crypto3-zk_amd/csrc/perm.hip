@@ -1,6 +1,8 @@
-// The grand products of placeholder's permutation and lookup arguments (the lookup's rows: LookupRows below).  The permutation argument's (zk/snark/systems/plonk/placeholder/permutation_argument.hpp:103-136):
+// The grand products of placeholder's permutation and lookup arguments, and the pointwise a b / c behind their multi-part forms.
+// The permutation argument's (zk/snark/systems/plonk/placeholder/permutation_argument.hpp:103-136):
 //   g_i = column_i + beta S_id_i + gamma,   h_i = column_i + beta S_sigma_i + gamma          (pointwise over the n rows, i < k)
 //   V_P[0] = 1,   V_P[j] = V_P[j - 1] * prod_i g_i[j - 1] / prod_i h_i[j - 1]
+// The lookup argument's V_L (lookup_argument.hpp:375-409) is the same recurrence over other rows (LookupRows below), zero behind usable_rows.
 // The reference walks the rows one after the other with one field inversion per row.  Here: every lane takes PERM_CHUNK consecutive
 // rows, forms their numerators and denominators, inverts the denominators with ONE inversion (Montgomery's trick), and the exclusive
 // prefix PRODUCT over all rows is a three-level scan (lane chunk -> workgroup in LDS -> one workgroup over the workgroup totals).
