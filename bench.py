@@ -897,6 +897,17 @@ def lpc_leg(np, log_n=20, cols=16, steps=4):
             return {"error": rc}
         res[name] = {"ms_per_commit": [round(float(x), 2) for x in ms], "mean_after_first_ms": round(float(ms[1:].mean()), 2)}
         roots.append(root.value)
+    # the opening proof of the same batch (two points per polynomial) up to and including the FRI commit phase
+    pe_steps = 4
+    ms = np.zeros(2 * pe_steps, dtype=np.float64)
+    rounds = ctypes.c_uint64(0)
+    rc = lib.zkhip_bench_lpc_proof_eval(0, ctypes.c_size_t(log_n), ctypes.c_size_t(cols), ctypes.c_size_t(1), pe_steps, 16, ms.ctypes.data_as(ctypes.c_void_p),
+                                        ctypes.byref(rounds))
+    if rc == 0:
+        pe = ms.reshape(pe_steps, 2)[1:, 1]
+        res["proof_eval"] = {"workload": "lpc_commitment_scheme_hip::proof_eval of the same %d polynomials at 2 points each: evaluations, combined quotient, its extension "
+                                         "to D[0], %d FRI rounds (one fold each) with every round's leaves to the tree builder" % (cols, int(rounds.value)),
+                             "ms_per_proof": [round(float(x), 2) for x in ms.reshape(pe_steps, 2)[:, 1]], "median_after_first_ms": round(float(np.median(pe)), 2)}
     return {"metric": "LPC commit, %d polynomial_dfs x 2^%d rows from host memory, domain 2^%d, leaves to the caller's tree builder" % (cols, log_n, log_n + 1),
             "value": res["streaming_builder"]["mean_after_first_ms"], "unit": "ms per commit", "higher_is_better": False,
             "leaf_bytes": cols * (2 << log_n) * 32, **res, "verified": roots[0] == roots[1],

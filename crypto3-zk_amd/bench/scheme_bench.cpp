@@ -59,6 +59,7 @@ struct streaming_fold_builder {
     fold_tree t;
     void begin(std::size_t, std::size_t) { t = fold_tree(); }
     void absorb(const Fr *leaves, std::size_t, std::size_t count) {
+        const unsigned threads = count >= ((std::size_t)1 << 16) ? this->threads : 1;    // the late FRI rounds are a few leaves: no thread is worth starting
         std::vector<uint64_t> part(threads, 0);
         std::vector<std::thread> th;
         for (unsigned k = 0; k < threads; ++k)
@@ -285,6 +286,51 @@ int zkhip_bench_lpc_scheme(int device, size_t log_n, size_t cols, size_t expand,
         return 0;
     } catch (const std::exception &e) {
         fprintf(stderr, "zkhip_bench_lpc_scheme: %s\n", e.what());
+        return -1;
+    }
+}
+
+/* lpc_commitment_scheme_hip::proof_eval at size (lpc.hpp:113-200 up to and including the FRI commit phase, basic_fri.hpp:705-742): `cols`
+ * polynomials of 2^log_n rows committed over D[0] = 2^(log_n + expand) (as zkhip_bench_lpc_scheme, streaming builder), every polynomial opened at
+ * two points (y, y omega -- what placeholder asks of a witness column with a rotation); then proof_eval: the evaluations (block Horner over the
+ * resident coefficients), the combined quotient, its extension to D[0] and the leaves of every FRI round -- one fold per round down to 16 points --
+ * handed to the caller's tree builder.  ms: steps x {commit, proof_eval}.  *rounds: FRI rounds of the last proof. */
+int zkhip_bench_lpc_proof_eval(int device, size_t log_n, size_t cols, size_t expand, int steps, unsigned threads, double *ms, uint64_t *rounds) {
+    try {
+        const size_t n = (size_t)1 << log_n;
+        context ctx(device);
+        fri_params_hip<C> params;
+        params.log_domain = log_n + expand;
+        params.step_list.assign(log_n + expand - 4, 1);
+        params.root_of_unity = bls_root;
+        splitmix sm {15};
+        std::vector<polynomial_dfs<C>> polys(cols);
+        for (auto &p : polys) {
+            p.values.resize(n);
+            for (auto &v : p.values) v = sm.nonzero();
+        }
+        std::vector<std::reference_wrapper<const polynomial_dfs<C>>> lent(polys.begin(), polys.end());
+        streaming_fold_builder b;
+        b.threads = threads ? threads : 8;
+        const Fr y = sm.nonzero(), w = bls_root(log_n);
+        for (int rep = 0; rep < steps; ++rep) {
+            lpc_commitment_scheme_hip<C, counting_transcript, streaming_fold_builder> scheme(ctx, params, b);
+            auto t0 = std::chrono::steady_clock::now();
+            scheme.append_to_batch(0, lent);
+            (void)scheme.commit(0);
+            ms[2 * rep] = ms_since(t0);
+            scheme.append_eval_point(0, y);
+            scheme.append_eval_point(0, y * w);
+            counting_transcript tr;
+            for (int i = 0; i < 64; ++i) tr.challenges.push_back(sm.nonzero());
+            t0 = std::chrono::steady_clock::now();
+            auto proof = scheme.proof_eval(tr);
+            ms[2 * rep + 1] = ms_since(t0);
+            if (rounds) *rounds = proof.fri_proof.fri_roots.size();
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkhip_bench_lpc_proof_eval: %s\n", e.what());
         return -1;
     }
 }

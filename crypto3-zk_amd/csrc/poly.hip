@@ -54,13 +54,36 @@ __global__ __launch_bounds__(256) void fri_leaf_gather(const uint4 *__restrict__
 
 static constexpr uint32_t FOLD_CHUNK = 128;  // consecutive i per lane: one power, then a running product
 
-// consts = [alpha, w^-1, 1/2] in Montgomery form, canonical representatives
+// consts = [alpha, w^-1, 1/2] in Montgomery form, canonical representatives.  One lane: w is a 2^log_size-th root of unity, so w^-1 = w^(2^log_size - 1) =
+// prod_k w^(2^k) -- 2 log_size products instead of a field inversion (380 products on a single lane: 0.33 ms, which made every round of an FRI commit
+// phase cost 0.7 ms whatever its size); 1/2 = (p + 1) / 2 needs no inversion either.  A w of another order takes the inversion.
 template <class U>
-__global__ void fri_fold_setup(const uint32_t *__restrict__ alpha_c, const uint32_t *__restrict__ omega_c, uint32_t *__restrict__ consts) {
+__global__ void fri_fold_setup(const uint32_t *__restrict__ alpha_c, const uint32_t *__restrict__ omega_c, uint32_t log_size, uint32_t *__restrict__ consts) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     fu_store<U>(consts, fu_cond_sub_p(fu_from_canonical<U>(alpha_c)));
-    fu_store<U>(consts + U::SL, fu_cond_sub_p(fu_inv(fu_from_canonical<U>(omega_c))));
-    fu_store<U>(consts + 2 * U::SL, fu_cond_sub_p(fu_inv(fu_add(Fu<U>::one(), Fu<U>::one()))));
+    const Fu<U> w = fu_cond_sub_p(fu_from_canonical<U>(omega_c));
+    Fu<U> winv = Fu<U>::one(), sq = w;
+    for (uint32_t k = 0; k < log_size; ++k) {
+        winv = fu_cond_sub_p(fu_mul(winv, sq));
+        sq = fu_cond_sub_p(fu_mul(sq, sq));
+    }
+    const Fu<U> one = fu_cond_sub_p(Fu<U>::one());
+    const Fu<U> check = fu_cond_sub_p(fu_mul(winv, w));
+    bool ok = true;
+#pragma unroll
+    for (int l = 0; l < U::L; ++l) ok = ok && check.v[l] == one.v[l];
+    if (!ok) winv = fu_cond_sub_p(fu_inv(w));
+    fu_store<U>(consts + U::SL, winv);
+    // (p + 1) / 2, canonical -> Montgomery: p is odd, so p + 1 halves exactly
+    uint32_t half[U::NL];
+    uint32_t carry = 1;
+    for (int l = 0; l < U::NL; ++l) {
+        const uint64_t t = (uint64_t)U::sat::mod(l) + carry;
+        half[l] = (uint32_t)t;
+        carry = (uint32_t)(t >> 32);
+    }
+    for (int l = 0; l < U::NL; ++l) half[l] = (half[l] >> 1) | ((l + 1 < U::NL ? half[l + 1] : carry) << 31);
+    fu_store<U>(consts + 2 * U::SL, fu_cond_sub_p(fu_from_canonical<U>(half)));
 }
 
 template <class U>
@@ -392,10 +415,10 @@ int zkhip_fri_fold_dev(zkhip_ctx *ctx, int curve, const void *d_f, size_t log_si
     size_t half = (size_t)1 << (log_size - 1), lanes = (half + FOLD_CHUNK - 1) / FOLD_CHUNK;
     dim3 grid((unsigned)((lanes + 255) / 256)), block(256);
     if (curve == CURVE_BLS12_381) {
-        ZK_LAUNCH(ctx, "fri_fold_setup", fri_fold_setup<BlsFrU>, dim3(1), dim3(64), 0, d_c, d_c + 8, consts);
+        ZK_LAUNCH(ctx, "fri_fold_setup", fri_fold_setup<BlsFrU>, dim3(1), dim3(64), 0, d_c, d_c + 8, (uint32_t)log_size, consts);
         ZK_LAUNCH(ctx, "fri_fold", fri_fold<BlsFrU>, grid, block, 0, (const uint32_t *)d_f, (uint32_t)log_size, consts, (uint32_t *)d_out);
     } else {
-        ZK_LAUNCH(ctx, "fri_fold_setup", fri_fold_setup<BnFrU>, dim3(1), dim3(64), 0, d_c, d_c + 8, consts);
+        ZK_LAUNCH(ctx, "fri_fold_setup", fri_fold_setup<BnFrU>, dim3(1), dim3(64), 0, d_c, d_c + 8, (uint32_t)log_size, consts);
         ZK_LAUNCH(ctx, "fri_fold", fri_fold<BnFrU>, grid, block, 0, (const uint32_t *)d_f, (uint32_t)log_size, consts, (uint32_t *)d_out);
     }
     return ZKHIP_OK;

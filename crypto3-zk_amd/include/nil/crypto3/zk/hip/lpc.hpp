@@ -32,6 +32,9 @@
 #define ZKHIP_SHIM_LPC_HPP
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstdio>
+#include <chrono>
 #include <deque>
 #include <functional>
 #include <iterator>
@@ -239,7 +242,18 @@ public:
 
     /// proof_eval (lpc.hpp:113-200) up to and including the FRI commit phase (basic_fri.hpp:705-742)
     proof_type proof_eval(transcript_type &transcript) {
+        /* ZKHIP_LPC_PHASES=1: host wall time of the phases on stderr */
+        const bool phases = std::getenv("ZKHIP_LPC_PHASES") != nullptr;
+        auto tp = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!phases) return;
+            _ctx.sync();
+            const auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "lpc proof_eval phase %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tp).count());
+            tp = now;
+        };
         eval_polys();
+        lap("eval_polys");
         for (const auto &it : _trees) transcript(it.second.root());
 
         /* Prepare z-s and combined_Q (lpc.hpp:124-186), coefficient form, resident */
@@ -312,23 +326,31 @@ public:
             add_quotient(ptrs, lens, coeffs, constant, _etha);
         }
         if (!have_combined) throw std::runtime_error("lpc proof_eval: nothing to open");
+        lap("combined quotient");
 
         /* combined_Q.from_coefficients + precommit(combined_Q, D[0], step_list.front()) (lpc.hpp:188-198): the extension to
            D[0] is the NTT of the zero-padded coefficients */
         const std::size_t D0 = domain_size(0);
         device_polynomial_dfs<CurveType> f(_ctx, D0);
-        check(zkhip_memcpy_d2d_async(_ctx.get(), f.data(), d_combined.get(), (max_len - 1) * 32), "zkhip_memcpy_d2d_async", _ctx.get());
-        zero_fill(static_cast<char *>(f.data()) + 32 * (max_len - 1), D0 - (max_len - 1));
+        {    /* the zero-padded copy in one pass on the device: f[j] = 1 * combined[j] below max_len - 1, zero behind */
+            const void *src = d_combined.get();
+            const std::size_t len = max_len - 1;
+            std::uint64_t one[4];
+            adapter::scalar_to_limbs(value_type::one(), one);
+            check(zkhip_poly_lincomb_dev(_ctx.get(), adapter::id, 1, &src, &len, one, 1, f.data(), D0, 0), "zkhip_poly_lincomb_dev", _ctx.get());
+        }
         {
             std::uint64_t w[4];
             adapter::scalar_to_limbs(_fri_params.root_of_unity(_fri_params.log_domain), w);
             check(zkhip_ntt_dev(_ctx.get(), adapter::id, f.data(), _fri_params.log_domain, 1, w, 0, nullptr), "zkhip_ntt_dev", _ctx.get());
         }
+        lap("extension to D[0]");
         precommitment_type precommitment = [&]() {
             ZKHIP_PROFILE_SCOPE("Basic FRI Precommit time");    // precommit(combined_Q, ...), lpc.hpp:196-198
             return build_tree(f.data(), 1, _fri_params.log_domain, _fri_params.step_list.front());
         }();
 
+        lap("precommit (leaves of round 0)");
         /* Commit phase (basic_fri.hpp:705-742) */
         proof_type proof;
         _fri_trees.clear();
@@ -344,10 +366,13 @@ public:
                 _alphas.push_back(transcript.challenge());
                 f = fold_polynomial<CurveType>(f, _alphas[t], _fri_params.root_of_unity(_fri_params.log_domain - t));
             }
+            if (phases && std::getenv("ZKHIP_LPC_ROUNDS")) lap("  fold");
             if (i != _fri_params.step_list.size() - 1)
                 precommitment = build_tree(f.data(), 1, _fri_params.log_domain - t, _fri_params.step_list[i + 1]);
+            if (phases && std::getenv("ZKHIP_LPC_ROUNDS")) lap("  leaves");
         }
         _fs.push_back(f);
+        lap("fold rounds + their leaves");
         {
             auto d_c = f.coefficients(_fri_params.root_of_unity);
             std::vector<std::uint64_t> h(4 * f.size());
@@ -383,12 +408,6 @@ protected:
         std::size_t l = 0;
         while (((std::size_t)1 << l) < n) ++l;
         return l;
-    }
-    void zero_fill(void *d, std::size_t elems) const {
-        if (elems == 0) return;
-        std::vector<std::uint64_t> z(4 * std::min<std::size_t>(elems, (std::size_t)1 << 16), 0);
-        for (std::size_t done = 0; done < elems; done += z.size() / 4)
-            _ctx.h2d(static_cast<char *>(d) + 32 * done, z.data(), 32 * std::min(z.size() / 4, elems - done));
     }
     /// the leaf layout of `batch` polynomials resident as evaluations over the 2^log_domain-point domain -> the caller's tree
     precommitment_type build_tree(const void *d_evals, std::size_t batch, std::size_t log_domain, std::size_t fri_step) const {

@@ -1,0 +1,28 @@
+"""Host-side cost of one call of the small polynomial-layer entry points on 64-element vectors (launch + argument staging)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, ctypes
+import bench
+zk = bench.load_pkg()
+ctx = zk.Context(0)
+n = 64
+d = [ctx.malloc(n * 32) for _ in range(4)]
+for p in d:
+    ctx.h2d(p, bench.random_scalars(np, n, 3))
+one = bench.lim(np, 1)
+def t(name, f, reps=200):
+    for _ in range(10): f()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps): f()
+    ctx.sync()
+    print("%-40s %.1f us per call" % (name, (time.perf_counter() - t0) / reps * 1e6))
+t("fr_vec_op (no host copies)", lambda: ctx.fr_vec_op_dev(0, 0, d[0], d[1], d[2], n))
+t("fr_vec_affine (scalars by value)", lambda: ctx.fr_vec_affine_dev(0, d[0], d[1], one, one, one, d[2], n))
+t("fr_vec_prod (1 pageable H2D)", lambda: ctx.fr_vec_prod_dev(0, [d[0], d[1]], d[2], n))
+P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+t("fri_fold (2 pageable H2D)", lambda: ctx.lib.zkhip_fri_fold_dev(ctx.h, 0, ctypes.c_void_p(d[0]), ctypes.c_size_t(6), P(one), P(one), ctypes.c_void_p(d[2])))
+t("poly_lincomb (3 pageable H2D)", lambda: ctx.poly_lincomb_dev(0, [d[0], d[1]], [n, n], np.stack([one, one]), 1, d[2], n, False))
