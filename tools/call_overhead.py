@@ -26,3 +26,16 @@ t("fr_vec_prod (1 pageable H2D)", lambda: ctx.fr_vec_prod_dev(0, [d[0], d[1]], d
 P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
 t("fri_fold (2 pageable H2D)", lambda: ctx.lib.zkhip_fri_fold_dev(ctx.h, 0, ctypes.c_void_p(d[0]), ctypes.c_size_t(6), P(one), P(one), ctypes.c_void_p(d[2])))
 t("poly_lincomb (3 pageable H2D)", lambda: ctx.poly_lincomb_dev(0, [d[0], d[1]], [n, n], np.stack([one, one]), 1, d[2], n, False))
+r = bench.R_BLS
+w6, w7 = bench.lim(np, pow(7, (r - 1) >> 6, r)), bench.lim(np, pow(7, (r - 1) >> 7, r))
+big = ctx.malloc(256 * 32)
+t("ntt 2^6", lambda: ctx.ntt_dev(0, d[0], 6, 1, w6))
+t("poly_resize 2^6 -> 2^7", lambda: ctx.poly_resize_dev(0, d[0], 6, 1, w6, big, 7, w7))
+t("poly_shift", lambda: ctx.poly_shift_dev(d[0], 6, 1, d[2]))
+t("poly_eval (1 point; returns to the host)", lambda: ctx.poly_eval_dev(0, d[0], n, 1, one.reshape(1, 4)))
+t("poly_div_linear (returns the remainder)", lambda: ctx.poly_div_linear_dev(0, d[0], n, one, d[2]))
+t("poly_div_vanishing", lambda: ctx.poly_div_vanishing_dev(0, big, 128, 64, d[2]))
+t("fr_vec_mul_div", lambda: ctx.fr_vec_mul_div_dev(0, d[0], d[1], d[3], d[2], n))
+t("perm_grand_product k=2", lambda: ctx.perm_grand_product_dev(0, [d[0], d[1]], [d[1], d[0]], [d[3], d[0]], n, one, one, 0, 0, d[2]))
+t("lookup_grand_product", lambda: ctx.lookup_grand_product_dev(0, [d[0]], [d[1]], [d[3], d[0]], n, n - 3, one, one, d[2]))
+t("fri_leaves", lambda: ctx.lib.zkhip_fri_leaves_dev(ctx.h, ctypes.c_void_p(d[0]), ctypes.c_size_t(6), ctypes.c_size_t(1), ctypes.c_size_t(1), ctypes.c_void_p(d[2])))
