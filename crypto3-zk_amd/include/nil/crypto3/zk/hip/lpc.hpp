@@ -366,10 +366,8 @@ public:
                 _alphas.push_back(transcript.challenge());
                 f = fold_polynomial<CurveType>(f, _alphas[t], _fri_params.root_of_unity(_fri_params.log_domain - t));
             }
-            if (phases && std::getenv("ZKHIP_LPC_ROUNDS")) lap("  fold");
             if (i != _fri_params.step_list.size() - 1)
                 precommitment = build_tree(f.data(), 1, _fri_params.log_domain - t, _fri_params.step_list[i + 1]);
-            if (phases && std::getenv("ZKHIP_LPC_ROUNDS")) lap("  leaves");
         }
         _fs.push_back(f);
         lap("fold rounds + their leaves");
