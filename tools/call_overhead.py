@@ -39,3 +39,13 @@ t("fr_vec_mul_div", lambda: ctx.fr_vec_mul_div_dev(0, d[0], d[1], d[3], d[2], n)
 t("perm_grand_product k=2", lambda: ctx.perm_grand_product_dev(0, [d[0], d[1]], [d[1], d[0]], [d[3], d[0]], n, one, one, 0, 0, d[2]))
 t("lookup_grand_product", lambda: ctx.lookup_grand_product_dev(0, [d[0]], [d[1]], [d[3], d[0]], n, n - 3, one, one, d[2]))
 t("fri_leaves", lambda: ctx.lib.zkhip_fri_leaves_dev(ctx.h, ctypes.c_void_p(d[0]), ctypes.c_size_t(6), ctypes.c_size_t(1), ctypes.c_size_t(1), ctypes.c_void_p(d[2])))
+# small MSMs: the fixed cost of the launch chain
+for log_n in (0, 6, 10, 12, 14, 16):
+    nn = 1 << log_n
+    ks = bench.random_scalars(np, nn, 11)
+    b = ctx.bases_from_scalars(0, 1, ks)
+    d_s = ctx.malloc(nn * 32)
+    ctx.h2d(d_s, bench.random_scalars(np, nn, 12))
+    d_o = ctx.malloc(3 * 6 * 8)
+    t("G1 MSM of 2^%d points (resident)" % log_n, lambda: ctx.msm_dev(b, d_s, d_o, 0, nn), reps=50)
+    b.free()
