@@ -646,10 +646,14 @@ int zkhip_bench_lookup(int device, size_t log_n, size_t k_in, size_t k_val, int 
  *   gate argument q (w0 w1 - w2) masked by 1 - q_last - q_blind over the 4n-point domain,
  *   quotient of the eight constraint polynomials (domains 2n .. 8n) by X^n - 1 -- exact: every part vanishes on the rows --, split into 8 parts,
  *   commit(QUOTIENT_BATCH).
- * ms: steps x {permutation, lookup (with its LOOKUP_BATCH commit), PERMUTATION_BATCH commit, gate argument, quotient, split, QUOTIENT_BATCH commit}.
+ * witness_cols > 0: the round is preceded by commit(VARIABLE_VALUES_BATCH) of that many resident witness columns (prover.hpp:130-142) and followed by the
+ * opening proof of everything committed (prover.hpp:363-410: the witness columns at y and y omega, V_P and V_L at y and y omega, the sorted vectors at y,
+ * y omega and y omega^usable, the quotient parts at y) -- BASELINE config 5's proof shape, device side, in one figure.
+ * ms: steps x {witness commit, permutation, lookup (with its LOOKUP_BATCH commit), PERMUTATION_BATCH commit, gate argument, quotient, split, QUOTIENT_BATCH commit,
+ * proof_eval} (9 numbers; the first and the last are 0 when witness_cols == 0).
  * *verified: V_P[usable] = V_L[usable] = 1, the division left no remainder (quotient_polynomial throws otherwise) and
  * T(y) (y^n - 1) == sum_i alpha_i F_i(y) at a random y, every polynomial evaluated from its coefficient form. */
-int zkhip_bench_placeholder_round(int device, size_t log_n, int steps, double *ms, int *verified) {
+int zkhip_bench_placeholder_round(int device, size_t log_n, size_t witness_cols, int steps, double *ms, int *verified) {
     try {
         typedef placeholder_quotient_hip<C> Q;
         typedef placeholder_permutation_hip<C> PA;
@@ -686,6 +690,15 @@ int zkhip_bench_placeholder_round(int device, size_t log_n, int steps, double *m
         for (size_t i = 0; i < n; ++i) pw[i] = x, x = x * alpha;
         kzg_params_hip<C> params(ctx, device_bases<C, ZKHIP_G1>::from_scalars(ctx, pw.begin(), pw.end()));
         std::vector<Fr>().swap(pw);
+        std::vector<dfs> witness;    // resident witness columns: a few distinct random ones, uploaded in turn (the values do not change the work)
+        if (witness_cols) {
+            std::vector<polynomial_dfs<C>> h(std::min<size_t>(witness_cols, 5));
+            for (auto &p : h) {
+                p.values.resize(n);
+                for (auto &v : p.values) v = sm.nonzero();
+            }
+            for (size_t c = 0; c < witness_cols; ++c) witness.emplace_back(ctx, h[c % h.size()], n - 1);
+        }
         const Fr bp = sm.nonzero(), gp = sm.nonzero(), bl = sm.nonzero(), gl = sm.nonzero();
         const std::vector<Fr> l_alphas = {sm.nonzero(), sm.nonzero()};
         std::vector<Fr> alphas;
@@ -694,12 +707,19 @@ int zkhip_bench_placeholder_round(int device, size_t log_n, int steps, double *m
         typename Q::device_coefficients T;
         std::unique_ptr<PA::prover_result_type> perm;
         std::unique_ptr<LA::prover_result_type> look;
-        constexpr std::size_t PERMUTATION_BATCH = 2, QUOTIENT_BATCH = 3, LOOKUP_BATCH = 4;
+        constexpr std::size_t VARIABLE_VALUES_BATCH = 1, PERMUTATION_BATCH = 2, QUOTIENT_BATCH = 3, LOOKUP_BATCH = 4;
         for (int rep = 0; rep < steps; ++rep) {
-            double *t = ms + 7 * rep;
+            double *t = ms + 9 * rep + 1;
             kzg_commitment_scheme_v2_hip<C, counting_transcript> scheme(params, bls_root);
             ctx.sync();
             auto t0 = std::chrono::steady_clock::now();
+            t[-1] = 0;
+            if (witness_cols) {
+                scheme.append_to_batch(VARIABLE_VALUES_BATCH, witness);
+                if (scheme.commit(VARIABLE_VALUES_BATCH).size() != witness_cols) throw std::runtime_error("placeholder round: witness batch");
+                t[-1] = ms_since(t0);
+                t0 = std::chrono::steady_clock::now();
+            }
             perm.reset(new PA::prover_result_type(PA::prove_eval(ctx, cols, sid, ssig, q_last, q_blind, lagrange_0, bp, gp, bls_root)));
             scheme.append_to_batch(PERMUTATION_BATCH, perm->permutation_polynomial_dfs);
             t[0] = ms_since(t0);
@@ -736,6 +756,30 @@ int zkhip_bench_placeholder_round(int device, size_t log_n, int steps, double *m
             auto t_commit = scheme.commit(QUOTIENT_BATCH);
             t[6] = ms_since(t0);
             if (lookup_commit.size() != 3 || perm_commit.size() != 2 || t_commit.size() != 8) throw std::runtime_error("placeholder round: batch sizes");
+            t[7] = 0;
+            if (witness_cols) {    // the evaluation points of prover.hpp:363-410, then the opening proof of all four batches
+                const Fr y = sm.nonzero(), w = bls_root(log_n);
+                Fr wu = Fr::one();
+                {    // omega^usable by square and multiply
+                    Fr acc = Fr::one(), sq = w;
+                    for (size_t e = usable; e; e >>= 1) {
+                        if (e & 1) acc = acc * sq;
+                        sq = sq * sq;
+                    }
+                    wu = acc;
+                }
+                scheme.append_eval_point(VARIABLE_VALUES_BATCH, y);
+                for (size_t c = 0; c < witness_cols; c += 2) scheme.append_eval_point(VARIABLE_VALUES_BATCH, c, y * w);    // every other column has a rotation
+                scheme.append_eval_points(PERMUTATION_BATCH, {y, y * w});
+                scheme.append_eval_points(LOOKUP_BATCH, {y, y * w, y * wu});
+                scheme.append_eval_point(QUOTIENT_BATCH, y);
+                counting_transcript tr;
+                tr.challenges = {sm.nonzero(), sm.nonzero()};
+                t0 = std::chrono::steady_clock::now();
+                auto proof = scheme.proof_eval(tr);
+                t[7] = ms_since(t0);
+                (void)proof;
+            }
         }
         if (verified) {
             uint64_t one_at[4];
