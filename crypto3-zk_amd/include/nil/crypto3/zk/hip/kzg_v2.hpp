@@ -247,13 +247,15 @@ public:
         /* The polynomials go up in chunks on a second in-order stream: while chunk c is transformed (p.coefficients(), kzg.hpp:431:
            one batched inverse NTT per chunk of equally sized polynomials) and committed (multiexp against the resident key, the
            chunk's bucket reductions sharing one launch), chunk c + 1 crosses PCIe. */
-        const bool pipelined = upload_chunk != 0 && count > upload_chunk;
+        bool any_from_host = false;    // a batch that is resident already has nothing to overlap: one chunk, one shared tail over all its multiexps
+        for (const poly_type *p : polys) any_from_host = any_from_host || p != nullptr;
+        const bool pipelined = upload_chunk != 0 && count > upload_chunk && any_from_host;
         const context &up = pipelined ? upload_context() : ctx;
         for (std::size_t i = 0; i < count;) {
             std::size_t j = i;
             /* the first chunk is a short one: nothing runs on the device until it has arrived */
             const std::size_t limit = (pipelined && i == 0) ? std::max<std::size_t>(1, upload_chunk / 4) : upload_chunk;
-            while (j < count && db.len[j] == db.len[i] && (limit == 0 || j - i < limit)) ++j;
+            while (j < count && db.len[j] == db.len[i] && (!pipelined || limit == 0 || j - i < limit)) ++j;
             for (std::size_t p = i; p < j; ++p) {
                 if (polys[p]) upload_scalars<adapter>(up, db.at(p), detail::poly_data<adapter>(*polys[p]), polys[p]->size());
                 else check(zkhip_memcpy_d2d_async(up.get(), db.at(p), resident.at(p).data(), db.len[p] * 32), "zkhip_memcpy_d2d_async", up.get());
