@@ -64,3 +64,18 @@ def test_generated_asm_products_are_current(tmp_path):
     # 14-limb product: 2 L^2 multiply-adds, L mul_lo, 2 L masks, 2 L - 1 shifts, one move
     body = text.split("struct MontAsm<14>")[1].split("static __device__")[1]
     assert body.count("v_mad_u64_u32") == 2 * 14 * 14 and body.count("v_lshrrev_b64") == 27 and body.count("v_mul_lo_u32") == 14
+
+
+def test_isa_mix_is_current():
+    """profiles/isa_mix.json (the static instruction mix bench.py prices the VALU roofline with) carries the hash of the kernel
+    sources it was compiled from; a kernel edit without `python3 tools/isa_mix.py > profiles/isa_mix.json` would price the new
+    kernel with the old mix -- bench.py then drops the priced figure, and this test says why."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("zk_isa_mix", os.path.join(ROOT, "tools", "isa_mix.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mix = json.load(open(os.path.join(ROOT, "profiles", "isa_mix.json")))
+    assert mix["source_sha256"] == mod.sources_hash(), "regenerate: python3 tools/isa_mix.py > profiles/isa_mix.json"
+    for k in ("msm_bucket_acc", "ntt_pass"):
+        assert abs(sum(mix[k]["fractions"].values()) - 1) < 1e-3

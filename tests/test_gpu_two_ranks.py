@@ -15,33 +15,37 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(port, extra):
+def _run(port, extra, tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--same-device", "--steps", "3", "--warmup", "1", "--log-n", "18",
-           "--no-cpu-baseline", "--no-pmc", "--ntt-log-m", "18"] + extra
+           "--no-cpu-baseline", "--no-pmc", "--ntt-log-m", "18", "--detail", str(tmp_path / "detail.json")] + extra
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]  # rank 0 only
-    return json.loads(lines[0])
+    assert len(lines[0]) <= 6144
+    return json.loads(lines[0]), json.load(open(tmp_path / "detail.json"))
 
 
-def test_two_ranks_point_split_and_sharded_legs():
+def test_two_ranks_point_split_and_sharded_legs(tmp_path):
     """point-range partition of the MSM, ONE Groth16 proof sharded over the two ranks (each generates and holds half of every query
     of the same valid key, over the step radix-2 domain the reference picks for 2^16 + 11), the 50 KZG columns dealt over the ranks"""
-    line = _run(29641, ["--split", "points", "--log-constraints", "16", "--kzg-log-rows", "16"])
+    line, detail = _run(29641, ["--split", "points", "--log-constraints", "16", "--kzg-log-rows", "16"], tmp_path)
     assert line["n_gpus"] == 2 and line["verified"] is True
     assert "point-range partition x2" in line["config"]["parallelism"]
-    g = line["groth16_sharded"]
+    assert all(l.get("verified") is True for l in line["legs"].values()), line["legs"]
+    d = line["dist"]    # two ranks, ONE device (--same-device): the line says so
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and len(d["devices"]) == 2 and d["distinct_devices"] == 1 and d["same_device_flag"]
+    g = detail["groth16_sharded"]
     assert g["verified"] is True and len(g["ms_per_proof"]) >= 2
-    k = line["kzg_sharded"]
+    k = detail["kzg_sharded"]
     assert k["verified"] is True and k["columns_per_rank"] == 25
-    t = line["ntt_sharded"]    # BASELINE config 3's split: 8 polynomials dealt 4 / 4, no collective in the data path
+    t = detail["ntt_sharded"]    # BASELINE config 3's split: 8 polynomials dealt 4 / 4, no collective in the data path
     assert t["verified"] is True and t["polynomials_per_rank"] == 4 and t["scaling"] == "strong"
 
 
-def test_two_ranks_window_split():
+def test_two_ranks_window_split(tmp_path):
     """north_star's bucket-window shard: every rank holds all points and the window tables {w : w mod 2 == rank}"""
-    line = _run(29643, ["--split", "windows", "--no-groth16", "--no-kzg"])
+    line, _ = _run(29643, ["--split", "windows", "--no-groth16", "--no-kzg"], tmp_path)
     assert line["n_gpus"] == 2 and line["verified"] is True
     assert "window partition x2" in line["config"]["parallelism"]

@@ -6,8 +6,12 @@ v_mad_u64_u32, v_mul_lo_u32, 64-bit shifts and adds, three-operand adds) holds i
 VOP1 instruction for 2 when another wave is there to take the next slot (4 for a lone wave) -- measured by tools/microbench2.hip
 and tools/mulbench4.hip (profiles/r04_microbench2_valu_wallclock.txt, profiles/r04_mulbench4_asm_vs_cpp_13x30.txt).
 
-Usage (dev container, no GPU needed):  python3 tools/isa_mix.py > profiles/r04_isa_mix.json
+Usage (dev container, no GPU needed):  python3 tools/isa_mix.py > profiles/isa_mix.json
+The output is STAMPED with a hash of the kernel sources it was compiled from (`source_sha256`, = sources_hash() below); bench.py ignores a
+mix whose stamp is not the tree's (a rebuilt kernel would otherwise be priced with a stale mix: ADVICE r4), and tests/test_abi.py
+fails when the committed file is stale.
 """
+import hashlib
 import json
 import os
 import re
@@ -19,6 +23,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = {"msm_bucket_acc": ("csrc/msm_bls_g1.hip", r"msm_bucket_acc_lds.*BlsFqU.*Li64ELi3ELi1"),
        "ntt_pass": ("csrc/ntt.hip", r"ntt_passIN5zkhip6BlsFrUELi2")}
 VOP2 = re.compile(r"^(v_(add|sub|subrev|and|or|xor|lshlrev|lshrrev|ashrrev|mov|cndmask|min|max|addc|subb|subbrev|add_co|sub_co|not|bfrev)_[a-z0-9_]*?)(_e32|_dpp|_sdwa)?$")
+
+
+def sources_hash():
+    """sha256 over what the two kernels are built from: every header of crypto3-zk_amd/csrc/ and the two translation units
+    (names and contents, sorted)"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "crypto3-zk_amd", "csrc")
+    units = {os.path.basename(src) for src, _ in SRC.values()}
+    for name in sorted(os.listdir(d)):
+        if name.endswith(".hpp") or name in units:
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
 
 
 def classify(op):
@@ -63,6 +80,7 @@ def main():
                                                     "profiles/r04_mulbench4_asm_vs_cpp_13x30.txt (a 461-instruction product block issues in 4.03 "
                                                     "shader cycles per instruction from ONE wave; VOP2 at 1.0 ns against 1.73-2.2 ns for VOP3 / "
                                                     "multiply-adds at 8 waves per SIMD)"}
+    out["source_sha256"] = sources_hash()
     json.dump(out, sys.stdout, indent=1)
     print()
 
