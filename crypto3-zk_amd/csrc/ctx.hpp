@@ -32,7 +32,7 @@
 static constexpr int ZK_MSM_MAX_C = 21;  // largest Pippenger window (bits); 2^(c-1) buckets per set (the sort handles <= 2^20 x sets / 1024 super-buckets)
 
 // bits of the sticky device status word (kernels atomicOr them in; zkhip_device_status reports and clears)
-enum : uint32_t { ZK_STATUS_GATHER_RANGE = 1u, ZK_STATUS_MSM_PLAN_OVERFLOW = 2u };
+enum : uint32_t { ZK_STATUS_GATHER_RANGE = 1u, ZK_STATUS_MSM_PLAN_OVERFLOW = 2u, ZK_STATUS_LOOKUP_NOT_IN_TABLE = 4u, ZK_STATUS_LOOKUP_SORT_OVERFLOW = 8u };
 
 struct zkhip_bases {
     int curve, group;

@@ -414,6 +414,12 @@ class Context:
                                                             ctypes.c_size_t(len(d_sorted)), arr(d_sorted), ctypes.c_size_t(n), ctypes.c_size_t(usable_rows),
                                                             _p(_u64(beta).reshape(4)), _p(_u64(gamma).reshape(4)), ctypes.c_void_p(d_vl)), "lookup_grand_product_dev")
 
+    def lookup_sort_dev(self, d_input, d_value, n: int, usable_rows: int, d_sorted):
+        """placeholder's sort_polynomials (lookup_argument.hpp:565-638): len(d_input) + len(d_value) sorted vectors of n at d_sorted"""
+        arr = lambda ps: (ctypes.c_void_p * max(len(ps), 1))(*ps)
+        self._check(self.lib.zkhip_lookup_sort_dev(self.h, ctypes.c_size_t(len(d_input)), arr(d_input), ctypes.c_size_t(len(d_value)), arr(d_value),
+                                                   ctypes.c_size_t(n), ctypes.c_size_t(usable_rows), arr(d_sorted)), "lookup_sort_dev")
+
     def poly_lincomb_dev(self, curve: int, d_polys, lens, coeffs: np.ndarray, taps: int, d_acc: int, acc_len: int, accumulate: bool):
         count = len(d_polys)
         ptrs = (ctypes.c_void_p * max(1, count))(*d_polys)

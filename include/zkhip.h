@@ -58,7 +58,8 @@ int zkhip_stream_wait(zkhip_ctx *waiter, zkhip_ctx *signal);
 int zkhip_device(const zkhip_ctx *ctx);
 int zkhip_sync(zkhip_ctx *ctx);
 /* Sticky error flags raised by kernels since the last call (bit 0: a gather index out of range, bit 1: the MSM's
- * large-bucket plan overflowed its capacity).  Synchronises the stream, clears the flags; returns ZKHIP_ERR_RANGE if
+ * large-bucket plan overflowed its capacity, bit 2: zkhip_lookup_sort_dev met a looked-up value that is in no table, bit 3: its
+ * emitted sequence does not fit the sorted vectors).  Synchronises the stream, clears the flags; returns ZKHIP_ERR_RANGE if
  * any was set (the results computed meanwhile are then not to be used).  The shims call it once per proof. */
 int zkhip_device_status(zkhip_ctx *ctx, uint32_t *flags /* nullable */);
 /* Tunables: "msm_window_bits" (0 = auto), "msm_sets" (bucket sets with window tables, 0 = auto), "msm_segment_log" (tail: 2^k buckets
@@ -313,6 +314,20 @@ int zkhip_perm_grand_product_dev(zkhip_ctx *ctx, int curve, size_t k, const void
  * usable_rows < n (ZKHIP_ERR_RANGE otherwise); d_vl: n outputs. */
 int zkhip_lookup_grand_product_dev(zkhip_ctx *ctx, int curve, size_t k_in, const void *const *d_input, size_t k_val, const void *const *d_value, size_t k_sorted,
                                    const void *const *d_sorted, size_t n, size_t usable_rows, const uint64_t *beta, const uint64_t *gamma, void *d_vl);
+/* sort_polynomials of placeholder's lookup argument (ph/lookup_argument.hpp:565-638; called at :188 between the reduction of the
+ * lookup inputs / values to the basic domain and `commit(LOOKUP_BATCH)`).  Over the first usable_rows entries of every vector: the
+ * values of the table columns in their order (columns one after the other), every maximal run of one value replaced by as many copies
+ * as the value occurs among ALL table entries and inputs -- a run of zeros by a single zero, a trailing run of zeros by nothing, and one
+ * zero in front when the first value is non-zero (the reference's walk starts from a virtual zero) --, dealt over the k_in + k_val
+ * output vectors, usable_rows entries each; entry usable_rows of every vector but the last repeats the head of the next; all other
+ * entries are zero.  d_input / d_value / d_sorted: HOST arrays of device pointers to n canonical Fr each (the REDUCED vectors);
+ * usable_rows < n.  Equality is equality of the canonical limbs.  The reference counts with an unordered_map and emits in one serial
+ * walk; here: run detection + u32 scans, an open-addressing hash table over the run heads, one atomic per input, a binary search per
+ * output entry.  A looked-up value that is in no table (the reference's BOOST_ASSERT, :583) raises bit 2 of the sticky status word and
+ * is otherwise ignored; more emitted entries than the vectors hold (a table whose equal values are not adjacent, :559-564) raise bit 3
+ * and the excess is dropped. */
+int zkhip_lookup_sort_dev(zkhip_ctx *ctx, size_t k_in, const void *const *d_input, size_t k_val, const void *const *d_value, size_t n, size_t usable_rows,
+                          void *const *d_sorted);
 /* d_acc[j] (+)= sum_i sum_{t < taps} coeffs[i * taps + t] * poly_i[j - t] for j < acc_len (poly_i is zero outside
  * [0, lens[i])): the accumulation `f += theta_i * (f_i - U) * diffpoly` (kzg_v2.hpp:258-263) for every committed
  * polynomial in ONE pass (coeffs[i] = theta_i * diffpoly_i, a few taps), and `L += ...` (:281-288) with taps = 1.

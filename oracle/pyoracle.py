@@ -1228,18 +1228,24 @@ def reduce_dfs_polynomial_domain(evals: Sequence[int], new_size: int) -> List[in
     return [evals[i * step] for i in range(new_size)]
 
 
-def lookup_sort_polynomials(reduced_input, reduced_value, domain_size: int, usable_rows: int) -> List[List[int]]:
+def lookup_sort_polynomials(reduced_input, reduced_value, domain_size: int, usable_rows: int, strict: bool = True) -> List[List[int]]:
     """lookup_argument.hpp:565-638: the values of the table columns in their order, each repeated as often as it is looked up
     (+ once per table occurrence), dealt over |input| + |value| vectors of usable_rows entries; entry usable_rows of every vector
-    but the last repeats the next vector's head."""
+    but the last repeats the next vector's head.
+    strict (the reference with its BOOST_ASSERTs, :583, :613-617): a looked-up value that is in no table, or more emitted entries than
+    the vectors hold, is an error.  strict = False is the reference as it runs WITHOUT assertions where that is still defined: a
+    looked-up value that is in no table is counted under a key the walk never reaches (:584 `sorting_map[...]++` inserts it), so it
+    changes nothing; a value whose table entries are not adjacent is emitted `count` times at the end of EACH of its runs (:609-624);
+    writing behind the last vector stays an error (the reference indexes past `sorted` there)."""
     count = {}
     for v in reduced_value:
         for j in range(usable_rows):
             count[v[j]] = count.get(v[j], 0) + 1
     for v in reduced_input:
         for j in range(usable_rows):
-            assert v[j] in count, "a looked-up value that is in no table"
-            count[v[j]] += 1
+            if strict:
+                assert v[j] in count, "a looked-up value that is in no table"
+            count[v[j]] = count.get(v[j], 0) + 1
     total = len(reduced_input) + len(reduced_value)
     flat = []
     prev = 0
@@ -1250,7 +1256,7 @@ def lookup_sort_polynomials(reduced_input, reduced_value, domain_size: int, usab
                 prev = v[j]
     if prev != 0:
         flat.extend([prev] * count[prev])
-    assert len(flat) <= total * usable_rows
+    assert len(flat) <= total * usable_rows, "the emitted sequence does not fit the sorted vectors"
     out = [[0] * domain_size for _ in range(total)]
     for idx, val in enumerate(flat):
         out[idx // usable_rows][idx % usable_rows] = val

@@ -188,6 +188,89 @@ def test_lookup_grand_product_abi(ctx, curve, n, usable, k_in, k_val):
         ctx.free(p)
 
 
+def _lookup_sort_on_device(ctx, inputs, values, n, usable):
+    ptrs = []
+    for v in inputs + values:
+        d = ctx.malloc(n * 32)
+        ctx.h2d(d, fr_arr(v))
+        ptrs.append(d)
+    outs = [ctx.malloc(n * 32) for _ in range(len(inputs) + len(values))]
+    junk = fr_arr([5] * n)
+    for d in outs:
+        ctx.h2d(d, junk)        # every entry of every vector must be written
+    ctx.lookup_sort_dev(ptrs[:len(inputs)], ptrs[len(inputs):], n, usable, outs)
+    got = []
+    for d in outs:
+        a = np.zeros((n, 4), dtype=np.uint64)
+        ctx.d2h(a, d)
+        got.append(fr_ints(a))
+    for p in ptrs + outs:
+        ctx.free(p)
+    import ctypes
+    flags = ctypes.c_uint32()
+    ctx.lib.zkhip_device_status(ctx.h, ctypes.byref(flags))     # reads and clears; ZKHIP_ERR_RANGE when a flag was set
+    return got, flags.value
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("log_n,k_in,k_val", [(6, 1, 1), (7, 2, 1), (8, 3, 2), (10, 2, 2), (12, 1, 1), (14, 2, 1), (14, 1, 3)])
+def test_lookup_sort_polynomials_genuine(ctx, curve, log_n, k_in, k_val):
+    """zkhip_lookup_sort_dev = sort_polynomials (lookup_argument.hpp:565-638) on GENUINE instances (tests/util.lookup_instance: every table
+    column starts with a zero, holds distinct values with one repeated in adjacent rows, zeros behind; every input draws from the tables or
+    is zero), 2^6 - 2^14 rows, both curves, against the oracle's restatement of the reference's map + walk: every entry of every vector,
+    the stitch at usable_rows and the zero tails included; no status flag."""
+    from util import lookup_instance
+    C = CURVES[curve]
+    rng = po.SplitMix64(9100 + log_n + 7 * k_in + curve)
+    inputs, values, usable = lookup_instance(C, rng, log_n, k_in, k_val)
+    n = 1 << log_n
+    exp = po.lookup_sort_polynomials(inputs, values, n, usable)
+    got, flags = _lookup_sort_on_device(ctx, inputs, values, n, usable)
+    assert flags == 0
+    assert got == exp
+
+
+def test_lookup_sort_polynomials_edge_cases(ctx):
+    """The corners of the reference's walk (lookup_argument.hpp:601-631), small enough to read: a table that starts on a non-zero value (the
+    walk's virtual zero is emitted first), zero runs in the middle (one zero each) and at the end (nothing), a run of equal values that
+    spans the boundary between two table columns, no inputs, no table; then what the reference only survives without its assertions --
+    a looked-up value that is in no table (ignored, status bit 2), a value whose table entries are NOT adjacent (emitted `count` times per
+    run), an emitted sequence that does not fit (status bit 3, the excess dropped)."""
+    n, u = 16, 12
+    pad = lambda v: v + [0] * (n - len(v))
+    cases = [
+        ([pad([7, 7, 9, 3, 3, 3, 0, 0, 9, 9, 7, 0])], [pad([7, 7, 0, 0, 9, 9, 3, 0, 0, 0, 0, 0])]),                      # leading zero, zero runs
+        ([pad([5] * 12)], [pad([0, 5, 5, 5, 0, 0, 0, 0, 0, 0, 0, 0])]),                                                 # one hot value
+        ([], [pad([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11]), pad([11, 11, 12, 0, 0, 0, 0, 0, 0, 0, 0, 0])]),              # no inputs; a run across two columns
+        ([pad([0] * 12), pad([2, 2, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0])], [pad([0, 0, 0, 2, 2, 0, 0, 0, 0, 0, 0, 0])]),     # zero inputs, zero runs around a value
+        ([pad([1] * 12)], [pad([0] + [1] * 11)]),                                                                        # a table of one value: fills both vectors to the last entry
+    ]
+    for inputs, values in cases:
+        exp = po.lookup_sort_polynomials(inputs, values, n, u)
+        got, flags = _lookup_sort_on_device(ctx, inputs, values, n, u)
+        assert flags == 0 and got == exp, (inputs, values)
+    # no table at all: nothing is emitted, every looked-up value is foreign
+    got, flags = _lookup_sort_on_device(ctx, [pad([0] * 12)], [], n, u)
+    assert got == [[0] * n] and flags == 4
+    # a foreign input: ignored (the reference without assertions counts a key it never emits), flagged
+    inputs, values = [pad([4, 4, 8, 0, 0, 0, 0, 0, 0, 0, 0, 0])], [pad([0, 4, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0])]
+    got, flags = _lookup_sort_on_device(ctx, inputs, values, n, u)
+    assert flags == 4 and got == po.lookup_sort_polynomials(inputs, values, n, u, strict=False)
+    # the same value in two separate runs: `count` copies per run, as the walk does; fits here, no flag
+    inputs, values = [pad([4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0])], [pad([0, 4, 6, 4, 0, 0, 0, 0, 0, 0, 0, 0])]
+    got, flags = _lookup_sort_on_device(ctx, inputs, values, n, u)
+    exp = po.lookup_sort_polynomials(inputs, values, n, u, strict=False)
+    assert flags == 0 and got == exp and exp[0][:9] == [0, 4, 4, 4, 6, 4, 4, 4, 0]
+    # ... and does not fit here: flagged, the vectors hold the head of the sequence
+    inputs, values = [pad([4] * 12)], [pad([4, 6, 4, 6, 4, 6, 4, 6, 4, 6, 4, 6])]
+    got, flags = _lookup_sort_on_device(ctx, inputs, values, n, u)
+    assert flags == 8
+    flat = [0] + sum(([4] * 18 if i % 2 == 0 else [6] * 6 for i in range(12)), [])
+    assert got[0][:u] == flat[:u] and got[1][:u] == flat[u:2 * u] and got[0][u] == flat[u] and got[1][u:] == [0] * (n - u)
+    with pytest.raises(Exception):
+        _lookup_sort_on_device(ctx, inputs, values, n, n)       # usable_rows >= n is refused
+
+
 def test_block_cache_behind_malloc_free(ctx):
     """zkhip_malloc / zkhip_free keep freed blocks for the next request of their size class (option alloc_cache_mb): a block
     comes back for an equal or slightly smaller request, not for a much smaller or a larger one; its contents are whatever the last
