@@ -1143,31 +1143,36 @@ def permutation_leg(np, log_n=20, k=4, steps=6, verify=True):
 
 
 def lookup_leg(np, log_n=20, k_in=2, k_val=1, steps=6, verify=True):
-    """placeholder's lookup argument, prover side, from the sorted vectors on, at BASELINE config 5's row count (hip/placeholder_lookup.hpp mirrors
-    lookup_argument.hpp:153-296): a genuine instance -- k_in inputs drawn from k_val table columns --, resident; V_L (compute_V_L: one inversion
-    per ROW in a serial loop in the reference; the permutation argument's scan here) and the four constraint polynomials."""
+    """placeholder's lookup argument, prover side, at BASELINE config 5's row count (hip/placeholder_lookup.hpp mirrors lookup_argument.hpp:153-296):
+    a genuine instance -- k_in inputs drawn from k_val table columns --, resident; sort_polynomials ON THE DEVICE (zkhip_lookup_sort_dev; the
+    reference: an unordered_map count + one serial walk, :565-638), V_L (compute_V_L: one inversion per ROW in a serial loop in the reference;
+    the permutation argument's scan here) and the four constraint polynomials."""
     import ctypes
 
     lib = _bench_lib()
-    ms = np.zeros(2 * steps, dtype=np.float64)
+    ms = np.zeros(3 * steps, dtype=np.float64)
     verified = ctypes.c_int(-1)
     rc = lib.zkhip_bench_lookup(0, ctypes.c_size_t(log_n), ctypes.c_size_t(k_in), ctypes.c_size_t(k_val), steps, ms.ctypes.data_as(ctypes.c_void_p),
                                 ctypes.byref(verified) if verify else None)
     if rc != 0:
         return {"error": rc}
-    ms = ms.reshape(steps, 2)
+    ms = ms.reshape(steps, 3)
     timed = ms[2:] if steps > 2 else ms    # the first two runs warm the transforms' tables and the context's block cache
-    gp, whole = (float(x) for x in np.median(timed, axis=0))
+    srt, gp, whole = (float(x) for x in np.median(timed, axis=0))
     n = 1 << log_n
     # V_L reads the k_in + k_val + (k_in + k_val) reduced vectors and writes one: 32 B per element each
     alg_gp = (2 * (k_in + k_val) + 1) * n * 32
     ach = alg_gp / (gp * 1e-3) / 1e9
-    return {"metric": "placeholder lookup argument (prover side, from the sorted vectors on), BLS12-381, %d inputs over %d table columns x 2^%d rows, resident"
+    # sort_polynomials reads k_in + k_val vectors and writes as many
+    alg_sort = 2 * (k_in + k_val) * n * 32
+    return {"metric": "placeholder lookup argument (prover side, sort_polynomials included), BLS12-381, %d inputs over %d table columns x 2^%d rows, resident"
                       % (k_in, k_val, log_n),
             "value": round(whole, 3), "unit": "ms per prove_eval", "higher_is_better": False, "statistic": "median of the runs after the first two",
-            "ms_grand_product": round(gp, 3), "ms_per_run": [round(float(x), 2) for x in ms[:, 1]],
+            "ms_sort_polynomials": round(srt, 3), "ms_grand_product": round(gp, 3), "ms_per_run": [round(float(x), 2) for x in ms[:, 2]],
+            "sort_polynomials_gbs": round(alg_sort / (srt * 1e-3) / 1e9, 1),
             "verified": None if not verify else bool(verified.value == 1),
-            "verification": "V_L[0] = 1, V_L[usable_rows] = 1 (the product over all rows closes: the reference's own check, lookup_argument.hpp:217), zeros behind, "
+            "verification": "the device's sorted vectors == the host's construction of them, entry by entry, no status flag; V_L[0] = 1, V_L[usable_rows] = 1 "
+                            "(the product over all rows closes: the reference's own check, lookup_argument.hpp:217), zeros behind, "
                             "the recurrence at 64 sampled rows; F_2(y) against its definition at a random y",
             "roofline": {"bound": "hbm", "kernel": "perm_grand_product (3 launches: chunk ratios + workgroup scan, top scan, apply)", "achieved": round(ach, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None, "algorithmic_bytes": alg_gp,

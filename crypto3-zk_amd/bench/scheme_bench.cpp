@@ -546,7 +546,8 @@ int zkhip_bench_permutation(int device, size_t log_n, size_t k, int steps, doubl
 /* placeholder's lookup argument, prover side, from the sorted vectors on (hip/placeholder_lookup.hpp; lookup_argument.hpp:153-296): k_in inputs drawn
  * from k_val table columns of 2^log_n rows, resident.  A GENUINE instance: table column i is zero at row 0, holds usable_rows / 2 distinct non-zero values
  * behind it and zeros after them; the inputs take table values (or zero) in the usable rows; `sorted` is built on the host as sort_polynomials (:565-638)
- * builds it.  ms: steps x {V_L alone (zkhip_lookup_grand_product_dev), whole prove_eval}.
+ * builds it -- as the EXPECTATION: the timed argument sorts on the device (LA::sort_polynomials) and its vectors must equal the host's entry by entry.
+ * ms: steps x {sort_polynomials, V_L alone (zkhip_lookup_grand_product_dev), the whole argument = sort + prove_eval}.
  * *verified: V_L[0] = 1, V_L[usable_rows] = 1 -- the product over all rows closes: the reference's own BOOST_CHECK (:217) --, zeros behind it, the
  * recurrence at 64 sampled rows (host arithmetic), and F_2(y) == ((q_last + q_blind)(y) - 1)(V_L(y) g(y) - V_L(omega y) h(y)) at a random y, every
  * polynomial evaluated from its coefficient form. */
@@ -587,23 +588,42 @@ int zkhip_bench_lookup(int device, size_t log_n, size_t k_in, size_t k_val, int 
         std::vector<Fr> alphas;
         for (size_t i = 0; i + 1 < total; ++i) alphas.push_back(rnd());
         std::unique_ptr<LA::prover_result_type> last;
+        bool sort_ok = true;
         for (int rep = 0; rep < steps; ++rep) {
             ctx.sync();
             auto t0 = std::chrono::steady_clock::now();
+            /* sort_polynomials on the device (lookup_argument.hpp:187-189); its result replaces the host-built vectors from here on */
+            std::vector<dfs> dev_sorted = LA::sort_polynomials(ctx, d_in, d_val, n, usable);
+            ctx.sync();
+            ms[3 * rep] = ms_since(t0);
+            if (rep == 0 && verified) {    // every entry of every sorted vector against the host's construction (from the draw counts, no map)
+                std::vector<uint64_t> got(4 * n);
+                for (size_t i = 0; i < total && sort_ok; ++i) {
+                    ctx.d2h(got.data(), dev_sorted[i].data(), n * 32);
+                    uint64_t want[4];
+                    for (size_t j = 0; j < n && sort_ok; ++j) {
+                        A::scalar_to_limbs(sorted[i].values[j], want);
+                        sort_ok = std::memcmp(want, &got[4 * j], 32) == 0;
+                    }
+                }
+                sort_ok = sort_ok && ctx.device_status() == 0;
+            }
+            for (auto &p : dev_sorted) p.set_degree(n - 1);
+            t0 = std::chrono::steady_clock::now();
             {
-                dfs v = LA::compute_V_L(ctx, d_sorted, d_in, d_val, beta, gamma, usable);
+                dfs v = LA::compute_V_L(ctx, dev_sorted, d_in, d_val, beta, gamma, usable);
                 ctx.sync();
             }
-            ms[2 * rep] = ms_since(t0);
+            ms[3 * rep + 1] = ms_since(t0);
             t0 = std::chrono::steady_clock::now();
-            last.reset(new LA::prover_result_type(LA::prove_eval(ctx, d_in, d_val, d_sorted, q_last, q_blind, lagrange_0, beta, gamma, alphas, usable, bls_root)));
-            ms[2 * rep + 1] = ms_since(t0);
+            last.reset(new LA::prover_result_type(LA::prove_eval(ctx, d_in, d_val, dev_sorted, q_last, q_blind, lagrange_0, beta, gamma, alphas, usable, bls_root)));
+            ms[3 * rep + 2] = ms_since(t0) + ms[3 * rep];    // the whole argument: sort + prove_eval from the sorted vectors on
         }
         if (verified) {
             std::vector<uint64_t> vl(4 * n);
             ctx.d2h(vl.data(), last->V_L.data(), n * 32);
             auto V = [&](size_t j) { return A::scalar_from_limbs(&vl[4 * j]); };
-            bool ok = V(0) == Fr::one() && V(usable) == Fr::one();
+            bool ok = sort_ok && V(0) == Fr::one() && V(usable) == Fr::one();
             for (size_t j = usable + 1; j < n && ok; ++j) ok = V(j) == Fr::zero();
             const Fr part1 = (Fr::one() + beta) * gamma;
             for (int t = 0; t < 64 && ok; ++t) {
@@ -642,7 +662,7 @@ int zkhip_bench_lookup(int device, size_t log_n, size_t k_in, size_t k_val, int 
 /* One placeholder-shaped prover round at BASELINE config 5's row count, the pieces composed as placeholder_prover::process strings them
  * (prover.hpp:170-218, 262-277, 220-259, 314-317) over GENUINE instances, every polynomial resident from the arguments to the commitments:
  *   permutation argument (4 permuted columns, copy constraints closed inside the usable rows) -> V_P to PERMUTATION_BATCH,
- *   lookup argument (2 inputs over 1 table column; sorted -> LOOKUP_BATCH + commit, V_L -> PERMUTATION_BATCH) + commit(PERMUTATION_BATCH),
+ *   lookup argument (2 inputs over 1 table column; sort_polynomials on the device -> LOOKUP_BATCH + commit, V_L -> PERMUTATION_BATCH) + commit(PERMUTATION_BATCH),
  *   gate argument q (w0 w1 - w2) masked by 1 - q_last - q_blind over the 4n-point domain,
  *   quotient of the eight constraint polynomials (domains 2n .. 8n) by X^n - 1 -- exact: every part vanishes on the rows --, split into 8 parts,
  *   commit(QUOTIENT_BATCH).
@@ -651,7 +671,7 @@ int zkhip_bench_lookup(int device, size_t log_n, size_t k_in, size_t k_val, int 
  * y omega and y omega^usable, the quotient parts at y) -- BASELINE config 5's proof shape, device side, in one figure.
  * ms: steps x {witness commit, permutation, lookup (with its LOOKUP_BATCH commit), PERMUTATION_BATCH commit, gate argument, quotient, split, QUOTIENT_BATCH commit,
  * proof_eval} (9 numbers; the first and the last are 0 when witness_cols == 0).
- * *verified: V_P[usable] = V_L[usable] = 1, the division left no remainder (quotient_polynomial throws otherwise) and
+ * *verified: the device's sorted vectors equal the host's construction entry by entry, V_P[usable] = V_L[usable] = 1, the division left no remainder (quotient_polynomial throws otherwise) and
  * T(y) (y^n - 1) == sum_i alpha_i F_i(y) at a random y, every polynomial evaluated from its coefficient form. */
 int zkhip_bench_placeholder_round(int device, size_t log_n, size_t witness_cols, int steps, double *ms, int *verified) {
     try {
@@ -708,6 +728,7 @@ int zkhip_bench_placeholder_round(int device, size_t log_n, size_t witness_cols,
         std::unique_ptr<PA::prover_result_type> perm;
         std::unique_ptr<LA::prover_result_type> look;
         constexpr std::size_t VARIABLE_VALUES_BATCH = 1, PERMUTATION_BATCH = 2, QUOTIENT_BATCH = 3, LOOKUP_BATCH = 4;
+        bool sort_ok = true;
         for (int rep = 0; rep < steps; ++rep) {
             double *t = ms + 9 * rep + 1;
             kzg_commitment_scheme_v2_hip<C, counting_transcript> scheme(params, bls_root);
@@ -724,9 +745,21 @@ int zkhip_bench_placeholder_round(int device, size_t log_n, size_t witness_cols,
             scheme.append_to_batch(PERMUTATION_BATCH, perm->permutation_polynomial_dfs);
             t[0] = ms_since(t0);
             t0 = std::chrono::steady_clock::now();
-            scheme.append_to_batch(LOOKUP_BATCH, sorted);
+            /* lookup_argument.hpp:187-196: sort_polynomials ON THE DEVICE (round 4 uploaded a host-built `sorted`), LOOKUP_BATCH, commit */
+            std::vector<dfs> dev_sorted = LA::sort_polynomials(ctx, l_in, l_val, n, usable);
+            for (auto &p : dev_sorted) p.set_degree(n - 1);
+            if (rep == 0 && verified) {    // against the host's construction of the same vectors (from the draw counts)
+                std::vector<uint64_t> a(4 * n), b(4 * n);
+                for (size_t i = 0; i < sorted.size(); ++i) {
+                    ctx.d2h(a.data(), dev_sorted[i].data(), n * 32);
+                    ctx.d2h(b.data(), sorted[i].data(), n * 32);
+                    sort_ok = sort_ok && a == b;
+                }
+                sort_ok = sort_ok && ctx.device_status() == 0;
+            }
+            scheme.append_to_batch(LOOKUP_BATCH, dev_sorted);
             auto lookup_commit = scheme.commit(LOOKUP_BATCH);
-            look.reset(new LA::prover_result_type(LA::prove_eval(ctx, l_in, l_val, sorted, q_last, q_blind, lagrange_0, bl, gl, l_alphas, usable, bls_root)));
+            look.reset(new LA::prover_result_type(LA::prove_eval(ctx, l_in, l_val, dev_sorted, q_last, q_blind, lagrange_0, bl, gl, l_alphas, usable, bls_root)));
             scheme.append_to_batch(PERMUTATION_BATCH, look->V_L);
             t[1] = ms_since(t0);
             t0 = std::chrono::steady_clock::now();
@@ -787,7 +820,7 @@ int zkhip_bench_placeholder_round(int device, size_t log_n, size_t witness_cols,
                 ctx.d2h(one_at, static_cast<const char *>(p.data()) + 32 * row, 32);
                 return A::scalar_from_limbs(one_at);
             };
-            bool ok = at_row(perm->permutation_polynomial_dfs, usable) == Fr::one() && at_row(look->V_L, usable) == Fr::one();
+            bool ok = sort_ok && at_row(perm->permutation_polynomial_dfs, usable) == Fr::one() && at_row(look->V_L, usable) == Fr::one();
             const Fr y = sm.nonzero();
             uint64_t yl[4], v[4];
             A::scalar_to_limbs(y, yl);

@@ -66,6 +66,13 @@ public:
     /// work enqueued here from now on runs after what `other` has enqueued so far (both on the same GPU)
     void wait_for(const context &other) const { check(zkhip_stream_wait(ctx_, other.ctx_), "zkhip_stream_wait", ctx_); }
     void sync() const { check(zkhip_sync(ctx_), "zkhip_sync", ctx_); }
+    /// the sticky flags kernels raised since the last call (zkhip.h: zkhip_device_status), read and cleared; synchronises; 0 = none
+    std::uint32_t device_status() const {
+        std::uint32_t flags = 0;
+        const int rc = zkhip_device_status(ctx_, &flags);
+        if (rc != ZKHIP_OK && rc != ZKHIP_ERR_RANGE) check(rc, "zkhip_device_status", ctx_);
+        return flags;
+    }
     void set_option(const char *name, std::int64_t value) const { check(zkhip_set_option(ctx_, name, value), "zkhip_set_option", ctx_); }
     std::int64_t get_option(const char *name) const {
         std::int64_t v = 0;

@@ -14,9 +14,10 @@
 //             current[j] = previous[j] g_i[j] / h_i[j] over the usable rows (zkhip_fr_vec_mul_div_dev), appended to PERMUTATION_BATCH after V_L, and
 //             F_dfs[2] = ((q_last + q_blind) - 1)(sum_i alpha_i (previous_i g_i - current_i h_i) + previous_last g_last - V_L(omega X) h_last)
 //   :278-288  F_dfs[3] = sum_i alpha_i lagrange_0 (sorted_(i + 1) - sorted_i(omega^usable_rows X))
+//   :187-189  sort_polynomials (:565-638, an unordered_map count + one serial walk over the rows in the reference) -- sort_polynomials below
+//             (zkhip_lookup_sort_dev: run detection + scans, a hash table over the run heads, one atomic per input, a binary search per entry)
 // What the caller keeps: the constraint system's side -- prepare_lookup_value / prepare_lookup_input (:411-496, a walk over the lookup tables and
-// gates with theta) and sort_polynomials (:565-638, a hash-map walk over the rows) --, the transcript (beta, gamma, the alphas are arguments) and the
-// two append_to_batch calls (LOOKUP_BATCH: sorted, PERMUTATION_BATCH: V_L): device_polynomial_dfs go to the KZG scheme where they lie.
+// gates with theta); device_polynomial_dfs go to the KZG scheme where they lie.
 //---------------------------------------------------------------------------//
 #ifndef ZKHIP_SHIM_PLACEHOLDER_LOOKUP_HPP
 #define ZKHIP_SHIM_PLACEHOLDER_LOOKUP_HPP
@@ -55,6 +56,31 @@ struct placeholder_lookup_hip {
         check(zkhip_poly_resize_dev(ctx.get(), adapter::id, p.data(), log2_of(p.size()), 1, unused, out.data(), log2_of(new_domain_size), unused), "zkhip_poly_resize_dev",
               ctx.get());
         return out;
+    }
+
+    /// sort_polynomials (:565-638) over the REDUCED vectors, on the device (zkhip_lookup_sort_dev): |input| + |value| vectors of domain_size
+    /// entries that never leave HBM on their way to commit(LOOKUP_BATCH) and compute_V_L.  The reference counts in an unordered_map and
+    /// emits in one serial walk over the rows.  A looked-up value that is in no table (the reference's BOOST_ASSERT, :583) or a table whose
+    /// equal values are not adjacent and overflow the vectors raise bits 2 / 3 of the sticky device status (context::device_status()).
+    static std::vector<dfs_type> sort_polynomials(const context &ctx, const std::vector<dfs_type> &reduced_input, const std::vector<dfs_type> &reduced_value,
+                                                  std::size_t domain_size, std::size_t usable_rows) {
+        std::vector<const void *> pi, pv;
+        for (const auto &x : reduced_input) {
+            if (x.size() != domain_size) throw std::invalid_argument("sort_polynomials: a reduced input's size differs from the basic domain's");
+            pi.push_back(x.data());
+        }
+        for (const auto &x : reduced_value) {
+            if (x.size() != domain_size) throw std::invalid_argument("sort_polynomials: a reduced value's size differs from the basic domain's");
+            pv.push_back(x.data());
+        }
+        std::vector<dfs_type> sorted;
+        std::vector<void *> ps;
+        for (std::size_t i = 0; i < pi.size() + pv.size(); ++i) {
+            sorted.emplace_back(ctx, domain_size);
+            ps.push_back(sorted.back().data());
+        }
+        check(zkhip_lookup_sort_dev(ctx.get(), pi.size(), pi.data(), pv.size(), pv.data(), domain_size, usable_rows, ps.data()), "zkhip_lookup_sort_dev", ctx.get());
+        return sorted;
     }
 
     /// compute_V_L (:375-409) over the REDUCED vectors
