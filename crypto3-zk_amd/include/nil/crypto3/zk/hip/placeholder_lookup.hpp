@@ -23,6 +23,7 @@
 #define ZKHIP_SHIM_PLACEHOLDER_LOOKUP_HPP
 
 #include <array>
+#include <functional>
 #include <stdexcept>
 #include <vector>
 
@@ -113,6 +114,25 @@ struct placeholder_lookup_hip {
                                          const std::vector<dfs_type> &sorted, const dfs_type &q_last, const dfs_type &q_blind, const dfs_type &lagrange_0,
                                          const value_type &beta, const value_type &gamma, const std::vector<value_type> &alphas, std::size_t usable_rows,
                                          const root_of_unity_type &root, std::vector<std::size_t> part_sizes = {}, const std::vector<value_type> &part_alphas = {}) {
+        if (alphas.size() + 1 != sorted.size()) throw std::invalid_argument("lookup argument: one alpha per sorted vector but the first");
+        hooks_type hooks;
+        std::size_t next = 0;
+        hooks.draw_alpha = [&alphas, &next]() { return alphas.at(next++); };
+        return prove_eval_hooked(ctx, lookup_input, lookup_value, sorted, q_last, q_blind, lagrange_0, beta, gamma, usable_rows, root, std::move(part_sizes), part_alphas, hooks);
+    }
+
+    /// what the reference does BETWEEN the numeric steps from `sorted` on (placeholder_arguments.hpp drives them from the transcript and the
+    /// commitment scheme): on_V_L: V_L is final (:213 append_to_batch(PERMUTATION_BATCH)); on_part: an intermediate polynomial is final (:267);
+    /// draw_alpha: the next challenge of F_dfs[3]'s sum, drawn inside its loop (:282-283).  on_V_L / on_part may be empty.
+    struct hooks_type {
+        std::function<void(const dfs_type &)> on_V_L, on_part;
+        std::function<value_type()> draw_alpha;
+    };
+
+    static prover_result_type prove_eval_hooked(const context &ctx, const std::vector<dfs_type> &lookup_input, const std::vector<dfs_type> &lookup_value,
+                                                const std::vector<dfs_type> &sorted, const dfs_type &q_last, const dfs_type &q_blind, const dfs_type &lagrange_0,
+                                                const value_type &beta, const value_type &gamma, std::size_t usable_rows, const root_of_unity_type &root,
+                                                std::vector<std::size_t> part_sizes, const std::vector<value_type> &part_alphas, const hooks_type &hooks) {
         typedef placeholder_permutation_hip<CurveType> PA;    // the shared helpers: plus / minus / scale / multiplied_up
         if (part_sizes.empty()) part_sizes.push_back(sorted.size());
         std::size_t covered = 0;
@@ -124,7 +144,7 @@ struct placeholder_lookup_hip {
             throw std::invalid_argument("lookup argument: part_sizes must add up to the sorted vectors, with one alpha per part but the last");
         if (sorted.empty() || sorted.size() != lookup_input.size() + lookup_value.size())
             throw std::invalid_argument("lookup argument: one sorted vector per input and value vector");
-        if (alphas.size() + 1 != sorted.size()) throw std::invalid_argument("lookup argument: one alpha per sorted vector but the first");
+        if (sorted.size() > 1 && !hooks.draw_alpha) throw std::invalid_argument("lookup argument: no source for F_dfs[3]'s alphas");
         const std::size_t n = sorted[0].size();
         if (q_last.size() != n || q_blind.size() != n || lagrange_0.size() != n) throw std::invalid_argument("lookup argument: selector sizes differ from the basic domain's");
         if (usable_rows >= n) throw std::invalid_argument("lookup argument: usable_rows must be below the domain size");
@@ -134,6 +154,8 @@ struct placeholder_lookup_hip {
         for (const auto &p : lookup_input) reduced_input.push_back(reduce_dfs_polynomial_domain(p, n));
         for (const auto &p : lookup_value) reduced_value.push_back(reduce_dfs_polynomial_domain(p, n));
         dfs_type V_L = compute_V_L(ctx, sorted, reduced_input, reduced_value, beta, gamma, usable_rows);
+        V_L.set_degree(n - 1);
+        if (hooks.on_V_L) hooks.on_V_L(V_L);    // :213
         reduced_input.clear();
         reduced_value.clear();
         /* compute_gs / compute_hs */
@@ -173,6 +195,7 @@ struct placeholder_lookup_hip {
         for (std::size_t p = 0; p + 1 < parts; ++p) {
             dfs_type current = PA::multiplied_up(previous, V_L, gs[p], hs[p], n, usable_rows);
             res.parts_dfs.push_back(current);
+            if (hooks.on_part) hooks.on_part(current);    // :267
             const dfs_type current_ext = PA::extended(current, V.size(), root);    // once for current h_p and, as the next previous, for previous g_(p + 1)
             dfs_type part = minus(polynomial_product<CurveType>({previous_ext, gs[p]}, root), polynomial_product<CurveType>({current_ext, hs[p]}, root), root);
             PA::scale(part, part_alphas[p]);
@@ -191,8 +214,9 @@ struct placeholder_lookup_hip {
         if (sorted.size() > 1) {
             dfs_type sum(ctx, n);
             for (std::size_t i = 0; i + 1 < sorted.size(); ++i) {
+                const value_type alpha = hooks.draw_alpha();    // :282
                 dfs_type shifted = polynomial_shift(sorted[i], (int)usable_rows, n);
-                dfs_type part = affine(sorted[i + 1], &shifted, alphas[i], zero - alphas[i], zero);
+                dfs_type part = affine(sorted[i + 1], &shifted, alpha, zero - alpha, zero);
                 if (i == 0)
                     sum = part;
                 else

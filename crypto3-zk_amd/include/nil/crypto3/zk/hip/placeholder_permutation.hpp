@@ -21,6 +21,7 @@
 #define ZKHIP_SHIM_PLACEHOLDER_PERMUTATION_HPP
 
 #include <array>
+#include <functional>
 #include <stdexcept>
 #include <vector>
 
@@ -44,6 +45,14 @@ struct placeholder_permutation_hip {
         std::vector<dfs_type> parts_dfs;        // the intermediate polynomials of the multi-part form, in PERMUTATION_BATCH order behind V_P
     };
 
+    /// what the reference does BETWEEN the numeric steps (placeholder_arguments.hpp drives them from the transcript and the commitment scheme):
+    /// on_V_P: V_P is final (:139 append_to_batch); draw_alphas(permutation_parts): the parts' challenges (:181-183); on_part: an intermediate
+    /// polynomial is final (:200 append_to_batch).  Any of them may be empty.
+    struct hooks_type {
+        std::function<void(const dfs_type &)> on_V_P, on_part;
+        std::function<std::vector<value_type>(std::size_t parts)> draw_alphas;
+    };
+
     /// `columns[i]`: the i-th permuted column (column_polynomials[global_indices[i]], :93-97), S_id / S_sigma the preprocessed identity /
     /// permutation polynomials, all over the n-row basic domain.  max_quotient_chunks / alphas / usable_rows: the multi-part form
     /// (alphas: permutation_parts - 1 challenges in drawing order, :181-183).
@@ -51,6 +60,19 @@ struct placeholder_permutation_hip {
                                          const std::vector<dfs_type> &S_sigma, const dfs_type &q_last, const dfs_type &q_blind, const dfs_type &lagrange_0,
                                          const value_type &beta, const value_type &gamma, const root_of_unity_type &root, std::size_t max_quotient_chunks = 0,
                                          const std::vector<value_type> &alphas = {}, std::size_t usable_rows = 0) {
+        hooks_type hooks;
+        hooks.draw_alphas = [&alphas](std::size_t parts) {
+            if (alphas.size() + 1 != parts) throw std::invalid_argument("permutation argument: permutation_parts - 1 alphas");
+            return alphas;
+        };
+        return prove_eval_hooked(ctx, columns, S_id, S_sigma, q_last, q_blind, lagrange_0, beta, gamma, root, max_quotient_chunks, usable_rows, hooks);
+    }
+
+    /// the same with the challenges of the parts and the batch appends handed to the caller's hooks, each at the point of the reference's flow
+    static prover_result_type prove_eval_hooked(const context &ctx, const std::vector<dfs_type> &columns, const std::vector<dfs_type> &S_id,
+                                                const std::vector<dfs_type> &S_sigma, const dfs_type &q_last, const dfs_type &q_blind, const dfs_type &lagrange_0,
+                                                const value_type &beta, const value_type &gamma, const root_of_unity_type &root, std::size_t max_quotient_chunks,
+                                                std::size_t usable_rows, const hooks_type &hooks) {
         const std::size_t k = columns.size();
         if (k == 0 || S_id.size() != k || S_sigma.size() != k) throw std::invalid_argument("permutation argument: one S_id / S_sigma per permuted column");
         const std::size_t n = columns[0].size();
@@ -59,7 +81,6 @@ struct placeholder_permutation_hip {
         if (q_last.size() != n || q_blind.size() != n || lagrange_0.size() != n) throw std::invalid_argument("permutation argument: selector sizes differ from the basic domain's");
         if (max_quotient_chunks == 1) throw std::invalid_argument("permutation argument: max_quotient_chunks = 1 leaves no factor per part");
         const std::size_t step = max_quotient_chunks ? max_quotient_chunks - 1 : k, parts = (k + step - 1) / step;    // preprocessor.hpp:80-87
-        if (alphas.size() + 1 != parts) throw std::invalid_argument("permutation argument: permutation_parts - 1 alphas");
         if (parts > 1 && (usable_rows == 0 || usable_rows >= n)) throw std::invalid_argument("permutation argument: the multi-part form needs usable_rows");
         /* 2.-3.: g_v, h_v and V_P in one device call */
         auto d_g = ctx.alloc(k * n * 32), d_h = ctx.alloc(k * n * 32);
@@ -75,6 +96,8 @@ struct placeholder_permutation_hip {
         adapter::scalar_to_limbs(gamma, gl);
         check(zkhip_perm_grand_product_dev(ctx.get(), adapter::id, k, pc.data(), pi.data(), ps.data(), n, bl, gl, d_g.get(), d_h.get(), V_P.data()),
               "zkhip_perm_grand_product_dev", ctx.get());
+        V_P.set_degree(n - 1);
+        if (hooks.on_V_P) hooks.on_V_P(V_P);    // 4. (:139)
         /* 5.: gs[p] = prod of the p-th group's g_v, hs[p] likewise */
         std::vector<dfs_type> gs, hs;
         for (std::size_t lo = 0; lo < k; lo += step) {
@@ -98,6 +121,8 @@ struct placeholder_permutation_hip {
         prover_result_type res {{dfs_type(ctx, 1), dfs_type(ctx, 1), dfs_type(ctx, 1)}, V_P, {}};
         /* F_dfs[0] = lagrange_0 (1 - V_P) = lagrange_0 - lagrange_0 V_P */
         res.F_dfs[0] = minus(L0, polynomial_product<CurveType>({L0, V}, root, L0.size()), root);
+        const std::vector<value_type> alphas = hooks.draw_alphas ? hooks.draw_alphas(parts) : std::vector<value_type>();    // :181-183
+        if (alphas.size() + 1 != parts) throw std::invalid_argument("permutation argument: permutation_parts - 1 alphas");
         dfs_type q(ctx, n);    // q_last + q_blind, in a buffer of its own
         q.set_degree(std::max(q_last.degree(), q_blind.degree()));
         check(zkhip_fr_vec_op_dev(ctx.get(), adapter::id, 0, q_last.data(), q_blind.data(), q.data(), n), "zkhip_fr_vec_op_dev", ctx.get());
@@ -111,6 +136,7 @@ struct placeholder_permutation_hip {
             for (std::size_t p = 0; p + 1 < parts; ++p) {
                 dfs_type current = multiplied_up(previous, V_P, gs[p], hs[p], n, usable_rows);
                 res.parts_dfs.push_back(current);
+                if (hooks.on_part) hooks.on_part(current);    // :200
                 const dfs_type current_ext = extended(current, V.size(), root);    // once for current h_p and, as the next previous, for previous g_(p + 1)
                 dfs_type part = minus(polynomial_product<CurveType>({previous_ext, gs[p]}, root), polynomial_product<CurveType>({current_ext, hs[p]}, root), root);
                 scale(part, alphas[p]);

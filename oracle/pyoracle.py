@@ -1228,6 +1228,62 @@ def reduce_dfs_polynomial_domain(evals: Sequence[int], new_size: int) -> List[in
     return [evals[i * step] for i in range(new_size)]
 
 
+def lookup_prepare_value(tables, selectors, constants, theta: int, mask, root_of_unity, r: int) -> List[List[int]]:
+    """prepare_lookup_value, lookup_argument.hpp:411-433.  tables: [(tag_index, columns_number, lookup_options)], lookup_options[o][i] = index of a
+    constant column; selectors / constants / mask: DFS vectors on the n-row basic domain (degree n - 1).  Per table t and option o
+        v = (t + 1) tag;  v += theta^(i + 1) tag constant_i  (i < columns_number);  v *= mask
+    as POLYNOMIALS: polynomial_dfs's operator* puts a product on the smallest power-of-two domain that holds the sum of the degrees, so v
+    lives on 4n points (2n without columns).  Dense coefficient arithmetic here."""
+    n = len(mask)
+    co = lambda e: intt(list(e), root_of_unity(len(e).bit_length() - 1), r)
+    out = []
+    for t_id, (tag_index, columns_number, options) in enumerate(tables):
+        tag = co(selectors[tag_index])
+        for option in options:
+            v = poly_scale(tag, (t_id + 1) % r, r)
+            theta_acc, degree = theta, n - 1
+            for i in range(columns_number):
+                v = poly_add(v, poly_scale(poly_mul(tag, co(constants[option[i]]), r), theta_acc, r), r)
+                theta_acc = theta_acc * theta % r
+                degree = 2 * (n - 1)
+            v = poly_mul(v, co(mask), r)
+            degree += n - 1
+            size = 1
+            while size < degree + 1:
+                size <<= 1
+            v = (list(v) + [0] * size)[:size]
+            out.append(ntt(v, root_of_unity(size.bit_length() - 1), r))
+    return out
+
+
+# the order in which the two arguments touch the transcript and the commitment scheme (what decides whether a proof is byte-identical):
+# a replay of the reference's statements, for the shim's reference-shaped entry points to be held against (tests/cpp/arguments_test.cpp)
+EV_CHALLENGE, EV_ABSORB, EV_APPEND, EV_COMMIT = 1, 3, 100, 200
+PERMUTATION_BATCH, LOOKUP_BATCH = 2, 4      # systems/plonk/placeholder/proof.hpp:37-41
+
+
+def permutation_argument_events(permutation_parts: int) -> List[int]:
+    """placeholder_permutation_argument::prove_eval, permutation_argument.hpp:70-224"""
+    ev = [EV_CHALLENGE, EV_CHALLENGE]                               # :95-97    beta, gamma
+    ev.append(EV_APPEND + PERMUTATION_BATCH)                        # :139      V_P
+    ev += [EV_CHALLENGE] * (permutation_parts - 1)                  # :181-183  permutation_alphas
+    ev += [EV_APPEND + PERMUTATION_BATCH] * (permutation_parts - 1)  # :200      current_poly of every part but the last
+    return ev
+
+
+def lookup_argument_events(n_sorted: int, n_parts: int) -> List[int]:
+    """placeholder_lookup_argument_prover: the constructor (:128-151) and prove_eval (:153-296)"""
+    ev = [EV_CHALLENGE]                                             # :150      theta
+    ev += [EV_APPEND + LOOKUP_BATCH] * n_sorted                     # :192-194  the sorted polynomials
+    ev += [EV_COMMIT + LOOKUP_BATCH, EV_ABSORB]                     # :195-196  commit, transcript(lookup_commitment)
+    ev += [EV_CHALLENGE, EV_CHALLENGE]                              # :199-200  beta, gamma
+    ev += [EV_CHALLENGE] * (n_parts - 1)                            # :204-206  lookup_alphas
+    ev.append(EV_APPEND + PERMUTATION_BATCH)                        # :213      V_L
+    ev += [EV_APPEND + PERMUTATION_BATCH] * (n_parts - 1)           # :267      current_poly of every part but the last
+    ev += [EV_CHALLENGE] * (n_sorted - 1)                           # :282      one alpha per sorted vector but the first
+    return ev
+
+
 def lookup_sort_polynomials(reduced_input, reduced_value, domain_size: int, usable_rows: int, strict: bool = True) -> List[List[int]]:
     """lookup_argument.hpp:565-638: the values of the table columns in their order, each repeated as often as it is looked up
     (+ once per table occurrence), dealt over |input| + |value| vectors of usable_rows entries; entry usable_rows of every vector
@@ -1306,7 +1362,8 @@ def lookup_argument(lookup_input, lookup_value, sorted_, q_last, q_blind, lagran
     # the factors as (coefficients, values on the rows)
     nxt = lambda v: polynomial_shift(v, 1, n)
     g_f = [(poly_scale(poly_add([gamma], co(v), r), (1 + beta) % r, r), [(1 + beta) * (gamma + x) % r for x in rv]) for v, rv in zip(lookup_input, red_in)]
-    g_f += [(poly_add(poly_add([part1], co(v), r), poly_scale(co(nxt(v)), beta, r), r), [(part1 + a + beta * b) % r for a, b in zip(v, nxt(v))]) for v in lookup_value]
+    g_f += [(poly_add(poly_add([part1], co(v), r), poly_scale(co(nxt(v)), beta, r), r), [(part1 + a + beta * b) % r for a, b in zip(rv, rv[1:] + rv[:1])])
+            for v, rv in zip(lookup_value, red_val)]    # lookup_value may live on a larger domain too (prepare_lookup_value's products: 4n)
     h_f = [(poly_add(poly_add([part1], co(v), r), poly_scale(co(nxt(v)), beta, r), r), [(part1 + a + beta * b) % r for a, b in zip(v, nxt(v))]) for v in sorted_]
     VL, VLs = co(V), co(polynomial_shift(V, 1))
     one = [1]

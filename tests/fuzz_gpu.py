@@ -187,7 +187,46 @@ def fuzz_arguments(zk, ctx, rng, stats):
     srng = po.SplitMix64(int(rng.integers(1, 1 << 30)))
     vec = lambda: [srng.next_mod(r) if rng.random() < 0.97 else int(rng.integers(0, 2)) * (r - 1) for _ in range(n)]
     beta, gamma = srng.next_mod(r), srng.next_mod(r)
-    which = int(rng.integers(0, 3))
+    which = int(rng.integers(0, 4))
+    if which == 3:
+        # sort_polynomials (zkhip_lookup_sort_dev) over a SMALL alphabet, so that every branch of the reference's walk is hit: zero runs at
+        # the head / in the middle / at the end, equal values in separate runs, looked-up values that are in no table; compared with the
+        # reference as it runs without assertions (pyoracle strict = False); an emitted sequence that does not fit must raise bit 3 instead
+        if n < 2:
+            return
+        import ctypes
+        k_in, k_val = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+        usable = int(rng.integers(0, n))
+        sym = [0] + [srng.next_mod(r) for _ in range(int(rng.integers(1, 40)))]
+        runs = float(rng.random())
+        def table():
+            out, cur = [], sym[int(rng.integers(0, len(sym)))]
+            for _ in range(n):
+                if rng.random() > runs:
+                    cur = sym[int(rng.integers(0, len(sym)))]
+                out.append(cur)
+            return out
+        foreign = rng.random() < 0.2
+        values = [table() for _ in range(k_val)]
+        inputs = [[sym[int(rng.integers(0, len(sym)))] if not (foreign and rng.random() < 0.01) else srng.next_mod(r) for _ in range(n)] for _ in range(k_in)]
+        try:
+            exp = po.lookup_sort_polynomials(inputs, values, n, usable, strict=False)
+        except AssertionError:
+            exp = None    # does not fit the vectors
+        present = {v for col in values for v in col[:usable]}
+        want_flags = (4 if any(v not in present for col in inputs for v in col[:usable]) else 0) | (8 if exp is None else 0)
+        ptrs = [_up(ctx, v) for v in inputs + values]
+        outs = [_up(ctx, [5] * n) for _ in range(k_in + k_val)]
+        ctx.lookup_sort_dev(ptrs[:k_in], ptrs[k_in:], n, usable, outs)
+        flags = ctypes.c_uint32()
+        ctx.lib.zkhip_device_status(ctx.h, ctypes.byref(flags))
+        ok = flags.value == want_flags and (exp is None or [_down(ctx, d, n) for d in outs] == exp)
+        for p_ in ptrs + outs:
+            ctx.free(p_)
+        if not ok:
+            raise SystemExit("sort_polynomials differs: n %d usable %d k_in %d k_val %d flags %d (expected %d)" % (n, usable, k_in, k_val, flags.value, want_flags))
+        stats["lookup_sort"] = stats.get("lookup_sort", 0) + 1
+        return
     if which == 0:
         k = int(rng.integers(1, 5))
         cols, sid, ssig = [vec() for _ in range(k)], [vec() for _ in range(k)], [vec() for _ in range(k)]

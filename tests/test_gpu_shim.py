@@ -20,8 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def shim():
     so = os.path.join(ROOT, "tests", "cpp", "libshimtest.so")
-    src = os.path.join(ROOT, "tests", "cpp", "shim_test.cpp")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(ROOT, "tests", "cpp", f) for f in ("shim_test.cpp", "arguments_test.cpp")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")])
     return ctypes.CDLL(so)
 
@@ -510,6 +510,131 @@ def test_placeholder_lookup_argument_shim(shim, curve, log_n, k_in, k_val, big, 
     for f in range(4):
         got = po.poly_trim(fr_ints(out_F[f][: int(sizes[f])]))
         assert got == F[f], f
+
+
+def argument_instances(C, rng, log_n, k, options, columns, k_in, big):
+    """a genuine permutation instance over k witness columns and a genuine lookup instance in the constraint system's OWN terms: a tag
+    selector (1 on rows 1 .. T), `options * columns` constant columns (two adjacent rows equal in every column: a repeated table value),
+    inputs that take values of the theta-compressed table (or zero) on the usable rows.  -> everything shim_placeholder_arguments_transcript takes"""
+    r, n = C.r, 1 << log_n
+    usable = n - 3
+    cols, S_id, S_sigma = permutation_instance(C, rng, log_n, k, usable)
+    q_last = [1 if j == usable else 0 for j in range(n)]
+    q_blind = [1 if j > usable else 0 for j in range(n)]
+    L0 = [1] + [0] * (n - 1)
+    T = usable // 2
+    tag = [1 if 1 <= j <= T else 0 for j in range(n)]
+    consts = []
+    for _ in range(options * columns):
+        c = [rng.next_mod(r) for _ in range(n)]
+        consts.append(c)
+    for o in range(options):            # rows 3 and 4 hold the same table entry in every option
+        for i in range(columns):
+            consts[o * columns + i][4] = consts[o * columns + i][3]
+    return usable, cols, S_id, S_sigma, q_last, q_blind, L0, tag, consts
+
+
+@pytest.mark.parametrize("curve,log_n,k,chunks,options,columns,k_in,big,lookup_parts", [(0, 5, 2, 0, 1, 2, 1, (), None), (1, 5, 3, 3, 2, 1, 1, (0,), [2, 1]),
+                                                                                      (0, 6, 4, 3, 1, 3, 2, (1,), [1, 1, 1]), (1, 6, 1, 0, 2, 2, 2, (), None)])
+def test_placeholder_arguments_reference_entry_points(shim, curve, log_n, k, chunks, options, columns, k_in, big, lookup_parts):
+    """placeholder's permutation and lookup arguments through the REFERENCE'S entry points (hip/placeholder_arguments.hpp):
+    prove_eval(constraint_system, preprocessed_data, table_description, column_polynomials, commitment_scheme, transcript) and
+    placeholder_lookup_argument_prover(constraint_system, preprocessed_data, plonk_columns, commitment_scheme, transcript).prove_eval(),
+    driven in tests/cpp/arguments_test.cpp by stand-ins declared like the reference's classes, with a transcript and a commitment scheme
+    that RECORD.  Held here against the oracle:
+      * the recorded ORDER of challenge draws, append_to_batch, commit and absorb == the oracle's replay of permutation_argument.hpp:95-97,
+        139, 181-183, 200 and lookup_argument.hpp:150, 192-206, 213, 267, 282-283 (BLS12-381 through transcript.challenge<FieldType>());
+      * prepare_lookup_value on the device (the table columns compressed with theta, tagged, masked: a polynomial on 4n points),
+        sort_polynomials on the device, V_P, V_L, every intermediate polynomial value by value, all seven F polynomials coefficient by
+        coefficient == the oracle's;
+      * (inside the harness) the explicit-challenge overloads give the same bits."""
+    C = CURVES[curve]
+    r, n = C.r, 1 << log_n
+    rng = po.SplitMix64(7700 + 13 * curve + log_n + k + 5 * options + columns)
+    usable, cols, S_id, S_sigma, q_last, q_blind, L0, tag, consts = argument_instances(C, rng, log_n, k, options, columns, k_in, big)
+    perm_parts = 1 if chunks == 0 else -(-k // (chunks - 1))
+    total = k_in + options
+    lparts = lookup_parts or [total]
+    assert sum(lparts) == total
+    ch = [rng.next_mod(r) for _ in range(2 + perm_parts - 1 + 3 + len(lparts) - 1 + total - 1)]
+    beta_p, gamma_p, alphas_p = ch[0], ch[1], ch[2:2 + perm_parts - 1]
+    c0 = 2 + perm_parts - 1
+    theta, beta_l, gamma_l = ch[c0], ch[c0 + 1], ch[c0 + 2]
+    part_alphas = ch[c0 + 3:c0 + 3 + len(lparts) - 1]
+    alphas_l = ch[c0 + 3 + len(lparts) - 1:]
+    # the oracle's side of the lookup argument, from the constraint system's terms on
+    mask = [(1 - a - b) % r for a, b in zip(q_last, q_blind)]
+    tables = [(0, columns, [[o * columns + i for i in range(columns)] for o in range(options)])]
+    values = po.lookup_prepare_value(tables, [tag], consts, theta, mask, C.root_of_unity, r)
+    assert all(len(v) == 4 * n for v in values)
+    red_val = [po.reduce_dfs_polynomial_domain(v, n) for v in values]
+    for v in red_val:       # the definition on the rows: mask tag ((t + 1) + sum theta^(i + 1) constant_i)
+        o = red_val.index(v)
+        assert v == [mask[j] * tag[j] * (1 + sum(pow(theta, i + 1, r) * consts[o * columns + i][j] for i in range(columns))) % r for j in range(n)]
+    pool = [0] + [x for v in red_val for x in v[:usable] if x]
+    inputs = []
+    for i in range(k_in):
+        f = [pool[rng.next_mod(len(pool))] for _ in range(usable)] + [rng.next_mod(r) for _ in range(n - usable)]
+        if i in big:
+            bigf = po.dfs_resize(f, 2 * n, C.root_of_unity, r)
+            c = rng.next_mod(r)
+            f = [(v - 2 * c * (j & 1)) % r for j, v in enumerate(bigf)]
+        inputs.append(f)
+    red_in = [po.reduce_dfs_polynomial_domain(f, n) for f in inputs]
+    sorted_ = po.lookup_sort_polynomials(red_in, red_val, n, usable)
+    lres = po.lookup_argument(inputs, values, sorted_, q_last, q_blind, L0, beta_l, gamma_l, alphas_l, usable, C.root_of_unity, r, lookup_parts, part_alphas)
+    VL, FL = lres[0], lres[1]
+    l_currents = lres[2] if lookup_parts else []
+    assert VL[usable] == 1
+    pres = po.permutation_argument(cols, S_id, S_sigma, q_last, q_blind, L0, beta_p, gamma_p, C.root_of_unity, r, chunks, alphas_p, usable)
+    VP, FP = pres[0], pres[1]
+    p_currents = pres[2] if chunks else []
+    assert VP[usable] == 1
+    # through the harness
+    alpha = 7
+    srs = cp.batch_mul(curve, 1, fr_arr([pow(alpha, i, r) for i in range(n)]))[0]
+    evals = fr_arr([x for v in cols + S_id + S_sigma + [q_last, q_blind, L0, tag] + consts + inputs for x in v])
+    in_logs = np.array([len(f).bit_length() - 1 for f in inputs], dtype=np.uint64)
+    lp = np.array(lparts, dtype=np.uint64)
+    events = np.zeros(256, dtype=np.uint64)
+    n_events = np.zeros(1, dtype=np.uint64)
+    out_perm = np.zeros(((1 + len(p_currents)) * n + 3 * 8 * n, 4), dtype=np.uint64)
+    perm_sizes = np.zeros(3, dtype=np.uint64)
+    out_look = np.zeros(((1 + len(l_currents) + total) * n + 4 * 16 * n, 4), dtype=np.uint64)
+    look_sizes = np.zeros(4, dtype=np.uint64)
+    rc = shim.shim_placeholder_arguments_transcript(curve, P(srs), ctypes.c_size_t(n), P(evals), ctypes.c_size_t(k), ctypes.c_size_t(log_n), ctypes.c_size_t(usable),
+                                                    ctypes.c_size_t(chunks), ctypes.c_size_t(perm_parts), ctypes.c_size_t(options), ctypes.c_size_t(columns),
+                                                    ctypes.c_size_t(k_in), P(in_logs), P(lp), ctypes.c_size_t(len(lparts)), P(np.stack([limbs(c, 4) for c in ch])),
+                                                    ctypes.c_size_t(len(ch)), P(events), ctypes.c_size_t(len(events)), P(n_events), P(out_perm), P(perm_sizes),
+                                                    P(out_look), P(look_sizes))
+    assert rc == 0
+    ev = [int(x) for x in events[: int(n_events[0])]]
+    cut = ev.index(0)
+    assert ev[:cut] == po.permutation_argument_events(perm_parts)
+    assert ev[cut + 1:] == po.lookup_argument_events(total, len(lparts))
+    # the permutation argument's polynomials
+    at = 0
+    assert fr_ints(out_perm[at:at + n]) == VP
+    at += n
+    for c in p_currents:
+        assert fr_ints(out_perm[at:at + n]) == c
+        at += n
+    for f in range(3):
+        got = po.poly_trim(fr_ints(out_perm[at + f * 8 * n: at + f * 8 * n + int(perm_sizes[f])]))
+        assert got == FP[f], f
+    # the lookup argument's
+    at = 0
+    assert fr_ints(out_look[at:at + n]) == VL
+    at += n
+    for c in l_currents:
+        assert fr_ints(out_look[at:at + n]) == c
+        at += n
+    for sv in sorted_:
+        assert fr_ints(out_look[at:at + n]) == sv
+        at += n
+    for f in range(4):
+        got = po.poly_trim(fr_ints(out_look[at + f * 16 * n: at + f * 16 * n + int(look_sizes[f])]))
+        assert got == FL[f], f
 
 
 @pytest.mark.parametrize("curve,n", [(0, 64), (1, 48), (0, 1040), (1, 4096)])

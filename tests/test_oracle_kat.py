@@ -468,3 +468,29 @@ def test_placeholder_permutation_argument_definitions(curve, log_n, k, chunks):
     bad[0][1] = (bad[0][1] + 1) % r
     Vb, Fb = po.permutation_argument(bad, S_id, S_sigma, q_last, q_blind, L0, beta, gamma, C.root_of_unity, r)[:2]
     assert Vb[usable] != 1 and any(on_rows(Fb[2]))
+
+
+def test_lookup_prepare_value_and_argument_order():
+    """pyoracle.lookup_prepare_value (lookup_argument.hpp:411-433) pinned to its definition: on the rows of the basic domain the polynomial
+    takes mask tag ((t + 1) + sum_i theta^(i + 1) constant_i) -- a product of three degree-(n - 1) polynomials, so it lives on 4n points
+    (2n without table columns) and its coefficients above 3 (n - 1) are zero.  The replayed call order of the two arguments is pinned to the
+    statement counts of the reference's own code (one part: no part alphas, no intermediate appends)."""
+    C = po.BLS12_381
+    r, n = C.r, 16
+    rng = po.SplitMix64(41)
+    vec = lambda: [rng.next_mod(r) for _ in range(n)]
+    tag, mask, consts, theta = [1 if 1 <= j <= 9 else 0 for j in range(n)], [1] * 13 + [0] * 3, [vec() for _ in range(3)], rng.next_mod(r)
+    tables = [(0, 2, [[0, 1]]), (0, 1, [[2], [0]]), (0, 0, [[]])]
+    vals = po.lookup_prepare_value(tables, [tag], consts, theta, mask, C.root_of_unity, r)
+    assert [len(v) for v in vals] == [4 * n, 4 * n, 4 * n, 2 * n]
+    want = [[(1 + theta * consts[0][j] + theta * theta * consts[1][j]) % r for j in range(n)], [(2 + theta * consts[2][j]) % r for j in range(n)],
+            [(2 + theta * consts[0][j]) % r for j in range(n)], [3] * n]
+    for v, w in zip(vals, want):
+        assert po.reduce_dfs_polynomial_domain(v, n) == [mask[j] * tag[j] * w[j] % r for j in range(n)]
+        c = po.intt(list(v), C.root_of_unity(len(v).bit_length() - 1), r)
+        assert not any(c[3 * (n - 1) + 1:])
+    E = po
+    assert po.permutation_argument_events(1) == [E.EV_CHALLENGE, E.EV_CHALLENGE, E.EV_APPEND + 2]
+    assert po.permutation_argument_events(3) == [1, 1, 102, 1, 1, 102, 102]
+    assert po.lookup_argument_events(2, 1) == [1, 104, 104, 204, 3, 1, 1, 102, 1]
+    assert po.lookup_argument_events(3, 2) == [1, 104, 104, 104, 204, 3, 1, 1, 1, 102, 102, 1, 1]
