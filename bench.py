@@ -1345,7 +1345,7 @@ def cpu_baseline(np, bases, scalars, gpu_affine):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cport as cp
 
-    omp = cp.num_threads()
+    omp = cp.omp_default_threads()
     try:
         usable = len(os.sched_getaffinity(0))
     except AttributeError:

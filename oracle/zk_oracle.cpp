@@ -1137,6 +1137,52 @@ struct BasesHandle {
     std::shared_ptr<void> data;
 };
 
+// one transform with the work of every stage spread over the threads (the batch transform above parallelises over polynomials)
+template <class S>
+static void ntt_wide(std::vector<S> &a, size_t log_m, const S &omega) {
+    const size_t m = (size_t)1 << log_m;
+    for (size_t i = 0; i < m; ++i) {
+        size_t j = 0;
+        for (size_t b = 0; b < log_m; ++b) j |= ((i >> b) & 1) << (log_m - 1 - b);
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    std::vector<S> tw(std::max<size_t>(1, m / 2));
+    const size_t blk = 1024;
+#pragma omp parallel for schedule(static)
+    for (size_t b = 0; b < (m / 2 + blk - 1) / blk; ++b) {
+        S w = omega.pow_u64(b * blk);
+        for (size_t i = b * blk; i < std::min(m / 2, (b + 1) * blk); ++i) {
+            tw[i] = w;
+            w = w * omega;
+        }
+    }
+    for (size_t s = 1; s <= log_m; ++s) {
+        const size_t half = (size_t)1 << (s - 1), stride = m >> s;
+#pragma omp parallel for schedule(static)
+        for (size_t t = 0; t < m / 2; ++t) {
+            const size_t k = (t / half) * 2 * half, j = t % half;
+            const S x = tw[j * stride] * a[k + j + half], u = a[k + j];
+            a[k + j] = u + x;
+            a[k + j + half] = u - x;
+        }
+    }
+}
+
+template <class S>
+static void poly_mul_t(const uint64_t *a, size_t na, const uint64_t *b, size_t nb, const uint64_t *omega_c, size_t log_m, uint64_t *out) {
+    const size_t m = (size_t)1 << log_m, no = na + nb - 1;
+    std::vector<S> x(m, S::zero()), y(m, S::zero());
+    for (size_t i = 0; i < na; ++i) x[i] = S::from_canonical(a + 4 * i);
+    for (size_t i = 0; i < nb; ++i) y[i] = S::from_canonical(b + 4 * i);
+    const S omega = S::from_canonical(omega_c);
+    ntt_wide<S>(x, log_m, omega);
+    ntt_wide<S>(y, log_m, omega);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < m; ++i) x[i] = x[i] * y[i];
+    ntt_wide<S>(x, log_m, omega.inv());
+    const S minv = S::from_u64(m).inv();
+    for (size_t i = 0; i < no; ++i) (x[i] * minv).to_canonical(out + 4 * i);
+}
 extern "C" {
 
 int zko_num_threads() {
@@ -1282,6 +1328,142 @@ int zko_random_fr(int curve, uint64_t seed, size_t n, uint64_t *out) {
     SplitMix64 rng{seed};
     const uint64_t *mod = curve == 0 ? BLS_R : BN_R;
     for (size_t i = 0; i < n; ++i) rng.next_mod(mod, out + 4 * i);
+    return 0;
+}
+
+// ---- placeholder's argument arithmetic at sizes the big-integer oracle cannot reach ------------------------------
+// Primitives only -- the orchestration (which products, which domains) stays in oracle/cport.py, statement by statement next to
+// pyoracle.permutation_argument / lookup_argument, whose dense O(n^2) arithmetic they are pinned to at <= 2^8 rows
+// (tests/test_oracle_kat.py).  Polynomials cross as coefficient vectors of canonical Fr.
+
+// out (na + nb - 1 coefficients) = a * b by transforms over 2^log_m >= na + nb - 1 points, omega the primitive 2^log_m-th root
+int zko_poly_mul(int curve, const uint64_t *a, size_t na, const uint64_t *b, size_t nb, const uint64_t *omega, size_t log_m, uint64_t *out) {
+    if (na == 0 || nb == 0 || ((size_t)1 << log_m) < na + nb - 1) return -1;
+    if (curve == 0) poly_mul_t<FrBLS>(a, na, b, nb, omega, log_m, out);
+    else if (curve == 1) poly_mul_t<FrBN>(a, na, b, nb, omega, log_m, out);
+    else return -1;
+    return 0;
+}
+// one transform of one vector, threads over the butterflies (cport's dfs <-> coefficients at 2^16 .. 2^20)
+int zko_ntt_wide(int curve, uint64_t *data, size_t log_m, const uint64_t *omega, int inverse) {
+    auto run = [&](auto tag) {
+        typedef decltype(tag) S;
+        const size_t m = (size_t)1 << log_m;
+        std::vector<S> a(m);
+        for (size_t i = 0; i < m; ++i) a[i] = S::from_canonical(data + 4 * i);
+        S w = S::from_canonical(omega);
+        ntt_wide<S>(a, log_m, inverse ? w.inv() : w);
+        const S minv = inverse ? S::from_u64(m).inv() : S::one();
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < m; ++i) (a[i] * minv).to_canonical(data + 4 * i);
+    };
+    if (curve == 0) run(FrBLS());
+    else if (curve == 1) run(FrBN());
+    else return -1;
+    return 0;
+}
+// pointwise over n elements: op 0 a + b, 1 a - b, 2 a b, 3 a b[0] (scale), 4 a b / c (one inversion per element, as the reference's loops)
+int zko_fr_vec(int curve, int op, const uint64_t *a, const uint64_t *b, const uint64_t *c, uint64_t *out, size_t n) {
+    auto run = [&](auto tag) {
+        typedef decltype(tag) S;
+        const S k = op == 3 ? S::from_canonical(b) : S::zero();
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < n; ++i) {
+            const S x = S::from_canonical(a + 4 * i);
+            S r;
+            if (op == 3) r = x * k;
+            else {
+                const S y = S::from_canonical(b + 4 * i);
+                r = op == 0 ? x + y : op == 1 ? x - y : x * y;
+                if (op == 4) r = r * S::from_canonical(c + 4 * i).inv();
+            }
+            r.to_canonical(out + 4 * i);
+        }
+    };
+    if (op < 0 || op > 4) return -1;
+    if (curve == 0) run(FrBLS());
+    else if (curve == 1) run(FrBN());
+    else return -1;
+    return 0;
+}
+// permutation_argument.hpp:103-136: g_v / h_v (k x n each) and V_P by the row-by-row recurrence, one inversion per row (the inversions
+// are independent of the recurrence: taken in parallel, then the serial product)
+int zko_perm_grand_product(int curve, size_t k, size_t n, const uint64_t *cols, const uint64_t *sid, const uint64_t *ssig, const uint64_t *beta_c,
+                           const uint64_t *gamma_c, uint64_t *out_g, uint64_t *out_h, uint64_t *out_v) {
+    auto run = [&](auto tag) {
+        typedef decltype(tag) S;
+        const S beta = S::from_canonical(beta_c), gamma = S::from_canonical(gamma_c);
+        std::vector<S> ratio(n);
+#pragma omp parallel for schedule(static)
+        for (size_t j = 0; j < n; ++j) {
+            S nom = S::one(), den = S::one();
+            for (size_t i = 0; i < k; ++i) {
+                const S col = S::from_canonical(cols + 4 * (i * n + j));
+                const S g = col + beta * S::from_canonical(sid + 4 * (i * n + j)) + gamma, h = col + beta * S::from_canonical(ssig + 4 * (i * n + j)) + gamma;
+                g.to_canonical(out_g + 4 * (i * n + j));
+                h.to_canonical(out_h + 4 * (i * n + j));
+                nom = nom * g;
+                den = den * h;
+            }
+            ratio[j] = nom * den.inv();
+        }
+        S v = S::one();
+        for (size_t j = 0; j < n; ++j) {
+            v.to_canonical(out_v + 4 * j);
+            v = v * ratio[j];
+        }
+    };
+    if (curve == 0) run(FrBLS());
+    else if (curve == 1) run(FrBN());
+    else return -1;
+    return 0;
+}
+// compute_V_L, lookup_argument.hpp:375-409: V[0] = 1, V[k] = V[k - 1] g(k - 1) / h(k - 1) for k <= usable_rows, zero behind
+int zko_lookup_grand_product(int curve, size_t k_in, size_t k_val, size_t k_sorted, size_t n, size_t usable_rows, const uint64_t *in, const uint64_t *val,
+                             const uint64_t *sorted, const uint64_t *beta_c, const uint64_t *gamma_c, uint64_t *out_v) {
+    auto run = [&](auto tag) {
+        typedef decltype(tag) S;
+        const S beta = S::from_canonical(beta_c), gamma = S::from_canonical(gamma_c), opb = S::one() + beta, part1 = opb * gamma;
+        S pw = S::one();
+        for (size_t i = 0; i < k_in; ++i) pw = pw * opb;
+        std::vector<S> ratio(usable_rows);
+#pragma omp parallel for schedule(static)
+        for (size_t j = 0; j < usable_rows; ++j) {
+            const size_t nx = j + 1 == n ? 0 : j + 1;
+            S g = pw, h = S::one();
+            for (size_t i = 0; i < k_in; ++i) g = g * (gamma + S::from_canonical(in + 4 * (i * n + j)));
+            for (size_t i = 0; i < k_val; ++i) g = g * (part1 + S::from_canonical(val + 4 * (i * n + j)) + beta * S::from_canonical(val + 4 * (i * n + nx)));
+            for (size_t i = 0; i < k_sorted; ++i) h = h * (part1 + S::from_canonical(sorted + 4 * (i * n + j)) + beta * S::from_canonical(sorted + 4 * (i * n + nx)));
+            ratio[j] = g * h.inv();
+        }
+        S v = S::one();
+        memset(out_v, 0, n * 32);
+        for (size_t j = 0; j <= usable_rows && j < n; ++j) {
+            v.to_canonical(out_v + 4 * j);
+            if (j < usable_rows) v = v * ratio[j];
+        }
+    };
+    if (usable_rows >= n) return -1;
+    if (curve == 0) run(FrBLS());
+    else if (curve == 1) run(FrBN());
+    else return -1;
+    return 0;
+}
+// f (len coefficients) = q (X^n - 1) + rem: q[i] = f[i + n] + q[i + n] top down; returns the number of non-zero remainder coefficients
+int zko_poly_div_vanishing(int curve, const uint64_t *f, size_t len, size_t n, uint64_t *out_q, uint64_t *nonzero_rem) {
+    auto run = [&](auto tag) {
+        typedef decltype(tag) S;
+        std::vector<S> a(len);
+        for (size_t i = 0; i < len; ++i) a[i] = S::from_canonical(f + 4 * i);
+        for (size_t i = len; i-- > n;) a[i - n] = a[i - n] + a[i];      // a[i] is final: it is q[i - n]
+        for (size_t i = n; i < len; ++i) a[i].to_canonical(out_q + 4 * (i - n));
+        uint64_t nz = 0;
+        for (size_t i = 0; i < std::min(n, len); ++i) nz += !a[i].is_zero();
+        *nonzero_rem = nz;
+    };
+    if (curve == 0) run(FrBLS());
+    else if (curve == 1) run(FrBN());
+    else return -1;
     return 0;
 }
 

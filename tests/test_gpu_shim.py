@@ -712,6 +712,128 @@ def test_placeholder_round_composed_shim(shim, curve, log_n):
         assert (out_commits[i] == g(c)).all(), i
 
 
+def _selectors(n, usable):
+    return [1 if j == usable else 0 for j in range(n)], [1 if j > usable else 0 for j in range(n)], [1] + [0] * (n - 1)
+
+
+@pytest.mark.parametrize("curve,log_n", [(0, 12), (1, 12), (0, 16), (1, 16)])
+def test_placeholder_arguments_at_multipass_sizes(shim, curve, log_n):
+    """the arguments' parity beyond toy sizes.  At 2^12 and 2^16 rows the device runs what the 2^20 legs run -- multi-pass
+    transforms, subsampled extensions inside polynomial_product, the block cache's reuse -- and every output is held against the
+    C++-backed oracle (oracle/cport.py permutation_argument / lookup_argument / quotient_polynomial, pinned to pyoracle's dense arithmetic
+    at <= 2^8 rows in tests/test_oracle_kat.py), bit for bit:
+      * permutation argument, 4 columns, one part and max_quotient_chunks = 3 (two parts): V_P, the intermediate polynomial, F_0 .. F_2;
+      * lookup argument, 2 inputs (one on the 2n-point domain) over 1 table, one part and parts [2, 1]: sorted (oracle's map + walk),
+        V_L, the intermediate polynomial, F_0 .. F_3;
+      * the composed round (permutation + lookup + gate arguments, quotient of the eight parts, split, commitments): T coefficient by
+        coefficient, every commitment = polynomial(alpha) G."""
+    C = CURVES[curve]
+    r, n = C.r, 1 << log_n
+    usable = n - 3
+    root = C.root_of_unity
+    A = fr_arr
+    rng = po.SplitMix64(9900 + curve + log_n)
+    q_last, q_blind, L0 = _selectors(n, usable)
+    roots = np.stack([limbs(root(l), 4) for l in range(log_n + 5)])
+    # ---- permutation argument
+    k = 4
+    cols, S_id, S_sigma = permutation_instance(C, rng, log_n, k, usable)
+    e_perm = fr_arr([x for v in cols + S_id + S_sigma + [q_last, q_blind, L0] for x in v])
+    a_cols, a_sid, a_ssig = [A(c) for c in cols], [A(c) for c in S_id], [A(c) for c in S_sigma]
+    for chunks in (0, 3):
+        parts = 1 if chunks == 0 else -(-k // (chunks - 1))
+        beta, gamma = rng.next_mod(r), rng.next_mod(r)
+        alphas = [rng.next_mod(r) for _ in range(parts - 1)]
+        want = cp.permutation_argument(curve, a_cols, a_sid, a_ssig, A(q_last), A(q_blind), A(L0), beta, gamma, chunks, alphas, usable)
+        assert fr_ints(want[0][usable:usable + 1]) == [1]
+        out_vp = np.zeros((n, 4), dtype=np.uint64)
+        out_F = np.zeros((3, 8 * n, 4), dtype=np.uint64)
+        sizes = np.zeros(3, dtype=np.uint64)
+        out_parts = np.zeros((max(1, parts - 1), n, 4), dtype=np.uint64)
+        al = np.stack([limbs(a, 4) for a in alphas] + [limbs(0, 4)])
+        rc = shim.shim_placeholder_permutation(curve, P(e_perm), ctypes.c_size_t(k), ctypes.c_size_t(log_n), P(roots), P(limbs(beta, 4)), P(limbs(gamma, 4)),
+                                               ctypes.c_size_t(chunks), P(al), ctypes.c_size_t(len(alphas)), ctypes.c_size_t(usable), P(out_vp), P(out_F), P(sizes),
+                                               P(out_parts))
+        assert rc == 0
+        assert (out_vp == want[0]).all()
+        for i, c in enumerate(want[2] if chunks else []):
+            assert (out_parts[i] == c).all(), i
+        for f in range(3):
+            got = cp.poly_trim(out_F[f][: int(sizes[f])])
+            assert got.shape == want[1][f].shape and (got == want[1][f]).all(), (chunks, f)
+    # ---- lookup argument
+    k_in, k_val = 2, 1
+    inputs, values, usable_l = lookup_instance(C, rng, log_n, k_in, k_val, (1,))
+    assert usable_l == usable
+    a_in, a_val = [A(f) for f in inputs], [A(v) for v in values]
+    red_in = [cp.reduce_dfs_polynomial_domain(f, n) for f in a_in]
+    sorted_ = cp.lookup_sort_polynomials(red_in, a_val, n, usable)
+    e_look = np.concatenate(a_in + a_val + sorted_ + [A(q_last), A(q_blind), A(L0)])
+    in_logs = np.array([len(f).bit_length() - 1 for f in inputs], dtype=np.uint64)
+    for part_sizes in (None, [2, 1]):
+        beta, gamma = rng.next_mod(r), rng.next_mod(r)
+        alphas = [rng.next_mod(r) for _ in range(k_in + k_val - 1)]
+        part_alphas = [rng.next_mod(r) for _ in range(len(part_sizes) - 1)] if part_sizes else []
+        want = cp.lookup_argument(curve, a_in, a_val, sorted_, A(q_last), A(q_blind), A(L0), beta, gamma, alphas, usable, part_sizes, part_alphas)
+        assert fr_ints(want[0][usable:usable + 1]) == [1]
+        currents = want[2] if part_sizes else []
+        out_vl = np.zeros((n, 4), dtype=np.uint64)
+        out_F = np.zeros((4, 16 * n, 4), dtype=np.uint64)
+        sizes = np.zeros(4, dtype=np.uint64)
+        al = np.stack([limbs(a, 4) for a in alphas] + [limbs(0, 4)])
+        ps = np.array(part_sizes or [], dtype=np.uint64)
+        pa = np.stack([limbs(a, 4) for a in part_alphas] + [limbs(0, 4)])
+        out_parts = np.zeros((max(1, len(currents)), n, 4), dtype=np.uint64)
+        rc = shim.shim_placeholder_lookup(curve, P(e_look), ctypes.c_size_t(k_in), P(in_logs), ctypes.c_size_t(k_val), ctypes.c_size_t(log_n), ctypes.c_size_t(usable),
+                                          P(roots), P(limbs(beta, 4)), P(limbs(gamma, 4)), P(al), P(ps) if len(ps) else None, ctypes.c_size_t(len(ps)), P(pa), P(out_vl),
+                                          P(out_F), P(sizes), P(out_parts))
+        assert rc == 0
+        assert (out_vl == want[0]).all()
+        for i, c in enumerate(currents):
+            assert (out_parts[i] == c).all(), i
+        for f in range(4):
+            got = cp.poly_trim(out_F[f][: int(sizes[f])])
+            assert got.shape == want[1][f].shape and (got == want[1][f]).all(), (part_sizes, f)
+    # ---- the composed round: 2 permuted columns, 1 input over 1 table, the gate q (w0 w1 - w2)
+    k, alpha = 2, 7
+    inputs1, values1, _ = lookup_instance(C, rng, log_n, 1, 1)
+    a_in1, a_val1 = [A(f) for f in inputs1], [A(v) for v in values1]
+    sorted1 = cp.lookup_sort_polynomials(a_in1, a_val1, n, usable)
+    q = [1 if (j % 3 == 0 and j < usable) else 0 for j in range(n)]
+    w0, w1 = ([rng.next_mod(r) for _ in range(n)] for _ in range(2))
+    w2 = [w0[j] * w1[j] % r if q[j] else rng.next_mod(r) for j in range(n)]
+    ch = [rng.next_mod(r) for _ in range(13)]
+    bp, gp, bl, gl, al1 = ch[:5]
+    alphas = ch[5:]
+    VL, Fl = cp.lookup_argument(curve, a_in1, a_val1, sorted1, A(q_last), A(q_blind), A(L0), bl, gl, [al1], usable)[:2]
+    co = lambda e: cp.dfs_coefficients(curve, A(e) if isinstance(e, list) else e)
+    mask = [(1 - a - b) % r for a, b in zip(q_last, q_blind)]
+    # gate argument (gates_argument.hpp:203-216): mask (q w0 w1 - q w2)
+    cq = co(q)
+    G = cp.poly_mul(curve, co(mask), cp.poly_sub(curve, cp.poly_mul(curve, cp.poly_mul(curve, cq, co(w0)), co(w1)), cp.poly_mul(curve, cq, co(w2))))
+    # a 2-column copy-constraint instance of its own (the cycles of the 4-column one cross into columns 2 and 3)
+    cols2, S_id2, S_sigma2 = permutation_instance(C, rng, log_n, k, usable)
+    a2 = [A(c) for c in cols2], [A(c) for c in S_id2], [A(c) for c in S_sigma2]
+    VP, Fp = cp.permutation_argument(curve, a2[0], a2[1], a2[2], A(q_last), A(q_blind), A(L0), bp, gp)[:2]
+    T = cp.quotient_polynomial(curve, list(Fp) + list(Fl) + [G], alphas, n)
+    assert len(T) <= 3 * n
+    srs = _srs(curve, alpha, n)
+    L1 = srs.shape[1]
+    evals = np.concatenate(a2[0] + a2[1] + a2[2] + a_in1 + a_val1 + sorted1 + [A(q), A(w0), A(w1), A(w2), A(q_last), A(q_blind), A(L0)])
+    out_T = np.zeros((3 * n, 4), dtype=np.uint64)
+    out_commits = np.zeros((8, L1), dtype=np.uint64)
+    rc = shim.shim_placeholder_round(curve, P(srs), ctypes.c_size_t(n), P(evals), ctypes.c_size_t(k), ctypes.c_size_t(log_n), ctypes.c_size_t(usable), P(roots),
+                                     P(np.stack([limbs(c, 4) for c in ch])), P(out_T), P(out_commits))
+    assert rc == 0
+    Tp = np.concatenate([T, np.zeros((3 * n - len(T), 4), dtype=np.uint64)])
+    assert (out_T == Tp).all()
+    at_alpha = lambda c: cp.fr_horner(curve, c, limbs(alpha, 4)) if len(c) else limbs(0, 4)
+    g = lambda c: cp.batch_mul(curve, 1, at_alpha(c).reshape(1, 4))[0][0]
+    expected = [co(VP), co(VL), co(sorted1[0]), co(sorted1[1])] + [Tp[i * n:(i + 1) * n] for i in range(4)]
+    for i, c in enumerate(expected):
+        assert (out_commits[i] == g(c)).all(), i
+
+
 def test_placeholder_transcript_bytes_bls12_381(shim):
     """a placeholder proof is bit-exact with the reference's only if the TRANSCRIPT absorbs the same bytes.  The
     placeholder-facing KZG scheme with the reference's encodings -- commitments as 48-byte compressed BLS12-381 points (the

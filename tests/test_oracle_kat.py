@@ -494,3 +494,58 @@ def test_lookup_prepare_value_and_argument_order():
     assert po.permutation_argument_events(3) == [1, 1, 102, 1, 1, 102, 102]
     assert po.lookup_argument_events(2, 1) == [1, 104, 104, 204, 3, 1, 1, 102, 1]
     assert po.lookup_argument_events(3, 2) == [1, 104, 104, 104, 204, 3, 1, 1, 1, 102, 102, 1, 1]
+
+
+@pytest.mark.parametrize("curve,log_n,k,chunks", [(0, 5, 3, 0), (1, 6, 4, 3), (0, 8, 5, 3), (1, 7, 2, 8)])
+def test_fast_argument_oracle_equals_dense_oracle_permutation(curve, log_n, k, chunks):
+    """The C++-backed restatement of the permutation argument (oracle/cport.py permutation_argument: transform-based products, the row
+    recurrence with one inversion per row in liboracle.so) -- what the -m gpu suite holds the device against at 2^12 and 2^16 rows -- PINNED to
+    pyoracle.permutation_argument's dense big-integer arithmetic (itself pinned to what the argument is for): V_P, the intermediate
+    polynomials of the multi-part form and F_0 .. F_2 coefficient by coefficient."""
+    from util import CURVES, fr_arr, fr_ints, permutation_instance
+    C = CURVES[curve]
+    r, n = C.r, 1 << log_n
+    usable = n - 3
+    rng = po.SplitMix64(500 + log_n + k)
+    cols, S_id, S_sigma = permutation_instance(C, rng, log_n, k, usable)
+    q_last = [1 if j == usable else 0 for j in range(n)]
+    q_blind = [1 if j > usable else 0 for j in range(n)]
+    L0 = [1] + [0] * (n - 1)
+    beta, gamma = rng.next_mod(r), rng.next_mod(r)
+    parts = 1 if chunks == 0 else -(-k // (chunks - 1))
+    alphas = [rng.next_mod(r) for _ in range(parts - 1)]
+    want = po.permutation_argument(cols, S_id, S_sigma, q_last, q_blind, L0, beta, gamma, C.root_of_unity, r, chunks, alphas, usable)
+    A = fr_arr
+    got = cp.permutation_argument(curve, [A(c) for c in cols], [A(c) for c in S_id], [A(c) for c in S_sigma], A(q_last), A(q_blind), A(L0), beta, gamma, chunks, alphas,
+                                  usable)
+    assert fr_ints(got[0]) == want[0]
+    assert [fr_ints(f) for f in got[1]] == want[1]
+    if chunks:
+        assert [fr_ints(c) for c in got[2]] == want[2]
+
+
+@pytest.mark.parametrize("curve,log_n,k_in,k_val,big,part_sizes", [(0, 6, 1, 1, (), None), (1, 5, 2, 1, (1,), [2, 1]), (0, 7, 3, 2, (0,), [2, 1, 2]), (1, 8, 2, 2, (), None)])
+def test_fast_argument_oracle_equals_dense_oracle_lookup(curve, log_n, k_in, k_val, big, part_sizes):
+    """likewise for the lookup argument (cport.lookup_sort_polynomials, lookup_argument; a `big` input lives on the 2n-point domain)"""
+    from util import CURVES, fr_arr, fr_ints, lookup_instance
+    C = CURVES[curve]
+    r, n = C.r, 1 << log_n
+    rng = po.SplitMix64(600 + log_n + k_in)
+    inputs, values, usable = lookup_instance(C, rng, log_n, k_in, k_val, big)
+    red_in = [po.reduce_dfs_polynomial_domain(f, n) for f in inputs]
+    sorted_ = po.lookup_sort_polynomials(red_in, values, n, usable)
+    q_last = [1 if j == usable else 0 for j in range(n)]
+    q_blind = [1 if j > usable else 0 for j in range(n)]
+    L0 = [1] + [0] * (n - 1)
+    beta, gamma = rng.next_mod(r), rng.next_mod(r)
+    alphas = [rng.next_mod(r) for _ in range(k_in + k_val - 1)]
+    pa = [rng.next_mod(r) for _ in range(len(part_sizes) - 1)] if part_sizes else []
+    want = po.lookup_argument(inputs, values, sorted_, q_last, q_blind, L0, beta, gamma, alphas, usable, C.root_of_unity, r, part_sizes, pa)
+    A = fr_arr
+    s2 = cp.lookup_sort_polynomials([A(x) for x in red_in], [A(x) for x in values], n, usable)
+    assert [fr_ints(x) for x in s2] == sorted_
+    got = cp.lookup_argument(curve, [A(x) for x in inputs], [A(x) for x in values], s2, A(q_last), A(q_blind), A(L0), beta, gamma, alphas, usable, part_sizes, pa)
+    assert fr_ints(got[0]) == want[0]
+    assert [fr_ints(f) for f in got[1]] == want[1]
+    if part_sizes:
+        assert [fr_ints(c) for c in got[2]] == want[2]
