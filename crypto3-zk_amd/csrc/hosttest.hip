@@ -6,6 +6,7 @@
 
 #define ZK_NOINLINE_MUL 1  // keeps this shim's build time short; fu_sqr is reached through op 9
 #include "curve.hpp"
+#include "fu_safegcd.hpp"
 #include "msm_recode.hpp"
 
 using namespace zkhip;
@@ -22,6 +23,12 @@ F sqr_direct(const F &x) { return FieldOps<F>::sqr(x); }
 template <class U>
 Fu<U> sqr_direct(const Fu<U> &x) { return fu_sqr(x); }
 
+// op 11: the safegcd inverse the grand products take once per call (fu_safegcd.hpp); the saturated reference types have none of their own
+template <class F>
+F inv_gcd(const F &x) { return FieldOps<F>::inv(x); }
+template <class U>
+Fu<U> inv_gcd(const Fu<U> &x) { return fu_inv_gcd(fu_canon(x)); }
+
 template <class F>
 int field_op(int op, const uint32_t *a, const uint32_t *b, uint32_t *out) {
     typedef FieldOps<F> O;
@@ -37,6 +44,7 @@ int field_op(int op, const uint32_t *a, const uint32_t *b, uint32_t *out) {
         case 7: r = O::template sub<O::K2>(x, y); break;
         case 9: r = sqr_direct(O::add(x, y)); break;  // (a + b)^2 through fu_sqr, operand not reduced
         case 10: r = O::template mul_sub<O::K2>(x, O::add(x, y), O::template sub<O::K1>(F::zero(), y), y); break;
+        case 11: r = inv_gcd(x); break;
         case 8: {
             F ab = O::mul(x, y), bb = O::sqr(y);
             F X = O::template sub<O::K1>(O::sqr(x), O::add(ab, O::add(bb, bb)));

@@ -1158,6 +1158,12 @@ def quotient_polynomial_split_dfs(T: Sequence[int], rows_amount: int, split_poly
 # (tests/test_oracle_kat.py: on a genuine instance the product closes and every F vanishes on the rows): V_P by the row-by-row recurrence of :126-136 (one inversion per row), the
 # three constraint polynomials as DENSE coefficient-form polynomial arithmetic of the comment formulas (:166, 175, 215) -- domain sizes
 # of the reference's intermediate polynomial_dfs objects are crypto3-math's business and do not show in the coefficients.
+def inv0(x: int, r: int) -> int:
+    """the field type's inversed() as the argument loops use it: 0 for 0 (crypto3-algebra is not in the tree; the value is the one both the
+    round-4 kernels and ADVICE r4 assume -- a zero denominator has probability ~ k n / r for honest inputs)"""
+    return pow(x, -1, r) if x % r else 0
+
+
 def permutation_grand_product(cols, S_id, S_sigma, beta: int, gamma: int, r: int):
     n = len(cols[0])
     g = [[(c[j] + beta * s_[j] + gamma) % r for j in range(n)] for c, s_ in zip(cols, S_id)]
@@ -1168,7 +1174,7 @@ def permutation_grand_product(cols, S_id, S_sigma, beta: int, gamma: int, r: int
         for gi, hi in zip(g, h):
             nom = nom * gi[j - 1] % r
             den = den * hi[j - 1] % r
-        V[j] = V[j - 1] * nom * pow(den, -1, r) % r
+        V[j] = V[j - 1] * nom * inv0(den, r) % r
     return g, h, V
 
 
@@ -1336,7 +1342,7 @@ def lookup_grand_product(reduced_input, reduced_value, sorted_, beta: int, gamma
         h = 1
         for v in sorted_:
             h = h * (part1 + v[k - 1] + beta * v[k]) % r
-        V[k] = V[k - 1] * g % r * pow(h, -1, r) % r
+        V[k] = V[k - 1] * g % r * inv0(h, r) % r
     return V
 
 

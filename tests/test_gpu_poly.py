@@ -188,6 +188,63 @@ def test_lookup_grand_product_abi(ctx, curve, n, usable, k_in, k_val):
         ctx.free(p)
 
 
+@pytest.mark.parametrize("curve", [0, 1])
+def test_grand_products_zero_denominator(ctx, curve):
+    """one inversion per CALL must not change what a zero denominator does.  The reference inverts per row (0^-1 = 0 in
+    its field type): the row's ratio is 0, V keeps its values up to that row and is zero behind it; a zero c[j] of a b / c zeroes out[j] alone.
+    Forced here: a column entry chosen so that h = column + beta S_sigma + gamma vanishes at two rows (the FIRST decides), a sorted pair that
+    kills the lookup denominator, zeros in c -- against the oracle's row-by-row loops with that inverse."""
+    r = CURVES[curve].r
+    n, k = 700, 2
+    rng = po.SplitMix64(4400 + curve)
+    vec = lambda: [rng.next_mod(r) for _ in range(n)]
+    beta, gamma = rng.next_mod(r), rng.next_mod(r)
+    cols, sid, ssig = [vec() for _ in range(k)], [vec() for _ in range(k)], [vec() for _ in range(k)]
+    for z in (333, 520):
+        cols[1][z] = (-(beta * ssig[1][z] + gamma)) % r         # h_1[z] = 0
+    g, h, V = po.permutation_grand_product(cols, sid, ssig, beta, gamma, r)
+    assert V[333] != 0 and V[334:] == [0] * (n - 334)
+    ptrs = []
+    for v in cols + sid + ssig:
+        d = ctx.malloc(n * 32)
+        ctx.h2d(d, fr_arr(v))
+        ptrs.append(d)
+    d_g, d_h, d_v = ctx.malloc(k * n * 32), ctx.malloc(k * n * 32), ctx.malloc(n * 32)
+    ctx.perm_grand_product_dev(curve, ptrs[:k], ptrs[k:2 * k], ptrs[2 * k:], n, limbs(beta, 4), limbs(gamma, 4), d_g, d_h, d_v)
+    got = np.zeros((n, 4), dtype=np.uint64)
+    ctx.d2h(got, d_v)
+    assert fr_ints(got) == V
+    gh = np.zeros((k * n, 4), dtype=np.uint64)
+    ctx.d2h(gh, d_h)
+    assert fr_ints(gh) == [x for v in h for x in v]
+    # the lookup product: sorted[0][j] + beta sorted[0][j + 1] + (1 + beta) gamma = 0 at row 100
+    inputs, values, sorted_ = [vec()], [vec()], [vec(), vec()]
+    usable = n - 5
+    sorted_[0][100] = (-(beta * sorted_[0][101] + (1 + beta) * gamma)) % r
+    VL = po.lookup_grand_product(inputs, values, sorted_, beta, gamma, usable, r)
+    assert VL[100] != 0 and VL[101:] == [0] * (n - 101)
+    lp = []
+    for v in inputs + values + sorted_:
+        d = ctx.malloc(n * 32)
+        ctx.h2d(d, fr_arr(v))
+        lp.append(d)
+    ctx.lookup_grand_product_dev(curve, lp[:1], lp[1:2], lp[2:], n, usable, limbs(beta, 4), limbs(gamma, 4), d_v)
+    ctx.d2h(got, d_v)
+    assert fr_ints(got) == VL
+    # a b / c with zeros in c (also the first and the last row, and a whole lane chunk)
+    a, b, c = vec(), vec(), vec()
+    for j in [0, 5, 64, 65, 66, 67, 68, 69, 70, 71, 72, n - 1]:
+        c[j] = 0
+    d_a, d_b, d_c = (ctx.malloc(n * 32) for _ in range(3))
+    for d, v in ((d_a, a), (d_b, b), (d_c, c)):
+        ctx.h2d(d, fr_arr(v))
+    ctx.fr_vec_mul_div_dev(curve, d_a, d_b, d_c, d_v, n)
+    ctx.d2h(got, d_v)
+    assert fr_ints(got) == [x * y % r * po.inv0(w, r) % r for x, y, w in zip(a, b, c)]
+    for p_ in ptrs + lp + [d_g, d_h, d_v, d_a, d_b, d_c]:
+        ctx.free(p_)
+
+
 def _lookup_sort_on_device(ctx, inputs, values, n, usable):
     ptrs = []
     for v in inputs + values:

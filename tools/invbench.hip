@@ -11,125 +11,9 @@
 #include <cstdint>
 #include <cstdio>
 
-#include "fu.hpp"
+#include "fu_safegcd.hpp"  // SafeGcd<U> lives with the kernels since round 5
 
 using namespace zkhip;
-
-template <class U>
-struct SafeGcd {
-    static constexpr int L = U::L, B = U::B;
-    static constexpr int32_t M = (1 << B) - 1;
-    static constexpr int BATCHES = 31;
-
-    struct Mat {
-        int32_t u, v, q, r;
-    };
-    // B half-delta divsteps on the low bits of f, g; zeta = -(delta + 1/2)
-    ZK_HD static int32_t divsteps(int32_t zeta, uint32_t f0, uint32_t g0, Mat &t) {
-        uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
-ZK_UNROLL
-        for (int i = 0; i < B; ++i) {
-            uint32_t c1 = (uint32_t)(zeta >> 31);  // all ones iff zeta < 0
-            const uint32_t c2 = -(g & 1u);
-            const uint32_t x = (f ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;  // conditionally negated f, u, v
-            g += x & c2;
-            q += y & c2;
-            r += z & c2;
-            c1 &= c2;
-            zeta = (int32_t)(((uint32_t)zeta ^ c1) - 1u);
-            f += g & c1;
-            u += q & c1;
-            v += r & c1;
-            g >>= 1;
-            u <<= 1;
-            v <<= 1;
-        }
-        t.u = (int32_t)u, t.v = (int32_t)v, t.q = (int32_t)q, t.r = (int32_t)r;
-        return zeta;
-    }
-    // (f, g) <- t (f, g) / 2^B  (exact)
-    ZK_HD static void update_fg(int32_t (&f)[L], int32_t (&g)[L], const Mat &t) {
-        int64_t cf = (int64_t)t.u * f[0] + (int64_t)t.v * g[0], cg = (int64_t)t.q * f[0] + (int64_t)t.r * g[0];
-        cf >>= B;
-        cg >>= B;
-ZK_UNROLL
-        for (int i = 1; i < L; ++i) {
-            cf += (int64_t)t.u * f[i] + (int64_t)t.v * g[i];
-            cg += (int64_t)t.q * f[i] + (int64_t)t.r * g[i];
-            f[i - 1] = (int32_t)cf & M;
-            g[i - 1] = (int32_t)cg & M;
-            cf >>= B;
-            cg >>= B;
-        }
-        f[L - 1] = (int32_t)cf;
-        g[L - 1] = (int32_t)cg;
-    }
-    // (d, e) <- t (d, e) / 2^B mod p, kept in (-2p, p)
-    ZK_HD static void update_de(int32_t (&d)[L], int32_t (&e)[L], const Mat &t) {
-        constexpr uint32_t PINV = (0u - U::QINV) & (uint32_t)M;  // p^-1 mod 2^B (QINV = -p^-1)
-        const int32_t sd = d[L - 1] >> 31, se = e[L - 1] >> 31;
-        int32_t md = (t.u & sd) + (t.v & se), me = (t.q & sd) + (t.r & se);
-        int64_t cd = (int64_t)t.u * d[0] + (int64_t)t.v * e[0], ce = (int64_t)t.q * d[0] + (int64_t)t.r * e[0];
-        md -= (int32_t)((PINV * (uint32_t)cd + (uint32_t)md) & (uint32_t)M);
-        me -= (int32_t)((PINV * (uint32_t)ce + (uint32_t)me) & (uint32_t)M);
-        cd += (int64_t)(int32_t)U::mod(0) * md;
-        ce += (int64_t)(int32_t)U::mod(0) * me;
-        cd >>= B;
-        ce >>= B;
-ZK_UNROLL
-        for (int i = 1; i < L; ++i) {
-            cd += (int64_t)t.u * d[i] + (int64_t)t.v * e[i] + (int64_t)(int32_t)U::mod(i) * md;
-            ce += (int64_t)t.q * d[i] + (int64_t)t.r * e[i] + (int64_t)(int32_t)U::mod(i) * me;
-            d[i - 1] = (int32_t)cd & M;
-            e[i - 1] = (int32_t)ce & M;
-            cd >>= B;
-            ce >>= B;
-        }
-        d[L - 1] = (int32_t)cd;
-        e[L - 1] = (int32_t)ce;
-    }
-    // a (plain integer, normalised 29-bit limbs, 0 < a < p)  ->  a^-1 mod p in [0, p)
-    ZK_HD static Fu<U> inverse(const Fu<U> &a) {
-        int32_t f[L], g[L], d[L], e[L];
-ZK_UNROLL
-        for (int i = 0; i < L; ++i) {
-            f[i] = (int32_t)U::mod(i);
-            g[i] = (int32_t)a.v[i];
-            d[i] = 0;
-            e[i] = i == 0 ? 1 : 0;
-        }
-        int32_t zeta = -1;
-        for (int b = 0; b < BATCHES; ++b) {
-            Mat t;
-            zeta = divsteps(zeta, (uint32_t)f[0], (uint32_t)g[0], t);
-            update_de(d, e, t);
-            update_fg(f, g, t);
-        }
-        // f = +-1; d = +-a^-1 in (-2p, p): negate when f < 0, then bring into [0, p)
-        const int32_t sf = f[L - 1] >> 31;
-        int32_t carry = 0;
-ZK_UNROLL
-        for (int i = 0; i < L; ++i) {  // d = sf ? -d : d
-            int32_t x = (d[i] ^ sf) - sf + carry;
-            carry = i + 1 < L ? x >> B : 0;
-            d[i] = i + 1 < L ? x & M : x;
-        }
-        for (int rep = 0; rep < 2; ++rep) {  // while d < 0: d += p  (at most twice)
-            const int32_t neg = d[L - 1] >> 31;
-            carry = 0;
-ZK_UNROLL
-            for (int i = 0; i < L; ++i) {
-                int32_t x = d[i] + ((int32_t)U::mod(i) & neg) + carry;
-                carry = i + 1 < L ? x >> B : 0;
-                d[i] = i + 1 < L ? x & M : x;
-            }
-        }
-        Fu<U> r;
-ZK_UNROLL
-        for (int i = 0; i < L; ++i) r.v[i] = (uint32_t)d[i];
-        return fu_cond_sub_p(r);
-    }
-};
 
 // a (plain) * inv (plain) == 1 mod p ?
 template <class U>
