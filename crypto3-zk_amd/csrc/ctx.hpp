@@ -116,6 +116,7 @@ struct zkhip_ctx {
     int opt_msm_segment_log = -1;  // tail segments of 2^k buckets per lane; < 0: chosen from the lane count
     int opt_ntt_radix_log = 8;
     int opt_ntt_tile_log = 3;
+    int opt_poly_coset_extend = 1;  // zkhip_poly_resize_dev n -> K n (K <= 16): the K - 1 new cosets by n-point transforms, the n known values copied (0: inverse + K n-point transform)
     int opt_ntt_pair = 1;  // log2 of the polynomials of a batch one NTT workgroup carries (1: pairs share indices, twiddles, factor-table reads)
     int opt_msm_precompute = 1;       // build window tables at upload for bases of >= opt_msm_precompute_min points
     int opt_msm_shard_rank = 0, opt_msm_shard_world = 1;  // window partition applied to bases uploaded from now on
@@ -235,5 +236,7 @@ int zk_jac_sum(zkhip_ctx *ctx, int curve, int group, const uint32_t *d_pts, size
 int zk_jac_to_affine(zkhip_ctx *ctx, int curve, int group, const uint32_t *d_jac, uint32_t *d_aff, uint8_t *d_inf);
 int zk_ntt_run(zkhip_ctx *ctx, int curve, uint32_t *d_data, size_t log_m, size_t batch, const uint64_t *omega, int inverse,
                const uint64_t *coset);
+int zk_ntt_extend(zkhip_ctx *ctx, int curve, uint32_t *d_coeffs, size_t log_m, size_t batch, const uint64_t *omega, uint32_t *d_out, size_t log_k,
+                  const uint64_t *omega_big);
 void zk_ntt_free_tables(zkhip_ctx *ctx);
 void zk_dom_free_tables(zkhip_ctx *ctx);

@@ -72,6 +72,11 @@ struct NttPass {
     const uint32_t *scale;      // single-pass inverse transform: 1/m (Fu form), else null
     uint32_t in_lazy, out_lazy; // the vector read / written is in limb form (an intermediate between passes), else canonical
     size_t planeb;              // words from a limb-form data buffer's base to its limb-8 plane (batch x m x 8)
+    // EXTENSION mode (ntt_pass<U, PB, true>; zk_ntt_extend): "polynomial" w of the launch is coset j = w % ext_k1 + 1 of source polynomial
+    // w / ext_k1: the first pass reads the source's COEFFICIENTS times g_j^index (table j of ext_pre), the last pass stores its value for
+    // index oi at out[(source << (log_m + ext_log_k)) + (oi << ext_log_k) + j] -- the natural order of the K n-point domain
+    uint32_t ext_k1, ext_log_k;
+    const uint32_t *ext_pre;    // ext_k1 tables of g_j^i, i < m, limb form (m x 36 B each)
 };
 
 // parameters of the table-building kernel: everything ntt_pass used to look up on the fly
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(256) void ntt_build_stage(const uint32_t *__restric
 }
 
 // One pass over PB polynomials of the batch per workgroup (they share every index, twiddle and table entry).
-template <class U, int PB>
+template <class U, int PB, bool EXT = false>
 __global__ __launch_bounds__(256) void ntt_pass(NttPass p) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     const uint32_t R = 1u << p.s, T = 1u << p.log_t, nelem = R * T;
@@ -267,6 +272,14 @@ __global__ __launch_bounds__(256) void ntt_pass(NttPass p) {
     const uint64_t j0 = (uint64_t)tile << p.log_t;
     const uint32_t ns_mask = (1u << p.log_ns) - 1;  // log_ns < 32 always (m <= 2^32)
 
+    uint32_t ext_src[PB], ext_j[PB];  // EXT: source polynomial and coset (0-based: coset ext_j + 1) of the workgroup's polynomials
+    if constexpr (EXT) {
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            ext_src[b] = (poly0 + b) / p.ext_k1;
+            ext_j[b] = (poly0 + b) % p.ext_k1;
+        }
+    }
     for (uint32_t q = tid; q < R / 2; q += nth) lds_put(twr, nhalf, q, fu_load<U>(p.stage + (size_t)q * U::SL));
     // load tile: row bitrev(t), column c  <-  x[j0 + c + t m/R]   [* g^index on the first pass of a coset transform]
     for (uint32_t e = tid; e < nelem; e += nth) {
@@ -278,8 +291,18 @@ __global__ __launch_bounds__(256) void ntt_pass(NttPass p) {
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
             const size_t ei = (((size_t)(poly0 + b)) << p.log_m) + gi;
-            Fu<U> x = p.in_lazy ? l_load<U>(p.in, p.planeb, ei) : g_load<U>(p.in + ei * 8);
-            if (p.pre) x = fu_mul(x, g);
+            Fu<U> x;
+            if constexpr (EXT) {
+                if (p.in_lazy) {
+                    x = l_load<U>(p.in, p.planeb, ei);
+                } else {  // the source's coefficient times this coset's g^index
+                    x = g_load<U>(p.in + ((((size_t)ext_src[b]) << p.log_m) + gi) * 8);
+                    x = fu_mul(x, l_load<U>(p.ext_pre + (size_t)ext_j[b] * ((size_t)9 << p.log_m), (size_t)8 << p.log_m, gi));
+                }
+            } else {
+                x = p.in_lazy ? l_load<U>(p.in, p.planeb, ei) : g_load<U>(p.in + ei * 8);
+                if (p.pre) x = fu_mul(x, g);
+            }
             lds_put(lds + b * tile_u4, slots, slot, x);
         }
     }
@@ -369,7 +392,11 @@ __global__ __launch_bounds__(256) void ntt_pass(NttPass p) {
             if (ftab) x = fu_cond_sub_p(fu_mul(x, f));
             else if (p.scale) x = fu_cond_sub_p(fu_mul(x, scale));
             else x = fu_reduce_small(x);
-            g_store<U>(p.out + eo * 8, x);
+            if constexpr (EXT) {
+                g_store<U>(p.out + ((((size_t)ext_src[b]) << (p.log_m + p.ext_log_k)) + ((size_t)oi << p.ext_log_k) + ext_j[b] + 1) * 8, x);
+            } else {
+                g_store<U>(p.out + eo * 8, x);
+            }
         }
     }
 }
@@ -390,9 +417,11 @@ static void ntt_free_one(NttTables *t) {
     delete t;
 }
 
+void zk_ntt_free_ext_tables(zkhip_ctx *ctx);
 void zk_ntt_free_tables(zkhip_ctx *ctx) {
     for (NttTables *t : ctx->ntt_tables) ntt_free_one(t);
     ctx->ntt_tables.clear();
+    zk_ntt_free_ext_tables(ctx);
 }
 
 // the radix plan: log_m split into np nearly equal radices (larger first), tile widths
@@ -519,10 +548,17 @@ static int ntt_get_tables(zkhip_ctx *ctx, int curve, size_t log_m, const uint64_
     return 0;
 }
 
+// the extension mode of a forward transform (zk_ntt_extend): `batch` = the launch's polynomials = sources x k1 cosets
+struct NttExt {
+    uint32_t k1, log_k;
+    const uint32_t *pre;
+    uint32_t *out;
+};
+
 template <class U>
 static int ntt_run_t(zkhip_ctx *ctx, int curve, uint32_t *d_data, size_t log_m, size_t batch, const uint64_t *omega, int inverse,
-                     const uint64_t *coset) {
-    if (batch == 0 || log_m == 0) return 0;  // a 1-point transform is the identity (also with coset: g^0 = 1, 1/1 = 1)
+                     const uint64_t *coset, const NttExt *ext = nullptr) {
+    if (batch == 0 || (log_m == 0 && !ext)) return 0;  // a 1-point transform is the identity (also with coset: g^0 = 1, 1/1 = 1)
     const int smax = std::max(1, std::min(10, ctx->opt_ntt_radix_log));
     NttTables *tb = nullptr;
     ZK_TRY(ntt_get_tables<U>(ctx, curve, log_m, omega, inverse, coset, smax, ctx->opt_ntt_tile_log, &tb));
@@ -543,7 +579,7 @@ static int ntt_run_t(zkhip_ctx *ctx, int curve, uint32_t *d_data, size_t log_m, 
     uint32_t log_ns = 0;
     const uint32_t *src = d_data;
     for (int i = 0; i < np; ++i) {
-        uint32_t *dst = i == np - 1 ? d_data : ws2[i & 1];  // np == 1: in place (the single tile is read fully into LDS before any store)
+        uint32_t *dst = i == np - 1 ? (ext ? ext->out : d_data) : ws2[i & 1];  // np == 1: in place (the single tile is read fully into LDS before any store)
         NttPass p;
         p.in = src;
         p.out = dst;
@@ -561,11 +597,14 @@ static int ntt_run_t(zkhip_ctx *ctx, int curve, uint32_t *d_data, size_t log_m, 
         p.in_lazy = i > 0 ? 1u : 0u;
         p.out_lazy = i < np - 1 ? 1u : 0u;
         p.planeb = batch * m * 8;
+        p.ext_k1 = ext ? ext->k1 : 0u;
+        p.ext_log_k = ext ? ext->log_k : 0u;
+        p.ext_pre = ext ? ext->pre : nullptr;
         const size_t nelem = (size_t)1 << (p.s + p.log_t), nhalf = std::max<size_t>(1, ((size_t)1 << p.s) / 2);
         const size_t slots = ((size_t)1 << p.s) * (((size_t)1 << p.log_t) + NTT_PAD);
         // PB = 1, 2 or 4 polynomials of the batch per workgroup (they share indices, twiddle registers and the factor-table
         // reads) while the batch divides and the tiles leave room for a second workgroup on the CU; option "ntt_pair" = log2(PB) wanted
-        int pb = 1 << std::max(0, std::min(2, ctx->opt_ntt_pair));
+        int pb = 1 << std::max(0, std::min(ext ? 1 : 2, ctx->opt_ntt_pair));
         while (pb > 1 && batch % pb != 0) pb >>= 1;
         // a narrower tile that lets the polynomials share a workgroup beats a wider one that does not (measured)
         while (pb > 1 && p.log_t > 2 && ((size_t)pb * ntt_tile_u4((1u << p.s) * ((1u << p.log_t) + NTT_PAD)) + ntt_tile_u4((uint32_t)nhalf)) * 16 > 80 * 1024) {
@@ -581,7 +620,15 @@ static int ntt_run_t(zkhip_ctx *ctx, int curve, uint32_t *d_data, size_t log_m, 
         unsigned threads = (unsigned)std::min<size_t>(256, std::max<size_t>(64, nelem_p / 4));
         (void)nelem;
         (void)slots;
-        if (pb == 4) {
+        if (ext) {  // pairs or singles (four per workgroup is the slow shape: DESIGN.md section 5)
+            if (pb >= 2) {
+                ZK_MAX_LDS(ctx, (ntt_pass<U, 2, true>), 160 * 1024);
+                ZK_LAUNCH(ctx, "ntt_pass_ext", (ntt_pass<U, 2, true>), dim3((unsigned)grid), dim3(threads), lds, p);
+            } else {
+                ZK_MAX_LDS(ctx, (ntt_pass<U, 1, true>), 160 * 1024);
+                ZK_LAUNCH(ctx, "ntt_pass_ext", (ntt_pass<U, 1, true>), dim3((unsigned)grid), dim3(threads), lds, p);
+            }
+        } else if (pb == 4) {
             ZK_MAX_LDS(ctx, (ntt_pass<U, 4>), 160 * 1024);
             ZK_LAUNCH(ctx, "ntt_pass", (ntt_pass<U, 4>), dim3((unsigned)grid), dim3(threads), lds, p);
         } else if (pb == 2) {
@@ -595,6 +642,96 @@ static int ntt_run_t(zkhip_ctx *ctx, int curve, uint32_t *d_data, size_t log_m, 
         log_ns += p.s;
     }
     return 0;
+}
+
+// g_j^i = omega_big^(j i) for the cosets j = 1 .. k1 of the n-point domain inside the K n-point one, i < m: k1 tables in limb form.
+// One lane per entry, square-and-multiply over the bits of j i (< 2^36): built once per (size, K, root), ~35 products per entry.
+template <class U>
+__global__ __launch_bounds__(256) void ntt_build_ext_pre(const uint32_t *__restrict__ omega_big_c, uint32_t log_m, uint32_t k1, uint32_t *__restrict__ out) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((e >> log_m) >= k1) return;
+    const uint64_t j = (e >> log_m) + 1, i = e & (((uint64_t)1 << log_m) - 1);
+    Fu<U> b = fu_cond_sub_p(fu_from_canonical<U>(omega_big_c)), r = Fu<U>::one();
+    for (uint64_t x = j * i; x; x >>= 1) {
+        if (x & 1) r = fu_mul(r, b);
+        b = fu_mul(b, b);
+    }
+    l_store<U>(out + (size_t)(j - 1) * ((size_t)9 << log_m), (size_t)8 << log_m, i, fu_cond_sub_p(r));
+}
+
+struct NttExtTables {
+    int curve;
+    size_t log_m, log_k;
+    uint64_t omega_big[4];
+    uint32_t *d_pre = nullptr;
+};
+static std::vector<std::pair<zkhip_ctx *, NttExtTables *>> g_ext_tables;  // owned per context; freed with the context's NTT tables
+static std::mutex g_ext_mutex;
+
+void zk_ntt_free_ext_tables(zkhip_ctx *ctx) {
+    std::lock_guard<std::mutex> lock(g_ext_mutex);
+    for (size_t i = g_ext_tables.size(); i-- > 0;)
+        if (g_ext_tables[i].first == ctx) {
+            (void)hipFree(g_ext_tables[i].second->d_pre);
+            delete g_ext_tables[i].second;
+            g_ext_tables.erase(g_ext_tables.begin() + i);
+        }
+}
+
+template <class U>
+static int ntt_extend_t(zkhip_ctx *ctx, int curve, uint32_t *d_coeffs, size_t log_m, size_t batch, const uint64_t *omega, uint32_t *d_out, size_t log_k,
+                        const uint64_t *omega_big) {
+    const size_t m = (size_t)1 << log_m, k1 = ((size_t)1 << log_k) - 1;
+    NttExtTables *t = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_ext_mutex);
+        size_t mine = 0;
+        for (auto &e : g_ext_tables) {
+            if (e.first != ctx) continue;
+            ++mine;
+            if (e.second->curve == curve && e.second->log_m == log_m && e.second->log_k == log_k && memcmp(e.second->omega_big, omega_big, 32) == 0) t = e.second;
+        }
+        if (!t && mine >= 16) {  // keep the cache bounded: drop this context's oldest entry
+            for (size_t i = 0; i < g_ext_tables.size(); ++i)
+                if (g_ext_tables[i].first == ctx) {
+                    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                    (void)hipFree(g_ext_tables[i].second->d_pre);
+                    delete g_ext_tables[i].second;
+                    g_ext_tables.erase(g_ext_tables.begin() + i);
+                    break;
+                }
+        }
+    }
+    if (!t) {
+        t = new NttExtTables();
+        t->curve = curve;
+        t->log_m = log_m;
+        t->log_k = log_k;
+        memcpy(t->omega_big, omega_big, 32);
+        uint32_t *d_w = nullptr;
+        ZK_HIP_CHECK(ctx, hipMalloc((void **)&t->d_pre, k1 * m * 36));
+        ZK_HIP_CHECK(ctx, hipMalloc((void **)&d_w, 32));
+        ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_w, omega_big, 32, hipMemcpyHostToDevice, ctx->stream));
+        const size_t entries = k1 * m;
+        ZK_LAUNCH(ctx, "ntt_build_tw", ntt_build_ext_pre<U>, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, d_w, (uint32_t)log_m, (uint32_t)k1, t->d_pre);
+        ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(d_w);
+        std::lock_guard<std::mutex> lock(g_ext_mutex);
+        g_ext_tables.emplace_back(ctx, t);
+    }
+    NttExt ext{(uint32_t)k1, (uint32_t)log_k, t->d_pre, d_out};
+    return ntt_run_t<U>(ctx, curve, d_coeffs, log_m, batch * k1, omega, 0, nullptr, &ext);
+}
+
+// evaluations on the cosets 1 .. K - 1 of the n-point domain inside the K n-point one, written into their places of the K n-point vector
+// (d_out[b][i K + j], j >= 1; the caller puts the n known values at j = 0): d_coeffs holds `batch` coefficient vectors of n = 2^log_m
+int zk_ntt_extend(zkhip_ctx *ctx, int curve, uint32_t *d_coeffs, size_t log_m, size_t batch, const uint64_t *omega, uint32_t *d_out, size_t log_k,
+                  const uint64_t *omega_big) {
+    if (log_m + log_k > 32 || log_k == 0 || log_k > 4) return ZKHIP_ERR_RANGE;
+    if (batch * (((size_t)1 << log_k) - 1) >= ((size_t)1 << 20)) return ZKHIP_ERR_RANGE;
+    if (curve == CURVE_BLS12_381) return ntt_extend_t<BlsFrU>(ctx, curve, d_coeffs, log_m, batch, omega, d_out, log_k, omega_big);
+    if (curve == CURVE_BN254) return ntt_extend_t<BnFrU>(ctx, curve, d_coeffs, log_m, batch, omega, d_out, log_k, omega_big);
+    return ZKHIP_ERR_INVALID;
 }
 
 int zk_ntt_run(zkhip_ctx *ctx, int curve, uint32_t *d_data, size_t log_m, size_t batch, const uint64_t *omega, int inverse,

@@ -30,6 +30,16 @@ __global__ __launch_bounds__(256) void poly_pad_copy(const uint4 *__restrict__ i
 }
 
 
+// out[b][i << log_k] = in[b][i]: the n known values of an n -> K n extension at their places (coset 0 of the larger domain)
+__global__ __launch_bounds__(256) void poly_spread(const uint4 *__restrict__ in, uint32_t log_k, size_t total, uint32_t log_n, uint4 *__restrict__ out) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // index into in, in elements
+    if (e >= total) return;
+    const size_t b = e >> log_n, i = e & (((size_t)1 << log_n) - 1);
+    const size_t o = (b << (log_n + log_k)) + (i << log_k);
+    out[2 * o] = in[2 * e];
+    out[2 * o + 1] = in[2 * e + 1];
+}
+
 // precommit<FRI>'s leaf layout (basic_fri.hpp:456-492, m = 2): leaf x (< D / 2^step) holds, for every polynomial in
 // turn, the pairs (f[s_i], f[s_i + D/2 mod D]) for i < 2^step / 2, with s_0 = x and
 // s_(2^l + j) = s_j + D / (4 * 2^l) mod D.  out[((x * batch + p) * half + i) * 2 + {0, 1}], 32-byte elements.
@@ -392,6 +402,18 @@ int zkhip_poly_resize_dev(zkhip_ctx *ctx, int curve, void *d_in, size_t log_n, s
         ZK_LAUNCH(ctx, "poly_subsample", poly_subsample, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (const uint4 *)d_in, (uint32_t)log_n,
                   (uint32_t)log_out, tot, (uint4 *)d_out);
         return ZKHIP_OK;
+    }
+    const size_t log_k = log_out - log_n;
+    if (ctx->opt_poly_coset_extend && log_k >= 1 && log_k <= 4 && log_n >= 1 && batch * (((size_t)1 << log_k) - 1) < ((size_t)1 << 20)) {
+        // Round 5: the K n-point domain is the n-point one and its K - 1 cosets omega_out^j <omega_n>.  The n known values are copied to their
+        // places, the coefficients (inverse transform in place: d_in is consumed as before) are evaluated on the K - 1 new cosets by n-point
+        // transforms that store straight into theirs: K n transform points instead of (K + 1) n, in transforms of the smaller size, and a lone
+        // polynomial still fills the pairs-per-workgroup kernel with two of its cosets.
+        const size_t tot = batch << log_n;
+        ZK_LAUNCH(ctx, "poly_spread", poly_spread, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (const uint4 *)d_in, (uint32_t)log_k, tot, (uint32_t)log_n,
+                  (uint4 *)d_out);
+        ZK_TRY(zk_ntt_run(ctx, curve, (uint32_t *)d_in, log_n, batch, omega_n, 1, nullptr));
+        return zk_ntt_extend(ctx, curve, (uint32_t *)d_in, log_n, batch, omega_n, (uint32_t *)d_out, log_k, omega_out);
     }
     // coefficients in place (d_in is consumed), zero-extended copy, evaluation on the larger domain
     ZK_TRY(zk_ntt_run(ctx, curve, (uint32_t *)d_in, log_n, batch, omega_n, 1, nullptr));

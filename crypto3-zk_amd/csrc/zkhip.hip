@@ -137,6 +137,7 @@ int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value) {
     else if (n == "ntt_radix_log") ctx->opt_ntt_radix_log = (int)value;
     else if (n == "ntt_tile_log") ctx->opt_ntt_tile_log = (int)value;
     else if (n == "ntt_pair") ctx->opt_ntt_pair = (int)value;
+    else if (n == "poly_coset_extend") ctx->opt_poly_coset_extend = value != 0;
     else if (n == "msm_precompute") ctx->opt_msm_precompute = (int)value;
     else if (n == "msm_precompute_min") ctx->opt_msm_precompute_min = (int)value;
     else if (n == "msm_shard_world") {
@@ -187,6 +188,7 @@ int zkhip_get_option(const zkhip_ctx *ctx, const char *name, int64_t *value) {
     else if (n == "ntt_radix_log") *value = ctx->opt_ntt_radix_log;
     else if (n == "ntt_tile_log") *value = ctx->opt_ntt_tile_log;
     else if (n == "ntt_pair") *value = ctx->opt_ntt_pair;
+    else if (n == "poly_coset_extend") *value = ctx->opt_poly_coset_extend;
     else if (n == "msm_precompute") *value = ctx->opt_msm_precompute;
     else if (n == "msm_precompute_min") *value = ctx->opt_msm_precompute_min;
     else if (n == "msm_shard_world") *value = ctx->opt_msm_shard_world;

@@ -159,6 +159,45 @@ def test_lpc_resize_and_fold(ctx, zk, curve, log_n, expand):
         ctx.free(p)
 
 
+@pytest.mark.parametrize("curve,log_n,expand,batch", [(0, 1, 1, 1), (0, 3, 4, 2), (1, 8, 1, 1), (0, 9, 2, 5), (1, 10, 3, 2), (0, 13, 3, 1), (0, 16, 2, 3), (1, 17, 1, 1),
+                                                      (0, 17, 4, 1), (0, 18, 1, 2), (0, 5, 5, 1)])
+def test_poly_resize_coset_extension(ctx, curve, log_n, expand, batch):
+    """zkhip_poly_resize_dev growing n -> K n (round 5): the n known values copied to their places + the K - 1 new cosets by n-point
+    transforms that store straight into theirs (K <= 16; K = 32 takes the old path) -- against the oracle's inverse transform, zero
+    padding and K n-point transform; single- and multi-pass sizes, lone polynomials and batches, odd numbers of cosets x polynomials
+    (the unpaired kernel), both curves; the option poly_coset_extend = 0 (one big transform) must give the same bits; d_in holds the
+    coefficients afterwards either way."""
+    import ctypes
+
+    C = CURVES[curve]
+    n = 1 << log_n
+    log_out = log_n + expand
+    m = 1 << log_out
+    wn, wm = limbs(C.root_of_unity(log_n), 4), limbs(C.root_of_unity(log_out), 4)
+    evals = cp.random_fr(curve, 770 + log_n, batch * n).reshape(batch, n, 4)
+    coeffs = cp.ntt(curve, evals, log_n, wn, inverse=True)
+    padded = np.zeros((batch, m, 4), dtype=np.uint64)
+    padded[:, :n] = coeffs
+    exp = cp.ntt(curve, padded, log_out, wm)
+    d_in, d_out = ctx.malloc(evals.nbytes), ctx.malloc(exp.nbytes)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for mode in (1, 0):
+        ctx.set_option("poly_coset_extend", mode)
+        ctx.h2d(d_in, evals)
+        ctx.h2d(d_out, np.full_like(exp, 7))
+        rc = ctx.lib.zkhip_poly_resize_dev(ctx.h, curve, ctypes.c_void_p(d_in), ctypes.c_size_t(log_n), ctypes.c_size_t(batch), P(wn),
+                                           ctypes.c_void_p(d_out), ctypes.c_size_t(log_out), P(wm))
+        assert rc == 0
+        got, back = np.zeros_like(exp), np.zeros_like(evals)
+        ctx.d2h(got, d_out)
+        ctx.d2h(back, d_in)
+        assert (got == exp).all(), mode
+        assert (back == coeffs).all(), mode
+    ctx.set_option("poly_coset_extend", 1)
+    ctx.free(d_in)
+    ctx.free(d_out)
+
+
 def test_ntt_rejects_a_root_of_the_wrong_order(zk, ctx):
     """omega must be a PRIMITIVE 2^log_m-th root of unity (a key generated over another domain must fail loudly,
     not transform over the wrong domain): the square of the right root (order m / 2), 1, and the root of the next size are refused."""
