@@ -75,6 +75,7 @@ struct NttPass {
     // EXTENSION mode (ntt_pass<U, PB, true>; zk_ntt_extend): "polynomial" w of the launch is coset j = w % ext_k1 + 1 of source polynomial
     // w / ext_k1: the first pass reads the source's COEFFICIENTS times g_j^index (table j of ext_pre), the last pass stores its value for
     // index oi at out[(source << (log_m + ext_log_k)) + (oi << ext_log_k) + j] -- the natural order of the K n-point domain
+    uint32_t poly_base;         // the launch's first polynomial (an odd batch runs as pairs + one single launch per pass)
     uint32_t ext_k1, ext_log_k;
     const uint32_t *ext_pre;    // ext_k1 tables of g_j^i, i < m, limb form (m x 36 B each)
 };
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void ntt_pass(NttPass p) {
     uint4 *twr = lds + PB * tile_u4;  // stage twiddles behind the tiles, same three-plane shape
     const uint32_t nhalf = R / 2 > 0 ? R / 2 : 1;
 
-    const uint32_t poly0 = (blockIdx.x / p.tiles_per_poly) * PB;
+    const uint32_t poly0 = p.poly_base + (blockIdx.x / p.tiles_per_poly) * PB;
     const uint32_t tile = blockIdx.x % p.tiles_per_poly;
     const uint32_t log_stride = p.log_m - p.s;  // m / R
     const uint64_t j0 = (uint64_t)tile << p.log_t;
@@ -600,44 +601,52 @@ static int ntt_run_t(zkhip_ctx *ctx, int curve, uint32_t *d_data, size_t log_m, 
         p.ext_k1 = ext ? ext->k1 : 0u;
         p.ext_log_k = ext ? ext->log_k : 0u;
         p.ext_pre = ext ? ext->pre : nullptr;
-        const size_t nelem = (size_t)1 << (p.s + p.log_t), nhalf = std::max<size_t>(1, ((size_t)1 << p.s) / 2);
-        const size_t slots = ((size_t)1 << p.s) * (((size_t)1 << p.log_t) + NTT_PAD);
+        const size_t nhalf = std::max<size_t>(1, ((size_t)1 << p.s) / 2);
         // PB = 1, 2 or 4 polynomials of the batch per workgroup (they share indices, twiddle registers and the factor-table
-        // reads) while the batch divides and the tiles leave room for a second workgroup on the CU; option "ntt_pair" = log2(PB) wanted
-        int pb = 1 << std::max(0, std::min(ext ? 1 : 2, ctx->opt_ntt_pair));
-        while (pb > 1 && batch % pb != 0) pb >>= 1;
-        // a narrower tile that lets the polynomials share a workgroup beats a wider one that does not (measured)
-        while (pb > 1 && p.log_t > 2 && ((size_t)pb * ntt_tile_u4((1u << p.s) * ((1u << p.log_t) + NTT_PAD)) + ntt_tile_u4((uint32_t)nhalf)) * 16 > 80 * 1024) {
-            --p.log_t;
-            p.tiles_per_poly <<= 1;
-        }
-        const size_t slots_p = ((size_t)1 << p.s) * (((size_t)1 << p.log_t) + NTT_PAD);
-        while (pb > 1 && ((size_t)pb * ntt_tile_u4((uint32_t)slots_p) + ntt_tile_u4((uint32_t)nhalf)) * 16 > 80 * 1024) pb >>= 1;
-        const size_t nelem_p = (size_t)1 << (p.s + p.log_t);
-        const size_t lds = ((size_t)pb * ntt_tile_u4((uint32_t)slots_p) + ntt_tile_u4((uint32_t)nhalf)) * 16;
-        size_t grid = batch / pb * p.tiles_per_poly;
-        if (grid >= (1ull << 31)) return ZKHIP_ERR_RANGE;
-        unsigned threads = (unsigned)std::min<size_t>(256, std::max<size_t>(64, nelem_p / 4));
-        (void)nelem;
-        (void)slots;
-        if (ext) {  // pairs or singles (four per workgroup is the slow shape: DESIGN.md section 5)
-            if (pb >= 2) {
-                ZK_MAX_LDS(ctx, (ntt_pass<U, 2, true>), 160 * 1024);
-                ZK_LAUNCH(ctx, "ntt_pass_ext", (ntt_pass<U, 2, true>), dim3((unsigned)grid), dim3(threads), lds, p);
-            } else {
-                ZK_MAX_LDS(ctx, (ntt_pass<U, 1, true>), 160 * 1024);
-                ZK_LAUNCH(ctx, "ntt_pass_ext", (ntt_pass<U, 1, true>), dim3((unsigned)grid), dim3(threads), lds, p);
+        // reads) while the tiles leave room for a second workgroup on the CU; option "ntt_pair" = log2(PB) wanted.  A batch that PB
+        // does not divide runs its remainder as one more launch of single polynomials (round 5: an odd batch -- a lone polynomial's
+        // 3 or 7 new cosets -- used to run unpaired altogether).
+        // The cosets of an extension run ONE per workgroup: as pairs they share no table entry (each coset has its own g^i) and measured 5 % slower
+        // (permutation argument 13.9 against 14.6-14.9 ms, profiles/r05_ab_legs_pair_coset.txt).
+        const int want = ext ? 1 : 1 << std::max(0, std::min(2, ctx->opt_ntt_pair));
+        auto launch = [&](NttPass q, int pb, size_t first, size_t count) -> int {
+            if (count == 0) return 0;
+            q.poly_base = (uint32_t)first;
+            // a narrower tile that lets the polynomials share a workgroup beats a wider one that does not (measured)
+            while (pb > 1 && q.log_t > 2 && ((size_t)pb * ntt_tile_u4((1u << q.s) * ((1u << q.log_t) + NTT_PAD)) + ntt_tile_u4((uint32_t)nhalf)) * 16 > 80 * 1024) {
+                --q.log_t;
+                q.tiles_per_poly <<= 1;
             }
-        } else if (pb == 4) {
-            ZK_MAX_LDS(ctx, (ntt_pass<U, 4>), 160 * 1024);
-            ZK_LAUNCH(ctx, "ntt_pass", (ntt_pass<U, 4>), dim3((unsigned)grid), dim3(threads), lds, p);
-        } else if (pb == 2) {
-            ZK_MAX_LDS(ctx, (ntt_pass<U, 2>), 160 * 1024);
-            ZK_LAUNCH(ctx, "ntt_pass", (ntt_pass<U, 2>), dim3((unsigned)grid), dim3(threads), lds, p);
-        } else {
-            ZK_MAX_LDS(ctx, (ntt_pass<U, 1>), 160 * 1024);
-            ZK_LAUNCH(ctx, "ntt_pass", (ntt_pass<U, 1>), dim3((unsigned)grid), dim3(threads), lds, p);
-        }
+            const size_t slots_p = ((size_t)1 << q.s) * (((size_t)1 << q.log_t) + NTT_PAD);
+            while (pb > 1 && (((size_t)pb * ntt_tile_u4((uint32_t)slots_p) + ntt_tile_u4((uint32_t)nhalf)) * 16 > 80 * 1024 || count % pb != 0)) pb >>= 1;
+            const size_t nelem_p = (size_t)1 << (q.s + q.log_t);
+            const size_t lds = ((size_t)pb * ntt_tile_u4((uint32_t)slots_p) + ntt_tile_u4((uint32_t)nhalf)) * 16;
+            const size_t grid = count / pb * q.tiles_per_poly;
+            if (grid >= (1ull << 31)) return ZKHIP_ERR_RANGE;
+            const unsigned threads = (unsigned)std::min<size_t>(256, std::max<size_t>(64, nelem_p / 4));
+            if (ext) {  // pairs or singles (four per workgroup is the slow shape: DESIGN.md section 5)
+                if (pb >= 2) {
+                    ZK_MAX_LDS(ctx, (ntt_pass<U, 2, true>), 160 * 1024);
+                    ZK_LAUNCH(ctx, "ntt_pass_ext", (ntt_pass<U, 2, true>), dim3((unsigned)grid), dim3(threads), lds, q);
+                } else {
+                    ZK_MAX_LDS(ctx, (ntt_pass<U, 1, true>), 160 * 1024);
+                    ZK_LAUNCH(ctx, "ntt_pass_ext", (ntt_pass<U, 1, true>), dim3((unsigned)grid), dim3(threads), lds, q);
+                }
+            } else if (pb == 4) {
+                ZK_MAX_LDS(ctx, (ntt_pass<U, 4>), 160 * 1024);
+                ZK_LAUNCH(ctx, "ntt_pass", (ntt_pass<U, 4>), dim3((unsigned)grid), dim3(threads), lds, q);
+            } else if (pb == 2) {
+                ZK_MAX_LDS(ctx, (ntt_pass<U, 2>), 160 * 1024);
+                ZK_LAUNCH(ctx, "ntt_pass", (ntt_pass<U, 2>), dim3((unsigned)grid), dim3(threads), lds, q);
+            } else {
+                ZK_MAX_LDS(ctx, (ntt_pass<U, 1>), 160 * 1024);
+                ZK_LAUNCH(ctx, "ntt_pass", (ntt_pass<U, 1>), dim3((unsigned)grid), dim3(threads), lds, q);
+            }
+            return 0;
+        };
+        const size_t whole = want > 1 ? batch / want * want : batch;
+        ZK_TRY(launch(p, want, 0, whole));
+        ZK_TRY(launch(p, 1, whole, batch - whole));
         src = dst;
         log_ns += p.s;
     }

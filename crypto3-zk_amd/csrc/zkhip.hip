@@ -48,6 +48,20 @@ int zkhip_init(int device_id, zkhip_ctx **out) {
         return ZKHIP_ERR_OOM;
     }
     *out = ctx;
+    // A/B runs of programs that create their own contexts (the bench library, the shim's default context): ZKHIP_OPTIONS="name=value,name=value"
+    // is applied to every new context; an unknown name or a malformed entry is ignored (the variable is for measurements, not for deployments)
+    if (const char *env = getenv("ZKHIP_OPTIONS")) {
+        std::string all(env);
+        size_t at = 0;
+        while (at < all.size()) {
+            const size_t end = all.find(',', at);
+            const std::string item = all.substr(at, end == std::string::npos ? std::string::npos : end - at);
+            const size_t eq = item.find('=');
+            if (eq != std::string::npos && eq > 0) (void)zkhip_set_option(ctx, item.substr(0, eq).c_str(), (int64_t)atoll(item.c_str() + eq + 1));
+            if (end == std::string::npos) break;
+            at = end + 1;
+        }
+    }
     return ZKHIP_OK;
 }
 
