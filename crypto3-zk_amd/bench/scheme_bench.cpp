@@ -480,6 +480,9 @@ int zkhip_bench_permutation(int device, size_t log_n, size_t k, int steps, doubl
         }
         std::vector<dfs> all;
         for (auto &p : h) all.emplace_back(ctx, p, n - 1);
+        /* the preprocessed polynomials (S_id, S_sigma, q_last, q_blind, lagrange_0) are the same in every proof: the key holder keeps their extensions
+           (device_polynomial_dfs::enable_extension_cache); the witness columns are not cached across proofs */
+        for (size_t i = k; i < all.size(); ++i) all[i].enable_extension_cache();
         std::vector<dfs> cols(all.begin(), all.begin() + k), sid(all.begin() + k, all.begin() + 2 * k), ssig(all.begin() + 2 * k, all.begin() + 3 * k);
         const Fr beta = rnd(), gamma = rnd();
         std::unique_ptr<PA::prover_result_type> last;
@@ -584,6 +587,7 @@ int zkhip_bench_lookup(int device, size_t log_n, size_t k_in, size_t k_val, int 
         for (auto &p : value) d_val.emplace_back(ctx, p, n - 1);
         for (auto &p : sorted) d_sorted.emplace_back(ctx, p, n - 1);
         dfs q_last(ctx, hq_last, n - 1), q_blind(ctx, hq_blind, n - 1), lagrange_0(ctx, hl0, n - 1);
+        for (dfs *p : {&q_last, &q_blind, &lagrange_0}) p->enable_extension_cache();    // preprocessed: their extensions are the same in every proof
         const Fr beta = rnd(), gamma = rnd();
         std::vector<Fr> alphas;
         for (size_t i = 0; i + 1 < total; ++i) alphas.push_back(rnd());
@@ -705,6 +709,10 @@ int zkhip_bench_placeholder_round(int device, size_t log_n, size_t witness_cols,
         std::vector<dfs> cols = up(h_cols), sid = up(h_sid), ssig = up(h_ssig), l_val = up(h_val), l_in = up(h_in), sorted = up(h_sorted);
         dfs q(ctx, hq, n - 1), w0(ctx, hw0, n - 1), w1(ctx, hw1, n - 1), w2(ctx, hw2, n - 1), q_last(ctx, hq_last, n - 1), q_blind(ctx, hq_blind, n - 1),
             lagrange_0(ctx, hl0, n - 1);
+        /* preprocessed polynomials: their extensions are kept across proofs (the key holder's side of device_polynomial_dfs::enable_extension_cache) */
+        for (auto *v : {&sid, &ssig})
+            for (auto &p : *v) p.enable_extension_cache();
+        for (dfs *p : {&q, &q_last, &q_blind, &lagrange_0}) p->enable_extension_cache();
         std::vector<Fr> pw(n);
         Fr x = Fr::one(), alpha(7);
         for (size_t i = 0; i < n; ++i) pw[i] = x, x = x * alpha;

@@ -16,6 +16,8 @@
 
 #include <algorithm>
 #include <functional>
+#include <map>
+#include <memory>
 #include <stdexcept>
 #include <vector>
 
@@ -50,6 +52,37 @@ public:
     void *data() const { return d_.get(); }
     const context &ctx() const { return *ctx_; }
 
+    /// EXTENSION CACHE (round 5).  placeholder's arguments extend the same polynomials again and again: the preprocessed ones (q_last, q_blind,
+    /// lagrange_0, the identity / permutation polynomials) in every proof, a witness column once per argument that reads it.  A polynomial whose
+    /// holder calls enable_extension_cache() keeps the extensions extension() computes (size -> buffer; copies of the object share buffer AND
+    /// cache) until clear_extension_cache(), an in-place change of the values, or the last copy's end.  The key holder enables it on the
+    /// preprocessed polynomials for good (2^20 rows: 32 MiB per polynomial and factor of extension), the prover on the columns it hands to
+    /// several arguments for the duration of a proof.  The reference extends anew at every use (polynomial_dfs::resize inside operator*).
+    void enable_extension_cache() {
+        if (!cache_) cache_ = std::make_shared<std::map<std::size_t, std::shared_ptr<void>>>();
+    }
+    bool extension_cache_enabled() const { return (bool)cache_; }
+    void clear_extension_cache() {
+        if (cache_) cache_->clear();
+    }
+    /// this polynomial on the `size`-point domain (size >= size(), a power of two): itself, a cached extension, or a fresh one (cached when the
+    /// cache is on).  The result SHARES its buffer with the cache: read it, never write into it (as every copy of a device_polynomial_dfs).
+    device_polynomial_dfs extension(std::size_t size, const root_of_unity_type &root) const {
+        if (size <= size_) return *this;
+        if (cache_) {
+            auto it = cache_->find(size);
+            if (it != cache_->end()) {
+                device_polynomial_dfs hit(*ctx_, size, degree_, it->second);
+                return hit;
+            }
+        }
+        device_polynomial_dfs e = *this;
+        e.cache_.reset();
+        e.resize(size, root);
+        if (cache_) (*cache_)[size] = e.d_;
+        return e;
+    }
+
     polynomial_dfs<CurveType> to_host() const {
         polynomial_dfs<CurveType> out;
         download_scalars<adapter>(*ctx_, d_.get(), size_, out.values);
@@ -78,6 +111,7 @@ public:
         ctx_->sync();    // the temporaries are released below
         d_ = d_new;
         size_ = new_size;
+        cache_.reset();    // another polynomial object now: copies made before keep the old buffer and its cache
     }
     /// coefficients(): inverse NTT into a new device buffer of size() elements
     std::shared_ptr<void> coefficients(const root_of_unity_type &root) const {
@@ -90,6 +124,7 @@ public:
     }
     /// from_coefficients(): the evaluations of the polynomial whose size() coefficients are at d_coeffs
     void from_coefficients(const void *d_coeffs, const root_of_unity_type &root) {
+        clear_extension_cache();
         check(zkhip_memcpy_d2d_async(ctx_->get(), d_.get(), d_coeffs, size_ * 32), "zkhip_memcpy_d2d_async", ctx_->get());
         std::uint64_t w[4];
         adapter::scalar_to_limbs(root(log2_exact(size_)), w);
@@ -118,14 +153,19 @@ private:
         return l;
     }
     device_polynomial_dfs &pointwise(int op, const device_polynomial_dfs &o) {
+        clear_extension_cache();    // the values change in place
         if (o.size_ != size_) throw std::runtime_error("device_polynomial_dfs: operands must share the domain (resize first)");
         check(zkhip_fr_vec_op_dev(ctx_->get(), adapter::id, op, d_.get(), o.d_.get(), d_.get(), size_), "zkhip_fr_vec_op_dev", ctx_->get());
         return *this;
     }
 
+    /// a view of an existing buffer (a cached extension)
+    device_polynomial_dfs(const context &ctx, std::size_t size, std::size_t degree, std::shared_ptr<void> d) : ctx_(&ctx), size_(size), degree_(degree), d_(std::move(d)) { }
+
     const context *ctx_;
     std::size_t size_, degree_;
     std::shared_ptr<void> d_;
+    std::shared_ptr<std::map<std::size_t, std::shared_ptr<void>>> cache_;    // extension cache, shared by the copies of this object (null: off)
 };
 
 /// math::polynomial_product(multipliers) (ph/permutation_argument.hpp:148, gates_argument.hpp:117): the product of k

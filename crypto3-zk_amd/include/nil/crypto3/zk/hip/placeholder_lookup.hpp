@@ -207,8 +207,7 @@ struct placeholder_lookup_hip {
             dfs_type last = minus(polynomial_product<CurveType>({previous_ext, gs[parts - 1]}, root), polynomial_product<CurveType>({V_shifted, hs[parts - 1]}, root), root);
             T = parts == 1 ? last : PA::plus(T, last, root);
         }
-        dfs_type q = affine(q_last, &q_blind, one, one, zero);
-        q.set_degree(std::max(q_last.degree(), q_blind.degree()));
+        const dfs_type q = PA::selector_sum(q_last, q_blind, PA::pow2_holding(std::max(q_last.degree(), q_blind.degree()) + T.degree()), root);
         res.F_dfs[2] = minus(polynomial_product<CurveType>({q, T}, root), T, root);
         /* F_dfs[3] = sum_i alpha_i lagrange_0 (sorted[i + 1] - sorted[i](omega^usable_rows X)) */
         if (sorted.size() > 1) {

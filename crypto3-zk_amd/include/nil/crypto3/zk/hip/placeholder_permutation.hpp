@@ -82,8 +82,17 @@ struct placeholder_permutation_hip {
         if (max_quotient_chunks == 1) throw std::invalid_argument("permutation argument: max_quotient_chunks = 1 leaves no factor per part");
         const std::size_t step = max_quotient_chunks ? max_quotient_chunks - 1 : k, parts = (k + step - 1) / step;    // preprocessor.hpp:80-87
         if (parts > 1 && (usable_rows == 0 || usable_rows >= n)) throw std::invalid_argument("permutation argument: the multi-part form needs usable_rows");
+        /* Round 5: with extension caches on S_id / S_sigma (preprocessed, the same in every proof) the factors g_v, h_v are formed ON the products'
+           domain from ONE extension per column -- ext(column) + beta ext(S) + gamma, a pointwise pass -- instead of being extended one by one (2 k
+           transforms); a column's extension is shared with whatever else extended it (the gate argument) when the column's cache is on as well. */
+        bool factors_from_columns = true;
+        for (std::size_t i = 0; i < k; ++i) factors_from_columns = factors_from_columns && S_id[i].extension_cache_enabled() && S_sigma[i].extension_cache_enabled();
         /* 2.-3.: g_v, h_v and V_P in one device call */
-        auto d_g = ctx.alloc(k * n * 32), d_h = ctx.alloc(k * n * 32);
+        std::shared_ptr<void> d_g, d_h;
+        if (!factors_from_columns) {
+            d_g = ctx.alloc(k * n * 32);
+            d_h = ctx.alloc(k * n * 32);
+        }
         dfs_type V_P(ctx, n);
         std::vector<const void *> pc, pi, ps;
         for (std::size_t i = 0; i < k; ++i) {
@@ -102,12 +111,22 @@ struct placeholder_permutation_hip {
         std::vector<dfs_type> gs, hs;
         for (std::size_t lo = 0; lo < k; lo += step) {
             std::vector<dfs_type> g_v, h_v;
-            for (std::size_t i = lo; i < std::min(k, lo + step); ++i) {
+            const std::size_t hi = std::min(k, lo + step), size = pow2_holding((hi - lo) * (n - 1));
+            for (std::size_t i = lo; i < hi; ++i) {
+                if (factors_from_columns) {
+                    const dfs_type col = extended(columns[i], size, root), sid = extended(S_id[i], size, root), ssig = extended(S_sigma[i], size, root);
+                    g_v.push_back(affine(col, sid, value_type::one(), beta, gamma));
+                    h_v.push_back(affine(col, ssig, value_type::one(), beta, gamma));
+                    g_v.back().set_degree(n - 1);
+                    h_v.back().set_degree(n - 1);
+                    continue;
+                }
                 g_v.emplace_back(ctx, n);
                 h_v.emplace_back(ctx, n);
                 check(zkhip_memcpy_d2d_async(ctx.get(), g_v.back().data(), static_cast<const char *>(d_g.get()) + i * n * 32, n * 32), "zkhip_memcpy_d2d_async", ctx.get());
                 check(zkhip_memcpy_d2d_async(ctx.get(), h_v.back().data(), static_cast<const char *>(d_h.get()) + i * n * 32, n * 32), "zkhip_memcpy_d2d_async", ctx.get());
             }
+            if (factors_from_columns) ctx.sync();    // the extensions' temporaries are released
             gs.push_back(polynomial_product<CurveType>(std::move(g_v), root));
             hs.push_back(polynomial_product<CurveType>(std::move(h_v), root));
         }
@@ -123,9 +142,7 @@ struct placeholder_permutation_hip {
         res.F_dfs[0] = minus(L0, polynomial_product<CurveType>({L0, V}, root, L0.size()), root);
         const std::vector<value_type> alphas = hooks.draw_alphas ? hooks.draw_alphas(parts) : std::vector<value_type>();    // :181-183
         if (alphas.size() + 1 != parts) throw std::invalid_argument("permutation argument: permutation_parts - 1 alphas");
-        dfs_type q(ctx, n);    // q_last + q_blind, in a buffer of its own
-        q.set_degree(std::max(q_last.degree(), q_blind.degree()));
-        check(zkhip_fr_vec_op_dev(ctx.get(), adapter::id, 0, q_last.data(), q_blind.data(), q.data(), n), "zkhip_fr_vec_op_dev", ctx.get());
+        const dfs_type q = selector_sum(q_last, q_blind, pow2_holding(n - 1 + V_P.degree() + deg_g), root);    // q_last + q_blind
         if (parts == 1) {
             /* F_dfs[1] = (1 - q)(V_P_shifted h - V_P g) = T - q T,  q = q_last + q_blind */
             dfs_type T = minus(polynomial_product<CurveType>({V_shifted, hs[0]}, root), polynomial_product<CurveType>({V, gs[0]}, root), root);
@@ -154,6 +171,27 @@ struct placeholder_permutation_hip {
         return res;
     }
 
+    /// q_last + q_blind: on the n-point domain, or -- when both hold extension caches (preprocessed selectors) -- directly on the `size`-point one
+    /// their sum is multiplied on afterwards: two cached extensions and one addition instead of a transform
+    static dfs_type selector_sum(const dfs_type &q_last, const dfs_type &q_blind, std::size_t size, const root_of_unity_type &root) {
+        const bool cached = q_last.extension_cache_enabled() && q_blind.extension_cache_enabled();
+        const dfs_type a = cached ? extended(q_last, size, root) : q_last, b = cached ? extended(q_blind, size, root) : q_blind;
+        dfs_type q(a.ctx(), a.size());
+        q.set_degree(std::max(q_last.degree(), q_blind.degree()));
+        check(zkhip_fr_vec_op_dev(a.ctx().get(), adapter::id, 0, a.data(), b.data(), q.data(), a.size()), "zkhip_fr_vec_op_dev", a.ctx().get());
+        return q;
+    }
+    /// a x + b y + c over the shared domain, into a buffer of its own
+    static dfs_type affine(const dfs_type &x, const dfs_type &y, const value_type &a, const value_type &b, const value_type &c) {
+        if (y.size() != x.size()) throw std::invalid_argument("permutation argument: operands must share the domain");
+        dfs_type out(x.ctx(), x.size());
+        std::uint64_t al[4], bl[4], cl[4];
+        adapter::scalar_to_limbs(a, al);
+        adapter::scalar_to_limbs(b, bl);
+        adapter::scalar_to_limbs(c, cl);
+        check(zkhip_fr_vec_affine_dev(x.ctx().get(), adapter::id, x.data(), y.data(), al, bl, cl, out.data(), x.size()), "zkhip_fr_vec_affine_dev", x.ctx().get());
+        return out;
+    }
     /// the intermediate polynomial of a part (:193-199): current[j] = previous[j] reduced_g[j] / reduced_h[j] for j < usable_rows, `fill`'s values
     /// behind them (V_P's, which `current_poly` starts as); reduced = every (size / n)-th evaluation (reduce_dfs_polynomial_domain)
     static dfs_type multiplied_up(const dfs_type &previous, const dfs_type &fill, const dfs_type &g, const dfs_type &h, std::size_t n, std::size_t usable_rows) {
@@ -167,11 +205,7 @@ struct placeholder_permutation_hip {
         return current;
     }
     /// p on the `size`-point domain (a copy with a buffer of its own; p itself where it already lives there)
-    static dfs_type extended(const dfs_type &p, std::size_t size, const root_of_unity_type &root) {
-        dfs_type e = p;
-        if (size > p.size()) e.resize(size, root);
-        return e;
-    }
+    static dfs_type extended(const dfs_type &p, std::size_t size, const root_of_unity_type &root) { return p.extension(size, root); }
     static std::size_t pow2_holding(std::size_t degree) {
         std::size_t size = 1;
         while (size < degree + 1) size <<= 1;

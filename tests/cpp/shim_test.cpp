@@ -1407,6 +1407,28 @@ int placeholder_permutation_t(const uint64_t *evals, size_t k, size_t log_n, con
                                                              A::scalar_from_limbs(gamma), root, chunks, al, usable_rows);
     ctx.d2h(out_vp, res.permutation_polynomial_dfs.data(), n * 32);
     if (res.parts_dfs.size() != n_alphas) return -54;
+    {   /* round 5: the same call with extension caches on the preprocessed polynomials and the columns -- the factors are then formed on the
+           products' domains from one extension per column, q_last + q_blind from cached extensions --, twice (the second run hits the caches):
+           the same bits */
+        for (auto &p : all) p.enable_extension_cache();
+        std::vector<dfs> c2(all.begin(), all.begin() + k), i2(all.begin() + k, all.begin() + 2 * k), s2(all.begin() + 2 * k, all.begin() + 3 * k);
+        for (int rep = 0; rep < 2; ++rep) {
+            auto again = placeholder_permutation_hip<Curve>::prove_eval(ctx, c2, i2, s2, all[3 * k], all[3 * k + 1], all[3 * k + 2], A::scalar_from_limbs(beta),
+                                                                       A::scalar_from_limbs(gamma), root, chunks, al, usable_rows);
+            auto same = [&](const dfs &a, const dfs &b) {
+                if (a.size() != b.size() || a.degree() != b.degree()) return false;
+                std::vector<uint64_t> x(4 * a.size()), y(4 * a.size());
+                ctx.d2h(x.data(), a.data(), a.size() * 32);
+                ctx.d2h(y.data(), b.data(), b.size() * 32);
+                return x == y;
+            };
+            if (!same(again.permutation_polynomial_dfs, res.permutation_polynomial_dfs) || again.parts_dfs.size() != res.parts_dfs.size()) return -55;
+            for (size_t i = 0; i < res.parts_dfs.size(); ++i)
+                if (!same(again.parts_dfs[i], res.parts_dfs[i])) return -56;
+            for (int f = 0; f < 3; ++f)
+                if (!same(again.F_dfs[f], res.F_dfs[f])) return -57 - 10 * rep;
+        }
+    }
     for (size_t i = 0; i < res.parts_dfs.size(); ++i) ctx.d2h(out_parts + 4 * i * n, res.parts_dfs[i].data(), n * 32);
     for (int f = 0; f < 3; ++f) {
         const size_t sz = res.F_dfs[f].size();
@@ -1481,6 +1503,25 @@ int placeholder_lookup_t(const uint64_t *evals, size_t k_in, const uint64_t *in_
                                                          usable_rows, root, ps, pa);
     ctx.d2h(out_vl, res.V_L.data(), n * 32);
     if (res.parts_dfs.size() != (n_parts ? n_parts - 1 : 0)) return -64;
+    {   /* round 5: with extension caches on the preprocessed selectors, twice (the second run hits the caches): the same bits */
+        for (dfs *p : {&q_last, &q_blind, &lagrange_0}) p->enable_extension_cache();
+        for (int rep = 0; rep < 2; ++rep) {
+            auto again = placeholder_lookup_hip<Curve>::prove_eval(ctx, input, value, sorted, q_last, q_blind, lagrange_0, A::scalar_from_limbs(beta),
+                                                                  A::scalar_from_limbs(gamma), al, usable_rows, root, ps, pa);
+            auto same = [&](const dfs &a, const dfs &b) {
+                if (a.size() != b.size() || a.degree() != b.degree()) return false;
+                std::vector<uint64_t> x(4 * a.size()), y(4 * a.size());
+                ctx.d2h(x.data(), a.data(), a.size() * 32);
+                ctx.d2h(y.data(), b.data(), b.size() * 32);
+                return x == y;
+            };
+            if (!same(again.V_L, res.V_L) || again.parts_dfs.size() != res.parts_dfs.size()) return -65;
+            for (size_t i = 0; i < res.parts_dfs.size(); ++i)
+                if (!same(again.parts_dfs[i], res.parts_dfs[i])) return -66;
+            for (int f = 0; f < 4; ++f)
+                if (!same(again.F_dfs[f], res.F_dfs[f])) return -67 - 10 * rep;
+        }
+    }
     for (size_t i = 0; i < res.parts_dfs.size(); ++i) ctx.d2h(out_parts + 4 * i * n, res.parts_dfs[i].data(), n * 32);
     for (int f = 0; f < 4; ++f) {
         const size_t sz = res.F_dfs[f].size();
