@@ -402,11 +402,14 @@ int zkhip_bench_quotient(int device, size_t log_n, int steps, double *ms, int *v
             T = Q::quotient_polynomial(ctx, {G, F1}, {a0, a1}, n, bls_root);
             ms[5 * rep + 2] = ms_since(t0);
             t0 = std::chrono::steady_clock::now();
-            parts = Q::quotient_polynomial_split_dfs(ctx, T, n, 4, n, bls_root);
+            /* round 5: the parts stay in coefficient form on their way into the scheme (T_splitted_dfs has no other consumer, prover.hpp:199-202,
+               314-317): no from_coefficients here, no coefficients() inside commit */
+            auto cparts = Q::quotient_polynomial_split_coefficients(ctx, T, n, 4, n);
+            ctx.sync();
             ms[5 * rep + 3] = ms_since(t0);
             t0 = std::chrono::steady_clock::now();
             kzg_commitment_scheme_v2_hip<C, counting_transcript> scheme(params, bls_root);
-            scheme.append_to_batch(3, parts);    // QUOTIENT_BATCH (proof.hpp:40)
+            scheme.append_to_batch(3, cparts);    // QUOTIENT_BATCH (proof.hpp:40)
             commits = scheme.commit(3);
             ms[5 * rep + 4] = ms_since(t0);
             if (rep == steps - 1) {
@@ -790,7 +793,8 @@ int zkhip_bench_placeholder_round(int device, size_t log_n, size_t witness_cols,
             T = Q::quotient_polynomial(ctx, F, alphas, n, bls_root);
             t[4] = ms_since(t0);
             t0 = std::chrono::steady_clock::now();
-            auto parts = Q::quotient_polynomial_split_dfs(ctx, T, n, 8, n, bls_root);
+            auto parts = Q::quotient_polynomial_split_coefficients(ctx, T, n, 8, n);    // coefficient form straight into the scheme (see zkhip_bench_quotient)
+            ctx.sync();
             t[5] = ms_since(t0);
             t0 = std::chrono::steady_clock::now();
             scheme.append_to_batch(QUOTIENT_BATCH, parts);

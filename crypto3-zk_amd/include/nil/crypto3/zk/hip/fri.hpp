@@ -168,6 +168,24 @@ private:
     std::shared_ptr<std::map<std::size_t, std::shared_ptr<void>>> cache_;    // extension cache, shared by the copies of this object (null: off)
 };
 
+/// A polynomial resident in COEFFICIENT form: `size` (a power of two) coefficients, zero-padded.  What a KZG scheme keeps of every committed
+/// polynomial anyway; placeholder's quotient parts are born in this form (chunks of T's coefficients, prover.hpp:244-249) and the reference
+/// turns them into polynomial_dfs (:255) only for commit() to turn them back (kzg.hpp:431) -- 2 n transform points per part that
+/// append_to_batch(batch, device_polynomial_coefficients) saves.
+template <typename CurveType>
+class device_polynomial_coefficients {
+public:
+    device_polynomial_coefficients(const context &ctx, std::size_t size) : ctx_(&ctx), size_(size), d_(ctx.alloc(std::max<std::size_t>(1, size) * 32)) { }
+    std::size_t size() const { return size_; }
+    void *data() const { return d_.get(); }
+    const context &ctx() const { return *ctx_; }
+
+private:
+    const context *ctx_;
+    std::size_t size_;
+    std::shared_ptr<void> d_;
+};
+
 /// math::polynomial_product(multipliers) (ph/permutation_argument.hpp:148, gates_argument.hpp:117): the product of k
 /// DFS polynomials on the smallest power-of-two domain that holds its degree (sum of the degrees): every factor is
 /// resized to it, then ONE k-way pointwise pass multiplies them.  A factor may arrive on a LARGER domain than the product's (a polynomial

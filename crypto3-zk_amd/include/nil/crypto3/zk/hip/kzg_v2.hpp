@@ -209,6 +209,17 @@ public:
     void append_to_batch(std::size_t index, const std::vector<device_polynomial_dfs<CurveType>> &polys) {
         for (const auto &p : polys) append_to_batch(index, p);
     }
+    /// A resident polynomial that is ALREADY in coefficient form (placeholder's quotient parts: placeholder_quotient_hip::
+    /// quotient_polynomial_split_coefficients): commit skips its inverse transform.  Same commitment, same opening proof as for the
+    /// polynomial_dfs the reference would have made of it.
+    void append_to_batch(std::size_t index, const device_polynomial_coefficients<CurveType> &poly) {
+        if (_locked[index]) throw std::runtime_error("append_to_batch: batch already committed");
+        _resident_coefficients[index].emplace(_polys[index].size(), poly);
+        _polys[index].push_back(nullptr);
+    }
+    void append_to_batch(std::size_t index, const std::vector<device_polynomial_coefficients<CurveType>> &polys) {
+        for (const auto &p : polys) append_to_batch(index, p);
+    }
     void append_eval_point(std::size_t batch_id, const scalar_value_type &point) {
         for (auto &pts : _points.at(batch_id)) pts.push_back(point);
     }
@@ -231,10 +242,12 @@ public:
         const context &ctx = _params.ctx;
         const std::vector<const poly_type *> &polys = _polys[index];
         const auto &resident = _resident[index];    // position -> a polynomial that is already on the device (polys[position] == nullptr)
+        const auto &resident_c = _resident_coefficients[index];    // ... and already in coefficient form
+        auto is_coefficients = [&resident_c](std::size_t i) { return resident_c.count(i) != 0; };
         device_batch db;
         std::size_t total = 0;
         for (std::size_t i = 0; i < polys.size(); ++i) {
-            const std::size_t sz = polys[i] ? polys[i]->size() : resident.at(i).size();
+            const std::size_t sz = polys[i] ? polys[i]->size() : is_coefficients(i) ? resident_c.at(i).size() : resident.at(i).size();
             if (sz == 0 || (sz & (sz - 1))) throw std::runtime_error("commit: polynomial_dfs size must be a power of two");
             if (sz > _params.commitment_key.size()) throw std::runtime_error("commit: polynomial longer than the commitment key");
             db.offset.push_back(total);
@@ -251,21 +264,28 @@ public:
         for (const poly_type *p : polys) any_from_host = any_from_host || p != nullptr;
         const bool pipelined = upload_chunk != 0 && count > upload_chunk && any_from_host;
         const context &up = pipelined ? upload_context() : ctx;
+        /* a resident polynomial may still be in the making on ctx's stream (polynomial_product, resize do not synchronise): the stream that
+           copies it waits for ctx once */
+        if (pipelined && (!resident.empty() || !resident_c.empty())) up.wait_for(ctx);
         for (std::size_t i = 0; i < count;) {
             std::size_t j = i;
             /* the first chunk is a short one: nothing runs on the device until it has arrived */
             const std::size_t limit = (pipelined && i == 0) ? std::max<std::size_t>(1, upload_chunk / 4) : upload_chunk;
-            while (j < count && db.len[j] == db.len[i] && (!pipelined || limit == 0 || j - i < limit)) ++j;
+            while (j < count && db.len[j] == db.len[i] && is_coefficients(j) == is_coefficients(i) && (!pipelined || limit == 0 || j - i < limit)) ++j;
             for (std::size_t p = i; p < j; ++p) {
                 if (polys[p]) upload_scalars<adapter>(up, db.at(p), detail::poly_data<adapter>(*polys[p]), polys[p]->size());
-                else check(zkhip_memcpy_d2d_async(up.get(), db.at(p), resident.at(p).data(), db.len[p] * 32), "zkhip_memcpy_d2d_async", up.get());
+                else
+                    check(zkhip_memcpy_d2d_async(up.get(), db.at(p), is_coefficients(p) ? resident_c.at(p).data() : resident.at(p).data(), db.len[p] * 32),
+                          "zkhip_memcpy_d2d_async", up.get());
             }
             if (pipelined) ctx.wait_for(up);
-            std::size_t log_n = 0;
-            while (((std::size_t)1 << log_n) < db.len[i]) ++log_n;
-            std::uint64_t w[4];
-            adapter::scalar_to_limbs(_root_of_unity(log_n), w);
-            check(zkhip_ntt_dev(ctx.get(), adapter::id, db.at(i), log_n, j - i, w, 1, nullptr), "zkhip_ntt_dev", ctx.get());
+            if (!is_coefficients(i)) {
+                std::size_t log_n = 0;
+                while (((std::size_t)1 << log_n) < db.len[i]) ++log_n;
+                std::uint64_t w[4];
+                adapter::scalar_to_limbs(_root_of_unity(log_n), w);
+                check(zkhip_ntt_dev(ctx.get(), adapter::id, db.at(i), log_n, j - i, w, 1, nullptr), "zkhip_ntt_dev", ctx.get());
+            }
             commit_resident(db, i, j, d_res.get());
             i = j;
         }
@@ -283,6 +303,7 @@ public:
         _points[index].resize(polys.size());
         _polys[index].clear();    // no pointer to a lent polynomial outlives the call
         _resident[index].clear();
+        _resident_coefficients[index].clear();
         return _ind_commitments[index];
     }
 
@@ -433,6 +454,7 @@ protected:
     std::map<std::size_t, std::vector<const poly_type *>> _polys;    // in append order: copies held in _owned, or the caller's (lent)
     std::map<std::size_t, std::deque<poly_type>> _owned;             // a deque: references stay valid as it grows
     std::map<std::size_t, std::map<std::size_t, device_polynomial_dfs<CurveType>>> _resident;    // batch -> position -> resident polynomial
+    std::map<std::size_t, std::map<std::size_t, device_polynomial_coefficients<CurveType>>> _resident_coefficients;    // ... in coefficient form
     std::map<std::size_t, bool> _locked;
     std::map<std::size_t, std::vector<std::vector<scalar_value_type>>> _points;
     std::map<std::size_t, device_batch> _dev;

@@ -211,6 +211,28 @@ struct placeholder_quotient_hip {
         ctx.sync();
         return out;
     }
+
+    /// The same parts left in COEFFICIENT form (zero-padded to dfs_size): what T_commit's commitment scheme needs of them (prover.hpp:314-317 --
+    /// the only consumer of T_splitted_dfs in the reference).  kzg_commitment_scheme_v2_hip::append_to_batch takes them as they are, which
+    /// saves the from_coefficients of :255 and the coefficients() of kzg.hpp:431: 2 dfs_size transform points per part.
+    static std::vector<device_polynomial_coefficients<CurveType>> quotient_polynomial_split_coefficients(const context &ctx, const device_coefficients &T,
+                                                                                                         std::size_t rows_amount, std::size_t split_polynomial_size,
+                                                                                                         std::size_t dfs_size) {
+        const std::size_t chunks = (T.size + rows_amount - 1) / rows_amount;
+        if (chunks > split_polynomial_size) throw std::invalid_argument("quotient_polynomial_split_coefficients: the quotient needs more parts than split_polynomial_size");
+        if (dfs_size < rows_amount || (dfs_size & (dfs_size - 1))) throw std::invalid_argument("quotient_polynomial_split_coefficients: dfs_size must be a power of two >= rows_amount");
+        std::vector<device_polynomial_coefficients<CurveType>> out;
+        std::uint64_t one[4];
+        adapter::scalar_to_limbs(value_type::one(), one);
+        for (std::size_t k = 0; k < split_polynomial_size; ++k) {
+            device_polynomial_coefficients<CurveType> p(ctx, dfs_size);
+            const std::size_t lo = k * rows_amount, len = lo < T.size ? std::min(rows_amount, T.size - lo) : 0;
+            const void *src = len ? T.at(lo) : nullptr;
+            check(zkhip_poly_lincomb_dev(ctx.get(), adapter::id, len ? 1 : 0, &src, &len, one, 1, p.data(), dfs_size, 0), "zkhip_poly_lincomb_dev", ctx.get());
+            out.push_back(std::move(p));
+        }
+        return out;
+    }
 };
 
 }    // namespace hip

@@ -1615,6 +1615,14 @@ int placeholder_round_t(const uint64_t *srs, size_t n_srs, const uint64_t *evals
     scheme.append_to_batch(QUOTIENT_BATCH, parts);
     auto t_commit = scheme.commit(QUOTIENT_BATCH);
     if (perm_commit.size() != 2 || lookup_commit.size() != 2 || t_commit.size() != 4) return -72;
+    {   /* round 5: the parts handed over in COEFFICIENT form (no from_coefficients, no coefficients() inside commit): the same commitments */
+        kzg_commitment_scheme_v2_hip<Curve, scripted_any_transcript<Curve>> scheme2(params, root);
+        scheme2.append_to_batch(QUOTIENT_BATCH, Q::quotient_polynomial_split_coefficients(ctx, T, n, 4, n));
+        auto t_commit2 = scheme2.commit(QUOTIENT_BATCH);
+        if (t_commit2.size() != 4) return -74;
+        for (size_t i = 0; i < 4; ++i)
+            if (!(t_commit2[i] == t_commit[i])) return -75;
+    }
     size_t o = 0;
     for (auto &c : perm_commit) c.to_affine(out_commits + (o++) * L1);
     for (auto &c : lookup_commit) c.to_affine(out_commits + (o++) * L1);
