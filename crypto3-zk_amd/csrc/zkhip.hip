@@ -28,6 +28,14 @@ const char *zkhip_strerror(int status) {
     }
 }
 
+// Process-wide view of the block caches: which context a live block of zkhip_malloc belongs to -- so that zkhip_free through
+// ANOTHER context of the process settles the block with its owner instead of leaving a stale entry there --, and which contexts exist,
+// so that an out-of-memory in one of them can empty its siblings' caches on the same device.  Lock order: g_alloc_mutex, then a
+// context's alloc_mutex; never the other way round.
+static std::mutex g_alloc_mutex;
+static std::unordered_map<void *, zkhip_ctx *> g_block_owner;
+static std::unordered_set<zkhip_ctx *> g_contexts;
+
 int zkhip_init(int device_id, zkhip_ctx **out) {
     if (!out) return ZKHIP_ERR_INVALID;
     *out = nullptr;
@@ -48,6 +56,10 @@ int zkhip_init(int device_id, zkhip_ctx **out) {
         return ZKHIP_ERR_OOM;
     }
     *out = ctx;
+    {
+        std::lock_guard<std::mutex> g(g_alloc_mutex);
+        g_contexts.insert(ctx);
+    }
     // A/B runs of programs that create their own contexts (the bench library, the shim's default context): ZKHIP_OPTIONS="name=value,name=value"
     // is applied to every new context; an unknown name or a malformed entry is ignored (the variable is for measurements, not for deployments)
     if (const char *env = getenv("ZKHIP_OPTIONS")) {
@@ -83,9 +95,17 @@ void zkhip_destroy(zkhip_ctx *ctx) {
     }
     zk_graphs_clear(ctx);
     if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
-    alloc_cache_flush(ctx);
-    for (auto &e : ctx->alloc_live) (void)hipFree(e.first);  // blocks the caller never returned
-    ctx->alloc_live.clear();
+    {
+        /* the cached blocks go back to the driver; blocks the caller still HOLDS (a shared_ptr handle of the shim that outlives its context)
+           are left alone and lose their owner: a later zkhip_free through any context hands them to hipFree (they used to be
+           freed here, under the handle) */
+        std::lock_guard<std::mutex> g(g_alloc_mutex);
+        std::lock_guard<std::mutex> lock(ctx->alloc_mutex);
+        alloc_cache_flush(ctx);
+        for (auto &e : ctx->alloc_live) g_block_owner.erase(e.first);
+        ctx->alloc_live.clear();
+        g_contexts.erase(ctx);
+    }
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -165,6 +185,7 @@ int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value) {
     else if (n == "msm_graphs") ctx->opt_msm_graphs = (int)value;
     else if (n == "alloc_cache_mb") {
         if (value < 0) return ZKHIP_ERR_RANGE;
+        std::lock_guard<std::mutex> g(g_alloc_mutex);
         std::lock_guard<std::mutex> lock(ctx->alloc_mutex);
         ctx->opt_alloc_cache_bytes = (size_t)value << 20;
         if (ctx->alloc_cached_bytes > ctx->opt_alloc_cache_bytes) alloc_cache_flush(ctx);
@@ -213,9 +234,12 @@ int zkhip_get_option(const zkhip_ctx *ctx, const char *name, int64_t *value) {
     return ZKHIP_OK;
 }
 
-// give every cached block back to the driver
+// give every cached block back to the driver; the caller holds g_alloc_mutex and ctx->alloc_mutex
 static void alloc_cache_flush(zkhip_ctx *ctx) {
-    for (auto &e : ctx->alloc_free) (void)hipFree(e.second);
+    for (auto &e : ctx->alloc_free) {
+        g_block_owner.erase(e.second);
+        (void)hipFree(e.second);
+    }
     ctx->alloc_free.clear();
     ctx->alloc_cached_bytes = 0;
 }
@@ -223,23 +247,33 @@ int zkhip_malloc(zkhip_ctx *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) return ZKHIP_ERR_INVALID;
     ZK_TRY(check_device(ctx));
     const size_t want = ((bytes ? bytes : 1) + 0xFFFF) & ~(size_t)0xFFFF;
-    std::lock_guard<std::mutex> lock(ctx->alloc_mutex);
-    auto it = ctx->alloc_free.lower_bound(want);
-    if (it != ctx->alloc_free.end() && it->first <= want + (want >> 3)) {  // a cached block of this size class (blocks enter the cache after a stream sync)
-        *dptr = it->second;
-        ctx->alloc_cached_bytes -= it->first;
-        ctx->alloc_live[*dptr] = it->first;
-        ctx->alloc_free.erase(it);
-        return ZKHIP_OK;
+    {
+        std::lock_guard<std::mutex> lock(ctx->alloc_mutex);
+        auto it = ctx->alloc_free.lower_bound(want);
+        if (it != ctx->alloc_free.end() && it->first <= want + (want >> 3)) {  // a cached block of this size class (blocks enter the cache after a device sync)
+            *dptr = it->second;
+            ctx->alloc_cached_bytes -= it->first;
+            ctx->alloc_live[*dptr] = it->first;
+            ctx->alloc_free.erase(it);
+            return ZKHIP_OK;  // its owner entry was kept while it sat in the cache
+        }
     }
     hipError_t e = hipMalloc(dptr, want);
-    if (e != hipSuccess && !ctx->alloc_free.empty()) {  // out of memory with blocks in the cache: give them back and try once more
+    if (e != hipSuccess) {  // out of memory: the caches of EVERY context on this device go back to the driver (a shim process holds several), then once more
         (void)hipGetLastError();
-        alloc_cache_flush(ctx);
+        std::lock_guard<std::mutex> g(g_alloc_mutex);
+        for (zkhip_ctx *c : g_contexts)
+            if (c->device == ctx->device) {
+                std::lock_guard<std::mutex> lock(c->alloc_mutex);
+                alloc_cache_flush(c);
+            }
         e = hipMalloc(dptr, want);
     }
     ZK_HIP_CHECK(ctx, e);
+    std::lock_guard<std::mutex> g(g_alloc_mutex);
+    std::lock_guard<std::mutex> lock(ctx->alloc_mutex);
     ctx->alloc_live[*dptr] = want;
+    g_block_owner[*dptr] = ctx;
     return ZKHIP_OK;
 }
 int zkhip_free(zkhip_ctx *ctx, void *dptr) {
@@ -249,19 +283,24 @@ int zkhip_free(zkhip_ctx *ctx, void *dptr) {
     // hipFree used to synchronise the whole device before the block could be handed out again; a block entering the cache gets the same
     // guarantee -- no stream of ANY context (a scheme's upload stream, the prover's G2 stream) still reads or writes it
     ZK_HIP_CHECK(ctx, hipDeviceSynchronize());
-    std::lock_guard<std::mutex> lock(ctx->alloc_mutex);
-    auto it = ctx->alloc_live.find(dptr);
-    if (it == ctx->alloc_live.end()) {  // not from zkhip_malloc of this context
+    std::lock_guard<std::mutex> g(g_alloc_mutex);
+    auto own = g_block_owner.find(dptr);
+    if (own == g_block_owner.end()) {  // not a live block of any context's zkhip_malloc (or its context is gone): the driver's
         ZK_HIP_CHECK(ctx, hipFree(dptr));
         return ZKHIP_OK;
     }
+    zkhip_ctx *owner = own->second;  // the block is settled with the context that allocated it, whichever context it is freed through
+    std::lock_guard<std::mutex> lock(owner->alloc_mutex);
+    auto it = owner->alloc_live.find(dptr);
+    if (it == owner->alloc_live.end()) return ZKHIP_ERR_INVALID;  // a double free: the block already sits in the owner's cache
     const size_t sz = it->second;
-    ctx->alloc_live.erase(it);
-    if (sz <= ctx->opt_alloc_cache_bytes && ctx->alloc_cached_bytes + sz <= ctx->opt_alloc_cache_bytes) {
-        ctx->alloc_free.emplace(sz, dptr);
-        ctx->alloc_cached_bytes += sz;
+    owner->alloc_live.erase(it);
+    if (sz <= owner->opt_alloc_cache_bytes && owner->alloc_cached_bytes + sz <= owner->opt_alloc_cache_bytes) {
+        owner->alloc_free.emplace(sz, dptr);
+        owner->alloc_cached_bytes += sz;
         return ZKHIP_OK;
     }
+    g_block_owner.erase(own);
     ZK_HIP_CHECK(ctx, hipFree(dptr));
     return ZKHIP_OK;
 }

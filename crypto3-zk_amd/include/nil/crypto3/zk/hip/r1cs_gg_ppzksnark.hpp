@@ -515,21 +515,45 @@ public:
     static bool forget(const KeyType &proving_key) { return device_key_cache().erase(&proving_key) != 0; }
 
 private:
+    /// What identifies a key's CONTENT cheaply (the address and the query sizes alone also match a second key of the same
+    /// circuit that reuses the slot -- a fresh trapdoor in a loop --, which would then be proved with the first key's resident
+    /// queries): alpha_g1, delta_g1 and the first and last entry of the A, H and L queries, as affine limbs.
+    static std::vector<std::uint64_t> key_fingerprint(const KeyType &pk) {
+        std::vector<std::uint64_t> fp = {(std::uint64_t)pk.A_query.size(), (std::uint64_t)pk.H_query.size(), (std::uint64_t)pk.L_query.size(),
+                                         (std::uint64_t)pk.B_query.values.size()};
+        auto add = [&fp](const auto &point) {
+            std::uint64_t limbs[2 * adapter::g1_coord_limbs];
+            const bool finite = adapter::point_to_affine_limbs(point, limbs);
+            fp.push_back(finite ? 1 : 0);
+            if (finite) fp.insert(fp.end(), limbs, limbs + 2 * adapter::g1_coord_limbs);
+        };
+        add(pk.alpha_g1);
+        add(pk.delta_g1);
+        for (const auto *q : {&pk.A_query, &pk.H_query, &pk.L_query})
+            if (!q->empty()) {
+                add(*q->begin());
+                add(*(q->begin() + (q->size() - 1)));
+            }
+        return fp;
+    }
     struct cached_key {
-        std::size_t a = 0, h = 0, l = 0;    // query sizes when the device key was built: a key object reused for another key is rebuilt
+        std::vector<std::uint64_t> fingerprint;    // of the host key the device key was built from: another key in the same object is rebuilt
         std::unique_ptr<proving_key_type> device;
     };
     static std::map<const KeyType *, cached_key> &device_key_cache() {
+        /* the context first: thread_local objects die in reverse order of construction, and the cached keys release their device memory
+           THROUGH the default context (with the cache constructed first, its keys outlived the context they free into) */
+        (void)default_context();
         thread_local std::map<const KeyType *, cached_key> cache;    // per thread, like default_context(): a context is not thread-safe
         return cache;
     }
     static const proving_key_type &cached_device_key(const KeyType &pk) {
         cached_key &e = device_key_cache()[&pk];
-        if (!e.device || e.a != pk.A_query.size() || e.h != pk.H_query.size() || e.l != pk.L_query.size()) {
+        std::vector<std::uint64_t> fp = key_fingerprint(pk);
+        if (!e.device || e.fingerprint != fp) {
+            e.device.reset();    // the old key's queries go first: two resident keys of 2^20 constraints are 1.5 GB
             e.device.reset(new proving_key_type(pk));
-            e.a = pk.A_query.size();
-            e.h = pk.H_query.size();
-            e.l = pk.L_query.size();
+            e.fingerprint = std::move(fp);
         }
         return *e.device;
     }

@@ -200,6 +200,17 @@ int groth16_prove_t(size_t M, size_t n, size_t N, const uint32_t *const rowptr[3
             typename prover::proof_type q3 = prover::process(proving_key, primary, auxiliary);    // the three-argument form: fresh blinders
             if (q3.g_A.is_zero()) return -109;
             if (!prover::forget(proving_key) || prover::forget(proving_key)) return -110;
+            /* ANOTHER key in the same object (same address, same query sizes -- a fresh trapdoor in a loop) must not be proved with
+               the first key's resident queries: the cache holds a content fingerprint */
+            r1cs_gg_ppzksnark_proving_key<Curve> slot = pk;
+            auto s1 = prover::process(slot, primary, auxiliary, A::scalar_from_limbs(r), A::scalar_from_limbs(s));
+            if (!(s1.g_A == proof_v.g_A)) return -112;
+            slot.A_query[0] = slot.A_query[0] + slot.alpha_g1;    // a different key of the same shape
+            auto s2 = prover::process(slot, primary, auxiliary, A::scalar_from_limbs(r), A::scalar_from_limbs(s));
+            r1cs_gg_ppzksnark_proving_key_hip<Curve> fresh(slot);
+            auto s3 = prover::process(fresh, primary, auxiliary, A::scalar_from_limbs(r), A::scalar_from_limbs(s));
+            if (s2.g_A == s1.g_A || !(s2.g_A == s3.g_A) || !(s2.g_C == s3.g_C)) return -113;
+            prover::forget(slot);
         }
         const auto h_plain = r1cs_to_qap_hip<Curve>::witness_map(pk.constraint_system, primary, auxiliary);
         device_r1cs<Curve> dcs(ctx, pk.constraint_system);

@@ -361,3 +361,21 @@ def test_block_cache_behind_malloc_free(ctx):
     ctx.free(g)
     ctx.set_option("alloc_cache_mb", 16384)
     ctx.free(0)                                              # a null pointer is accepted
+    # a block is settled with the context that ALLOCATED it, whichever context it is freed through -- no stale entry that the
+    # owner's zkhip_destroy would free a second time; a block its caller still holds survives the owner's destruction
+    import sys
+    zk = sys.modules["crypto3_zk_amd"]
+    other = zk.Context(0)
+    p1, p2 = other.malloc(5 << 20), other.malloc(6 << 20)
+    ctx.free(p1)                                             # through ANOTHER context: lands in `other`'s cache
+    assert other.malloc(5 << 20) == p1                       # ... from where `other` hands it out again
+    ctx.free(p1)
+    with pytest.raises(Exception):
+        ctx.free(p1)                                         # a double free is refused instead of corrupting the cache
+    other.close()                                            # p2 is still held: the context's end must not free it
+    data = np.arange(1 << 10, dtype=np.uint64)
+    ctx.h2d(p2, data)
+    back = np.zeros_like(data)
+    ctx.d2h(back, p2)
+    assert (back == data).all()
+    ctx.free(p2)                                             # ownerless now: handed to the driver
