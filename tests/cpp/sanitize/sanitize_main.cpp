@@ -16,6 +16,7 @@
 #include <nil/crypto3/zk/hip/column_polynomial.hpp>
 #include <nil/crypto3/zk/hip/lpc.hpp>
 #include <nil/crypto3/zk/hip/marshalling.hpp>
+#include <nil/crypto3/zk/hip/placeholder_arguments.hpp>
 #include <nil/crypto3/zk/hip/placeholder_lookup.hpp>
 #include <nil/crypto3/zk/hip/placeholder_quotient.hpp>
 #include <nil/crypto3/zk/hip/r1cs_gg_ppzksnark_generator.hpp>
@@ -314,6 +315,117 @@ void placeholder_host_paths() {
     evaluation_domain_hip<Curve> dom(ZKHIP_DOMAIN_BASIC_RADIX2, n, Fr(2));
     std::vector<std::vector<Fr>> columns(3, std::vector<Fr>(n, Fr(4)));
     EXPECT(column_range_polynomials<Curve>(ctx, columns, dom).size() == 3);
+    /* round 5: extension caches (shared by copies, dropped by in-place changes), the factors-from-columns path, coefficient-form quotient parts */
+    for (auto *v : {&sid, &ssig})
+        for (auto &p : *v) p.enable_extension_cache();
+    for (dfs *p : {&q_last, &q_blind, &l0}) p->enable_extension_cache();
+    dfs copy_of_l0 = l0;
+    const dfs e1 = l0.extension(4 * n, root), e2 = copy_of_l0.extension(4 * n, root);
+    EXPECT(e1.data() == e2.data() && e1.size() == 4 * n);    // the copy hit the cache the original filled
+    copy_of_l0 += q_last;                                     // an in-place change drops the (shared) cache's entries
+    EXPECT(l0.extension(4 * n, root).data() != e1.data());
+    auto cached = PA::prove_eval(ctx, cols, sid, ssig, q_last, q_blind, l0, Fr(3), Fr(5), root, 3, {Fr(7), Fr(8)}, usable);
+    auto cached2 = PA::prove_eval(ctx, cols, sid, ssig, q_last, q_blind, l0, Fr(3), Fr(5), root, 3, {Fr(7), Fr(8)}, usable);
+    EXPECT(cached.parts_dfs.size() == 2 && cached2.F_dfs[1].size() == cached.F_dfs[1].size());
+    auto cparts = Q::quotient_polynomial_split_coefficients(ctx, T, n, T.size / n + 1, n);
+    EXPECT(cparts.size() == T.size / n + 1 && cparts[0].size() == n);
+}
+
+/// the reference-shaped entry points of placeholder_arguments.hpp over the stub: the duck-typed reads, the hooks' lifetimes, the lookup prover class
+namespace ref_like_ph {
+    struct variable {
+        std::size_t index;
+        bool operator<(const variable &o) const { return index < o.index; }
+    };
+    struct table_description {
+        std::size_t usable_rows_amount;
+        std::size_t global_index(const variable &v) const { return v.index; }
+    };
+    struct lookup_table {
+        std::size_t tag_index, columns_number;
+        std::vector<std::vector<variable>> lookup_options;
+    };
+    struct constraint_system {
+        std::vector<variable> _permuted;
+        std::vector<lookup_table> _tables;
+        const std::vector<variable> &permuted_columns() const { return _permuted; }
+        const std::vector<lookup_table> &lookup_tables() const { return _tables; }
+        std::vector<std::size_t> lookup_parts(std::size_t) const { return {2, 1}; }
+    };
+    template <typename Poly>
+    struct preprocessed_data {
+        std::vector<Poly> permutation_polynomials, identity_polynomials;
+        Poly q_last, q_blind;
+        struct {
+            Poly lagrange_0;
+            std::size_t max_quotient_chunks, permutation_parts;
+            table_description desc;
+        } common_data;
+    };
+    template <typename Poly>
+    struct polynomial_table {
+        std::vector<Poly> cols;
+        const Poly &operator[](std::size_t i) const { return cols[i]; }
+        const Poly &selector(std::size_t i) const { return cols[i]; }
+        const Poly &constant(std::size_t i) const { return cols[i]; }
+    };
+    template <typename Fr>
+    struct counting_transcript {
+        std::size_t challenges = 0, absorbed = 0;
+        Fr challenge() { return Fr((std::uint64_t)(100 + challenges++)); }
+        template <typename T>
+        void operator()(const T &) {
+            ++absorbed;
+        }
+    };
+    template <typename Curve>
+    struct counting_scheme {
+        typedef std::vector<int> commitment_type;
+        std::map<std::size_t, std::size_t> appended;
+        void append_to_batch(std::size_t batch, const device_polynomial_dfs<Curve> &) { ++appended[batch]; }
+        commitment_type commit(std::size_t batch) { return commitment_type(appended[batch], 1); }
+    };
+}    // namespace ref_like_ph
+template <typename Curve>
+void placeholder_reference_entry_points() {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::scalar_value_type Fr;
+    typedef polynomial_dfs<Curve> poly;
+    context ctx(0);
+    set_default_context(&ctx);
+    const std::size_t n = 32, usable = 28;
+    auto make = [&](std::size_t size, std::uint64_t seed) {
+        poly h;
+        for (std::size_t i = 0; i < size; ++i) h.values.push_back(Fr(i * 5 + seed));
+        return h;
+    };
+    ref_like_ph::preprocessed_data<poly> pd;
+    ref_like_ph::polynomial_table<poly> table;
+    ref_like_ph::constraint_system cs;
+    for (std::size_t i = 0; i < 3; ++i) {
+        table.cols.push_back(make(n, i));
+        pd.identity_polynomials.push_back(make(n, 10 + i));
+        pd.permutation_polynomials.push_back(make(n, 20 + i));
+        cs._permuted.push_back({i});
+    }
+    pd.q_last = make(n, 31), pd.q_blind = make(n, 32), pd.common_data.lagrange_0 = make(n, 33);
+    pd.common_data.max_quotient_chunks = 3;    // 3 factors in groups of 2: 2 parts
+    pd.common_data.permutation_parts = 2;
+    pd.common_data.desc.usable_rows_amount = usable;
+    cs._tables.push_back({0, 2, {{{1}, {2}}}});    // one table, one option, two constant columns
+    ref_like_ph::counting_transcript<Fr> transcript;
+    ref_like_ph::counting_scheme<Curve> scheme;
+    auto root = [](std::size_t l) { return Fr((std::uint64_t)(l + 2)); };
+    auto perm = placeholder_permutation_argument_hip<Curve>::prove_eval(cs, pd, pd.common_data.desc, table, scheme, transcript, root);
+    EXPECT(transcript.challenges == 3 && scheme.appended[PERMUTATION_BATCH] == 2 && perm.parts_dfs.size() == 1);
+    std::vector<poly> inputs = {make(n, 50), make(2 * n, 51)};
+    auto prover = make_placeholder_lookup_argument_prover<Curve>(cs, pd, table, scheme, transcript, [&](const Fr &) { return inputs; }, root);
+    EXPECT(transcript.challenges == 4);
+    auto look = prover.prove_eval();
+    /* theta | beta, gamma, one part alpha | two F_3 alphas; three sorted vectors committed; V_L and one intermediate polynomial appended */
+    EXPECT(transcript.challenges == 4 + 3 + 2 && transcript.absorbed == 1 && look.lookup_commitment.size() == 3 && scheme.appended[PERMUTATION_BATCH] == 4);
+    EXPECT(prover.sorted_dfs.size() == 3 && prover.parts_dfs.size() == 1 && prover.V_L_dfs.size() == 1);
+    set_default_context(nullptr);
 }
 
 template <typename Curve>
@@ -449,6 +561,8 @@ int main(int argc, char **argv) {
         scheme_host_paths<converting_curve>();
         placeholder_host_paths<bls12_381>();
         placeholder_host_paths<converting_curve>();
+        placeholder_reference_entry_points<bls12_381>();
+        placeholder_reference_entry_points<converting_curve>();
         bulk_transfers<converting_curve>();
         bulk_transfers<bls12_381>();
     }
