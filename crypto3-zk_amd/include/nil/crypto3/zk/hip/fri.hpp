@@ -179,11 +179,16 @@ public:
     std::size_t size() const { return size_; }
     void *data() const { return d_.get(); }
     const context &ctx() const { return *ctx_; }
+    /// the producer KNOWS every coefficient is zero (a quotient part beyond the quotient's length: the reference commits those too,
+    /// prover.hpp:251-257, and gets the point at infinity): a commitment scheme may skip the multiexp and put down the neutral element
+    bool known_zero() const { return zero_; }
+    void set_known_zero(bool z) { zero_ = z; }
 
 private:
     const context *ctx_;
     std::size_t size_;
     std::shared_ptr<void> d_;
+    bool zero_ = false;
 };
 
 /// math::polynomial_product(multipliers) (ph/permutation_argument.hpp:148, gates_argument.hpp:117): the product of k

@@ -244,6 +244,10 @@ public:
         const auto &resident = _resident[index];    // position -> a polynomial that is already on the device (polys[position] == nullptr)
         const auto &resident_c = _resident_coefficients[index];    // ... and already in coefficient form
         auto is_coefficients = [&resident_c](std::size_t i) { return resident_c.count(i) != 0; };
+        auto is_zero = [&resident_c](std::size_t i) {    // known to be the zero polynomial: its commitment is the neutral element, no multiexp
+            auto it = resident_c.find(i);
+            return it != resident_c.end() && it->second.known_zero();
+        };
         device_batch db;
         std::size_t total = 0;
         for (std::size_t i = 0; i < polys.size(); ++i) {
@@ -271,7 +275,9 @@ public:
             std::size_t j = i;
             /* the first chunk is a short one: nothing runs on the device until it has arrived */
             const std::size_t limit = (pipelined && i == 0) ? std::max<std::size_t>(1, upload_chunk / 4) : upload_chunk;
-            while (j < count && db.len[j] == db.len[i] && is_coefficients(j) == is_coefficients(i) && (!pipelined || limit == 0 || j - i < limit)) ++j;
+            while (j < count && db.len[j] == db.len[i] && is_coefficients(j) == is_coefficients(i) && is_zero(j) == is_zero(i) &&
+                   (!pipelined || limit == 0 || j - i < limit))
+                ++j;
             for (std::size_t p = i; p < j; ++p) {
                 if (polys[p]) upload_scalars<adapter>(up, db.at(p), detail::poly_data<adapter>(*polys[p]), polys[p]->size());
                 else
@@ -286,14 +292,14 @@ public:
                 adapter::scalar_to_limbs(_root_of_unity(log_n), w);
                 check(zkhip_ntt_dev(ctx.get(), adapter::id, db.at(i), log_n, j - i, w, 1, nullptr), "zkhip_ntt_dev", ctx.get());
             }
-            commit_resident(db, i, j, d_res.get());
+            if (!is_zero(i)) commit_resident(db, i, j, d_res.get());    // the coefficients of a known-zero polynomial still go into db (proof_eval reads them)
             i = j;
         }
         commitment_type out;
         if (count) {
             std::vector<std::uint64_t> res(count * jl);
             ctx.d2h(res.data(), d_res.get(), res.size() * 8);
-            for (std::size_t i = 0; i < count; ++i) out.push_back(adapter::g1_from_jacobian(&res[i * jl]));
+            for (std::size_t i = 0; i < count; ++i) out.push_back(is_zero(i) ? single_commitment_type::zero() : adapter::g1_from_jacobian(&res[i * jl]));
         }
         _ind_commitments[index] = out;
         _dev[index] = std::move(db);

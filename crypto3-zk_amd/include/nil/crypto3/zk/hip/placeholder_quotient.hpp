@@ -229,6 +229,7 @@ struct placeholder_quotient_hip {
             const std::size_t lo = k * rows_amount, len = lo < T.size ? std::min(rows_amount, T.size - lo) : 0;
             const void *src = len ? T.at(lo) : nullptr;
             check(zkhip_poly_lincomb_dev(ctx.get(), adapter::id, len ? 1 : 0, &src, &len, one, 1, p.data(), dfs_size, 0), "zkhip_poly_lincomb_dev", ctx.get());
+            p.set_known_zero(len == 0);    // a part beyond the quotient's length
             out.push_back(std::move(p));
         }
         return out;
