@@ -1116,7 +1116,8 @@ def quotient_leg(np, log_n=20, steps=6, verify=True):
 def permutation_leg(np, log_n=20, k=4, steps=6, verify=True):
     """placeholder's permutation argument, prover side, at BASELINE config 5's row count (hip/placeholder_permutation.hpp mirrors
     permutation_argument.hpp:70-224): k permuted columns resident; the grand product V_P (one inversion per ROW in a serial loop in the
-    reference; chunks sharing an inversion + a three-level prefix-product scan here) and the three constraint polynomials."""
+    reference; prefix / suffix product scans and ONE inversion per call here) and the three constraint polynomials; the preprocessed
+    polynomials (S_id, S_sigma, the selectors) keep their extensions across proofs (device_polynomial_dfs::enable_extension_cache)."""
     import ctypes
 
     lib = _bench_lib()
@@ -1137,7 +1138,8 @@ def permutation_leg(np, log_n=20, k=4, steps=6, verify=True):
             "ms_grand_product": round(gp, 3), "ms_per_run": [round(float(x), 2) for x in ms[:, 1]],
             "verified": None if not verify else bool(verified.value == 1),
             "verification": "V_P[0] = 1 and the recurrence at 64 sampled rows; F_1(y) against its definition at a random y",
-            "roofline": {"bound": "hbm", "kernel": "perm_grand_product (3 launches: chunk ratios + workgroup scan, top scan, apply)", "achieved": round(ach, 2),
+            "roofline": {"bound": "hbm", "kernel": "perm_grand_product (gp_rows: coalesced row products; gp_local / gp_top: prefix + suffix product scans and the call's ONE "
+                                                   "inversion; gp_apply)", "achieved": round(ach, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None, "algorithmic_bytes": alg_gp,
                          "per": "the grand product alone: 3 k input vectors read, 2 k + 1 written, 32 B per element"}}
 
@@ -1174,7 +1176,7 @@ def lookup_leg(np, log_n=20, k_in=2, k_val=1, steps=6, verify=True):
             "verification": "the device's sorted vectors == the host's construction of them, entry by entry, no status flag; V_L[0] = 1, V_L[usable_rows] = 1 "
                             "(the product over all rows closes: the reference's own check, lookup_argument.hpp:217), zeros behind, "
                             "the recurrence at 64 sampled rows; F_2(y) against its definition at a random y",
-            "roofline": {"bound": "hbm", "kernel": "perm_grand_product (3 launches: chunk ratios + workgroup scan, top scan, apply)", "achieved": round(ach, 2),
+            "roofline": {"bound": "hbm", "kernel": "perm_grand_product (gp_rows, gp_local, gp_top, gp_apply: one inversion per call)", "achieved": round(ach, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None, "algorithmic_bytes": alg_gp,
                          "per": "V_L alone: 2 (k_in + k_val) input vectors read, 1 written, 32 B per element"}}
 
