@@ -552,7 +552,11 @@ def dry_run(args):
     total = zd.allgather_fold(part, world, lambda o, i: dist.all_gather_into_tensor(o, i), lambda g, w: g.view(w, 18).sum(0))
     ok = bool((total == sum(range(1, world + 1))).all())
     windows = [zd.shard_windows(16, r, world) for r in range(world)]
+    parts = [{"rank": rank, "uuid": "dry-run-device-%d" % rank}]
     if world > 1:
+        # the `dist` field of the real line (one device uuid per rank, all-gathered), with stand-in uuids
+        parts = [None] * world
+        dist.all_gather_object(parts, {"rank": rank, "uuid": "dry-run-device-%d" % rank})
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -561,6 +565,8 @@ def dry_run(args):
                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": 0.0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
                  "data": "synthetic", "config": {"workload": "dry run: launch + exchange plumbing only", "points_per_gpu": 1 << args.log_n, "parallelism": args.split},
                  "verified": None, "roofline": {"bound": "hbm", "kernel": "msm_bucket_acc", "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None}}
+        frame["dist"] = {"backend": "gloo", "world_size": world, "devices": [p_["uuid"] for p_ in parts], "distinct_devices": len({p_["uuid"] for p_ in parts}),
+                         "same_device_flag": False}
         line = compact_line(frame, None)
         line.update({"dry_run": True, "split": args.split, "exchange_ok": ok, "windows_per_rank": windows,
                      "point_ranges": [zd.shard_range(world << args.log_n, r, world) for r in range(world)]})

@@ -21,6 +21,8 @@ def test_bench_gpus_flag_launches_ranks(gpus, split):
     line = json.loads(lines[0])
     assert line["n_gpus"] == gpus and line["exchange_ok"] and line["split"] == split
     assert sorted(sum(line["windows_per_rank"], [])) == list(range(16))
+    d = line["dist"]    # one device id per rank, gathered over the process group: what shows that a SCALE run saw N distinct GPUs
+    assert d["world_size"] == gpus and len(d["devices"]) == gpus and d["distinct_devices"] == gpus
 
 
 def test_bench_under_external_launcher():
