@@ -484,14 +484,43 @@ static Jac<F> msm_naive(const Affine<F> *bases, const uint64_t *scalars, size_t 
 // fixed-base multiples of a point with an 8-bit window table (batch_exp in generator.hpp:187-214)
 template <class F>
 static void batch_mul(const Affine<F> &base, const uint64_t *scalars, size_t n, Affine<F> *out) {
-    const int W = 8, NW = 32;
-    std::vector<Jac<F>> table((size_t)NW << W);
-    Jac<F> b = Jac<F>::from_affine(base);
-    for (int w = 0; w < NW; ++w) {
-        Jac<F> *row = &table[(size_t)w << W];
-        row[0] = Jac<F>::infinity();
-        for (int i = 1; i < (1 << W); ++i) row[i] = row[i - 1].add(b);
-        for (int i = 0; i < W; ++i) b = b.dbl();
+    // fixed-base windows of W bits with an AFFINE table (mixed additions: 7M + 4S instead of 11M + 5S); for many scalars 12-bit windows
+    // (22 additions per point instead of 32; the table -- 22 x 4096 points -- is built once, in parallel over the windows).  Round 5: the
+    // 2^20-constraint key the CPU baseline needs took 18-21 s with 8-bit windows over a Jacobian table, half of bench.py's default run.
+    const int W = n >= 4096 ? 12 : 8, NW = (256 + W - 1) / W;
+    std::vector<Affine<F>> table((size_t)NW << W);
+    {
+        std::vector<Jac<F>> start(NW);
+        Jac<F> b = Jac<F>::from_affine(base);
+        for (int w = 0; w < NW; ++w) {
+            start[w] = b;
+            for (int i = 0; i < W; ++i) b = b.dbl();
+        }
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int w = 0; w < NW; ++w) {
+            const size_t cnt = (size_t)1 << W;
+            std::vector<Jac<F>> row(cnt);
+            row[0] = Jac<F>::infinity();
+            for (size_t i = 1; i < cnt; ++i) row[i] = row[i - 1].add(start[w]);
+            // to affine with one inversion per row (Montgomery's trick)
+            std::vector<F> pre(cnt);
+            F run = F::one();
+            for (size_t i = 0; i < cnt; ++i) {
+                pre[i] = run;
+                if (!row[i].is_inf()) run = run * row[i].Z;
+            }
+            F inv = run.inv();
+            Affine<F> *dst = &table[(size_t)w << W];
+            for (size_t i = cnt; i-- > 0;) {
+                if (row[i].is_inf()) {
+                    dst[i] = {F::zero(), F::zero(), true};
+                    continue;
+                }
+                F zi = inv * pre[i], zi2 = zi.sqr();
+                inv = inv * row[i].Z;
+                dst[i] = {row[i].X * zi2, row[i].Y * zi2 * zi, false};
+            }
+        }
     }
     // chunks of 256 results share ONE inversion (Montgomery's trick; batch_to_special in generator.hpp:190-192 does the same):
     // a 2^20-constraint key (5.2 M G1 + 1 M G2 points) takes tens of seconds instead of minutes, which is what lets bench.py time
@@ -507,7 +536,7 @@ static void batch_mul(const Affine<F> &base, const uint64_t *scalars, size_t n, 
             Jac<F> a = Jac<F>::infinity();
             for (int w = 0; w < NW; ++w) {
                 unsigned d = get_bits(scalars + 4 * i, 4, w * W, W);
-                if (d) a = a.add(table[((size_t)w << W) + d]);
+                if (d) a = a.madd(table[((size_t)w << W) + d]);
             }
             acc[i - lo] = a;
             pre[i - lo] = run;  // product of the non-zero Z before this one
