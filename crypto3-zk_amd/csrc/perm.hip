@@ -25,6 +25,14 @@ using namespace zkhip;
 namespace {
 
 constexpr uint32_t PERM_CHUNK = 8, PERM_THREADS = 256;
+// Where row `row`'s nominator / denominator live in the scratch vectors: inside each block of PERM_THREADS * PERM_CHUNK rows (one workgroup
+// of the scan kernels) the r-th row of lane t sits at r * PERM_THREADS + t, so that the scan kernels -- lane = PERM_CHUNK consecutive rows --
+// read consecutive 32-byte elements across a wave, while gp_rows (one row per lane) still writes runs of 8 elements (256 B).
+ZK_D size_t perm_slot(size_t row) {
+    constexpr size_t BLK = (size_t)PERM_THREADS * PERM_CHUNK;
+    const size_t in = row % BLK;
+    return row - in + (in % PERM_CHUNK) * PERM_THREADS + in / PERM_CHUNK;
+}
 enum : uint32_t { C_BETA_M = 0, C_GAMMA = 1, C_ACC_NOM = 2, C_ACC_DEN = 3, C_PART1 = 4, C_SLOTS = 8 };  // the constants' slots (32 B each)
 
 template <class U>
@@ -165,8 +173,8 @@ __global__ __launch_bounds__(PERM_THREADS) void gp_rows(Rows rows_of, size_t row
         atomicMin(first_zero, (uint32_t)row);
         dn = Fu<U>::one();
     }
-    p_store_raw<U>(nom, row, nm);
-    p_store_raw<U>(den, row, dn);
+    p_store_raw<U>(nom, perm_slot(row), nm);
+    p_store_raw<U>(den, perm_slot(row), dn);
 }
 
 // pass 1: every lane takes PERM_CHUNK consecutive rows (rows >= `rows` count as 1 / 1): the products of their nominators and denominators,
@@ -182,8 +190,8 @@ __global__ __launch_bounds__(PERM_THREADS) void gp_local(size_t rows, const uint
     if (lo < rows) {
         const uint32_t cnt = (uint32_t)(rows - lo < PERM_CHUNK ? rows - lo : PERM_CHUNK);
         for (uint32_t r = 0; r < cnt; ++r) {
-            ln = mmul(ln, p_load_raw<U>(nom, lo + r));
-            ld = mmul(ld, p_load_raw<U>(den, lo + r));
+            ln = mmul(ln, p_load_raw<U>(nom, perm_slot(lo + r)));
+            ld = mmul(ld, p_load_raw<U>(den, perm_slot(lo + r)));
         }
     }
     Fu<U> x = ln, y = ld;
@@ -255,14 +263,14 @@ __global__ __launch_bounds__(PERM_THREADS) void gp_apply(const uint32_t *__restr
     Fu<U> suf[PERM_CHUNK];
     Fu<U> s = mmul(mmul(p_load_raw<U>(blk_suf, blockIdx.x), p_load_raw<U>(lane_suf, lane)), p_load_raw<U>(consts, C_SLOTS - 1));
     for (uint32_t r = cnt; r-- > 0;) {
-        if (lo + r < rows) s = mmul(s, p_load_raw<U>(den, lo + r));
+        if (lo + r < rows) s = mmul(s, p_load_raw<U>(den, perm_slot(lo + r)));
         suf[r] = s;
     }
     Fu<U> run = mmul(p_load_raw<U>(blk_pre, blockIdx.x), p_load_raw<U>(lane_pre, lane));
     for (uint32_t r = 0; r < cnt; ++r) {
         if (lo + r <= last) {
             p_store_raw<U>(vp, lo + r, from_mont(mmul(run, suf[r])));
-            if (lo + r < rows) run = mmul(run, p_load_raw<U>(nom, lo + r));
+            if (lo + r < rows) run = mmul(run, p_load_raw<U>(nom, perm_slot(lo + r)));
         } else {
             p_store_raw<U>(vp, lo + r, Fu<U>::zero());
         }
@@ -298,13 +306,14 @@ int scan_run(zkhip_ctx *ctx, size_t count, MakeRows make_rows, size_t n, size_t 
     const size_t lanes = (n + PERM_CHUNK - 1) / PERM_CHUNK, nblk = (lanes + PERM_THREADS - 1) / PERM_THREADS;
     if (nblk > (size_t)PERM_THREADS * 4096) return ZKHIP_ERR_RANGE;
     const uint32_t per = (uint32_t)((nblk + PERM_THREADS - 1) / PERM_THREADS);
-    size_t need = zkhip_ctx::ws_round(count * sizeof(void *)) + zkhip_ctx::ws_round((C_SLOTS + 2) * 32 + 64) + 2 * zkhip_ctx::ws_round(n * 32) +
+    const size_t n_slots = nblk * PERM_THREADS * PERM_CHUNK;  // perm_slot stays inside the row's block: whole blocks of scratch
+    size_t need = zkhip_ctx::ws_round(count * sizeof(void *)) + zkhip_ctx::ws_round((C_SLOTS + 2) * 32 + 64) + 2 * zkhip_ctx::ws_round(n_slots * 32) +
                   2 * zkhip_ctx::ws_round(nblk * PERM_THREADS * 32) + 2 * zkhip_ctx::ws_round(nblk * 32);
     ZK_TRY(ctx->ws_reserve(need));
     ctx->ws_reset();
     const uint32_t **d_ptrs = ctx->ws_take<const uint32_t *>(count);
     uint32_t *d_consts = ctx->ws_take<uint32_t>((C_SLOTS + 2) * 8 + 16);  // C_SLOTS constants | beta, gamma as uploaded | the first-zero-row cell
-    uint32_t *d_nom = ctx->ws_take<uint32_t>(n * 8), *d_den = ctx->ws_take<uint32_t>(n * 8);
+    uint32_t *d_nom = ctx->ws_take<uint32_t>(n_slots * 8), *d_den = ctx->ws_take<uint32_t>(n_slots * 8);
     uint32_t *d_lpre = ctx->ws_take<uint32_t>(nblk * PERM_THREADS * 8), *d_lsuf = ctx->ws_take<uint32_t>(nblk * PERM_THREADS * 8);
     uint32_t *d_bn = ctx->ws_take<uint32_t>(nblk * 8), *d_bd = ctx->ws_take<uint32_t>(nblk * 8);
     uint32_t *d_in = d_consts + C_SLOTS * 8, *d_z = d_consts + (C_SLOTS + 2) * 8;
