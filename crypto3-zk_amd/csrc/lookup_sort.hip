@@ -266,6 +266,7 @@ extern "C" int zkhip_lookup_sort_dev(zkhip_ctx *ctx, size_t k_in, const void *co
     if (k_in >= 4096 || k_val >= 4096 || n >= ((size_t)1 << 31)) return ZKHIP_ERR_RANGE;
     if (n && usable_rows >= n) return ZKHIP_ERR_RANGE;
     if (kk * usable_rows >= ((size_t)1 << 31) || kk * n >= ((size_t)1 << 38)) return ZKHIP_ERR_RANGE;  // positions and emission indices are u32
+    if (k_val * usable_rows >= ((size_t)1 << 30)) return ZKHIP_ERR_RANGE;                                // the hash table (2 slots per table entry, a power of two) is indexed by u32
     for (size_t i = 0; n && i < k_in; ++i)
         if (!d_input[i]) return ZKHIP_ERR_INVALID;
     for (size_t i = 0; n && i < k_val; ++i)
