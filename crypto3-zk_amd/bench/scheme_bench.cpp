@@ -372,6 +372,8 @@ int zkhip_bench_quotient(int device, size_t log_n, int steps, double *ms, int *v
         for (size_t i = 0; i < n; ++i) h[3].values[i] = h[1].values[i] * h[2].values[i];
         std::vector<dfs> col;
         for (size_t c = 0; c < 6; ++c) col.emplace_back(ctx, h[c], c == 5 ? 0 : n - 1);
+        col[4].enable_extension_cache();    // the selector and the mask are preprocessed: their extensions are kept across proofs
+        col[5].enable_extension_cache();
         std::vector<polynomial_dfs<C>>().swap(h);
         std::vector<Fr> pw(n);
         Fr x = Fr::one(), alpha(7);
@@ -716,6 +718,8 @@ int zkhip_bench_placeholder_round(int device, size_t log_n, size_t witness_cols,
         for (auto *v : {&sid, &ssig})
             for (auto &p : *v) p.enable_extension_cache();
         for (dfs *p : {&q, &q_last, &q_blind, &lagrange_0}) p->enable_extension_cache();
+        dfs mask = placeholder_lookup_hip<C>::affine(q_last, &q_blind, Fr::zero() - Fr::one(), Fr::zero() - Fr::one(), Fr::one());    // 1 - q_last - q_blind: preprocessed too
+        mask.enable_extension_cache();
         std::vector<Fr> pw(n);
         Fr x = Fr::one(), alpha(7);
         for (size_t i = 0; i < n; ++i) pw[i] = x, x = x * alpha;
@@ -777,7 +781,6 @@ int zkhip_bench_placeholder_round(int device, size_t log_n, size_t witness_cols,
             auto perm_commit = scheme.commit(PERMUTATION_BATCH);
             t[2] = ms_since(t0);
             t0 = std::chrono::steady_clock::now();
-            dfs mask = LA::affine(q_last, &q_blind, Fr::zero() - Fr::one(), Fr::zero() - Fr::one(), Fr::one());
             gate_product_hip<C> g1, g2;
             g1.factors = {&q, &w0, &w1};
             g1.rotations = {0, 0, 0};

@@ -16,6 +16,7 @@
 #define ZKHIP_SHIM_PLACEHOLDER_QUOTIENT_HPP
 
 #include <algorithm>
+#include <map>
 #include <stdexcept>
 #include <vector>
 
@@ -92,22 +93,44 @@ struct placeholder_quotient_hip {
                 if (hi > lo && unique.size() + added.size() + (first ? 1 : 0) > max_slots) break;
                 unique.insert(unique.end(), added.begin(), added.end());
             }
-            const std::size_t U = unique.size(), slots = U + (first ? 1 : 0);
-            auto d_in = ctx.alloc(slots * n * 32);
-            auto d_ext = ctx.alloc(slots * extended_size * 32);
-            for (std::size_t u = 0; u < U; ++u) {
-                const dfs_type &f = *unique[u].first;
+            const std::size_t U = unique.size();
+            /* Round 5: a factor (or the mask) whose holder switched its extension cache on -- a selector, a preprocessed column, a witness column
+               other arguments extend as well -- is taken from device_polynomial_dfs::extension() (computed once, rotated on the extended domain when
+               the gate asks for a rotation); the others are laid side by side and extended by ONE batched call as before */
+            std::vector<const void *> ext_of(U + 1, nullptr);    // where unique factor u (and, at U, the mask) lives on the extended domain
+            std::vector<dfs_type> keep;                          // cached / rotated extensions stay alive until the group is done
+            std::vector<std::size_t> batched;                    // the factors (U = the mask) that go through the batched extension, in slot order
+            const bool mask_here = first;
+            for (std::size_t u = 0; u <= U; ++u) {
+                if (u == U && !mask_here) break;
+                const dfs_type &f = u < U ? *unique[u].first : mask_polynomial;
                 if (f.size() != n) throw std::invalid_argument("gate_argument: every factor lives on the original domain (the mask's size)");
-                char *slot = static_cast<char *>(d_in.get()) + u * n * 32;
-                if (unique[u].second)
-                    check(zkhip_poly_shift_dev(ctx.get(), f.data(), log_n, (std::int64_t)unique[u].second, slot), "zkhip_poly_shift_dev", ctx.get());
-                else check(zkhip_memcpy_d2d_async(ctx.get(), slot, f.data(), n * 32), "zkhip_memcpy_d2d_async", ctx.get());
+                if (extended_size > n && f.extension_cache_enabled()) {
+                    dfs_type e = f.extension(extended_size, root);
+                    const int rot = u < U ? unique[u].second : 0;
+                    if (rot) e = polynomial_shift(e, rot, n);
+                    ext_of[u] = e.data();
+                    keep.push_back(std::move(e));
+                } else {
+                    batched.push_back(u);
+                }
             }
-            if (first)
-                check(zkhip_memcpy_d2d_async(ctx.get(), static_cast<char *>(d_in.get()) + U * n * 32, mask_polynomial.data(), n * 32), "zkhip_memcpy_d2d_async",
-                      ctx.get());
-            if (extended_size == n) check(zkhip_memcpy_d2d_async(ctx.get(), d_ext.get(), d_in.get(), slots * n * 32), "zkhip_memcpy_d2d_async", ctx.get());
-            else check(zkhip_poly_resize_dev(ctx.get(), adapter::id, d_in.get(), log_n, slots, wn, d_ext.get(), log_e, we), "zkhip_poly_resize_dev", ctx.get());
+            const std::size_t slots = batched.size();
+            auto d_in = ctx.alloc(std::max<std::size_t>(1, slots) * n * 32);
+            auto d_ext = ctx.alloc(std::max<std::size_t>(1, slots) * extended_size * 32);
+            for (std::size_t b = 0; b < slots; ++b) {
+                const std::size_t u = batched[b];
+                const dfs_type &f = u < U ? *unique[u].first : mask_polynomial;
+                const int rot = u < U ? unique[u].second : 0;
+                char *slot = static_cast<char *>(d_in.get()) + b * n * 32;
+                if (rot) check(zkhip_poly_shift_dev(ctx.get(), f.data(), log_n, (std::int64_t)rot, slot), "zkhip_poly_shift_dev", ctx.get());
+                else check(zkhip_memcpy_d2d_async(ctx.get(), slot, f.data(), n * 32), "zkhip_memcpy_d2d_async", ctx.get());
+                ext_of[u] = static_cast<const char *>(d_ext.get()) + b * extended_size * 32;
+            }
+            if (slots) {
+                if (extended_size == n) check(zkhip_memcpy_d2d_async(ctx.get(), d_ext.get(), d_in.get(), slots * n * 32), "zkhip_memcpy_d2d_async", ctx.get());
+                else check(zkhip_poly_resize_dev(ctx.get(), adapter::id, d_in.get(), log_n, slots, wn, d_ext.get(), log_e, we), "zkhip_poly_resize_dev", ctx.get());
+            }
             dfs_type term(ctx, extended_size);
             for (std::size_t gi = lo; gi < hi; ++gi) {
                 const auto &g = products[gi];
@@ -115,7 +138,7 @@ struct placeholder_quotient_hip {
                 std::vector<const void *> ptrs;
                 for (std::size_t k = 0; k < g.factors.size(); ++k) {
                     degree += g.factors[k]->degree();
-                    ptrs.push_back(static_cast<const char *>(d_ext.get()) + slot_of(g.factors[k], g.rotations[k]) * extended_size * 32);
+                    ptrs.push_back(ext_of[slot_of(g.factors[k], g.rotations[k])]);
                 }
                 if (degree >= extended_size) throw std::invalid_argument("gate_argument: the product's degree does not fit the extended domain");
                 check(zkhip_fr_vec_prod_dev(ctx.get(), adapter::id, ptrs.size(), ptrs.data(), term.data(), extended_size), "zkhip_fr_vec_prod_dev", ctx.get());
@@ -128,10 +151,9 @@ struct placeholder_quotient_hip {
                       ctx.get());
                 F.set_degree(very_first ? degree : std::max(F.degree(), degree));
             }
-            if (first) {    // keep the extended mask (the last slot) for the final product
+            if (first) {    // keep the extended mask for the final product
                 d_mask_ext = ctx.alloc(extended_size * 32);
-                check(zkhip_memcpy_d2d_async(ctx.get(), d_mask_ext.get(), static_cast<const char *>(d_ext.get()) + U * extended_size * 32, extended_size * 32),
-                      "zkhip_memcpy_d2d_async", ctx.get());
+                check(zkhip_memcpy_d2d_async(ctx.get(), d_mask_ext.get(), ext_of[U], extended_size * 32), "zkhip_memcpy_d2d_async", ctx.get());
             }
             first = false;
             lo = hi;
@@ -154,20 +176,44 @@ struct placeholder_quotient_hip {
         for (const auto &f : F_dfs) size = std::max(size, f.size());
         if (size < 2 * rows_amount) size = 2 * rows_amount;    // at least one quotient coefficient block
         /* The reference adds the parts in DFS form on the largest domain and inverts the sum (:262-273).  The coefficients of a sum are the sum
-           of the coefficients: every part is inverted on ITS OWN domain (an inverse transform of its size instead of an extension to the largest
-           one) and the weighted coefficient vectors are added in one pass -- the same field elements, about half the transform work */
+           of the coefficients, and a weighted sum of evaluation vectors over ONE domain is the evaluation vector of the weighted sum: the parts
+           that live on the same domain are added there first (one pass), every such sum is inverted on ITS OWN domain (round 4 inverted every
+           part: 34 n transform points for placeholder's eight parts on 2n / 4n / 8n; round 5: one inverse transform per domain size, 14 n), and
+           the coefficient vectors are added in one pass -- the same field elements as the reference's extension of everything to the largest
+           domain (74 n) */
+        std::map<std::size_t, std::vector<std::size_t>> by_size;
+        for (std::size_t i = 0; i < F_dfs.size(); ++i)
+            if (F_dfs[i].size() != 0) by_size[F_dfs[i].size()].push_back(i);
         std::vector<std::shared_ptr<void>> parts;
         std::vector<const void *> ptrs;
         std::vector<std::size_t> lens;
         std::vector<std::uint64_t> coeffs;
-        for (std::size_t i = 0; i < F_dfs.size(); ++i) {
-            if (F_dfs[i].size() == 0) continue;
-            parts.push_back(F_dfs[i].coefficients(root));
-            ptrs.push_back(parts.back().get());
-            lens.push_back(F_dfs[i].size());
-            std::uint64_t a[4];
-            adapter::scalar_to_limbs(alphas[i], a);
-            coeffs.insert(coeffs.end(), a, a + 4);
+        std::uint64_t one_limbs[4];
+        adapter::scalar_to_limbs(value_type::one(), one_limbs);
+        for (const auto &group : by_size) {
+            const std::size_t gsize = group.first;
+            std::vector<const void *> gp;
+            std::vector<std::size_t> gl;
+            std::vector<std::uint64_t> gc;
+            for (std::size_t i : group.second) {
+                gp.push_back(F_dfs[i].data());
+                gl.push_back(gsize);
+                std::uint64_t a[4];
+                adapter::scalar_to_limbs(alphas[i], a);
+                gc.insert(gc.end(), a, a + 4);
+            }
+            auto acc = ctx.alloc(gsize * 32);    // sum_i alpha_i F_i over this domain, then its coefficients in place
+            check(zkhip_poly_lincomb_dev(ctx.get(), adapter::id, gp.size(), gp.data(), gl.data(), gc.data(), 1, acc.get(), gsize, 0), "zkhip_poly_lincomb_dev", ctx.get());
+            std::size_t log_g = 0;
+            while (((std::size_t)1 << log_g) < gsize) ++log_g;
+            if (((std::size_t)1 << log_g) != gsize) throw std::invalid_argument("quotient_polynomial: a part's size is not a power of two");
+            std::uint64_t w[4];
+            adapter::scalar_to_limbs(root(log_g), w);
+            check(zkhip_ntt_dev(ctx.get(), adapter::id, acc.get(), log_g, 1, w, 1, nullptr), "zkhip_ntt_dev", ctx.get());
+            parts.push_back(acc);
+            ptrs.push_back(acc.get());
+            lens.push_back(gsize);
+            coeffs.insert(coeffs.end(), one_limbs, one_limbs + 4);
         }
         dfs_type F(ctx, size);    // holds COEFFICIENTS from here on
         check(zkhip_poly_lincomb_dev(ctx.get(), adapter::id, ptrs.size(), ptrs.data(), lens.data(), coeffs.data(), 1, F.data(), size, 0), "zkhip_poly_lincomb_dev",

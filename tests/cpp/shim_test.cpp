@@ -1614,6 +1614,24 @@ int placeholder_round_t(const uint64_t *srs, size_t n_srs, const uint64_t *evals
         ctx.d2h(a.data(), G.data(), 4 * n * 32);
         ctx.d2h(b.data(), G1.data(), 4 * n * 32);
         if (a != b || G.degree() != G1.degree()) return -73;
+        /* round 5: the selector (with a rotation in a second gate) and the mask taken from their extension caches, twice: identical evaluations */
+        gate[0].enable_extension_cache();
+        mask.enable_extension_cache();
+        gate_product_hip<Curve> g3 = g2;
+        g3.rotations = {1, 0};
+        for (int rep = 0; rep < 2; ++rep) {
+            dfs Gc = Q::gate_argument(ctx, {g1, g2}, mask, 4 * n, root);
+            ctx.d2h(b.data(), Gc.data(), 4 * n * 32);
+            if (a != b || Gc.degree() != G.degree()) return -76;
+        }
+        dfs plain_mask = placeholder_lookup_hip<Curve>::affine(q_last, &q_blind, Fr::zero() - Fr::one(), Fr::zero() - Fr::one(), Fr::one());
+        dfs plain_q = dfs(ctx, gate[0].to_host(), n - 1);    // the same selector without a cache
+        gate_product_hip<Curve> g3p = g3;
+        g3p.factors = {&plain_q, &gate[3]};
+        dfs Gr = Q::gate_argument(ctx, {g1, g3}, mask, 4 * n, root), Grp = Q::gate_argument(ctx, {g1, g3p}, plain_mask, 4 * n, root);
+        ctx.d2h(a.data(), Gr.data(), 4 * n * 32);
+        ctx.d2h(b.data(), Grp.data(), 4 * n * 32);
+        if (a != b) return -77;    // a rotated factor from the cache == the same factor rotated before its extension
     }
     /* 7. quotient over all eight parts, split, T_commit */
     std::vector<dfs> F = {perm.F_dfs[0], perm.F_dfs[1], perm.F_dfs[2], look.F_dfs[0], look.F_dfs[1], look.F_dfs[2], look.F_dfs[3], G};
