@@ -177,6 +177,20 @@ __global__ __launch_bounds__(PERM_THREADS) void gp_rows(Rows rows_of, size_t row
     p_store_raw<U>(den, perm_slot(row), dn);
 }
 
+// the row functor's two products as CANONICAL vectors in natural order: prod_i g_i and prod_i h_i of the permutation argument on whatever domain
+// the caller's vectors live on (zkhip_perm_factor_products_dev: the argument's g and h polynomials on the extended domain in ONE pass over the
+// extended columns and permutation polynomials, instead of 2 k linear passes and two k-way products)
+template <class U, class Rows>
+__global__ __launch_bounds__(PERM_THREADS) void gp_products(Rows rows_of, size_t rows, const uint32_t *__restrict__ consts, uint32_t *__restrict__ out_n,
+                                                            uint32_t *__restrict__ out_d) {
+    const size_t row = (size_t)blockIdx.x * PERM_THREADS + threadIdx.x;
+    if (row >= rows) return;
+    Fu<U> nm, dn;
+    rows_of(row, consts, nm, dn);
+    p_store_raw<U>(out_n, row, from_mont(fu_cond_sub_p(nm)));
+    p_store_raw<U>(out_d, row, from_mont(fu_cond_sub_p(dn)));
+}
+
 // pass 1: every lane takes PERM_CHUNK consecutive rows (rows >= `rows` count as 1 / 1): the products of their nominators and denominators,
 // the lane's exclusive prefix (nominators) and exclusive suffix (denominators) inside its workgroup, the workgroup's totals
 template <class U>
@@ -348,6 +362,33 @@ int perm_run(zkhip_ctx *ctx, size_t k, const void *const *d_cols, const void *co
 }
 
 template <class U>
+int perm_products_run(zkhip_ctx *ctx, size_t k, const void *const *d_cols, const void *const *d_sid, const void *const *d_ssig, size_t n, const uint64_t *beta,
+                      const uint64_t *gamma, uint32_t *d_g, uint32_t *d_h) {
+    ZK_TRY(ctx->ws_reserve(zkhip_ctx::ws_round(3 * k * sizeof(void *)) + zkhip_ctx::ws_round((C_SLOTS + 2) * 32 + 64)));
+    ctx->ws_reset();
+    const uint32_t **d_ptrs = ctx->ws_take<const uint32_t *>(3 * k);
+    uint32_t *d_consts = ctx->ws_take<uint32_t>((C_SLOTS + 2) * 8 + 16);
+    uint32_t *d_in = d_consts + C_SLOTS * 8, *d_z = d_consts + (C_SLOTS + 2) * 8;
+    ctx->batch_ptrs.resize(3 * k);
+    for (size_t i = 0; i < k; ++i) {
+        ctx->batch_ptrs[i] = (uint32_t *)d_cols[i];
+        ctx->batch_ptrs[k + i] = (uint32_t *)d_sid[i];
+        ctx->batch_ptrs[2 * k + i] = (uint32_t *)d_ssig[i];
+    }
+    ctx->lagrange_stage.assign(16, 0u);
+    memcpy(ctx->lagrange_stage.data(), beta, 32);
+    memcpy(ctx->lagrange_stage.data() + 8, gamma, 32);
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_ptrs, ctx->batch_ptrs.data(), 3 * k * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_in, ctx->lagrange_stage.data(), 64, hipMemcpyHostToDevice, ctx->stream));
+    ZK_LAUNCH(ctx, "perm_factor_products", gp_setup<U>, dim3(1), dim3(64), 0, d_in, d_consts, (uint32_t)k, (uint32_t)k, 0u, d_z);
+    PermRows<U> rows_of{d_ptrs, d_ptrs + k, d_ptrs + 2 * k, (uint32_t)k, n, nullptr, nullptr};
+    ZK_LAUNCH(ctx, "perm_factor_products", (gp_products<U, PermRows<U>>), dim3((unsigned)((n + PERM_THREADS - 1) / PERM_THREADS)), dim3(PERM_THREADS), 0, rows_of, n,
+              d_consts, d_g, d_h);
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the staged pointers / constants may be reused after return
+    return ZKHIP_OK;
+}
+
+template <class U>
 int lookup_run(zkhip_ctx *ctx, size_t k_in, const void *const *d_in, size_t k_val, const void *const *d_val, size_t k_sorted, const void *const *d_sorted, size_t n,
                size_t usable_rows, const uint64_t *beta, const uint64_t *gamma, uint32_t *d_vl) {
     ctx->batch_ptrs.clear();
@@ -460,6 +501,21 @@ extern "C" int zkhip_perm_grand_product_dev(zkhip_ctx *ctx, int curve, size_t k,
     ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (curve == CURVE_BLS12_381) return perm_run<BlsFrU>(ctx, k, d_cols, d_sid, d_ssigma, n, beta, gamma, (uint32_t *)d_g, (uint32_t *)d_h, (uint32_t *)d_vp);
     return perm_run<BnFrU>(ctx, k, d_cols, d_sid, d_ssigma, n, beta, gamma, (uint32_t *)d_g, (uint32_t *)d_h, (uint32_t *)d_vp);
+}
+
+/* prod_i (column_i + beta S_id_i + gamma) and prod_i (column_i + beta S_sigma_i + gamma), pointwise over n entries of vectors on ANY domain: the g and
+ * h polynomials of the permutation argument (permutation_argument.hpp:140-160) on the extended domain, from the extended columns in one pass */
+extern "C" int zkhip_perm_factor_products_dev(zkhip_ctx *ctx, int curve, size_t k, const void *const *d_cols, const void *const *d_sid, const void *const *d_ssigma,
+                                              size_t n, const uint64_t *beta, const uint64_t *gamma, void *d_g, void *d_h) {
+    if (!ctx || k == 0 || !d_cols || !d_sid || !d_ssigma || !beta || !gamma || (n && (!d_g || !d_h))) return ZKHIP_ERR_INVALID;
+    if (curve != CURVE_BLS12_381 && curve != CURVE_BN254) return ZKHIP_ERR_INVALID;
+    if (k >= 4096 || n >= ((size_t)1 << 38)) return ZKHIP_ERR_RANGE;
+    for (size_t i = 0; i < k; ++i)
+        if (n && (!d_cols[i] || !d_sid[i] || !d_ssigma[i])) return ZKHIP_ERR_INVALID;
+    if (n == 0) return ZKHIP_OK;
+    ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (curve == CURVE_BLS12_381) return perm_products_run<BlsFrU>(ctx, k, d_cols, d_sid, d_ssigma, n, beta, gamma, (uint32_t *)d_g, (uint32_t *)d_h);
+    return perm_products_run<BnFrU>(ctx, k, d_cols, d_sid, d_ssigma, n, beta, gamma, (uint32_t *)d_g, (uint32_t *)d_h);
 }
 
 /* V_L of the lookup argument (lookup_argument.hpp:375-409): V_L[0] = 1, V_L[k] = V_L[k - 1] g(k - 1) / h(k - 1) for k <= usable_rows, zero behind */

@@ -112,21 +112,33 @@ struct placeholder_permutation_hip {
         for (std::size_t lo = 0; lo < k; lo += step) {
             std::vector<dfs_type> g_v, h_v;
             const std::size_t hi = std::min(k, lo + step), size = pow2_holding((hi - lo) * (n - 1));
-            for (std::size_t i = lo; i < hi; ++i) {
-                if (factors_from_columns) {
-                    const dfs_type col = extended(columns[i], size, root), sid = extended(S_id[i], size, root), ssig = extended(S_sigma[i], size, root);
-                    g_v.push_back(affine(col, sid, value_type::one(), beta, gamma));
-                    h_v.push_back(affine(col, ssig, value_type::one(), beta, gamma));
-                    g_v.back().set_degree(n - 1);
-                    h_v.back().set_degree(n - 1);
-                    continue;
+            if (factors_from_columns) {
+                /* the group's g and h on their domain in ONE pass over the extended columns and (cached) permutation polynomials */
+                std::vector<dfs_type> ext;    // alive until the pass ran
+                std::vector<const void *> ec, ei, es;
+                for (std::size_t i = lo; i < hi; ++i) {
+                    ext.push_back(extended(columns[i], size, root));
+                    ec.push_back(ext.back().data());
+                    ext.push_back(extended(S_id[i], size, root));
+                    ei.push_back(ext.back().data());
+                    ext.push_back(extended(S_sigma[i], size, root));
+                    es.push_back(ext.back().data());
                 }
+                dfs_type g(ctx, size), h(ctx, size);
+                g.set_degree((hi - lo) * (n - 1));
+                h.set_degree((hi - lo) * (n - 1));
+                check(zkhip_perm_factor_products_dev(ctx.get(), adapter::id, hi - lo, ec.data(), ei.data(), es.data(), size, bl, gl, g.data(), h.data()),
+                      "zkhip_perm_factor_products_dev", ctx.get());
+                gs.push_back(std::move(g));
+                hs.push_back(std::move(h));
+                continue;
+            }
+            for (std::size_t i = lo; i < hi; ++i) {
                 g_v.emplace_back(ctx, n);
                 h_v.emplace_back(ctx, n);
                 check(zkhip_memcpy_d2d_async(ctx.get(), g_v.back().data(), static_cast<const char *>(d_g.get()) + i * n * 32, n * 32), "zkhip_memcpy_d2d_async", ctx.get());
                 check(zkhip_memcpy_d2d_async(ctx.get(), h_v.back().data(), static_cast<const char *>(d_h.get()) + i * n * 32, n * 32), "zkhip_memcpy_d2d_async", ctx.get());
             }
-            if (factors_from_columns) ctx.sync();    // the extensions' temporaries are released
             gs.push_back(polynomial_product<CurveType>(std::move(g_v), root));
             hs.push_back(polynomial_product<CurveType>(std::move(h_v), root));
         }

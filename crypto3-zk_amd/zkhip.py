@@ -19,7 +19,7 @@ EXPORTS = [
     "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_batch_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_domain_choice", "zkhip_domain_fft_dev", "zkhip_domain_lagrange_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_set_domain", "zkhip_r1cs_domain_size", "zkhip_r1cs_domain_kind", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev", "zkhip_groth16_witness_h_domain_dev", "zkhip_fr_gather_dev", "zkhip_poly_resize_dev", "zkhip_fri_fold_dev", "zkhip_fri_leaves_dev", "zkhip_ec_ntt_dev",
-    "zkhip_fr_vec_op_dev", "zkhip_fr_vec_affine_dev", "zkhip_fr_vec_mul_div_dev", "zkhip_fr_vec_prod_dev", "zkhip_poly_shift_dev", "zkhip_poly_eval_dev", "zkhip_poly_div_linear_dev", "zkhip_poly_div_vanishing_dev", "zkhip_poly_lincomb_dev", "zkhip_perm_grand_product_dev", "zkhip_lookup_grand_product_dev", "zkhip_lookup_sort_dev",
+    "zkhip_fr_vec_op_dev", "zkhip_fr_vec_affine_dev", "zkhip_fr_vec_mul_div_dev", "zkhip_fr_vec_prod_dev", "zkhip_poly_shift_dev", "zkhip_poly_eval_dev", "zkhip_poly_div_linear_dev", "zkhip_poly_div_vanishing_dev", "zkhip_poly_lincomb_dev", "zkhip_perm_grand_product_dev", "zkhip_lookup_grand_product_dev", "zkhip_lookup_sort_dev", "zkhip_perm_factor_products_dev",
     "zkhip_profile_enable", "zkhip_profile_reset", "zkhip_profile_filter", "zkhip_profile_get", "zkhip_profile_dump",
 ]
 

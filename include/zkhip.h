@@ -306,6 +306,11 @@ int zkhip_poly_div_vanishing_dev(zkhip_ctx *ctx, int curve, const void *d_f, siz
  * in a serial loop; here rows are taken in chunks that share an inversion and the prefix product is a three-level scan. */
 int zkhip_perm_grand_product_dev(zkhip_ctx *ctx, int curve, size_t k, const void *const *d_cols, const void *const *d_sid, const void *const *d_ssigma,
                                  size_t n, const uint64_t *beta, const uint64_t *gamma, void *d_g, void *d_h, void *d_vp);
+/* The g and h polynomials of the same argument (ph/permutation_argument.hpp:140-160: polynomial_product(g_v), polynomial_product(h_v)) from vectors on
+ * ANY domain: d_g[j] = prod_i (column_i[j] + beta S_id_i[j] + gamma), d_h[j] likewise over S_sigma, j < n.  With the columns and the (cached)
+ * permutation polynomials extended to the products' domain this is ONE pass instead of 2 k extensions, 2 k linear passes and two k-way products. */
+int zkhip_perm_factor_products_dev(zkhip_ctx *ctx, int curve, size_t k, const void *const *d_cols, const void *const *d_sid, const void *const *d_ssigma, size_t n,
+                                   const uint64_t *beta, const uint64_t *gamma, void *d_g, void *d_h);
 /* V_L of placeholder's lookup argument (ph/lookup_argument.hpp:375-409, `compute_V_L`), the same scan over other rows:
  *   V_L[0] = 1,  V_L[k] = V_L[k - 1] g(k - 1) / h(k - 1) for 1 <= k <= usable_rows,  V_L[k] = 0 behind,
  *   g(j) = (1 + beta)^k_in prod_i (gamma + input_i[j]) prod_i ((1 + beta) gamma + value_i[j] + beta value_i[j + 1]),

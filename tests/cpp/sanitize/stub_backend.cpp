@@ -278,6 +278,12 @@ int zkhip_perm_grand_product_dev(zkhip_ctx *, int, size_t k, const void *const *
     touch(d_vp, n * 32);
     return ZKHIP_OK;
 }
+int zkhip_perm_factor_products_dev(zkhip_ctx *, int, size_t, const void *const *, const void *const *, const void *const *, size_t n, const uint64_t *,
+                                   const uint64_t *, void *d_g, void *d_h) {
+    touch(d_g, n * 32);
+    touch(d_h, n * 32);
+    return ZKHIP_OK;
+}
 int zkhip_fr_vec_affine_dev(zkhip_ctx *, int, const void *, const void *, const uint64_t *, const uint64_t *, const uint64_t *, void *d_out, size_t count) {
     touch(d_out, count * 32);
     return ZKHIP_OK;
