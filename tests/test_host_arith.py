@@ -189,3 +189,34 @@ def test_folded_recoding(shim, curve_id, curve, c):
         assert all(abs(int(d)) <= (1 << (off[w + 1] - off[w] - 1)) for w, d in enumerate(dig[:W]))
         got = sum(int(d) << off[w] for w, d in enumerate(dig[:W]))
         assert got % r == v % r and abs(got) <= (r - 1) // 2
+
+
+def test_generated_asm_blocks_compute_montgomery_products():
+    """The device products are single inline-asm blocks written by tools/gen_mont_asm.py (crypto3-zk_amd/csrc/mont_asm.hpp); the host
+    build uses the C++ form, so here the emitted instructions themselves are interpreted on the CPU (tools/sim_mont_asm.py) and
+    checked against the big-integer Montgomery product: mul, sqr, mul2 at the three limb counts shipped, and the Karatsuba block
+    of round 5's experiment against the shipped 14-limb block, limb for limb."""
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import sim_mont_asm as sim
+    from gen_mont_asm import Block, KBlock
+    rng = random.Random(17)
+    for L, modulus, bits in ((9, sim.BLS_R, 257), (10, sim.BN_Q, 262), (14, sim.BLS_Q, 386)):
+        for kind in ("mul", "sqr", "mul2"):
+            blk = Block(L, 29, False, kind)
+            blk.build()
+            bound = bits - 1 if kind == "mul2" else bits
+            cases = [{k: rng.randrange(1 << bound) for k in "abcd"} for _ in range(6)]
+            cases.append({k: (1 << bound) - 1 for k in "abcd"})
+            cases.append({"a": 0, "b": modulus - 1, "c": 1, "d": 0})
+            for ops in cases:
+                r, ok = sim.montgomery_check(blk, modulus, ops)
+                assert ok, (L, kind, ops)
+    k, u = KBlock(), Block(14, 29, False, "mul")
+    k.build()
+    u.build()
+    assert k.mads == 343 and len(k.lines) == 466 and len(u.lines) == 461
+    for _ in range(20):
+        ops = {"a": rng.randrange(1 << 386), "b": rng.randrange(1 << 386)}
+        assert sim.montgomery_check(k, sim.BLS_Q, ops) == sim.montgomery_check(u, sim.BLS_Q, ops)

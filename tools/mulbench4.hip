@@ -3,6 +3,7 @@
 // Timed by WALL CLOCK (hipEvents over a long dependent chain), at exactly w waves per SIMD for w = 1 ... 8 where the
 // registers allow (dynamic LDS sized so that exactly w one-wave-per-SIMD workgroups fit a CU), plus the s_memtime tick
 // count of the same run -- the ratio calibrates s_memtime (it does NOT tick at the shader clock on gfx950).
+// Round 5: k14x29_asm = the same 14 x 29-bit product with ONE Karatsuba level (gen_mont_asm.py KBlock).
 // Build: make -C tools mulbench4 ; run on the GPU box.  Prints CHECK lines that tools/mulbench4_check.py verifies.
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -72,14 +73,14 @@ __device__ __forceinline__ void smul_cpp(int32_t (&r)[L], const int32_t (&a)[L],
 }
 
 #define ITERS 1500
-enum { V_U14_CPP = 0, V_S13_CPP = 1, V_S13_ASM = 2, V_U14_ASM = 3, V_S13_ASM_MUL2 = 4 };
+enum { V_U14_CPP = 0, V_S13_CPP = 1, V_S13_ASM = 2, V_U14_ASM = 3, V_S13_ASM_MUL2 = 4, V_K14_ASM = 5 };
 
 template <int V>
 __global__ __launch_bounds__(256) void kmul(uint32_t *out, const uint32_t *in, uint64_t *cyc, const int32_t *ps) {
     extern __shared__ uint32_t lds_dummy[];
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t t0, t1;
-    if constexpr (V == V_U14_CPP || V == V_U14_ASM) {
+    if constexpr (V == V_U14_CPP || V == V_U14_ASM || V == V_K14_ASM) {
         constexpr int L = 14;
         uint32_t a[L], b[L], q[L];
         for (int i = 0; i < L; i++) {
@@ -93,13 +94,13 @@ __global__ __launch_bounds__(256) void kmul(uint32_t *out, const uint32_t *in, u
         asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
         for (int it = 0; it < ITERS; ++it) {
             uint32_t r[L];
-            if constexpr (V == V_U14_CPP) umul_cpp<L, 29>(r, a, b, q, 0x1ffcfffdu); else mont_u14_mul(r, a, b, q, 0x1ffcfffdu);
+            if constexpr (V == V_U14_CPP) umul_cpp<L, 29>(r, a, b, q, 0x1ffcfffdu); else if constexpr (V == V_U14_ASM) mont_u14_mul(r, a, b, q, 0x1ffcfffdu); else mont_k14_mul(r, a, b, q, 0x1ffcfffdu);
             for (int i = 0; i < L; i++) a[i] = r[i];
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
         if (tid < 4) {  // one product for the checker
             uint32_t r[L];
-            if constexpr (V == V_U14_CPP) umul_cpp<L, 29>(r, a0, b, q, 0x1ffcfffdu); else mont_u14_mul(r, a0, b, q, 0x1ffcfffdu);
+            if constexpr (V == V_U14_CPP) umul_cpp<L, 29>(r, a0, b, q, 0x1ffcfffdu); else if constexpr (V == V_U14_ASM) mont_u14_mul(r, a0, b, q, 0x1ffcfffdu); else mont_k14_mul(r, a0, b, q, 0x1ffcfffdu);
             for (int i = 0; i < L; i++) { out[tid * 64 + i] = a0[i]; out[tid * 64 + 16 + i] = b[i]; out[tid * 64 + 32 + i] = r[i]; }
         }
         if (tid >= 4) out[1024 + tid] = a[0];
@@ -178,6 +179,8 @@ void run(const char *name, int L, int mads) {
 int main() {
     run<V_U14_CPP>("u14x29_cpp", 14, 392);
     run<V_U14_ASM>("u14x29_asm", 14, 392);
+    run<V_K14_ASM>("k14x29_asm", 14, 343);  // round 5: one Karatsuba level, same limbs, same reduction half
+    run<V_U14_ASM>("u14x29_asm", 14, 392);  // again, after: the clock drifts over a run
     run<V_S13_CPP>("s13x30_cpp", 13, 338);
     run<V_S13_ASM>("s13x30_asm", 13, 338);
     run<V_S13_ASM_MUL2>("s13x30_asm_mul2", 13, 507);

@@ -9,7 +9,7 @@ for line in sys.stdin:
     t = line.split()
     name, L = t[1], int(t[2][2:])
     v = [int(x) for x in t[3:]]
-    B = 29 if name.startswith('u14') else 30
+    B = 29 if 'x29' in name else 30
     a, b, r = (sum(x << (B * i) for i, x in enumerate(v[j * L:(j + 1) * L])) for j in range(3))
     prod = 2 * a * b if name.endswith('mul2') else a * b
     good = (r * (1 << (B * L)) - prod) % P == 0
