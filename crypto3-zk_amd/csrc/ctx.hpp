@@ -113,6 +113,8 @@ struct zkhip_ctx {
     uint32_t opt_ec_ntt_table_lanes = 0;  // EC-NTT: lanes per multiplication launch = window tables held at once (0: as many as fit 1 GiB)
     int opt_msm_share_sort = 1;    // batches: consecutive members over the same scalars and table geometry share one sort (msm_same_entries)
     int opt_msm_tail_quads = 1;    // group law over lane quads in the tail of small bucket sets (fu_quad.hpp); 0: pairs everywhere
+    int opt_msm_tail_fold = 16;    // two-level tail (msm_core.hpp: row / column sums of the bucket index, then the old tail over 2 sets of ~sqrt(B) buckets) for table-backed sets of >= 2^k buckets; 0: off
+    int opt_msm_fold_run = 0;      // two-level tail: buckets a lane sums before the workgroup's tree (a power of two; 0: auto)
     int opt_msm_segment_log = -1;  // tail segments of 2^k buckets per lane; < 0: chosen from the lane count
     int opt_ntt_radix_log = 8;
     int opt_ntt_tile_log = 3;

@@ -630,6 +630,105 @@ __global__ __launch_bounds__(256) void msm_window_sum(const uint32_t *__restrict
 // every operation is ~10 us of one wave: a tree level more (256 lanes) is cheaper than three more serial additions per lane
 inline uint32_t msm_window_threads(uint32_t nblk, int lanes_per_point) { return (size_t)nblk * lanes_per_point > 128 ? 256u : 64u; }
 
+// ---- two-level tail (round 5) -----------------------------------------------------------------------------------------------
+// The running sums above are a DEPENDENT chain of 2 L additions per lane plus the (seg L) multiple: at 2^19 buckets ~76 operations of
+// ~9 us each, 0.8 ms of a 2.85-ms MSM with one wave per SIMD.  Split the bucket index instead: bucket b = h C + l (l < C, h < R,
+// B = R C) holds digit value b + 1 = h C + (l + 1), so
+//     sum_b (b + 1) bucket[b]  =  sum_l (l + 1) COL[l]  +  C sum_h h ROW[h],     COL[l] = sum_h bucket[h C + l],   ROW[h] = sum_l bucket[h C + l]
+// -- 2 B additions like the running sums, but every one of them sits in an independent SUM, and what is left for the dependent chain is the old
+// tail over 2 sets of C = 2^ceil(log2(B) / 2) buckets (COL as it is, ROW[h] in bucket h - 1, the rest empty) and log2(C) doublings of the second
+// set's sum.  (The "split the windows" step of bucket-method MSMs on GPUs, applied to the ONE merged bucket set the window tables leave.)
+struct MsmFold {
+    uint32_t B, C, R, log_c;
+    uint32_t run;           // buckets a lane sums before the workgroup's tree takes over
+    uint32_t m_row, m_col;  // runs (= LDS partial sums) per row: C / run, per column: R / run
+};
+inline MsmFold msm_fold_geom(const zkhip_ctx *ctx, uint32_t B) {
+    MsmFold g;
+    int lb = 0;
+    while ((1u << lb) < B) ++lb;
+    g.B = B;
+    g.log_c = (uint32_t)((lb + 1) / 2);
+    g.C = 1u << g.log_c;
+    g.R = B >> g.log_c;
+    // measured (tools/msm_profile.py, G1): 2^19 buckets: 8 and 16 the same (0.31 ms), 32 slower (0.52: half the SIMDs idle); 2^16 buckets: 8: 0.150,
+    // 4: 0.108, 2: 0.094 ms
+    g.run = ctx->opt_msm_fold_run > 0 ? (uint32_t)ctx->opt_msm_fold_run : (B >= (1u << 18) ? 8u : 4u);
+    g.run = std::max(1u, std::min(g.run, g.R));
+    g.m_row = g.C / g.run;
+    g.m_col = g.R / g.run;
+    return g;
+}
+
+// grid = sets x B / (RUN SA) workgroups, SA = threads / LA points: the first half of a set's workgroups sum ROWS (SA / m_row whole rows each), the second
+// half COLUMNS (SA / m_col whole columns each).
+//   phase 1, bound by WORK: every point slot sums RUN buckets of its row / column with the lane shape FA (one lane per point for G1: an addition
+//            in the fewest issue slots), interleaved so that adjacent lanes read adjacent buckets, and leaves the sum in LDS;
+//   phase 2, bound by LATENCY: binary trees over the m partial sums of each row / column in LDS with the lane shape FT (G1: lane quads);
+//   level2[2 set][l] = COL[l], level2[2 set + 1][h - 1] = ROW[h] (row 0 has weight 0: dropped; entries R - 1 ... C - 1 of the second set stay
+//   empty = zeroed by the caller).
+template <class FA, int LA, class FT, int LT>
+__global__ __launch_bounds__(MSM_TAIL_THREADS, ZK_TAIL_WAVES) void msm_fold(const uint32_t *__restrict__ buckets, MsmFold g, uint32_t *__restrict__ level2) {
+    constexpr int NL = FieldOps<FA>::WORDS;
+    constexpr uint32_t SA = MSM_TAIL_THREADS / LA, ST = MSM_TAIL_THREADS / LT, PW = 4 * NL;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t half_wgs = g.B / (SA * g.run);
+    const uint32_t w = blockIdx.x / (2 * half_wgs), k = blockIdx.x % (2 * half_wgs);
+    const bool col = k >= half_wgs;
+    const uint32_t wg = col ? k - half_wgs : k, s = threadIdx.x / LA;
+    const uint32_t m = col ? g.m_col : g.m_row, G = SA / m;  // partial sums per output, outputs of this workgroup
+    uint32_t first, stride, slot;
+    if (!col) {  // slot (r, j): buckets h C + j + i m_row of row h = wg G + r
+        first = (wg * G + s / m) * g.C + s % m;
+        stride = m;
+        slot = s;
+    } else {  // slot (j, ll), ll fastest: buckets (j + i m_col) C + l of column l = wg G + ll; its sum goes to LDS slot ll m_col + j
+        const uint32_t j = s / G, ll = s % G;
+        first = j * g.C + wg * G + ll;
+        stride = m * g.C;
+        slot = ll * m + j;
+    }
+    {
+        const uint32_t *src = buckets + ((size_t)w * g.B + first) * PW;
+        XYZZ<FA> acc = xyzz_load<FA>(src);
+        for (uint32_t i = 1; i < g.run; ++i) acc = xyzz_add(acc, xyzz_load<FA>(src + (size_t)i * stride * PW));
+        xyzz_store<FA>(lds + (size_t)slot * PW, acc);
+    }
+    __syncthreads();
+    const uint32_t t = threadIdx.x / LT;
+    for (uint32_t half = m / 2; half >= 1; half >>= 1) {
+        const uint32_t adds = G * half;
+        for (uint32_t idx = t; idx < adds; idx += ST) {
+            uint32_t *p = lds + (size_t)((idx / half) * m + idx % half) * PW;
+            xyzz_store<FT>(p, xyzz_add(xyzz_load<FT>(p), xyzz_load<FT>(p + (size_t)half * PW)));
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = t; i < G; i += ST) {
+        const uint32_t o = wg * G + i;  // row h / column l
+        if (col || o != 0)
+            xyzz_store<FT>(level2 + (((size_t)2 * w + (col ? 0 : 1)) * g.C + (col ? o : o - 1)) * PW, xyzz_load<FT>(lds + (size_t)i * m * PW));
+    }
+}
+
+// out[i] = winsum[2 i] + 2^shift winsum[2 i + 1] as canonical Jacobian; outs == nullptr: the single output `out`
+template <class F, int LPB>
+__global__ __launch_bounds__(64) void msm_final_fold(const uint32_t *__restrict__ winsum, uint32_t count, uint32_t shift, uint32_t *const *__restrict__ outs,
+                                                     uint32_t *__restrict__ out) {
+    constexpr int NL = FieldOps<F>::WORDS;
+    if (blockIdx.x >= count || threadIdx.x >= LPB) return;
+    XYZZ<F> acc = xyzz_load<F>(winsum + ((size_t)2 * blockIdx.x + 1) * (4 * NL));
+    if (!acc.is_inf())
+        for (uint32_t i = 0; i < shift; ++i) acc = xyzz_dbl(acc);
+    acc = xyzz_add(acc, xyzz_load<F>(winsum + (size_t)2 * blockIdx.x * (4 * NL)));
+    Jacobian<F> j = xyzz_to_jacobian(acc);
+    constexpr int CW = FieldOps<F>::CANON_WORDS;
+    uint32_t *dst = outs ? outs[blockIdx.x] : out;
+    FieldOps<F>::to_canonical(dst, j.X);
+    FieldOps<F>::to_canonical(dst + CW, j.Y);
+    FieldOps<F>::to_canonical(dst + 2 * CW, j.Z);
+}
+
 // result = sum_w 2^off(w) winsum[w]  (Horner from the top window; a single set with tables), emitted as canonical Jacobian
 template <class F, int LPB>
 __global__ __launch_bounds__(64) void msm_final(const uint32_t *__restrict__ winsum, int W, MsmWindows win, uint32_t *__restrict__ out_jac) {
@@ -889,6 +988,74 @@ inline uint32_t msm_tail_segment(const zkhip_ctx *ctx, uint32_t B, size_t sets, 
     return std::min(B, L);
 }
 
+// ---- the two-level tail on the host: buffers and launches --------------------------------------------------------------------
+// Applies to merged bucket sets with window tables (ONE set per MSM) of at least 2^opt_msm_tail_fold buckets whose rows and columns fit a workgroup.
+template <class F>
+bool msm_fold_applies(const zkhip_ctx *ctx, uint32_t B, bool tables) {
+    if (!tables || ctx->opt_msm_tail_fold <= 0 || B < (1u << std::min(ctx->opt_msm_tail_fold, 30))) return false;
+    const MsmFold g = msm_fold_geom(ctx, B);
+    const uint32_t sa = MSM_TAIL_THREADS / BucketLane<F>::LANES;
+    return g.m_col >= 1 && g.m_row <= sa && g.m_col <= sa && B >= sa * g.run && g.m_row * g.run == g.C && g.m_col * g.run == g.R;
+}
+struct MsmFoldBuffers {
+    MsmFold g;
+    size_t level2_words, segsum_words, winsum_words;
+    uint32_t *level2 = nullptr, *segsum = nullptr, *winsum = nullptr;
+    size_t need() const { return zkhip_ctx::ws_round(level2_words * 4) + zkhip_ctx::ws_round(segsum_words * 4) + zkhip_ctx::ws_round(winsum_words * 4); }
+    void take(zkhip_ctx *ctx) {
+        level2 = ctx->ws_take<uint32_t>(level2_words);
+        segsum = ctx->ws_take<uint32_t>(segsum_words);
+        winsum = ctx->ws_take<uint32_t>(winsum_words);
+    }
+};
+template <class F>
+MsmFoldBuffers msm_fold_buffers(const zkhip_ctx *ctx, uint32_t B, size_t nsets) {
+    constexpr size_t PW = (size_t)4 * FieldOps<F>::WORDS;  // words per XYZZ point
+    MsmFoldBuffers fb;
+    fb.g = msm_fold_geom(ctx, B);
+    fb.level2_words = nsets * 2 * fb.g.C * PW;
+    fb.segsum_words = nsets * 2 * ((fb.g.C + 63) / 64) * PW;  // segments of >= 1 bucket, >= 64 of them per workgroup
+    fb.winsum_words = nsets * 2 * PW;
+    return fb;
+}
+
+// the old tail over the 2 nsets level-2 sets with lane type TX, then the outputs
+template <class TX, int XL, bool G2>
+int msm_fold_level2(zkhip_ctx *ctx, const MsmFoldBuffers &fb, size_t nsets, uint32_t *const *d_outs, uint32_t *d_out) {
+    constexpr int NL = FieldOps<TX>::WORDS;
+    const size_t sets2 = 2 * nsets;
+    const uint32_t C = fb.g.C, L2 = msm_tail_segment(ctx, C, sets2, XL, G2), slots = MSM_TAIL_THREADS / XL;
+    const uint32_t nseg = C / L2, nblk = (nseg + slots - 1) / slots;
+    ZK_MAX_LDS(ctx, (msm_bucket_red<TX, XL>), (size_t)slots * 4 * NL * 4);
+    ZK_LAUNCH(ctx, "msm_bucket_red", (msm_bucket_red<TX, XL>), dim3((unsigned)(sets2 * nblk)), dim3(MSM_TAIL_THREADS), (size_t)slots * 4 * NL * 4, fb.level2, C, L2,
+              nseg, nblk, fb.segsum);
+    const uint32_t wt = msm_window_threads(nblk, XL);
+    ZK_LAUNCH(ctx, "msm_window_sum", (msm_window_sum<TX, XL>), dim3((unsigned)sets2), dim3(wt), (size_t)wt / XL * 4 * NL * 4, fb.segsum, nblk, fb.winsum);
+    ZK_LAUNCH(ctx, "msm_final", (msm_final_fold<TX, XL>), dim3((unsigned)nsets), dim3(64), 0, fb.winsum, (uint32_t)nsets, fb.g.log_c, d_outs, d_out);
+    return 0;
+}
+
+// sets[nsets][B] merged buckets -> nsets canonical Jacobian results (d_outs: device array of output pointers, or the one output d_out).
+// TL / TLPB: the lane shape of the level-2 tail when the quads do not apply.
+template <class F, class TL, int TLPB>
+int msm_fold_tail(zkhip_ctx *ctx, const uint32_t *sets, size_t nsets, const MsmFoldBuffers &fb, uint32_t *const *d_outs, uint32_t *d_out) {
+    constexpr int NL = FieldOps<F>::WORDS;
+    constexpr bool G2 = FieldOps<F>::WORDS > 16;
+    typedef typename BucketLane<F>::type FL;
+    constexpr int LPB = BucketLane<F>::LANES;
+    typedef typename QuadLane<F>::type TQ;  // the trees are latency: quads where the field has them (else this IS the tail lane)
+    constexpr int QL = QuadLane<F>::LANES;
+    const MsmFold &g = fb.g;
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(fb.level2, 0, fb.level2_words * 4, ctx->stream));  // empty buckets (the second set's upper part stays so)
+    const size_t lds = (size_t)MSM_TAIL_THREADS / LPB * 4 * NL * 4;
+    ZK_MAX_LDS(ctx, (msm_fold<FL, LPB, TQ, QL>), lds);
+    ZK_LAUNCH(ctx, "msm_fold", (msm_fold<FL, LPB, TQ, QL>), dim3((unsigned)(nsets * (g.B / (MSM_TAIL_THREADS / LPB * g.run)) * 2)), dim3(MSM_TAIL_THREADS), lds,
+              sets, g, fb.level2);
+    if (QuadLane<F>::AVAILABLE && ctx->opt_msm_tail_quads && 2 * nsets * g.C <= ((size_t)1 << 18))
+        return msm_fold_level2<TQ, QL, G2>(ctx, fb, nsets, d_outs, d_out);
+    return msm_fold_level2<TL, TLPB, G2>(ctx, fb, nsets, d_outs, d_out);
+}
+
 // the tail workgroups keep 256 XYZZ points in LDS (56 KiB for G1, 128 KiB for BLS12-381 G2)
 template <class F>
 int msm_tail_attr(zkhip_ctx *ctx) {
@@ -1011,6 +1178,12 @@ int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
     need += 2 * zkhip_ctx::ws_round(((size_t)nsh + 1) * 4) + zkhip_ctx::ws_round((size_t)sblk2 * 4) + zkhip_ctx::ws_round((size_t)nb * 4);  // size sort
     need += zkhip_ctx::ws_round((size_t)Sr * nblk_cap * 4 * NL * 4);
     need += zkhip_ctx::ws_round((size_t)std::max(1, Sr) * 4 * NL * 4);
+    const bool fold = !batch_slot && msm_fold_applies<F>(ctx, B, P.tables);  // batches fold once, for all members (msm_batch_tail)
+    MsmFoldBuffers fb;
+    if (fold) {
+        fb = msm_fold_buffers<F>(ctx, B, 1);
+        need += fb.need();
+    }
     // worst-case plan of the large-bucket path: every entry in a large bucket
     const size_t entries = (size_t)W * n;
     const uint32_t large_thresh = (uint32_t)std::max<size_t>(MSM_LARGE_BUCKET, 4 * ((entries + nb - 1) / nb));
@@ -1039,6 +1212,7 @@ int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
     uint32_t *order = ctx->ws_take<uint32_t>(nb);
     uint32_t *segsum = ctx->ws_take<uint32_t>((size_t)Sr * nblk_cap * 4 * NL);
     uint32_t *winsum = ctx->ws_take<uint32_t>((size_t)std::max(1, Sr) * 4 * NL);
+    if (fold) fb.take(ctx);
     uint32_t *plan = ctx->ws_take<uint32_t>(4);
     uint32_t *tasks = ctx->ws_take<uint32_t>((size_t)task_cap * 3);
     uint32_t *large = ctx->ws_take<uint32_t>((size_t)large_cap * 3);
@@ -1102,6 +1276,7 @@ int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
         ZK_HIP_CHECK(ctx, hipMemcpyAsync(batch_slot, buckets, (size_t)B * 4 * NL * 4, hipMemcpyDeviceToDevice, ctx->stream));
         return 0;
     }
+    if (fold) return msm_fold_tail<F, TL, TLPB>(ctx, buckets, 1, fb, nullptr, d_out_jac);
     // Small bucket sets leave lanes to spare even as pairs: the group law then runs over lane QUADS (fu_quad.hpp: 4 product steps per
     // addition instead of 7) with segments twice as long -- from 2^18 buckets down; at 2^19 the longer segments eat the gain.
     if (QuadLane<F>::AVAILABLE && ctx->opt_msm_tail_quads && (size_t)Sr * B <= ((size_t)1 << 18)) {
@@ -1180,6 +1355,12 @@ int msm_batch_tail(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases
     const size_t slot_words = (size_t)B * 4 * NL;
     size_t fixed = zkhip_ctx::ws_round(count * slot_words * 4) + zkhip_ctx::ws_round(count * nblk_tail * 4 * NL * 4) +
                    zkhip_ctx::ws_round(count * 4 * NL * 4) + zkhip_ctx::ws_round(count * sizeof(void *));
+    const bool fold = msm_fold_applies<F>(ctx, B, true);
+    MsmFoldBuffers fb;
+    if (fold) {
+        fb = msm_fold_buffers<F>(ctx, B, count);
+        fixed += fb.need();
+    }
     ctx->ws_floor = 0;
     ZK_TRY(ctx->ws_reserve(fixed + max_need));
     ctx->ws_reset();
@@ -1187,6 +1368,7 @@ int msm_batch_tail(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases
     uint32_t *segsum = ctx->ws_take<uint32_t>(count * nblk_tail * 4 * NL);
     uint32_t *winsum = ctx->ws_take<uint32_t>(count * 4 * NL);
     uint32_t **d_ptrs = ctx->ws_take<uint32_t *>(count);
+    if (fold) fb.take(ctx);
     ctx->ws_floor = ctx->ws_off;  // the per-MSM stages bump-allocate above the batch area
     int rc = 0;
     size_t prev = (size_t)-1;  // the member whose sort the workspace holds
@@ -1209,6 +1391,7 @@ int msm_batch_tail(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases
         ctx->batch_ptrs.assign(d_outs, d_outs + count);
         ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_ptrs, ctx->batch_ptrs.data(), count * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
     }
+    if (fold) return msm_fold_tail<F, TL, TLPB>(ctx, slots, count, fb, d_ptrs, nullptr);
     ZK_MAX_LDS(ctx, (msm_bucket_red<TL, TLPB>), MSM_TAIL_THREADS / TLPB * 4 * NL * 4);
     ZK_LAUNCH(ctx, "msm_bucket_red", (msm_bucket_red<TL, TLPB>), dim3((unsigned)count * nblk_tail), dim3(MSM_TAIL_THREADS), (size_t)tail_slots * 4 * NL * 4, slots,
               B, L, nseg, nblk_tail, segsum);
