@@ -46,7 +46,13 @@ def scalars(rng, curve, n, pattern):
 def fuzz_msm(zk, ctx, rng, stats):
     curve, group = int(rng.integers(0, 2)), int(rng.integers(1, 3))
     n = int(rng.integers(1, (6000 if group == 1 else 1500) * SCALE))
+    # the two-level bucket reduction (G1, window tables) starts at 2^16 buckets by default: draw its threshold, its run length and -- one call in
+    # three -- a window size that gives it 2^9 ... 2^17 buckets to fold
+    ctx.set_option("msm_window_bits", int(rng.integers(10, 19)) if rng.random() < 0.33 else 0)
+    ctx.set_option("msm_tail_fold", int(rng.choice([0, 8, 8, 16])))
+    ctx.set_option("msm_fold_run", int(rng.choice([0, 0, 1, 2, 4, 8])))
     b = ctx.bases_from_scalars(curve, group, cp.random_fr(curve, int(rng.integers(1, 1 << 30)), n))
+    ctx.set_option("msm_window_bits", 0)
     pts, inf = b.download()
     off = int(rng.integers(0, n)) if rng.random() < 0.3 else 0
     cnt = n - off
@@ -85,6 +91,8 @@ def fuzz_msm(zk, ctx, rng, stats):
     ctx.free(d_s)
     ctx.free(d_o)
     b.free()
+    ctx.set_option("msm_tail_fold", 16)
+    ctx.set_option("msm_fold_run", 0)
     stats["msm"] += len(got)
 
 
@@ -126,6 +134,7 @@ def fuzz_witness(zk, ctx, rng, stats):
     curve = int(rng.integers(0, 2))
     C = CURVES[curve]
     M, nin = int(rng.integers(3, 5000 * SCALE)), int(rng.integers(1, 12))
+    nin = min(nin, M + 2)  # the oracle's instances have M + 2 variables; more inputs than variables is no instance (the library says RANGE)
     g16 = cp.Groth16(curve, M, nin, seed=int(rng.integers(1, 1000)))
     kind, m = cp.domain_choice(M + nin + 1, C.two_adicity)
     wd = limbs(C.root_of_unity((M + nin).bit_length()), 4)
