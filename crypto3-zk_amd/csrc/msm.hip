@@ -145,6 +145,7 @@ static std::string key_begin(zkhip_ctx *ctx, char kind) {
     key_add(k, ctx->opt_msm_tail_quads);
     key_add(k, ctx->opt_msm_tail_fold);
     key_add(k, ctx->opt_msm_fold_run);
+    key_add(k, ctx->opt_msm_tail_fold_g2);
     key_add(k, ctx->opt_msm_share_sort);
     key_add(k, ctx->opt_msm_sort_tile_log);  // the captured launch sequence depends on the sort's tile shape
     return k;

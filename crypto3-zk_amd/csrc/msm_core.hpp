@@ -990,11 +990,14 @@ inline uint32_t msm_tail_segment(const zkhip_ctx *ctx, uint32_t B, size_t sets, 
 
 // ---- the two-level tail on the host: buffers and launches --------------------------------------------------------------------
 // Applies to merged bucket sets with window tables (ONE set per MSM) of at least 2^opt_msm_tail_fold buckets whose rows and columns fit a workgroup.
-// G1 only: measured on BLS12-381 G2 (2^19 buckets, lane pairs throughout) the two levels cost what the running sums cost (1.94 against 1.97 ms).
+// G2 (lane pairs throughout): a lone 2^20-point MSM measures the same either way (tail 1.94 against 1.97 ms), but the two levels are HALF the
+// additions, and a Groth16 proof runs its G2 MSM under the G1 MSMs, which take the issue slots (50.7-51.0 -> 51.9-52.4 M constraints/s, A/B on
+// one box, three times interleaved): on by default, with its own switch msm_tail_fold_g2.
 template <class F>
-constexpr bool MSM_FOLD_COMPILED = FieldOps<F>::WORDS <= 16;
+constexpr bool MSM_FOLD_COMPILED = true;
 template <class F>
 bool msm_fold_applies(const zkhip_ctx *ctx, uint32_t B, bool tables) {
+    if (FieldOps<F>::WORDS > 16 && !ctx->opt_msm_tail_fold_g2) return false;
     if (!MSM_FOLD_COMPILED<F> || !tables || ctx->opt_msm_tail_fold <= 0 || B < (1u << std::min(ctx->opt_msm_tail_fold, 30))) return false;
     const MsmFold g = msm_fold_geom(ctx, B);
     const uint32_t sa = MSM_TAIL_THREADS / BucketLane<F>::LANES;

@@ -167,6 +167,7 @@ int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value) {
     else if (n == "msm_tail_quads") ctx->opt_msm_tail_quads = (int)value;
     else if (n == "msm_tail_fold") ctx->opt_msm_tail_fold = (int)value;
     else if (n == "msm_fold_run") ctx->opt_msm_fold_run = (int)value;
+    else if (n == "msm_tail_fold_g2") ctx->opt_msm_tail_fold_g2 = (int)value;
     else if (n == "msm_share_sort") ctx->opt_msm_share_sort = (int)value;
     else if (n == "ec_ntt_table_lanes") ctx->opt_ec_ntt_table_lanes = value < 0 ? 0 : (uint32_t)std::min<int64_t>(value, 1 << 24);
     else if (n == "msm_sort_tile_log") ctx->opt_msm_sort_tile_log = (int)value;
@@ -221,6 +222,7 @@ int zkhip_get_option(const zkhip_ctx *ctx, const char *name, int64_t *value) {
     else if (n == "msm_tail_quads") *value = ctx->opt_msm_tail_quads;
     else if (n == "msm_tail_fold") *value = ctx->opt_msm_tail_fold;
     else if (n == "msm_fold_run") *value = ctx->opt_msm_fold_run;
+    else if (n == "msm_tail_fold_g2") *value = ctx->opt_msm_tail_fold_g2;
     else if (n == "msm_share_sort") *value = ctx->opt_msm_share_sort;
     else if (n == "ec_ntt_table_lanes") *value = ctx->opt_ec_ntt_table_lanes;
     else if (n == "msm_sort_tile_log") *value = ctx->opt_msm_sort_tile_log;

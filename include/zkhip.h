@@ -63,7 +63,7 @@ int zkhip_sync(zkhip_ctx *ctx);
  * any was set (the results computed meanwhile are then not to be used).  The shims call it once per proof. */
 int zkhip_device_status(zkhip_ctx *ctx, uint32_t *flags /* nullable */);
 /* Tunables: "msm_window_bits" (0 = auto), "msm_sets" (bucket sets with window tables, 0 = auto), "msm_segment_log" (tail: 2^k buckets
- * per lane, < 0 = auto), "msm_tail_quads" (1: the tail of bucket sets up to 2^18 runs the group law over lane quads, 0: pairs everywhere), "msm_tail_fold" (k > 0: the bucket reduction of table-backed sets of >= 2^k buckets is two-level -- row and column sums of the bucket index, then the old tail over 2 sets of ~sqrt(B) buckets; 0: off; default 16), "msm_fold_run" (buckets a lane of that kernel sums before the workgroup trees, 0 = auto), "msm_share_sort" (1: consecutive members of zkhip_msm_batch_dev with the same scalars pointer, range and
+ * per lane, < 0 = auto), "msm_tail_quads" (1: the tail of bucket sets up to 2^18 runs the group law over lane quads, 0: pairs everywhere), "msm_tail_fold" (k > 0: the bucket reduction of table-backed sets of >= 2^k buckets is two-level -- row and column sums of the bucket index, then the old tail over 2 sets of ~sqrt(B) buckets; 0: off; default 16), "msm_fold_run" (buckets a lane of that kernel sums before the workgroup trees, 0 = auto), "msm_tail_fold_g2" (1: G2 sets too), "msm_share_sort" (1: consecutive members of zkhip_msm_batch_dev with the same scalars pointer, range and
  * table geometry share one digit extraction / sort / large-bucket plan; 0: every member sorts), "msm_sort_tile_log" (14: the MSM has the GPU to itself; 12: kernels of another context run alongside and
  * the sort's LDS tiles must fit next to them), "ntt_radix_log", "ntt_tile_log", "poly_coset_extend" (1: zkhip_poly_resize_dev grows n -> K n, K <= 16, by n-point transforms over the K - 1 new cosets; 0: one K n-point transform), "ec_ntt_table_lanes" (zkhip_ec_ntt_dev: points multiplied per launch = per-lane window tables held at
  * once; 0 = as many as fit 1 GiB), "msm_precompute" / "msm_precompute_min" (window

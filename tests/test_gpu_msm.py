@@ -534,6 +534,7 @@ def test_msm_random_configurations(zk, ctx):
                 ctx.set_option("msm_segment_log", int(rng.integers(-1, 6)))
                 ctx.set_option("msm_tail_fold", int(rng.choice([0, 8, 12, 16])))  # two-level tail from 2^k buckets on (G1, tables)
                 ctx.set_option("msm_fold_run", int(rng.choice([0, 1, 2, 4, 8, 16])))
+                ctx.set_option("msm_tail_fold_g2", int(rng.integers(0, 2)))
                 lo = int(rng.integers(0, n // 2))
                 cnt = int(rng.integers(1, n - lo + 1))
                 exp, einf = cp.msm(curve, group, pts[lo:lo + cnt], sc[lo:lo + cnt], chunks=4)
@@ -542,16 +543,16 @@ def test_msm_random_configurations(zk, ctx):
                 b.free()
         finally:
             for name, v in (("msm_precompute", 1), ("msm_window_bits", 0), ("msm_sets", 0), ("msm_sort_tile_log", 14), ("msm_segment_log", -1),
-                            ("msm_tail_fold", 16), ("msm_fold_run", 0)):
+                            ("msm_tail_fold", 16), ("msm_fold_run", 0), ("msm_tail_fold_g2", 1)):
                 ctx.set_option(name, v)
 
 
-@pytest.mark.parametrize("curve,n", [(0, 1 << 17), (1, 40000)])
-def test_two_level_tail_equals_running_sums(zk, ctx, curve, n):
+@pytest.mark.parametrize("curve,group,n", [(0, 1, 1 << 17), (1, 1, 40000), (0, 2, 12000), (1, 2, 5000)])
+def test_two_level_tail_equals_running_sums(zk, ctx, curve, group, n):
     """The bucket reduction in two levels (msm_core.hpp msm_fold: row and column sums of the bucket index, then the running sums over
     2 sets of ~sqrt(B) buckets) against the running sums over the whole set, for every bucket count 2^8 ... 2^20 (square and 2 : 1
-    splits), every run length the kernel's geometry admits, a lone MSM and a batch with an empty and a sub-range member; the
-    smallest case also against the oracle.  Bit-exact: both are sums of the same points."""
+    splits), every run length the kernel's geometry admits, a lone MSM and a batch with an empty and a sub-range member, G1 and G2;
+    one case per group also against the oracle.  Bit-exact: both are sums of the same points."""
     ks = cp.random_fr(curve, 71, n)
     sc = cp.random_fr(curve, 72, n)
     sc[::7] = 0
@@ -560,29 +561,30 @@ def test_two_level_tail_equals_running_sums(zk, ctx, curve, n):
     d_s, d_s2 = ctx.malloc(sc.nbytes), ctx.malloc(sc2.nbytes)
     ctx.h2d(d_s, sc)
     ctx.h2d(d_s2, sc2)
-    d_o = [ctx.malloc(144) for _ in range(3)]
+    L = zk.coord_limbs(curve, group)
+    d_o = [ctx.malloc(3 * L * 8) for _ in range(3)]
 
     def fetch(k):
-        out = np.zeros((3, zk.coord_limbs(curve, 1)), dtype=np.uint64)
+        out = np.zeros((3, L), dtype=np.uint64)
         ctx.d2h(out, d_o[k])
-        return jac_to_affine_py(curve, 1, out)
+        return jac_to_affine_py(curve, group, out)
 
     try:
-        for c in (9, 12, 13, 16, 17, 18, 19, 20, 21):
+        for c in ((9, 12, 13, 16, 17, 18, 19, 20, 21) if group == 1 else (9, 13, 16, 17, 20)):
             ctx.set_option("msm_window_bits", c)
-            b = ctx.bases_from_scalars(curve, 1, ks)
+            b = ctx.bases_from_scalars(curve, group, ks)
             results = []
             for fold, run in ((0, 0), (8, 0), (8, 1), (8, 2), (8, 4), (8, 8), (8, 16), (8, 32)):
                 ctx.set_option("msm_tail_fold", fold)
                 ctx.set_option("msm_fold_run", run)
-                lone = jac_to_affine_py(curve, 1, ctx.msm(b, sc))
+                lone = jac_to_affine_py(curve, group, ctx.msm(b, sc))
                 ctx.msm_batch_dev([b, b, b], [d_s, d_s2, d_s], d_o, offsets=[0, 0, 100], ns=[n, 0, n - 1000])
                 results.append((lone, fetch(0), fetch(1), fetch(2)))
-            assert all(r == results[0] for r in results[1:]), (curve, c)
+            assert all(r == results[0] for r in results[1:]), (curve, group, c)
             assert results[0][0] == results[0][1] and results[0][2] is None and results[0][0] is not None
             if c == 17 and curve == 1:
-                exp, einf = cp.msm(curve, 1, b.download()[0], sc, chunks=8)
-                assert results[0][0] == pt_from_limbs(curve, 1, exp, einf)
+                exp, einf = cp.msm(curve, group, b.download()[0], sc, chunks=8)
+                assert results[0][0] == pt_from_limbs(curve, group, exp, einf)
             b.free()
     finally:
         for name, v in (("msm_window_bits", 0), ("msm_tail_fold", 16), ("msm_fold_run", 0)):
