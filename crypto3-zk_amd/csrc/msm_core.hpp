@@ -1212,6 +1212,7 @@ int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
     uint32_t *offs = ctx->ws_take<uint32_t>((size_t)nb + 1);
     uint32_t *idx = ctx->ws_take<uint32_t>((size_t)W * n);
     uint32_t *buckets = ctx->ws_take<uint32_t>((size_t)nb * 4 * NL);
+    if (batch_slot && S == 1) buckets = batch_slot;  // a batch member with ONE set accumulates straight into its slot of the batch (no copy of 2^19 buckets = 117 MB)
     uint32_t *sh = ctx->ws_take<uint32_t>((size_t)nsh + 1);
     uint32_t *so = ctx->ws_take<uint32_t>((size_t)nsh + 1);
     uint32_t *ssums = ctx->ws_take<uint32_t>(sblk2);
@@ -1279,7 +1280,7 @@ int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
         }
     }
     if (batch_slot) {  // batched call: hand the merged buckets over, the reduction runs once for the whole batch
-        ZK_HIP_CHECK(ctx, hipMemcpyAsync(batch_slot, buckets, (size_t)B * 4 * NL * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        if (buckets != batch_slot) ZK_HIP_CHECK(ctx, hipMemcpyAsync(batch_slot, buckets, (size_t)B * 4 * NL * 4, hipMemcpyDeviceToDevice, ctx->stream));
         return 0;
     }
     if constexpr (MSM_FOLD_COMPILED<F>)
