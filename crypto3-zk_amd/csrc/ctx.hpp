@@ -103,6 +103,8 @@ struct zkhip_ctx {
     bool capturing = false;
     void *batch_dptrs_override = nullptr;  // during a batch capture: the graph-owned output-pointer array
     int opt_msm_graphs = 0;  // off: replaying the captured launch sequence measured no faster than issuing it
+    uint32_t *msm_host_buf = nullptr;  // zkhip_msm (scalars in host memory): result + scalars on the device, kept across calls
+    size_t msm_host_cap = 0;
     // pinned staging for small results
     void *pinned = nullptr;
     size_t pinned_cap = 0;

@@ -106,6 +106,7 @@ void zkhip_destroy(zkhip_ctx *ctx) {
         ctx->alloc_live.clear();
         g_contexts.erase(ctx);
     }
+    if (ctx->msm_host_buf) (void)hipFree(ctx->msm_host_buf);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -647,29 +648,27 @@ int zkhip_msm_batch_dev(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *
 int zkhip_msm(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint64_t *scalars, uint64_t *out_jacobian) {
     if (!ctx || !bases || !out_jacobian || (n && !scalars)) return ZKHIP_ERR_INVALID;
     ZK_TRY(check_device(ctx));
-    uint32_t *d_s = nullptr, *d_o = nullptr;
-    size_t obytes = 3 * zk_coord_limbs64(bases->curve, bases->group) * 8;
-    int rc = 0;
-    do {
-        if (hipMalloc((void **)&d_s, std::max<size_t>(1, n) * 32) != hipSuccess || hipMalloc((void **)&d_o, obytes) != hipSuccess) {
-            rc = ZKHIP_ERR_OOM;
-            break;
+    // The scalars land in a buffer the context keeps (grow-only, freed with the context): no hipMalloc / hipFree per call (the free is a device
+    // synchronisation), and the SAME device addresses call after call, so the launch sequence replays as a HIP graph like the resident path's.
+    const size_t obytes = 3 * zk_coord_limbs64(bases->curve, bases->group) * 8, want = std::max<size_t>(1, n) * 32 + 512;
+    if (ctx->msm_host_cap < want) {
+        ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->msm_host_buf) (void)hipFree(ctx->msm_host_buf);
+        ctx->msm_host_buf = nullptr;
+        ctx->msm_host_cap = 0;
+        zk_graphs_clear(ctx);  // graphs over the old buffer
+        if (hipMalloc((void **)&ctx->msm_host_buf, want) != hipSuccess) {
+            (void)hipGetLastError();
+            return ZKHIP_ERR_OOM;
         }
-        if (n && hipMemcpyAsync(d_s, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
-            rc = ZKHIP_ERR_HIP;
-            break;
-        }
-        rc = zk_msm_run(ctx, bases, offset, n, d_s, d_o);
-        if (rc) break;
-        if (hipMemcpyAsync(out_jacobian, d_o, obytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) {
-            ctx->last_error = hipGetErrorString(hipGetLastError());
-            rc = ZKHIP_ERR_HIP;
-        }
-    } while (0);
-    if (d_s) (void)hipFree(d_s);
-    if (d_o) (void)hipFree(d_o);
-    return rc;
+        ctx->msm_host_cap = want;
+    }
+    uint32_t *d_o = ctx->msm_host_buf, *d_s = ctx->msm_host_buf + 128;  // result in the first 512 bytes, scalars behind it
+    if (n) ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_s, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_TRY(zk_msm_run(ctx, bases, offset, n, d_s, d_o));
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(out_jacobian, d_o, obytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
 }
 
 int zkhip_jacobian_sum_dev(zkhip_ctx *ctx, int curve, int group, const void *d_points, size_t count, void *d_out_jacobian) {

@@ -131,7 +131,9 @@ void zkhip_bases_free(zkhip_ctx *ctx, zkhip_bases *b);
  * knowledge_commitment_multiexp.hpp:107).  `chunks` has no counterpart: the device splits the work itself.
  * out_jacobian: 3 * (coordinate limbs) u64, canonical X | Y | Z of the group element; WHICH projective representative comes out is
  * not fixed (the order of additions inside a bucket follows the sort's atomics): compare points after zkhip_jacobian_to_affine,
- * as the reference's own operator== normalises before comparing. */
+ * as the reference's own operator== normalises before comparing.
+ * The context keeps the device copy of the scalars (32 n bytes, grow-only, freed by zkhip_destroy): a prover's repeated calls neither allocate nor free, and
+ * replay their launch sequence as a HIP graph. */
 int zkhip_msm(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint64_t *scalars /* host, n x 4 */,
               uint64_t *out_jacobian /* host */);
 /* Same, scalars and result resident in device memory; asynchronous on the context's stream. */

@@ -591,3 +591,34 @@ def test_two_level_tail_equals_running_sums(zk, ctx, curve, group, n):
             ctx.set_option(name, v)
         for d in [d_s, d_s2] + d_o:
             ctx.free(d)
+
+
+@pytest.mark.parametrize("curve,group", [(0, 1), (1, 1), (0, 2)])
+def test_two_level_tail_degenerate_buckets(zk, ctx, curve, group):
+    """Row and column sums over buckets that hold THE SAME point (every base equal, scalar v once for v = 1 ... : each addition of the runs and of
+    the trees is a doubling), its negative (scalars r - v: rows cancel to infinity), and mostly nothing (a handful of entries in 2^12 buckets):
+    two levels == running sums == oracle."""
+    r = CURVES[curve].r
+    n, c = 6000, 13
+    ks = fr_arr([5] * n)
+    cases = {
+        "doublings": fr_arr([(v % 4095) + 1 for v in range(n)]),
+        "cancellations": fr_arr([(v % 2000) + 1 if v % 2 == 0 else r - ((v - 1) % 2000) - 1 for v in range(n)]),
+        "sparse": fr_arr([0] * (n - 5) + [1, 4096, r - 4096, 77, 2 ** 40 + 3]),
+    }
+    try:
+        ctx.set_option("msm_window_bits", c)
+        b = ctx.bases_from_scalars(curve, group, ks)
+        pts = b.download()[0]
+        for name, sc in cases.items():
+            got = []
+            for fold, run in ((0, 0), (8, 0), (8, 2), (8, 8)):
+                ctx.set_option("msm_tail_fold", fold)
+                ctx.set_option("msm_fold_run", run)
+                got.append(jac_to_affine_py(curve, group, ctx.msm(b, sc)))
+            exp, einf = cp.msm(curve, group, pts, sc, chunks=4)
+            assert all(g == got[0] for g in got) and got[0] == pt_from_limbs(curve, group, exp, einf), (curve, group, name)
+        b.free()
+    finally:
+        for name, v in (("msm_window_bits", 0), ("msm_tail_fold", 16), ("msm_fold_run", 0)):
+            ctx.set_option(name, v)
