@@ -36,9 +36,13 @@
 //                     points, XYZZ mixed additions, accumulator coordinates in LDS                          <- dominant
 //   msm_plan_large / msm_bucket_large / msm_large_combine   buckets far above the mean, one workgroup per 4096-entry task
 //   msm_bucket_merge  S > 1: fold the S equal-weight sets bucket by bucket (radix-4 tree)
+//   msm_fold          (round 5, table-backed sets of >= 2^16 buckets) row and column sums of the bucket index b = h C + l: the reduction
+//                     sum_b (b + 1) bucket[b] becomes sum_l (l + 1) COL[l] + C sum_h h ROW[h], i.e. the three kernels below over 2 sets of
+//                     C ~ sqrt(B) buckets instead of one of B
 //   msm_bucket_red    running sums over segments of L buckets + (seg L) * segment sum per lane, LDS tree per workgroup
 //   msm_window_sum    LDS tree over the per-workgroup partials of a set
 //   msm_final         (Horner over the windows when there are no tables,) XYZZ -> Jacobian, Montgomery -> canonical
+//   msm_final_fold    the same after msm_fold: COL sum + 2^log2(C) ROW sum
 // Point order inside a bucket depends on LDS-atomic arrival order; the group law is exact, so the sum
 // (compared in affine) does not.
 #pragma once
