@@ -998,11 +998,9 @@ inline uint32_t msm_tail_segment(const zkhip_ctx *ctx, uint32_t B, size_t sets, 
 // additions, and a Groth16 proof runs its G2 MSM under the G1 MSMs, which take the issue slots (50.7-51.0 -> 51.9-52.4 M constraints/s, A/B on
 // one box, three times interleaved): on by default, with its own switch msm_tail_fold_g2.
 template <class F>
-constexpr bool MSM_FOLD_COMPILED = true;
-template <class F>
 bool msm_fold_applies(const zkhip_ctx *ctx, uint32_t B, bool tables) {
     if (FieldOps<F>::WORDS > 16 && !ctx->opt_msm_tail_fold_g2) return false;
-    if (!MSM_FOLD_COMPILED<F> || !tables || ctx->opt_msm_tail_fold <= 0 || B < (1u << std::min(ctx->opt_msm_tail_fold, 30))) return false;
+    if (!tables || ctx->opt_msm_tail_fold <= 0 || B < (1u << std::min(ctx->opt_msm_tail_fold, 30))) return false;
     const MsmFold g = msm_fold_geom(ctx, B);
     const uint32_t sa = MSM_TAIL_THREADS / BucketLane<F>::LANES;
     return g.m_col >= 1 && g.m_row <= sa && g.m_col <= sa && B >= sa * g.run && g.m_row * g.run == g.C && g.m_col * g.run == g.R;
@@ -1288,8 +1286,7 @@ int msm_run_t(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n,
         if (buckets != batch_slot) ZK_HIP_CHECK(ctx, hipMemcpyAsync(batch_slot, buckets, (size_t)B * 4 * NL * 4, hipMemcpyDeviceToDevice, ctx->stream));
         return 0;
     }
-    if constexpr (MSM_FOLD_COMPILED<F>)
-        if (fold) return msm_fold_tail<F, TL, TLPB>(ctx, buckets, 1, fb, nullptr, d_out_jac);
+    if (fold) return msm_fold_tail<F, TL, TLPB>(ctx, buckets, 1, fb, nullptr, d_out_jac);
     // Small bucket sets leave lanes to spare even as pairs: the group law then runs over lane QUADS (fu_quad.hpp: 4 product steps per
     // addition instead of 7) with segments twice as long -- from 2^18 buckets down; at 2^19 the longer segments eat the gain.
     if (QuadLane<F>::AVAILABLE && ctx->opt_msm_tail_quads && (size_t)Sr * B <= ((size_t)1 << 18)) {
@@ -1404,8 +1401,7 @@ int msm_batch_tail(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *bases
         ctx->batch_ptrs.assign(d_outs, d_outs + count);
         ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_ptrs, ctx->batch_ptrs.data(), count * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
     }
-    if constexpr (MSM_FOLD_COMPILED<F>)
-        if (fold) return msm_fold_tail<F, TL, TLPB>(ctx, slots, count, fb, d_ptrs, nullptr);
+    if (fold) return msm_fold_tail<F, TL, TLPB>(ctx, slots, count, fb, d_ptrs, nullptr);
     ZK_MAX_LDS(ctx, (msm_bucket_red<TL, TLPB>), MSM_TAIL_THREADS / TLPB * 4 * NL * 4);
     ZK_LAUNCH(ctx, "msm_bucket_red", (msm_bucket_red<TL, TLPB>), dim3((unsigned)count * nblk_tail), dim3(MSM_TAIL_THREADS), (size_t)tail_slots * 4 * NL * 4, slots,
               B, L, nseg, nblk_tail, segsum);
