@@ -12,6 +12,8 @@ from .zkhip import (  # noqa: F401
     G2,
     Bases,
     Context,
+    DeviceGroup,
+    GroupBases,
     R1CS,
     ZkhipError,
     build,

@@ -243,5 +243,6 @@ int zk_ntt_run(zkhip_ctx *ctx, int curve, uint32_t *d_data, size_t log_m, size_t
                const uint64_t *coset);
 int zk_ntt_extend(zkhip_ctx *ctx, int curve, uint32_t *d_coeffs, size_t log_m, size_t batch, const uint64_t *omega, uint32_t *d_out, size_t log_k,
                   const uint64_t *omega_big);
+int zk_msm_host_reserve(zkhip_ctx *ctx, size_t n);  // zkhip.hip: ctx->msm_host_buf holds 512 B of result + n scalars
 void zk_ntt_free_tables(zkhip_ctx *ctx);
 void zk_dom_free_tables(zkhip_ctx *ctx);

@@ -286,9 +286,17 @@ int zkhip_malloc(zkhip_ctx *ctx, size_t bytes, void **dptr) {
 int zkhip_free(zkhip_ctx *ctx, void *dptr) {
     if (!ctx) return ZKHIP_ERR_INVALID;
     if (!dptr) return ZKHIP_OK;
-    ZK_TRY(check_device(ctx));
     // hipFree used to synchronise the whole device before the block could be handed out again; a block entering the cache gets the same
-    // guarantee -- no stream of ANY context (a scheme's upload stream, the prover's G2 stream) still reads or writes it
+    // guarantee -- no stream of ANY context (a scheme's upload stream, the prover's G2 stream) still reads or writes it.  The device
+    // that is drained is the one the BLOCK lives on (its owner's; ADVICE r5: a free through a context on another GPU used to drain that
+    // GPU instead), ctx's own for a block no context owns.
+    int block_device = ctx->device;
+    {
+        std::lock_guard<std::mutex> g(g_alloc_mutex);
+        auto own = g_block_owner.find(dptr);
+        if (own != g_block_owner.end()) block_device = own->second->device;
+    }
+    ZK_HIP_CHECK(ctx, hipSetDevice(block_device));
     ZK_HIP_CHECK(ctx, hipDeviceSynchronize());
     std::lock_guard<std::mutex> g(g_alloc_mutex);
     auto own = g_block_owner.find(dptr);
@@ -645,25 +653,35 @@ int zkhip_msm_batch_dev(zkhip_ctx *ctx, size_t count, const zkhip_bases *const *
     return zk_msm_run_batch(ctx, count, bases, offsets, ns, (const uint32_t *const *)d_scalars, (uint32_t *const *)d_out_jacobian);
 }
 
+}  // extern "C"
+
+// The device buffer zkhip_msm / zkhip_group_msm stage host scalars in: result in the first 512 bytes, scalars behind it.  The context keeps it
+// (grow-only, freed with the context): no hipMalloc / hipFree per call (the free is a device synchronisation), and the SAME device addresses
+// call after call, so the launch sequence replays as a HIP graph like the resident path's.
+int zk_msm_host_reserve(zkhip_ctx *ctx, size_t n) {
+    const size_t want = std::max<size_t>(1, n) * 32 + 512;
+    if (ctx->msm_host_cap >= want) return 0;
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->msm_host_buf) (void)hipFree(ctx->msm_host_buf);
+    ctx->msm_host_buf = nullptr;
+    ctx->msm_host_cap = 0;
+    zk_graphs_clear(ctx);  // graphs over the old buffer
+    if (hipMalloc((void **)&ctx->msm_host_buf, want) != hipSuccess) {
+        (void)hipGetLastError();
+        return ZKHIP_ERR_OOM;
+    }
+    ctx->msm_host_cap = want;
+    return 0;
+}
+
+extern "C" {
+
 int zkhip_msm(zkhip_ctx *ctx, const zkhip_bases *bases, size_t offset, size_t n, const uint64_t *scalars, uint64_t *out_jacobian) {
     if (!ctx || !bases || !out_jacobian || (n && !scalars)) return ZKHIP_ERR_INVALID;
     ZK_TRY(check_device(ctx));
-    // The scalars land in a buffer the context keeps (grow-only, freed with the context): no hipMalloc / hipFree per call (the free is a device
-    // synchronisation), and the SAME device addresses call after call, so the launch sequence replays as a HIP graph like the resident path's.
-    const size_t obytes = 3 * zk_coord_limbs64(bases->curve, bases->group) * 8, want = std::max<size_t>(1, n) * 32 + 512;
-    if (ctx->msm_host_cap < want) {
-        ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->msm_host_buf) (void)hipFree(ctx->msm_host_buf);
-        ctx->msm_host_buf = nullptr;
-        ctx->msm_host_cap = 0;
-        zk_graphs_clear(ctx);  // graphs over the old buffer
-        if (hipMalloc((void **)&ctx->msm_host_buf, want) != hipSuccess) {
-            (void)hipGetLastError();
-            return ZKHIP_ERR_OOM;
-        }
-        ctx->msm_host_cap = want;
-    }
-    uint32_t *d_o = ctx->msm_host_buf, *d_s = ctx->msm_host_buf + 128;  // result in the first 512 bytes, scalars behind it
+    const size_t obytes = 3 * zk_coord_limbs64(bases->curve, bases->group) * 8;
+    ZK_TRY(zk_msm_host_reserve(ctx, n));
+    uint32_t *d_o = ctx->msm_host_buf, *d_s = ctx->msm_host_buf + 128;
     if (n) ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_s, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
     ZK_TRY(zk_msm_run(ctx, bases, offset, n, d_s, d_o));
     ZK_HIP_CHECK(ctx, hipMemcpyAsync(out_jacobian, d_o, obytes, hipMemcpyDeviceToHost, ctx->stream));

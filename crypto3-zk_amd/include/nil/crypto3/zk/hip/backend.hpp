@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cerrno>
 #include <cstdint>
+#include <cstdlib>
 #include <future>
 #include <iterator>
 #include <memory>
@@ -58,7 +59,14 @@ public:
     explicit context(int device = 0) {
         check(zkhip_init(device, &ctx_), "zkhip_init");
     }
-    ~context() { zkhip_destroy(ctx_); }
+    /// a view of a context somebody else owns and outlives this object with (a member of a device_group)
+    struct borrowed_tag { };
+    context(borrowed_tag, zkhip_ctx *borrowed) : ctx_(borrowed), owns_(false) {
+        if (!borrowed) throw std::invalid_argument("context: null handle");
+    }
+    ~context() {
+        if (owns_) zkhip_destroy(ctx_);
+    }
     context(const context &) = delete;
     context &operator=(const context &) = delete;
     zkhip_ctx *get() const { return ctx_; }
@@ -96,6 +104,79 @@ public:
 
 private:
     zkhip_ctx *ctx_ = nullptr;
+    bool owns_ = true;
+};
+
+/// N GPUs behind ONE caller (include/zkhip.h, "device group").  The reference hides its parallelism inside the call -- `chunks =
+/// omp_get_max_threads()` inside r1cs_gg_ppzksnark_prover::process (prover.hpp:94-99), the loop over the batch inside
+/// kzg_commitment_scheme_v2::commit (kzg_v2.hpp:208-226) -- and so do the shim classes that take a device_group: one context per device,
+/// one host thread, the partial sums exchanged INSIDE the library (RCCL all-gather over xGMI, peer copies, or a staged copy).
+///     device_group gpus({0, 1, 2, 3, 4, 5, 6, 7});      // or device_group::from_env(): ZKHIP_DEVICES=0,1,2,3,4,5,6,7
+/// A device may be named more than once (several members on one GPU).
+class device_group {
+public:
+    explicit device_group(const std::vector<int> &devices) {
+        if (devices.empty()) throw std::invalid_argument("device_group: no devices");
+        check(zkhip_group_init(devices.data(), (int)devices.size(), &g_), "zkhip_group_init");
+        try {
+            for (std::size_t k = 0; k < devices.size(); ++k)
+                members_.emplace_back(new context(context::borrowed_tag(), zkhip_group_ctx(g_, (int)k)));
+        } catch (...) {
+            members_.clear();
+            zkhip_group_destroy(g_);
+            throw;
+        }
+    }
+    ~device_group() {
+        members_.clear();
+        zkhip_group_destroy(g_);
+    }
+    device_group(const device_group &) = delete;
+    device_group &operator=(const device_group &) = delete;
+
+    /// the devices ZKHIP_DEVICES names ("0,1,2,3"; empty when the variable is unset or malformed)
+    static std::vector<int> devices_from_env() {
+        std::vector<int> out;
+        const char *e = std::getenv("ZKHIP_DEVICES");
+        if (!e) return out;
+        const std::string all(e);
+        std::size_t at = 0;
+        while (at <= all.size()) {
+            const std::size_t end = all.find(',', at);
+            const std::string item = all.substr(at, end == std::string::npos ? std::string::npos : end - at);
+            if (item.empty() || item.find_first_not_of("0123456789") != std::string::npos) return {};
+            out.push_back(std::atoi(item.c_str()));
+            if (end == std::string::npos) break;
+            at = end + 1;
+        }
+        return out;
+    }
+
+    std::size_t size() const { return members_.size(); }
+    const context &operator[](std::size_t k) const { return *members_.at(k); }
+    /// member 0: where gathered partial sums are folded and what one-device objects of a group-aware caller live on
+    const context &root() const { return *members_.front(); }
+    zkhip_device_group *get() const { return g_; }
+    void check_group(int rc, const char *what) const {
+        if (rc != ZKHIP_OK) throw std::runtime_error(std::string(what) + ": " + zkhip_strerror(rc) + " [" + zkhip_group_last_error(g_) + "]");
+    }
+    /// ZKHIP_GROUP_AUTO / _RCCL / _PEER / _STAGED (zkhip.h)
+    void set_transport(int kind) const { check_group(zkhip_group_set_transport(g_, kind), "zkhip_group_set_transport"); }
+    int transport() const { return zkhip_group_transport(g_); }
+    /// member k's `bytes` bytes at d_send[k] -> d_recv[j] + k * bytes on every member j with a non-null d_recv[j]; in stream order
+    void all_gather(const std::vector<const void *> &d_send, const std::vector<void *> &d_recv, std::size_t bytes) const {
+        if (d_send.size() != size() || d_recv.size() != size()) throw std::invalid_argument("device_group::all_gather: one pointer per member");
+        check_group(zkhip_group_all_gather(g_, d_send.data(), d_recv.data(), bytes), "zkhip_group_all_gather");
+    }
+    /// d_dst on member dst <- d_src on member src, after src's stream so far, on dst's stream
+    void copy(std::size_t dst, void *d_dst, std::size_t src, const void *d_src, std::size_t bytes) const {
+        check_group(zkhip_group_copy(g_, (int)dst, d_dst, (int)src, d_src, bytes), "zkhip_group_copy");
+    }
+    void sync() const { check_group(zkhip_group_sync(g_), "zkhip_group_sync"); }
+
+private:
+    zkhip_device_group *g_ = nullptr;
+    std::vector<std::unique_ptr<context>> members_;
 };
 
 /// Page-locked host memory that grows on demand and is reused: transfers at link speed, no first-touch page faults on reuse.

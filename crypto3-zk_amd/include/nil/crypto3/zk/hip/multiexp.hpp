@@ -122,10 +122,36 @@ namespace detail {
         return p;
     }
 }    // namespace detail
+namespace detail {
+    inline device_group *&default_group_override() {
+        thread_local device_group *p = nullptr;
+        return p;
+    }
+}    // namespace detail
+/// The device group the context-less entry points spread over -- the reference's static `process(proving_key, primary_input,
+/// auxiliary_input)` (prover.hpp:73-75) among them --, or nullptr when the caller runs on one GPU: the group the caller installed
+/// (set_default_group), else one per host thread over the devices ZKHIP_DEVICES names when it names more than one ("0,1,2,3").
+inline const device_group *default_group() {
+    if (device_group *p = detail::default_group_override()) return p;
+    thread_local std::unique_ptr<device_group> own;
+    thread_local bool looked = false;
+    if (!looked) {
+        looked = true;
+        const std::vector<int> devices = device_group::devices_from_env();
+        if (devices.size() > 1) own.reset(new device_group(devices));
+    }
+    return own.get();
+}
+/// make `group` the calling thread's default group (nullptr: back to ZKHIP_DEVICES); the caller keeps it alive
+inline void set_default_group(device_group *group) { detail::default_group_override() = group; }
+
 /// The context the context-less overloads run on: one per host thread, created on first use on device ZKHIP_DEVICE (default 0)
-/// -- "one context per GPU per process, a context is not thread-safe" (include/zkhip.h) -- unless the caller installed its own.
+/// -- "one context per GPU per process, a context is not thread-safe" (include/zkhip.h) -- unless the caller installed its own;
+/// with a default group (above) and no ZKHIP_DEVICE it is the group's member 0.
 inline const context &default_context() {
     if (context *p = detail::default_context_override()) return *p;
+    if (!std::getenv("ZKHIP_DEVICE"))
+        if (const device_group *g = default_group()) return g->root();
     thread_local std::unique_ptr<context> own;
     if (!own) {
         const char *e = std::getenv("ZKHIP_DEVICE");

@@ -20,6 +20,9 @@ EXPORTS = [
     "zkhip_domain_choice", "zkhip_domain_fft_dev", "zkhip_domain_lagrange_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_set_domain", "zkhip_r1cs_domain_size", "zkhip_r1cs_domain_kind", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev", "zkhip_groth16_witness_h_domain_dev", "zkhip_fr_gather_dev", "zkhip_poly_resize_dev", "zkhip_fri_fold_dev", "zkhip_fri_leaves_dev", "zkhip_ec_ntt_dev",
     "zkhip_fr_vec_op_dev", "zkhip_fr_vec_affine_dev", "zkhip_fr_vec_mul_div_dev", "zkhip_fr_vec_prod_dev", "zkhip_poly_shift_dev", "zkhip_poly_eval_dev", "zkhip_poly_div_linear_dev", "zkhip_poly_div_vanishing_dev", "zkhip_poly_lincomb_dev", "zkhip_perm_grand_product_dev", "zkhip_lookup_grand_product_dev", "zkhip_lookup_sort_dev", "zkhip_perm_factor_products_dev",
+    "zkhip_group_init", "zkhip_group_destroy", "zkhip_group_size", "zkhip_group_ctx", "zkhip_group_last_error", "zkhip_group_set_transport", "zkhip_group_transport",
+    "zkhip_group_all_gather", "zkhip_group_copy", "zkhip_group_sync", "zkhip_group_bases_upload", "zkhip_group_bases_from_scalars", "zkhip_group_bases_free",
+    "zkhip_group_bases_size", "zkhip_group_bases_member", "zkhip_group_msm", "zkhip_group_ntt",
     "zkhip_profile_enable", "zkhip_profile_reset", "zkhip_profile_filter", "zkhip_profile_get", "zkhip_profile_dump",
 ]
 
@@ -103,6 +106,18 @@ def load_library() -> ctypes.CDLL:
     lib.zkhip_r1cs_domain_kind.argtypes = [ctypes.c_void_p]
     lib.zkhip_destroy.argtypes = [ctypes.c_void_p]
     lib.zkhip_bases_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.zkhip_group_destroy.argtypes = [ctypes.c_void_p]
+    lib.zkhip_group_size.argtypes = [ctypes.c_void_p]
+    lib.zkhip_group_ctx.restype = ctypes.c_void_p
+    lib.zkhip_group_ctx.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.zkhip_group_last_error.restype = ctypes.c_char_p
+    lib.zkhip_group_last_error.argtypes = [ctypes.c_void_p]
+    lib.zkhip_group_transport.argtypes = [ctypes.c_void_p]
+    lib.zkhip_group_bases_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.zkhip_group_bases_size.restype = ctypes.c_size_t
+    lib.zkhip_group_bases_size.argtypes = [ctypes.c_void_p]
+    lib.zkhip_group_bases_member.restype = ctypes.c_void_p
+    lib.zkhip_group_bases_member.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     _LIB = lib
     return lib
 
@@ -118,6 +133,9 @@ def _u64(a):
     return np.ascontiguousarray(a, dtype=np.uint64)
 
 
+_BLOCK_HOLDER = {}  # device pointer of a live Context.malloc block -> the Context that tracks it
+
+
 class Context:
     """One context per GPU per process (zkhip_init / zkhip_destroy)."""
 
@@ -129,6 +147,8 @@ class Context:
             raise ZkhipError(f"zkhip_init: {self.lib.zkhip_strerror(rc).decode()}")
         self.h = h
         self.device = device
+        self._live = set()  # blocks of malloc() not freed yet: close() hands them back (zkhip_destroy leaves live blocks alone, zkhip.h)
+        self._owns = True
 
     def _check(self, rc, what):
         if rc != 0:
@@ -136,7 +156,12 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.zkhip_destroy(self.h)
+            for p in list(getattr(self, "_live", ())):
+                _BLOCK_HOLDER.pop(p, None)
+                self.lib.zkhip_free(self.h, ctypes.c_void_p(p))
+            self._live = set()
+            if getattr(self, "_owns", True):
+                self.lib.zkhip_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -173,9 +198,14 @@ class Context:
     def malloc(self, nbytes: int) -> int:
         p = ctypes.c_void_p()
         self._check(self.lib.zkhip_malloc(self.h, ctypes.c_size_t(nbytes), ctypes.byref(p)), "zkhip_malloc")
+        self._live.add(p.value)
+        _BLOCK_HOLDER[p.value] = self
         return p.value
 
     def free(self, dptr: int):
+        holder = _BLOCK_HOLDER.pop(dptr, None)  # a block may be freed through another Context than the one that allocated it
+        if holder is not None:
+            holder._live.discard(dptr)
         self._check(self.lib.zkhip_free(self.h, ctypes.c_void_p(dptr)), "zkhip_free")
 
     def h2d(self, dptr: int, arr: np.ndarray):
@@ -475,6 +505,125 @@ class R1CS:
     def free(self):
         if self.h is not None and self.ctx.h:
             self.ctx.lib.zkhip_r1cs_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+GROUP_AUTO, GROUP_RCCL, GROUP_PEER, GROUP_STAGED = 0, 1, 2, 3
+
+
+class DeviceGroup:
+    """zkhip_group_*: one context per entry of `devices` behind one caller (a device may repeat: several members on one GPU)."""
+
+    def __init__(self, devices):
+        self.lib = load_library()
+        devices = [int(d) for d in devices]
+        arr = (ctypes.c_int * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        rc = self.lib.zkhip_group_init(arr, len(devices), ctypes.byref(h))
+        if rc != 0:
+            raise ZkhipError(f"zkhip_group_init({devices}): {self.lib.zkhip_strerror(rc).decode()}")
+        self.h = h
+        self.devices = devices
+        self.members = []
+        for k in range(len(devices)):  # the members as ordinary Context objects that do not own their handle
+            c = Context.__new__(Context)
+            c.lib, c.h, c.device, c._live, c._owns = self.lib, ctypes.c_void_p(self.lib.zkhip_group_ctx(self.h, k)), devices[k], set(), False
+            self.members.append(c)
+
+    def __len__(self):
+        return len(self.devices)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise ZkhipError(f"{what}: {self.lib.zkhip_strerror(rc).decode()} [{self.lib.zkhip_group_last_error(self.h).decode()}]")
+
+    def close(self):
+        if getattr(self, "h", None):
+            for c in self.members:
+                c.close()  # frees what was allocated through the member; the handle is the group's
+            self.lib.zkhip_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_transport(self, kind: int):
+        self._check(self.lib.zkhip_group_set_transport(self.h, int(kind)), "zkhip_group_set_transport")
+
+    def transport(self) -> int:
+        return self.lib.zkhip_group_transport(self.h)
+
+    def sync(self):
+        self._check(self.lib.zkhip_group_sync(self.h), "zkhip_group_sync")
+
+    def all_gather(self, d_send, d_recv, nbytes: int):
+        """d_send / d_recv: one device pointer per member (d_recv entries may be None)"""
+        n = len(self)
+        S = (ctypes.c_void_p * n)(*d_send)
+        R = (ctypes.c_void_p * n)(*[r if r else None for r in d_recv])
+        self._check(self.lib.zkhip_group_all_gather(self.h, S, R, ctypes.c_size_t(nbytes)), "zkhip_group_all_gather")
+
+    def copy(self, dst_member: int, d_dst: int, src_member: int, d_src: int, nbytes: int):
+        self._check(self.lib.zkhip_group_copy(self.h, dst_member, ctypes.c_void_p(d_dst), src_member, ctypes.c_void_p(d_src), ctypes.c_size_t(nbytes)),
+                    "zkhip_group_copy")
+
+    def upload_bases(self, curve: int, group: int, affine: np.ndarray, inf=None) -> "GroupBases":
+        affine = _u64(affine)
+        n = affine.shape[0] if affine.ndim == 2 else 0
+        infa = np.ascontiguousarray(inf, dtype=np.uint8) if inf is not None else None
+        h = ctypes.c_void_p()
+        self._check(self.lib.zkhip_group_bases_upload(self.h, curve, group, _p(affine), _p(infa), ctypes.c_size_t(n), ctypes.byref(h)), "zkhip_group_bases_upload")
+        return GroupBases(self, h, curve, group, n)
+
+    def bases_from_scalars(self, curve: int, group: int, scalars: np.ndarray, base=None) -> "GroupBases":
+        scalars = _u64(scalars)
+        h = ctypes.c_void_p()
+        b = _u64(base) if base is not None else None
+        self._check(self.lib.zkhip_group_bases_from_scalars(self.h, curve, group, _p(b), _p(scalars), ctypes.c_size_t(scalars.shape[0]), ctypes.byref(h)),
+                    "zkhip_group_bases_from_scalars")
+        return GroupBases(self, h, curve, group, scalars.shape[0])
+
+    def msm(self, bases: "GroupBases", scalars: np.ndarray, offset: int = 0, n=None) -> np.ndarray:
+        scalars = _u64(scalars)
+        n = scalars.shape[0] if n is None else n
+        out = np.zeros((3, coord_limbs(bases.curve, bases.group)), dtype=np.uint64)
+        self._check(self.lib.zkhip_group_msm(self.h, bases.h, ctypes.c_size_t(offset), ctypes.c_size_t(n), _p(scalars), _p(out)), "zkhip_group_msm")
+        return out
+
+    def msm_affine(self, bases: "GroupBases", scalars: np.ndarray, offset: int = 0, n=None):
+        return self.members[0].jacobian_to_affine(bases.curve, bases.group, self.msm(bases, scalars, offset, n))
+
+    def ntt(self, curve: int, data: np.ndarray, log_m: int, omega, inverse=False, coset=None) -> np.ndarray:
+        d = _u64(data).copy()
+        batch = d.shape[0] if d.ndim == 3 else 1
+        self._check(self.lib.zkhip_group_ntt(self.h, curve, _p(d), ctypes.c_size_t(log_m), ctypes.c_size_t(batch), _p(_u64(omega)), 1 if inverse else 0,
+                                             _p(_u64(coset)) if coset is not None else None), "zkhip_group_ntt")
+        return d
+
+
+class GroupBases:
+    """zkhip_group_bases: resident bases cut by point range over a group's members."""
+
+    def __init__(self, group: DeviceGroup, h, curve, grp, n):
+        self.g, self.h, self.curve, self.group, self.n = group, h, curve, grp, n
+
+    def member_first(self, k: int) -> int:
+        first = ctypes.c_size_t()
+        self.g.lib.zkhip_group_bases_member(self.h, k, ctypes.byref(first))
+        return first.value
+
+    def free(self):
+        if self.h is not None and self.g.h:
+            self.g.lib.zkhip_group_bases_free(self.g.h, self.h)
         self.h = None
 
     def __del__(self):

@@ -15,7 +15,9 @@
  *   - Group results are returned as Jacobian (X, Y, Z) with x = X/Z^2, y = Y/Z^3 and Z = 0 for infinity,
  *     the 3-coordinate shape of the reference's G::value_type; compare in affine.
  *   - omega and the coset generator are ARGUMENTS (arithmetic_params<F> lives in crypto3-algebra).
- *   - One context per GPU per process (one process per GPU); a context is not thread-safe.
+ *   - One context per GPU per process (one process per GPU); a context is not thread-safe.  A caller that wants SEVERAL GPUs behind
+ *     one call -- the shape of the reference, whose parallelism sits inside process() / commit() -- takes a device group
+ *     (zkhip_group_init below): one context per GPU, one host thread, the exchange inside the library.
  *   - The library has no CPU fallback: without a usable HIP device every call fails with
  *     ZKHIP_ERR_NO_DEVICE.
  */
@@ -76,9 +78,14 @@ int zkhip_set_option(zkhip_ctx *ctx, const char *name, int64_t value);
 int zkhip_get_option(const zkhip_ctx *ctx, const char *name, int64_t *value);
 
 /* ---- device memory (plumbing for callers that keep vectors resident) --------------------------
- * zkhip_free synchronises the device and keeps the block for the next zkhip_malloc of its size class (option "alloc_cache_mb":
- * megabytes kept per context, default 16384, 0 = hand every block back at once); the cache is emptied at zkhip_destroy and when
- * the driver runs out of memory. */
+ * zkhip_free synchronises the device the block lives on and keeps the block for the next zkhip_malloc of its size class (option
+ * "alloc_cache_mb": megabytes kept per context, default 16384, 0 = hand every block back at once); the cache is emptied at
+ * zkhip_destroy and when the driver runs out of memory.
+ * OWNERSHIP: a block belongs to the context it was allocated through, whichever context it is freed through (the free settles it with
+ * its owner).  zkhip_destroy returns the CACHED blocks to the driver and leaves the blocks the caller still holds alone: they lose
+ * their owner, stay valid, and a later zkhip_free through any live context hands them to hipFree.  A caller that wants its memory
+ * back must therefore zkhip_free every block BEFORE (or after) destroying the context -- destroy does not reclaim live blocks
+ * (the shim's shared_ptr handles may outlive their context and must not dangle). */
 int zkhip_malloc(zkhip_ctx *ctx, size_t bytes, void **dptr);
 int zkhip_free(zkhip_ctx *ctx, void *dptr);
 int zkhip_memcpy_h2d(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes);
@@ -342,6 +349,68 @@ int zkhip_lookup_sort_dev(zkhip_ctx *ctx, size_t k_in, const void *const *d_inpu
  * overwrites d_acc. */
 int zkhip_poly_lincomb_dev(zkhip_ctx *ctx, int curve, size_t count, const void *const *d_polys, const size_t *lens, const uint64_t *coeffs,
                            size_t taps, void *d_acc, size_t acc_len, int accumulate);
+
+/* ---- device group: N GPUs behind ONE caller ---------------------------------------------------------------------
+ * The reference hides all of its parallelism INSIDE the call: r1cs_gg_ppzksnark_prover::process splits every multiexp into
+ * `chunks = omp_get_max_threads()` pieces (r1cs_gg_ppzksnark/prover.hpp:94-99, 108-139) and kzg_commitment_scheme_v2::commit loops
+ * over the batch (commitments/polynomial/kzg_v2.hpp:208-226) -- the caller sees one call and one result.  A group is the same for
+ * GPUs: one zkhip_ctx per entry of device_ids (SURVEY 8b sketched this as `zkhip_init(const int *device_ids, int n_dev, ...)`),
+ * all driven from ONE host thread (every entry point of this ABI is asynchronous on its context's stream), with the one exchange the
+ * path has -- the partial sums of a sharded multiexp, <= 864 bytes per member for a Groth16 proof -- INSIDE the library.
+ * device_ids may name a device more than once (several members on one GPU: a 1-GPU box, tests).
+ * Members are ordinary contexts (zkhip_group_ctx): every other entry point of this header works on them; they are destroyed with
+ * the group.  A group is not thread-safe. */
+typedef struct zkhip_device_group zkhip_device_group;
+int zkhip_group_init(const int *device_ids, int n_dev, zkhip_device_group **out);
+void zkhip_group_destroy(zkhip_device_group *g);
+int zkhip_group_size(const zkhip_device_group *g);
+zkhip_ctx *zkhip_group_ctx(const zkhip_device_group *g, int member);
+const char *zkhip_group_last_error(const zkhip_device_group *g);
+/* How the exchanges travel.
+ *   ZKHIP_GROUP_RCCL    one single-process RCCL communicator per member (ncclCommInitAll) and a grouped ncclAllGather on the members'
+ *                       streams over xGMI; librccl.so is loaded on first use (dlopen), so a single-GPU caller never pays for it.
+ *                       Needs pairwise distinct devices (RCCL refuses two ranks on one GPU): ZKHIP_ERR_INVALID otherwise.
+ *   ZKHIP_GROUP_PEER    stream-ordered peer copies (hipMemcpyPeerAsync behind an event per source stream; a plain device-to-device
+ *                       copy between members that share a GPU).  No host synchronisation.
+ *   ZKHIP_GROUP_STAGED  through one page-locked host buffer: D2H on every member, a host synchronisation, H2D.  The fallback that
+ *                       works wherever HIP works.
+ *   ZKHIP_GROUP_AUTO    (default) RCCL when the group has more than one member on pairwise distinct devices and librccl loads,
+ *                       PEER otherwise.
+ * zkhip_group_transport returns what AUTO resolved to (RCCL is tried at the first exchange). */
+enum zkhip_group_transport_kind { ZKHIP_GROUP_AUTO = 0, ZKHIP_GROUP_RCCL = 1, ZKHIP_GROUP_PEER = 2, ZKHIP_GROUP_STAGED = 3 };
+int zkhip_group_set_transport(zkhip_device_group *g, int transport);
+int zkhip_group_transport(const zkhip_device_group *g);
+/* All-gather in stream order: the `bytes` bytes at d_send[k] (member k's device memory) arrive at d_recv[j] + k * bytes for every
+ * member j whose d_recv[j] is not NULL (a NULL entry: that member receives nothing -- the one-host-thread caller usually needs the
+ * result on member 0 only).  d_send / d_recv: HOST arrays of zkhip_group_size device pointers.  Ordered after everything enqueued
+ * on the members' streams so far; with RCCL / PEER nothing blocks the host.  This is the exchange SURVEY 8e names (ncclAllGather
+ * of 144- / 288-byte Jacobian partial sums + a local fold: RCCL has no elliptic-curve reduction). */
+int zkhip_group_all_gather(zkhip_device_group *g, const void *const *d_send, void *const *d_recv, size_t bytes);
+/* d_dst (member dst) <- d_src (member src), `bytes` bytes, ordered after src's stream so far, enqueued on dst's stream.  The source
+ * must stay untouched until dst's stream has passed the copy (zkhip_sync on dst, or a later exchange). */
+int zkhip_group_copy(zkhip_device_group *g, int dst_member, void *d_dst, int src_member, const void *d_src, size_t bytes);
+int zkhip_group_sync(zkhip_device_group *g); /* every member's stream has drained */
+/* Resident bases cut by POINT RANGE over the members: member k holds points [k n / N, (k + 1) n / N) (balanced; the
+ * first n mod N members hold one more) with their own window tables.  Same arguments as zkhip_bases_upload. */
+typedef struct zkhip_group_bases zkhip_group_bases;
+int zkhip_group_bases_upload(zkhip_device_group *g, int curve, int group, const uint64_t *affine_xy, const uint8_t *is_infinity /* nullable */, size_t n,
+                             zkhip_group_bases **out);
+int zkhip_group_bases_from_scalars(zkhip_device_group *g, int curve, int group, const uint64_t *base_affine_xy /* nullable */, const uint64_t *scalars, size_t n,
+                                   zkhip_group_bases **out);
+void zkhip_group_bases_free(zkhip_device_group *g, zkhip_group_bases *b);
+size_t zkhip_group_bases_size(const zkhip_group_bases *b);
+/* member k's slice as an ordinary bases object (owned by the group object); *first receives the index of its first point */
+const zkhip_bases *zkhip_group_bases_member(const zkhip_group_bases *b, int member, size_t *first /* nullable */);
+/* zkhip_msm over the group: algebra::multiexp<BDLO12>(b0, b1, s0, s1, chunks) with the chunks on N GPUs (prover.hpp:94-99 chooses
+ * chunks = omp_get_max_threads(); here a chunk is a member's point range).  Every member receives its slice of the scalars and
+ * runs the whole pipeline over its points; the partial sums are all-gathered to member 0, folded there
+ * (zkhip_jacobian_sum_dev) and returned.  Same result as zkhip_msm over one device (compare in affine). */
+int zkhip_group_msm(zkhip_device_group *g, const zkhip_group_bases *bases, size_t offset, size_t n, const uint64_t *scalars /* host, n x 4 */,
+                    uint64_t *out_jacobian /* host */);
+/* zkhip_ntt with the batch dealt over the members in contiguous ranges ("partition by polynomial, no collective"):
+ * member k transforms vectors [k batch / N, (k + 1) batch / N).  Bit-identical to zkhip_ntt. */
+int zkhip_group_ntt(zkhip_device_group *g, int curve, uint64_t *data /* host, batch x m x 4 */, size_t log_m, size_t batch, const uint64_t *omega, int inverse,
+                    const uint64_t *coset_gen /* nullable */);
 
 /* ---- profiling (HIP events on the context's stream around every kernel launch) ------------------ */
 int zkhip_profile_enable(zkhip_ctx *ctx, int on);
