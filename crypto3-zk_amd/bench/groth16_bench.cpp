@@ -56,21 +56,19 @@ size_t g_dom_m = 0;
 uint64_t g_last_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // domain kind, domain points, A / B / H / L query sizes of this rank, N, n
 double g_last_instance_ms = 0;    // building the synthetic constraint system + assignment of the last run (not part of *setup_ms)
 
+/// the synthetic instance of both bench entry points: the reference's generate_r1cs_example_with_field_input family
+/// (r1cs_examples.hpp:77-140), M constraints, n public inputs, N = M + 2 variables; returns the generator state for (r, s)
 template <typename Curve>
-int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gather, size_t M, size_t n, uint64_t seed, int steps, const uint64_t *omega,
-                    const uint64_t *coset, double *times, double *setup_ms, int *verified, char *prof, size_t prof_cap) {
+SplitMix build_instance(size_t M, size_t n, uint64_t seed, r1cs_constraint_system<Curve> &cs, std::vector<typename curve_adapter<Curve>::scalar_value_type> &full) {
     typedef curve_adapter<Curve> A;
     typedef typename A::scalar_value_type Fr;
-    auto t0 = std::chrono::steady_clock::now();
     SplitMix rng {seed};
     auto rnd = [&]() {    // < 2^252 < r for both curves: canonical
         uint64_t w[4] = {rng.next(), rng.next(), rng.next(), rng.next() & 0x0fffffffffffffffULL};
         return A::scalar_from_limbs(w);
     };
-    r1cs_constraint_system<Curve> cs;
     cs.primary_input_size = n;
     cs.auxiliary_input_size = 2 + M - n;
-    std::vector<Fr> full;
     Fr a = rnd(), b = rnd();
     full.push_back(a);
     full.push_back(b);
@@ -106,6 +104,22 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
         cs.add_constraint(c);
         full.push_back(fin * fin);
     }
+    return rng;
+}
+
+template <typename Curve>
+int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gather, size_t M, size_t n, uint64_t seed, int steps, const uint64_t *omega,
+                    const uint64_t *coset, double *times, double *setup_ms, int *verified, char *prof, size_t prof_cap) {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::scalar_value_type Fr;
+    auto t0 = std::chrono::steady_clock::now();
+    r1cs_constraint_system<Curve> cs;
+    std::vector<Fr> full;
+    SplitMix rng = build_instance<Curve>(M, n, seed, cs, full);
+    auto rnd = [&]() {    // < 2^252 < r for both curves: canonical
+        uint64_t w[4] = {rng.next(), rng.next(), rng.next(), rng.next() & 0x0fffffffffffffffULL};
+        return A::scalar_from_limbs(w);
+    };
     std::vector<Fr> primary(full.begin(), full.begin() + n), auxiliary(full.begin() + n, full.end());
 
     context ctx(device);
@@ -211,9 +225,77 @@ int groth16_bench_t(int device, size_t rank, size_t world, all_gather_fn all_gat
     return 0;
 }
 
+// ONE proof over a DEVICE GROUP (r1cs_gg_ppzksnark_proving_key_group_hip): `n_dev` contexts in THIS process, one host thread, the exchange
+// inside the library -- BASELINE cfg 4's arrangement as a C++ caller of the drop-in class reaches it.  The key is generated slice by
+// slice on the members' GPUs; every timed proof must equal the first (same r, s) and the proof the trapdoor dictates.
+// info[0..3]: host ms of the last proof's phases (launches | host products | exchange + wait | assembly), info[4]: the transport used.
+template <typename Curve>
+int groth16_group_bench_t(const int *devices, int n_dev, int transport, size_t M, size_t n, uint64_t seed, int steps, const uint64_t *omega, const uint64_t *coset,
+                          double *times, double *setup_ms, int *verified, double *info) {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::scalar_value_type Fr;
+    r1cs_constraint_system<Curve> cs;
+    std::vector<Fr> full;
+    SplitMix rng = build_instance<Curve>(M, n, seed, cs, full);
+    auto rnd = [&]() {
+        uint64_t w[4] = {rng.next(), rng.next(), rng.next(), rng.next() & 0x0fffffffffffffffULL};
+        return A::scalar_from_limbs(w);
+    };
+    std::vector<Fr> primary(full.begin(), full.begin() + n), auxiliary(full.begin() + n, full.end());
+    device_group grp(std::vector<int>(devices, devices + n_dev));
+    grp.set_transport(transport);
+    domain_params<Curve> dom {A::scalar_from_limbs(omega), A::scalar_from_limbs(coset)};
+    dom.kind = g_dom_kind;
+    dom.m = g_dom_m;
+    SplitMix key_rng {seed * 1000003 + 1};
+    auto rnd_key = [&]() {
+        uint64_t w[4] = {key_rng.next(), key_rng.next(), key_rng.next(), key_rng.next() & 0x0fffffffffffffffULL};
+        return A::scalar_from_limbs(w);
+    };
+    const Fr t = rnd_key(), alpha = rnd_key(), beta = rnd_key(), gamma = rnd_key(), delta = rnd_key();
+    auto t0 = std::chrono::steady_clock::now();
+    auto key = r1cs_gg_ppzksnark_generator_hip<Curve>::deterministic_basic_process(grp, cs, dom, t, alpha, beta, gamma, delta);
+    grp.sync();
+    *setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const Fr r = rnd(), s = rnd();
+    typedef r1cs_gg_ppzksnark_prover_hip<Curve> prover;
+    typename prover::proof_type proof, first;
+    int differing = 0;
+    (void)prover::process(*key->device, primary, auxiliary, r, s);    // work buffers, side streams, the communicator: outside the timed proofs
+    for (int k = 0; k < steps; ++k) {
+        auto t1 = std::chrono::steady_clock::now();
+        proof = prover::process(*key->device, primary, auxiliary, r, s);
+        times[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+        if (k == 0) first = proof;
+        else if (!(proof.g_A == first.g_A && proof.g_B == first.g_B && proof.g_C == first.g_C)) ++differing;
+    }
+    for (int i = 0; i < 4; ++i) info[i] = key->device->last_phase_ms[i];
+    info[4] = grp.transport();
+    if (verified) {
+        const auto e = groth16_proof_exponents<Curve>(key->parts[0]->host.constraint_system, dom, primary, auxiliary, t, alpha, beta, delta, r, s);
+        std::vector<Fr> one = {Fr::one()};
+        const auto g1 = device_bases<Curve, ZKHIP_G1>::from_scalars(grp[0], one.begin(), one.end()).at(0);
+        const auto g2 = device_bases<Curve, ZKHIP_G2>::from_scalars(grp[0], one.begin(), one.end()).at(0);
+        *verified = (differing == 0 && proof.g_A == e[0] * g1 && proof.g_B == e[1] * g2 && proof.g_C == e[2] * g1) ? 1 : 0;
+    }
+    return 0;
+}
+
 }    // namespace
 
 extern "C" {
+
+/* one proof over a device group of THIS process (see groth16_group_bench_t); info: 5 doubles */
+int zkhip_bench_groth16_group(const int *devices, int n_dev, int transport, int curve, size_t M, size_t n, uint64_t seed, int steps, const uint64_t *omega,
+                              const uint64_t *coset, double *times, double *setup_ms, int *verified, double *info) {
+    try {
+        if (curve == ZKHIP_BLS12_381) return groth16_group_bench_t<bls12_381>(devices, n_dev, transport, M, n, seed, steps, omega, coset, times, setup_ms, verified, info);
+        return groth16_group_bench_t<alt_bn128_254>(devices, n_dev, transport, M, n, seed, steps, omega, coset, times, setup_ms, verified, info);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkhip_bench_groth16_group: %s\n", e.what());
+        return -1;
+    }
+}
 
 void zkhip_bench_set_after_setup(void (*fn)()) { g_after_setup = fn; }
 /* lanes > 1: after the one-at-a-time proofs, zkhip_bench_groth16 runs `lanes` provers at once over the same key (steps proofs each);

@@ -140,12 +140,14 @@ int zkhip_set_stream(zkhip_ctx *ctx, void *hip_stream) {
 
 int zkhip_sync(zkhip_ctx *ctx) {
     if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
     ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return ZKHIP_OK;
 }
 
 int zkhip_device_status(zkhip_ctx *ctx, uint32_t *flags) {
     if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
     uint32_t f = 0;
     ZK_HIP_CHECK(ctx, hipMemcpyAsync(&f, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -321,29 +323,33 @@ int zkhip_free(zkhip_ctx *ctx, void *dptr) {
 }
 int zkhip_memcpy_h2d(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
     ZK_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return ZKHIP_OK;
 }
 int zkhip_memcpy_h2d_async(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
     ZK_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     return ZKHIP_OK;
 }
 int zkhip_host_alloc(zkhip_ctx *ctx, size_t bytes, void **hptr) {
     if (!ctx || !hptr) return ZKHIP_ERR_INVALID;
     ZK_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    ZK_HIP_CHECK(ctx, hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    ZK_HIP_CHECK(ctx, hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocPortable));  // page-locked for EVERY device: a group's members upload from one staging buffer
     return ZKHIP_OK;
 }
 int zkhip_host_free(zkhip_ctx *ctx, void *hptr) {
     if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
     ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ZK_HIP_CHECK(ctx, hipHostFree(hptr));
     return ZKHIP_OK;
 }
 int zkhip_memcpy_d2h(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
     ZK_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return ZKHIP_OK;
@@ -351,12 +357,14 @@ int zkhip_memcpy_d2h(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes) {
 
 int zkhip_memcpy_d2h_async(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
     ZK_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return ZKHIP_OK;
 }
 
 int zkhip_memcpy_d2d_async(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
     ZK_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return ZKHIP_OK;
 }
@@ -632,7 +640,10 @@ size_t zkhip_bases_size(const zkhip_bases *b) { return b ? b->n : 0; }
 
 void zkhip_bases_free(zkhip_ctx *ctx, zkhip_bases *b) {
     if (!b) return;
-    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
     (void)hipFree(b->d);
     delete b;
 }

@@ -343,6 +343,19 @@ public:
         check(zkhip_bases_download(ctx_->get(), b_, i, 1, xy.data(), &inf), "zkhip_bases_download", ctx_->get());
         return G::from_affine(xy.data(), inf != 0);
     }
+    /// a copy of these bases on ANOTHER context -- another GPU of a device group (an SRS replicated over the members): through the
+    /// canonical affine form (one download, one upload; no conversion of group values on the host)
+    device_bases replicate(const context &other) const {
+        const std::size_t cl = Group == ZKHIP_G1 ? adapter::g1_coord_limbs : adapter::g2_coord_limbs;
+        std::vector<std::uint64_t> xy(std::max<std::size_t>(1, size_) * 2 * cl);
+        std::vector<std::uint8_t> inf(std::max<std::size_t>(1, size_));
+        if (size_) check(zkhip_bases_download(ctx_->get(), b_, 0, size_, xy.data(), inf.data()), "zkhip_bases_download", ctx_->get());
+        device_bases r;
+        r.ctx_ = &other;
+        r.size_ = size_;
+        check(zkhip_bases_upload(other.get(), adapter::id, Group, xy.data(), inf.data(), size_, &r.b_), "zkhip_bases_upload", other.get());
+        return r;
+    }
     /// a second handle on the SAME resident points (they are read-only once built): for another prover lane on the same GPU
     /// (its own context / stream); `o` keeps the ownership and must outlive the alias
     static device_bases alias(const device_bases &o) {
@@ -378,6 +391,39 @@ private:
     zkhip_bases *b_ = nullptr;
     std::size_t size_ = 0;
     bool owner_ = true;
+};
+
+/// Resident bases cut by point range over a device group's members (zkhip_group_bases_upload): the `bases_begin, bases_end` of a
+/// multiexp whose chunks are GPUs.
+template <typename CurveType, int Group>
+class device_group_bases {
+public:
+    typedef curve_adapter<CurveType> adapter;
+    template <typename InputIt>
+    device_group_bases(const device_group &group, InputIt first, InputIt last) : group_(&group) {
+        const std::size_t cl = Group == ZKHIP_G1 ? adapter::g1_coord_limbs : adapter::g2_coord_limbs;
+        std::vector<std::uint64_t> xy;
+        std::vector<std::uint8_t> inf;
+        for (InputIt it = first; it != last; ++it) {
+            xy.resize(xy.size() + 2 * cl);
+            inf.push_back(adapter::point_to_affine_limbs(*it, xy.data() + xy.size() - 2 * cl) ? 0 : 1);
+        }
+        size_ = inf.size();
+        group.check_group(zkhip_group_bases_upload(group.get(), adapter::id, Group, xy.data(), inf.data(), size_, &b_), "zkhip_group_bases_upload");
+    }
+    ~device_group_bases() {
+        if (b_) zkhip_group_bases_free(group_->get(), b_);
+    }
+    device_group_bases(const device_group_bases &) = delete;
+    device_group_bases &operator=(const device_group_bases &) = delete;
+    const zkhip_group_bases *get() const { return b_; }
+    std::size_t size() const { return size_; }
+    const device_group &group() const { return *group_; }
+
+private:
+    const device_group *group_ = nullptr;
+    zkhip_group_bases *b_ = nullptr;
+    std::size_t size_ = 0;
 };
 
 }    // namespace hip

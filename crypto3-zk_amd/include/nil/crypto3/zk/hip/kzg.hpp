@@ -13,6 +13,7 @@
 #ifndef ZKHIP_SHIM_KZG_HPP
 #define ZKHIP_SHIM_KZG_HPP
 
+#include <memory>
 #include <vector>
 
 #include "multiexp.hpp"
@@ -78,6 +79,38 @@ private:
         std::vector<Fr> p(count, Fr::one());
         for (std::size_t i = 1; i < count; ++i) p[i] = p[i - 1] * alpha;
         return device_bases<CurveType, Group>::from_scalars(c, p.begin(), p.end());
+    }
+};
+
+/// kzg::params_type over a device group (backend.hpp): the commitment key REPLICATED on every member -- SURVEY 8e: "each GPU then MSMs its
+/// own columns against a replicated SRS and only 96-byte commitments are gathered".  A scheme constructed from it
+/// (kzg_commitment_scheme[_v2]_hip, kzg_v2.hpp) deals the columns of commit(batch) over the members; everything else runs on member 0
+/// (`root()`), where the coefficient forms are collected for proof_eval.
+template <typename CurveType>
+struct kzg_params_group_hip {
+    typedef multiexp_method_hip multiexp_method;
+    /// the key from a range of group values: converted and uploaded once (member 0), replicated device to device from there
+    template <typename InputIt>
+    kzg_params_group_hip(const device_group &group, InputIt ck_first, InputIt ck_last) : group(group) {
+        members.emplace_back(new kzg_params_hip<CurveType>(group[0], ck_first, ck_last));
+        replicate();
+    }
+    /// params_type(d, t, alpha) (kzg.hpp:262-275) with the powers computed on member 0
+    kzg_params_group_hip(const device_group &group, std::size_t d, const typename curve_adapter<CurveType>::scalar_value_type &alpha) : group(group) {
+        typedef typename curve_adapter<CurveType>::scalar_value_type Fr;
+        std::vector<Fr> p(d, Fr::one());
+        for (std::size_t i = 1; i < d; ++i) p[i] = p[i - 1] * alpha;
+        members.emplace_back(new kzg_params_hip<CurveType>(group[0], device_bases<CurveType, ZKHIP_G1>::from_scalars(group[0], p.begin(), p.end())));
+        replicate();
+    }
+    const kzg_params_hip<CurveType> &root() const { return *members.front(); }
+    const device_group &group;
+    std::vector<std::unique_ptr<kzg_params_hip<CurveType>>> members;    // members[k] lives on group[k]
+
+private:
+    void replicate() {
+        for (std::size_t k = 1; k < group.size(); ++k)
+            members.emplace_back(new kzg_params_hip<CurveType>(group[k], members[0]->commitment_key.replicate(group[k])));
     }
 };
 

@@ -26,7 +26,9 @@
 
 #include <algorithm>
 #include <deque>
+#include <exception>
 #include <functional>
+#include <future>
 #include <iterator>
 #include <map>
 #include <memory>
@@ -152,6 +154,14 @@ typename curve_adapter<CurveType>::g1_value_type kzg_proof_eval(const kzg_params
 /// over (prover.hpp:137-138, 316) included.
 template <typename CurveType, typename TranscriptType, typename PolynomialType = polynomial_dfs<CurveType>>
 class kzg_polys_evaluator_hip {
+protected:
+    /// a committed batch on the device: the coefficient forms of its polynomials, one behind the other
+    struct device_batch {
+        std::shared_ptr<void> data;
+        std::vector<std::size_t> offset, len;    // in elements
+        void *at(std::size_t i) const { return static_cast<char *>(data.get()) + 32 * offset[i]; }
+    };
+
 public:
     typedef curve_adapter<CurveType> adapter;
     typedef CurveType curve_type;
@@ -173,6 +183,14 @@ public:
     /// the reference's constructor argument list (kzg.hpp:667, kzg_v2.hpp:94: the parameters alone): the roots of unity from the curve adapter
     explicit kzg_polys_evaluator_hip(const params_type &kzg_params) :
         _params(kzg_params), _root_of_unity([](std::size_t log_n) { return adapter::root_of_unity(log_n); }) { }
+    /// Over a DEVICE GROUP: commit(batch) deals the batch's columns over the group's members (each transforms and commits its columns
+    /// against its replica of the key; only commitments and -- device to device -- the coefficient forms travel to member 0), the rest
+    /// of the scheme runs on member 0.  The reference's commit is a loop over the batch inside the call (kzg_v2.hpp:208-226): so is this.
+    typedef kzg_params_group_hip<CurveType> group_params_type;
+    kzg_polys_evaluator_hip(const group_params_type &group_params, root_of_unity_type root_of_unity) :
+        _params(group_params.root()), _root_of_unity(std::move(root_of_unity)), _group_params(&group_params) { }
+    explicit kzg_polys_evaluator_hip(const group_params_type &group_params) :
+        _params(group_params.root()), _root_of_unity([](std::size_t log_n) { return adapter::root_of_unity(log_n); }), _group_params(&group_params) { }
 
     const params_type &get_commitment_params() const { return _params; }
     preprocessed_data_type preprocess(transcript_type &) const { return true; }
@@ -239,6 +257,7 @@ public:
     /// commit(index) (kzg_v2.hpp:208-226): one commitment per polynomial of the batch; the coefficient forms stay
     /// on the device for proof_eval.
     commitment_type commit(std::size_t index) {
+        if (_group_params && _group_params->members.size() > 1) return commit_group(index);
         const context &ctx = _params.ctx;
         const std::vector<const poly_type *> &polys = _polys[index];
         const auto &resident = _resident[index];    // position -> a polynomial that is already on the device (polys[position] == nullptr)
@@ -301,17 +320,150 @@ public:
             ctx.d2h(res.data(), d_res.get(), res.size() * 8);
             for (std::size_t i = 0; i < count; ++i) out.push_back(is_zero(i) ? single_commitment_type::zero() : adapter::g1_from_jacobian(&res[i * jl]));
         }
-        _ind_commitments[index] = out;
+        return commit_done(index, std::move(db), std::move(out));
+    }
+
+private:
+    /// state_commited (batched_commitment.hpp:163-166).  The host polynomials are not read again: lent ones may go; copies and
+    /// handed-over ones are released with the scheme (freeing gigabytes of host memory here costs ~100 ms: more than the upload)
+    commitment_type commit_done(std::size_t index, device_batch &&db, commitment_type &&out) {
+        const std::size_t count = _polys[index].size();
+        _ind_commitments[index] = std::move(out);
         _dev[index] = std::move(db);
-        /* state_commited (batched_commitment.hpp:163-166).  The host polynomials are not read again: lent ones may go; copies and
-           handed-over ones are released with the scheme (freeing gigabytes of host memory here costs ~100 ms: more than the upload) */
         _locked[index] = true;
-        _points[index].resize(polys.size());
+        _points[index].resize(count);
         _polys[index].clear();    // no pointer to a lent polynomial outlives the call
         _resident[index].clear();
         _resident_coefficients[index].clear();
         return _ind_commitments[index];
     }
+
+    /// commit(index) over the device group: member k takes the k-th contiguous range of the batch's columns.  Resident polynomials (they
+    /// live on member 0's GPU) are dealt first, device to device, from this thread; then every member runs on a host thread of its own --
+    /// uploads of its host columns (the members' PCIe links work side by side), one batched inverse transform per run of equal sizes, its
+    /// multiexps as one batch, one small download of its commitments -- and what is left for this thread is to pull the coefficient forms
+    /// of the other members into member 0's batch buffer, where proof_eval expects them.
+    commitment_type commit_group(std::size_t index) {
+        const group_params_type &gp = *_group_params;
+        const device_group &group = gp.group;
+        const std::size_t world = gp.members.size(), jl = 3 * adapter::g1_coord_limbs;
+        const context &root = _params.ctx;
+        const std::vector<const poly_type *> &polys = _polys[index];
+        const auto &resident = _resident[index];
+        const auto &resident_c = _resident_coefficients[index];
+        auto is_coefficients = [&resident_c](std::size_t i) { return resident_c.count(i) != 0; };
+        auto is_zero = [&resident_c](std::size_t i) {
+            auto it = resident_c.find(i);
+            return it != resident_c.end() && it->second.known_zero();
+        };
+        const std::size_t count = polys.size();
+        device_batch db;
+        std::size_t total = 0;
+        for (std::size_t i = 0; i < count; ++i) {
+            const std::size_t sz = polys[i] ? polys[i]->size() : is_coefficients(i) ? resident_c.at(i).size() : resident.at(i).size();
+            if (sz == 0 || (sz & (sz - 1))) throw std::runtime_error("commit: polynomial_dfs size must be a power of two");
+            if (sz > _params.commitment_key.size()) throw std::runtime_error("commit: polynomial longer than the commitment key");
+            db.offset.push_back(total);
+            db.len.push_back(sz);
+            total += sz;
+        }
+        db.data = root.alloc(std::max<std::size_t>(1, total) * 32);
+        /* member k's columns [lo, hi): a contiguous range, so its coefficient forms are ONE contiguous piece of the batch buffer */
+        struct part {
+            std::size_t lo = 0, hi = 0;
+            std::shared_ptr<void> data, d_res;    // data: the member's own buffer (member 0 works in the batch buffer itself)
+            char *base = nullptr;
+            std::vector<std::uint64_t> res;
+        };
+        std::vector<part> parts(world);
+        for (std::size_t k = 0; k < world; ++k) {
+            part &pt = parts[k];
+            pt.lo = count / world * k + std::min(k, count % world);
+            pt.hi = count / world * (k + 1) + std::min(k + 1, count % world);
+            if (pt.hi == pt.lo) continue;
+            const std::size_t elems = (pt.hi < count ? db.offset[pt.hi] : total) - db.offset[pt.lo];
+            if (k == 0) pt.base = static_cast<char *>(db.at(pt.lo));
+            else {
+                pt.data = group[k].alloc(elems * 32);
+                pt.base = static_cast<char *>(pt.data.get());
+            }
+            pt.d_res = group[k].alloc((pt.hi - pt.lo) * jl * 8);
+            pt.res.resize((pt.hi - pt.lo) * jl);
+            /* resident polynomials: off member 0's GPU, in the order of this (the group's) thread */
+            for (std::size_t p = pt.lo; p < pt.hi; ++p) {
+                if (polys[p]) continue;
+                const void *src = is_coefficients(p) ? resident_c.at(p).data() : resident.at(p).data();
+                group.copy(k, pt.base + 32 * (db.offset[p] - db.offset[pt.lo]), 0, src, db.len[p] * 32);
+            }
+        }
+        auto member_work = [&](std::size_t k) {
+            part &pt = parts[k];
+            if (pt.hi == pt.lo) return;
+            const context &ctx = group[k];
+            const kzg_params_hip<CurveType> &params = *gp.members[k];
+            auto at = [&](std::size_t p) { return pt.base + 32 * (db.offset[p] - db.offset[pt.lo]); };
+            for (std::size_t p = pt.lo; p < pt.hi; ++p)
+                if (polys[p]) upload_scalars<adapter>(ctx, at(p), detail::poly_data<adapter>(*polys[p]), polys[p]->size());
+            for (std::size_t i = pt.lo; i < pt.hi;) {
+                std::size_t j = i;
+                while (j < pt.hi && db.len[j] == db.len[i] && is_coefficients(j) == is_coefficients(i) && is_zero(j) == is_zero(i)) ++j;
+                if (!is_coefficients(i)) {
+                    std::size_t log_n = 0;
+                    while (((std::size_t)1 << log_n) < db.len[i]) ++log_n;
+                    std::uint64_t w[4];
+                    adapter::scalar_to_limbs(_root_of_unity(log_n), w);
+                    check(zkhip_ntt_dev(ctx.get(), adapter::id, at(i), log_n, j - i, w, 1, nullptr), "zkhip_ntt_dev", ctx.get());
+                }
+                if (!is_zero(i)) {
+                    const std::size_t cnt = j - i;
+                    std::vector<const zkhip_bases *> qb(cnt, params.commitment_key.get());
+                    std::vector<std::size_t> qo(cnt, 0), qn(db.len.begin() + i, db.len.begin() + j);
+                    std::vector<const void *> qs(cnt);
+                    std::vector<void *> qr(cnt);
+                    for (std::size_t c = 0; c < cnt; ++c) {
+                        qs[c] = at(i + c);
+                        qr[c] = static_cast<std::uint64_t *>(pt.d_res.get()) + (i + c - pt.lo) * jl;
+                    }
+                    check(zkhip_msm_batch_dev(ctx.get(), cnt, qb.data(), qo.data(), qn.data(), qs.data(), qr.data()), "zkhip_msm_batch_dev", ctx.get());
+                }
+                i = j;
+            }
+            ctx.d2h(pt.res.data(), pt.d_res.get(), pt.res.size() * 8);    // synchronises this member's stream
+        };
+        {
+            std::vector<std::future<void>> others;
+            for (std::size_t k = 1; k < world; ++k) others.push_back(std::async(std::launch::async, member_work, k));
+            std::exception_ptr failed;
+            try {
+                member_work(0);
+            } catch (...) {
+                failed = std::current_exception();
+            }
+            for (auto &f : others) {
+                try {
+                    f.get();
+                } catch (...) {
+                    if (!failed) failed = std::current_exception();
+                }
+            }
+            if (failed) std::rethrow_exception(failed);
+        }
+        /* the other members' coefficient forms join the batch on member 0 (xGMI peer copies; proof_eval reads them there) */
+        for (std::size_t k = 1; k < world; ++k) {
+            const part &pt = parts[k];
+            if (pt.hi == pt.lo) continue;
+            const std::size_t elems = (pt.hi < count ? db.offset[pt.hi] : total) - db.offset[pt.lo];
+            group.copy(0, db.at(pt.lo), k, pt.base, elems * 32);
+        }
+        root.sync();    // the copies ran on member 0's stream: the members' buffers may go
+        commitment_type out;
+        for (std::size_t k = 0; k < world; ++k)
+            for (std::size_t p = parts[k].lo; p < parts[k].hi; ++p)
+                out.push_back(is_zero(p) ? single_commitment_type::zero() : adapter::g1_from_jacobian(&parts[k].res[(p - parts[k].lo) * jl]));
+        return commit_done(index, std::move(db), std::move(out));
+    }
+
+public:
 
     /// polynomials per upload chunk (0: the whole batch in one transfer, one shared bucket reduction)
     std::size_t upload_chunk = 10;
@@ -319,12 +471,6 @@ public:
     const std::map<std::size_t, commitment_type> &commitments() const { return _ind_commitments; }
 
 protected:
-    struct device_batch {
-        std::shared_ptr<void> data;
-        std::vector<std::size_t> offset, len;    // in elements
-        void *at(std::size_t i) const { return static_cast<char *>(data.get()) + 32 * offset[i]; }
-    };
-
     /// multiexp(commitment_key[0 .. len), coefficients) for polynomials [first, last) of a resident batch, as one device batch
     /// (enqueued only); results: Jacobian points at d_res + i * 3 * coordinate limbs
     void commit_resident(const device_batch &db, std::size_t first, std::size_t last, void *d_res) const {
@@ -467,6 +613,7 @@ protected:
     std::map<std::size_t, commitment_type> _ind_commitments;
     std::vector<scalar_value_type> _merged_points;
     mutable std::unique_ptr<context> _upload_ctx;
+    const group_params_type *_group_params = nullptr;    // set: commit(batch) deals its columns over this group's members
 };
 
 /// kzg_commitment_scheme_v2 (kzg_v2.hpp:56-360): two quotient commitments (pi_1, pi_2)
@@ -494,6 +641,9 @@ public:
 
     kzg_commitment_scheme_v2_hip(const params_type &kzg_params, root_of_unity_type root_of_unity) : base(kzg_params, std::move(root_of_unity)) { }
     explicit kzg_commitment_scheme_v2_hip(const params_type &kzg_params) : base(kzg_params) { }    // kzg_v2.hpp:94
+    /// over a device group (kzg_params_group_hip): commit(batch) on all of its GPUs, the opening proof on member 0
+    kzg_commitment_scheme_v2_hip(const kzg_params_group_hip<CurveType> &group_params, root_of_unity_type root_of_unity) : base(group_params, std::move(root_of_unity)) { }
+    explicit kzg_commitment_scheme_v2_hip(const kzg_params_group_hip<CurveType> &group_params) : base(group_params) { }
 
     /// proof_eval (kzg_v2.hpp:236-305)
     proof_type proof_eval(transcript_type &transcript) {
@@ -634,6 +784,9 @@ public:
 
     kzg_commitment_scheme_hip(const params_type &kzg_params, root_of_unity_type root_of_unity) : base(kzg_params, std::move(root_of_unity)) { }
     explicit kzg_commitment_scheme_hip(const params_type &kzg_params) : base(kzg_params) { }    // kzg.hpp:667
+    /// over a device group (kzg_params_group_hip): commit(batch) on all of its GPUs, the opening proof on member 0
+    kzg_commitment_scheme_hip(const kzg_params_group_hip<CurveType> &group_params, root_of_unity_type root_of_unity) : base(group_params, std::move(root_of_unity)) { }
+    explicit kzg_commitment_scheme_hip(const kzg_params_group_hip<CurveType> &group_params) : base(group_params) { }
 
     /// proof_eval (kzg.hpp:782-807)
     proof_type proof_eval(transcript_type &transcript) {

@@ -162,10 +162,27 @@ inline const context &default_context() {
 /// make `ctx` the calling thread's default context (nullptr: back to the thread's own); the caller keeps it alive
 inline void set_default_context(context *ctx) { detail::default_context_override() = ctx; }
 
+/// sum scalars[i] * bases[offset + i] over bases cut over a device group: every member multiplies its point range, the partial sums
+/// meet on member 0 inside the library (zkhip_group_msm).  `chunks` of the reference's call = the group's members.
+template <typename CurveType, int Group, typename ScalarIt>
+typename detail::jac_result<CurveType, Group>::type multiexp(const device_group_bases<CurveType, Group> &bases, std::size_t offset, ScalarIt scalars_begin,
+                                                             ScalarIt scalars_end, std::size_t /*chunks*/ = 1) {
+    typedef detail::jac_result<CurveType, Group> R;
+    std::vector<std::uint64_t> s = detail::pack_scalars<CurveType>(scalars_begin, scalars_end);
+    std::uint64_t jac[R::limbs];
+    bases.group().check_group(zkhip_group_msm(bases.group().get(), bases.get(), offset, s.size() / 4, s.data(), jac), "zkhip_group_msm");
+    return R::make(jac);
+}
+
 template <typename BaseIt, typename ScalarIt>
 typename std::iterator_traits<BaseIt>::value_type multiexp_method_hip::process(BaseIt bases_begin, BaseIt bases_end, ScalarIt scalars_begin,
                                                                                ScalarIt scalars_end) {
     typedef group_traits<typename std::iterator_traits<BaseIt>::value_type> T;
+    /* with a default device group (ZKHIP_DEVICES / set_default_group) the one-shot multiexp is cut over its GPUs */
+    if (const device_group *g = default_group()) {
+        device_group_bases<typename T::curve_type, T::group> b(*g, bases_begin, bases_end);
+        return multiexp<typename T::curve_type, T::group>(b, 0, scalars_begin, scalars_end, 1);
+    }
     return multiexp<multiexp_method_hip, typename T::curve_type, T::group>(default_context(), bases_begin, bases_end, scalars_begin, scalars_end, 1);
 }
 

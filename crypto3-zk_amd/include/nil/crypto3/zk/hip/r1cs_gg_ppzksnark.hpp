@@ -475,6 +475,44 @@ private:
     mutable std::size_t work_cpa_ = 0;
 };
 
+// ---- the same key over a device group ---------------------------------------------------------------------------------
+/// One proving key over the N GPUs of a device_group: member k holds the k-th point-range slice of every query and the
+/// whole constraint system (the witness map is replicated: 7 transforms, no exchange).  r1cs_gg_ppzksnark_prover_hip::process(group_key,
+/// primary_input, auxiliary_input) then proves over all of them from the ONE calling thread and does the exchange -- one all-gather of
+/// partial_limbs() u64 per member, 864 bytes for BLS12-381 -- inside the library: what `chunks = omp_get_max_threads()` is inside the
+/// reference's process (prover.hpp:94-99, 108-139).  Same proof as over one device, bit for bit (the group law is exact; only the order
+/// of the additions differs).
+template <typename CurveType, typename KeyType = r1cs_gg_ppzksnark_proving_key<CurveType>>
+class r1cs_gg_ppzksnark_proving_key_group_hip {
+public:
+    typedef r1cs_gg_ppzksnark_proving_key_hip<CurveType, KeyType> member_key_type;
+    typedef KeyType host_key_type;
+
+    r1cs_gg_ppzksnark_proving_key_group_hip(const device_group &group, const host_key_type &pk, const domain_params<CurveType> &dom) : group(group) {
+        for (std::size_t k = 0; k < group.size(); ++k) members.emplace_back(new member_key_type(group[k], pk, dom, k, group.size()));
+    }
+    /// adopts member keys that exist already -- generated on the devices (r1cs_gg_ppzksnark_generator_hip over a group), decoded from the
+    /// wire form --: keys[k] lives on group[k] and holds slice k of `group.size()`
+    r1cs_gg_ppzksnark_proving_key_group_hip(const device_group &group, std::vector<std::shared_ptr<member_key_type>> keys) :
+        group(group), members(std::move(keys)) {
+        if (members.size() != group.size()) throw std::invalid_argument("proving key group: one member key per device of the group");
+        for (std::size_t k = 0; k < members.size(); ++k)
+            if (!members[k] || members[k]->ctx.get() != group[k].get() || members[k]->shard.rank != k || members[k]->shard.world != members.size())
+                throw std::invalid_argument("proving key group: member key " + std::to_string(k) + " is not slice k of the group on the group's context k");
+    }
+    /// the reference's argument list plus the group: the domain make_evaluation_domain(M + n + 1) returns, constants from the curve adapter
+    r1cs_gg_ppzksnark_proving_key_group_hip(const device_group &group, const host_key_type &pk) :
+        r1cs_gg_ppzksnark_proving_key_group_hip(
+            group, pk, standard_domain_params<CurveType>(pk.constraint_system.num_constraints() + pk.constraint_system.num_inputs() + 1)) { }
+
+    const device_group &group;
+    std::vector<std::shared_ptr<member_key_type>> members;
+    /// member 0's receive buffer of the all-gather (world x partial sums), allocated at the first proof
+    mutable std::shared_ptr<void> d_all;
+    /// host wall time of the last proof's phases, ms: staging + launches on all members | host products | exchange + waiting | assembly
+    mutable double last_phase_ms[4] = {0, 0, 0, 0};
+};
+
 // ---- r1cs_gg_ppzksnark_prover<CurveType, basic>::process -------------------------------------------------------
 /// `KeyType` / `ProofType`: the host-side key the device key was built from and the proof type to return (the
 /// reference's r1cs_gg_ppzksnark_proving_key / r1cs_gg_ppzksnark_proof, proof.hpp:41-46: constructible from (g_A, g_B, g_C)).
@@ -502,17 +540,24 @@ public:
     /// sizes; `forget(proving_key)` drops it when the host key goes away), on the calling thread's default context and over the
     /// domain make_evaluation_domain(M + n + 1) returns.  A call site then changes by the class name alone; callers that manage
     /// contexts / domains / shards themselves keep using the device-key overloads above.
+    /// With a default device group (set_default_group, or ZKHIP_DEVICES naming several GPUs: multiexp.hpp) the SAME call proves over all of
+    /// its devices -- slices of the key on every member, the exchange inside the library: a reference caller reaches BASELINE cfg 4's
+    /// 8-GPU configuration by setting ZKHIP_DEVICES=0,1,2,3,4,5,6,7 and nothing else.
     template <typename K = KeyType, typename std::enable_if<std::is_same<K, KeyType>::value && curve_adapter<CurveType>::has_field_constants, bool>::type = true>
     static proof_type process(const K &proving_key, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input) {
-        return process(cached_device_key(proving_key), primary_input, auxiliary_input);
+        return process(proving_key, primary_input, auxiliary_input, random_scalar(), random_scalar());
     }
     template <typename K = KeyType, typename std::enable_if<std::is_same<K, KeyType>::value && curve_adapter<CurveType>::has_field_constants, bool>::type = true>
     static proof_type process(const K &proving_key, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input,
                               const scalar_value_type &r, const scalar_value_type &s) {
+        if (const device_group *g = default_group()) return process(cached_group_key(*g, proving_key), primary_input, auxiliary_input, r, s);
         return process(cached_device_key(proving_key), primary_input, auxiliary_input, r, s);
     }
-    /// drop the cached device key of `proving_key` (and with it the resident queries); true if there was one
-    static bool forget(const KeyType &proving_key) { return device_key_cache().erase(&proving_key) != 0; }
+    /// drop the cached device key(s) of `proving_key` (and with them the resident queries); true if there was one
+    static bool forget(const KeyType &proving_key) {
+        const bool one = device_key_cache().erase(&proving_key) != 0, many = group_key_cache().erase(&proving_key) != 0;
+        return one || many;
+    }
 
 private:
     /// What identifies a key's CONTENT cheaply (the address and the query sizes alone also match a second key of the same
@@ -553,6 +598,28 @@ private:
         if (!e.device || e.fingerprint != fp) {
             e.device.reset();    // the old key's queries go first: two resident keys of 2^20 constraints are 1.5 GB
             e.device.reset(new proving_key_type(pk));
+            e.fingerprint = std::move(fp);
+        }
+        return *e.device;
+    }
+
+    struct cached_group_key_entry {
+        std::vector<std::uint64_t> fingerprint;
+        const device_group *group = nullptr;    // the group the member keys live on: another default group rebuilds them
+        std::unique_ptr<r1cs_gg_ppzksnark_proving_key_group_hip<CurveType, KeyType>> device;
+    };
+    static std::map<const KeyType *, cached_group_key_entry> &group_key_cache() {
+        (void)default_group();    // constructed first, destroyed last: the cached keys release their device memory through its contexts
+        thread_local std::map<const KeyType *, cached_group_key_entry> cache;
+        return cache;
+    }
+    static const r1cs_gg_ppzksnark_proving_key_group_hip<CurveType, KeyType> &cached_group_key(const device_group &g, const KeyType &pk) {
+        cached_group_key_entry &e = group_key_cache()[&pk];
+        std::vector<std::uint64_t> fp = key_fingerprint(pk);
+        if (!e.device || e.group != &g || e.fingerprint != fp) {
+            e.device.reset();
+            e.device.reset(new r1cs_gg_ppzksnark_proving_key_group_hip<CurveType, KeyType>(g, pk));
+            e.group = &g;
             e.fingerprint = std::move(fp);
         }
         return *e.device;
@@ -644,6 +711,63 @@ public:
         return assemble(pk, all, pk.shard.world, r, s, t);
     }
 
+    // ---- one proof over a device group: N GPUs, ONE caller, the exchange inside the library ---------------------------------------
+    typedef r1cs_gg_ppzksnark_proving_key_group_hip<CurveType, KeyType> group_key_type;
+
+    static proof_type process(const group_key_type &gk, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input) {
+        return process(gk, primary_input, auxiliary_input, random_scalar(), random_scalar());
+    }
+    /// Every member runs the witness map and its five partial multiexps (all enqueued from this thread, nothing waits in between); the
+    /// 4 G1 + 1 G2 Jacobian partial sums of all members meet on member 0 through device_group::all_gather -- RCCL over xGMI, peer copies
+    /// or a staged copy, in stream order -- and ONE download + the host's assembly follow.
+    static proof_type process(const group_key_type &gk, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input,
+                              const scalar_value_type &r, const scalar_value_type &s) {
+        typedef std::chrono::steady_clock clock;
+        const std::size_t world = gk.members.size();
+        if (world == 0) throw std::runtime_error("process: empty device group key");
+        const auto t0 = clock::now();
+        std::vector<std::unique_ptr<drain_on_unwind>> guards;
+        for (const auto &m : gk.members) guards.emplace_back(new drain_on_unwind {*m});
+        const std::uint64_t *staged = nullptr;
+        for (std::size_t k = 0; k < world; ++k) {
+            const proving_key_type &pk = *gk.members[k];
+            enqueue(pk, primary_input, auxiliary_input, staged);
+            /* member 0 has converted (1, x, w) into its page-locked buffer -- unless the scalars go out as they lie in the caller's vector */
+            if (k == 0 && !(detail::canonical_scalars<adapter>::value && pk.direct_assignment_upload)) staged = static_cast<const std::uint64_t *>(pk.h_cpa.get());
+        }
+        const auto t1 = clock::now();
+        const host_terms t = host_products(*gk.members[0], r, s);
+        const auto t2 = clock::now();
+        std::vector<const void *> send(world);
+        std::vector<void *> recv(world, nullptr);
+        for (std::size_t k = 0; k < world; ++k) {
+            const proving_key_type &pk = *gk.members[k];
+            if (pk.side) {
+                pk.ctx.wait_for(*pk.side);
+                pk.ctx.set_option("msm_sort_tile_log", pk.saved_sort_tile_log);
+            }
+            send[k] = pk.d_results.get();
+        }
+        const context &root = gk.members[0]->ctx;
+        if (!gk.d_all) gk.d_all = root.alloc(world * partial_limbs() * 8);
+        recv[0] = gk.d_all.get();
+        gk.group.all_gather(send, recv, partial_limbs() * 8);
+        std::vector<std::uint64_t> all(world * partial_limbs());
+        root.d2h(all.data(), gk.d_all.get(), all.size() * 8);    // the root's stream is behind the exchange
+        /* kernels flag what they cannot signal otherwise; zkhip_device_status drains every member's streams */
+        for (std::size_t k = 0; k < world; ++k) {
+            const proving_key_type &pk = *gk.members[k];
+            check(zkhip_device_status(pk.ctx.get(), nullptr), "zkhip_device_status", pk.ctx.get());
+            if (pk.side) check(zkhip_device_status(pk.side->get(), nullptr), "zkhip_device_status", pk.side->get());
+            guards[k]->armed = false;
+        }
+        const auto t3 = clock::now();
+        proof_type proof = assemble(*gk.members[0], all, world, r, s, t);
+        const clock::time_point marks[5] = {t0, t1, t2, t3, clock::now()};
+        for (int i = 0; i < 4; ++i) gk.last_phase_ms[i] = std::chrono::duration<double, std::milli>(marks[i + 1] - marks[i]).count();
+        return proof;
+    }
+
 private:
     /* What the proof needs besides the five multiexps (prover.hpp:141-155), regrouped so that everything that does not depend on
        a device result is computed while the device works:
@@ -683,7 +807,10 @@ private:
     }
 
     /// enqueue the whole device side of a proof on the context's stream (no synchronisation)
-    static void enqueue(const proving_key_type &pk, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input) {
+    /// `staged`: (1, x, w) as canonical limbs in page-locked memory, when another member of a device group has converted the
+    /// assignment already (one asynchronous copy instead of a second conversion)
+    static void enqueue(const proving_key_type &pk, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input,
+                        const std::uint64_t *staged = nullptr) {
         const context &ctx = pk.ctx;
         const query_shard &sh = pk.shard;
         const std::size_t num_inputs = primary_input.size();
@@ -709,7 +836,9 @@ private:
         /* the auxiliary input (almost all of the assignment) is converted into the page-locked staging buffer in
            slices by a few host threads, and every slice is sent as soon as it is ready: the conversion of slice k + 1
            overlaps the PCIe copy of slice k */
-        if (detail::canonical_scalars<adapter>::value && pk.direct_assignment_upload) {
+        if (staged) {
+            check(zkhip_memcpy_h2d_async(ctx.get(), cpa, staged, 32 * (num_variables + 1)), "zkhip_memcpy_h2d_async", ctx.get());
+        } else if (detail::canonical_scalars<adapter>::value && pk.direct_assignment_upload) {
             /* scalar values that ARE canonical limbs in memory: the auxiliary input goes out as it lies (0.3 ms per 2^20-constraint
                proof less than through the staging buffer) */
             static_assert(!detail::canonical_scalars<adapter>::value || sizeof(scalar_value_type) == 32, "canonical-limb scalars are 4 x u64");

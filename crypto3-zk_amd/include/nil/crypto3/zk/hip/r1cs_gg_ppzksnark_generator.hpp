@@ -105,6 +105,14 @@ struct generated_proving_key {
     std::unique_ptr<r1cs_gg_ppzksnark_proving_key_hip<CurveType>> device;
 };
 
+/// A key generated over a device group: one generated_proving_key per member (slice k of every query, generated ON member k's GPU)
+/// and the group key over them.
+template <typename CurveType>
+struct generated_proving_key_group {
+    std::vector<std::unique_ptr<generated_proving_key<CurveType>>> parts;
+    std::unique_ptr<r1cs_gg_ppzksnark_proving_key_group_hip<CurveType>> device;
+};
+
 template <typename CurveType>
 class r1cs_gg_ppzksnark_generator_hip {
     typedef curve_adapter<CurveType> adapter;
@@ -198,6 +206,23 @@ public:
                                                                           b_indices, std::move(h_query), std::move(l_query), world > 1 ? &sh : nullptr));
         lap("device key (r1cs upload)");
         return key;
+    }
+
+    /// The same over a device group: member k generates slice k of every query on its own GPU (the fixed-base batch exponentiations of
+    /// generator.hpp:165-214 cut by point range), nothing crosses between the members.
+    static std::unique_ptr<generated_proving_key_group<CurveType>> deterministic_basic_process(const device_group &group, const constraint_system_type &constraint_system,
+                                                                                               const domain_params<CurveType> &dom, const scalar_value_type &t,
+                                                                                               const scalar_value_type &alpha, const scalar_value_type &beta,
+                                                                                               const scalar_value_type &gamma, const scalar_value_type &delta) {
+        std::unique_ptr<generated_proving_key_group<CurveType>> out(new generated_proving_key_group<CurveType>());
+        std::vector<std::shared_ptr<r1cs_gg_ppzksnark_proving_key_hip<CurveType>>> members;
+        for (std::size_t k = 0; k < group.size(); ++k) {
+            out->parts.push_back(deterministic_basic_process(group[k], constraint_system, dom, t, alpha, beta, gamma, delta, k, group.size()));
+            /* the part owns its device key; the group key refers to it (`out` keeps both alive together) */
+            members.emplace_back(out->parts.back()->device.get(), [](r1cs_gg_ppzksnark_proving_key_hip<CurveType> *) { });
+        }
+        out->device.reset(new r1cs_gg_ppzksnark_proving_key_group_hip<CurveType>(group, std::move(members)));
+        return out;
     }
 
     /// generator.hpp:84-236: fresh toxic waste from the operating system's CSPRNG

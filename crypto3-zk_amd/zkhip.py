@@ -154,11 +154,15 @@ class Context:
         if rc != 0:
             raise ZkhipError(f"{what}: {self.lib.zkhip_strerror(rc).decode()} [{self.lib.zkhip_last_error(self.h).decode()}]")
 
-    def close(self):
+    def close(self, release_blocks: bool = True):
+        """zkhip_destroy; blocks of malloc() that were never freed go back first (zkhip_destroy itself leaves live blocks alone -- zkhip.h,
+        "OWNERSHIP" -- so a script that forgets them would leak until the process ends: ADVICE r5).  release_blocks=False keeps them
+        (they stay valid and can be freed through any other context)."""
         if getattr(self, "h", None):
             for p in list(getattr(self, "_live", ())):
                 _BLOCK_HOLDER.pop(p, None)
-                self.lib.zkhip_free(self.h, ctypes.c_void_p(p))
+                if release_blocks:
+                    self.lib.zkhip_free(self.h, ctypes.c_void_p(p))
             self._live = set()
             if getattr(self, "_owns", True):
                 self.lib.zkhip_destroy(self.h)

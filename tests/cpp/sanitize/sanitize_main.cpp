@@ -129,6 +129,18 @@ void groth16_host_paths(std::size_t M) {
         gathered.insert(gathered.end(), mine.begin(), mine.end());
         if (rank == 1) (void)prover::finish(part, gathered, Fr(3), Fr(4));
     }
+    {
+        /* the device group: member keys over slices of every query, all members enqueued from this thread, the exchange, one assembly;
+           then the reference's static signature over the default group (its per-thread key cache) */
+        device_group grp({0, 0, 0});
+        r1cs_gg_ppzksnark_proving_key_group_hip<Curve> gk(grp, pk, dom);
+        for (int transport : {ZKHIP_GROUP_AUTO, ZKHIP_GROUP_STAGED}) {
+            grp.set_transport(transport);
+            (void)prover::process(gk, primary, auxiliary, Fr(3), Fr(4));
+        }
+        (void)prover::process(gk, primary, auxiliary);
+        EXPECT(gk.members.size() == 3 && gk.members[2]->shard.rank == 2 && gk.members[0]->shard.A_n + gk.members[1]->shard.A_n + gk.members[2]->shard.A_n == N + 1);
+    }
     /* malformed keys are refused, not read past their end */
     auto bad = pk;
     bad.H_query.pop_back();
@@ -218,6 +230,24 @@ void scheme_host_paths() {
         (void)v1.proof_eval(tr);
         (void)v1.commit_g2({Fr(1), Fr(2), Fr(3)});
         (void)commit_one<Curve>(params, std::vector<Fr> {Fr(1), Fr(2)});
+    }
+    {   /* KZG over a device group: the key replicated, commit(batch) dealt over the members on a host thread each (TSan: the members share
+           nothing but read-only inputs), host and resident columns mixed, more members than columns */
+        std::vector<typename A::g1_value_type> ck(600, A::g1_value_type::zero());
+        for (std::size_t world : {(std::size_t)2, (std::size_t)3, (std::size_t)9}) {
+            device_group grp(std::vector<int>(world, 0));
+            kzg_params_group_hip<Curve> gparams(grp, ck.begin(), ck.end());
+            EXPECT(gparams.members.size() == world);
+            kzg_commitment_scheme_v2_hip<Curve, any_transcript> v2(gparams, root);
+            std::vector<std::reference_wrapper<const polynomial_dfs<Curve>>> lent(polys.begin(), polys.end());
+            v2.append_to_batch(0, lent);
+            device_polynomial_dfs<Curve> resident(grp[0], polys[1]);
+            v2.append_to_batch(0, resident);
+            EXPECT(v2.commit(0).size() == 8);
+            v2.append_eval_point(0, Fr(77));
+            any_transcript tr;
+            (void)v2.proof_eval(tr);
+        }
     }
     fri_params_hip<Curve> fp;
     fp.log_domain = 10;

@@ -311,6 +311,97 @@ int zkhip_poly_lincomb_dev(zkhip_ctx *, int, size_t count, const void *const *d_
     touch(d_acc, acc_len * 32);
     return ZKHIP_OK;
 }
+// ---- device group: the members are stub contexts, the exchange is memcpy (what is exercised is the shim's bookkeeping around it)
+struct zkhip_device_group_stub {
+    int n;
+    zkhip_ctx **members;
+    int transport;
+};
+int zkhip_group_init(const int *device_ids, int n_dev, zkhip_device_group **out) {
+    if (!device_ids || n_dev < 1) return ZKHIP_ERR_INVALID;
+    auto *g = new zkhip_device_group_stub {n_dev, new zkhip_ctx *[n_dev], ZKHIP_GROUP_AUTO};
+    for (int k = 0; k < n_dev; ++k) g->members[k] = new zkhip_ctx {device_ids[k]};
+    *out = reinterpret_cast<zkhip_device_group *>(g);
+    return ZKHIP_OK;
+}
+static zkhip_device_group_stub *stub(const zkhip_device_group *g) { return reinterpret_cast<zkhip_device_group_stub *>(const_cast<zkhip_device_group *>(g)); }
+void zkhip_group_destroy(zkhip_device_group *g) {
+    if (!g) return;
+    for (int k = 0; k < stub(g)->n; ++k) delete stub(g)->members[k];
+    delete[] stub(g)->members;
+    delete stub(g);
+}
+int zkhip_group_size(const zkhip_device_group *g) { return stub(g)->n; }
+zkhip_ctx *zkhip_group_ctx(const zkhip_device_group *g, int member) { return member >= 0 && member < stub(g)->n ? stub(g)->members[member] : nullptr; }
+const char *zkhip_group_last_error(const zkhip_device_group *) { return ""; }
+int zkhip_group_set_transport(zkhip_device_group *g, int transport) {
+    stub(g)->transport = transport;
+    return ZKHIP_OK;
+}
+int zkhip_group_transport(const zkhip_device_group *g) { return stub(g)->transport == ZKHIP_GROUP_AUTO ? ZKHIP_GROUP_PEER : stub(g)->transport; }
+int zkhip_group_all_gather(zkhip_device_group *g, const void *const *d_send, void *const *d_recv, size_t bytes) {
+    const int n = stub(g)->n;
+    for (int j = 0; j < n; ++j)
+        if (d_recv[j])
+            for (int k = 0; k < n; ++k) memcpy(static_cast<char *>(d_recv[j]) + (size_t)k * bytes, d_send[k], bytes);
+    return ZKHIP_OK;
+}
+int zkhip_group_copy(zkhip_device_group *g, int dst_member, void *d_dst, int src_member, const void *d_src, size_t bytes) {
+    if (dst_member < 0 || src_member < 0 || dst_member >= stub(g)->n || src_member >= stub(g)->n) return ZKHIP_ERR_INVALID;
+    memmove(d_dst, d_src, bytes);
+    return ZKHIP_OK;
+}
+int zkhip_group_sync(zkhip_device_group *) { return ZKHIP_OK; }
+struct zkhip_group_bases {
+    int curve, group;
+    size_t n;
+    int world;
+    zkhip_bases **member;
+};
+static size_t part_lo(size_t n, size_t k, size_t world) { return k * (n / world) + (k < n % world ? k : n % world); }
+int zkhip_group_bases_upload(zkhip_device_group *g, int curve, int group, const uint64_t *xy, const uint8_t *inf, size_t n, zkhip_group_bases **out) {
+    const int world = stub(g)->n;
+    auto *b = new zkhip_group_bases {curve, group, n, world, new zkhip_bases *[world]};
+    for (int k = 0; k < world; ++k) {
+        const size_t lo = part_lo(n, k, world), cnt = part_lo(n, k + 1, world) - lo;
+        zkhip_bases_upload(stub(g)->members[k], curve, group, xy + lo * 2 * coord_limbs(curve, group), inf ? inf + lo : nullptr, cnt, &b->member[k]);
+    }
+    *out = b;
+    return ZKHIP_OK;
+}
+int zkhip_group_bases_from_scalars(zkhip_device_group *g, int curve, int group, const uint64_t *base, const uint64_t *scalars, size_t n, zkhip_group_bases **out) {
+    const int world = stub(g)->n;
+    auto *b = new zkhip_group_bases {curve, group, n, world, new zkhip_bases *[world]};
+    for (int k = 0; k < world; ++k) {
+        const size_t lo = part_lo(n, k, world), cnt = part_lo(n, k + 1, world) - lo;
+        zkhip_bases_from_scalars(stub(g)->members[k], curve, group, base, scalars + 4 * lo, cnt, &b->member[k]);
+    }
+    *out = b;
+    return ZKHIP_OK;
+}
+void zkhip_group_bases_free(zkhip_device_group *, zkhip_group_bases *b) {
+    if (!b) return;
+    for (int k = 0; k < b->world; ++k) delete b->member[k];
+    delete[] b->member;
+    delete b;
+}
+size_t zkhip_group_bases_size(const zkhip_group_bases *b) { return b->n; }
+const zkhip_bases *zkhip_group_bases_member(const zkhip_group_bases *b, int member, size_t *first) {
+    if (member < 0 || member >= b->world) return nullptr;
+    if (first) *first = part_lo(b->n, member, b->world);
+    return b->member[member];
+}
+int zkhip_group_msm(zkhip_device_group *, const zkhip_group_bases *b, size_t offset, size_t n, const uint64_t *scalars, uint64_t *out) {
+    if (offset + n > b->n) return ZKHIP_ERR_RANGE;
+    volatile uint64_t acc = 0;
+    for (size_t i = 0; i < 4 * n; ++i) acc += scalars[i];
+    memset(out, 0, 3 * coord_limbs(b->curve, b->group) * 8);
+    return ZKHIP_OK;
+}
+int zkhip_group_ntt(zkhip_device_group *, int, uint64_t *data, size_t log_m, size_t batch, const uint64_t *, int, const uint64_t *) {
+    touch(data, (batch << log_m) * 32);
+    return ZKHIP_OK;
+}
 int zkhip_profile_enable(zkhip_ctx *, int) { return ZKHIP_OK; }
 int zkhip_profile_reset(zkhip_ctx *) { return ZKHIP_OK; }
 int zkhip_profile_filter(zkhip_ctx *, const char *) { return ZKHIP_OK; }

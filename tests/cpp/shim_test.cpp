@@ -89,6 +89,7 @@ namespace ref_like {
 }    // namespace ref_like
 
 int g_world = 1;    // > 1: shim_groth16_prove emulates that many ranks one after the other on this GPU
+int g_gpus = 1;     // GPUs of the box: the members of a device group are dealt over them (shim_set_gpus)
 // evaluation domain the Groth16 entry points name: kind < 0 = "auto" (make_evaluation_domain's choice, or what the key's H query says)
 int g_dom_kind = -1;
 size_t g_dom_m = 0;
@@ -167,6 +168,36 @@ int groth16_prove_t(size_t M, size_t n, size_t N, const uint32_t *const rowptr[3
                                        std::memcpy(all, mine, words * 8);
                                    });
         if (!(pv2.g_A == pv.g_A) || !(pv2.g_B == pv.g_B) || !(pv2.g_C == pv.g_C)) return -102;
+        /* THE DEVICE GROUP: g_world contexts behind one caller (members dealt over the box's GPUs, device 0 repeated on a one-GPU box), the
+           exchange inside the library -- every transport the box offers must give the single-device proof bit for bit */
+        {
+            std::vector<int> devices;
+            for (int k = 0; k < g_world; ++k) devices.push_back(k % g_gpus);
+            device_group grp(devices);
+            r1cs_gg_ppzksnark_proving_key_group_hip<Curve> gk(grp, pk, dom);
+            bool distinct = g_world <= g_gpus;
+            for (int transport : {ZKHIP_GROUP_AUTO, ZKHIP_GROUP_PEER, ZKHIP_GROUP_STAGED, ZKHIP_GROUP_RCCL}) {
+                if (transport == ZKHIP_GROUP_RCCL && !distinct) continue;    // RCCL refuses two ranks on one GPU (test_gpu_group.py checks the refusal)
+                grp.set_transport(transport);
+                for (int rep = 0; rep < 2; ++rep) {
+                    auto pg = prover::process(gk, primary, auxiliary, A::scalar_from_limbs(r), A::scalar_from_limbs(s));
+                    if (!(pg.g_A == pv.g_A) || !(pg.g_B == pv.g_B) || !(pg.g_C == pv.g_C)) return -120 - transport;
+                }
+                if (grp.transport() == ZKHIP_GROUP_AUTO) return -125;    // resolved at the first exchange
+            }
+            auto pr = prover::process(gk, primary, auxiliary);    // fresh blinders
+            if (pr.g_A.is_zero()) return -126;
+            if (g_dom_kind < 0) {
+                /* the reference's static signature over the HOST key, spread over the default group: process(proving_key, x, w) */
+                set_default_group(&grp);
+                const r1cs_gg_ppzksnark_proving_key<Curve> &proving_key = pk;
+                auto q1 = prover::process(proving_key, primary, auxiliary, A::scalar_from_limbs(r), A::scalar_from_limbs(s));
+                auto q2 = prover::process(proving_key, primary, auxiliary, A::scalar_from_limbs(r), A::scalar_from_limbs(s));
+                const bool dropped = prover::forget(proving_key);
+                set_default_group(nullptr);
+                if (!(q1.g_A == pv.g_A) || !(q1.g_B == pv.g_B) || !(q1.g_C == pv.g_C) || !(q2.g_C == pv.g_C) || !dropped) return -127;
+            }
+        }
         pv.g_A.to_affine(proof);
         pv.g_B.to_affine(proof + L1);
         pv.g_C.to_affine(proof + L1 + L2);
@@ -404,6 +435,46 @@ int kzg_v2_t(const uint64_t *srs, size_t n_srs, size_t npolys, const uint64_t *b
     proof.pi_2.to_affine(pi + L1);
     absorbed[0] = tr.absorbed_points;
     absorbed[1] = tr.absorbed_scalars;
+    if (g_world > 1) {
+        /* THE SAME SCHEME OVER A DEVICE GROUP: commit(batch) deals the columns over g_world members (host columns and resident ones mixed),
+           proof_eval runs on member 0 over the gathered coefficient forms: commitments, evaluations and both quotient commitments must be
+           the single-device scheme's */
+        std::vector<int> devices;
+        for (int k = 0; k < g_world; ++k) devices.push_back(k % g_gpus);
+        device_group grp(devices);
+        for (int transport : {ZKHIP_GROUP_AUTO, ZKHIP_GROUP_STAGED}) {
+            grp.set_transport(transport);
+            kzg_params_group_hip<Curve> gparams(grp, ck.begin(), ck.end());
+            scheme_type gs(gparams, [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); });
+            std::vector<device_polynomial_dfs<Curve>> keep;
+            keep.reserve(npolys);
+            at = 0;
+            for (size_t p = 0; p < npolys; ++p) {
+                polynomial_dfs<Curve> poly;
+                for (size_t i = 0; i < ((size_t)1 << log_n[p]); ++i) poly.values.push_back(A::scalar_from_limbs(evals + 4 * at++));
+                if (p % 2 == 1) {
+                    keep.emplace_back(grp[0], poly);    // resident on member 0's GPU: dealt device to device
+                    gs.append_to_batch(batch_id[p], keep.back());
+                } else gs.append_to_batch(batch_id[p], poly);
+            }
+            ci = 0;
+            for (size_t b : batches)
+                for (const auto &c : gs.commit(b)) {
+                    std::vector<uint64_t> xy(L1);
+                    c.to_affine(xy.data());
+                    if (std::memcmp(xy.data(), commits + ci * L1, L1 * 8) != 0) return -130;
+                    ++ci;
+                }
+            pt = 0;
+            for (size_t p = 0; p < npolys; ++p)
+                for (size_t q = 0; q < npts[p]; ++q) gs.append_eval_point(batch_id[p], idx_in_batch[p], A::scalar_from_limbs(points + 4 * pt++));
+            scripted_transcript<Curve> gtr;
+            gtr.challenges = tr.challenges;
+            auto gproof = gs.proof_eval(gtr);
+            if (!(gproof.z == proof.z) || !(gproof.pi_1 == proof.pi_1) || !(gproof.pi_2 == proof.pi_2)) return -131;
+            if (gtr.absorbed_points != tr.absorbed_points || gtr.absorbed_scalars != tr.absorbed_scalars) return -132;
+        }
+    }
     return 0;
 }
 
@@ -628,6 +699,17 @@ int kzg_reference_arity_t(const uint64_t *srs, size_t n_srs, const uint64_t *vk,
     if (!(multiexp<typename KZG::multiexp_method>(params.commitment_key.begin(), params.commitment_key.begin() + fv.size(), fv.begin(), fv.end(), 1) == c1))
         throw std::runtime_error("free-function arity disagrees with the policy");
     set_default_context(nullptr);
+    {
+        /* the same QUALIFIED call with a default device group installed: the policy cuts the range over the group's members (G1 and G2) */
+        device_group grp(std::vector<int>(3, 0));
+        set_default_group(&grp);
+        auto cg = ref_shaped_commit<KZG>(params, fv, 1);
+        auto cg2 = ref_shaped_commit_g2<KZG>(params, gv);
+        set_default_group(nullptr);
+        std::vector<uint64_t> g2xy(L2);
+        cg2.to_affine(g2xy.data());
+        if (!(cg == c1) || std::memcmp(g2xy.data(), out_g2, L2 * 8) != 0) throw std::runtime_error("the policy over a device group disagrees with one device");
+    }
     return 0;
 }
 
@@ -1763,6 +1845,7 @@ void shim_host_query_shards(size_t world, size_t a, size_t b, size_t h, size_t l
 }
 
 void shim_set_world(int world) { g_world = world < 1 ? 1 : world; }
+void shim_set_gpus(int gpus) { g_gpus = gpus < 1 ? 1 : gpus; }
 void shim_set_lpc_builder(int kind) { g_lpc_builder = kind; }
 void shim_set_domain(int kind, size_t m, const uint64_t *shift) {
     g_dom_kind = kind;

@@ -372,10 +372,16 @@ def test_block_cache_behind_malloc_free(ctx):
     ctx.free(p1)
     with pytest.raises(Exception):
         ctx.free(p1)                                         # a double free is refused instead of corrupting the cache
-    other.close()                                            # p2 is still held: the context's end must not free it
+    other.close(release_blocks=False)                        # p2 is still held: zkhip_destroy must not free it (the Python wrapper would)
     data = np.arange(1 << 10, dtype=np.uint64)
     ctx.h2d(p2, data)
     back = np.zeros_like(data)
     ctx.d2h(back, p2)
     assert (back == data).all()
     ctx.free(p2)                                             # ownerless now: handed to the driver
+    # ... and the wrapper's default: close() hands back what its caller forgot, so nothing leaks for the life of the process
+    third = zk.Context(0)
+    q = third.malloc(7 << 20)
+    assert q in third._live
+    third.close()
+    assert not third._live and q not in zk.zkhip._BLOCK_HOLDER

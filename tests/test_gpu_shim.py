@@ -54,14 +54,19 @@ def _oracle_domain(g, curve, M, n, domain):
 @pytest.mark.parametrize("curve,M,n,world,domain", [(1, 1024, 10, 1, "basic"), (0, 1024, 10, 1, "basic"), (0, 100, 10, 1, "basic"), (0, 1 << 15, 10, 1, "basic"),
                                                     (0, 1024, 10, 2, "basic"), (1, 1024, 10, 3, "basic"), (0, 100, 10, 8, "basic"),
                                                     (0, 16, 2, 1, "ref"), (1, 1024, 10, 1, "ref"), (0, 1024, 10, 1, "ref"), (0, 1 << 15, 10, 1, "ref"),
-                                                    (0, 1024, 10, 2, "ref"), (1, 1024, 10, 3, "ref"), (0, 100, 10, 1, "extended"), (1, 1024, 10, 2, "extended")])
+                                                    (0, 1024, 10, 2, "ref"), (1, 1024, 10, 3, "ref"), (0, 100, 10, 1, "extended"), (1, 1024, 10, 2, "extended"),
+                                                    (0, 1024, 10, 4, "ref"), (1, 1024, 10, 4, "basic"), (0, 1 << 15, 10, 2, "ref")])
 def test_groth16_prover_shim(shim, curve, M, n, world, domain):
     """A key made by the oracle, over the basic domain of the next power of two or over the domain the reference's
     make_evaluation_domain picks (the shim tells them apart by the H query's size), proven with through the shim: bit-exact
     against the oracle's proof.  world > 1: the same proof sharded over `world` ranks (each holding a slice of every query;
     process_partial, the all-gather emulated by concatenation, finish) must equal the single-GPU proof -- SURVEY 8e's
-    point-range partition."""
+    point-range partition -- and so must the proof of the DEVICE GROUP (r1cs_gg_ppzksnark_proving_key_group_hip: `world` contexts behind one
+    caller, the 864-byte exchange inside the library, every transport the box offers; on a one-GPU box all members sit on device 0),
+    through the group key and through the reference's static process(proving_key, x, w) over the default group."""
+    import torch
     shim.shim_set_world(world)
+    shim.shim_set_gpus(max(1, torch.cuda.device_count()))
     if domain == "extended":
         C = CURVES[curve]
         shim.shim_set_domain(1, ctypes.c_size_t(1 << (M + n).bit_length()), P(limbs(pow(C.fr_generator, 2, C.r), 4)))
@@ -932,10 +937,22 @@ def test_placeholder_quotient_chain_shim(shim, curve, log_n):
         assert (out_commits[k] == cp.batch_mul(curve, 1, fr_arr([po.poly_eval(chunk, alpha, r)]))[0][0]).all(), k
 
 
-@pytest.mark.parametrize("curve", [0, 1])
-def test_kzg_v2_proof_eval_shim(shim, curve):
+@pytest.mark.parametrize("curve,world", [(0, 1), (1, 1), (0, 2), (1, 4), (0, 7)])
+def test_kzg_v2_proof_eval_shim(shim, curve, world):
     """kzg_commitment_scheme_v2::commit + proof_eval (kzg_v2.hpp:208-305) through the shim class against the oracle's
-    restatement: evaluations z, both quotient commitments, and the verifier's equation in the exponent (alpha known)."""
+    restatement: evaluations z, both quotient commitments, and the verifier's equation in the exponent (alpha known).
+    world > 1: additionally the scheme over a DEVICE GROUP of that many members (kzg_params_group_hip: the key replicated, the columns of
+    commit(batch) dealt, the coefficient forms gathered on member 0) must give the same commitments and the same opening proof."""
+    import torch
+    shim.shim_set_world(world)
+    shim.shim_set_gpus(max(1, torch.cuda.device_count()))
+    try:
+        _kzg_v2_proof_eval_shim(shim, curve)
+    finally:
+        shim.shim_set_world(1)
+
+
+def _kzg_v2_proof_eval_shim(shim, curve):
     C = CURVES[curve]
     r = C.r
     alpha = 7  # placeholder.cpp:175
