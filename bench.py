@@ -36,6 +36,11 @@ LOG_N = 20
 ALG_BYTES_PER_POINT = 128  # BLS12-381 G1: 96 B affine base + 32 B scalar, each read once
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 R_BLS = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+R_BN = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+# per curve: scalar-field modulus, its multiplicative generator (arithmetic_params<F>::multiplicative_generator), two-adicity, and SURVEY 8d's
+# algorithmic bytes per MSM point (affine base + 32-byte scalar, each read once) for G1 / G2
+CURVE = {0: {"name": "BLS12-381", "r": R_BLS, "gen": 7, "s": 32, "bytes": {1: 128, 2: 224}},
+         1: {"name": "BN254", "r": R_BN, "gen": 5, "s": 28, "bytes": {1: 96, 2: 160}}}
 MASK64 = (1 << 64) - 1
 LINE_LIMIT = 6144          # the driver keeps an 8 KiB tail of the output: the ONE line must fit with room to spare
 
@@ -108,6 +113,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL all-gather + fold at N = 1 too (checks the N > 1 path on one GPU)")
     ap.add_argument("--no-kzg", action="store_true", help="skip the KZG commit / opening-proof leg (BASELINE config 5's commitment layer, N = 1 only)")
     ap.add_argument("--no-ntt", action="store_true", help="skip the NTT leg (BASELINE config 3, N = 1 only)")
+    ap.add_argument("--no-other-msm", action="store_true", help="skip the BLS12-381 G2 and BN254 G1 MSM legs (N = 1 only)")
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the two-MSMs-in-flight throughput figure (N = 1 only)")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic with rocprofv3 --pmc child passes")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-timing full-size checks")
@@ -275,6 +281,13 @@ def main():
     if use_dist and not args.no_kzg:
         # BASELINE config 5's commitment leg: the 50 columns dealt over the ranks, one all-gather of the commitments
         kzg_sharded = kzg_sharded_leg(np, torch, dist, zk, ctx, rank, world, local_rank, log_n=args.kzg_log_rows, verify=not args.no_verify)
+    g16_group = None
+    if use_dist and world > 1 and not args.no_groth16:
+        # the SAME sharded proof as ONE process sees it: rank 0 drives a device group over all `world` GPUs (the drop-in class's own
+        # multi-GPU path, the exchange inside libzkhip.so) while the other ranks wait on the host; their GPUs are idle then
+        torch.cuda.synchronize()
+        devs = [0] * world if args.same_device else list(range(world))
+        g16_group = dist.host_wait_for_rank0(rank, lambda: groth16_group_leg(np, devs, log_constraints=args.log_constraints, steps=3, verify=not args.no_verify))
     dist_info = None
     if use_dist:
         # evidence that the collective saw `world` DISTINCT devices: every rank reports the uuid of the GPU it runs on
@@ -286,7 +299,7 @@ def main():
         dist_info = {"backend": "rccl" if args.dist_backend == "nccl" else "gloo", "world_size": world, "devices": uu,
                      "distinct_devices": len(set(uu)), "same_device_flag": bool(args.same_device),
                      "note": "value: weak scaling (2^log_n points per GPU, one all-gather of 144 B per rank per step); the *_sharded legs are STRONG scaling of fixed jobs "
-                             "and saturate at the replicated witness map + the small-MSM floor (emulated per rank: one proof 20.9 / 13.3 / 8.5 / 6.4 ms at world 1 / 2 / 4 / 8)"}
+                             "and saturate at the replicated witness map + the small-MSM floor (DESIGN.md section 9; this line carries only what this run measured)"}
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * n * args.steps / elapsed / 1e6
@@ -349,8 +362,20 @@ def main():
             full["groth16"] = groth16_leg(np, steps=8, verify=not args.no_verify, valu=valu, lanes=2)
             full["groth16_basic_2p21"] = groth16_leg(np, steps=6, verify=not args.no_verify, domain="basic", valu=valu)
             full["groth16_m2p20"] = groth16_leg(np, constraints=(1 << 20) - 11, steps=6, verify=not args.no_verify, valu=valu)
+            # the other curve north_star names, same instance shape (BN254's make_evaluation_domain picks the step domain of 2^20 + 16 points too)
+            full["groth16_bn254"] = groth16_leg(np, steps=5, verify=not args.no_verify, curve=1)
+            # ... and the drop-in classes over a device group inside ONE process: every GPU this box has (at least two members, so that the
+            # exchange runs; on a one-GPU box they share device 0 and the leg is labelled an emulation)
+            have = max(1, torch.cuda.device_count())
+            members = list(range(have)) if have > 1 else [0, 0]
+            full["groth16_device_group"] = groth16_group_leg(np, members, verify=not args.no_verify)
+        if world == 1 and not args.no_other_msm:
+            full["msm_g2"] = msm_other_leg(np, zk, ctx, 0, 2, verify=not args.no_verify)
+            full["msm_bn254_g1"] = msm_other_leg(np, zk, ctx, 1, 1, verify=not args.no_verify)
         if g16_sharded is not None:
             full["groth16_sharded"] = g16_sharded
+        if g16_group is not None:
+            full["groth16_device_group"] = g16_group
         if kzg_sharded is not None:
             full["kzg_sharded"] = kzg_sharded
         if ntt_sharded is not None:
@@ -367,18 +392,29 @@ def main():
             CPU_GROTH16_LOG = args.cpu_groth16_log
             jac = result.cpu().numpy().view(np.uint64).reshape(3, 6)
             gpu_affine = ctx.jacobian_to_affine(zk.BLS12_381, zk.G1, jac)
-            full["cpu_baseline"] = cpu_baseline(np, bases, scalars, gpu_affine)
+            others = {k: full[k] for k in ("msm_g2", "msm_bn254_g1") if isinstance(full.get(k), dict) and "_inputs" in full[k]}
+            full["cpu_baseline"] = cpu_baseline(np, bases, scalars, gpu_affine, zk=zk, ctx=ctx, others=others if not args.no_verify else None)
             same = full["cpu_baseline"].pop("gpu_result_equals_oracle")
             if not args.no_verify:
                 # the timed launch's output against the ORACLE's Pippenger over the same 2^log_n points and scalars (bit-exact, affine)
                 full["verified"] = bool(full["verified"] and same)
                 full["verified_vs"].append("oracle (cport) BDLO12 MSM of the same points and scalars, affine, bit-exact")
+        for k in ("msm_g2", "msm_bn254_g1"):
+            if isinstance(full.get(k), dict) and "_inputs" in full[k]:
+                full[k].pop("_inputs")[0].free()
         detail = write_detail(full, args.detail)
         line = compact_line(full, detail)
         text = json.dumps(line, separators=(",", ":"))
         if len(text) > LINE_LIMIT:  # never hand the driver a line its parser cannot hold: drop the optional parts, the sidecar has them
-            for k in ("legs_note", "two_in_flight", "host_scalars", "timing"):
+            for k in ("legs_note", "two_in_flight", "host_scalars", "timing", "value_note"):
                 line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+        if len(text) > LINE_LIMIT:  # still too long: the legs shrink to value + verified, then go altogether
+            line["legs"] = {k: _pick(v, "value", "verified", "error") for k, v in line.get("legs", {}).items()}
+            text = json.dumps(line, separators=(",", ":"))
+        if len(text) > LINE_LIMIT:
+            line["legs"] = {"dropped": "see detail"}
+            line.pop("dist", None)
             text = json.dumps(line, separators=(",", ":"))
         os.write(json_fd, (text + "\n").encode())
     fence()
@@ -432,6 +468,7 @@ def compact_line(full, detail_path):
                        "note": "50/10 steps/warmup reads 3-4 % above 20/5 (clocks settle over ~100 ms)"}
     if full.get("host_scalars"):
         c["host_scalars"] = _pick(full["host_scalars"], "value", "unit", "ms_per_msm", "verified")
+        c["value_note"] = "value: scalars resident (prover-internal MSMs); host_scalars: what a caller of algebra::multiexp sees (scalars H2D + result D2H per call)"
     if full.get("two_in_flight"):
         c["two_in_flight"] = _pick(full["two_in_flight"], "value", "ms_per_msm")
     if full.get("dist"):
@@ -456,6 +493,10 @@ def compact_line(full, detail_path):
     leg("groth16_m2p20", "ms_per_proof_mean")
     if (full.get("groth16") or {}).get("lanes_over_one_key"):
         legs["groth16"]["two_lanes_constraints_per_s"] = full["groth16"]["lanes_over_one_key"]["constraints_per_s"]
+    leg("groth16_bn254", "ms_per_proof_mean", "domain_points")
+    leg("groth16_device_group", "ms_per_proof_mean", "members", "distinct_gpus", "transport")
+    leg("msm_g2", "ms_per_msm")
+    leg("msm_bn254_g1", "ms_per_msm")
     leg("groth16_sharded", "ms_per_proof_mean", "scaling")
     leg("ntt_sharded", "scaling")
     leg("kzg_sharded", "scaling")
@@ -531,6 +572,28 @@ class Comm:
 
     def all_gather_object(self, parts, obj):
         return self.d.all_gather_object(parts, obj)
+
+    def host_wait_for_rank0(self, rank, work=None):
+        """Rank 0 runs `work` while every other rank waits ON THE HOST (a key of the rendezvous store) -- an RCCL barrier would park a
+        spinning kernel on the other ranks' GPUs, and `work` (the device-group leg) uses exactly those GPUs.  Returns work()'s result on
+        rank 0, None elsewhere."""
+        store = None
+        try:
+            store = self.d.distributed_c10d._get_default_store()
+        except Exception:
+            pass
+        out = None
+        if rank == 0:
+            try:
+                out = work() if work else None
+            finally:
+                if store is not None:
+                    store.set("zkhip_bench_rank0_work_done", "1")
+        elif store is not None:
+            store.wait(["zkhip_bench_rank0_work_done"])
+        if store is None:  # no store to wait on: the collective barrier after all (the leg then shares the GPUs with spinning kernels)
+            self.barrier(device_ids=[self.local_rank])
+        return out
 
     def destroy_process_group(self):
         return self.d.destroy_process_group()
@@ -738,7 +801,7 @@ def _bench_lib():
     return ctypes.CDLL(so)
 
 
-def groth16_leg(np, constraints=1 << 20, inputs=10, steps=4, verify=True, domain="ref", valu=None, lanes=1):
+def groth16_leg(np, constraints=1 << 20, inputs=10, steps=4, verify=True, domain="ref", valu=None, lanes=1, curve=0):
     """The other half of BASELINE.json's metric: Groth16 prove constraints/s on one GPU (config 4's single-GPU leg: M = 2^20,
     n = 10) through the header-only shim, assignment H2D and result D2H included.  domain = "ref": the evaluation domain the
     reference reduces over, make_evaluation_domain(M + n + 1) (r1cs_to_qap.hpp:229-230) -- for M = 2^20, n = 10 the step radix-2
@@ -749,7 +812,7 @@ def groth16_leg(np, constraints=1 << 20, inputs=10, steps=4, verify=True, domain
 
     lib = _bench_lib()
     lib.zkhip_bench_last_instance_ms.restype = ctypes.c_double
-    r, g = R_BLS, 7
+    r, g = CURVE[curve]["r"], CURVE[curve]["gen"]
     M = constraints
     m = 1
     while m < M + inputs + 1:
@@ -763,7 +826,7 @@ def groth16_leg(np, constraints=1 << 20, inputs=10, steps=4, verify=True, domain
     lib.zkhip_bench_set_domain(0 if domain == "basic" else -1, ctypes.c_size_t(m if domain == "basic" else 0))
     lib.zkhip_bench_set_lanes(int(lanes))
     try:
-        rc = lib.zkhip_bench_groth16(0, 0, ctypes.c_size_t(M), ctypes.c_size_t(inputs), ctypes.c_uint64(1), steps, omega.ctypes.data_as(ctypes.c_void_p),
+        rc = lib.zkhip_bench_groth16(0, curve, ctypes.c_size_t(M), ctypes.c_size_t(inputs), ctypes.c_uint64(1), steps, omega.ctypes.data_as(ctypes.c_void_p),
                                      coset.ctypes.data_as(ctypes.c_void_p), times.ctypes.data_as(ctypes.c_void_p), ctypes.byref(setup),
                                      ctypes.byref(verified) if verify else None, prof, ctypes.c_size_t(16384))
     finally:
@@ -785,7 +848,7 @@ def groth16_leg(np, constraints=1 << 20, inputs=10, steps=4, verify=True, domain
             kern[f[0]] = round(float(f[1]), 4)
     # SURVEY 8d's algorithmic bytes of a proof: 7 transforms x m x 64 B + every G1 base and its scalar once (96 + 32 B) + the G2
     # bases of the B query (192 + 32 B)
-    alg = 7 * dm * 64 + (qa + qb + qh + ql) * 128 + qb * 224
+    alg = 7 * dm * 64 + (qa + qb + qh + ql) * CURVE[curve]["bytes"][1] + qb * CURVE[curve]["bytes"][2]
     ach = alg / (mean * 1e-3) / 1e9
     tot = sum(kern.values()) or 1.0
     dom_k = max(kern, key=kern.get) if kern else None
@@ -803,7 +866,7 @@ def groth16_leg(np, constraints=1 << 20, inputs=10, steps=4, verify=True, domain
                      "what": "the THROUGHPUT arrangement, not the headline: %d provers at once on %d host threads over the SAME resident key "
                              "(r1cs_gg_ppzksnark_proving_key_hip lane constructor: the queries are shared in HBM, each lane has its own streams and "
                              "work buffers), %d proofs each; they fill each other's latency-bound phases" % (int(lane_info[0]), int(lane_info[0]), steps)}
-    return {"metric": "Groth16 prove constraints/sec, BLS12-381, %d constraints, 1 GPU" % M, "value": round(M / mean * 1e3, 1),
+    return {"metric": "Groth16 prove constraints/sec, %s, %d constraints, 1 GPU" % (CURVE[curve]["name"], M), "value": round(M / mean * 1e3, 1),
             "unit": "constraints/s", "statistic": "mean of the proofs after the first", "ms_per_proof": [round(float(x), 2) for x in times],
             "ms_per_proof_mean": round(mean, 3), "domain_points": dm,
             "domain": {"kind": ("basic_radix2", "extended_radix2", "step_radix2")[kind], "points": dm,
@@ -819,6 +882,100 @@ def groth16_leg(np, constraints=1 << 20, inputs=10, steps=4, verify=True, domain
             "roofline": roof, "kernel_ms_serial_proof": kern,
             "kernel_ms_source": "HIP events around every launch of ONE extra, untimed proof with the G2 multiexp on the main stream: a single in-order "
                                 "stream makes the event pairs exact kernel durations (the timed proofs run the G2 multiexp on a second stream and carry no events)", **({"lanes_over_one_key": lanes_obj} if lanes_obj else {})}
+
+
+def msm_other_leg(np, zk, ctx, curve, group, log_n=20, steps=10, warmup=3, verify=True):
+    """north_star names both curves and both groups; the headline is BLS12-381 G1.  The same step for another (curve, group): ONE MSM of
+    2^log_n device-generated points (P_i = k_i G) and uniform scalars, bases and scalars resident.  Checked after the timing against
+    (sum s_i k_i) G from the fixed-base kernel (host big integers for the exponent, no bucket method); cpu_baseline() additionally holds a
+    2^16-point prefix of the same inputs against the oracle's Pippenger."""
+    n = 1 << log_n
+    seed = 3000 + 10 * curve + group
+    r = CURVE[curve]["r"]
+    ks, sc = random_scalars(np, n, seed), random_scalars(np, n, seed + 1)
+    if curve != 0:  # random_scalars draws below the BLS12-381 modulus; BN254's is smaller: 252-bit values are canonical for both
+        ks[:, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+        sc[:, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+    bases = ctx.bases_from_scalars(curve, group, ks)
+    cl = zk.coord_limbs(curve, group)
+    d_s, d_o = ctx.malloc(sc.nbytes), ctx.malloc(3 * cl * 8)
+    ctx.h2d(d_s, sc)
+    for _ in range(warmup):
+        ctx.msm_dev(bases, d_s, d_o, 0, n)
+    ctx.sync()
+    ctx.profile_reset()
+    ctx.profile_filter("msm_bucket_acc")
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.msm_dev(bases, d_s, d_o, 0, n)
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / steps
+    ctx.profile(False)
+    acc_ms, acc_cnt = ctx.profile_get("msm_bucket_acc")
+    ctx.profile_filter("")
+    ctx.profile_reset()
+    jac = np.zeros((3, cl), dtype=np.uint64)
+    ctx.d2h(jac, d_o)
+    ok = None
+    if verify:
+        e = sum(a * b for a, b in zip(to_ints(ks), to_ints(sc))) % r
+        got, got_inf = ctx.jacobian_to_affine(curve, group, jac)
+        eb = ctx.bases_from_scalars(curve, group, lim(np, e).reshape(1, 4))
+        exp, exp_inf = eb.download()
+        eb.free()
+        ok = bool(int(exp_inf[0]) == got_inf and (exp[0] == got).all())
+    ctx.free(d_s), ctx.free(d_o)
+    alg = CURVE[curve]["bytes"][group] * n
+    avg = acc_ms / max(1, acc_cnt)
+    ach = alg / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+    out = {"metric": "MSM Mpoints/sec, %s G%d Pippenger, 2^%d points" % (CURVE[curve]["name"], group, log_n), "value": round(n / dt / 1e6, 3), "unit": "Mpoints/s",
+           "ms_per_msm": round(dt * 1e3, 4), "verified": ok, "verified_vs": "(sum s_i k_i) G by the fixed-base kernel",
+           "roofline": {"bound": "hbm", "kernel": "msm_bucket_acc", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6),
+                        "traffic": None, "avg_launch_ms": round(avg, 4), "algorithmic_bytes_per_launch": alg},
+           "_inputs": (bases, ks, sc)}  # kept for cpu_baseline()'s oracle check of a prefix; dropped before the line is written
+    return out
+
+
+def groth16_group_leg(np, devices, transport=0, log_constraints=20, inputs=10, steps=4, verify=True, curve=0):
+    """BASELINE cfg 4's arrangement AS A C++ CALLER OF THE DROP-IN CLASS REACHES IT: one process, one host thread, a device_group of
+    len(devices) contexts, r1cs_gg_ppzksnark_prover_hip::process(group key, x, w) -- every member holds a point-range slice of every query
+    (generated on its own GPU), runs the replicated witness map and its five partial multiexps, and the 864-byte exchange happens INSIDE
+    the library (zkhip_group_all_gather: RCCL over xGMI between distinct GPUs, peer copies between members that share one).  On a one-GPU
+    box the members share device 0: that measures the orchestration, not a speed-up, and the leg says so."""
+    import ctypes
+
+    lib = _bench_lib()
+    r, g = CURVE[curve]["r"], CURVE[curve]["gen"]
+    M = 1 << log_constraints
+    m = 1
+    while m < M + inputs + 1:
+        m <<= 1
+    omega, coset = lim(np, pow(g, (r - 1) // m, r)), lim(np, g)
+    times = np.zeros(steps, dtype=np.float64)
+    setup = ctypes.c_double()
+    verified = ctypes.c_int(-1)
+    info = np.zeros(5, dtype=np.float64)
+    devs = (ctypes.c_int * len(devices))(*devices)
+    rc = lib.zkhip_bench_groth16_group(devs, len(devices), int(transport), curve, ctypes.c_size_t(M), ctypes.c_size_t(inputs), ctypes.c_uint64(1), steps,
+                                       omega.ctypes.data_as(ctypes.c_void_p), coset.ctypes.data_as(ctypes.c_void_p), times.ctypes.data_as(ctypes.c_void_p),
+                                       ctypes.byref(setup), ctypes.byref(verified) if verify else None, info.ctypes.data_as(ctypes.c_void_p))
+    if rc != 0:
+        return {"error": rc}
+    mean = float(times.mean())
+    distinct = len(set(devices))
+    return {"metric": "Groth16 prove constraints/sec, %s, 2^%d constraints, ONE proof over a device group of %d member(s) on %d GPU(s), one process" %
+                      (CURVE[curve]["name"], log_constraints, len(devices), distinct),
+            "value": round(M / mean * 1e3, 1), "unit": "constraints/s", "scaling": "strong", "ms_per_proof": [round(float(x), 2) for x in times],
+            "ms_per_proof_mean": round(mean, 3), "members": len(devices), "distinct_gpus": distinct, "devices": list(devices),
+            "transport": ("auto", "rccl", "peer", "staged")[int(info[4])],
+            "host_phase_ms": {"launches_all_members": round(float(info[0]), 3), "host_products": round(float(info[1]), 3),
+                              "exchange_and_wait": round(float(info[2]), 3), "assembly": round(float(info[3]), 3)},
+            "key_setup_ms": round(setup.value, 1), "verified": None if not verify else bool(verified.value == 1),
+            "verification": "every timed proof equal to the first and to (a G1, b G2, c G1) from the trapdoor identities (prover.hpp:141-153)",
+            "what": ("members on distinct GPUs: the single-process form of groth16_sharded" if distinct == len(devices) else
+                     "EMULATION: %d members share %d GPU(s) -- the group's orchestration and exchange at work, not a speed-up (their kernels queue on one device)"
+                     % (len(devices), distinct))}
 
 
 def _last_domain(np, lib):
@@ -1346,7 +1503,7 @@ def kzg_sharded_leg(np, torch, dist, zk, ctx, rank, world, local_rank, log_n=20,
 CPU_GROTH16_LOG = 20  # --cpu-groth16-log: size of the CPU prover sample next to the 2^17 one (20 = the headline instance)
 
 
-def cpu_baseline(np, bases, scalars, gpu_affine):
+def cpu_baseline(np, bases, scalars, gpu_affine, zk=None, ctx=None, others=None):
     """The oracle's BDLO12 Pippenger (the CPU restatement of algebra::multiexp with chunks = #threads, as prover.hpp:94-99)
     timed on this host on bounded samples of the same workloads: the headline's OWN 2^20 points and scalars on
     the best thread count of a short sweep (the headline `value`; its result is held against the GPU's: `gpu_result_equals_oracle`),
@@ -1406,12 +1563,28 @@ def cpu_baseline(np, bases, scalars, gpu_affine):
     # NTT: config 3 in full -- 8 polynomials of 2^22, the oracle's transform parallel over the batch
     r = R_BLS
     a = random_scalars(np, 8 << 22, 78).reshape(8, 1 << 22, 4)
+    ntt_threads = best  # the thread count the MSM sweep found this host can keep busy (more only contend)
+    cp.set_threads(ntt_threads)
     t0 = time.perf_counter()
     cp.ntt(0, a, 22, lim(np, pow(7, (r - 1) >> 22, r)))
     dtn = time.perf_counter() - t0
-    out["ntt"] = {"value": round((8 << 22) / dtn / 1e6, 3), "unit": "Melements/s", "cores": min(8, cores),
-                  "sample": "all 8 polynomials of 2^22 (config 3), one thread per polynomial, %.1f s" % dtn}
+    cp.set_threads(cores)
+    inside = 16 <= ntt_threads  # cport.ntt puts the threads INSIDE each transform when the batch is smaller than half of them
+    out["ntt"] = {"value": round((8 << 22) / dtn / 1e6, 3), "unit": "Melements/s", "cores": ntt_threads if inside else min(8, ntt_threads),
+                  "sample": ("all 8 polynomials of 2^22 (config 3), one after the other with %d threads inside each transform, %.1f s" % (ntt_threads, dtn)) if inside
+                            else "all 8 polynomials of 2^22 (config 3), one thread per polynomial (%d of %d usable threads busy), %.1f s" % (min(8, ntt_threads), cores, dtn)}
     del a
+    # the other (curve, group) MSM legs: a 2^16-point prefix of their inputs through the oracle's Pippenger against the GPU's MSM of the same prefix
+    if others and zk is not None and ctx is not None:
+        for name, leg in others.items():
+            ob, _, osc = leg["_inputs"]
+            cnt = min(ob.n, 1 << 16)
+            opts, oinf = ob.download(0, cnt)
+            exp, einf = cp.msm(ob.curve, ob.group, opts, np.ascontiguousarray(osc[:cnt]), chunks=cores)
+            got, ginf = ctx.msm_affine(ob, np.ascontiguousarray(osc[:cnt]), 0, cnt)
+            okp = bool(einf == ginf and (exp == got).all())
+            leg["verified"] = bool(leg.get("verified") and okp)
+            leg["verified_vs"] = str(leg.get("verified_vs")) + "; oracle (cport) MSM of the first 2^%d points, affine, bit-exact" % (cnt.bit_length() - 1)
     # Groth16 AT THE SIZE OF THE HEADLINE METRIC (2^20 constraints, over the domain the reference reduces over): the oracle generates its
     # own valid key from a fixed trapdoor (outside the timing) and ONE proof is timed on the best thread count of the MSM sweep
     def cpu_proof(log_m):

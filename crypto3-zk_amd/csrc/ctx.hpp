@@ -95,6 +95,7 @@ struct zkhip_ctx {
     size_t ws_cap = 0, ws_off = 0, ws_floor = 0;  // ws_floor: start of the per-call region (a batch parks data below it)
     std::unordered_set<const void *> lds_configured;  // kernels whose dynamic-LDS limit was raised on this context's device
     std::vector<uint64_t> lincomb_stage, lincomb_coeffs;  // host staging of zkhip_poly_lincomb_dev's tables
+    std::vector<uint32_t> gate_stage;                     // host image of zkhip_gate_eval_dev's program
     std::vector<uint32_t *> batch_ptrs;            // host copy of a batch's output pointers (alive until the copy ran)
     // HIP graphs of repeated MSM calls (msm.hip: zk_graph_run)
     std::unordered_map<std::string, ZkGraph> graphs;

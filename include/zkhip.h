@@ -350,6 +350,32 @@ int zkhip_lookup_sort_dev(zkhip_ctx *ctx, size_t k_in, const void *const *d_inpu
 int zkhip_poly_lincomb_dev(zkhip_ctx *ctx, int curve, size_t count, const void *const *d_polys, const size_t *lens, const uint64_t *coeffs,
                            size_t taps, void *d_acc, size_t acc_len, int accumulate);
 
+/* ---- the gate argument's sum over a flat program -------------------------------------------------------------------------
+ * placeholder's gates argument (ph/gates_argument.hpp:93-121, 203-216) computes, on the extended domain of 2^log_size points,
+ *     F = mask * sum_gates selector_g * sum_constraints theta^k * constraint(columns, rotated).
+ * Which monomials a constraint is made of is decided by the reference's symbolic machinery (math::expression and its visitors: the
+ * caller's, SURVEY section 2 out of scope); once flattened it is a PROGRAM over column slots, evaluated here in ONE launch, a lane per row:
+ *   d_out[j] = [d_mask[j] *] ( [d_out[j] +] sum_g [slot_{sel_g}[j + rs_g] *] sum_{t in gate g} coeff_t prod_{f in term t} slot_{s_f}[(j + r_f) mod 2^log_size] )
+ * -- rotations are index arithmetic on the extended domain (a rotation by k rows of the ORIGINAL n-row domain is k * 2^log_size / n here;
+ * no math::polynomial_shift copies), every distinct column is read where it lies, selector and mask are multiplied in the same pass.
+ * The expressions of prepare_lookup_input (ph/lookup_argument.hpp:435-496) are the same program without selectors and mask.
+ * All arrays of the program are HOST memory; d_slots is a host array of n_slots device pointers to 2^log_size canonical Fr each.
+ * accumulate != 0 adds to what d_out holds (a program evaluated in pieces: the mask then belongs to the LAST piece).
+ * A malformed program (ranges out of order, a slot that does not exist) is refused with ZKHIP_ERR_INVALID / ZKHIP_ERR_RANGE. */
+#define ZKHIP_GATE_NO_SELECTOR 0xFFFFFFFFu
+typedef struct zkhip_gate_program {
+    uint32_t n_gates, n_terms, n_factors, n_slots;
+    const uint32_t *gate_terms;        /* n_gates + 1: gate g owns terms [gate_terms[g], gate_terms[g + 1]) */
+    const uint32_t *gate_selector;     /* n_gates: slot of the gate's selector, or ZKHIP_GATE_NO_SELECTOR */
+    const int32_t *gate_selector_rot;  /* n_gates: its rotation, in rows of THIS domain */
+    const uint32_t *term_factors;      /* n_terms + 1: term t owns factors [term_factors[t], term_factors[t + 1]) (none: the constant coeff_t) */
+    const uint32_t *factor_slot;       /* n_factors */
+    const int32_t *factor_rot;         /* n_factors: rows of THIS domain, may be negative */
+    const uint64_t *term_coeff;        /* n_terms x 4 limbs, canonical */
+} zkhip_gate_program;
+int zkhip_gate_eval_dev(zkhip_ctx *ctx, int curve, const zkhip_gate_program *prog, const void *const *d_slots, size_t log_size, const void *d_mask /* nullable */,
+                        int accumulate, void *d_out);
+
 /* ---- device group: N GPUs behind ONE caller ---------------------------------------------------------------------
  * The reference hides all of its parallelism INSIDE the call: r1cs_gg_ppzksnark_prover::process splits every multiexp into
  * `chunks = omp_get_max_threads()` pieces (r1cs_gg_ppzksnark/prover.hpp:94-99, 108-139) and kzg_commitment_scheme_v2::commit loops

@@ -117,6 +117,34 @@ def test_ntt_oracles(curve):
 
 
 @pytest.mark.parametrize("curve", [0, 1])
+def test_ntt_oracle_threads_inside_equals_one_thread_per_polynomial(curve):
+    """cport.ntt transforms a batch smaller than half the thread count with the threads INSIDE each transform (bench.py's CPU NTT baseline
+    on all cores); that path must be the serial one's output bit for bit (which test_ntt_oracles pins to the O(n^2) definition), and a
+    random-point Horner check holds it to the definition directly at 2^14."""
+    C = CURVES[curve]
+    lg, batch = 14, 2
+    w, g = limbs(C.root_of_unity(lg), 4), limbs(C.fr_generator, 4)
+    a = cp.random_fr(curve, 31, batch << lg).reshape(batch, 1 << lg, 4)
+    was = cp.num_threads()
+    try:
+        for inverse, coset in ((False, None), (True, None), (False, g), (True, g)):
+            cp.set_threads(max(4, 2 * batch))
+            inside = cp.ntt(curve, a, lg, w, inverse=inverse, coset=coset)
+            cp.set_threads(1)
+            serial = cp.ntt(curve, a, lg, w, inverse=inverse, coset=coset)
+            assert (inside == serial).all(), (inverse, coset is not None)
+        cp.set_threads(max(4, 2 * batch))
+        ev = cp.ntt(curve, a, lg, w)
+    finally:
+        cp.set_threads(was)
+    # out[i] = a(omega^i): three random rows by Horner over the coefficients
+    coeffs = fr_ints(a[0])
+    for i in (1, 777, (1 << lg) - 1):
+        x = pow(C.root_of_unity(lg), i, C.r)
+        assert po.from_limbs(ev[0][i]) == po.poly_eval(coeffs, x, C.r)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
 def test_groth16_oracles_in_exponent(curve):
     """Whole proofs are unpinned in the reference (random r, s); pin both oracles to the trapdoor identity."""
     C = CURVES[curve]
