@@ -52,9 +52,124 @@ struct placeholder_quotient_hip {
     };
 
     /// gates_argument.hpp:203-216: F = (sum over the gates' products) * mask_polynomial on the extended domain of `extended_size`
-    /// points (original_domain->m * 2^ceil(log2(max_gates_degree + 1)), :149-150).
+    /// points (original_domain->m * 2^ceil(log2(max_gates_degree + 1)), :149-150) -- ONE launch over a flat program (zkhip_gate_eval_dev,
+    /// round 6).  Every DISTINCT column the products name is extended once, UNROTATED (from its extension cache when the holder switched it
+    /// on, else by one batched call); a rotation is index arithmetic on the extended domain inside the kernel (rotation * extended_size / n
+    /// rows), so a column used with three rotations costs one extension and no math::polynomial_shift copy; consecutive products that share
+    /// their first factor and its rotation (the selector, by gate_product_hip's convention) become one gate whose selector is multiplied
+    /// once; selector, coefficients and the mask are applied in the same pass over the rows.  Round 5's two launches per product are kept
+    /// below as gate_argument_per_term (A / B measurements, and a second implementation the tests hold this one against).  When the
+    /// extensions of all distinct columns pass `slot_budget` bytes the products are evaluated in groups that accumulate into F.
     static dfs_type gate_argument(const context &ctx, const std::vector<gate_product_hip<CurveType>> &products, const dfs_type &mask_polynomial,
                                   std::size_t extended_size, const root_of_unity_type &root, std::size_t slot_budget = (std::size_t)16 << 30) {
+        if (products.empty()) throw std::invalid_argument("gate_argument: no products");
+        const std::size_t n = mask_polynomial.size();
+        std::size_t log_n = 0, log_e = 0;
+        while (((std::size_t)1 << log_n) < n) ++log_n;
+        while (((std::size_t)1 << log_e) < extended_size) ++log_e;
+        if (((std::size_t)1 << log_n) != n || ((std::size_t)1 << log_e) != extended_size || extended_size < n)
+            throw std::invalid_argument("gate_argument: domain sizes must be powers of two, extended >= original");
+        const std::int64_t stretch = (std::int64_t)(extended_size / n);    // one row of the original domain = this many of the extended one
+        std::uint64_t wn[4], we[4];
+        adapter::scalar_to_limbs(root(log_n), wn);
+        adapter::scalar_to_limbs(root(log_e), we);
+        dfs_type F(ctx, extended_size);
+        std::size_t F_degree = 0;
+        const std::size_t max_slots = std::max<std::size_t>(2, slot_budget / (extended_size * 32));
+        for (std::size_t lo = 0; lo < products.size();) {
+            /* the group [lo, hi): as many products as fit `max_slots` distinct columns (the last group also holds the mask) */
+            std::vector<const dfs_type *> unique;
+            auto slot_of = [&unique](const dfs_type *f) { return (std::size_t)(std::find(unique.begin(), unique.end(), f) - unique.begin()); };
+            std::size_t hi = lo;
+            for (; hi < products.size(); ++hi) {
+                const auto &g = products[hi];
+                if (g.factors.empty() || g.rotations.size() != g.factors.size()) throw std::invalid_argument("gate_argument: factors / rotations");
+                std::vector<const dfs_type *> added;
+                for (const dfs_type *f : g.factors)
+                    if (slot_of(f) == unique.size() && std::find(added.begin(), added.end(), f) == added.end()) added.push_back(f);
+                if (hi > lo && unique.size() + added.size() + 1 > max_slots) break;
+                unique.insert(unique.end(), added.begin(), added.end());
+            }
+            const bool last = hi == products.size();
+            const std::size_t U = unique.size();
+            /* where column u (and, at U, the mask -- needed by the last group only) lives on the extended domain */
+            std::vector<const void *> ext_of(U + 1, nullptr);
+            std::vector<dfs_type> keep;
+            std::vector<std::size_t> batched;
+            for (std::size_t u = 0; u <= U; ++u) {
+                if (u == U && !last) break;
+                const dfs_type &f = u < U ? *unique[u] : mask_polynomial;
+                if (f.size() != n) throw std::invalid_argument("gate_argument: every factor lives on the original domain (the mask's size)");
+                if (extended_size == n) ext_of[u] = f.data();
+                else if (f.extension_cache_enabled()) {
+                    keep.push_back(f.extension(extended_size, root));
+                    ext_of[u] = keep.back().data();
+                } else batched.push_back(u);
+            }
+            const std::size_t slots = batched.size();
+            std::shared_ptr<void> d_in, d_ext;
+            if (slots) {
+                d_in = ctx.alloc(slots * n * 32);
+                d_ext = ctx.alloc(slots * extended_size * 32);
+                for (std::size_t b = 0; b < slots; ++b) {
+                    const std::size_t u = batched[b];
+                    const dfs_type &f = u < U ? *unique[u] : mask_polynomial;
+                    check(zkhip_memcpy_d2d_async(ctx.get(), static_cast<char *>(d_in.get()) + b * n * 32, f.data(), n * 32), "zkhip_memcpy_d2d_async", ctx.get());
+                    ext_of[u] = static_cast<const char *>(d_ext.get()) + b * extended_size * 32;
+                }
+                check(zkhip_poly_resize_dev(ctx.get(), adapter::id, d_in.get(), log_n, slots, wn, d_ext.get(), log_e, we), "zkhip_poly_resize_dev", ctx.get());
+            }
+            /* the flat program of the group */
+            std::vector<std::uint32_t> gate_terms {0}, gate_sel, term_factors {0}, factor_slot;
+            std::vector<std::int32_t> gate_sel_rot, factor_rot;
+            std::vector<std::uint64_t> term_coeff;
+            for (std::size_t gi = lo; gi < hi; ++gi) {
+                const auto &g = products[gi];
+                std::size_t degree = 0;
+                for (const dfs_type *f : g.factors) degree += f->degree();
+                if (degree >= extended_size) throw std::invalid_argument("gate_argument: the product's degree does not fit the extended domain");
+                F_degree = std::max(F_degree, degree);
+                const bool same_selector = gi > lo && products[gi - 1].factors[0] == g.factors[0] && products[gi - 1].rotations[0] == g.rotations[0];
+                if (!same_selector) {
+                    if (gi > lo) gate_terms.push_back((std::uint32_t)(term_factors.size() - 1));
+                    gate_sel.push_back((std::uint32_t)slot_of(g.factors[0]));
+                    gate_sel_rot.push_back((std::int32_t)(g.rotations[0] * stretch));
+                }
+                for (std::size_t k = 1; k < g.factors.size(); ++k) {
+                    factor_slot.push_back((std::uint32_t)slot_of(g.factors[k]));
+                    factor_rot.push_back((std::int32_t)(g.rotations[k] * stretch));
+                }
+                term_factors.push_back((std::uint32_t)factor_slot.size());
+                term_coeff.resize(term_coeff.size() + 4);
+                adapter::scalar_to_limbs(g.coefficient, term_coeff.data() + term_coeff.size() - 4);
+            }
+            gate_terms.push_back((std::uint32_t)(term_factors.size() - 1));
+            zkhip_gate_program prog;
+            prog.n_gates = (std::uint32_t)gate_sel.size();
+            prog.n_terms = (std::uint32_t)(term_factors.size() - 1);
+            prog.n_factors = (std::uint32_t)factor_slot.size();
+            prog.n_slots = (std::uint32_t)U;
+            prog.gate_terms = gate_terms.data();
+            prog.gate_selector = gate_sel.data();
+            prog.gate_selector_rot = gate_sel_rot.data();
+            prog.term_factors = term_factors.data();
+            prog.factor_slot = factor_slot.data();
+            prog.factor_rot = factor_rot.data();
+            prog.term_coeff = term_coeff.data();
+            check(zkhip_gate_eval_dev(ctx.get(), adapter::id, &prog, ext_of.data(), log_e, last ? ext_of[U] : nullptr, lo != 0 ? 1 : 0, F.data()),
+                  "zkhip_gate_eval_dev", ctx.get());
+            lo = hi;
+            ctx.sync();    // the group's extensions are released at the end of the iteration
+        }
+        if (F_degree + mask_polynomial.degree() >= extended_size) throw std::invalid_argument("gate_argument: mask * F does not fit the extended domain");
+        F.set_degree(F_degree + mask_polynomial.degree());
+        return F;
+    }
+
+    /// Round 5's evaluation of the same sum: per product a k-way pointwise product and a scaled accumulation (two launches, each streaming
+    /// whole vectors), every (column, rotation) pair extended on its own.  Same polynomial, bit for bit.
+    static dfs_type gate_argument_per_term(const context &ctx, const std::vector<gate_product_hip<CurveType>> &products, const dfs_type &mask_polynomial,
+                                           std::size_t extended_size, const root_of_unity_type &root, std::size_t slot_budget = (std::size_t)16 << 30) {
         if (products.empty()) throw std::invalid_argument("gate_argument: no products");
         dfs_type F(ctx, extended_size);
         bool first = true;

@@ -19,7 +19,7 @@ EXPORTS = [
     "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_batch_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_domain_choice", "zkhip_domain_fft_dev", "zkhip_domain_lagrange_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_set_domain", "zkhip_r1cs_domain_size", "zkhip_r1cs_domain_kind", "zkhip_groth16_scratch_bytes", "zkhip_groth16_witness_h_dev", "zkhip_groth16_witness_h_domain_dev", "zkhip_fr_gather_dev", "zkhip_poly_resize_dev", "zkhip_fri_fold_dev", "zkhip_fri_leaves_dev", "zkhip_ec_ntt_dev",
-    "zkhip_fr_vec_op_dev", "zkhip_fr_vec_affine_dev", "zkhip_fr_vec_mul_div_dev", "zkhip_fr_vec_prod_dev", "zkhip_poly_shift_dev", "zkhip_poly_eval_dev", "zkhip_poly_div_linear_dev", "zkhip_poly_div_vanishing_dev", "zkhip_poly_lincomb_dev", "zkhip_perm_grand_product_dev", "zkhip_lookup_grand_product_dev", "zkhip_lookup_sort_dev", "zkhip_perm_factor_products_dev",
+    "zkhip_fr_vec_op_dev", "zkhip_fr_vec_affine_dev", "zkhip_fr_vec_mul_div_dev", "zkhip_fr_vec_prod_dev", "zkhip_poly_shift_dev", "zkhip_poly_eval_dev", "zkhip_poly_div_linear_dev", "zkhip_poly_div_vanishing_dev", "zkhip_poly_lincomb_dev", "zkhip_perm_grand_product_dev", "zkhip_lookup_grand_product_dev", "zkhip_lookup_sort_dev", "zkhip_perm_factor_products_dev", "zkhip_gate_eval_dev",
     "zkhip_group_init", "zkhip_group_destroy", "zkhip_group_size", "zkhip_group_ctx", "zkhip_group_last_error", "zkhip_group_set_transport", "zkhip_group_transport",
     "zkhip_group_all_gather", "zkhip_group_copy", "zkhip_group_sync", "zkhip_group_bases_upload", "zkhip_group_bases_from_scalars", "zkhip_group_bases_free",
     "zkhip_group_bases_size", "zkhip_group_bases_member", "zkhip_group_msm", "zkhip_group_ntt",
@@ -49,6 +49,13 @@ class Domain(ctypes.Structure):
             for i, v in enumerate(np.asarray(shift, dtype=np.uint64).reshape(4)):
                 d.shift[i] = int(v)
         return d
+
+
+class GateProgram(ctypes.Structure):
+    """zkhip_gate_program"""
+    _fields_ = [("n_gates", ctypes.c_uint32), ("n_terms", ctypes.c_uint32), ("n_factors", ctypes.c_uint32), ("n_slots", ctypes.c_uint32),
+                ("gate_terms", ctypes.c_void_p), ("gate_selector", ctypes.c_void_p), ("gate_selector_rot", ctypes.c_void_p), ("term_factors", ctypes.c_void_p),
+                ("factor_slot", ctypes.c_void_p), ("factor_rot", ctypes.c_void_p), ("term_coeff", ctypes.c_void_p)]
 
 
 def domain_choice(curve: int, min_size: int):
@@ -300,6 +307,29 @@ class Context:
         self._check(self.lib.zkhip_ntt_dev(self.h, curve, ctypes.c_void_p(d_data), ctypes.c_size_t(log_m), ctypes.c_size_t(batch),
                                            _p(_u64(omega)), 1 if inverse else 0, _p(_u64(coset)) if coset is not None else None),
                     "zkhip_ntt_dev")
+
+    # ---- the gate argument's sum over a flat program (zkhip_gate_eval_dev)
+    def gate_eval_dev(self, curve: int, gates, d_slots, log_size: int, d_out: int, d_mask: int = 0, accumulate: bool = False):
+        """gates: [(selector or None, [(coeff int, [(slot, rot), ...]), ...]), ...] with selector = (slot, rot); rotations in rows of the
+        2^log_size-point domain; d_slots: device pointers"""
+        gate_terms, gate_sel, gate_rot, term_factors, fslot, frot, coeffs = [0], [], [], [0], [], [], []
+        for sel, terms in gates:
+            gate_sel.append(0xFFFFFFFF if sel is None else sel[0])
+            gate_rot.append(0 if sel is None else sel[1])
+            for c, factors in terms:
+                for sl, rt in factors:
+                    fslot.append(sl)
+                    frot.append(rt)
+                term_factors.append(len(fslot))
+                coeffs.append([(c >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)])
+            gate_terms.append(len(term_factors) - 1)
+        keep = [np.array(gate_terms, dtype=np.uint32), np.array(gate_sel, dtype=np.uint32), np.array(gate_rot, dtype=np.int32),
+                np.array(term_factors, dtype=np.uint32), np.array(fslot or [0], dtype=np.uint32), np.array(frot or [0], dtype=np.int32),
+                np.array(coeffs or [[0, 0, 0, 0]], dtype=np.uint64)]
+        prog = GateProgram(len(gate_sel), len(coeffs), len(fslot), len(d_slots), *[a.ctypes.data_as(ctypes.c_void_p) for a in keep])
+        S = (ctypes.c_void_p * max(1, len(d_slots)))(*d_slots)
+        self._check(self.lib.zkhip_gate_eval_dev(self.h, curve, ctypes.byref(prog), S, ctypes.c_size_t(log_size), ctypes.c_void_p(d_mask) if d_mask else None,
+                                                 1 if accumulate else 0, ctypes.c_void_p(d_out)), "zkhip_gate_eval_dev")
 
     # ---- Groth16 witness map
     def upload_r1cs(self, curve: int, M: int, n: int, N: int, csr_a, csr_b, csr_c) -> "R1CS":

@@ -369,6 +369,32 @@ def reduce_dfs_polynomial_domain(evals, new_size: int) -> np.ndarray:
     return np.ascontiguousarray(e[:: e.shape[0] // new_size])
 
 
+def dfs_resize(curve, evals, new_size: int) -> np.ndarray:
+    """polynomial_dfs::resize (pyoracle.dfs_resize): coefficients over the old domain, evaluations over the new power-of-two domain
+    (a smaller one takes every k-th evaluation -- the caller knows the degree fits)"""
+    e = _u64(evals)
+    n = e.shape[0]
+    if new_size == n:
+        return e.copy()
+    if new_size < n:
+        return reduce_dfs_polynomial_domain(e, new_size)
+    return ntt_wide(curve, _pad(ntt_wide(curve, e, inverse=True), new_size))
+
+
+def gate_argument_dfs(curve, products, mask, extended_size: int) -> np.ndarray:
+    """pyoracle.gate_argument_dfs (gates_argument.hpp:203-216) statement by statement over limb arrays: products = [(coefficient, [(evals,
+    rotation), ...]), ...] over the ORIGINAL domain; every factor shifted there (:108-110), resized to the extended domain (:111-113),
+    multiplied pointwise; the weighted sum times the extended mask (:215).  Pinned to pyoracle at <= 2^8 rows in tests/test_oracle_kat.py."""
+    F = np.zeros((extended_size, 4), dtype=np.uint64)
+    for coeff, factors in products:
+        term = np.repeat(_ONE, extended_size, axis=0)
+        for evals, rot in factors:
+            e = polynomial_shift(evals, rot) if rot else _u64(evals)
+            term = fr_vec(curve, 2, term, dfs_resize(curve, e, extended_size))
+        F = fr_vec(curve, 0, F, fr_vec(curve, 3, term, _limbs(coeff % _R[curve])))
+    return fr_vec(curve, 2, F, dfs_resize(curve, mask, extended_size))
+
+
 _ONE = np.array([[1, 0, 0, 0]], dtype=np.uint64)
 
 

@@ -742,6 +742,50 @@ int precommit_leaves_t(const uint64_t *evals, size_t npolys, const uint64_t *log
     return 0;
 }
 
+/// placeholder_quotient_hip::gate_argument on a product list the caller describes (coefficient, then (column, rotation) pairs; the first
+/// factor of a product is its selector by convention).  variant 0: the fused evaluation (one launch over a flat program), 1: round 5's two
+/// launches per product, 2: fused with a slot budget that forces several groups (accumulate), 3: fused with the extension cache on for
+/// the even columns and the mask (twice: the second run reads the caches).  `degrees[c]`: the degree claimed for column c.
+template <typename Curve>
+int gate_argument_t(const uint64_t *evals, size_t ncols, size_t log_n, const uint64_t *degrees, const uint64_t *mask_evals, size_t mask_degree, const uint64_t *roots,
+                    size_t nprod, const uint64_t *coeffs, const uint64_t *nfac, const int64_t *fac, size_t log_ext, int variant, uint64_t *out, uint64_t *out_degree) {
+    typedef curve_adapter<Curve> A;
+    typedef device_polynomial_dfs<Curve> dfs;
+    typedef placeholder_quotient_hip<Curve> Q;
+    context ctx(0);
+    auto root = [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); };
+    const size_t n = (size_t)1 << log_n, ext = (size_t)1 << log_ext;
+    auto make = [&](const uint64_t *e, size_t degree) {
+        polynomial_dfs<Curve> h;
+        for (size_t i = 0; i < n; ++i) h.values.push_back(A::scalar_from_limbs(e + 4 * i));
+        return dfs(ctx, h, degree);
+    };
+    std::vector<dfs> cols;
+    cols.reserve(ncols);
+    for (size_t c = 0; c < ncols; ++c) cols.push_back(make(evals + 4 * n * c, degrees[c]));
+    dfs mask = make(mask_evals, mask_degree);
+    if (variant == 3) {
+        for (size_t c = 0; c < ncols; c += 2) cols[c].enable_extension_cache();
+        mask.enable_extension_cache();
+    }
+    std::vector<gate_product_hip<Curve>> products(nprod);
+    size_t at = 0;
+    for (size_t p = 0; p < nprod; ++p) {
+        products[p].coefficient = A::scalar_from_limbs(coeffs + 4 * p);
+        for (size_t k = 0; k < nfac[p]; ++k, ++at) {
+            products[p].factors.push_back(&cols.at((size_t)fac[2 * at]));
+            products[p].rotations.push_back((int)fac[2 * at + 1]);
+        }
+    }
+    const size_t budget = variant == 2 ? 3 * ext * 32 : (size_t)16 << 30;    // three slots: one product (plus the mask) per group at most
+    dfs F = variant == 1 ? Q::gate_argument_per_term(ctx, products, mask, ext, root) : Q::gate_argument(ctx, products, mask, ext, root, budget);
+    if (variant == 3) F = Q::gate_argument(ctx, products, mask, ext, root);
+    if (F.size() != ext) return -2;
+    *out_degree = F.degree();
+    ctx.d2h(out, F.data(), ext * 32);
+    return 0;
+}
+
 /// a.resize(big); b.resize(big); a *= b (out_prod); then a -> coefficients -> from_coefficients (out_round), a += b, a -= b (out_addsub);
 /// fold of the product with alpha (out_fold, big / 2 elements)
 template <typename Curve>
@@ -1979,6 +2023,12 @@ int shim_precommit_leaves(int curve, const uint64_t *evals, size_t npolys, const
     CURVE_CALL("shim_precommit_leaves", precommit_leaves_t, evals, npolys, log_n, log_domain, fri_step, roots, out)
 }
 
+int shim_gate_argument(int curve, const uint64_t *evals, size_t ncols, size_t log_n, const uint64_t *degrees, const uint64_t *mask_evals, size_t mask_degree,
+                       const uint64_t *roots, size_t nprod, const uint64_t *coeffs, const uint64_t *nfac, const int64_t *fac, size_t log_ext, int variant,
+                       uint64_t *out, uint64_t *out_degree) {
+    CURVE_CALL("shim_gate_argument", gate_argument_t, evals, ncols, log_n, degrees, mask_evals, mask_degree, roots, nprod, coeffs, nfac, fac, log_ext, variant, out,
+               out_degree)
+}
 int shim_dfs_ops(int curve, const uint64_t *a_evals, const uint64_t *b_evals, size_t log_n, size_t log_big, const uint64_t *roots, const uint64_t *alpha,
                  uint64_t *out_prod, uint64_t *out_round, uint64_t *out_addsub, uint64_t *out_fold) {
     CURVE_CALL("shim_dfs_ops", dfs_ops_t, a_evals, b_evals, log_n, log_big, roots, alpha, out_prod, out_round, out_addsub, out_fold)

@@ -1,6 +1,8 @@
 """Coefficient-form polynomial arithmetic behind the KZG opening proof (kzg_v2.hpp:236-305) through the C ABI,
 against plain big-integer arithmetic: pointwise operators, batched evaluation, division by (X - z), and the
 multi-polynomial accumulation f += theta_i (f_i - U_i) diffpoly_i."""
+from functools import reduce
+
 import numpy as np
 import pytest
 
@@ -385,3 +387,72 @@ def test_block_cache_behind_malloc_free(ctx):
     assert q in third._live
     third.close()
     assert not third._live and q not in zk.zkhip._BLOCK_HOLDER
+
+
+@pytest.mark.parametrize("curve,log_size", [(0, 6), (1, 9), (0, 14), (1, 16)])
+def test_gate_eval_flat_program(zk, ctx, curve, log_size):
+    """zkhip_gate_eval_dev: the gate argument's sum as ONE launch over a flat program (gates_argument.hpp:93-121, 203-216 once the
+    expressions are monomials) against the same sum from big integers / the oracle's pointwise arithmetic: gates with and without a
+    selector, shared factors, a repeated column, rotations of both signs that wrap, a constant term, more than 16 terms in one gate
+    (the unreduced sums fold), an empty gate; with and without mask; accumulate."""
+    C = CURVES[curve]
+    r, size = C.r, 1 << log_size
+    n_slots = 6
+    cols = [cp.random_fr(curve, 700 + s, size) for s in range(n_slots)]
+    cols[5][::3] = 0  # a selector-like column
+    rng = po.SplitMix64(55 + log_size)
+    big_gate = (None, [(rng.next_mod(r), [(t % 5, (t % 7) - 3), ((t + 1) % 5, 0)]) for t in range(37)])
+    gates = [((5, 0), [(rng.next_mod(r), [(0, 0), (1, 1)]), (r - 1, [(2, -1)])]),
+             ((5, 2), [(rng.next_mod(r), [(0, 2), (0, 0), (3, -2)]), (7, [])]),
+             (None, [(rng.next_mod(r), [(4, 1), (4, 1), (4, size - 1)])]),
+             big_gate, (None, []), ((3, -5), [(1, [])])]
+
+    def expect(gs, mask=None, prev=None):
+        acc = np.zeros((size, 4), dtype=np.uint64) if prev is None else prev
+        for sel, terms in gs:
+            g = np.zeros((size, 4), dtype=np.uint64)
+            for c, factors in terms:
+                t = np.repeat(fr_arr([c]), size, axis=0)
+                for sl, rot in factors:
+                    t = cp.fr_vec(curve, 2, t, np.roll(cols[sl], -rot, axis=0))
+                g = cp.fr_vec(curve, 0, g, t)
+            if sel is not None:
+                g = cp.fr_vec(curve, 2, g, np.roll(cols[sel[0]], -sel[1], axis=0))
+            acc = cp.fr_vec(curve, 0, acc, g)
+        return cp.fr_vec(curve, 2, acc, mask) if mask is not None else acc
+
+    d_slots = [ctx.malloc(size * 32) for _ in range(n_slots)]
+    for p, c in zip(d_slots, cols):
+        ctx.h2d(p, c)
+    mask = cp.random_fr(curve, 799, size)
+    mask[-5:] = 0
+    d_mask, d_out = ctx.malloc(size * 32), ctx.malloc(size * 32)
+    ctx.h2d(d_mask, mask)
+    out = np.zeros((size, 4), dtype=np.uint64)
+    ctx.gate_eval_dev(curve, gates, d_slots, log_size, d_out, d_mask)
+    ctx.d2h(out, d_out)
+    want = expect(gates, mask)
+    assert (out == want).all()
+    if log_size <= 9:  # and from big integers, row by row
+        ci = [fr_ints(c) for c in cols]
+        mi = fr_ints(mask)
+        for j in (0, 1, size // 2, size - 1):
+            tot = 0
+            for sel, terms in gates:
+                g = sum(c * reduce(lambda a, b: a * b % r, [ci[sl][(j + rot) % size] for sl, rot in fs], 1) for c, fs in terms) % r
+                tot += g * (ci[sel[0]][(j + sel[1]) % size] if sel is not None else 1)
+            assert po.from_limbs(out[j]) == tot * mi[j] % r
+    # in two pieces: the first without mask, the second accumulates and carries the mask
+    ctx.gate_eval_dev(curve, gates[:2], d_slots, log_size, d_out)
+    ctx.d2h(out, d_out)
+    assert (out == expect(gates[:2])).all()
+    ctx.gate_eval_dev(curve, gates[2:], d_slots, log_size, d_out, d_mask, accumulate=True)
+    ctx.d2h(out, d_out)
+    assert (out == want).all()
+    # a malformed program is refused on the host
+    with pytest.raises(zk.ZkhipError):
+        ctx.gate_eval_dev(curve, [(None, [(1, [(n_slots, 0)])])], d_slots, log_size, d_out)
+    with pytest.raises(zk.ZkhipError):
+        ctx.gate_eval_dev(curve, [((n_slots + 3, 0), [(1, [(0, 0)])])], d_slots, log_size, d_out)
+    for p in d_slots + [d_mask, d_out]:
+        ctx.free(p)

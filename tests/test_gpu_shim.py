@@ -1296,3 +1296,38 @@ def test_kzg_placeholder_contract_shim(shim, curve):
     _, f, L = po.kzg_v2_proof_eval(r, polys, points, theta, theta2)
     g = lambda e: cp.batch_mul(curve, 1, fr_arr([e]))[0][0]
     assert (pi[0] == g(po.poly_eval(f, alpha, r))).all() and (pi[1] == g(po.poly_eval(L, alpha, r))).all()
+
+
+@pytest.mark.parametrize("curve,log_n", [(0, 6), (1, 8), (0, 12), (1, 14), (0, 16)])
+def test_gate_argument_fused_flat_program(shim, curve, log_n):
+    """placeholder_quotient_hip::gate_argument as ONE launch over a flat program (zkhip_gate_eval_dev; gates_argument.hpp:93-121,
+    203-216) against the C++ oracle's statement-by-statement restatement (cport.gate_argument_dfs, pinned to pyoracle at <= 2^8 rows) on
+    a gate set with shared factors, rotations +-1 / +-2, a repeated column, a selector used with a rotation, a one-factor product, and a
+    mask that is not all ones -- 2^6 ... 2^16 rows, extended domain 4 n, both curves.  Four evaluations must agree with the oracle bit
+    for bit: fused; round 5's two launches per product; fused in several accumulating groups; fused from extension caches (twice)."""
+    C = CURVES[curve]
+    r, n, log_ext = C.r, 1 << log_n, log_n + 2
+    ncols = 7
+    cols = [cp.random_fr(curve, 1200 + c, n) for c in range(ncols)]
+    cols[0][1::2] = 0                                           # selectors: zero on half / two thirds of the rows
+    cols[1][::3] = 0
+    mask = np.repeat(fr_arr([1]), n, axis=0)
+    mask[-4:] = 0
+    rng = po.SplitMix64(60 + log_n)
+    # (coefficient, [(column, rotation), ...]); the first factor is the selector.  Degrees: every product has <= 4 factors of degree n - 1
+    products = [(rng.next_mod(r), [(0, 0), (2, 0), (3, 1)]), (r - 1, [(0, 0), (4, -1)]), (rng.next_mod(r), [(0, 0), (2, 2), (2, 0)]),
+                (rng.next_mod(r), [(1, 0), (3, -2), (5, 0)]), (5, [(1, 0)]), (rng.next_mod(r), [(1, 1), (6, 0), (6, 1)]),
+                (rng.next_mod(r), [(4, 0), (5, 1)]), (rng.next_mod(r), [(0, 0), (6, -1), (3, 1)])]
+    want = cp.gate_argument_dfs(curve, [(c, [(cols[k], rot) for k, rot in fs]) for c, fs in products], mask, 4 * n)
+    roots = np.stack([limbs(C.root_of_unity(l), 4) for l in range(log_ext + 1)])
+    u64 = lambda v: np.array(v, dtype=np.uint64)
+    fac = np.array([x for _, fs in products for k, rot in fs for x in (k, rot)], dtype=np.int64)
+    for variant in (0, 1, 2, 3):
+        out = np.zeros((4 * n, 4), dtype=np.uint64)
+        deg = np.zeros(1, dtype=np.uint64)
+        rc = shim.shim_gate_argument(curve, P(np.concatenate(cols)), ctypes.c_size_t(ncols), ctypes.c_size_t(log_n), P(u64([n - 1] * ncols)), P(mask),
+                                     ctypes.c_size_t(n - 1), P(roots), ctypes.c_size_t(len(products)), P(fr_arr([c for c, _ in products])),
+                                     P(u64([len(fs) for _, fs in products])), P(fac), ctypes.c_size_t(log_ext), variant, P(out), P(deg))
+        assert rc == 0, variant
+        assert (out == want).all(), variant
+        assert int(deg[0]) == 3 * (n - 1) + (n - 1), variant   # the largest product (three factors) times the mask

@@ -116,6 +116,26 @@ def test_ntt_oracles(curve):
         assert (cp.ntt(curve, oc, lg, limbs(w, 4), inverse=True, coset=limbs(g, 4)) == arr).all()
 
 
+@pytest.mark.parametrize("curve,log_n", [(0, 4), (1, 5), (0, 7)])
+def test_fast_gate_argument_oracle_equals_dense_oracle(curve, log_n):
+    """cport.gate_argument_dfs (limb arrays, transform-based resize: the yard-stick of the fused gate kernel at 2^12 - 2^16 rows) against
+    pyoracle.gate_argument_dfs (big integers; held to the dense definition in test_placeholder_quotient_chain_definitions): several gates
+    sharing factors, rotations +-1 / +-2, a repeated column, a constant term, a mask that is not all ones."""
+    C = CURVES[curve]
+    r, n = C.r, 1 << log_n
+    rng = random.Random(100 + log_n)
+    cols = [[rng.randrange(r) for _ in range(n)] for _ in range(5)]
+    sel = [[rng.randrange(r) if rng.random() < 0.5 else 0 for _ in range(n)] for _ in range(2)]
+    mask = [1 if i < n - 3 else 0 for i in range(n)]
+    products = [(rng.randrange(r), [(sel[0], 0), (cols[0], 0), (cols[1], 1)]), (r - 1, [(sel[0], 0), (cols[2], -1)]),
+                (rng.randrange(r), [(sel[1], 0), (cols[0], 2), (cols[0], 0), (cols[3], -2)]), (7, [(sel[1], 0)]),
+                (rng.randrange(r), [(cols[4], 1), (cols[4], 1)])]
+    ext = 4 * n
+    want = po.gate_argument_dfs(products, mask, ext, C.root_of_unity, r)
+    got = cp.gate_argument_dfs(curve, [(c, [(fr_arr(e), rot) for e, rot in fs]) for c, fs in products], fr_arr(mask), ext)
+    assert fr_ints(got) == want
+
+
 @pytest.mark.parametrize("curve", [0, 1])
 def test_ntt_oracle_threads_inside_equals_one_thread_per_polynomial(curve):
     """cport.ntt transforms a batch smaller than half the thread count with the threads INSIDE each transform (bench.py's CPU NTT baseline
