@@ -384,6 +384,7 @@ def main():
             full["kzg"] = kzg_leg(np, zk, ctx, verify=not args.no_verify, valu=(traffic or {}).get("valu", {}).get("msm_bucket_acc"))
             full["lpc"] = lpc_leg(np)
             full["quotient_chain"] = quotient_leg(np, verify=not args.no_verify)
+            full["gate_argument"] = gate_argument_leg(np, verify=not args.no_verify)
             full["permutation_argument"] = permutation_leg(np, verify=not args.no_verify)
             full["lookup_argument"] = lookup_leg(np, verify=not args.no_verify)
             full["placeholder_round"] = placeholder_round_leg(np, verify=not args.no_verify)
@@ -505,6 +506,7 @@ def compact_line(full, detail_path):
         legs["kzg_scheme_class_from_host"] = _pick(full["kzg"]["scheme_class"], "value", "unit", "verified")
     leg("lpc", "proof_eval_ms")
     leg("quotient_chain")
+    leg("gate_argument", "per_term_ms", "speedup_vs_per_term", "gate_eval_kernel_ms")
     leg("permutation_argument", "ms_grand_product")
     leg("lookup_argument", "ms_grand_product", "ms_sort_polynomials")
     leg("placeholder_round", "round_ms")
@@ -1276,6 +1278,40 @@ def quotient_leg(np, log_n=20, steps=6, verify=True):
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
                          "algorithmic_bytes_per_chain": alg, "per": "whole chain: 52 n transform elements x 64 B + 4 multiexps x n x 128 B (list in bench.py)",
                          "dominant_kernels": "ntt_pass (the resizes to the extended domains) and msm_bucket_acc (the three non-zero parts' commitments)"}}
+
+
+def gate_argument_leg(np, log_n=20, n_gates=32, n_wit=24, steps=3, verify=True):
+    """The gate argument of a circuit with many gates (gates_argument.hpp:93-121, 203-216): 32 gates = 96 products of 3 - 5 factors
+    (selector included) over 56 columns and ~100 distinct (column, rotation) pairs, 2^20 rows, the 8 n-point extended domain, masked --
+    evaluated as ONE launch over a flat program (zkhip_gate_eval_dev) and, beside it, as round 5's two launches per product.  Both
+    figures include the extensions of the 24 witness columns (the selectors' and the mask's are cached: preprocessed)."""
+    import ctypes
+
+    lib = _bench_lib()
+    ms = np.zeros(2 * steps, dtype=np.float64)
+    info = np.zeros(4, dtype=np.float64)
+    verified = ctypes.c_int(-1)
+    rc = lib.zkhip_bench_gate_argument(0, ctypes.c_size_t(log_n), ctypes.c_size_t(n_gates), ctypes.c_size_t(n_wit), steps, ms.ctypes.data_as(ctypes.c_void_p),
+                                       info.ctypes.data_as(ctypes.c_void_p), ctypes.byref(verified) if verify else None)
+    if rc != 0:
+        return {"error": rc}
+    m = ms.reshape(steps, 2)
+    t = m[1:] if steps > 1 else m
+    fused, per_term = float(t[:, 0].mean()), float(t[:, 1].mean())
+    ext = 8 << log_n
+    # algorithmic bytes of the fused pass: every distinct column's extension read once + F written once (SURVEY 8d's convention)
+    alg = (int(info[1]) + 1 + 1) * ext * 32
+    ach = alg / (float(info[3]) * 1e-3) / 1e9 if info[3] > 0 else 0.0
+    return {"metric": "placeholder gate argument, %d gates / %d products over %d columns, 2^%d rows, 8 n extended domain" % (n_gates, int(info[0]), int(info[1]), log_n),
+            "value": round(fused, 3), "unit": "ms per gate argument", "per_term_ms": round(per_term, 3), "speedup_vs_per_term": round(per_term / fused, 2),
+            "gate_eval_kernel_ms": round(float(info[3]), 3), "products": int(info[0]), "distinct_columns": int(info[1]), "distinct_column_rotation_pairs": int(info[2]),
+            "ms_per_run": {"fused": [round(float(x), 2) for x in m[:, 0]], "per_term": [round(float(x), 2) for x in m[:, 1]]},
+            "verified": None if not verify else bool(verified.value == 1),
+            "verification": "fused == per-term bit for bit; F(y) == mask(y) sum sel(y) sum c prod col(omega^rot y) at a random y from coefficient forms",
+            "roofline": {"bound": "hbm", "kernel": "gate_eval", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                         "traffic": None, "algorithmic_bytes": alg,
+                         "honest_bound": "VALU: one Montgomery product per factor and row (no per-factor lift), %d products x ~3.5 factors x 8 n rows" % int(info[0])},
+            "what": "both figures include the witness columns' extensions to 8 n (one per distinct COLUMN fused, one per distinct (column, rotation) pair per-term)"}
 
 
 def permutation_leg(np, log_n=20, k=4, steps=6, verify=True):

@@ -6,6 +6,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <array>
+#include <map>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -448,6 +451,135 @@ int zkhip_bench_quotient(int device, size_t log_n, int steps, double *ms, int *v
         return 0;
     } catch (const std::exception &e) {
         fprintf(stderr, "zkhip_bench_quotient: %s\n", e.what());
+        return -1;
+    }
+}
+
+/* The gate argument of a circuit with MANY gates (VERDICT r5 missing #2: the quotient leg's one four-factor gate hides what per-term launches
+ * cost): n_gates gates, each a (preprocessed, cached) selector times a sum of 3 products of 2 - 4 witness columns with rotations from
+ * {0, +1, -1} -- 3 - 5 factors per product with the selector -- over n_wit witness columns of 2^log_n rows, on the 8 n-point extended domain
+ * (n * 2^ceil(log2(5 + 1)), gates_argument.hpp:149-150), masked.  ms: steps x {fused: one launch over the flat program; per_term: round 5's
+ * two launches per product}, both INCLUDING the extensions of the witness columns (the selectors' and the mask's extensions are cached:
+ * preprocessed).  info: {products, distinct columns, distinct (column, rotation) pairs, gate_eval kernel ms of the last fused run}.
+ * *verified: both evaluations bit-equal, and F(y) == mask(y) sum_g sel_g(y) sum_t c_t prod_f col_f(omega^rot y) at a random y with every
+ * polynomial evaluated from its COEFFICIENT form (independent of the extension, the rotations' index arithmetic and the program). */
+int zkhip_bench_gate_argument(int device, size_t log_n, size_t n_gates, size_t n_wit, int steps, double *ms, double *info, int *verified) {
+    try {
+        typedef placeholder_quotient_hip<C> Q;
+        typedef device_polynomial_dfs<C> dfs;
+        const size_t n = (size_t)1 << log_n, ext = 8 * n;
+        context ctx(device);
+        uint64_t seed = 4242;
+        auto sm = [&seed]() {
+            uint64_t z = (seed += 0x9E3779B97F4A7C15ull);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return z ^ (z >> 31);
+        };
+        auto rnd = [&]() {
+            uint64_t w[4] = {sm(), sm(), sm(), sm() & 0x0fffffffffffffffull};
+            return A::scalar_from_limbs(w);
+        };
+        /* columns are generated ON the device (a host vector of 2^20 field values per column would take minutes to fill for 56 columns):
+           column c = the inverse transform of nothing in particular -- its rows are c-dependent multiples of the powers of a random base */
+        std::vector<dfs> sel, wit;
+        auto fill = [&](std::vector<dfs> &out, size_t count) {
+            polynomial_dfs<C> h;
+            h.values.resize(n);
+            for (size_t c = 0; c < count; ++c) {
+                const Fr base = rnd();
+                Fr x = rnd();
+                for (size_t i = 0; i < n; ++i) h.values[i] = x, x = x * base;
+                out.emplace_back(ctx, h, n - 1);
+            }
+        };
+        fill(sel, n_gates);
+        fill(wit, n_wit);
+        polynomial_dfs<C> hm;
+        hm.values.assign(n, Fr::one());
+        for (size_t i = n - 8; i < n; ++i) hm.values[i] = Fr::zero();
+        dfs mask(ctx, hm, n - 1);
+        for (auto &s : sel) s.enable_extension_cache();
+        mask.enable_extension_cache();
+        std::vector<gate_product_hip<C>> products;
+        const int rots[3] = {0, 1, -1};
+        std::vector<std::pair<const dfs *, int>> pairs;
+        for (size_t g = 0; g < n_gates; ++g)
+            for (int t = 0; t < 3; ++t) {
+                gate_product_hip<C> p;
+                p.factors.push_back(&sel[g]);
+                p.rotations.push_back(0);
+                const size_t k = 2 + (sm() % 3);    // 2 - 4 witness factors
+                for (size_t f = 0; f < k; ++f) {
+                    p.factors.push_back(&wit[sm() % n_wit]);
+                    p.rotations.push_back(rots[sm() % 3]);
+                }
+                p.coefficient = rnd();
+                for (size_t f = 0; f < p.factors.size(); ++f) {
+                    const std::pair<const dfs *, int> key(p.factors[f], p.rotations[f]);
+                    if (std::find(pairs.begin(), pairs.end(), key) == pairs.end()) pairs.push_back(key);
+                }
+                products.push_back(std::move(p));
+            }
+        info[0] = (double)products.size();
+        info[1] = (double)(n_gates + n_wit);
+        info[2] = (double)pairs.size();
+        std::unique_ptr<dfs> fused, per_term;
+        for (int rep = 0; rep < steps; ++rep) {
+            auto t0 = std::chrono::steady_clock::now();
+            dfs F = Q::gate_argument(ctx, products, mask, ext, bls_root);
+            ctx.sync();
+            ms[2 * rep] = ms_since(t0);
+            t0 = std::chrono::steady_clock::now();
+            dfs P = Q::gate_argument_per_term(ctx, products, mask, ext, bls_root);
+            ctx.sync();
+            ms[2 * rep + 1] = ms_since(t0);
+            if (rep == steps - 1) {
+                fused.reset(new dfs(F));
+                per_term.reset(new dfs(P));
+            }
+        }
+        /* the kernel alone: one more fused run with HIP events around its launches */
+        zkhip_profile_reset(ctx.get());
+        zkhip_profile_enable(ctx.get(), 1);
+        (void)Q::gate_argument(ctx, products, mask, ext, bls_root);
+        zkhip_profile_enable(ctx.get(), 0);
+        double kms = 0;
+        uint64_t kc = 0;
+        zkhip_profile_get(ctx.get(), "gate_eval", &kms, &kc);
+        info[3] = kms;
+        if (verified) {
+            std::vector<uint64_t> a(4 * ext), b(4 * ext);
+            ctx.d2h(a.data(), fused->data(), ext * 32);
+            ctx.d2h(b.data(), per_term->data(), ext * 32);
+            bool ok = a == b && fused->degree() == per_term->degree();
+            std::vector<uint64_t>().swap(a);
+            std::vector<uint64_t>().swap(b);
+            const Fr y = rnd(), w = bls_root(log_n), wi = w.inversed();
+            const Fr pts[3] = {y, y * w, y * wi};    // rotation 0, +1, -1
+            uint64_t pl[12], v[12];
+            for (int i = 0; i < 3; ++i) A::scalar_to_limbs(pts[i], pl + 4 * i);
+            auto evals_of = [&](const dfs &p) {    // p at y, omega y, omega^-1 y from its coefficients
+                auto c = p.coefficients(bls_root);
+                check(zkhip_poly_eval_dev(ctx.get(), A::id, c.get(), p.size(), p.size(), 1, pl, 3, v), "zkhip_poly_eval_dev", ctx.get());
+                return std::array<Fr, 3> {A::scalar_from_limbs(v), A::scalar_from_limbs(v + 4), A::scalar_from_limbs(v + 8)};
+            };
+            std::map<const dfs *, std::array<Fr, 3>> at;
+            for (const auto &s : sel) at[&s] = evals_of(s);
+            for (const auto &c : wit) at[&c] = evals_of(c);
+            Fr total = Fr::zero();
+            for (const auto &p : products) {
+                Fr t = p.coefficient;
+                for (size_t f = 0; f < p.factors.size(); ++f) t = t * at[p.factors[f]][p.rotations[f] == 0 ? 0 : (p.rotations[f] == 1 ? 1 : 2)];
+                total = total + t;
+            }
+            total = total * evals_of(mask)[0];
+            ok = ok && evals_of(*fused)[0] == total;
+            *verified = ok ? 1 : 0;
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkhip_bench_gate_argument: %s\n", e.what());
         return -1;
     }
 }
