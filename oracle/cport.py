@@ -554,3 +554,207 @@ def quotient_polynomial(curve, F_coeffs, alphas, n: int):
     assert lib().zko_poly_div_vanishing(curve, _p(acc), ctypes.c_size_t(len(acc)), ctypes.c_size_t(n), _p(q), ctypes.byref(nz)) == 0
     assert nz.value == 0, "the constraints do not vanish on the rows"
     return poly_trim(q)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The commitment SCHEMES at sizes pyoracle's dense O(n^2) arithmetic cannot reach: LPC's leaf layout and opening
+# proof through the FRI commit phase, the two batched KZG opening proofs.  Each function follows its pyoracle namesake statement by
+# statement -- same sums, same divisions, same order -- over (len, 4) uint64 limb arrays; products by transforms (poly_mul), divisions
+# by linear factors as synthetic divisions (exact: the remainders are the reference's BOOST_ASSERTs and are asserted here), the few-
+# coefficient polynomials (U, V, the difference polynomials) in Python integers through pyoracle's own helpers.  PINNED to pyoracle at
+# <= 2^8 in tests/test_oracle_kat.py::test_fast_scheme_oracle_*.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _ints(a):
+    return [int(x[0]) | (int(x[1]) << 64) | (int(x[2]) << 128) | (int(x[3]) << 192) for x in _u64(a).reshape(-1, 4)]
+
+
+def _arr(vals):
+    return np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in vals], dtype=np.uint64).reshape(len(vals), 4)
+
+
+def poly_eval(curve, coeffs, x: int) -> int:
+    c = _u64(coeffs).reshape(-1, 4)
+    if len(c) == 0:
+        return 0
+    return _ints(fr_horner(curve, c, _limbs(x % _R[curve])).reshape(1, 4))[0]
+
+
+def poly_div_linear(curve, f, z: int):
+    """(quotient, remainder) of f / (X - z), coefficient arrays"""
+    f = _u64(f).reshape(-1, 4)
+    if len(f) == 0:
+        return f, 0
+    q, rem = np.zeros((len(f) - 1, 4), dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+    assert lib().zko_poly_div_linear(curve, _p(f), ctypes.c_size_t(len(f)), _p(_limbs(z % _R[curve])), _p(q), _p(rem)) == 0
+    return q, _ints(rem.reshape(1, 4))[0]
+
+
+def poly_div_exact_by_roots(curve, f, roots):
+    """f / prod (X - x) for x in roots, asserting every remainder (pyoracle: poly_divmod + `assert not rem`)"""
+    for x in roots:
+        f, rem = poly_div_linear(curve, f, x)
+        assert rem == 0, "the division is not exact"
+    return f
+
+
+def fri_leaves(polys_on_D, fri_step: int) -> np.ndarray:
+    """pyoracle.fri_leaves (basic_fri.hpp:456-492, FRI::m = 2) as an index computation: the offsets of a leaf's pairs relative to x do not
+    depend on x"""
+    polys = [_u64(p).reshape(-1, 4) for p in polys_on_D]
+    D, coset = polys[0].shape[0], 1 << fri_step
+    off = [0] * (coset // 2)
+    base, prev_half, i = D // 4, 1, 1
+    while i < coset // 2:
+        for j in range(prev_half):
+            off[i] = (base + off[j]) % D
+            i += 1
+        base //= 2
+        prev_half <<= 1
+    x = np.arange(D // coset, dtype=np.int64)[:, None]
+    first = (x + np.array(off, dtype=np.int64)[None, :]) % D                       # (leaves, coset / 2)
+    idx = np.stack([first, (first + D // 2) % D], axis=2).reshape(D // coset, coset)    # the pairs (s, s + D / 2), in order
+    out = np.stack([p[idx] for p in polys], axis=1)                                # (leaves, polys, coset, 4)
+    return np.ascontiguousarray(out.reshape(-1, 4))
+
+
+def fold_polynomial_dfs(curve, f, alpha: int, omega: int) -> np.ndarray:
+    f = _u64(f).reshape(-1, 4)
+    log_size = f.shape[0].bit_length() - 1
+    out = np.zeros((f.shape[0] // 2, 4), dtype=np.uint64)
+    assert lib().zko_fri_fold(curve, _p(f), ctypes.c_size_t(log_size), _p(_limbs(alpha % _R[curve])), _p(_limbs(omega % _R[curve])), _p(out)) == 0
+    return out
+
+
+def toy_root(curve):
+    """the tests' stand-in for the caller's Merkle tree, on limb arrays: (per_leaf + sum_i (i + 1) v_i) mod r"""
+    def root(leaves, per_leaf: int) -> int:
+        a = _u64(leaves).reshape(-1, 4)
+        out = np.zeros(4, dtype=np.uint64)
+        assert lib().zko_toy_root(curve, _p(a), ctypes.c_size_t(a.shape[0]), ctypes.c_uint64(per_leaf), _p(out)) == 0
+        return _ints(out.reshape(1, 4))[0]
+    return root
+
+
+def _root_int(curve, log_n: int) -> int:
+    return pow(_GEN[curve], (_R[curve] - 1) >> log_n, _R[curve])
+
+
+def lpc_proof_eval(curve, batches: dict, points: dict, fixed, log_domain: int, step_list, challenges, tree_root):
+    """pyoracle.lpc_proof_eval (lpc.hpp:101-200 + basic_fri.hpp:433-496, 705-742 + fold_polynomial.hpp:68-93) over limb arrays.
+    batches[k]: DFS polynomials as (2^l, 4) arrays; -> (roots {k: int}, z {k: [[int]]}, fri_roots [int], final coefficients array)"""
+    r = _R[curve]
+    D = 1 << log_domain
+    ch = iter(challenges)
+    coeffs = {k: [ntt_wide(curve, p, inverse=True) for p in ps] for k, ps in batches.items()}
+    roots = {}
+    for k in sorted(batches):
+        ext = [dfs_resize(curve, p, D) for p in batches[k]]
+        roots[k] = tree_root(fri_leaves(ext, step_list[0]), len(ext) << step_list[0])
+    etha = next(ch)
+    fixed_vals = {k: [poly_eval(curve, c, etha) for c in coeffs[k]] for k in fixed}
+    assert next(ch) == etha
+    z = {k: [[poly_eval(curve, coeffs[k][i], x) for x in points[k][i]] for i in range(len(coeffs[k]))] for k in sorted(batches)}
+    theta = next(ch)
+    uniq = []
+    for k in sorted(points):
+        for pl in points[k]:
+            for x in pl:
+                if x not in uniq:
+                    uniq.append(x)
+    theta_acc = 1
+    combined = np.zeros((0, 4), dtype=np.uint64)
+
+    def sub_const(q, c):
+        return poly_sub(curve, q, _arr([c % r]))
+
+    for pt in uniq:
+        q = np.zeros((0, 4), dtype=np.uint64)
+        for k in sorted(batches):
+            for i, c in enumerate(coeffs[k]):
+                if pt not in points[k][i]:
+                    continue
+                zi = z[k][i][points[k][i].index(pt)]
+                q = poly_add(curve, q, poly_scale(curve, c, theta_acc))
+                q = sub_const(q, zi * theta_acc)
+                theta_acc = theta_acc * theta % r
+        qq, rem = poly_div_linear(curve, q, pt)
+        assert rem == 0
+        combined = poly_add(curve, combined, qq)
+    for k in sorted(batches):
+        if k not in fixed:
+            continue
+        q = np.zeros((0, 4), dtype=np.uint64)
+        for i, c in enumerate(coeffs[k]):
+            q = poly_add(curve, q, poly_scale(curve, c, theta_acc))
+            q = sub_const(q, fixed_vals[k][i] * theta_acc)
+            theta_acc = theta_acc * theta % r
+        qq, rem = poly_div_linear(curve, q, etha)
+        assert rem == 0
+        combined = poly_add(curve, combined, qq)
+    f = ntt_wide(curve, _pad(combined, D))
+    pre = tree_root(fri_leaves([f], step_list[0]), 1 << step_list[0])
+    fri_roots, t = [], 0
+    for i, step in enumerate(step_list):
+        fri_roots.append(pre)
+        for _ in range(step):
+            f = fold_polynomial_dfs(curve, f, next(ch), _root_int(curve, log_domain - t))
+            t += 1
+        if i != len(step_list) - 1:
+            pre = tree_root(fri_leaves([f], step_list[i + 1]), 1 << step_list[i + 1])
+    final = ntt_wide(curve, f, inverse=True)
+    return roots, z, fri_roots, final
+
+
+def _small(curve):
+    import pyoracle as po
+    return po
+
+
+def kzg_v2_proof_eval(curve, polys: dict, points: dict, theta: int, theta2: int):
+    """pyoracle.kzg_v2_proof_eval (kzg_v2.hpp:236-305) over limb arrays: polys[k][i] coefficient arrays -> (z, f, L) with f, L coefficient
+    arrays (the quotients committed as pi_1, pi_2)"""
+    po = _small(curve)
+    r = _R[curve]
+    z = {k: [[poly_eval(curve, p, x) for x in points[k][i]] for i, p in enumerate(ps)] for k, ps in polys.items()}
+    merged = sorted({x for k in points for pl in points[k] for x in pl})
+    V = po.vanishing_poly(merged, r)
+
+    def diffpoly(pts):
+        return po.vanishing_poly([x for x in merged if x not in pts], r)
+
+    theta_i = 1
+    f = np.zeros((0, 4), dtype=np.uint64)
+    for k in sorted(polys):
+        for i, p in enumerate(polys[k]):
+            U = po.lagrange_interpolation(list(zip(points[k][i], z[k][i])), r)
+            f = poly_add(curve, f, poly_scale(curve, poly_mul(curve, poly_sub(curve, p, _arr(U)), _arr(diffpoly(points[k][i]))), theta_i))
+            theta_i = theta_i * theta % r
+    f = poly_div_exact_by_roots(curve, f, merged)                                   # f / V, BOOST_ASSERT(f % V == 0) (:266)
+    theta_i = 1
+    L = np.zeros((0, 4), dtype=np.uint64)
+    for k in sorted(polys):
+        for i, p in enumerate(polys[k]):
+            U = po.lagrange_interpolation(list(zip(points[k][i], z[k][i])), r)
+            zts = po.poly_eval(diffpoly(points[k][i]), theta2, r)
+            L = poly_add(curve, L, poly_scale(curve, poly_sub(curve, p, _arr([po.poly_eval(U, theta2, r)])), theta_i * zts % r))
+            theta_i = theta_i * theta % r
+    L = poly_sub(curve, L, poly_scale(curve, f, po.poly_eval(V, theta2, r)))
+    L, rem = poly_div_linear(curve, L, theta2)                                      # (:290-291)
+    assert rem == 0
+    return z, poly_trim(f), poly_trim(L)
+
+
+def kzg_v1_proof_eval(curve, polys: dict, points: dict, gamma: int):
+    """pyoracle.kzg_v1_proof_eval (kzg.hpp:782-807) over limb arrays -> (z, accum)"""
+    po = _small(curve)
+    r = _R[curve]
+    z = {k: [[poly_eval(curve, p, x) for x in points[k][i]] for i, p in enumerate(ps)] for k, ps in polys.items()}
+    factor = 1
+    accum = np.zeros((0, 4), dtype=np.uint64)
+    for k in sorted(polys):
+        for i, p in enumerate(polys[k]):
+            U = po.lagrange_interpolation(list(zip(points[k][i], z[k][i])), r)
+            q = poly_div_exact_by_roots(curve, poly_sub(curve, p, _arr(U)), points[k][i])
+            accum = poly_add(curve, accum, poly_scale(curve, q, factor))
+            factor = factor * gamma % r
+    return z, poly_trim(accum)

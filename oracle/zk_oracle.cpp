@@ -1477,6 +1477,76 @@ int zko_fr_vec(int curve, int op, const uint64_t *a, const uint64_t *b, const ui
     else return -1;
     return 0;
 }
+// detail::fold_polynomial, DFS form (commitments/detail/polynomial/fold_polynomial.hpp:68-93):
+//   out[i] = 1/2 [(1 + alpha w^-i) f[i] + (1 - alpha w^-i) f[i + size/2]],  i < size/2 = 2^(log_size - 1)
+// (w^-i by blocks: a power per thread block, then the running product the reference's loop keeps)
+int zko_fri_fold(int curve, const uint64_t *f, size_t log_size, const uint64_t *alpha_c, const uint64_t *omega_c, uint64_t *out) {
+    auto run = [&](auto tag) {
+        typedef decltype(tag) S;
+        const size_t half = ((size_t)1 << log_size) / 2;
+        const S alpha = S::from_canonical(alpha_c), winv = S::from_canonical(omega_c).inv(), inv2 = S::from_u64(2).inv(), one = S::one();
+        const int nt = omp_get_max_threads();
+        const size_t per = (half + nt - 1) / nt;
+#pragma omp parallel for schedule(static, 1)
+        for (int t = 0; t < nt; ++t) {
+            const size_t lo = std::min(half, per * t), hi = std::min(half, lo + per);
+            if (lo >= hi) continue;
+            S wi = winv.pow_u64(lo);
+            for (size_t i = lo; i < hi; ++i) {
+                const S a = alpha * wi;
+                const S r = inv2 * ((one + a) * S::from_canonical(f + 4 * i) + (one - a) * S::from_canonical(f + 4 * (half + i)));
+                r.to_canonical(out + 4 * i);
+                wi = wi * winv;
+            }
+        }
+    };
+    if (curve == 0) run(FrBLS());
+    else if (curve == 1) run(FrBN());
+    else return -1;
+    return 0;
+}
+// synthetic division of f (n coefficients) by (X - z): quot (n - 1 coefficients) and the remainder f(z) -- one step of poly_divmod by a
+// product of linear factors (kzg_v2.hpp:266-267 `f /= V`, :290-291 `L /= (X - theta_2)`; lpc.hpp's quotients by (X - point))
+int zko_poly_div_linear(int curve, const uint64_t *f, size_t n, const uint64_t *z_c, uint64_t *quot, uint64_t *rem) {
+    auto run = [&](auto tag) {
+        typedef decltype(tag) S;
+        const S z = S::from_canonical(z_c);
+        S carry = S::zero();
+        for (size_t i = n; i-- > 0;) {
+            carry = carry * z + S::from_canonical(f + 4 * i);
+            if (i > 0) carry.to_canonical(quot + 4 * (i - 1));
+        }
+        carry.to_canonical(rem);
+    };
+    if (n == 0) return -1;
+    if (curve == 0) run(FrBLS());
+    else if (curve == 1) run(FrBN());
+    else return -1;
+    return 0;
+}
+// the tests' stand-in for the caller's Merkle tree: (per_leaf + sum_i (i + 1) v_i) mod r over the concatenated leaves
+int zko_toy_root(int curve, const uint64_t *leaves, size_t count, uint64_t per_leaf, uint64_t *out) {
+    auto run = [&](auto tag) {
+        typedef decltype(tag) S;
+        const int nt = omp_get_max_threads();
+        std::vector<S> part(nt, S::zero());
+        const size_t per = (count + nt - 1) / nt;
+#pragma omp parallel for schedule(static, 1)
+        for (int t = 0; t < nt; ++t) {
+            const size_t lo = std::min(count, per * t), hi = std::min(count, lo + per);
+            S acc = S::zero();
+            for (size_t i = lo; i < hi; ++i) acc = acc + S::from_u64(i + 1) * S::from_canonical(leaves + 4 * i);
+            part[t] = acc;
+        }
+        S r = S::from_u64(per_leaf);
+        for (auto &p : part) r = r + p;
+        r.to_canonical(out);
+    };
+    if (curve == 0) run(FrBLS());
+    else if (curve == 1) run(FrBN());
+    else return -1;
+    return 0;
+}
 // permutation_argument.hpp:103-136: g_v / h_v (k x n each) and V_P by the row-by-row recurrence, one inversion per row (the inversions
 // are independent of the recurrence: taken in parallel, then the serial product)
 int zko_perm_grand_product(int curve, size_t k, size_t n, const uint64_t *cols, const uint64_t *sid, const uint64_t *ssig, const uint64_t *beta_c,

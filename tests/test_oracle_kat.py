@@ -136,6 +136,60 @@ def test_fast_gate_argument_oracle_equals_dense_oracle(curve, log_n):
     assert fr_ints(got) == want
 
 
+def _toy_root_py(r):
+    return lambda leaves, per_leaf: (per_leaf + sum((i + 1) * v for i, v in enumerate(leaves))) % r
+
+
+@pytest.mark.parametrize("curve,log_domain,steps", [(0, 8, [1, 2]), (1, 7, [2, 1, 1]), (0, 7, [3])])
+def test_fast_scheme_oracle_lpc_equals_dense_oracle(curve, log_domain, steps):
+    """cport.lpc_proof_eval / fri_leaves / fold_polynomial_dfs / toy_root (limb arrays, transform-based: the yard-stick of the LPC scheme at
+    2^12 - 2^21 points) against pyoracle.lpc_proof_eval (big integers, dense arithmetic; held to the definitions in
+    test_lpc_oracle_definitions): batch roots over the leaf layout, evaluations, FRI round roots, final polynomial."""
+    C = CURVES[curve]
+    r = C.r
+    logs = [log_domain - 3, log_domain - 3, log_domain - 2, log_domain - 3]
+    evals = [cp.random_fr(curve, 1300 + i, 1 << l) for i, l in enumerate(logs)]
+    rng = po.SplitMix64(55 + curve)
+    p0, p1, p2 = (rng.next_mod(r) for _ in range(3))
+    etha, theta = rng.next_mod(r), rng.next_mod(r)
+    challenges = [etha, etha, theta] + [rng.next_mod(r) for _ in range(sum(steps))]
+    points = {0: [[p0], [p0, p2]], 1: [[p0, p1], [p0]]}
+    e_roots, e_z, e_fri, e_final = po.lpc_proof_eval(r, {0: [fr_ints(e) for e in evals[:2]], 1: [fr_ints(e) for e in evals[2:]]}, points, [0], log_domain, steps,
+                                                     C.root_of_unity, challenges, _toy_root_py(r))
+    g_roots, g_z, g_fri, g_final = cp.lpc_proof_eval(curve, {0: evals[:2], 1: evals[2:]}, points, [0], log_domain, steps, challenges, cp.toy_root(curve))
+    assert g_roots == e_roots and g_z == e_z and g_fri == e_fri
+    nfinal = 1 << (log_domain - sum(steps))
+    assert fr_ints(g_final) == (e_final + [0] * nfinal)[:nfinal]
+    # the leaf layout on its own, every fri_step the schemes use
+    ext = [fr_ints(cp.dfs_resize(curve, e, 1 << log_domain)) for e in evals[:3]]
+    for step in (1, 2, 3):
+        assert fr_ints(cp.fri_leaves([fr_arr(e) for e in ext], step)) == po.fri_leaves(ext, step)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_fast_scheme_oracle_kzg_equals_dense_oracle(curve):
+    """cport.kzg_v2_proof_eval / kzg_v1_proof_eval against pyoracle's (kzg_v2.hpp:236-305, kzg.hpp:782-807): evaluations and the quotient
+    polynomials committed as pi_1, pi_2 / kzg_proof, coefficient by coefficient; ragged sizes and point sets."""
+    C = CURVES[curve]
+    r = C.r
+    rng = po.SplitMix64(77 + curve)
+    x1, x2, x3 = (rng.next_mod(r) for _ in range(3))
+    layout = [(0, 6, [x1, x2]), (0, 6, [x1, x2]), (0, 6, [x1, x2]), (2, 6, [x2]), (2, 7, [x1, x3])]
+    polys_i, polys_a, points = {}, {}, {}
+    for p, (k, log_n, pts) in enumerate(layout):
+        c = cp.ntt(curve, cp.random_fr(curve, 500 + p, 1 << log_n).reshape(1, -1, 4), log_n, limbs(C.root_of_unity(log_n), 4), inverse=True)[0]
+        polys_a.setdefault(k, []).append(c)
+        polys_i.setdefault(k, []).append(fr_ints(c))
+        points.setdefault(k, []).append(pts)
+    theta, theta2 = rng.next_mod(r), rng.next_mod(r)
+    z, f, L = po.kzg_v2_proof_eval(r, polys_i, points, theta, theta2)
+    gz, gf, gL = cp.kzg_v2_proof_eval(curve, polys_a, points, theta, theta2)
+    assert gz == z and fr_ints(gf) == po.poly_trim(f) and fr_ints(gL) == po.poly_trim(L)
+    z1, acc = po.kzg_v1_proof_eval(r, polys_i, points, theta)
+    gz1, gacc = cp.kzg_v1_proof_eval(curve, polys_a, points, theta)
+    assert gz1 == z1 and fr_ints(gacc) == po.poly_trim(acc)
+
+
 @pytest.mark.parametrize("curve", [0, 1])
 def test_ntt_oracle_threads_inside_equals_one_thread_per_polynomial(curve):
     """cport.ntt transforms a batch smaller than half the thread count with the threads INSIDE each transform (bench.py's CPU NTT baseline
