@@ -394,6 +394,8 @@ def main():
             jac = result.cpu().numpy().view(np.uint64).reshape(3, 6)
             gpu_affine = ctx.jacobian_to_affine(zk.BLS12_381, zk.G1, jac)
             others = {k: full[k] for k in ("msm_g2", "msm_bn254_g1") if isinstance(full.get(k), dict) and "_inputs" in full[k]}
+            if not args.no_verify and isinstance(full.get("lpc"), dict) and "_fold" in full["lpc"]:
+                others["lpc"] = full["lpc"]
             full["cpu_baseline"] = cpu_baseline(np, bases, scalars, gpu_affine, zk=zk, ctx=ctx, others=others if not args.no_verify else None)
             same = full["cpu_baseline"].pop("gpu_result_equals_oracle")
             if not args.no_verify:
@@ -403,6 +405,8 @@ def main():
         for k in ("msm_g2", "msm_bn254_g1"):
             if isinstance(full.get(k), dict) and "_inputs" in full[k]:
                 full[k].pop("_inputs")[0].free()
+        if isinstance(full.get("lpc"), dict):
+            full["lpc"].pop("_fold", None), full["lpc"].pop("_shape", None)
         detail = write_detail(full, args.detail)
         line = compact_line(full, detail)
         text = json.dumps(line, separators=(",", ":"))
@@ -1240,7 +1244,8 @@ def lpc_leg(np, log_n=20, cols=16, steps=4):
             "value": res["streaming_builder"]["mean_after_first_ms"], "unit": "ms per commit", "higher_is_better": False,
             "leaf_bytes": cols * (2 << log_n) * 32, **res, "proof_eval_ms": (res.get("proof_eval") or {}).get("median_after_first_ms"),
             "verified": roots[0] == roots[1],
-            "verification": "the streaming and the vector builder fold the same leaves (bit-exact parity of the layout: tests/test_gpu_shim.py)"}
+            "verification": "the streaming and the vector builder yield the same POSITION-WEIGHTED fold sum_k (k + 1) w_k mod 2^64 over the leaves' u64 words",
+            "_fold": roots[0], "_shape": (log_n, cols)}  # cpu_baseline() holds the fold against the oracle's leaf layout of the same polynomials
 
 
 def quotient_leg(np, log_n=20, steps=6, verify=True):
@@ -1611,6 +1616,35 @@ def cpu_baseline(np, bases, scalars, gpu_affine, zk=None, ctx=None, others=None)
                             else "all 8 polynomials of 2^22 (config 3), one thread per polynomial (%d of %d usable threads busy), %.1f s" % (min(8, ntt_threads), cores, dtn)}
     del a
     # the other (curve, group) MSM legs: a 2^16-point prefix of their inputs through the oracle's Pippenger against the GPU's MSM of the same prefix
+    if others and "lpc" in others:
+        # the LPC commit leg: the oracle's extension of the SAME 16 x 2^20 polynomials to D[0] = 2^21 and its coset-ordered leaf layout
+        # (cport.fri_leaves = basic_fri.hpp:456-492), folded like the tree builders of the leg fold theirs
+        leg = others.pop("lpc")
+        lg, cols = leg["_shape"]
+        t0 = time.perf_counter()
+        with np.errstate(over="ignore"):
+            k = np.arange(1, cols * (4 << lg) + 1, dtype=np.uint64)
+            z = np.uint64(5) + k * np.uint64(0x9E3779B97F4A7C15)   # the bench library's splitmix (seed 5), word by word
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+        w = z.reshape(cols, 1 << lg, 4)
+        w[:, :, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+        del k, z
+        coeffs = cp.ntt(0, w, lg, lim(np, pow(7, (R_BLS - 1) >> lg, R_BLS)), inverse=True)
+        ext = np.zeros((cols, 2 << lg, 4), dtype=np.uint64)
+        ext[:, : 1 << lg] = coeffs
+        del coeffs, w
+        ext = cp.ntt(0, ext, lg + 1, lim(np, pow(7, (R_BLS - 1) >> (lg + 1), R_BLS)))
+        flat = cp.fri_leaves(list(ext), 1).reshape(-1)
+        del ext
+        with np.errstate(over="ignore"):
+            fold = int((np.arange(1, flat.size + 1, dtype=np.uint64) * flat).sum(dtype=np.uint64))
+        del flat
+        okl = fold == leg["_fold"]
+        leg["verified"] = bool(leg.get("verified") and okl)
+        leg["verification"] += "; == the same fold over the ORACLE's leaves (cport: extension of the same %d x 2^%d polynomials to 2^%d, fri_leaves), %.1f s" % (
+            cols, lg, lg + 1, time.perf_counter() - t0)
     if others and zk is not None and ctx is not None:
         for name, leg in others.items():
             ob, _, osc = leg["_inputs"]

@@ -57,29 +57,34 @@ struct fold_tree {
     uint64_t r = 0;
     uint64_t root() const { return r; }
 };
+/// The fold is POSITION-WEIGHTED (round 6; it used to be an XOR, which any permutation of the leaves passes): with the leaves' limbs as one
+/// sequence w_0, w_1, ... of u64 words, r = sum_k (k + 1) w_k mod 2^64 -- so bench.py can hold it against the same sum over the ORACLE's
+/// leaf layout (cport.fri_leaves over the oracle's extension of the same polynomials) and a misplaced leaf shows.
 struct streaming_fold_builder {
     unsigned threads = 8;
     fold_tree t;
     void begin(std::size_t, std::size_t) { t = fold_tree(); }
-    void absorb(const Fr *leaves, std::size_t, std::size_t count) {
+    void absorb(const Fr *leaves, std::size_t first, std::size_t count) {
         const unsigned threads = count >= ((std::size_t)1 << 16) ? this->threads : 1;    // the late FRI rounds are a few leaves: no thread is worth starting
         std::vector<uint64_t> part(threads, 0);
         std::vector<std::thread> th;
         for (unsigned k = 0; k < threads; ++k)
             th.emplace_back([&, k]() {
                 uint64_t x = 0;
-                for (std::size_t i = count * k / threads; i < count * (k + 1) / threads; ++i) x ^= leaves[i].limbs[0];
+                for (std::size_t i = count * k / threads; i < count * (k + 1) / threads; ++i)
+                    for (int j = 0; j < 4; ++j) x += (uint64_t)(4 * (first + i) + j + 1) * leaves[i].limbs[j];
                 part[k] = x;
             });
         for (auto &w : th) w.join();
-        for (uint64_t x : part) t.r ^= x;
+        for (uint64_t x : part) t.r += x;
     }
     fold_tree finish() { return t; }
 };
 struct vector_fold_builder {    // round 2's shape: the leaves materialised in a std::vector
     fold_tree operator()(const std::vector<Fr> &leaves, std::size_t) const {
         fold_tree t;
-        for (const auto &v : leaves) t.r ^= v.limbs[0];
+        for (std::size_t i = 0; i < leaves.size(); ++i)
+            for (int j = 0; j < 4; ++j) t.r += (uint64_t)(4 * i + j + 1) * leaves[i].limbs[j];
         return t;
     }
 };

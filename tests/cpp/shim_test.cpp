@@ -1034,6 +1034,7 @@ struct toy_streaming_builder {
         return t;
     }
 };
+std::size_t g_lpc_slice = 64;    // elements per leaf slice of the streaming builder (shim_set_lpc_slice: the tests at 2^15 - 2^19 points use larger ones)
 int g_lpc_builder = 0;    // 0: vector builder, 1: span, 2: streaming (64-element slices, one polynomial per upload chunk, lent polynomials)
 
 /// The consumer contract placeholder has with its commitment_scheme_type (what dummy_commitment_scheme_type implements,
@@ -1086,7 +1087,7 @@ int lpc_scheme_run(const uint64_t *evals, size_t npolys, const uint64_t *log_n, 
     static_assert(scheme_type::is_lpc(), "placeholder branches on is_lpc()");
     scheme_type scheme(ctx, fp, Builder());
     if (g_lpc_builder == 2) {
-        scheme.leaf_slice_elements = 64;
+        scheme.leaf_slice_elements = g_lpc_slice;
         scheme.upload_chunk = 1;
     }
     std::vector<polynomial_dfs<Curve>> polys(npolys);
@@ -1891,6 +1892,7 @@ void shim_host_query_shards(size_t world, size_t a, size_t b, size_t h, size_t l
 void shim_set_world(int world) { g_world = world < 1 ? 1 : world; }
 void shim_set_gpus(int gpus) { g_gpus = gpus < 1 ? 1 : gpus; }
 void shim_set_lpc_builder(int kind) { g_lpc_builder = kind; }
+void shim_set_lpc_slice(size_t elements) { g_lpc_slice = elements ? elements : 64; }
 void shim_set_domain(int kind, size_t m, const uint64_t *shift) {
     g_dom_kind = kind;
     g_dom_m = m;

@@ -1270,6 +1270,131 @@ def _lpc_scheme_shim(shim, curve, log_domain, steps):
     assert list(o_counts) == [6, len(steps), nfinal, len(challenges), 2 + len(steps), len(steps) + 100 * sum(steps) + 10000 * 2]
 
 
+def test_precommit_leaves_full_size_16_columns(shim):
+    """BASELINE cfg 5's LPC shape AT ITS SIZE: 16 polynomial_dfs of 2^20 rows extended to D[0] = 2^21 and laid out as coset-ordered leaves
+    (precommit<FRI>, basic_fri.hpp:433-496) -- 2^20 leaves of 32 elements, 1.07 GB -- bit-exact against the oracle (cport: inverse
+    transform, zero padding, forward transform over 2^21 points, then fri_leaves' index computation, pinned to pyoracle's replay of the
+    reference's s_indices loop at <= 2^8).  cfg 2 and cfg 3 are checked this way at their full sizes; this is the LPC row's turn."""
+    curve, log_n, cols, fri_step = 0, 20, 16, 1
+    C = CURVES[curve]
+    evals = cp.random_fr(curve, 4100, cols << log_n).reshape(cols, 1 << log_n, 4)
+    coeffs = cp.ntt(curve, evals, log_n, limbs(C.root_of_unity(log_n), 4), inverse=True)
+    ext = np.zeros((cols, 2 << log_n, 4), dtype=np.uint64)
+    ext[:, : 1 << log_n] = coeffs
+    del coeffs
+    ext = cp.ntt(curve, ext, log_n + 1, limbs(C.root_of_unity(log_n + 1), 4))
+    want = cp.fri_leaves(list(ext), fri_step)
+    del ext
+    roots = np.stack([limbs(C.root_of_unity(l), 4) for l in range(log_n + 2)])
+    out = np.zeros((cols * (2 << log_n), 4), dtype=np.uint64)
+    rc = shim.shim_precommit_leaves(curve, P(evals.reshape(-1, 4)), ctypes.c_size_t(cols), P(np.full(cols, log_n, dtype=np.uint64)), ctypes.c_size_t(log_n + 1),
+                                    ctypes.c_size_t(fri_step), P(roots), P(out))
+    assert rc == 0
+    assert out.shape == want.shape and np.array_equal(out, want)
+
+
+@pytest.mark.parametrize("builder", ["vector", "span", "streaming"])
+@pytest.mark.parametrize("curve,log_domain,steps", [(0, 15, [3, 2, 2]), (1, 15, [2, 3, 1]), (0, 19, [3, 3, 2]), (1, 19, [4, 2, 2])])
+def test_lpc_scheme_at_multipass_sizes(shim, curve, log_domain, steps, builder):
+    """the LPC scheme at sizes where every transform is multi-pass, uploads are chunked and the streaming leaf builder
+    wraps -- polynomials of 2^12 / 2^13 evaluations on a 2^15-point domain and of 2^16 / 2^17 on a 2^19-point one, both curves, all three
+    tree-builder shapes -- against the C++ oracle's restatement of lpc.hpp:101-200 + basic_fri.hpp:433-496, 705-742 (cport.lpc_proof_eval,
+    pinned to pyoracle at <= 2^8): batch roots over the coset-ordered leaves, every evaluation, every FRI round root, the final polynomial."""
+    C = CURVES[curve]
+    r = C.r
+    logs = [log_domain - 3, log_domain - 3, log_domain - 2, log_domain - 3]
+    evals = [cp.random_fr(curve, 2300 + i + log_domain, 1 << l) for i, l in enumerate(logs)]
+    rng = po.SplitMix64(155 + curve + log_domain)
+    p0, p1, p2 = (rng.next_mod(r) for _ in range(3))
+    etha, theta = rng.next_mod(r), rng.next_mod(r)
+    challenges = [etha, etha, theta] + [rng.next_mod(r) for _ in range(sum(steps))]
+    points = {0: [[p0], [p0, p2]], 1: [[p0, p1], [p0]]}
+    e_roots, e_z, e_fri, e_final = cp.lpc_proof_eval(curve, {0: evals[:2], 1: evals[2:]}, points, [0], log_domain, steps, challenges, cp.toy_root(curve))
+    roots = np.stack([limbs(C.root_of_unity(l), 4) for l in range(log_domain + 1)])
+    o_roots, o_z, o_fri = np.zeros((2, 4), dtype=np.uint64), np.zeros((6, 4), dtype=np.uint64), np.zeros((len(steps), 4), dtype=np.uint64)
+    nfinal = 1 << (log_domain - sum(steps))
+    o_final, o_counts = np.zeros((nfinal, 4), dtype=np.uint64), np.zeros(6, dtype=np.uint64)
+    shim.shim_set_lpc_builder({"vector": 0, "span": 1, "streaming": 2}[builder])
+    shim.shim_set_lpc_slice(ctypes.c_size_t(3 << (log_domain - 4)))   # slices of whole leaves that do not divide the leaf count evenly
+    try:
+        rc = shim.shim_lpc_scheme(curve, P(np.concatenate(evals)), ctypes.c_size_t(4), P(np.array(logs, dtype=np.uint64)), ctypes.c_size_t(log_domain),
+                                  P(np.array(steps, dtype=np.uint64)), ctypes.c_size_t(len(steps)), P(roots), P(fr_arr([p0, p1, p2])), P(fr_arr(challenges)),
+                                  ctypes.c_size_t(len(challenges)), P(o_roots), P(o_z), P(o_fri), P(o_final), P(o_counts))
+    finally:
+        shim.shim_set_lpc_builder(0)
+        shim.shim_set_lpc_slice(ctypes.c_size_t(64))
+    assert rc == 0
+    assert fr_ints(o_roots) == [e_roots[0], e_roots[1]]
+    assert fr_ints(o_z) == [v for k in (0, 1) for pl in e_z[k] for v in pl]
+    assert fr_ints(o_fri) == e_fri
+    assert (o_final == cp._pad(e_final, nfinal)[:nfinal]).all()
+    assert list(o_counts) == [6, len(steps), nfinal, len(challenges), 2 + len(steps), len(steps) + 100 * sum(steps) + 10000 * 2]
+
+
+def _kzg_layout_at(curve, log_n):
+    """five polynomials in two batches, sizes 2^log_n and 2^(log_n + 1), ragged point sets (the shape of test_kzg_v2_proof_eval_shim)"""
+    C = CURVES[curve]
+    r = C.r
+    rng = po.SplitMix64(177 + curve + log_n)
+    x1, x2, x3 = (rng.next_mod(r) for _ in range(3))
+    layout = [(0, log_n, [x1, x2]), (0, log_n, [x1, x2]), (0, log_n, [x1, x2]), (2, log_n, [x2]), (2, log_n + 1, [x1, x3])]
+    evals, polys, points = [], {}, {}
+    for p, (k, l, pts) in enumerate(layout):
+        e = cp.random_fr(curve, 2500 + p + log_n, 1 << l)
+        evals.append(e)
+        polys.setdefault(k, []).append(cp.ntt(curve, e.reshape(1, -1, 4), l, limbs(C.root_of_unity(l), 4), inverse=True)[0])
+        points.setdefault(k, []).append(pts)
+    return layout, evals, polys, points, rng.next_mod(r), rng.next_mod(r)
+
+
+@pytest.mark.parametrize("curve,log_n", [(0, 12), (1, 12), (0, 16), (1, 16)])
+def test_kzg_proof_eval_at_multipass_sizes(shim, curve, log_n):
+    """both batched KZG opening proofs (kzg_v2.hpp:236-305, kzg.hpp:782-807) through the shim classes with polynomials
+    of 2^12 / 2^13 and 2^16 / 2^17 evaluations, both curves, against the C++ oracle's restatements (cport.kzg_v2_proof_eval /
+    kzg_v1_proof_eval, pinned to pyoracle at <= 2^7): every evaluation, and the quotient commitments pi_1, pi_2 / kzg_proof equal to the
+    oracle's MSM of the oracle's quotient polynomials over the same SRS (and to quotient(alpha) G in the exponent)."""
+    C = CURVES[curve]
+    r, alpha = C.r, 7
+    layout, evals, polys, points, theta, theta2 = _kzg_layout_at(curve, log_n)
+    npolys = len(layout)
+    n_srs = 2 << log_n
+    srs = _srs(curve, alpha, n_srs)
+    u64 = lambda v: np.array(v, dtype=np.uint64)
+    roots = np.stack([limbs(C.root_of_unity(l), 4) for l in range(log_n + 2)])
+    allpts = fr_arr([x for _, _, pts in layout for x in pts])
+    g = lambda v: cp.batch_mul(curve, 1, fr_arr([v % r]))[0][0]
+    z, f, L = cp.kzg_v2_proof_eval(curve, polys, points, theta, theta2)
+    commits = np.zeros((npolys, srs.shape[1]), dtype=np.uint64)
+    zvals = np.zeros((len(allpts), 4), dtype=np.uint64)
+    pi = np.zeros((2, srs.shape[1]), dtype=np.uint64)
+    absorbed = np.zeros(2, dtype=np.uint64)
+    rc = shim.shim_kzg_v2_proof_eval(curve, P(srs), ctypes.c_size_t(n_srs), ctypes.c_size_t(npolys), P(u64([k for k, _, _ in layout])),
+                                     P(u64([l for _, l, _ in layout])), P(np.concatenate(evals)), P(u64([len(p) for _, _, p in layout])), P(allpts),
+                                     P(roots), P(limbs(theta, 4)), P(limbs(theta2, 4)), P(commits), P(zvals), P(pi), P(absorbed))
+    assert rc == 0
+    flat = [c for k in sorted(polys) for c in polys[k]]
+    for p in range(npolys):
+        assert (commits[p] == g(cp.poly_eval(curve, flat[p], alpha))).all(), p
+    assert [po.from_limbs(x) for x in zvals] == [v for k in sorted(z) for zl in z[k] for v in zl]
+    e1, i1 = cp.msm(curve, 1, srs[: len(f)], f, chunks=cp.num_threads())
+    e2, i2 = cp.msm(curve, 1, srs[: len(L)], L, chunks=cp.num_threads())
+    assert i1 == 0 and i2 == 0 and (pi[0] == e1).all() and (pi[1] == e2).all()
+    assert (pi[0] == g(cp.poly_eval(curve, f, alpha))).all() and (pi[1] == g(cp.poly_eval(curve, L, alpha))).all()
+    # the first batched scheme: one quotient commitment
+    z1, acc = cp.kzg_v1_proof_eval(curve, polys, points, theta)
+    vk = cp.batch_mul(curve, 2, fr_arr([pow(alpha, i, r) for i in range(3)]))[0]
+    proof = np.zeros(srs.shape[1], dtype=np.uint64)
+    g2_out = np.zeros((2, vk.shape[1]), dtype=np.uint64)
+    g2_poly = fr_arr([3, 5, 11])
+    rc = shim.shim_kzg_v1_proof_eval(curve, P(srs), ctypes.c_size_t(n_srs), P(vk), ctypes.c_size_t(3), ctypes.c_size_t(npolys), P(u64([k for k, _, _ in layout])),
+                                     P(u64([l for _, l, _ in layout])), P(np.concatenate(evals)), P(u64([len(p) for _, _, p in layout])), P(allpts), P(roots),
+                                     P(limbs(theta, 4)), P(g2_poly), ctypes.c_size_t(3), P(commits), P(zvals), P(proof), P(g2_out), P(absorbed))
+    assert rc == 0
+    assert [po.from_limbs(x) for x in zvals] == [v for k in sorted(z1) for zl in z1[k] for v in zl]
+    e3, i3 = cp.msm(curve, 1, srs[: len(acc)], acc, chunks=cp.num_threads())
+    assert i3 == 0 and (proof == e3).all()
+
+
 @pytest.mark.parametrize("curve", [0, 1])
 def test_kzg_placeholder_contract_shim(shim, curve):
     """kzg_commitment_scheme_v2_placeholder_hip under the same consumer: byte-blob commitments through the caller's packer
