@@ -15,10 +15,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(port, extra, tmp_path):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--same-device", "--steps", "3", "--warmup", "1", "--log-n", "18",
-           "--no-cpu-baseline", "--no-pmc", "--ntt-log-m", "18", "--detail", str(tmp_path / "detail.json")] + extra
+def _run(port, extra, tmp_path, ranks=2, log_n=18, ntt_log_m=18):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--dist-backend", "gloo", "--same-device", "--steps", "3", "--warmup", "1", "--log-n", str(log_n),
+           "--no-cpu-baseline", "--no-pmc", "--ntt-log-m", str(ntt_log_m), "--detail", str(tmp_path / "detail.json")] + extra
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
@@ -49,3 +49,28 @@ def test_two_ranks_window_split(tmp_path):
     line, _ = _run(29643, ["--split", "windows", "--no-groth16", "--no-kzg"], tmp_path)
     assert line["n_gpus"] == 2 and line["verified"] is True
     assert "window partition x2" in line["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("split", ["points", "windows"])
+def test_eight_ranks_the_shape_of_the_scale_run(tmp_path, split):
+    """the launch the driver's SCALE run makes at N = 8 -- eight rank processes of bench.py with every sharded leg -- at
+    small sizes on the one GPU of the test box (--same-device, gloo): rank 0 prints exactly ONE line, dist.world_size == 8, every leg
+    verified.  13 windows over 8 ranks (the window split): ranks own two windows or one.  The point split deals 2^14 points per rank,
+    50 KZG columns as 7 / 7 / 6 ..., 8 polynomials one per rank, and the proof's queries in eighths; and rank 0 drives a device group
+    of eight members (the drop-in class's own multi-GPU path) while the other ranks wait on the host."""
+    extra = ["--split", split, "--log-constraints", "12", "--kzg-log-rows", "12"]
+    if split == "windows":
+        extra += ["--no-kzg"]
+    line, detail = _run(29651 if split == "points" else 29653, extra, tmp_path, ranks=8, log_n=14, ntt_log_m=14)
+    assert line["n_gpus"] == 8 and line["verified"] is True
+    d = line["dist"]
+    assert d["world_size"] == 8 and len(d["devices"]) == 8 and d["distinct_devices"] == 1 and d["same_device_flag"]
+    assert all(l.get("verified") is True for l in line["legs"].values()), line["legs"]
+    assert detail["groth16_sharded"]["verified"] is True and detail["ntt_sharded"]["polynomials_per_rank"] == 1
+    g = detail["groth16_device_group"]
+    assert g["verified"] is True and g["members"] == 8 and g["distinct_gpus"] == 1
+    if split == "points":
+        assert detail["kzg_sharded"]["verified"] is True and detail["kzg_sharded"]["columns_per_rank"] in (6, 7)
+        assert "point-range partition x8" in line["config"]["parallelism"]
+    else:
+        assert "window partition x8" in line["config"]["parallelism"]
