@@ -55,20 +55,27 @@ __device__ __forceinline__ uint32_t key_hash(const Key &k) {
 }
 
 // ---- exclusive u32 scan, three kernels: tile-local scan + tile totals, scan of the totals by one workgroup, add-back
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t x, uint32_t *lds, uint32_t &total) {  // x: this lane's value; returns its exclusive prefix
+// Sums SATURATE at `cap` (a table whose equal values are not adjacent emits count copies per run -- 2^39 entries for 2^20 rows
+// alternating two values -- and a wrapped u32 total could pass for a small one: the overflow flag would stay down and the offsets would
+// stop being monotone).  Saturating addition is associative and monotone, so the scans stay scans; every prefix below `cap` is exact.
+__device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b, uint32_t cap) {
+    const uint64_t s = (uint64_t)a + b;
+    return s > cap ? cap : (uint32_t)s;
+}
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t x, uint32_t *lds, uint32_t &total, uint32_t cap = 0xffffffffu) {  // x: this lane's value; returns its exclusive prefix
     const uint32_t t = threadIdx.x;
-    lds[t] = x;
+    lds[t] = x > cap ? cap : x;
     __syncthreads();
     for (uint32_t d = 1; d < LS_THREADS; d <<= 1) {
         const uint32_t o = t >= d ? lds[t - d] : 0;
         __syncthreads();
-        lds[t] += o;
+        lds[t] = sat_add(lds[t], o, cap);
         __syncthreads();
     }
     total = lds[LS_THREADS - 1];
-    const uint32_t incl = lds[t];
+    const uint32_t excl = t ? lds[t - 1] : 0;
     __syncthreads();
-    return incl - x;
+    return excl;
 }
 
 // start flags of the table values, scanned per tile: run_idx[t] = runs started before t inside the tile (fixed up by ls_scan_add)
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(LS_THREADS) void ls_starts(const uint32_t *const *_
 }
 
 // exclusive scan of `count` tile totals in place by ONE workgroup (a serial loop over tiles of LS_TILE); the grand total goes to *total
-__global__ __launch_bounds__(LS_THREADS) void ls_scan_top(uint32_t *__restrict__ v, uint32_t count, uint32_t *__restrict__ total) {
+__global__ __launch_bounds__(LS_THREADS) void ls_scan_top(uint32_t *__restrict__ v, uint32_t count, uint32_t *__restrict__ total, uint32_t cap) {
     __shared__ uint32_t lds[LS_THREADS];
     uint32_t carry = 0;
     for (uint32_t base = 0; base < count; base += LS_TILE) {
@@ -114,16 +121,16 @@ __global__ __launch_bounds__(LS_THREADS) void ls_scan_top(uint32_t *__restrict__
 #pragma unroll
         for (uint32_t i = 0; i < LS_PER; ++i) {
             x[i] = lo + i < count ? v[lo + i] : 0;
-            sum += x[i];
+            sum = sat_add(sum, x[i], cap);
         }
         uint32_t tot;
-        uint32_t run = carry + block_excl_scan(sum, lds, tot);
+        uint32_t run = sat_add(carry, block_excl_scan(sum, lds, tot, cap), cap);
 #pragma unroll
         for (uint32_t i = 0; i < LS_PER; ++i) {
             if (lo + i < count) v[lo + i] = run;
-            run += x[i];
+            run = sat_add(run, x[i], cap);
         }
-        carry += tot;
+        carry = sat_add(carry, tot, cap);
     }
     if (threadIdx.x == 0) *total = carry;
 }
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(LS_THREADS) void ls_count_inputs(const uint32_t *co
 // size of run r's emission, scanned per tile (slot 0 of the sequence is the leading zero of a walk that starts on a non-zero value)
 __global__ __launch_bounds__(LS_THREADS) void ls_sizes(const uint32_t *const *__restrict__ vals, uint32_t u, const uint32_t *__restrict__ st,
                                                        const uint32_t *__restrict__ runs_p, const uint32_t *__restrict__ canon, const uint32_t *__restrict__ cnt,
-                                                       uint32_t *__restrict__ off, uint32_t *__restrict__ tile_tot) {
+                                                       uint32_t *__restrict__ off, uint32_t *__restrict__ tile_tot, uint32_t cap) {
     __shared__ uint32_t lds[LS_THREADS];
     const uint32_t runs = *runs_p, lo = blockIdx.x * LS_TILE + threadIdx.x * LS_PER;
     uint32_t s[LS_PER], sum = 0;
@@ -199,16 +206,16 @@ __global__ __launch_bounds__(LS_THREADS) void ls_sizes(const uint32_t *const *__
         if (r < runs) {
             const bool zero = key_zero(key_at(vals, u, st[r]));
             s[i] = zero ? (r + 1 < runs ? 1u : 0u) : cnt[canon[r]];
-            if (r == 0 && !zero) s[i] += 1;  // the leading zero rides on run 0 (ls_emit tells them apart)
+            if (r == 0 && !zero) s[i] = sat_add(s[i], 1, cap);  // the leading zero rides on run 0 (ls_emit tells them apart)
         }
-        sum += s[i];
+        sum = sat_add(sum, s[i], cap);
     }
     uint32_t total;
-    uint32_t run = block_excl_scan(sum, lds, total);
+    uint32_t run = block_excl_scan(sum, lds, total, cap);
 #pragma unroll
     for (uint32_t i = 0; i < LS_PER; ++i) {
         if (lo + i < runs) off[lo + i] = run;
-        run += s[i];
+        run = sat_add(run, s[i], cap);
     }
     if (threadIdx.x == 0) tile_tot[blockIdx.x] = total;
 }
@@ -216,10 +223,10 @@ __global__ __launch_bounds__(LS_THREADS) void ls_sizes(const uint32_t *const *__
 __global__ __launch_bounds__(LS_THREADS) void ls_offsets(uint32_t *__restrict__ off, const uint32_t *__restrict__ tile_pre, const uint32_t *__restrict__ runs_p,
                                                          const uint32_t *__restrict__ total_p, uint32_t capacity, uint32_t *__restrict__ status) {
     const uint32_t r = blockIdx.x * LS_THREADS + threadIdx.x, runs = *runs_p;
-    if (r < runs) off[r] += tile_pre[r / LS_TILE];
+    if (r < runs) off[r] = sat_add(off[r], tile_pre[r / LS_TILE], capacity + 1);
     if (r == 0) {
         off[runs] = *total_p;  // sentinel
-        if (*total_p > capacity) atomicOr(status, ZK_STATUS_LOOKUP_SORT_OVERFLOW);
+        if (*total_p > capacity) atomicOr(status, ZK_STATUS_LOOKUP_SORT_OVERFLOW);  // the sums saturate at capacity + 1: no wrapped total slips under
     }
 }
 
@@ -302,7 +309,7 @@ extern "C" int zkhip_lookup_sort_dev(zkhip_ctx *ctx, size_t k_in, const void *co
         ZK_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, (size_t)lv * 4, ctx->stream));
         ZK_HIP_CHECK(ctx, hipMemsetAsync(d_slots, 0xff, (size_t)table * 4, ctx->stream));
         ZK_LAUNCH(ctx, "lookup_sort", ls_starts, dim3(vt), dim3(LS_THREADS), 0, p_val, u, lv, d_run, d_start, d_tile_a);
-        ZK_LAUNCH(ctx, "lookup_sort", ls_scan_top, dim3(1), dim3(LS_THREADS), 0, d_tile_a, vt, d_scal);
+        ZK_LAUNCH(ctx, "lookup_sort", ls_scan_top, dim3(1), dim3(LS_THREADS), 0, d_tile_a, vt, d_scal, 0xffffffffu);
         const dim3 per_value((lv + LS_THREADS - 1) / LS_THREADS);
         ZK_LAUNCH(ctx, "lookup_sort", ls_heads, per_value, dim3(LS_THREADS), 0, d_run, d_start, d_tile_a, lv, d_st);
         // the run count stays on the device: the per-run kernels are launched over its upper bound lv and read it
@@ -310,8 +317,9 @@ extern "C" int zkhip_lookup_sort_dev(zkhip_ctx *ctx, size_t k_in, const void *co
         if (li)
             ZK_LAUNCH(ctx, "lookup_sort", ls_count_inputs, dim3((li + LS_THREADS - 1) / LS_THREADS), dim3(LS_THREADS), 0, p_in, p_val, u, li, d_st, d_slots, table - 1, d_cnt,
                       ctx->d_status);
-        ZK_LAUNCH(ctx, "lookup_sort", ls_sizes, dim3(vt), dim3(LS_THREADS), 0, p_val, u, d_st, d_scal, d_canon, d_cnt, d_off, d_tile_b);
-        ZK_LAUNCH(ctx, "lookup_sort", ls_scan_top, dim3(1), dim3(LS_THREADS), 0, d_tile_b, vt, d_scal + 1);
+        const uint32_t cap1 = (uint32_t)(kk * usable_rows) + 1;  // emission sizes and offsets saturate one above what the vectors hold
+        ZK_LAUNCH(ctx, "lookup_sort", ls_sizes, dim3(vt), dim3(LS_THREADS), 0, p_val, u, d_st, d_scal, d_canon, d_cnt, d_off, d_tile_b, cap1);
+        ZK_LAUNCH(ctx, "lookup_sort", ls_scan_top, dim3(1), dim3(LS_THREADS), 0, d_tile_b, vt, d_scal + 1, cap1);
         ZK_LAUNCH(ctx, "lookup_sort", ls_offsets, per_value, dim3(LS_THREADS), 0, d_off, d_tile_b, d_scal, d_scal + 1, (uint32_t)(kk * usable_rows), ctx->d_status);
     } else if (li) {
         // inputs without a table: nothing they could be found in

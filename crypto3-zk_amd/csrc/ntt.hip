@@ -718,13 +718,23 @@ static int ntt_extend_t(zkhip_ctx *ctx, int curve, uint32_t *d_coeffs, size_t lo
         t->log_k = log_k;
         memcpy(t->omega_big, omega_big, 32);
         uint32_t *d_w = nullptr;
-        ZK_HIP_CHECK(ctx, hipMalloc((void **)&t->d_pre, k1 * m * 36));
-        ZK_HIP_CHECK(ctx, hipMalloc((void **)&d_w, 32));
-        ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_w, omega_big, 32, hipMemcpyHostToDevice, ctx->stream));
-        const size_t entries = k1 * m;
-        ZK_LAUNCH(ctx, "ntt_build_tw", ntt_build_ext_pre<U>, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, d_w, (uint32_t)log_m, (uint32_t)k1, t->d_pre);
-        ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(d_w);
+        // a HIP call that fails half way must not leak the table object or its device memory
+        auto build = [&]() -> int {
+            ZK_HIP_CHECK(ctx, hipMalloc((void **)&t->d_pre, k1 * m * 36));
+            ZK_HIP_CHECK(ctx, hipMalloc((void **)&d_w, 32));
+            ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_w, omega_big, 32, hipMemcpyHostToDevice, ctx->stream));
+            const size_t entries = k1 * m;
+            ZK_LAUNCH(ctx, "ntt_build_tw", ntt_build_ext_pre<U>, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, d_w, (uint32_t)log_m, (uint32_t)k1, t->d_pre);
+            ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            return 0;
+        };
+        const int rc = build();
+        if (d_w) (void)hipFree(d_w);
+        if (rc != 0) {
+            if (t->d_pre) (void)hipFree(t->d_pre);
+            delete t;
+            return rc;
+        }
         std::lock_guard<std::mutex> lock(g_ext_mutex);
         g_ext_tables.emplace_back(ctx, t);
     }

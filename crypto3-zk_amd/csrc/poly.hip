@@ -13,6 +13,15 @@
 
 using namespace zkhip;
 
+#define ZK_FR_DISPATCH(curve, ...)                 \
+    if ((curve) == CURVE_BLS12_381) {           \
+        typedef BlsFrU U;                       \
+        __VA_ARGS__;                            \
+    } else {                                    \
+        typedef BnFrU U;                        \
+        __VA_ARGS__;                            \
+    }
+
 // out[b][i] = in[b][i] for i < n, 0 for n <= i < m   (32-byte elements)
 __global__ __launch_bounds__(256) void poly_pad_copy(const uint4 *__restrict__ in, uint32_t log_n, uint32_t log_m, size_t total,
                                                      uint4 *__restrict__ out) {
@@ -353,14 +362,6 @@ __global__ __launch_bounds__(256) void poly_lincomb(const uint32_t *const *__res
     fu_pack<U>(acc_out + j * U::NL, fu_cond_sub_p(fu_mul(acc, Fu<U>::one())));
 }
 
-#define ZK_FR_DISPATCH(curve, ...)                 \
-    if ((curve) == CURVE_BLS12_381) {           \
-        typedef BlsFrU U;                       \
-        __VA_ARGS__;                            \
-    } else {                                    \
-        typedef BnFrU U;                        \
-        __VA_ARGS__;                            \
-    }
 
 // shared front half of evaluation and division: per-(polynomial, point) workgroup partials and the pass over them
 template <class U>
@@ -387,6 +388,16 @@ static int horner_run(zkhip_ctx *ctx, const uint32_t *d_polys, size_t n, size_t 
     return ZKHIP_OK;
 }
 
+// omega_out^(2^log_k) == omega_n ?  (host arithmetic: the C++ bodies of fu.hpp) -- what the coset extension below relies on
+template <class U>
+static bool roots_nested(const uint64_t *omega_out, size_t log_k, const uint64_t *omega_n) {
+    Fu<U> x = fu_from_canonical<U>(reinterpret_cast<const uint32_t *>(omega_out));
+    for (size_t i = 0; i < log_k; ++i) x = fu_mul(x, x);
+    uint32_t c[U::NL];
+    fu_to_canonical<U>(c, x);
+    return memcmp(c, omega_n, U::NL * 4) == 0;
+}
+
 extern "C" {
 
 int zkhip_poly_resize_dev(zkhip_ctx *ctx, int curve, void *d_in, size_t log_n, size_t batch, const uint64_t *omega_n, void *d_out, size_t log_out,
@@ -404,7 +415,12 @@ int zkhip_poly_resize_dev(zkhip_ctx *ctx, int curve, void *d_in, size_t log_n, s
         return ZKHIP_OK;
     }
     const size_t log_k = log_out - log_n;
-    if (ctx->opt_poly_coset_extend && log_k >= 1 && log_k <= 4 && log_n >= 1 && batch * (((size_t)1 << log_k) - 1) < ((size_t)1 << 20)) {
+    // The coset extension places the n known values at positions i K and evaluates the other cosets with omega_out^j: that is the K n-point
+    // vector only when the two roots are NESTED, omega_out^K == omega_n (roots taken from one generator always are).  Any other pair of
+    // primitive roots takes the general path below, which is correct for every pair (the relation used to be assumed).
+    bool nested = false;
+    if (log_k >= 1 && log_k <= 4) { ZK_FR_DISPATCH(curve, nested = roots_nested<U>(omega_out, log_k, omega_n)); }
+    if (ctx->opt_poly_coset_extend && nested && log_n >= 1 && batch * (((size_t)1 << log_k) - 1) < ((size_t)1 << 20)) {
         // Round 5: the K n-point domain is the n-point one and its K - 1 cosets omega_out^j <omega_n>.  The n known values are copied to their
         // places, the coefficients (inverse transform in place: d_in is consumed as before) are evaluated on the K - 1 new cosets by n-point
         // transforms that store straight into theirs: K n transform points instead of (K + 1) n, in transforms of the smaller size, and a lone

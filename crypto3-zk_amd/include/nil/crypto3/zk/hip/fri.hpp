@@ -66,21 +66,38 @@ public:
         if (cache_) cache_->clear();
     }
     /// this polynomial on the `size`-point domain (size >= size(), a power of two): itself, a cached extension, or a fresh one (cached when the
-    /// cache is on).  The result SHARES its buffer with the cache: read it, never write into it (as every copy of a device_polynomial_dfs).
+    /// cache is on).  A result that SHARES its buffer with the cache is a read-only VIEW (is_view()): the in-place operations of this class
+    /// (operator+= / -= / *=, from_coefficients) first give it a buffer of its own (copy on write: ADVICE r5 -- they used to corrupt the
+    /// owner's cached extension for every later proof); code that writes through data() must call make_writable() first.
     device_polynomial_dfs extension(std::size_t size, const root_of_unity_type &root) const {
         if (size <= size_) return *this;
         if (cache_) {
             auto it = cache_->find(size);
             if (it != cache_->end()) {
                 device_polynomial_dfs hit(*ctx_, size, degree_, it->second);
+                hit.view_ = true;
                 return hit;
             }
         }
         device_polynomial_dfs e = *this;
         e.cache_.reset();
         e.resize(size, root);
-        if (cache_) (*cache_)[size] = e.d_;
+        if (cache_) {
+            (*cache_)[size] = e.d_;
+            e.view_ = true;
+        }
         return e;
+    }
+    /// true for a polynomial whose buffer is a holder's cached extension (see extension())
+    bool is_view() const { return view_; }
+    /// a private buffer for a view (no-op otherwise), and the end of this object's own cached extensions: call before writing through data()
+    void make_writable() {
+        clear_extension_cache();
+        if (!view_) return;
+        auto d_new = ctx_->alloc(std::max<std::size_t>(1, size_) * 32);
+        check(zkhip_memcpy_d2d_async(ctx_->get(), d_new.get(), d_.get(), size_ * 32), "zkhip_memcpy_d2d_async", ctx_->get());
+        d_ = d_new;    // the cache keeps the old buffer alive; the copy is ordered before whatever this stream does next
+        view_ = false;
     }
 
     polynomial_dfs<CurveType> to_host() const {
@@ -112,6 +129,7 @@ public:
         d_ = d_new;
         size_ = new_size;
         cache_.reset();    // another polynomial object now: copies made before keep the old buffer and its cache
+        view_ = false;     // ... with a buffer of its own
     }
     /// coefficients(): inverse NTT into a new device buffer of size() elements
     std::shared_ptr<void> coefficients(const root_of_unity_type &root) const {
@@ -124,7 +142,7 @@ public:
     }
     /// from_coefficients(): the evaluations of the polynomial whose size() coefficients are at d_coeffs
     void from_coefficients(const void *d_coeffs, const root_of_unity_type &root) {
-        clear_extension_cache();
+        make_writable();
         check(zkhip_memcpy_d2d_async(ctx_->get(), d_.get(), d_coeffs, size_ * 32), "zkhip_memcpy_d2d_async", ctx_->get());
         std::uint64_t w[4];
         adapter::scalar_to_limbs(root(log2_exact(size_)), w);
@@ -153,7 +171,7 @@ private:
         return l;
     }
     device_polynomial_dfs &pointwise(int op, const device_polynomial_dfs &o) {
-        clear_extension_cache();    // the values change in place
+        make_writable();    // the values change in place: cached extensions go, a view gets its own buffer first
         if (o.size_ != size_) throw std::runtime_error("device_polynomial_dfs: operands must share the domain (resize first)");
         check(zkhip_fr_vec_op_dev(ctx_->get(), adapter::id, op, d_.get(), o.d_.get(), d_.get(), size_), "zkhip_fr_vec_op_dev", ctx_->get());
         return *this;
@@ -166,6 +184,7 @@ private:
     std::size_t size_, degree_;
     std::shared_ptr<void> d_;
     std::shared_ptr<std::map<std::size_t, std::shared_ptr<void>>> cache_;    // extension cache, shared by the copies of this object (null: off)
+    bool view_ = false;    // d_ is a cached extension of another polynomial: read-only (make_writable)
 };
 
 /// A polynomial resident in COEFFICIENT form: `size` (a power of two) coefficients, zero-padded.  What a KZG scheme keeps of every committed

@@ -186,6 +186,10 @@ public:
         for (const auto &p : lookup_input) reduced_input.push_back(body::reduce_dfs_polynomial_domain(p, n));
         std::vector<dfs_type> sorted = body::sort_polynomials(ctx, reduced_input, reduced_value, n, usable_rows);
         for (auto &s : sorted) s.set_degree(n - 1);
+        /* a looked-up value that is in no table / a table that overflows the sorted vectors: the reference's BOOST_ASSERTs (:583, :613-617).
+           Checked HERE -- before anything is appended, committed or absorbed (the throw used to leave the commitment scheme and
+           the transcript mutated) --, and only these two bits are the lookup argument's: any other sticky bit is reported as what it is */
+        throw_on_device_status("after sort_polynomials");
         reduced_value.clear();
         reduced_input.clear();
         /* 4. commit the sorted polynomials (:192-196) */
@@ -206,15 +210,25 @@ public:
         hooks.draw_alpha = [this]() { return detail::draw_challenge<CurveType>(transcript, detail::priority<1>()); };
         auto res = body::prove_eval_hooked(ctx, lookup_input, lookup_value, sorted, q_last, q_blind, lagrange_0, beta, gamma, usable_rows, root,
                                            part_sizes.size() == 1 ? std::vector<std::size_t>() : part_sizes, lookup_alphas, hooks);
-        /* a looked-up value that is in no table / a table that overflows the sorted vectors: the reference's BOOST_ASSERTs (:583, :613-617) */
-        if (const std::uint32_t flags = ctx.device_status())
-            throw std::runtime_error(flags & 4u ? "lookup argument: a looked-up value is in no lookup table" :
-                                     flags & 8u ? "lookup argument: the sorted sequence does not fit |input| + |value| vectors (equal table values must be adjacent)" :
-                                                  "lookup argument: the device raised a status flag");
+        throw_on_device_status("after the grand product");    // nothing of the lookup argument's own can be raised here any more
         V_L_dfs.assign(1, res.V_L);
         parts_dfs = res.parts_dfs;
         sorted_dfs = sorted;
         return prover_lookup_result {std::move(res.F_dfs), std::move(lookup_commitment)};
+    }
+
+    /// the sticky device status word (zkhip.h), read and cleared: bits 2 / 3 are sort_polynomials' own (the reference's assertions); bits 0 / 1
+    /// belong to whatever ran on this context before (a gather out of range, an MSM plan overflow) and are reported as such
+    void throw_on_device_status(const char *where) const {
+        const std::uint32_t flags = ctx.device_status();
+        if (!flags) return;
+        std::string msg;
+        if (flags & 4u) msg += "lookup argument: a looked-up value is in no lookup table; ";
+        if (flags & 8u) msg += "lookup argument: the sorted sequence does not fit |input| + |value| vectors (equal table values must be adjacent); ";
+        if (flags & 1u) msg += "device status: a gather index was out of range (raised before or beside the lookup argument); ";
+        if (flags & 2u) msg += "device status: an MSM large-bucket plan overflowed (raised before or beside the lookup argument); ";
+        if (flags & ~15u) msg += "device status: unknown flag(s) " + std::to_string(flags & ~15u) + "; ";
+        throw std::runtime_error(msg + "[" + where + "]");
     }
 
     /// prepare_lookup_value (:411-433) on the device: per table t and option o,

@@ -238,8 +238,9 @@ struct placeholder_permutation_hip {
     static dfs_type plus(dfs_type a, dfs_type b, const root_of_unity_type &root) { return combine(0, a, b, root); }
     /// a - b likewise (copies of a device_polynomial_dfs share their buffer: never in place)
     static dfs_type minus(dfs_type a, dfs_type b, const root_of_unity_type &root) { return combine(1, a, b, root); }
-    /// p *= c, in place (p must own its buffer)
+    /// p *= c, in place (a view of a cached extension gets a buffer of its own first; p's own cached extensions go)
     static void scale(dfs_type &p, const value_type &c) {
+        p.make_writable();
         std::uint64_t cl[4], zl[4];
         adapter::scalar_to_limbs(c, cl);
         adapter::scalar_to_limbs(value_type::zero(), zl);

@@ -245,7 +245,8 @@ int zkhip_fr_gather_dev(zkhip_ctx *ctx, const void *d_src, size_t src_count, con
  * polynomial_dfs::resize as precommit<FRI> applies it to every committed polynomial
  * (commitments/detail/polynomial/basic_fri.hpp:452-455): `batch` vectors of 2^log_n evaluations at d_in
  * (CONSUMED: left holding the coefficients) -> 2^log_out evaluations each at d_out.  omega_n / omega_out are the
- * primitive roots of the two domains. */
+ * primitive roots of the two domains.  Any pair of primitive roots is accepted; when they are NESTED (omega_out^(2^(log_out - log_n))
+ * == omega_n, as roots drawn from one generator are) and the growth is at most 16-fold, only the new cosets are evaluated ("poly_coset_extend"). */
 int zkhip_poly_resize_dev(zkhip_ctx *ctx, int curve, void *d_in, size_t log_n, size_t batch, const uint64_t *omega_n, void *d_out,
                           size_t log_out, const uint64_t *omega_out);
 /* log_out < log_n (a SMALLER domain, for a polynomial whose degree fits it): d_out receives every 2^(log_n - log_out)-th

@@ -316,6 +316,38 @@ int arguments_transcript_t(const uint64_t *srs, size_t n_srs, const uint64_t *ev
     if (events.size() > cap_events) return -318;
     std::memcpy(out_events, events.data(), events.size() * 8);
     *n_events = events.size();
+    {
+        /* a looked-up value that is in NO table (the reference's BOOST_ASSERT, lookup_argument.hpp:583) must throw BEFORE the
+           argument touches the commitment scheme or the transcript -- a second prover over fresh recorders, one input entry made foreign */
+        std::vector<poly> bad_inputs = prepared_inputs;
+        if (!bad_inputs.empty() && usable_rows > 1) {
+            {
+                std::vector<Fr> v;
+                for (size_t i = 0; i < bad_inputs[0].size(); ++i) v.push_back(bad_inputs[0][i]);
+                const size_t row1 = v.size() / n;    // an input on the 2 n-point domain is reduced to every second entry: this one is row 1
+                v[row1] = v[row1] + Fr((std::uint64_t)0x1234567) * ch(0);    // no table holds this (overwhelmingly)
+                bad_inputs[0] = poly(bad_inputs[0].degree(), std::move(v));
+            }
+            std::vector<uint64_t> ev2;
+            scheme_type inner2(params, detail::field_roots<Curve>());
+            recording_scheme<scheme_type> scheme2 {inner2, &ev2};
+            transcript_type tr2 {&ev2, {}, 0};
+            tr2.challenges = transcript.challenges;
+            tr2.next = perm_challenges;
+            auto bad_hook = [&](const Fr &) { return bad_inputs; };
+            auto prover2 = make_placeholder_lookup_argument_prover<Curve>(cs, pd, table, scheme2, tr2, bad_hook);
+            const size_t events_before = ev2.size(), drawn_before = tr2.next;
+            bool thrown = false;
+            try {
+                (void)prover2.prove_eval();
+            } catch (const std::runtime_error &e) {
+                thrown = std::string(e.what()).find("in no lookup table") != std::string::npos;
+            }
+            if (!thrown) return -320;
+            if (ev2.size() != events_before || tr2.next != drawn_before) return -321;    // nothing appended, committed, absorbed or drawn
+            if (ctx.device_status() != 0) return -322;                                   // ... and the sticky word was cleared by the report
+        }
+    }
     return 0;
 }
 

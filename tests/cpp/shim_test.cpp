@@ -777,6 +777,23 @@ int gate_argument_t(const uint64_t *evals, size_t ncols, size_t log_n, const uin
             products[p].rotations.push_back((int)fac[2 * at + 1]);
         }
     }
+    if (variant == 3) {
+        /* a view of a cached extension must not be writable in place -- operator*=, from_coefficients and scale give it its own
+           buffer first; the owner's cached extension stays what it was */
+        dfs view = cols[0].extension(ext, root);
+        if (!view.is_view()) return -30;
+        std::vector<uint64_t> before(4 * ext), after(4 * ext);
+        ctx.d2h(before.data(), view.data(), ext * 32);
+        const void *cached = view.data();
+        dfs other = cols[1 % ncols].extension(ext, root);
+        view *= other;
+        placeholder_permutation_hip<Curve>::scale(other, A::scalar_from_limbs(coeffs));
+        if (view.is_view() || view.data() == cached || other.is_view()) return -31;
+        dfs again = cols[0].extension(ext, root);
+        if (again.data() != cached) return -32;
+        ctx.d2h(after.data(), again.data(), ext * 32);
+        if (before != after) return -33;
+    }
     const size_t budget = variant == 2 ? 3 * ext * 32 : (size_t)16 << 30;    // three slots: one product (plus the mask) per group at most
     dfs F = variant == 1 ? Q::gate_argument_per_term(ctx, products, mask, ext, root) : Q::gate_argument(ctx, products, mask, ext, root, budget);
     if (variant == 3) F = Q::gate_argument(ctx, products, mask, ext, root);

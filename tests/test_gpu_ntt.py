@@ -194,6 +194,18 @@ def test_poly_resize_coset_extension(ctx, curve, log_n, expand, batch):
         assert (got == exp).all(), mode
         assert (back == coeffs).all(), mode
     ctx.set_option("poly_coset_extend", 1)
+    # roots that are NOT nested (omega_out^K != omega_n: primitive roots of the right orders, from different generators) are legal
+    # arguments of this entry point; the coset path would place the known values on the wrong points -- it must step aside for them
+    if expand >= 2:
+        wm3 = limbs(pow(C.root_of_unity(log_out), 3, C.r), 4)  # another primitive 2^log_out-th root; its K-th power is omega_n^3
+        exp3 = cp.ntt(curve, padded, log_out, wm3)
+        ctx.h2d(d_in, evals)
+        rc = ctx.lib.zkhip_poly_resize_dev(ctx.h, curve, ctypes.c_void_p(d_in), ctypes.c_size_t(log_n), ctypes.c_size_t(batch), P(wn),
+                                           ctypes.c_void_p(d_out), ctypes.c_size_t(log_out), P(wm3))
+        assert rc == 0
+        got = np.zeros_like(exp3)
+        ctx.d2h(got, d_out)
+        assert (got == exp3).all()
     ctx.free(d_in)
     ctx.free(d_out)
 

@@ -330,6 +330,38 @@ def test_lookup_sort_polynomials_edge_cases(ctx):
         _lookup_sort_on_device(ctx, inputs, values, n, n)       # usable_rows >= n is refused
 
 
+def test_lookup_sort_overflow_that_would_wrap_32_bits(ctx):
+    """a table whose equal values are NOT adjacent emits `count` copies per run; 2^17 rows alternating two values are 2^17 runs
+    of 2^16 copies each -- 2^33 + 1 emitted entries, which a u32 total wraps to 1: the overflow flag stayed down in exactly the malformed
+    case it exists for, and the run offsets stopped being monotone.  The scans saturate now: the flag is raised and the vectors hold the
+    HEAD of the sequence (a zero, then count(a) copies of a, count(b) copies of b, ...)."""
+    u, n = 1 << 17, 1 << 18
+    a, b = 4, 6
+    values = np.zeros((n, 4), dtype=np.uint64)
+    values[0:u:2, 0] = a
+    values[1:u:2, 0] = b
+    inputs = np.zeros((n, 4), dtype=np.uint64)
+    inputs[:u, 0] = a                                        # every looked-up value is in the table: a occurs 2^16 + 2^17 times
+    ptrs = [ctx.malloc(n * 32) for _ in range(4)]
+    ctx.h2d(ptrs[0], inputs)
+    ctx.h2d(ptrs[1], values)
+    for d in ptrs[2:]:
+        ctx.h2d(d, np.full((n, 4), 5, dtype=np.uint64))
+    ctx.lookup_sort_dev(ptrs[:1], ptrs[1:2], n, u, ptrs[2:])
+    import ctypes
+    flags = ctypes.c_uint32()
+    ctx.lib.zkhip_device_status(ctx.h, ctypes.byref(flags))
+    assert flags.value == 8
+    seq = np.concatenate([[0], np.repeat([a], 3 << 16), np.repeat([b], 1 << 16)])[: 2 * u]   # run 0: every copy of a; run 1: every copy of b; ...
+    got = [np.zeros((n, 4), dtype=np.uint64) for _ in range(2)]
+    for g, d in zip(got, ptrs[2:]):
+        ctx.d2h(g, d)
+    assert (got[0][:u, 0] == seq[:u]).all() and (got[1][:u, 0] == seq[u:]).all() and not got[0][:, 1:].any() and not got[1][:, 1:].any()
+    assert got[0][u, 0] == seq[u] and not got[1][u:].any() and not got[0][u + 1:].any()
+    for p in ptrs:
+        ctx.free(p)
+
+
 def test_block_cache_behind_malloc_free(ctx):
     """zkhip_malloc / zkhip_free keep freed blocks for the next request of their size class (option alloc_cache_mb): a block
     comes back for an equal or slightly smaller request, not for a much smaller or a larger one; its contents are whatever the last
