@@ -62,7 +62,20 @@ struct placeholder_quotient_hip {
     /// extensions of all distinct columns pass `slot_budget` bytes the products are evaluated in groups that accumulate into F.
     static dfs_type gate_argument(const context &ctx, const std::vector<gate_product_hip<CurveType>> &products, const dfs_type &mask_polynomial,
                                   std::size_t extended_size, const root_of_unity_type &root, std::size_t slot_budget = (std::size_t)16 << 30) {
+        return sum_of_products(ctx, products, &mask_polynomial, extended_size, root, slot_budget);
+    }
+
+    /// The evaluator under gate_argument, usable on its own: sum_p coefficient_p prod_f factor_f(omega^rotation_f X) on the `extended_size`-point
+    /// domain, times `mask_polynomial` when one is given.  Without a mask it is the numeric side of prepare_lookup_input
+    /// (lookup_argument.hpp:435-496: selector * (table_id + sum_k theta^(k+1) expression_k), see prepare_lookup_input_flat in
+    /// placeholder_lookup.hpp) -- any sum of monomials over resident columns.
+    static dfs_type sum_of_products(const context &ctx, const std::vector<gate_product_hip<CurveType>> &products, const dfs_type *mask_ptr, std::size_t extended_size,
+                                    const root_of_unity_type &root, std::size_t slot_budget = (std::size_t)16 << 30) {
         if (products.empty()) throw std::invalid_argument("gate_argument: no products");
+        if (products[0].factors.empty()) throw std::invalid_argument("gate_argument: factors / rotations");
+        /* without a mask the stand-in below is never read: only its size (the original domain's) and its degree (0) are */
+        const dfs_type &mask_polynomial = mask_ptr ? *mask_ptr : *products[0].factors[0];
+        const std::size_t mask_degree = mask_ptr ? mask_ptr->degree() : 0;
         const std::size_t n = mask_polynomial.size();
         std::size_t log_n = 0, log_e = 0;
         while (((std::size_t)1 << log_n) < n) ++log_n;
@@ -97,7 +110,7 @@ struct placeholder_quotient_hip {
             std::vector<dfs_type> keep;
             std::vector<std::size_t> batched;
             for (std::size_t u = 0; u <= U; ++u) {
-                if (u == U && !last) break;
+                if (u == U && (!last || !mask_ptr)) break;
                 const dfs_type &f = u < U ? *unique[u] : mask_polynomial;
                 if (f.size() != n) throw std::invalid_argument("gate_argument: every factor lives on the original domain (the mask's size)");
                 if (extended_size == n) ext_of[u] = f.data();
@@ -156,13 +169,13 @@ struct placeholder_quotient_hip {
             prog.factor_slot = factor_slot.data();
             prog.factor_rot = factor_rot.data();
             prog.term_coeff = term_coeff.data();
-            check(zkhip_gate_eval_dev(ctx.get(), adapter::id, &prog, ext_of.data(), log_e, last ? ext_of[U] : nullptr, lo != 0 ? 1 : 0, F.data()),
+            check(zkhip_gate_eval_dev(ctx.get(), adapter::id, &prog, ext_of.data(), log_e, last && mask_ptr ? ext_of[U] : nullptr, lo != 0 ? 1 : 0, F.data()),
                   "zkhip_gate_eval_dev", ctx.get());
             lo = hi;
             ctx.sync();    // the group's extensions are released at the end of the iteration
         }
-        if (F_degree + mask_polynomial.degree() >= extended_size) throw std::invalid_argument("gate_argument: mask * F does not fit the extended domain");
-        F.set_degree(F_degree + mask_polynomial.degree());
+        if (F_degree + mask_degree >= extended_size) throw std::invalid_argument("gate_argument: mask * F does not fit the extended domain");
+        F.set_degree(F_degree + mask_degree);
         return F;
     }
 

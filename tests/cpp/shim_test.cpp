@@ -20,6 +20,7 @@
 #include <array>
 #include <nil/crypto3/zk/hip/column_polynomial.hpp>
 #include <nil/crypto3/zk/hip/placeholder_lookup.hpp>
+#include <nil/crypto3/zk/hip/placeholder_lookup_input.hpp>
 #include <nil/crypto3/zk/hip/placeholder_permutation.hpp>
 #include <nil/crypto3/zk/hip/placeholder_quotient.hpp>
 #include <nil/crypto3/zk/hip/powers_of_tau.hpp>
@@ -800,6 +801,57 @@ int gate_argument_t(const uint64_t *evals, size_t ncols, size_t log_n, const uin
     if (F.size() != ext) return -2;
     *out_degree = F.degree();
     ctx.d2h(out, F.data(), ext * 32);
+    return 0;
+}
+
+/// prepare_lookup_input_flat (lookup_argument.hpp:435-496 over flattened expressions): column 0 is the lookup gate's selector; every
+/// constraint: table id, then per lookup_input expression its monomials (coefficient, (column, rotation) pairs).  Flat description:
+/// cons[c] = {table_id, n_expressions}; expr_monos[e] = monomials of expression e (all constraints' expressions in order);
+/// mono_nfac[m] = factors of monomial m; fac = (column, rotation) pairs.  out: the polynomials one behind the other, out_sizes their sizes.
+template <typename Curve>
+int lookup_input_flat_t(const uint64_t *evals, size_t ncols, size_t log_n, const uint64_t *degrees, const uint64_t *roots, size_t ncons, const uint64_t *cons,
+                        const uint64_t *expr_monos, const uint64_t *mono_coeffs, const uint64_t *mono_nfac, const int64_t *fac, const uint64_t *theta, uint64_t *out,
+                        uint64_t *out_sizes) {
+    typedef curve_adapter<Curve> A;
+    typedef device_polynomial_dfs<Curve> dfs;
+    context ctx(0);
+    auto root = [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); };
+    const size_t n = (size_t)1 << log_n;
+    std::vector<dfs> cols;
+    cols.reserve(ncols);
+    for (size_t c = 0; c < ncols; ++c) {
+        polynomial_dfs<Curve> h;
+        for (size_t i = 0; i < n; ++i) h.values.push_back(A::scalar_from_limbs(evals + 4 * (n * c + i)));
+        cols.emplace_back(ctx, h, degrees[c]);
+    }
+    cols[0].enable_extension_cache();    // the selector is preprocessed
+    std::vector<lookup_input_constraint_hip<Curve>> constraints(ncons);
+    size_t e = 0, m = 0, f = 0;
+    for (size_t c = 0; c < ncons; ++c) {
+        constraints[c].lookup_selector = &cols[0];
+        constraints[c].table_id = cons[2 * c];
+        for (size_t k = 0; k < cons[2 * c + 1]; ++k, ++e) {
+            constraints[c].lookup_input.emplace_back();
+            for (size_t j = 0; j < expr_monos[e]; ++j, ++m) {
+                typename lookup_input_constraint_hip<Curve>::monomial mono;
+                mono.coefficient = A::scalar_from_limbs(mono_coeffs + 4 * m);
+                for (size_t q = 0; q < mono_nfac[m]; ++q, ++f) {
+                    mono.factors.push_back(&cols.at((size_t)fac[2 * f]));
+                    mono.rotations.push_back((int)fac[2 * f + 1]);
+                }
+                constraints[c].lookup_input.back().push_back(std::move(mono));
+            }
+        }
+    }
+    auto polys = prepare_lookup_input_flat<Curve>(ctx, constraints, A::scalar_from_limbs(theta), root);
+    if (polys.size() != ncons) return -2;
+    size_t at = 0;
+    for (size_t c = 0; c < ncons; ++c) {
+        out_sizes[2 * c] = polys[c].size();
+        out_sizes[2 * c + 1] = polys[c].degree();
+        ctx.d2h(out + 4 * at, polys[c].data(), polys[c].size() * 32);
+        at += polys[c].size();
+    }
     return 0;
 }
 
@@ -2047,6 +2099,12 @@ int shim_gate_argument(int curve, const uint64_t *evals, size_t ncols, size_t lo
                        uint64_t *out, uint64_t *out_degree) {
     CURVE_CALL("shim_gate_argument", gate_argument_t, evals, ncols, log_n, degrees, mask_evals, mask_degree, roots, nprod, coeffs, nfac, fac, log_ext, variant, out,
                out_degree)
+}
+int shim_lookup_input_flat(int curve, const uint64_t *evals, size_t ncols, size_t log_n, const uint64_t *degrees, const uint64_t *roots, size_t ncons,
+                           const uint64_t *cons, const uint64_t *expr_monos, const uint64_t *mono_coeffs, const uint64_t *mono_nfac, const int64_t *fac,
+                           const uint64_t *theta, uint64_t *out, uint64_t *out_sizes) {
+    CURVE_CALL("shim_lookup_input_flat", lookup_input_flat_t, evals, ncols, log_n, degrees, roots, ncons, cons, expr_monos, mono_coeffs, mono_nfac, fac, theta, out,
+               out_sizes)
 }
 int shim_dfs_ops(int curve, const uint64_t *a_evals, const uint64_t *b_evals, size_t log_n, size_t log_big, const uint64_t *roots, const uint64_t *alpha,
                  uint64_t *out_prod, uint64_t *out_round, uint64_t *out_addsub, uint64_t *out_fold) {

@@ -1456,3 +1456,51 @@ def test_gate_argument_fused_flat_program(shim, curve, log_n):
         assert rc == 0, variant
         assert (out == want).all(), variant
         assert int(deg[0]) == 3 * (n - 1) + (n - 1), variant   # the largest product (three factors) times the mask
+
+
+@pytest.mark.parametrize("curve,log_n", [(0, 6), (1, 9), (0, 13), (1, 16)])
+def test_prepare_lookup_input_flat(shim, curve, log_n):
+    """prepare_lookup_input's numeric side (lookup_argument.hpp:435-496) over flattened expressions: l = selector * (table_id +
+    sum_k theta^(k + 1) expression_k), every constraint ONE gate of the flat-program kernel, on the domain polynomial_dfs arithmetic ends
+    up on (the smallest power of two that holds the degree).  Against the oracle's dense evaluation of the same sum (cport.gate_argument_dfs
+    with an all-ones mask): a constraint of two linear expressions, one with a product of two columns and rotations (degree 3: the 4 n
+    domain), one whose expression is a constant."""
+    C = CURVES[curve]
+    r, n = C.r, 1 << log_n
+    ncols = 5
+    cols = [cp.random_fr(curve, 3300 + c + log_n, n) for c in range(ncols)]
+    cols[0][::2] = 0
+    rng = po.SplitMix64(88 + log_n)
+    theta = rng.next_mod(r)
+    c1, c2, c3 = rng.next_mod(r), rng.next_mod(r), rng.next_mod(r)
+    # constraints: (table_id, [expression = [(coefficient, [(column, rotation), ...]), ...], ...])
+    constraints = [(1, [[(1, [(1, 0)])], [(c1, [(2, 1)]), (r - 1, [(3, 0)])]]),
+                   (2, [[(c2, [(1, 0), (4, -1)]), (c3, [(2, 2)]), (5, [])]]),
+                   (7, [[(9, [])]])]
+    ones = np.repeat(fr_arr([1]), n, axis=0)
+    want = []
+    for tid, exprs in constraints:
+        products, th, deg = [(tid, [(cols[0], 0)])], theta, 1
+        for e in exprs:
+            for coeff, fs in e:
+                products.append((th * coeff % r, [(cols[0], 0)] + [(cols[k], rot) for k, rot in fs]))
+                deg = max(deg, 1 + len(fs))
+            th = th * theta % r
+        size = n
+        while size < deg * (n - 1) + 1:
+            size <<= 1
+        want.append(cp.gate_argument_dfs(curve, products, ones, size))
+    u64 = lambda v: np.array(v, dtype=np.uint64)
+    monos = [m for _, exprs in constraints for e in exprs for m in e]
+    fac = np.array([x for _, fs in monos for k, rot in fs for x in (k, rot)] or [0, 0], dtype=np.int64)
+    roots = np.stack([limbs(C.root_of_unity(l), 4) for l in range(log_n + 3)])
+    out = np.zeros((sum(len(w) for w in want), 4), dtype=np.uint64)
+    sizes = np.zeros(2 * len(constraints), dtype=np.uint64)
+    rc = shim.shim_lookup_input_flat(curve, P(np.concatenate(cols)), ctypes.c_size_t(ncols), ctypes.c_size_t(log_n), P(u64([n - 1] * ncols)), P(roots),
+                                     ctypes.c_size_t(len(constraints)), P(u64([x for tid, exprs in constraints for x in (tid, len(exprs))])),
+                                     P(u64([len(e) for _, exprs in constraints for e in exprs])), P(fr_arr([c for c, _ in monos])), P(u64([len(fs) for _, fs in monos])),
+                                     P(fac), P(limbs(theta, 4)), P(out), P(sizes))
+    assert rc == 0
+    assert [int(x) for x in sizes[0::2]] == [len(w) for w in want] == [2 * n, 4 * n, n]
+    assert [int(x) for x in sizes[1::2]] == [2 * (n - 1), 3 * (n - 1), n - 1]
+    assert (out == np.concatenate(want)).all()
