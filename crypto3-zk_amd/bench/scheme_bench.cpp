@@ -59,7 +59,7 @@ struct fold_tree {
 };
 /// The fold is POSITION-WEIGHTED (round 6; it used to be an XOR, which any permutation of the leaves passes): with the leaves' limbs as one
 /// sequence w_0, w_1, ... of u64 words, r = sum_k (k + 1) w_k mod 2^64 -- so bench.py can hold it against the same sum over the ORACLE's
-/// leaf layout (cport.fri_leaves over the oracle's extension of the same polynomials) and a misplaced leaf shows.
+/// leaf layout (the checker's restatement of basic_fri.hpp:456-492 over its own extension of the same polynomials) and a misplaced leaf shows.
 struct streaming_fold_builder {
     unsigned threads = 8;
     fold_tree t;

@@ -25,6 +25,7 @@
 #define ZKHIP_SHIM_KZG_V2_HPP
 
 #include <algorithm>
+#include <array>
 #include <deque>
 #include <exception>
 #include <functional>
@@ -396,6 +397,14 @@ private:
                 group.copy(k, pt.base + 32 * (db.offset[p] - db.offset[pt.lo]), 0, src, db.len[p] * 32);
             }
         }
+        /* the caller's root-of-unity function is called from THIS thread only (it need not be thread-safe): one root per distinct size, up front */
+        std::map<std::size_t, std::array<std::uint64_t, 4>> root_limbs;
+        for (std::size_t i = 0; i < count; ++i) {
+            if (is_coefficients(i)) continue;
+            std::size_t log_n = 0;
+            while (((std::size_t)1 << log_n) < db.len[i]) ++log_n;
+            if (!root_limbs.count(log_n)) adapter::scalar_to_limbs(_root_of_unity(log_n), root_limbs[log_n].data());
+        }
         auto member_work = [&](std::size_t k) {
             part &pt = parts[k];
             if (pt.hi == pt.lo) return;
@@ -410,9 +419,7 @@ private:
                 if (!is_coefficients(i)) {
                     std::size_t log_n = 0;
                     while (((std::size_t)1 << log_n) < db.len[i]) ++log_n;
-                    std::uint64_t w[4];
-                    adapter::scalar_to_limbs(_root_of_unity(log_n), w);
-                    check(zkhip_ntt_dev(ctx.get(), adapter::id, at(i), log_n, j - i, w, 1, nullptr), "zkhip_ntt_dev", ctx.get());
+                    check(zkhip_ntt_dev(ctx.get(), adapter::id, at(i), log_n, j - i, root_limbs.at(log_n).data(), 1, nullptr), "zkhip_ntt_dev", ctx.get());
                 }
                 if (!is_zero(i)) {
                     const std::size_t cnt = j - i;

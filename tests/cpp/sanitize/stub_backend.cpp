@@ -311,6 +311,32 @@ int zkhip_poly_lincomb_dev(zkhip_ctx *, int, size_t count, const void *const *d_
     touch(d_acc, acc_len * 32);
     return ZKHIP_OK;
 }
+int zkhip_gate_eval_dev(zkhip_ctx *, int, const zkhip_gate_program *prog, const void *const *d_slots, size_t log_size, const void *d_mask, int, void *d_out) {
+    // walk the program the way the kernel would (every table entry and one element of every slot it names is read: the sanitizers see a
+    // program whose ranges or slots run past their arrays), then leave zeros behind
+    const size_t size = (size_t)1 << log_size;
+    volatile uint64_t acc = 0;
+    if (prog->n_gates && prog->gate_terms[prog->n_gates] != prog->n_terms) return ZKHIP_ERR_INVALID;
+    if (prog->n_terms && prog->term_factors[prog->n_terms] != prog->n_factors) return ZKHIP_ERR_INVALID;
+    for (uint32_t g = 0; g < prog->n_gates; ++g) {
+        if (prog->gate_selector[g] != ZKHIP_GATE_NO_SELECTOR) {
+            if (prog->gate_selector[g] >= prog->n_slots) return ZKHIP_ERR_RANGE;
+            const size_t at = ((size_t)(int64_t)prog->gate_selector_rot[g]) & (size - 1);
+            acc += static_cast<const uint64_t *>(d_slots[prog->gate_selector[g]])[4 * at];
+        }
+        for (uint32_t t = prog->gate_terms[g]; t < prog->gate_terms[g + 1]; ++t) {
+            acc += prog->term_coeff[4 * t] + prog->term_coeff[4 * t + 3];
+            for (uint32_t f = prog->term_factors[t]; f < prog->term_factors[t + 1]; ++f) {
+                if (prog->factor_slot[f] >= prog->n_slots) return ZKHIP_ERR_RANGE;
+                const size_t at = ((size_t)(int64_t)prog->factor_rot[f]) & (size - 1);
+                acc += static_cast<const uint64_t *>(d_slots[prog->factor_slot[f]])[4 * at + 3];
+            }
+        }
+    }
+    if (d_mask) acc += static_cast<const uint64_t *>(d_mask)[4 * (size - 1)];
+    touch(d_out, size * 32);
+    return ZKHIP_OK;
+}
 // ---- device group: the members are stub contexts, the exchange is memcpy (what is exercised is the shim's bookkeeping around it)
 struct zkhip_device_group_stub {
     int n;
