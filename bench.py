@@ -381,7 +381,9 @@ def main():
         if ntt_sharded is not None:
             full["ntt_sharded"] = ntt_sharded
         if world == 1 and not args.no_kzg:
-            full["kzg"] = kzg_leg(np, zk, ctx, verify=not args.no_verify, valu=(traffic or {}).get("valu", {}).get("msm_bucket_acc"))
+            have = max(1, torch.cuda.device_count())
+            full["kzg"] = kzg_leg(np, zk, ctx, verify=not args.no_verify, valu=(traffic or {}).get("valu", {}).get("msm_bucket_acc"),
+                                  group_devices=list(range(have)) if have > 1 else [0, 0])
             full["lpc"] = lpc_leg(np)
             full["quotient_chain"] = quotient_leg(np, verify=not args.no_verify)
             full["gate_argument"] = gate_argument_leg(np, verify=not args.no_verify)
@@ -508,6 +510,8 @@ def compact_line(full, detail_path):
     leg("kzg", "ms_per_commit_mean", "opening_proof_ms_mean")
     if (full.get("kzg") or {}).get("scheme_class"):
         legs["kzg_scheme_class_from_host"] = _pick(full["kzg"]["scheme_class"], "value", "unit", "verified")
+    if (full.get("kzg") or {}).get("device_group"):
+        legs["kzg_device_group"] = _pick(full["kzg"]["device_group"], "value", "unit", "verified", "members", "distinct_gpus", "error")
     leg("lpc", "proof_eval_ms")
     leg("quotient_chain")
     leg("gate_argument", "per_term_ms", "speedup_vs_per_term", "gate_eval_kernel_ms")
@@ -1059,7 +1063,7 @@ def groth16_sharded_leg(np, torch, dist, rank, world, local_rank, log_constraint
             "verified": None if not verify else bool(t[-1] == 0)}
 
 
-def kzg_leg(np, zk, ctx, log_n=20, cols=50, steps=2, verify=True, valu=None):
+def kzg_leg(np, zk, ctx, log_n=20, cols=50, steps=2, verify=True, valu=None, group_devices=None):
     """BASELINE config 5's commitment layer on one GPU: KZG commit of 50 witness columns of 2^20 rows (per column one
     inverse NTT + one G1 MSM against the resident SRS alpha^i G, alpha = 7 as placeholder.cpp:175; kzg_v2.hpp:208-226)
     and the device part of the batched opening proof of the same columns at two points (kzg_v2.hpp:236-305), the
@@ -1183,6 +1187,8 @@ def kzg_leg(np, zk, ctx, log_n=20, cols=50, steps=2, verify=True, valu=None):
            "verification": "50 commitments == f(alpha) G; sampled rows reproduced from the coefficient forms; pi_1, pi_2 == their division identities in the exponent",
            "roofline": roof, "kernel_ms_one_commit": kern}
     leg["scheme_class"] = kzg_scheme_leg(np, data, log_n, cols, raw_affine)
+    if group_devices:
+        leg["device_group"] = kzg_group_leg(np, data, log_n, cols, raw_affine, group_devices)
     return leg
 
 
@@ -1208,6 +1214,33 @@ def kzg_scheme_leg(np, data, log_n, cols, raw_affine, steps=3):
             "handover": "append_to_batch(std::cref): lent, no host copy; upload in chunks of 10 columns on a second stream",
             "verified": None if raw_affine is None else bool((out == raw_affine).all()),
             "verification": "all %d commitments equal the raw-ABI path's (themselves checked against f(alpha) G)" % cols}
+
+
+def kzg_group_leg(np, data, log_n, cols, raw_affine, devices, steps=3):
+    """BASELINE cfg 5's commitment leg AS A C++ CALLER OF THE DROP-IN CLASS REACHES SEVERAL GPUs: kzg_commitment_scheme_v2_hip over
+    kzg_params_group_hip -- one process, the key replicated on every member of the device group, commit(batch) dealing the 50 columns (each
+    member uploads, transforms and commits its own on a host thread of its own), the coefficient forms gathered on member 0 device to device,
+    proof_eval there.  On a one-GPU box the members share device 0 (an emulation: the orchestration, not a speed-up)."""
+    import ctypes
+
+    lib = _bench_lib()
+    ms = np.zeros(2 * steps, dtype=np.float64)
+    out = np.zeros((cols, 12), dtype=np.uint64)
+    devs = (ctypes.c_int * len(devices))(*devices)
+    rc = lib.zkhip_bench_kzg_scheme_group(devs, len(devices), ctypes.c_size_t(log_n), ctypes.c_size_t(cols), steps, data.ctypes.data_as(ctypes.c_void_p),
+                                          ms.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+    if rc != 0:
+        return {"error": rc}
+    ms = ms.reshape(steps, 2)
+    mean = float(ms[1:, 0].mean()) if steps > 1 else float(ms[0, 0])
+    distinct = len(set(devices))
+    return {"metric": "KZG commit columns/sec through kzg_commitment_scheme_v2_hip over a device group of %d member(s) on %d GPU(s), %d columns x 2^%d rows from HOST memory"
+                      % (len(devices), distinct, cols, log_n),
+            "value": round(cols / mean * 1e3, 2), "unit": "columns/s", "scaling": "strong", "ms_commit": [round(float(x), 2) for x in ms[:, 0]],
+            "ms_proof_eval": [round(float(x), 2) for x in ms[:, 1]], "members": len(devices), "distinct_gpus": distinct,
+            "verified": None if raw_affine is None else bool((out == raw_affine).all()),
+            "verification": "all %d commitments equal the single-device raw-ABI path's (themselves checked against f(alpha) G)" % cols,
+            "what": "members on distinct GPUs" if distinct == len(devices) else "EMULATION: the members share %d GPU(s) -- the orchestration at work, not a speed-up" % distinct}
 
 
 def lpc_leg(np, log_n=20, cols=16, steps=4):

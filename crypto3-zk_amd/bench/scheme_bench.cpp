@@ -242,6 +242,44 @@ int zkhip_bench_kzg_scheme(int device, size_t log_n, size_t cols, int steps, int
     }
 }
 
+/* The same through a scheme over a DEVICE GROUP (kzg_params_group_hip: the key replicated on every member, commit(batch) dealing the columns,
+ * the coefficient forms gathered on member 0 for proof_eval): `n_dev` members of THIS process, columns lent.  ms: steps x {commit, proof_eval}. */
+int zkhip_bench_kzg_scheme_group(const int *devices, int n_dev, size_t log_n, size_t cols, int steps, const uint64_t *evals, double *ms,
+                                 uint64_t *out_commitments) {
+    try {
+        const size_t n = (size_t)1 << log_n;
+        device_group grp(std::vector<int>(devices, devices + n_dev));
+        kzg_params_group_hip<C> params(grp, n, Fr(7));
+        std::vector<polynomial_dfs<C>> master(cols);
+        for (size_t c = 0; c < cols; ++c) {
+            master[c].values.resize(n);
+            std::memcpy(master[c].values.data(), evals + 4 * c * n, n * 32);
+        }
+        for (int rep = 0; rep < steps; ++rep) {
+            kzg_commitment_scheme_v2_hip<C, counting_transcript> scheme(params, bls_root);
+            std::vector<std::reference_wrapper<const polynomial_dfs<C>>> lent(master.begin(), master.end());
+            scheme.append_to_batch(0, lent);
+            auto t0 = std::chrono::steady_clock::now();
+            auto commits = scheme.commit(0);
+            ms[2 * rep] = ms_since(t0);
+            scheme.append_eval_point(0, Fr(1234567));
+            scheme.append_eval_point(0, Fr(7654321));
+            counting_transcript tr;
+            tr.challenges = {Fr(12345), Fr(54321)};
+            t0 = std::chrono::steady_clock::now();
+            auto proof = scheme.proof_eval(tr);
+            ms[2 * rep + 1] = ms_since(t0);
+            (void)proof;
+            if (out_commitments && rep == steps - 1)
+                for (size_t c = 0; c < cols; ++c) commits[c].to_affine(out_commitments + 12 * c);
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkhip_bench_kzg_scheme_group: %s\n", e.what());
+        return -1;
+    }
+}
+
 /* `cols` polynomial_dfs of 2^log_n rows in host memory -> lpc_commitment_scheme_hip::append_to_batch (lent) + commit over
  * D[0] = 2^(log_n + expand): upload, inverse NTTs, extension, coset-ordered leaf layout, and the leaves to the caller's tree
  * builder.  streaming != 0: the streaming builder shape (slices absorbed by `threads` host threads while the next slice is in
@@ -474,6 +512,9 @@ int zkhip_bench_gate_argument(int device, size_t log_n, size_t n_gates, size_t n
         typedef device_polynomial_dfs<C> dfs;
         const size_t n = (size_t)1 << log_n, ext = 8 * n;
         context ctx(device);
+        /* the per-term path holds one extension per distinct (column, rotation) pair (99 x 268 MB): both paths get a block cache that keeps
+           their buffers across repetitions, so that neither is timed through the driver's allocator (hundreds of ms when it has to scavenge) */
+        ctx.set_option("alloc_cache_mb", 96 * 1024);
         uint64_t seed = 4242;
         auto sm = [&seed]() {
             uint64_t z = (seed += 0x9E3779B97F4A7C15ull);

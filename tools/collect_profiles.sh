@@ -1,12 +1,12 @@
 #!/bin/bash
-# Evidence run of a round (on the GPU box, from the repository root; R=r05 by default): bench line + sidecar, rocprofv3 kernel stats, PMC
+# Evidence run of a round (on the GPU box, from the repository root; R=r06 by default): bench line + sidecar, rocprofv3 kernel stats, PMC
 # passes, sweeps.  Everything lands in gpurun_out/ (copied into profiles/ afterwards).  QUICK=1 skips the sweeps and micro-benchmarks.
 set -u
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$root"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-R=${R:-r05}
+R=${R:-r06}
 python3 bench.py > gpurun_out/${R}_bench_final.json 2> gpurun_out/${R}_bench_final.err
 cp bench_detail.json gpurun_out/${R}_bench_final_detail.json
 # the driver's own command line (20 timed steps after 5 warm-up steps)
@@ -31,6 +31,10 @@ tools/pmc_collect.sh gpurun_out/${R}_pmc_g2_msm.json tools/msm_g2_once.py > /dev
 # the grand-product kernels on their own
 rm -rf /tmp/rp5 && ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rp5 -o gp --output-format csv -- python3 "$root/tools/perm_profile.py" > /tmp/rp5.log 2>&1 )
 cp $(find /tmp/rp5 -name '*kernel_stats.csv' | head -1) gpurun_out/${R}_rocprofv3_kernel_stats_grand_products.csv 2>/dev/null
+# round 6: the realistic gate argument (fused against per-term) and its kernel table
+python3 tools/bench_gate_argument.py > gpurun_out/${R}_gate_argument.json 2>/dev/null
+rm -rf /tmp/rp6 && ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rp6 -o gate --output-format csv -- python3 "$root/tools/bench_gate_argument.py" > /tmp/rp6.log 2>&1 )
+cp $(find /tmp/rp6 -name '*kernel_stats.csv' | head -1) gpurun_out/${R}_rocprofv3_kernel_stats_gate_argument.csv 2>/dev/null
 python3 tools/call_overhead.py > gpurun_out/${R}_call_overhead.txt 2>/dev/null
 for seed in 1 2; do timeout 400 python3 tests/fuzz_gpu.py --seconds 300 --seed $seed 2>&1 | tail -3; done > gpurun_out/${R}_fuzz.txt
 if [ -n "${QUICK:-}" ]; then ls -la gpurun_out | tail -20; exit 0; fi
