@@ -728,13 +728,17 @@ public:
         const auto t0 = clock::now();
         std::vector<std::unique_ptr<drain_on_unwind>> guards;
         for (const auto &m : gk.members) guards.emplace_back(new drain_on_unwind {*m});
-        const std::uint64_t *staged = nullptr;
-        for (std::size_t k = 0; k < world; ++k) {
+        /* The assignment crosses PCIe ONCE, to member 0; the other members pull it from there (peer copies over xGMI, each on its own
+           stream behind an event that marks the end of member 0's upload -- NOT of its proof): a copy out of the caller's pageable vector
+           blocks this thread for its duration, and eight of them in a row would cost more than the sharded proof itself. */
+        const std::size_t num_inputs = primary_input.size(), num_variables = primary_input.size() + auxiliary_input.size();
+        upload_assignment(*gk.members[0], primary_input, auxiliary_input);
+        for (std::size_t k = 1; k < world; ++k) {
             const proving_key_type &pk = *gk.members[k];
-            enqueue(pk, primary_input, auxiliary_input, staged);
-            /* member 0 has converted (1, x, w) into its page-locked buffer -- unless the scalars go out as they lie in the caller's vector */
-            if (k == 0 && !(detail::canonical_scalars<adapter>::value && pk.direct_assignment_upload)) staged = static_cast<const std::uint64_t *>(pk.h_cpa.get());
+            pk.reserve_work(num_variables + 1, pk.constraint_system.domain_size(), partial_limbs() * 8);
+            gk.group.copy(k, pk.d_cpa.get(), 0, gk.members[0]->d_cpa.get(), 32 * (num_variables + 1));
         }
+        for (std::size_t k = 0; k < world; ++k) enqueue_compute(*gk.members[k], num_inputs, num_variables);
         const auto t1 = clock::now();
         const host_terms t = host_products(*gk.members[0], r, s);
         const auto t2 = clock::now();
@@ -811,22 +815,19 @@ private:
     /// assignment already (one asynchronous copy instead of a second conversion)
     static void enqueue(const proving_key_type &pk, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input,
                         const std::uint64_t *staged = nullptr) {
+        upload_assignment(pk, primary_input, auxiliary_input, staged);
+        enqueue_compute(pk, primary_input.size(), primary_input.size() + auxiliary_input.size());
+    }
+    /// the key's work buffers (first use) and const_padded_assignment = (1, x, w) on its way to d_cpa (asynchronous)
+    static void upload_assignment(const proving_key_type &pk, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input,
+                                  const std::uint64_t *staged = nullptr) {
         const context &ctx = pk.ctx;
-        const query_shard &sh = pk.shard;
         const std::size_t num_inputs = primary_input.size();
         const std::size_t num_variables = primary_input.size() + auxiliary_input.size();
-        const std::size_t degree = pk.constraint_system.domain_size();
-
         /* Everything below is enqueued on the context's stream without intermediate synchronisation; the device
            buffers live in the key object (allocated on first use) so a proof costs no hipMalloc. */
-        const std::size_t jl1 = 3 * adapter::g1_coord_limbs;
-        pk.reserve_work(num_variables + 1, degree, partial_limbs() * 8);
-        if (pk.side) {    // for this proof only: collect() gives the caller's context its own setting back
-            pk.saved_sort_tile_log = ctx.get_option("msm_sort_tile_log");
-            ctx.set_option("msm_sort_tile_log", 12);
-        }
+        pk.reserve_work(num_variables + 1, pk.constraint_system.domain_size(), partial_limbs() * 8);
         char *cpa = static_cast<char *>(pk.d_cpa.get());
-        std::uint64_t *d_res = static_cast<std::uint64_t *>(pk.d_results.get());
 
         /* const_padded_assignment = (1, x, w) (prover.hpp:102-106) */
         std::uint64_t *z = static_cast<std::uint64_t *>(pk.h_cpa.get());
@@ -864,6 +865,20 @@ private:
                           ctx.get());
             }
         }
+    }
+    /// the witness map and the five multiexps over the assignment at d_cpa (enqueued only)
+    static void enqueue_compute(const proving_key_type &pk, std::size_t num_inputs, std::size_t num_variables) {
+        const context &ctx = pk.ctx;
+        const query_shard &sh = pk.shard;
+        const std::size_t degree = pk.constraint_system.domain_size();
+        const std::size_t jl1 = 3 * adapter::g1_coord_limbs;
+        pk.reserve_work(num_variables + 1, degree, partial_limbs() * 8);
+        if (pk.side) {    // for this proof only: collect() gives the caller's context its own setting back
+            pk.saved_sort_tile_log = ctx.get_option("msm_sort_tile_log");
+            ctx.set_option("msm_sort_tile_log", 12);
+        }
+        char *cpa = static_cast<char *>(pk.d_cpa.get());
+        std::uint64_t *d_res = static_cast<std::uint64_t *>(pk.d_results.get());
         /* qap_wit.coefficients_for_H, resident (prover.hpp:79-83) */
         std::uint64_t g[4];
         const zkhip_domain dd = pk.evaluation_domain.c_desc();
