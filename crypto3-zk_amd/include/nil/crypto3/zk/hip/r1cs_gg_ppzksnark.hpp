@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <exception>
 #include <future>
 #include <memory>
 #include <stdexcept>
@@ -738,7 +739,29 @@ public:
             pk.reserve_work(num_variables + 1, pk.constraint_system.domain_size(), partial_limbs() * 8);
             gk.group.copy(k, pk.d_cpa.get(), 0, gk.members[0]->d_cpa.get(), 32 * (num_variables + 1));
         }
-        for (std::size_t k = 0; k < world; ++k) enqueue_compute(*gk.members[k], num_inputs, num_variables);
+        /* ~60 launches per member: from three members on, every member but the first is enqueued by a host thread of its own (a context
+           is used by one thread at a time: distinct contexts are independent), so that the last member does not start N x 0.3 ms late */
+        if (world <= 2) {
+            for (std::size_t k = 0; k < world; ++k) enqueue_compute(*gk.members[k], num_inputs, num_variables);
+        } else {
+            std::vector<std::future<void>> others;
+            for (std::size_t k = 1; k < world; ++k)
+                others.push_back(std::async(std::launch::async, [&gk, k, num_inputs, num_variables]() { enqueue_compute(*gk.members[k], num_inputs, num_variables); }));
+            std::exception_ptr failed;
+            try {
+                enqueue_compute(*gk.members[0], num_inputs, num_variables);
+            } catch (...) {
+                failed = std::current_exception();
+            }
+            for (auto &f : others) {
+                try {
+                    f.get();
+                } catch (...) {
+                    if (!failed) failed = std::current_exception();
+                }
+            }
+            if (failed) std::rethrow_exception(failed);
+        }
         const auto t1 = clock::now();
         const host_terms t = host_products(*gk.members[0], r, s);
         const auto t2 = clock::now();
