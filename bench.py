@@ -125,6 +125,10 @@ def main():
     ap.add_argument("--ntt-log-m", type=int, default=22, help="domain of the sharded NTT leg = 2^k (tests use a smaller one)")
     ap.add_argument("--detail", default=None, help="where the sidecar with every leg's full object goes (default: bench_detail.json next to bench.py, "
                                                    "and a copy under gpurun_out/ when that directory exists)")
+    ap.add_argument("--group-child", default=None, metavar="DEVICES",
+                    help="internal: run the device-group legs over these devices (comma-separated) in THIS process and print their JSON -- bench.py "
+                         "starts itself this way as a child, so that a group over GPUs no round could test on (RCCL single-process over xGMI) cannot take the line down")
+    ap.add_argument("--child-legs", default="groth16,kzg", help="internal: which group legs the child runs")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: launch the ranks, run the all-gather + fold plumbing over gloo with stand-in partial sums, print the line's frame")
     args = ap.parse_args()
@@ -133,6 +137,8 @@ def main():
         raise SystemExit(launch_ranks(args, sys.argv[1:]))
     if args.dry_run:
         return dry_run(args)
+    if args.group_child is not None:
+        return group_child(args)
 
     # stdout carries exactly ONE line, rank 0's JSON: libraries that print to the C stdout (librccl announces its path there,
     # flushed at exit, i.e. AFTER our line) are sent to stderr for the whole run; the line is written to the saved descriptor
@@ -287,7 +293,7 @@ def main():
         # multi-GPU path, the exchange inside libzkhip.so) while the other ranks wait on the host; their GPUs are idle then
         torch.cuda.synchronize()
         devs = [0] * world if args.same_device else list(range(world))
-        g16_group = dist.host_wait_for_rank0(rank, lambda: groth16_group_leg(np, devs, log_constraints=args.log_constraints, steps=3, verify=not args.no_verify))
+        g16_group = dist.host_wait_for_rank0(rank, lambda: run_group_child(devs, ["groth16"], args).get("groth16_device_group"))
     dist_info = None
     if use_dist:
         # evidence that the collective saw `world` DISTINCT devices: every rank reports the uuid of the GPU it runs on
@@ -353,6 +359,7 @@ def main():
         else:
             full["roofline"]["traffic_source"] = ("not collected: bench.py itself runs under a profiler (no nested rocprofv3)" if under_profiler() else
                                                   "not collected in this run (rocprofv3 unavailable, --no-pmc, or N > 1); see profiles/ for the offline passes")
+        group_child_out = None
         if world == 1 and not args.no_ntt:
             full["ntt"] = ntt_leg(np, zk, ctx, verify=not args.no_verify, traffic=traffic)
         if world == 1 and not args.no_groth16:
@@ -367,8 +374,10 @@ def main():
             # ... and the drop-in classes over a device group inside ONE process: every GPU this box has (at least two members, so that the
             # exchange runs; on a one-GPU box they share device 0 and the leg is labelled an emulation)
             have = max(1, torch.cuda.device_count())
-            members = list(range(have)) if have > 1 else [0, 0]
-            full["groth16_device_group"] = groth16_group_leg(np, members, verify=not args.no_verify)
+            group_members = list(range(have)) if have > 1 else [0, 0]
+            group_legs = ["groth16"] + ([] if args.no_kzg else ["kzg"])
+            group_child_out = run_group_child(group_members, group_legs, args)
+            full["groth16_device_group"] = group_child_out.get("groth16_device_group")
         if world == 1 and not args.no_other_msm:
             full["msm_g2"] = msm_other_leg(np, zk, ctx, 0, 2, verify=not args.no_verify)
             full["msm_bn254_g1"] = msm_other_leg(np, zk, ctx, 1, 1, verify=not args.no_verify)
@@ -381,9 +390,9 @@ def main():
         if ntt_sharded is not None:
             full["ntt_sharded"] = ntt_sharded
         if world == 1 and not args.no_kzg:
-            have = max(1, torch.cuda.device_count())
-            full["kzg"] = kzg_leg(np, zk, ctx, verify=not args.no_verify, valu=(traffic or {}).get("valu", {}).get("msm_bucket_acc"),
-                                  group_devices=list(range(have)) if have > 1 else [0, 0])
+            full["kzg"] = kzg_leg(np, zk, ctx, verify=not args.no_verify, valu=(traffic or {}).get("valu", {}).get("msm_bucket_acc"))
+            if group_child_out is not None and group_child_out.get("kzg_device_group"):
+                full["kzg"]["device_group"] = group_child_out["kzg_device_group"]
             full["lpc"] = lpc_leg(np)
             full["quotient_chain"] = quotient_leg(np, verify=not args.no_verify)
             full["gate_argument"] = gate_argument_leg(np, verify=not args.no_verify)
@@ -986,6 +995,57 @@ def groth16_group_leg(np, devices, transport=0, log_constraints=20, inputs=10, s
             "what": ("members on distinct GPUs: the single-process form of groth16_sharded" if distinct == len(devices) else
                      "EMULATION: %d members share %d GPU(s) -- the group's orchestration and exchange at work, not a speed-up (their kernels queue on one device)"
                      % (len(devices), distinct))}
+
+
+def group_child(args):
+    """`bench.py --group-child 0,1,...`: the device-group legs in a process of their own (see run_group_child); ONE JSON line on stdout."""
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)  # librccl announces itself on the C stdout
+    import numpy as np
+    import torch  # noqa: F401  (first: libzkhip.so shares torch's HIP runtime and, for the group's exchange, its librccl)
+
+    devices = [int(x) for x in args.group_child.split(",") if x != ""]
+    legs = set(args.child_legs.split(","))
+    out = {}
+    if "groth16" in legs:
+        out["groth16_device_group"] = groth16_group_leg(np, devices, log_constraints=args.log_constraints, steps=4, verify=not args.no_verify)
+    if "kzg" in legs:
+        import ctypes
+
+        log_n, cols = args.kzg_log_rows, 50
+        data = random_scalars(np, (1 << log_n) * cols, 5).reshape(cols, 1 << log_n, 4)  # the columns of kzg_leg (same seed)
+        raw = None
+        if not args.no_verify:
+            # the single-device scheme class over the same columns (its commitments are what kzg_leg checks against f(alpha) G in the parent)
+            lib = _bench_lib()
+            ms = np.zeros(3, dtype=np.float64)
+            raw = np.zeros((cols, 12), dtype=np.uint64)
+            rc = lib.zkhip_bench_kzg_scheme(devices[0], ctypes.c_size_t(log_n), ctypes.c_size_t(cols), 1, 2, ctypes.c_size_t(10), data.ctypes.data_as(ctypes.c_void_p),
+                                            ms.ctypes.data_as(ctypes.c_void_p), raw.ctypes.data_as(ctypes.c_void_p))
+            if rc != 0:
+                raw = None
+        out["kzg_device_group"] = kzg_group_leg(np, data, log_n, cols, raw, devices)
+        out["kzg_device_group"]["verification"] = "all %d commitments equal the single-device scheme class's over the same columns (same process); the parent checks those against f(alpha) G" % cols
+    os.write(json_fd, (json.dumps(out, separators=(",", ":")) + "\n").encode())
+    return 0
+
+
+def run_group_child(devices, legs, args, timeout=900):
+    """The device-group legs in a CHILD process (python bench.py --group-child ...): the group over several distinct GPUs runs RCCL single-process
+    communicators over xGMI, which no round of this build could test on hardware -- a failure or a hang there must cost the leg, not the line (the
+    child is started the ordinary way, a new process, never an exec from this one)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--group-child", ",".join(str(d) for d in devices), "--child-legs", ",".join(legs),
+           "--log-constraints", str(args.log_constraints), "--kzg-log-rows", str(args.kzg_log_rows)] + (["--no-verify"] if args.no_verify else [])
+    names = {"groth16": "groth16_device_group", "kzg": "kzg_device_group"}
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+        lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+        if r.returncode != 0 or not lines:
+            raise RuntimeError("exit code %d: %s" % (r.returncode, r.stderr[-300:].replace("\n", " | ")))
+        return json.loads(lines[-1])
+    except Exception as e:  # noqa: BLE001  (a timeout, a crash, a malformed line: the leg says so)
+        return {names[l]: {"error": "device-group child failed: %s" % str(e)[:400]} for l in legs}
 
 
 def _last_domain(np, lib):

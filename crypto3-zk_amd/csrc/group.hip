@@ -38,9 +38,23 @@ RcclApi *rccl_api(std::string &err) {
     std::lock_guard<std::mutex> g(m);
     if (!tried) {
         tried = true;
-        // a process that has torch loaded already maps torch's librccl under the same soname: dlopen then returns that one
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        // The RCCL that belongs to the HIP runtime THIS library is bound to: a process may hold two ROCm installations (PyTorch wheels ship their
+        // own libamdhip64 / librccl next to /opt/rocm's; whichever libamdhip64 was loaded first serves everybody), and an RCCL built against the
+        // other one fails inside ncclCommInitAll ("unhandled cuda error": found by tests/fuzz_gpu.py, which loads libzkhip.so before torch).  So:
+        // the directory of the libamdhip64 that hipGetDeviceCount resolves to first, then the loader's own search.
+        std::vector<std::string> names;
+        Dl_info where;
+        if (dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &where) && where.dli_fname) {
+            const std::string path(where.dli_fname);
+            const size_t slash = path.rfind('/');
+            if (slash != std::string::npos) {
+                names.push_back(path.substr(0, slash) + "/librccl.so.1");
+                names.push_back(path.substr(0, slash) + "/librccl.so");
+            }
+        }
+        for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) names.push_back(n);
+        for (const std::string &name : names) {
+            api.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (api.lib) break;
         }
         if (!api.lib) {

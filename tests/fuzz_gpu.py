@@ -5,7 +5,8 @@ Every iteration draws a shape the fixed tests do not enumerate -- curve, group, 
 scalar pattern (uniform, zeros / ones heavy, r - 1, few distinct values = large buckets, tiny values), MSM one by one / as a batch /
 as a batch whose members share a sort, NTT size / batch / direction / coset, evaluation domain of any kind, Groth16 witness map over the
 domain make_evaluation_domain picks, whole Groth16 proofs through the C++ shim, the grand products / pointwise kernels behind placeholder's
-permutation and lookup arguments on vectors of any length -- and compares bit for bit.  Exit code 0 and a JSON line with the counts = no difference."""
+permutation and lookup arguments on vectors of any length, the gate argument's flat-program kernel on random programs, the device group's MSM / NTT over
+1 .. 5 members and every transport -- and compares bit for bit.  Exit code 0 and a JSON line with the counts = no difference."""
 import argparse
 import json
 import os
@@ -279,6 +280,97 @@ def fuzz_arguments(zk, ctx, rng, stats):
     stats["argument_kernels"] += 1
 
 
+def fuzz_gate(zk, ctx, rng, stats):
+    """zkhip_gate_eval_dev on a random flat program (gates with / without selector, 0 .. 40 terms of 0 .. 5 factors, rotations of both signs up to the
+    domain's size, with / without mask, in one piece or two accumulating ones) against the same sum from the oracle's pointwise arithmetic"""
+    curve = int(rng.integers(0, 2))
+    log_size = int(rng.integers(1, 13 if SCALE == 1 else 15))
+    size = 1 << log_size
+    r = CURVES[curve].r
+    n_slots = int(rng.integers(1, 7))
+    cols = [cp.random_fr(curve, int(rng.integers(1, 1 << 30)), size) for _ in range(n_slots)]
+    if rng.random() < 0.5:
+        cols[0][:: int(rng.integers(2, 5))] = 0
+    rot = lambda: int(rng.integers(-size, size + 1)) if rng.random() < 0.5 else int(rng.integers(-2, 3))
+    gates = []
+    for _ in range(int(rng.integers(1, 6))):
+        sel = (int(rng.integers(0, n_slots)), rot()) if rng.random() < 0.6 else None
+        terms = []
+        for _ in range(int(rng.integers(0, 41 if rng.random() < 0.2 else 6))):
+            coeff = int(rng.integers(0, 5)) if rng.random() < 0.2 else po.from_limbs(cp.random_fr(curve, int(rng.integers(1, 1 << 30)), 1)[0])
+            terms.append((coeff % r, [(int(rng.integers(0, n_slots)), rot()) for _ in range(int(rng.integers(0, 6)))]))
+        gates.append((sel, terms))
+    from util import fr_arr
+
+    def expect(gs, mask, prev):
+        acc = np.zeros((size, 4), dtype=np.uint64) if prev is None else prev
+        for sel, terms in gs:
+            g = np.zeros((size, 4), dtype=np.uint64)
+            for c, fs in terms:
+                t = np.repeat(fr_arr([c]), size, axis=0)
+                for sl, rt in fs:
+                    t = cp.fr_vec(curve, 2, t, np.roll(cols[sl], -rt, axis=0))
+                g = cp.fr_vec(curve, 0, g, t)
+            if sel is not None:
+                g = cp.fr_vec(curve, 2, g, np.roll(cols[sel[0]], -sel[1], axis=0))
+            acc = cp.fr_vec(curve, 0, acc, g)
+        return cp.fr_vec(curve, 2, acc, mask) if mask is not None else acc
+
+    d_slots = [ctx.malloc(size * 32) for _ in range(n_slots)]
+    for p_, c in zip(d_slots, cols):
+        ctx.h2d(p_, c)
+    mask = cp.random_fr(curve, int(rng.integers(1, 1 << 30)), size) if rng.random() < 0.6 else None
+    d_mask = ctx.malloc(size * 32) if mask is not None else 0
+    if mask is not None:
+        ctx.h2d(d_mask, mask)
+    d_out = ctx.malloc(size * 32)
+    out = np.zeros((size, 4), dtype=np.uint64)
+    cut = int(rng.integers(1, len(gates))) if len(gates) > 1 and rng.random() < 0.4 else 0
+    if cut:
+        ctx.gate_eval_dev(curve, gates[:cut], d_slots, log_size, d_out)
+        ctx.gate_eval_dev(curve, gates[cut:], d_slots, log_size, d_out, d_mask, accumulate=True)
+    else:
+        ctx.gate_eval_dev(curve, gates, d_slots, log_size, d_out, d_mask)
+    ctx.d2h(out, d_out)
+    assert (out == expect(gates, mask, None)).all(), ("gate_eval", curve, log_size, gates)
+    for p_ in d_slots + [d_out] + ([d_mask] if d_mask else []):
+        ctx.free(p_)
+    stats["gate_eval"] = stats.get("gate_eval", 0) + 1
+
+
+def fuzz_group(zk, ctx, rng, stats):
+    """the device group (members on this box's one GPU or dealt over its GPUs): zkhip_group_msm and zkhip_group_ntt over 1 .. 5 members and a random
+    transport against the oracle"""
+    import torch
+    have = max(1, torch.cuda.device_count())
+    world = int(rng.integers(1, 6))
+    g = zk.DeviceGroup([k % have for k in range(world)])
+    distinct = world <= have
+    g.set_transport(int(rng.choice([zk.zkhip.GROUP_AUTO, zk.zkhip.GROUP_PEER, zk.zkhip.GROUP_STAGED] + ([zk.zkhip.GROUP_RCCL] if distinct else []))))
+    curve = int(rng.integers(0, 2))
+    if rng.random() < 0.6:
+        group = int(rng.integers(1, 3))
+        n = int(rng.integers(1, (3000 if group == 1 else 600) * SCALE))
+        pts, inf = cp.batch_mul(curve, group, cp.random_fr(curve, int(rng.integers(1, 1 << 30)), n))
+        gb = g.upload_bases(curve, group, pts)
+        off = int(rng.integers(0, n)) if rng.random() < 0.3 else 0
+        cnt = int(rng.integers(0, n - off + 1)) if rng.random() < 0.3 else n - off
+        sc = scalars(rng, curve, cnt, ["uniform", "zeros_ones", "few_values"][int(rng.integers(0, 3))])
+        aff, is_inf = g.msm_affine(gb, sc, offset=off, n=cnt)
+        exp, einf = cp.msm(curve, group, pts[off:off + cnt], sc, chunks=2) if cnt else (None, 1)
+        assert is_inf == einf and (einf or (aff == exp).all()), ("group msm", curve, group, n, off, cnt, world)
+        gb.free()
+    else:
+        log_m, batch = int(rng.integers(1, 13)), int(rng.integers(1, 7))
+        w = limbs(CURVES[curve].root_of_unity(log_m), 4)
+        a = cp.random_fr(curve, int(rng.integers(1, 1 << 30)), batch << log_m).reshape(batch, 1 << log_m, 4)
+        inverse = bool(rng.integers(0, 2))
+        coset = limbs(CURVES[curve].fr_generator, 4) if rng.random() < 0.4 else None
+        assert (g.ntt(curve, a, log_m, w, inverse=inverse, coset=coset) == cp.ntt(curve, a, log_m, w, inverse=inverse, coset=coset)).all(), ("group ntt", curve, log_m, batch, world)
+    g.close()
+    stats["device_group"] = stats.get("device_group", 0) + 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
@@ -291,7 +383,7 @@ def main():
     ctx = zk.Context(0)
     rng = np.random.default_rng(a.seed)
     stats = {"msm": 0, "ntt": 0, "domain": 0, "domain_skipped": 0, "witness_map": 0, "groth16_proof": 0, "argument_kernels": 0}
-    legs = [fuzz_msm, fuzz_msm, fuzz_ntt, fuzz_domain, fuzz_witness, fuzz_proof, fuzz_arguments]
+    legs = [fuzz_msm, fuzz_msm, fuzz_ntt, fuzz_domain, fuzz_witness, fuzz_proof, fuzz_arguments, fuzz_gate, fuzz_group]
     t0 = time.time()
     while time.time() - t0 < a.seconds:
         legs[int(rng.integers(0, len(legs)))](zk, ctx, rng, stats)

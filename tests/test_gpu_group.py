@@ -138,3 +138,31 @@ def test_group_ntt_bit_identical(zk, ctx, curve, log_m, batch):
             assert (got == one).all(), (world, inverse, coset is not None)
             g.close()
     assert (ctx.ntt(curve, a, log_m, w) == cp.ntt(curve, a, log_m, w)).all()
+
+
+@pytest.mark.parametrize("torch_first", [False, True])
+def test_group_rccl_matches_the_hip_runtime_in_use(torch_first):
+    """A process may hold two ROCm installations: PyTorch wheels ship their own libamdhip64 / librccl next to /opt/rocm's, and whichever
+    libamdhip64 is loaded first serves everybody.  The group must load the RCCL that belongs to the HIP runtime libzkhip.so is bound to (found by
+    tests/fuzz_gpu.py: with libzkhip.so loaded BEFORE torch, torch's librccl -- same soname -- failed inside ncclCommInitAll): both load orders,
+    each in a process of its own, RCCL transport at group size 1."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "%s"
+        "zk = bench.load_pkg(); zk.load_library()\n"
+        "%s"
+        "g = zk.DeviceGroup([0]); g.set_transport(zk.zkhip.GROUP_RCCL)\n"
+        "c = g.members[0]; a = c.malloc(864); b = c.malloc(864)\n"
+        "x = np.arange(864, dtype=np.uint8); c.h2d(a, x); g.all_gather([a], [b], 864); g.sync()\n"
+        "y = np.zeros(864, dtype=np.uint8); c.d2h(y, b); assert (x == y).all() and g.transport() == zk.zkhip.GROUP_RCCL\n"
+        "g.close(); print('ok')\n"
+    ) % (root, "import torch\n" if torch_first else "", "" if torch_first else "import torch\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
