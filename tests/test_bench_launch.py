@@ -91,3 +91,33 @@ def test_bench_rccl_path_on_one_gpu(tmp_path):
     assert line["dist"]["backend"] == "rccl" and line["dist"]["world_size"] == 1 and len(line["dist"]["devices"]) == 1
     detail = json.load(open(tmp_path / "detail.json"))   # the sidecar keeps every leg's full object
     assert detail["value"] == line["value"] and "kernel_ms_per_step" in detail and "ms_by_phase" in detail["placeholder_round"]
+
+
+def test_group_child_failure_costs_the_leg_not_the_line(tmp_path):
+    """bench.py runs the device-group legs in a CHILD process (a group over several distinct GPUs is RCCL single-process over xGMI, which no
+    round could run on hardware): whatever happens there -- here: no GPU at all, so the group cannot even be made; then a command that dies;
+    then one that hangs past its timeout -- must come back as an `error` entry of the leg, never as an exception in the parent."""
+    import importlib.util
+    import types
+
+    spec = importlib.util.spec_from_file_location("zk_bench_mod2", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    args = types.SimpleNamespace(log_constraints=10, kzg_log_rows=10, no_verify=True)
+    import torch
+    if not torch.cuda.is_available():
+        out = b.run_group_child([0, 0], ["groth16"], args, timeout=300)
+        assert "error" in out["groth16_device_group"], out          # the child ran, the leg failed inside it (zkhip has no CPU fallback)
+    real = b.sys.executable
+    try:
+        b.sys.executable = "/bin/false"                              # a child that dies at once
+        out = b.run_group_child([0, 1], ["groth16", "kzg"], args, timeout=30)
+        assert set(out) == {"groth16_device_group", "kzg_device_group"} and all("error" in v for v in out.values())
+        hang = tmp_path / "hang.sh"                                  # ... and one that never answers: the timeout ends it
+        hang.write_text("#!/bin/sh\nexec sleep 120\n")
+        hang.chmod(0o755)
+        b.sys.executable = str(hang)
+        out = b.run_group_child([0, 1], ["groth16"], args, timeout=2)
+        assert "error" in out["groth16_device_group"] and "timed out" in out["groth16_device_group"]["error"]
+    finally:
+        b.sys.executable = real
