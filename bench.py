@@ -293,7 +293,7 @@ def main():
         # multi-GPU path, the exchange inside libzkhip.so) while the other ranks wait on the host; their GPUs are idle then
         torch.cuda.synchronize()
         devs = [0] * world if args.same_device else list(range(world))
-        g16_group = dist.host_wait_for_rank0(rank, lambda: run_group_child(devs, ["groth16"], args).get("groth16_device_group"))
+        g16_group = dist.host_wait_for_rank0(rank, lambda: run_group_child(devs, ["groth16"], args, timeout=420).get("groth16_device_group"))
     dist_info = None
     if use_dist:
         # evidence that the collective saw `world` DISTINCT devices: every rank reports the uuid of the GPU it runs on
@@ -609,7 +609,8 @@ class Comm:
                 if store is not None:
                     store.set("zkhip_bench_rank0_work_done", "1")
         elif store is not None:
-            store.wait(["zkhip_bench_rank0_work_done"])
+            import datetime
+            store.wait(["zkhip_bench_rank0_work_done"], datetime.timedelta(seconds=900))  # rank 0's work is bounded well below this (run_group_child's timeout)
         if store is None:  # no store to wait on: the collective barrier after all (the leg then shares the GPUs with spinning kernels)
             self.barrier(device_ids=[self.local_rank])
         return out
