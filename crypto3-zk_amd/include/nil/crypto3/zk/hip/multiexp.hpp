@@ -136,9 +136,9 @@ inline const device_group *default_group() {
     thread_local std::unique_ptr<device_group> own;
     thread_local bool looked = false;
     if (!looked) {
-        looked = true;
         const std::vector<int> devices = device_group::devices_from_env();
-        if (devices.size() > 1) own.reset(new device_group(devices));
+        if (devices.size() > 1) own.reset(new device_group(devices));    // throws for a device that does not exist -- at EVERY call, not only the first:
+        looked = true;                                                      // a misconfigured ZKHIP_DEVICES must not quietly become one GPU
     }
     return own.get();
 }

@@ -1958,6 +1958,22 @@ void shim_host_query_shards(size_t world, size_t a, size_t b, size_t h, size_t l
     }
 }
 
+/* device_group::devices_from_env() on the current environment: writes up to cap ids, returns how many ZKHIP_DEVICES names (0: unset or malformed) */
+int shim_host_devices_from_env(int *out, int cap) {
+    const std::vector<int> d = device_group::devices_from_env();
+    for (int i = 0; i < (int)d.size() && i < cap; ++i) out[i] = d[i];
+    return (int)d.size();
+}
+/* members of the calling thread's default device group (ZKHIP_DEVICES), 0 when there is none, -1 when making it throws */
+int shim_default_group_size() {
+    try {
+        const device_group *g = default_group();
+        return g ? (int)g->size() : 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "shim_default_group_size: %s\n", e.what());
+        return -1;
+    }
+}
 void shim_set_world(int world) { g_world = world < 1 ? 1 : world; }
 void shim_set_gpus(int gpus) { g_gpus = gpus < 1 ? 1 : gpus; }
 void shim_set_lpc_builder(int kind) { g_lpc_builder = kind; }

@@ -166,3 +166,23 @@ def test_group_rccl_matches_the_hip_runtime_in_use(torch_first):
     ) % (root, "import torch\n" if torch_first else "", "" if torch_first else "import torch\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("value,expect", [("0,0,0", [3, 3]), ("0", [0, 0]), ("0,4096", [-1, -1])])
+def test_default_group_from_the_environment(value, expect):
+    """ZKHIP_DEVICES=... makes the calling thread's DEFAULT device group (what the reference's static process(proving_key, x, w) and the
+    multiexp policy spread over): three members on device 0; one device = no group; a device that does not exist fails at EVERY use (a
+    misconfigured list must not quietly become one GPU)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import ctypes, torch\n"
+            "s = ctypes.CDLL(%r)\n"
+            "print('sizes', s.shim_default_group_size(), s.shim_default_group_size())\n") % os.path.join(root, "tests", "cpp", "libshimtest.so")
+    env = dict(os.environ, ZKHIP_DEVICES=value)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("sizes")][0]
+    assert [int(x) for x in line.split()[1:]] == expect

@@ -132,3 +132,21 @@ def test_generator_host_side_matches_oracles(shim, curve, M, n, domain):
         eA, eB, eC = po.groth16_expected_in_exponent(C, cs, prim, aux, trap, rr, ss, dom)
         a, b, c = fr_ints(out)
         assert (C.g1.mul(C.g1.gen, a), C.g2.mul(C.g2.gen, b), C.g1.mul(C.g1.gen, c)) == (eA, eB, eC)
+
+
+@pytest.mark.parametrize("value,expect", [(None, []), ("0,1,2,3", [0, 1, 2, 3]), ("5", [5]), ("0,0", [0, 0]), ("", []), ("0,,1", []), ("0,1,", []), ("a,b", []), ("0, 1", []),
+                                          ("7,6,5,4,3,2,1,0", [7, 6, 5, 4, 3, 2, 1, 0])])
+def test_zkhip_devices_environment_variable(shim, value, expect):
+    """ZKHIP_DEVICES names the GPUs of the default device group (hip/backend.hpp: device_group::devices_from_env): a comma-separated list of
+    device ids; anything malformed reads as unset (one GPU) rather than as a partial list"""
+    old = os.environ.pop("ZKHIP_DEVICES", None)
+    try:
+        if value is not None:
+            os.environ["ZKHIP_DEVICES"] = value
+        out = (ctypes.c_int * 16)()
+        n = shim.shim_host_devices_from_env(out, 16)
+        assert [out[i] for i in range(n)] == expect
+    finally:
+        os.environ.pop("ZKHIP_DEVICES", None)
+        if old is not None:
+            os.environ["ZKHIP_DEVICES"] = old
