@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of the 512-lane NTT pass (option "ntt_wide") on one box, interleaved: tools/experiments/ab_ntt_wide.sh [rounds]
+# (needs tools/experiments/r06_ntt_wide.patch applied and the library rebuilt)
 cd "$(dirname "$0")/../.."
 for r in $(seq 1 ${1:-3}); do
   for v in 0 1 0; do
