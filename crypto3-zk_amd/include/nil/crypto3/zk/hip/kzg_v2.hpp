@@ -411,11 +411,21 @@ private:
             const context &ctx = group[k];
             const kzg_params_hip<CurveType> &params = *gp.members[k];
             auto at = [&](std::size_t p) { return pt.base + 32 * (db.offset[p] - db.offset[pt.lo]); };
-            for (std::size_t p = pt.lo; p < pt.hi; ++p)
-                if (polys[p]) upload_scalars<adapter>(ctx, at(p), detail::poly_data<adapter>(*polys[p]), polys[p]->size());
+            /* the member's own pipeline, as commit() runs it on one device: its host columns go up in chunks on a second in-order stream of
+               ITS GPU while the chunk before is transformed and committed (a third of the member's columns per chunk, at most upload_chunk) */
+            bool any_from_host = false;
+            for (std::size_t p = pt.lo; p < pt.hi; ++p) any_from_host = any_from_host || polys[p] != nullptr;
+            const std::size_t mine = pt.hi - pt.lo, chunk = upload_chunk ? std::max<std::size_t>(1, std::min(upload_chunk, (mine + 2) / 3)) : 0;
+            const bool pipelined = chunk != 0 && mine > chunk && any_from_host;
+            std::unique_ptr<context> up_own;
+            if (pipelined) up_own.reset(new context(ctx.device()));
+            const context &up = pipelined ? *up_own : ctx;
             for (std::size_t i = pt.lo; i < pt.hi;) {
                 std::size_t j = i;
-                while (j < pt.hi && db.len[j] == db.len[i] && is_coefficients(j) == is_coefficients(i) && is_zero(j) == is_zero(i)) ++j;
+                while (j < pt.hi && db.len[j] == db.len[i] && is_coefficients(j) == is_coefficients(i) && is_zero(j) == is_zero(i) && (!pipelined || j - i < chunk)) ++j;
+                for (std::size_t p = i; p < j; ++p)
+                    if (polys[p]) upload_scalars<adapter>(up, at(p), detail::poly_data<adapter>(*polys[p]), polys[p]->size());
+                if (pipelined) ctx.wait_for(up);
                 if (!is_coefficients(i)) {
                     std::size_t log_n = 0;
                     while (((std::size_t)1 << log_n) < db.len[i]) ++log_n;
@@ -435,7 +445,7 @@ private:
                 }
                 i = j;
             }
-            ctx.d2h(pt.res.data(), pt.d_res.get(), pt.res.size() * 8);    // synchronises this member's stream
+            ctx.d2h(pt.res.data(), pt.d_res.get(), pt.res.size() * 8);    // synchronises this member's stream (its upload stream has drained: every upload is a synchronous copy)
         };
         {
             std::vector<std::future<void>> others;
