@@ -38,6 +38,21 @@ def test_no_cpu_fallback(zk):
         zk.Context(0)
 
 
+def test_device_group_has_no_cpu_fallback_either(zk):
+    """zkhip_group_init without a HIP device: ZKHIP_ERR_NO_DEVICE, no handle -- the group is built from ordinary contexts and inherits their rule"""
+    lib = zk.load_library()
+    h = ctypes.c_void_p()
+    devs = (ctypes.c_int * 2)(0, 0)
+    rc = lib.zkhip_group_init(devs, 2, ctypes.byref(h))
+    if rc == 0:
+        lib.zkhip_group_destroy(h)
+        pytest.skip("a GPU is present: covered by tests/test_gpu_group.py")
+    assert rc == -1 and not h.value
+    assert lib.zkhip_group_init(devs, 0, ctypes.byref(h)) == -2      # no devices: invalid, whatever the box
+    with pytest.raises(zk.ZkhipError):
+        zk.DeviceGroup([0, 0])
+
+
 def test_product_does_not_reference_oracle():
     """The product path must not import, link or call anything under oracle/."""
     pkg = os.path.join(ROOT, "crypto3-zk_amd")
