@@ -834,16 +834,12 @@ private:
     }
 
     /// enqueue the whole device side of a proof on the context's stream (no synchronisation)
-    /// `staged`: (1, x, w) as canonical limbs in page-locked memory, when another member of a device group has converted the
-    /// assignment already (one asynchronous copy instead of a second conversion)
-    static void enqueue(const proving_key_type &pk, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input,
-                        const std::uint64_t *staged = nullptr) {
-        upload_assignment(pk, primary_input, auxiliary_input, staged);
+    static void enqueue(const proving_key_type &pk, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input) {
+        upload_assignment(pk, primary_input, auxiliary_input);
         enqueue_compute(pk, primary_input.size(), primary_input.size() + auxiliary_input.size());
     }
     /// the key's work buffers (first use) and const_padded_assignment = (1, x, w) on its way to d_cpa (asynchronous)
-    static void upload_assignment(const proving_key_type &pk, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input,
-                                  const std::uint64_t *staged = nullptr) {
+    static void upload_assignment(const proving_key_type &pk, const primary_input_type &primary_input, const auxiliary_input_type &auxiliary_input) {
         const context &ctx = pk.ctx;
         const std::size_t num_inputs = primary_input.size();
         const std::size_t num_variables = primary_input.size() + auxiliary_input.size();
@@ -860,9 +856,7 @@ private:
         /* the auxiliary input (almost all of the assignment) is converted into the page-locked staging buffer in
            slices by a few host threads, and every slice is sent as soon as it is ready: the conversion of slice k + 1
            overlaps the PCIe copy of slice k */
-        if (staged) {
-            check(zkhip_memcpy_h2d_async(ctx.get(), cpa, staged, 32 * (num_variables + 1)), "zkhip_memcpy_h2d_async", ctx.get());
-        } else if (detail::canonical_scalars<adapter>::value && pk.direct_assignment_upload) {
+        if (detail::canonical_scalars<adapter>::value && pk.direct_assignment_upload) {
             /* scalar values that ARE canonical limbs in memory: the auxiliary input goes out as it lies (0.3 ms per 2^20-constraint
                proof less than through the staging buffer) */
             static_assert(!detail::canonical_scalars<adapter>::value || sizeof(scalar_value_type) == 32, "canonical-limb scalars are 4 x u64");
