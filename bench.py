@@ -287,13 +287,14 @@ def main():
     if use_dist and not args.no_kzg:
         # BASELINE config 5's commitment leg: the 50 columns dealt over the ranks, one all-gather of the commitments
         kzg_sharded = kzg_sharded_leg(np, torch, dist, zk, ctx, rank, world, local_rank, log_n=args.kzg_log_rows, verify=not args.no_verify)
-    g16_group = None
+    g16_group, group_out = None, {}
     if use_dist and world > 1 and not args.no_groth16:
         # the SAME sharded proof as ONE process sees it: rank 0 drives a device group over all `world` GPUs (the drop-in class's own
         # multi-GPU path, the exchange inside libzkhip.so) while the other ranks wait on the host; their GPUs are idle then
         torch.cuda.synchronize()
         devs = [0] * world if args.same_device else list(range(world))
-        g16_group = dist.host_wait_for_rank0(rank, lambda: run_group_child(devs, ["groth16"], args, timeout=420).get("groth16_device_group"))
+        group_out = dist.host_wait_for_rank0(rank, lambda: run_group_child(devs, ["groth16"] + ([] if args.no_kzg else ["kzg"]), args, timeout=420)) or {}
+        g16_group = group_out.get("groth16_device_group")
     dist_info = None
     if use_dist:
         # evidence that the collective saw `world` DISTINCT devices: every rank reports the uuid of the GPU it runs on
@@ -385,6 +386,8 @@ def main():
             full["groth16_sharded"] = g16_sharded
         if g16_group is not None:
             full["groth16_device_group"] = g16_group
+        if use_dist and world > 1 and not args.no_groth16 and group_out.get("kzg_device_group"):
+            full["kzg_device_group"] = group_out["kzg_device_group"]
         if kzg_sharded is not None:
             full["kzg_sharded"] = kzg_sharded
         if ntt_sharded is not None:
@@ -519,8 +522,9 @@ def compact_line(full, detail_path):
     leg("kzg", "ms_per_commit_mean", "opening_proof_ms_mean")
     if (full.get("kzg") or {}).get("scheme_class"):
         legs["kzg_scheme_class_from_host"] = _pick(full["kzg"]["scheme_class"], "value", "unit", "verified")
-    if (full.get("kzg") or {}).get("device_group"):
-        legs["kzg_device_group"] = _pick(full["kzg"]["device_group"], "value", "unit", "verified", "members", "distinct_gpus", "error")
+    kg = (full.get("kzg") or {}).get("device_group") or full.get("kzg_device_group")
+    if kg:
+        legs["kzg_device_group"] = _pick(kg, "value", "unit", "verified", "members", "distinct_gpus", "error")
     leg("lpc", "proof_eval_ms")
     leg("quotient_chain")
     leg("gate_argument", "per_term_ms", "speedup_vs_per_term", "gate_eval_kernel_ms")

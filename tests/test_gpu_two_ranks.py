@@ -40,6 +40,8 @@ def test_two_ranks_point_split_and_sharded_legs(tmp_path):
     assert g["verified"] is True and len(g["ms_per_proof"]) >= 2
     k = detail["kzg_sharded"]
     assert k["verified"] is True and k["columns_per_rank"] == 25
+    kg = detail["kzg_device_group"]    # and rank 0's device group over the same two "GPUs" (one process, the drop-in scheme class): 50 columns dealt 25 / 25
+    assert kg["verified"] is True and kg["members"] == 2 and line["legs"]["kzg_device_group"]["verified"] is True
     t = detail["ntt_sharded"]    # BASELINE config 3's split: 8 polynomials dealt 4 / 4, no collective in the data path
     assert t["verified"] is True and t["polynomials_per_rank"] == 4 and t["scaling"] == "strong"
 
