@@ -1413,7 +1413,8 @@ def gate_argument_leg(np, log_n=20, n_gates=32, n_wit=24, steps=3, verify=True):
             "verification": "fused == per-term bit for bit; F(y) == mask(y) sum sel(y) sum c prod col(omega^rot y) at a random y from coefficient forms",
             "roofline": {"bound": "hbm", "kernel": "gate_eval", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                          "traffic": None, "algorithmic_bytes": alg,
-                         "honest_bound": "VALU: one Montgomery product per factor and row (no per-factor lift), %d products x ~3.5 factors x 8 n rows" % int(info[0])},
+                         "honest_bound": "VALU: one Montgomery product per factor and row (no per-factor lift), %d products x ~3.5 factors x 8 n rows; by PMC "
+                                         "(profiles/r06_pmc_gate.json, not re-measured in this run) 0.95 of the VALU issue capacity, 60.9 GB of HBM traffic per launch" % int(info[0])},
             "what": "both figures include the witness columns' extensions to 8 n (one per distinct COLUMN fused, one per distinct (column, rotation) pair per-term)"}
 
 

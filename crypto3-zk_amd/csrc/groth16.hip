@@ -307,7 +307,10 @@ int zkhip_r1cs_upload(zkhip_ctx *ctx, int curve, size_t num_constraints, size_t 
 
 void zkhip_r1cs_free(zkhip_ctx *ctx, zkhip_r1cs *r) {
     if (!r) return;
-    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
     for (int k = 0; k < 3; ++k) {
         (void)hipFree(r->rowptr[k]);
         (void)hipFree(r->col[k]);

@@ -17,7 +17,7 @@ res = {"command": "rocprofv3 --pmc <one group per pass> -- python3 " + cmd,
        "units": "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them (gfx950: x2 on FETCH_SIZE for 16-B-per-lane reads, see MI355X_MICROARCH.md)",
        "kernels": {}}
 for k in sorted(acc):
-    if not ("msm_" in k or "ntt_" in k or "r1cs" in k or "h_" in k or "bases_" in k or "jac" in k or "fri" in k or "poly" in k):
+    if not ("msm_" in k or "ntt_" in k or "r1cs" in k or "h_" in k or "bases_" in k or "jac" in k or "fri" in k or "poly" in k or "gate_" in k or "fr_vec" in k or "perm_" in k or "lookup" in k or "ls_" in k):
         continue
     res["kernels"][k] = {c: {"mean_per_launch": v[0] / max(1, len(v[1])), "launches": len(v[1])} for c, v in sorted(acc[k].items())}
     res["kernels"][k]["resources"] = regs[k]
