@@ -293,7 +293,7 @@ def main():
         # multi-GPU path, the exchange inside libzkhip.so) while the other ranks wait on the host; their GPUs are idle then
         torch.cuda.synchronize()
         devs = [0] * world if args.same_device else list(range(world))
-        group_out = dist.host_wait_for_rank0(rank, lambda: run_group_child(devs, ["groth16"] + ([] if args.no_kzg else ["kzg"]), args, timeout=420)) or {}
+        group_out = dist.host_wait_for_rank0(rank, lambda: run_group_child(devs, ["groth16"] + ([] if args.no_kzg else ["kzg", "lpc"]), args, timeout=420)) or {}
         g16_group = group_out.get("groth16_device_group")
     dist_info = None
     if use_dist:
@@ -376,7 +376,7 @@ def main():
             # exchange runs; on a one-GPU box they share device 0 and the leg is labelled an emulation)
             have = max(1, torch.cuda.device_count())
             group_members = list(range(have)) if have > 1 else [0, 0]
-            group_legs = ["groth16"] + ([] if args.no_kzg else ["kzg"])
+            group_legs = ["groth16"] + ([] if args.no_kzg else ["kzg", "lpc"])
             group_child_out = run_group_child(group_members, group_legs, args)
             full["groth16_device_group"] = group_child_out.get("groth16_device_group")
         if world == 1 and not args.no_other_msm:
@@ -388,6 +388,8 @@ def main():
             full["groth16_device_group"] = g16_group
         if use_dist and world > 1 and not args.no_groth16 and group_out.get("kzg_device_group"):
             full["kzg_device_group"] = group_out["kzg_device_group"]
+        if use_dist and world > 1 and not args.no_groth16 and group_out.get("lpc_device_group"):
+            full["lpc_device_group"] = group_out["lpc_device_group"]
         if kzg_sharded is not None:
             full["kzg_sharded"] = kzg_sharded
         if ntt_sharded is not None:
@@ -397,6 +399,8 @@ def main():
             if group_child_out is not None and group_child_out.get("kzg_device_group"):
                 full["kzg"]["device_group"] = group_child_out["kzg_device_group"]
             full["lpc"] = lpc_leg(np)
+            if group_child_out is not None and group_child_out.get("lpc_device_group"):
+                full["lpc_device_group"] = group_child_out["lpc_device_group"]
             full["quotient_chain"] = quotient_leg(np, verify=not args.no_verify)
             full["gate_argument"] = gate_argument_leg(np, verify=not args.no_verify)
             full["permutation_argument"] = permutation_leg(np, verify=not args.no_verify)
@@ -526,6 +530,7 @@ def compact_line(full, detail_path):
     if kg:
         legs["kzg_device_group"] = _pick(kg, "value", "unit", "verified", "members", "distinct_gpus", "error")
     leg("lpc", "proof_eval_ms")
+    leg("lpc_device_group", "members", "distinct_gpus", "leaf_owners")
     leg("quotient_chain")
     leg("gate_argument", "per_term_ms", "speedup_vs_per_term", "gate_eval_kernel_ms")
     leg("permutation_argument", "ms_grand_product")
@@ -1032,8 +1037,42 @@ def group_child(args):
                 raw = None
         out["kzg_device_group"] = kzg_group_leg(np, data, log_n, cols, raw, devices)
         out["kzg_device_group"]["verification"] = "all %d commitments equal the single-device scheme class's over the same columns (same process); the parent checks those against f(alpha) G" % cols
+    if "lpc" in legs:
+        out["lpc_device_group"] = lpc_group_leg(np, devices, verify=not args.no_verify)
     os.write(json_fd, (json.dumps(out, separators=(",", ":")) + "\n").encode())
     return 0
+
+
+def lpc_group_leg(np, devices, log_n=20, cols=16, steps=4, verify=True):
+    """The LPC commit of lpc_leg -- 16 polynomial_dfs of 2^20 rows from host memory, D[0] = 2^21, 1.07 GB of leaves to a streaming tree builder --
+    through lpc_commitment_scheme_hip over a DEVICE GROUP: the polynomials dealt over the members (own uploads, own extensions), the leaves cut by
+    range over the leaf owners (segments packed and pushed device to device, each owner's leaves over its own PCIe link), absorbed in leaf order."""
+    import ctypes
+
+    lib = _bench_lib()
+    ms = np.zeros(steps, dtype=np.float64)
+    root, owners = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    devs = (ctypes.c_int * len(devices))(*devices)
+    rc = lib.zkhip_bench_lpc_scheme_group(devs, len(devices), ctypes.c_size_t(log_n), ctypes.c_size_t(cols), ctypes.c_size_t(1), steps, 16,
+                                          ms.ctypes.data_as(ctypes.c_void_p), ctypes.byref(root), ctypes.byref(owners))
+    if rc != 0:
+        return {"error": rc}
+    single = None
+    if verify:  # one commit of the same seeded polynomials through the scheme on one context: the same position-weighted fold
+        ms1 = np.zeros(1, dtype=np.float64)
+        r1 = ctypes.c_uint64(0)
+        if lib.zkhip_bench_lpc_scheme(devices[0], ctypes.c_size_t(log_n), ctypes.c_size_t(cols), ctypes.c_size_t(1), 1, 1, 16, ms1.ctypes.data_as(ctypes.c_void_p),
+                                      ctypes.byref(r1)) == 0:
+            single = r1.value
+    distinct = len(set(devices))
+    return {"metric": "LPC commit through lpc_commitment_scheme_hip over a device group of %d member(s) on %d GPU(s), %d polynomial_dfs x 2^%d rows from HOST memory, "
+                      "domain 2^%d" % (len(devices), distinct, cols, log_n, log_n + 1),
+            "value": round(float(ms[1:].mean()) if steps > 1 else float(ms[0]), 2), "unit": "ms per commit", "higher_is_better": False, "scaling": "strong",
+            "ms_per_commit": [round(float(x), 2) for x in ms], "members": len(devices), "distinct_gpus": distinct, "leaf_owners": int(owners.value),
+            "verified": None if single is None else bool(single == root.value),
+            "verification": "the position-weighted fold over the leaves equals the single-context scheme's over the same polynomials (same process); the parent's "
+                            "cpu_baseline holds THAT fold against the oracle's leaf layout",
+            "what": "members on distinct GPUs" if distinct == len(devices) else "EMULATION: the members share %d GPU(s) -- the orchestration at work, not a speed-up" % distinct}
 
 
 def run_group_child(devices, legs, args, timeout=900):
@@ -1042,7 +1081,7 @@ def run_group_child(devices, legs, args, timeout=900):
     child is started the ordinary way, a new process, never an exec from this one)."""
     cmd = [sys.executable, os.path.abspath(__file__), "--group-child", ",".join(str(d) for d in devices), "--child-legs", ",".join(legs),
            "--log-constraints", str(args.log_constraints), "--kzg-log-rows", str(args.kzg_log_rows)] + (["--no-verify"] if args.no_verify else [])
-    names = {"groth16": "groth16_device_group", "kzg": "kzg_device_group"}
+    names = {"groth16": "groth16_device_group", "kzg": "kzg_device_group", "lpc": "lpc_device_group"}
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
         lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]

@@ -336,6 +336,52 @@ int zkhip_bench_lpc_scheme(int device, size_t log_n, size_t cols, size_t expand,
     }
 }
 
+/* The same commit through a scheme over a DEVICE GROUP (hip/lpc.hpp commit_group: polynomials dealt, segments pushed to the leaf owners, each
+ * owner's leaves over its own link), streaming builder, the same seeded polynomials: the fold must equal zkhip_bench_lpc_scheme's. */
+int zkhip_bench_lpc_scheme_group(const int *devices, int n_dev, size_t log_n, size_t cols, size_t expand, int steps, unsigned threads, double *ms, uint64_t *root,
+                                 uint64_t *owners) {
+    try {
+        const size_t n = (size_t)1 << log_n;
+        device_group grp(std::vector<int>(devices, devices + n_dev));
+        fri_params_hip<C> params;
+        params.log_domain = log_n + expand;
+        params.step_list.assign(log_n + expand - 4, 1);
+        params.root_of_unity = bls_root;
+        uint64_t seed = 5;
+        auto sm = [&seed]() {
+            uint64_t z = (seed += 0x9E3779B97F4A7C15ull);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return z ^ (z >> 31);
+        };
+        std::vector<polynomial_dfs<C>> polys(cols);
+        for (auto &p : polys) {
+            p.values.resize(n);
+            for (auto &v : p.values) {
+                uint64_t w[4] = {sm(), sm(), sm(), sm() & 0x0fffffffffffffffull};
+                v = A::scalar_from_limbs(w);
+            }
+        }
+        std::vector<std::reference_wrapper<const polynomial_dfs<C>>> lent(polys.begin(), polys.end());
+        streaming_fold_builder b;
+        b.threads = threads ? threads : 8;
+        lpc_commitment_scheme_hip<C, counting_transcript, streaming_fold_builder> scheme(grp, params, b);
+        uint64_t r = 0;
+        for (int rep = 0; rep < steps; ++rep) {
+            auto t0 = std::chrono::steady_clock::now();
+            scheme.append_to_batch(rep, lent);
+            r = scheme.commit(rep);
+            ms[rep] = ms_since(t0);
+        }
+        if (root) *root = r;
+        if (owners) *owners = scheme.last_leaf_owners();
+        return scheme.group_commits() == (std::size_t)steps || n_dev == 1 ? 0 : -2;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkhip_bench_lpc_scheme_group: %s\n", e.what());
+        return -1;
+    }
+}
+
 /* lpc_commitment_scheme_hip::proof_eval at size (lpc.hpp:113-200 up to and including the FRI commit phase, basic_fri.hpp:705-742): `cols`
  * polynomials of 2^log_n rows committed over D[0] = 2^(log_n + expand) (as zkhip_bench_lpc_scheme, streaming builder), every polynomial opened at
  * two points (y, y omega -- what placeholder asks of a witness column with a rotation); then proof_eval: the evaluations (block Horner over the

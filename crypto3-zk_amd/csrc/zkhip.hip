@@ -369,6 +369,15 @@ int zkhip_memcpy_d2d_async(zkhip_ctx *ctx, void *dst, const void *src, size_t by
     return ZKHIP_OK;
 }
 
+int zkhip_memcpy_2d_d2d_async(zkhip_ctx *ctx, void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width, size_t rows) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    if (width == 0 || rows == 0) return ZKHIP_OK;
+    if (!dst || !src || width > dst_pitch || width > src_pitch) return ZKHIP_ERR_INVALID;
+    ZK_TRY(check_device(ctx));
+    ZK_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width, rows, hipMemcpyDeviceToDevice, ctx->stream));
+    return ZKHIP_OK;
+}
+
 // ---- bases ------------------------------------------------------------------------------------------
 static int bases_alloc(zkhip_ctx *ctx, int curve, int group, size_t n, zkhip_bases **out) {
     if ((curve != CURVE_BLS12_381 && curve != CURVE_BN254) || (group != GROUP_G1 && group != GROUP_G2)) return ZKHIP_ERR_INVALID;

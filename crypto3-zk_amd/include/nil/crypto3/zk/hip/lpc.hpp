@@ -27,20 +27,29 @@
 //           proof_eval<FRI> (basic_fri.hpp:747-930: lambda Merkle openings at transcript-derived indices) reads only
 //           trees and a few evaluations and is left to the caller, who finds everything it needs through
 //           trees() / fri_trees() / fri_round_polynomial(i) / fri_alphas().
+//
+// Over a device group (constructor taking a device_group): commit(batch) deals the batch's polynomials over the members -- uploads over
+// their own PCIe links, extensions on their own GPUs --, then the path's one exchange: the leaf range of every LEAF OWNER (the first 2^k
+// members) is made of 2^fri_step segments of every polynomial, which the members pack and push to the owners; each owner lays out ITS
+// leaves and sends them to the host over ITS link while the caller hashes.  Same leaves, same order, same roots as on one device; the
+// coefficient forms are gathered on member 0, where proof_eval runs as before.  See commit_group.
 //---------------------------------------------------------------------------//
 #ifndef ZKHIP_SHIM_LPC_HPP
 #define ZKHIP_SHIM_LPC_HPP
 
 #include <algorithm>
+#include <array>
 #include <cstdlib>
 #include <cstdio>
 #include <chrono>
 #include <deque>
 #include <functional>
+#include <future>
 #include <iterator>
 #include <map>
 #include <memory>
 #include <set>
+#include <thread>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -137,6 +146,13 @@ public:
         if (fri_params.step_list.empty() || r > fri_params.log_domain) throw std::invalid_argument("lpc: step_list does not fit the domain");
     }
 
+    /// the scheme over a device group: commit(batch) spreads over the members (commit_group), everything else runs on member 0
+    lpc_commitment_scheme_hip(const device_group &group, const params_type &fri_params, TreeBuilder builder) :
+        lpc_commitment_scheme_hip(group.root(), fri_params, std::move(builder)) {
+        _group = &group;
+        _gs.reset(new group_scratch[group.size()]);
+    }
+
     const params_type &get_commitment_params() const { return _fri_params; }
 
     /// lpc.hpp:82-96: the fixed batches' polynomials evaluated at etha
@@ -191,6 +207,7 @@ public:
 
     /// commit(index) (lpc.hpp:101-106): precommit<FRI>(polys, D[0], step_list.front()) -> the tree's root
     commitment_type commit(std::size_t index) {
+        if (_group && _group->size() > 1 && !_polys[index].empty()) return commit_group(index);
         ZKHIP_PROFILE_SCOPE("Basic FRI Precommit time");    // commit = precommit<FRI> + root (lpc.hpp:101-106; the scope of basic_fri.hpp:449)
         const std::vector<const poly_type *> &polys = _polys[index];
         _locked[index] = true;    // state_commited (batched_commitment.hpp:163-166)
@@ -235,10 +252,157 @@ public:
         return _trees.at(index).root();
     }
 
+    /// commits that ran over the device group, and over how many leaf owners the last one cut its leaves (tests and logs)
+    std::size_t group_commits() const { return _group_commits; }
+    std::size_t last_leaf_owners() const { return _last_owners; }
+
     /// polynomials per upload chunk of commit() (0: the whole batch in one transfer)
     std::size_t upload_chunk = 4;
     /// elements per slice handed to a streaming tree builder (rounded up to whole leaves)
     std::size_t leaf_slice_elements = (std::size_t)1 << 21;
+
+    /// commit(index) over the device group.  Member k takes the k-th contiguous range of the batch's polynomials: its host thread uploads them
+    /// over the member's own link (chunked, a second in-order stream, as on one device) and extends them to D[0] on the member's GPU.  The
+    /// leaves are then cut by RANGE over the first 2^k members (the leaf owners): leaf x reads, of every polynomial, the positions
+    /// x + j D / 2^step (fri_leaf_gather, poly.hip), so an owner's L = D / 2^step / owners consecutive leaves read 2^step segments of L
+    /// consecutive evaluations per polynomial -- packed side by side they ARE the evaluations over a domain of D / owners points as far as the
+    /// leaf layout is concerned (segment j of the small domain is segment j of the large one), and the owner runs the ordinary leaf kernel on
+    /// them.  The exchange: every member packs, per owner, the segments of its polynomials (one strided copy) and pushes the block into the
+    /// owner's buffer (zkhip_group_copy: ordered after the extension on the source's stream, on the owner's stream); owners x members
+    /// copies of count / members x D / owners elements each.  Each owner then sends its leaves to the host over its own link while the
+    /// caller hashes.  The coefficient forms the extension leaves behind are gathered on member 0 for proof_eval.
+    commitment_type commit_group(std::size_t index) {
+        ZKHIP_PROFILE_SCOPE("Basic FRI Precommit time");
+        const device_group &group = *_group;
+        const std::vector<const poly_type *> &polys = _polys[index];
+        _locked[index] = true;
+        _points[index].resize(polys.size());
+        device_batch db;
+        std::size_t total = 0;
+        for (const poly_type *p : polys) {
+            if (p->size() == 0 || (p->size() & (p->size() - 1)) || p->size() > domain_size(0)) throw std::runtime_error("lpc commit: bad polynomial size");
+            db.offset.push_back(total);
+            db.len.push_back(p->size());
+            total += p->size();
+        }
+        db.data = _ctx.alloc(std::max<std::size_t>(1, total) * 32);
+        const std::size_t D = domain_size(0), count = polys.size(), world = group.size(), step = _fri_params.step_list.front();
+        std::size_t log_owners = 0;    // owners: a power of two (the compact domain is one), every owner with at least one leaf
+        while (((std::size_t)2 << log_owners) <= world && _fri_params.log_domain >= step + log_owners + 1) ++log_owners;
+        const std::size_t owners = (std::size_t)1 << log_owners, Ds = D >> log_owners, seg = Ds >> step, rows_per_poly = (std::size_t)1 << step;
+        struct part {
+            std::size_t lo = 0, hi = 0, elems = 0;
+            std::shared_ptr<void> data;    // the member's own coefficient buffer (member 0 works in the batch buffer itself)
+            char *base = nullptr;
+        };
+        std::vector<part> parts(world);
+        for (std::size_t k = 0; k < world; ++k) {
+            part &pt = parts[k];
+            pt.lo = count / world * k + std::min(k, count % world);
+            pt.hi = count / world * (k + 1) + std::min(k + 1, count % world);
+            group_scratch &gs = _gs[k];
+            if (k < owners) {
+                grow(group[k], gs.cmp, gs.cmp_cap, count * Ds * 32);
+                grow(group[k], gs.leaves, gs.leaves_cap, count * Ds * 32);
+            }
+            if (pt.hi == pt.lo) continue;
+            pt.elems = (pt.hi < count ? db.offset[pt.hi] : total) - db.offset[pt.lo];
+            if (k == 0) pt.base = static_cast<char *>(db.at(pt.lo));
+            else {
+                pt.data = group[k].alloc(pt.elems * 32);
+                pt.base = static_cast<char *>(pt.data.get());
+            }
+            grow(group[k], gs.ext, gs.ext_cap, (pt.hi - pt.lo) * D * 32);
+            grow(group[k], gs.send, gs.send_cap, (pt.hi - pt.lo) * D * 32);    // owners blocks of (hi - lo) * Ds
+        }
+        /* the caller's root-of-unity function is called from THIS thread only: one root per distinct size, up front */
+        std::map<std::size_t, std::array<std::uint64_t, 4>> root_limbs;
+        adapter::scalar_to_limbs(_fri_params.root_of_unity(_fri_params.log_domain), root_limbs[_fri_params.log_domain].data());
+        for (std::size_t i = 0; i < count; ++i) {
+            const std::size_t log_n = log2_of(db.len[i]);
+            if (!root_limbs.count(log_n)) adapter::scalar_to_limbs(_fri_params.root_of_unity(log_n), root_limbs[log_n].data());
+        }
+        auto member_work = [&](std::size_t k) {
+            part &pt = parts[k];
+            if (pt.hi == pt.lo) return;
+            const context &ctx = group[k];
+            group_scratch &gs = _gs[k];
+            const std::size_t mine = pt.hi - pt.lo;
+            auto at = [&](std::size_t p) { return pt.base + 32 * (db.offset[p] - db.offset[pt.lo]); };
+            const bool pipelined = upload_chunk != 0 && mine > upload_chunk;
+            if (pipelined && !gs.up) gs.up.reset(new context(ctx.device()));
+            const context &up = pipelined ? *gs.up : ctx;
+            char *d_ext = static_cast<char *>(gs.ext.get());
+            for (std::size_t i = pt.lo; i < pt.hi;) {
+                std::size_t j = i;
+                while (j < pt.hi && db.len[j] == db.len[i] && (upload_chunk == 0 || j - i < upload_chunk)) ++j;
+                for (std::size_t p = i; p < j; ++p) upload_scalars<adapter>(up, at(p), detail::poly_data<adapter>(*polys[p]), polys[p]->size());
+                if (pipelined) ctx.wait_for(up);
+                const std::size_t log_n = log2_of(db.len[i]);
+                check(zkhip_poly_resize_dev(ctx.get(), adapter::id, at(i), log_n, j - i, root_limbs.at(log_n).data(), d_ext + 32 * (i - pt.lo) * D,
+                                            _fri_params.log_domain, root_limbs.at(_fri_params.log_domain).data()),
+                      "zkhip_poly_resize_dev", ctx.get());
+                i = j;
+            }
+            /* per owner: the 2^step segments [d seg + j D / 2^step, + seg) of each of my polynomials, side by side (rows of seg elements at a
+               pitch of D / 2^step in, seg out) -- straight into my own buffer where I am the owner */
+            for (std::size_t d = 0; d < owners; ++d) {
+                char *dst = d == k ? static_cast<char *>(gs.cmp.get()) + 32 * pt.lo * Ds : static_cast<char *>(gs.send.get()) + 32 * d * mine * Ds;
+                check(zkhip_memcpy_2d_d2d_async(ctx.get(), dst, seg * 32, d_ext + 32 * d * seg, (D >> step) * 32, seg * 32, mine * rows_per_poly),
+                      "zkhip_memcpy_2d_d2d_async", ctx.get());
+            }
+        };
+        {
+            std::vector<std::future<void>> others;
+            for (std::size_t k = 1; k < world; ++k)
+                if (parts[k].hi != parts[k].lo) others.push_back(std::async(std::launch::async, member_work, k));
+            std::exception_ptr failed;
+            try {
+                member_work(0);
+            } catch (...) {
+                failed = std::current_exception();
+            }
+            for (auto &o : others) {
+                try {
+                    o.get();
+                } catch (...) {
+                    if (!failed) failed = std::current_exception();
+                }
+            }
+            if (failed) {
+                try {
+                    group.sync();    // nothing of this batch may still be running on buffers that are about to go
+                } catch (...) {
+                }
+                std::rethrow_exception(failed);
+            }
+        }
+        /* the exchange, from this thread: blocks to their owners, coefficient forms to member 0 */
+        for (std::size_t k = 0; k < world; ++k) {
+            const part &pt = parts[k];
+            if (pt.hi == pt.lo) continue;
+            const std::size_t mine = pt.hi - pt.lo;
+            for (std::size_t d = 0; d < owners; ++d)
+                if (d != k)
+                    group.copy(d, static_cast<char *>(_gs[d].cmp.get()) + 32 * pt.lo * Ds, k, static_cast<const char *>(_gs[k].send.get()) + 32 * d * mine * Ds,
+                               mine * Ds * 32);
+            if (k != 0) group.copy(0, db.at(pt.lo), k, pt.base, pt.elems * 32);
+        }
+        std::vector<const void *> d_leaves(owners);
+        for (std::size_t d = 0; d < owners; ++d) {
+            check(zkhip_fri_leaves_dev(group[d].get(), _gs[d].cmp.get(), _fri_params.log_domain - log_owners, count, step, _gs[d].leaves.get()),
+                  "zkhip_fri_leaves_dev", group[d].get());
+            d_leaves[d] = _gs[d].leaves.get();
+        }
+        _trees.erase(index);
+        _trees.emplace(index, build_tree_group(d_leaves, count * Ds, count * rows_per_poly));
+        group.sync();    // the members' own coefficient buffers go with `parts`: every copy out of them has finished
+        ++_group_commits;
+        _last_owners = owners;
+        _dev[index] = std::move(db);
+        _polys[index].clear();    // no pointer to a lent polynomial outlives the call
+        return _trees.at(index).root();
+    }
 
     /// proof_eval (lpc.hpp:113-200) up to and including the FRI commit phase (basic_fri.hpp:705-742)
     proof_type proof_eval(transcript_type &transcript) {
@@ -442,6 +606,55 @@ protected:
             return _builder(_leaf_vec, per_leaf);
         }
     }
+    /// the same tree from leaves that lie in `d_leaves.size()` consecutive blocks of `block` elements, block d on member d of the group: every
+    /// owner's first slice is requested at once and its link stays one slice ahead of the caller, who absorbs the blocks in leaf order
+    precommitment_type build_tree_group(const std::vector<const void *> &d_leaves, std::size_t block, std::size_t per_leaf) const {
+        const device_group &group = *_group;
+        const std::size_t owners = d_leaves.size(), total = owners * block;
+        if constexpr (builder_kind == detail::tree_builder_kind::streaming) {
+            const std::size_t slice = std::max<std::size_t>(1, (leaf_slice_elements + per_leaf - 1) / std::max<std::size_t>(1, per_leaf)) * std::max<std::size_t>(1, per_leaf);
+            const std::size_t first = std::min(slice, block);
+            _builder.begin(total, per_leaf);
+            for (std::size_t d = 0; d < owners; ++d) {
+                void *p0 = _gs[d].pin[0].reserve(group[d], first * 32);
+                _gs[d].pin[1].reserve(group[d], first * 32);
+                group[d].d2h_async(p0, d_leaves[d], first * 32);
+            }
+            for (std::size_t d = 0; d < owners; ++d) {
+                const char *src = static_cast<const char *>(d_leaves[d]);
+                void *pin[2] = {_gs[d].pin[0].get(), _gs[d].pin[1].get()};
+                group[d].sync();
+                for (std::size_t at = 0, k = 0; at < block; at += slice, ++k) {
+                    const std::size_t cnt = std::min(slice, block - at), next = at + slice;
+                    if (next < block) group[d].d2h_async(pin[(k + 1) & 1], src + 32 * next, std::min(slice, block - next) * 32);
+                    _builder.absorb(host_values(pin[k & 1], cnt), d * block + at, cnt);
+                    group[d].sync();
+                }
+            }
+            return _builder.finish();
+        } else {
+            /* one page-locked buffer for all leaves (portable: every member's copy engine may write it), the owners' downloads side by side */
+            char *pin = static_cast<char *>(_pin[0].reserve(_ctx, std::max<std::size_t>(1, total) * 32));
+            for (std::size_t d = 0; d < owners; ++d) group[d].d2h_async(pin + 32 * d * block, d_leaves[d], block * 32);
+            for (std::size_t d = 0; d < owners; ++d) group[d].sync();
+            const value_type *values = host_values(pin, total);
+            if constexpr (builder_kind == detail::tree_builder_kind::span) return _builder(values, total, per_leaf);
+            else {
+                _leaf_vec.assign(values, values + total);
+                return _builder(_leaf_vec, per_leaf);
+            }
+        }
+    }
+    /// a member's device buffer that grows on demand and is kept across commits
+    static void *grow(const context &ctx, std::shared_ptr<void> &buf, std::size_t &cap, std::size_t bytes) {
+        if (bytes > cap) {
+            ctx.sync();
+            buf.reset();
+            buf = ctx.alloc(bytes);
+            cap = bytes;
+        }
+        return buf.get();
+    }
     /// `count` canonical 32-byte elements in host memory as scalar-field values: in place when the scalar type IS four canonical
     /// limbs, through a converted copy (host threads) otherwise
     const value_type *host_values(const void *limbs, std::size_t count) const {
@@ -538,7 +751,17 @@ protected:
         return result;
     }
 
+    /// per member of the group, kept across commits: extensions, blocks to send, the owner's compact evaluations and its leaves
+    struct group_scratch {
+        std::shared_ptr<void> ext, send, cmp, leaves;
+        std::size_t ext_cap = 0, send_cap = 0, cmp_cap = 0, leaves_cap = 0;
+        pinned_buffer pin[2];
+        std::unique_ptr<context> up;    // the member's upload stream
+    };
     const context &_ctx;
+    const device_group *_group = nullptr;
+    std::size_t _group_commits = 0, _last_owners = 0;
+    mutable std::unique_ptr<group_scratch[]> _gs;    // an array: the page-locked buffers neither copy nor move
     params_type _fri_params;
     mutable TreeBuilder _builder;
     value_type _etha;

@@ -14,7 +14,7 @@ _FQ = {BLS12_381: 6, BN254: 4}
 
 EXPORTS = [
     "zkhip_init", "zkhip_destroy", "zkhip_strerror", "zkhip_last_error", "zkhip_set_stream", "zkhip_sync", "zkhip_device_status", "zkhip_stream_wait", "zkhip_device",
-    "zkhip_set_option", "zkhip_get_option", "zkhip_malloc", "zkhip_free", "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_memcpy_h2d_async", "zkhip_memcpy_d2h_async", "zkhip_memcpy_d2d_async", "zkhip_host_alloc", "zkhip_host_free",
+    "zkhip_set_option", "zkhip_get_option", "zkhip_malloc", "zkhip_free", "zkhip_memcpy_h2d", "zkhip_memcpy_d2h", "zkhip_memcpy_h2d_async", "zkhip_memcpy_d2h_async", "zkhip_memcpy_d2d_async", "zkhip_memcpy_2d_d2d_async", "zkhip_host_alloc", "zkhip_host_free",
     "zkhip_bases_upload", "zkhip_bases_upload_compressed", "zkhip_bases_from_scalars", "zkhip_bases_spread", "zkhip_bases_download", "zkhip_bases_size",
     "zkhip_bases_free", "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_batch_dev", "zkhip_jacobian_sum_dev", "zkhip_jacobian_to_affine", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_domain_choice", "zkhip_domain_fft_dev", "zkhip_domain_lagrange_dev",

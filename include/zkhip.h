@@ -98,6 +98,10 @@ int zkhip_memcpy_d2h_async(zkhip_ctx *ctx, void *dst, const void *src, size_t by
 /* page-locked host memory: H2D / D2H at link speed instead of through a staging copy */
 /* device-to-device copy in stream order (no synchronisation) */
 int zkhip_memcpy_d2d_async(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* the strided form, same device, stream order: `rows` rows of `width` bytes, row r from src + r * src_pitch to dst + r * dst_pitch
+ * (width <= both pitches; the two regions must not overlap).  What the LPC shim over a device group packs a member's share of the
+ * evaluations with: the 2^fri_step segments of every polynomial that one leaf owner's leaves are made of (hip/lpc.hpp). */
+int zkhip_memcpy_2d_d2d_async(zkhip_ctx *ctx, void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width, size_t rows);
 int zkhip_host_alloc(zkhip_ctx *ctx, size_t bytes, void **hptr);
 int zkhip_host_free(zkhip_ctx *ctx, void *hptr);
 

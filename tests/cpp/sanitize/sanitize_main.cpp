@@ -273,6 +273,28 @@ void scheme_host_paths() {
     run_lpc(vec_builder<Fr>());
     run_lpc(span_builder<Fr>());
     run_lpc(stream_builder<Fr>());
+    /* the same over a device group: one host thread per member with polynomials, the exchange, leaves by owner */
+    auto run_lpc_group = [&](auto builder, std::size_t world) {
+        device_group grp(std::vector<int>(world, 0));
+        lpc_commitment_scheme_hip<Curve, any_transcript, decltype(builder)> s(grp, fp, builder);
+        s.upload_chunk = 1;
+        s.leaf_slice_elements = 700;
+        std::vector<std::reference_wrapper<const polynomial_dfs<Curve>>> lent(polys.begin(), polys.end());
+        s.append_to_batch(0, lent);
+        (void)s.commit(0);
+        s.append_to_batch(1, polys[5]);
+        (void)s.commit(1);
+        EXPECT(s.group_commits() == 2);
+        s.append_eval_point(0, Fr(9));
+        s.append_eval_point(1, Fr(9));
+        any_transcript tr;
+        auto proof = s.proof_eval(tr);
+        EXPECT(proof.fri_proof.fri_roots.size() == 3);
+        (void)s.coefficients(0, 1);
+    };
+    run_lpc_group(vec_builder<Fr>(), 2);
+    run_lpc_group(span_builder<Fr>(), 3);
+    run_lpc_group(stream_builder<Fr>(), 9);
 }
 
 /// the host logic of placeholder's arguments and quotient chain over the stub backend (device buffers are host memory the stub only sizes and

@@ -77,6 +77,11 @@ int zkhip_memcpy_d2d_async(zkhip_ctx *, void *dst, const void *src, size_t bytes
     memmove(dst, src, bytes);
     return ZKHIP_OK;
 }
+int zkhip_memcpy_2d_d2d_async(zkhip_ctx *, void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width, size_t rows) {
+    if (width > dst_pitch || width > src_pitch) return ZKHIP_ERR_INVALID;
+    for (size_t r = 0; r < rows; ++r) memcpy(static_cast<char *>(dst) + r * dst_pitch, static_cast<const char *>(src) + r * src_pitch, width);
+    return ZKHIP_OK;
+}
 int zkhip_host_alloc(zkhip_ctx *, size_t bytes, void **hptr) {
     *hptr = malloc(bytes ? bytes : 1);
     return *hptr ? ZKHIP_OK : ZKHIP_ERR_OOM;

@@ -1154,7 +1154,16 @@ int lpc_scheme_run(const uint64_t *evals, size_t npolys, const uint64_t *log_n, 
     }
     typedef lpc_commitment_scheme_hip<Curve, scripted_any_transcript<Curve>, Builder> scheme_type;
     static_assert(scheme_type::is_lpc(), "placeholder branches on is_lpc()");
-    scheme_type scheme(ctx, fp, Builder());
+    /* g_world > 1: THE SAME SCHEME OVER A DEVICE GROUP (members dealt over the box's GPUs): commit(batch) spreads over the members, the
+       leaves come back in ranges over the leaf owners' links, everything after runs on member 0 -- the same roots, evaluations, rounds */
+    std::unique_ptr<device_group> grp;
+    if (g_world > 1) {
+        std::vector<int> devices;
+        for (int k = 0; k < g_world; ++k) devices.push_back(k % g_gpus);
+        grp.reset(new device_group(devices));
+        if (g_lpc_builder == 1) grp->set_transport(ZKHIP_GROUP_STAGED);    // one of the three builder shapes takes the host-staged exchange
+    }
+    scheme_type scheme = grp ? scheme_type(*grp, fp, Builder()) : scheme_type(ctx, fp, Builder());
     if (g_lpc_builder == 2) {
         scheme.leaf_slice_elements = g_lpc_slice;
         scheme.upload_chunk = 1;
@@ -1182,9 +1191,79 @@ int lpc_scheme_run(const uint64_t *evals, size_t npolys, const uint64_t *log_n, 
     out_counts[3] = tr.next;        // challenges drawn
     out_counts[4] = tr.absorbed;    // roots absorbed
     out_counts[5] = scheme.fri_trees().size() + 100 * scheme.fri_alphas().size() + 10000 * scheme.trees().size();
+    if (scheme.group_commits() != (g_world > 1 ? 2u : 0u)) return -9;    // both batches went over the group when there is one
     /* what the caller's query phase reads must be there: round polynomials and coefficient forms */
     if (scheme.fri_round_polynomial(0).size() != ((size_t)1 << log_domain)) return -7;
     if (scheme.coefficients(1, 0).size() != polys[2].size()) return -8;
+    return 0;
+}
+
+/// lpc_commitment_scheme_hip::commit(batch) with a tree builder that KEEPS the leaves it is handed (streaming shape: slices of whole leaves, in
+/// order): the leaf layout of the scheme itself -- over g_world members of a device group when g_world > 1 -- against the oracle's leaves.
+template <typename Curve>
+struct capture_tree {
+    typedef typename curve_adapter<Curve>::scalar_value_type Fr;
+    Fr r;
+    const Fr &root() const { return r; }
+};
+template <typename Curve>
+struct capture_streaming_builder {
+    typedef curve_adapter<Curve> A;
+    typedef typename A::scalar_value_type Fr;
+    uint64_t *out = nullptr;
+    std::size_t seen = 0, per = 0;
+    bool ordered = true;
+    void begin(std::size_t, std::size_t per_leaf) {
+        seen = 0;
+        per = per_leaf;
+        ordered = true;
+    }
+    void absorb(const Fr *leaves, std::size_t first, std::size_t count) {
+        if (first != seen || (per && (first % per || count % per))) ordered = false;
+        for (std::size_t i = 0; i < count; ++i) A::scalar_to_limbs(leaves[i], out + 4 * (first + i));
+        seen += count;
+    }
+    capture_tree<Curve> finish() {
+        capture_tree<Curve> t;
+        t.r = Fr((std::uint64_t)(ordered ? seen : 0));
+        return t;
+    }
+};
+template <typename Curve>
+int lpc_commit_leaves_t(const uint64_t *evals, size_t npolys, const uint64_t *log_n, size_t log_domain, size_t fri_step, size_t slice, uint64_t *out) {
+    typedef curve_adapter<Curve> A;
+    typedef lpc_commitment_scheme_hip<Curve, scripted_any_transcript<Curve>, capture_streaming_builder<Curve>> scheme_type;
+    const auto fp = fri_params_hip<Curve>::standard(log_domain, std::vector<std::size_t> {fri_step});
+    capture_streaming_builder<Curve> b;
+    b.out = out;
+    std::vector<polynomial_dfs<Curve>> polys(npolys);
+    size_t at = 0;
+    for (size_t p = 0; p < npolys; ++p)
+        for (size_t i = 0; i < ((size_t)1 << log_n[p]); ++i) polys[p].values.push_back(A::scalar_from_limbs(evals + 4 * at++));
+    context ctx(0);
+    std::unique_ptr<device_group> grp;
+    if (g_world > 1) {
+        std::vector<int> devices;
+        for (int k = 0; k < g_world; ++k) devices.push_back(k % g_gpus);
+        grp.reset(new device_group(devices));
+    }
+    scheme_type scheme = grp ? scheme_type(*grp, fp, b) : scheme_type(ctx, fp, b);
+    scheme.leaf_slice_elements = slice;
+    for (int rep = 0; rep < 2; ++rep) {    // twice: the second batch reuses every kept buffer
+        std::vector<std::reference_wrapper<const polynomial_dfs<Curve>>> lent(polys.begin(), polys.end());
+        scheme.append_to_batch(rep, lent);
+        const auto root = scheme.commit(rep);
+        if (!(root == typename A::scalar_value_type((std::uint64_t)(npolys << log_domain)))) return -40 - rep;    // every element, in order, whole leaves
+        /* the coefficient forms proof_eval reads are on member 0 */
+        const auto c = scheme.coefficients(rep, npolys - 1);
+        if (c.size() != polys[npolys - 1].size()) return -50;
+    }
+    /* the group path is the one that ran: both commits, over the largest power of two of members that still leaves every owner a leaf */
+    if (g_world > 1) {
+        std::size_t owners = 1;
+        while (2 * owners <= (std::size_t)g_world && 2 * owners <= ((std::size_t)1 << (log_domain - fri_step))) owners *= 2;
+        if (scheme.group_commits() != 2 || scheme.last_leaf_owners() != owners) return -60;
+    } else if (scheme.group_commits() != 0) return -61;
     return 0;
 }
 
@@ -2108,6 +2187,10 @@ int shim_groth16_generate_prove(int curve, size_t M, size_t n, size_t N, const u
 int shim_precommit_leaves(int curve, const uint64_t *evals, size_t npolys, const uint64_t *log_n, size_t log_domain, size_t fri_step,
                           const uint64_t *roots, uint64_t *out) {
     CURVE_CALL("shim_precommit_leaves", precommit_leaves_t, evals, npolys, log_n, log_domain, fri_step, roots, out)
+}
+
+int shim_lpc_commit_leaves(int curve, const uint64_t *evals, size_t npolys, const uint64_t *log_n, size_t log_domain, size_t fri_step, size_t slice, uint64_t *out) {
+    CURVE_CALL("shim_lpc_commit_leaves", lpc_commit_leaves_t, evals, npolys, log_n, log_domain, fri_step, slice, out)
 }
 
 int shim_gate_argument(int curve, const uint64_t *evals, size_t ncols, size_t log_n, const uint64_t *degrees, const uint64_t *mask_evals, size_t mask_degree,

@@ -1224,20 +1224,28 @@ def _toy_root(r):
     return lambda leaves, per_leaf: (per_leaf + sum((i + 1) * v for i, v in enumerate(leaves))) % r
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
 @pytest.mark.parametrize("builder", ["vector", "span", "streaming"])
 @pytest.mark.parametrize("curve,log_domain,steps", [(0, 8, [1, 2]), (1, 7, [2, 1, 1]), (0, 7, [3])])
-def test_lpc_scheme_shim(shim, curve, log_domain, steps, builder):
+def test_lpc_scheme_shim(shim, curve, log_domain, steps, builder, world):
     """lpc_commitment_scheme_hip driven through the consumer contract placeholder has with its commitment scheme (fixed batch,
     preprocess / setup, two batches, ragged point sets): commit roots, evaluations, FRI round roots and the final polynomial
     against po.lpc_proof_eval (lpc.hpp:101-200 + basic_fri.hpp:433-496, 705-742); the Merkle tree is a toy functor on both sides.
     builder: the three shapes of the caller's tree builder -- a std::vector of leaves, a span over page-locked memory, and slices
     of whole leaves absorbed while the next slice is in flight (64-element slices, one polynomial per upload chunk, the second
-    batch LENT to the scheme instead of copied)."""
+    batch LENT to the scheme instead of copied).
+    world > 1: the scheme over a DEVICE GROUP of that many members (hip/lpc.hpp commit_group: the polynomials dealt, the leaves cut by range
+    over the leaf owners -- the first 1, 2 or 4 members --, the coefficient forms gathered on member 0): the same roots, evaluations, rounds.
+    Two polynomials per batch: at world 3 and 8 some members hold leaves but no polynomial."""
+    import torch
     shim.shim_set_lpc_builder({"vector": 0, "span": 1, "streaming": 2}[builder])
+    shim.shim_set_world(world)
+    shim.shim_set_gpus(max(1, torch.cuda.device_count()))
     try:
         _lpc_scheme_shim(shim, curve, log_domain, steps)
     finally:
         shim.shim_set_lpc_builder(0)
+        shim.shim_set_world(1)
 
 
 def _lpc_scheme_shim(shim, curve, log_domain, steps):
@@ -1291,15 +1299,64 @@ def test_precommit_leaves_full_size_16_columns(shim):
                                     ctypes.c_size_t(fri_step), P(roots), P(out))
     assert rc == 0
     assert out.shape == want.shape and np.array_equal(out, want)
+    # the same leaves through the SCHEME's commit over a device group of four members (16 polynomials dealt four each, four leaf owners,
+    # slices of 2^21 elements absorbed in order) -- and over one context, for the record
+    import torch
+    for world in (4, 1):
+        out[:] = 0
+        shim.shim_set_world(world)
+        shim.shim_set_gpus(max(1, torch.cuda.device_count()))
+        try:
+            rc = shim.shim_lpc_commit_leaves(curve, P(evals.reshape(-1, 4)), ctypes.c_size_t(cols), P(np.full(cols, log_n, dtype=np.uint64)), ctypes.c_size_t(log_n + 1),
+                                             ctypes.c_size_t(fri_step), ctypes.c_size_t(1 << 21), P(out))
+        finally:
+            shim.shim_set_world(1)
+        assert rc == 0, world
+        assert np.array_equal(out, want), world
 
 
+@pytest.mark.parametrize("curve,logs,log_domain,fri_step,world,slice_elems", [
+    (0, [6, 6, 7, 7, 7], 9, 1, 2, 40), (0, [6, 6, 7, 7, 7], 9, 3, 4, 1 << 20), (1, [8] * 7, 10, 2, 3, 7 * 4 * 5), (1, [5], 8, 4, 8, 16),
+    (0, [10] * 9 + [11] * 4, 12, 1, 8, 13 * 2 * 100), (0, [4, 4, 4], 4, 4, 4, 1), (1, [13] * 6, 15, 2, 5, 1 << 14), (0, [7, 7], 7, 1, 1, 64)])
+def test_lpc_commit_leaves_over_group(shim, curve, logs, log_domain, fri_step, world, slice_elems):
+    """The leaves lpc_commitment_scheme_hip::commit hands to a streaming tree builder -- over a device group of `world` members (hip/lpc.hpp
+    commit_group: polynomials dealt, segments packed and pushed to the leaf owners, each owner's range laid out by the ordinary leaf kernel on its
+    compact domain) -- against the oracle's precommit leaves (inverse transform, zero padding, forward transform on D[0], fri_leaves): ragged
+    batches (runs of two sizes), more members than polynomials, a single leaf (log_domain == fri_step: one owner), no extension (size == D),
+    slices that cut the owners' ranges unevenly.  Twice per scheme: the second batch reuses every kept buffer."""
+    import torch
+    C = CURVES[curve]
+    D = 1 << log_domain
+    evals = [cp.random_fr(curve, 5200 + i + log_domain, 1 << l) for i, l in enumerate(logs)]
+    ext = []
+    for e, l in zip(evals, logs):
+        c = cp.ntt(curve, e.reshape(1, -1, 4), l, limbs(C.root_of_unity(l), 4), inverse=True)[0]
+        big = np.zeros((1, D, 4), dtype=np.uint64)
+        big[0, : 1 << l] = c
+        ext.append(cp.ntt(curve, big, log_domain, limbs(C.root_of_unity(log_domain), 4))[0])
+    want = cp.fri_leaves(ext, fri_step)
+    out = np.zeros((len(logs) * D, 4), dtype=np.uint64)
+    shim.shim_set_world(world)
+    shim.shim_set_gpus(max(1, torch.cuda.device_count()))
+    try:
+        rc = shim.shim_lpc_commit_leaves(curve, P(np.concatenate(evals)), ctypes.c_size_t(len(logs)), P(np.array(logs, dtype=np.uint64)), ctypes.c_size_t(log_domain),
+                                         ctypes.c_size_t(fri_step), ctypes.c_size_t(slice_elems), P(out))
+    finally:
+        shim.shim_set_world(1)
+    assert rc == 0
+    assert np.array_equal(out, want)
+
+
+@pytest.mark.parametrize("world", [1, 4])
 @pytest.mark.parametrize("builder", ["vector", "span", "streaming"])
 @pytest.mark.parametrize("curve,log_domain,steps", [(0, 15, [3, 2, 2]), (1, 15, [2, 3, 1]), (0, 19, [3, 3, 2]), (1, 19, [4, 2, 2])])
-def test_lpc_scheme_at_multipass_sizes(shim, curve, log_domain, steps, builder):
+def test_lpc_scheme_at_multipass_sizes(shim, curve, log_domain, steps, builder, world):
     """the LPC scheme at sizes where every transform is multi-pass, uploads are chunked and the streaming leaf builder
     wraps -- polynomials of 2^12 / 2^13 evaluations on a 2^15-point domain and of 2^16 / 2^17 on a 2^19-point one, both curves, all three
     tree-builder shapes -- against the C++ oracle's restatement of lpc.hpp:101-200 + basic_fri.hpp:433-496, 705-742 (cport.lpc_proof_eval,
-    pinned to pyoracle at <= 2^8): batch roots over the coset-ordered leaves, every evaluation, every FRI round root, the final polynomial."""
+    pinned to pyoracle at <= 2^8): batch roots over the coset-ordered leaves, every evaluation, every FRI round root, the final polynomial.
+    world 4: the same through the scheme over a device group of four members."""
+    import torch
     C = CURVES[curve]
     r = C.r
     logs = [log_domain - 3, log_domain - 3, log_domain - 2, log_domain - 3]
@@ -1316,6 +1373,8 @@ def test_lpc_scheme_at_multipass_sizes(shim, curve, log_domain, steps, builder):
     o_final, o_counts = np.zeros((nfinal, 4), dtype=np.uint64), np.zeros(6, dtype=np.uint64)
     shim.shim_set_lpc_builder({"vector": 0, "span": 1, "streaming": 2}[builder])
     shim.shim_set_lpc_slice(ctypes.c_size_t(3 << (log_domain - 4)))   # slices of whole leaves that do not divide the leaf count evenly
+    shim.shim_set_world(world)
+    shim.shim_set_gpus(max(1, torch.cuda.device_count()))
     try:
         rc = shim.shim_lpc_scheme(curve, P(np.concatenate(evals)), ctypes.c_size_t(4), P(np.array(logs, dtype=np.uint64)), ctypes.c_size_t(log_domain),
                                   P(np.array(steps, dtype=np.uint64)), ctypes.c_size_t(len(steps)), P(roots), P(fr_arr([p0, p1, p2])), P(fr_arr(challenges)),
@@ -1323,6 +1382,7 @@ def test_lpc_scheme_at_multipass_sizes(shim, curve, log_domain, steps, builder):
     finally:
         shim.shim_set_lpc_builder(0)
         shim.shim_set_lpc_slice(ctypes.c_size_t(64))
+        shim.shim_set_world(1)
     assert rc == 0
     assert fr_ints(o_roots) == [e_roots[0], e_roots[1]]
     assert fr_ints(o_z) == [v for k in (0, 1) for pl in e_z[k] for v in pl]

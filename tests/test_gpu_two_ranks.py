@@ -42,6 +42,8 @@ def test_two_ranks_point_split_and_sharded_legs(tmp_path):
     assert k["verified"] is True and k["columns_per_rank"] == 25
     kg = detail["kzg_device_group"]    # and rank 0's device group over the same two "GPUs" (one process, the drop-in scheme class): 50 columns dealt 25 / 25
     assert kg["verified"] is True and kg["members"] == 2 and line["legs"]["kzg_device_group"]["verified"] is True
+    lg = detail["lpc_device_group"]    # ... and the LPC scheme over the same group: 16 polynomials dealt 8 / 8, two leaf owners
+    assert lg["verified"] is True and lg["members"] == 2 and lg["leaf_owners"] == 2 and line["legs"]["lpc_device_group"]["verified"] is True
     t = detail["ntt_sharded"]    # BASELINE config 3's split: 8 polynomials dealt 4 / 4, no collective in the data path
     assert t["verified"] is True and t["polynomials_per_rank"] == 4 and t["scaling"] == "strong"
 
