@@ -371,6 +371,48 @@ def fuzz_group(zk, ctx, rng, stats):
     stats["device_group"] = stats.get("device_group", 0) + 1
 
 
+def fuzz_lpc_group(zk, ctx, rng, stats):
+    """lpc_commitment_scheme_hip::commit through the shim, on one context or over a device group of 2 .. 9 members: a ragged batch (runs of one or two
+    sizes), random domain, fri step, slice size -- the leaves the streaming tree builder is handed against the oracle's precommit leaves"""
+    import ctypes
+    import torch
+
+    if "lib" not in _SHIM:
+        _SHIM["lib"] = ctypes.CDLL(os.path.join(ROOT, "tests", "cpp", "libshimtest.so"))
+    shim = _SHIM["lib"]
+    curve = int(rng.integers(0, 2))
+    C = CURVES[curve]
+    log_domain = int(rng.integers(2, 13))
+    fri_step = int(rng.integers(1, min(5, log_domain) + 1))
+    npolys = int(rng.integers(1, 12))
+    small = int(rng.integers(1, log_domain + 1))
+    big = int(rng.integers(small, log_domain + 1))
+    cut = int(rng.integers(0, npolys + 1))
+    logs = [small] * cut + [big] * (npolys - cut)
+    world = 1 if rng.random() < 0.2 else int(rng.integers(2, 10))
+    slice_elems = int(rng.integers(1, 4 * npolys << log_domain))
+    D = 1 << log_domain
+    evals = [cp.random_fr(curve, int(rng.integers(1, 1 << 30)), 1 << l) for l in logs]
+    ext = []
+    for e, l in zip(evals, logs):
+        c = cp.ntt(curve, e.reshape(1, -1, 4), l, limbs(C.root_of_unity(l), 4), inverse=True)[0]
+        full = np.zeros((1, D, 4), dtype=np.uint64)
+        full[0, : 1 << l] = c
+        ext.append(cp.ntt(curve, full, log_domain, limbs(C.root_of_unity(log_domain), 4))[0])
+    want = cp.fri_leaves(ext, fri_step)
+    out = np.zeros((npolys * D, 4), dtype=np.uint64)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    shim.shim_set_world(world)
+    shim.shim_set_gpus(max(1, torch.cuda.device_count()))
+    try:
+        rc = shim.shim_lpc_commit_leaves(curve, P(np.concatenate(evals)), ctypes.c_size_t(npolys), P(np.array(logs, dtype=np.uint64)), ctypes.c_size_t(log_domain),
+                                         ctypes.c_size_t(fri_step), ctypes.c_size_t(slice_elems), P(out))
+    finally:
+        shim.shim_set_world(1)
+    assert rc == 0 and np.array_equal(out, want), ("lpc group", curve, logs, log_domain, fri_step, world, slice_elems, rc)
+    stats["lpc_commit_leaves"] = stats.get("lpc_commit_leaves", 0) + 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
@@ -383,7 +425,7 @@ def main():
     ctx = zk.Context(0)
     rng = np.random.default_rng(a.seed)
     stats = {"msm": 0, "ntt": 0, "domain": 0, "domain_skipped": 0, "witness_map": 0, "groth16_proof": 0, "argument_kernels": 0}
-    legs = [fuzz_msm, fuzz_msm, fuzz_ntt, fuzz_domain, fuzz_witness, fuzz_proof, fuzz_arguments, fuzz_gate, fuzz_group]
+    legs = [fuzz_msm, fuzz_msm, fuzz_ntt, fuzz_domain, fuzz_witness, fuzz_proof, fuzz_arguments, fuzz_gate, fuzz_group, fuzz_lpc_group]
     t0 = time.time()
     while time.time() - t0 < a.seconds:
         legs[int(rng.integers(0, len(legs)))](zk, ctx, rng, stats)
