@@ -484,6 +484,10 @@ public:
 
     /// polynomials per upload chunk (0: the whole batch in one transfer, one shared bucket reduction)
     std::size_t upload_chunk = 10;
+    /// over a device group: the quotient length from which proof_eval's multiexps are cut over the members (shorter ones stay on member 0)
+    std::size_t group_commit_min = (std::size_t)1 << 15;
+    /// quotient commitments that were cut over the group so far (tests and logs)
+    std::size_t group_multiexps() const { return _group_multiexps; }
 
     const std::map<std::size_t, commitment_type> &commitments() const { return _ind_commitments; }
 
@@ -519,7 +523,43 @@ protected:
     single_commitment_type commit_range(const void *d_coeffs, std::size_t len) const {
         if (len == 0) return single_commitment_type::zero();
         if (len > _params.commitment_key.size()) throw std::runtime_error("proof_eval: quotient longer than the commitment key");
+        if (_group_params && _group_params->members.size() > 1 && len >= std::max<std::size_t>(group_commit_min, _group_params->members.size()))
+            return commit_range_group(d_coeffs, len);
         return multiexp_dev<CurveType, ZKHIP_G1>(_params.ctx, _params.commitment_key, 0, len, d_coeffs);
+    }
+    /// proof_eval's quotient commitments over the device group: the coefficients (on member 0) are cut by point range, every other member pulls
+    /// its range device to device and runs it against ITS replica of the key at the same offset; the Jacobian partial sums meet on member 0
+    /// (the group's all-gather), are folded there and downloaded once -- the reference's multiexp with `chunks` = the members (kzg.hpp:146-147)
+    single_commitment_type commit_range_group(const void *d_coeffs, std::size_t len) const {
+        const group_params_type &gp = *_group_params;
+        const device_group &group = gp.group;
+        const std::size_t world = gp.members.size(), jl = 3 * adapter::g1_coord_limbs;
+        std::vector<std::shared_ptr<void>> d_sc(world), d_part(world);
+        std::vector<const void *> send(world);
+        std::vector<void *> recv(world, nullptr);
+        for (std::size_t k = 0; k < world; ++k) {
+            const std::size_t lo = len / world * k + std::min(k, len % world), hi = len / world * (k + 1) + std::min(k + 1, len % world);
+            const void *sc = static_cast<const char *>(d_coeffs) + 32 * lo;
+            d_part[k] = group[k].alloc(jl * 8);
+            if (k != 0) {
+                d_sc[k] = group[k].alloc((hi - lo) * 32);
+                group.copy(k, d_sc[k].get(), 0, sc, (hi - lo) * 32);
+                sc = d_sc[k].get();
+            }
+            check(zkhip_msm_dev(group[k].get(), gp.members[k]->commitment_key.get(), lo, hi - lo, sc, d_part[k].get()), "zkhip_msm_dev", group[k].get());
+            send[k] = d_part[k].get();
+        }
+        const context &root = group[0];
+        auto d_all = root.alloc((world + 1) * jl * 8);
+        recv[0] = d_all.get();
+        group.all_gather(send, recv, jl * 8);
+        void *d_sum = static_cast<char *>(d_all.get()) + world * jl * 8;
+        check(zkhip_jacobian_sum_dev(root.get(), adapter::id, ZKHIP_G1, d_all.get(), world, d_sum), "zkhip_jacobian_sum_dev", root.get());
+        std::uint64_t jac[3 * adapter::g1_coord_limbs];
+        root.d2h(jac, d_sum, sizeof(jac));
+        group.sync();    // the members' scalar ranges and partial sums are released on return
+        ++_group_multiexps;
+        return adapter::g1_from_jacobian(jac);
     }
     /// d[0 .. small.size()) += small
     void add_low_coefficients(void *d, const std::vector<scalar_value_type> &small, std::size_t len) const {
@@ -631,6 +671,7 @@ protected:
     std::vector<scalar_value_type> _merged_points;
     mutable std::unique_ptr<context> _upload_ctx;
     const group_params_type *_group_params = nullptr;    // set: commit(batch) deals its columns over this group's members
+    mutable std::size_t _group_multiexps = 0;
 };
 
 /// kzg_commitment_scheme_v2 (kzg_v2.hpp:56-360): two quotient commitments (pi_1, pi_2)

@@ -239,6 +239,7 @@ void scheme_host_paths() {
             kzg_params_group_hip<Curve> gparams(grp, ck.begin(), ck.end());
             EXPECT(gparams.members.size() == world);
             kzg_commitment_scheme_v2_hip<Curve, any_transcript> v2(gparams, root);
+            v2.group_commit_min = 1;    // the quotient commitments cut over the members too
             std::vector<std::reference_wrapper<const polynomial_dfs<Curve>>> lent(polys.begin(), polys.end());
             v2.append_to_batch(0, lent);
             device_polynomial_dfs<Curve> resident(grp[0], polys[1]);
@@ -247,6 +248,7 @@ void scheme_host_paths() {
             v2.append_eval_point(0, Fr(77));
             any_transcript tr;
             (void)v2.proof_eval(tr);
+            EXPECT(v2.group_multiexps() == 2);
         }
     }
     fri_params_hip<Curve> fp;

@@ -447,6 +447,7 @@ int kzg_v2_t(const uint64_t *srs, size_t n_srs, size_t npolys, const uint64_t *b
             grp.set_transport(transport);
             kzg_params_group_hip<Curve> gparams(grp, ck.begin(), ck.end());
             scheme_type gs(gparams, [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); });
+            gs.group_commit_min = 1;    // proof_eval's two quotient commitments cut over the members too, whatever their length
             std::vector<device_polynomial_dfs<Curve>> keep;
             keep.reserve(npolys);
             at = 0;
@@ -474,6 +475,7 @@ int kzg_v2_t(const uint64_t *srs, size_t n_srs, size_t npolys, const uint64_t *b
             auto gproof = gs.proof_eval(gtr);
             if (!(gproof.z == proof.z) || !(gproof.pi_1 == proof.pi_1) || !(gproof.pi_2 == proof.pi_2)) return -131;
             if (gtr.absorbed_points != tr.absorbed_points || gtr.absorbed_scalars != tr.absorbed_scalars) return -132;
+            if (gs.group_multiexps() != 2) return -133;    // pi_1 and pi_2 both went over the group
         }
     }
     return 0;
@@ -551,6 +553,38 @@ int kzg_v1_t(const uint64_t *srs, size_t n_srs, const uint64_t *vk, size_t n_vk,
     scripted_transcript<Curve> tr2;
     tr2.challenges = tr.challenges;
     if (!scheme.verify_eval(proof, scheme.packed_commitments(), tr2) || verify_calls != 1) return -9;
+    if (g_world > 1) {
+        /* the first batched scheme over a DEVICE GROUP: commit(batch) deals the columns, proof_eval's one quotient commitment is cut by point
+           range over the members' key replicas: the same commitments, evaluations and proof */
+        std::vector<int> devices;
+        for (int k = 0; k < g_world; ++k) devices.push_back(k % g_gpus);
+        device_group grp(devices);
+        kzg_params_group_hip<Curve> gparams(grp, ck.begin(), ck.end());
+        kzg_commitment_scheme_hip<Curve, scripted_transcript<Curve>> gs(gparams, [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); });
+        gs.group_commit_min = 1;
+        at = 0;
+        for (size_t p = 0; p < npolys; ++p) {
+            polynomial_dfs<Curve> poly;
+            for (size_t i = 0; i < ((size_t)1 << log_n[p]); ++i) poly.values.push_back(A::scalar_from_limbs(evals + 4 * at++));
+            gs.append_to_batch(batch_id[p], poly);
+        }
+        ci = 0;
+        for (size_t b : batches)
+            for (const auto &c : gs.commit(b)) {
+                std::vector<uint64_t> xy(L1);
+                c.to_affine(xy.data());
+                if (std::memcmp(xy.data(), commits + ci * L1, L1 * 8) != 0) return -140;
+                ++ci;
+            }
+        pt = 0;
+        for (size_t p = 0; p < npolys; ++p)
+            for (size_t q = 0; q < npts[p]; ++q) gs.append_eval_point(batch_id[p], idx_in_batch[p], A::scalar_from_limbs(points + 4 * pt++));
+        scripted_transcript<Curve> gtr;
+        gtr.challenges = tr.challenges;
+        auto gproof = gs.proof_eval(gtr);
+        if (!(gproof.z == proof.z) || !(gproof.kzg_proof == proof.kzg_proof)) return -141;
+        if (gs.group_multiexps() != 1) return -142;
+    }
     return 0;
 }
 

@@ -279,11 +279,23 @@ def test_kzg_batched_free_functions_shim(shim, curve):
         assert (proof == g(po.poly_eval(accum, alpha, r))).all()
 
 
-@pytest.mark.parametrize("curve", [0, 1])
-def test_kzg_v1_proof_eval_shim(shim, curve):
+@pytest.mark.parametrize("curve,world", [(0, 1), (1, 1), (0, 3), (1, 2)])
+def test_kzg_v1_proof_eval_shim(shim, curve, world):
     """kzg_commitment_scheme (the first batched scheme, kzg.hpp:636-873): commit + proof_eval through the shim class against the
     oracle's restatement of :782-807 -- evaluations z, the single quotient commitment kzg_proof, the verifier's equation in
-    the exponent with alpha known -- and commit_g2 (:497-510, 659-664) against the G2 MSM oracle."""
+    the exponent with alpha known -- and commit_g2 (:497-510, 659-664) against the G2 MSM oracle.
+    world > 1: additionally the scheme over a device group (columns dealt, the quotient commitment cut by point range over the members'
+    key replicas) must give the same commitments, evaluations and proof."""
+    import torch
+    shim.shim_set_world(world)
+    shim.shim_set_gpus(max(1, torch.cuda.device_count()))
+    try:
+        _kzg_v1_proof_eval_shim(shim, curve)
+    finally:
+        shim.shim_set_world(1)
+
+
+def _kzg_v1_proof_eval_shim(shim, curve):
     C = CURVES[curve]
     r = C.r
     alpha = 7
@@ -1407,12 +1419,24 @@ def _kzg_layout_at(curve, log_n):
     return layout, evals, polys, points, rng.next_mod(r), rng.next_mod(r)
 
 
-@pytest.mark.parametrize("curve,log_n", [(0, 12), (1, 12), (0, 16), (1, 16)])
-def test_kzg_proof_eval_at_multipass_sizes(shim, curve, log_n):
+@pytest.mark.parametrize("curve,log_n,world", [(0, 12, 1), (1, 12, 4), (0, 16, 3), (1, 16, 1)])
+def test_kzg_proof_eval_at_multipass_sizes(shim, curve, log_n, world):
     """both batched KZG opening proofs (kzg_v2.hpp:236-305, kzg.hpp:782-807) through the shim classes with polynomials
     of 2^12 / 2^13 and 2^16 / 2^17 evaluations, both curves, against the C++ oracle's restatements (cport.kzg_v2_proof_eval /
     kzg_v1_proof_eval, pinned to pyoracle at <= 2^7): every evaluation, and the quotient commitments pi_1, pi_2 / kzg_proof equal to the
-    oracle's MSM of the oracle's quotient polynomials over the same SRS (and to quotient(alpha) G in the exponent)."""
+    oracle's MSM of the oracle's quotient polynomials over the same SRS (and to quotient(alpha) G in the exponent).
+    world > 1: both schemes additionally over a device group of that many members (inside the harness: commitments, evaluations and the
+    quotient commitments -- cut by point range over the members -- equal to the single-device scheme's)."""
+    import torch
+    shim.shim_set_world(world)
+    shim.shim_set_gpus(max(1, torch.cuda.device_count()))
+    try:
+        _kzg_proof_eval_at_multipass_sizes(shim, curve, log_n)
+    finally:
+        shim.shim_set_world(1)
+
+
+def _kzg_proof_eval_at_multipass_sizes(shim, curve, log_n):
     C = CURVES[curve]
     r, alpha = C.r, 7
     layout, evals, polys, points, theta, theta2 = _kzg_layout_at(curve, log_n)
