@@ -374,6 +374,12 @@ int zkhip_memcpy_2d_d2d_async(zkhip_ctx *ctx, void *dst, size_t dst_pitch, const
     if (width == 0 || rows == 0) return ZKHIP_OK;
     if (!dst || !src || width > dst_pitch || width > src_pitch) return ZKHIP_ERR_INVALID;
     ZK_TRY(check_device(ctx));
+    if (dst_pitch >= ((size_t)1 << 31) || src_pitch >= ((size_t)1 << 31)) {  // beyond the 2D engine's pitch range (a 2^27-point domain at step 1): row by row
+        for (size_t r = 0; r < rows; ++r)
+            ZK_HIP_CHECK(ctx, hipMemcpyAsync(static_cast<char *>(dst) + r * dst_pitch, static_cast<const char *>(src) + r * src_pitch, width, hipMemcpyDeviceToDevice,
+                                             ctx->stream));
+        return ZKHIP_OK;
+    }
     ZK_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width, rows, hipMemcpyDeviceToDevice, ctx->stream));
     return ZKHIP_OK;
 }

@@ -226,6 +226,11 @@ class Context:
     def d2h(self, arr: np.ndarray, dptr: int):
         self._check(self.lib.zkhip_memcpy_d2h(self.h, _p(arr), ctypes.c_void_p(dptr), ctypes.c_size_t(arr.nbytes)), "zkhip_memcpy_d2h")
 
+    def copy_2d(self, dst: int, dst_pitch: int, src: int, src_pitch: int, width: int, rows: int):
+        """rows of `width` bytes at a pitch, device to device on this context's GPU, in stream order (zkhip_memcpy_2d_d2d_async)"""
+        self._check(self.lib.zkhip_memcpy_2d_d2d_async(self.h, ctypes.c_void_p(dst), ctypes.c_size_t(dst_pitch), ctypes.c_void_p(src), ctypes.c_size_t(src_pitch),
+                                                       ctypes.c_size_t(width), ctypes.c_size_t(rows)), "zkhip_memcpy_2d_d2d_async")
+
     # ---- bases
     def upload_bases(self, curve: int, group: int, affine: np.ndarray, inf=None) -> "Bases":
         affine = _u64(affine)

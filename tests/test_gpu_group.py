@@ -65,6 +65,29 @@ def test_group_all_gather_and_copy(zk, world, transport):
     g.close()
 
 
+def test_strided_copy(zk, ctx):
+    """zkhip_memcpy_2d_d2d_async: what the LPC scheme over a group packs a leaf owner's segments with -- rows of `width` bytes from one pitch
+    to another, stream-ordered; a width beyond a pitch is refused, empty copies are no-ops"""
+    rng = np.random.default_rng(5)
+    for rows, width, sp, dp in ((7, 96, 160, 96), (1, 32, 32, 64), (33, 4096, 8192, 4096), (256, 32, 1 << 14, 32)):
+        src = rng.integers(0, 256, rows * sp, dtype=np.uint8)
+        d_src, d_dst = ctx.malloc(rows * sp), ctx.malloc(rows * dp)
+        ctx.h2d(d_src, src)
+        ctx.h2d(d_dst, np.full(rows * dp, 0x5A, dtype=np.uint8))
+        ctx.copy_2d(d_dst, dp, d_src, sp, width, rows)
+        got = np.zeros(rows * dp, dtype=np.uint8)
+        ctx.d2h(got, d_dst)
+        want = np.full((rows, dp), 0x5A, dtype=np.uint8)
+        want[:, :width] = src.reshape(rows, sp)[:, :width]
+        assert (got.reshape(rows, dp) == want).all()
+        with pytest.raises(zk.ZkhipError):
+            ctx.copy_2d(d_dst, dp, d_src, sp, min(sp, dp) + 1, rows)
+        ctx.copy_2d(d_dst, dp, d_src, sp, 0, rows)
+        ctx.copy_2d(d_dst, dp, d_src, sp, width, 0)
+        ctx.free(d_src)
+        ctx.free(d_dst)
+
+
 def test_group_rccl_refuses_shared_devices(zk):
     import torch
     if torch.cuda.device_count() > 1:
