@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--cpu-groth16-log", type=int, default=20, help="constraints of the CPU prover sample = 2^k (default: the headline instance; 17 = quick)")
     ap.add_argument("--no-groth16", action="store_true", help="skip the Groth16 constraints/s leg")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL all-gather + fold at N = 1 too (checks the N > 1 path on one GPU)")
+    ap.add_argument("--sync-exchange", action="store_true", help="N > 1: finish every step's all-gather + fold before the next multiexp is enqueued (A/B of the pipelined exchange)")
     ap.add_argument("--no-kzg", action="store_true", help="skip the KZG commit / opening-proof leg (BASELINE config 5's commitment layer, N = 1 only)")
     ap.add_argument("--no-ntt", action="store_true", help="skip the NTT leg (BASELINE config 3, N = 1 only)")
     ap.add_argument("--no-other-msm", action="store_true", help="skip the BLS12-381 G2 and BN254 G1 MSM legs (N = 1 only)")
@@ -190,7 +191,8 @@ def main():
     ctx.set_option("msm_shard_world", 1)
     n_local = len(scalars)
     d_scalars = torch.from_numpy(scalars.view(np.int64)).to(dev)
-    d_out = torch.zeros(3 * 6, dtype=torch.int64, device=dev)
+    d_outs = [torch.zeros(3 * 6, dtype=torch.int64, device=dev) for _ in range(2)]  # two: step i + 1 writes one while step i's exchange reads the other
+    d_out = d_outs[0]
     d_total = torch.zeros(3 * 6, dtype=torch.int64, device=dev)
 
     from crypto3_zk_amd import dist as zd
@@ -199,18 +201,31 @@ def main():
         ctx.jacobian_sum_dev(zk.BLS12_381, zk.G1, gathered.data_ptr(), w, d_total.data_ptr())
         return d_total
 
+    # N > 1: one all-gather of the 144-byte partial sums over RCCL per step, then the on-device fold -- the exchange of step i runs on RCCL's
+    # stream UNDER the multiexp of step i + 1 (AllgatherFoldPipeline); every step's sum is produced, in order, inside the timed region
+    pipe = zd.AllgatherFoldPipeline(world, lambda o, i: dist.all_gather_into_tensor(o, i, async_op=not args.sync_exchange), fold,
+                                    lambda count: torch.zeros(count, dtype=torch.int64, device=dev)) if use_dist else None
+    step_no = [0]
+
     def step():
-        ctx.msm_dev(bases, d_scalars.data_ptr(), d_out.data_ptr(), 0, n_local)
-        # N > 1: one all-gather of the 144-byte partial sums over RCCL, then the on-device fold
-        return zd.allgather_fold(d_out, world, lambda o, i: dist.all_gather_into_tensor(o, i), fold, always=use_dist)
+        out = d_outs[step_no[0] & 1]
+        step_no[0] += 1
+        ctx.msm_dev(bases, d_scalars.data_ptr(), out.data_ptr(), 0, n_local)
+        return pipe.push(out) if pipe else out
+
+    def drain(last):
+        """the last step's exchange and fold (the steps before it were finished one step late)"""
+        return pipe.flush() if pipe else last
 
     def fence():
         if use_dist:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
+    result = None
     for _ in range(args.warmup):
-        step()
+        result = step()
+    result = drain(result)
     fence()
     # the timed region carries HIP events around the dominant kernel only (roofline.achieved); the full per-kernel breakdown
     # comes from three extra, untimed steps below
@@ -220,6 +235,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         result = step()
+    result = drain(result)
     fence()
     elapsed = time.perf_counter() - t0
     ctx.profile(False)
@@ -229,6 +245,7 @@ def main():
     ctx.profile(True)
     for _ in range(3):
         step()
+    drain(None)
     fence()
     ctx.profile(False)
     if use_dist:
@@ -305,6 +322,7 @@ def main():
         uu = [p_["uuid"] for p_ in parts]
         dist_info = {"backend": "rccl" if args.dist_backend == "nccl" else "gloo", "world_size": world, "devices": uu,
                      "distinct_devices": len(set(uu)), "same_device_flag": bool(args.same_device),
+                     "exchange": "synchronous" if (args.sync_exchange or args.dist_backend != "nccl") else "pipelined: step i's all-gather + fold under step i+1's multiexp",
                      "note": "value: weak scaling (2^log_n points per GPU, one all-gather of 144 B per rank per step); the *_sharded legs are STRONG scaling of fixed jobs "
                              "and saturate at the replicated witness map + the small-MSM floor (DESIGN.md section 9; this line carries only what this run measured)"}
     if rank == 0:
@@ -578,12 +596,15 @@ class Comm:
         self.torch, self.d, self.backend, self.local_rank = torch, tdist, backend, local_rank
         self.ReduceOp = tdist.ReduceOp
 
-    def all_gather_into_tensor(self, out, inp):
+    def all_gather_into_tensor(self, out, inp, async_op=False):
+        """async_op: over RCCL the collective's handle (its .wait() orders the CURRENT stream after it, the host does not block); gloo is staged through
+        the host and finished on return (None)"""
         if self.backend == "nccl":
-            return self.d.all_gather_into_tensor(out, inp)
+            return self.d.all_gather_into_tensor(out, inp, async_op=async_op)
         host = self.torch.empty(out.shape, dtype=out.dtype)
         self.d.all_gather_into_tensor(host, inp.cpu())  # .cpu() waits for the stream the partial sums were computed on
         out.copy_(host)
+        return None
 
     def all_reduce(self, t, op=None):
         if self.backend == "nccl":

@@ -50,3 +50,47 @@ def allgather_fold(partial, world: int, all_gather: Callable, fold: Callable, al
     gathered = partial.new_zeros(world * partial.numel())
     all_gather(gathered, partial)
     return fold(gathered, world)
+
+
+class AllgatherFoldPipeline:
+    """allgather_fold with the exchange of step i UNDER the multiexp of step i + 1.
+
+    The 144-byte all-gather is latency, not bandwidth (a kernel launch on RCCL's stream + the slowest rank's skew): issued synchronously it
+    sits between two multiexps on every rank.  Here step i's collective is started asynchronously (`all_gather(out, inp)` returns a handle
+    with .wait(), e.g. torch.distributed.all_gather_into_tensor(..., async_op=True): RCCL's stream waits for the partial sum, the compute
+    stream goes on), and its wait + fold are enqueued one step later, after the next multiexp is in the queue.  Two partial-sum buffers and
+    two receive buffers alternate, so nothing a collective still reads is overwritten.  Results come out in order, one step late; `flush`
+    returns the last one.  `all_gather` may also be synchronous (returns None: gloo through the host, test doubles): then this is
+    allgather_fold with preallocated buffers.
+    """
+
+    def __init__(self, world: int, all_gather: Callable, fold: Callable, new_buffer: Callable):
+        """new_buffer(n): a zeroed flat buffer of n elements where the partial sums live (two receive buffers are made up front)"""
+        self.world, self.all_gather, self.fold = world, all_gather, fold
+        self.new_buffer = new_buffer
+        self.recv = None
+        self.pending = None  # (handle, receive slot) of the step whose fold has not been enqueued yet
+        self.slot = 0
+
+    def push(self, partial):
+        """start this step's exchange; returns the folded result of the PREVIOUS step (None at the first call)"""
+        if self.recv is None:
+            self.recv = [self.new_buffer(self.world * partial.numel()) for _ in range(2)]
+        handle = self.all_gather(self.recv[self.slot], partial)
+        done = self._finish()
+        self.pending = (handle, self.slot)
+        self.slot ^= 1
+        return done
+
+    def flush(self):
+        """the folded result of the last pushed step (None when nothing is pending)"""
+        return self._finish()
+
+    def _finish(self):
+        if self.pending is None:
+            return None
+        handle, slot = self.pending
+        self.pending = None
+        if handle is not None:
+            handle.wait()
+        return self.fold(self.recv[slot], self.world)

@@ -45,6 +45,24 @@ def _worker(rank, world, port, n, out_q):
     total, tinf = zd.allgather_fold(t, world, lambda o, i: dist.all_gather_into_tensor(o, i), fold)
     exp, einf = cp.msm(0, 1, pts, sc, chunks=2)
     ok = bool(tinf == einf and (total == exp).all())
+    # the same exchange pipelined (the collective of step i under the work of step i + 1): asynchronous gloo collectives, three steps whose
+    # partial sums differ (step s contributes its point only on the ranks >= s), results one step late and in order
+    pipe = zd.AllgatherFoldPipeline(world, lambda o, i: dist.all_gather_into_tensor(o, i, async_op=True), fold, lambda count: torch.zeros(count, dtype=torch.int64))
+    inf_t = torch.zeros(18, dtype=torch.int64)
+    seen = []
+    for s in range(3):
+        seen.append(pipe.push(t if rank >= s else inf_t))
+    seen.append(pipe.flush())
+    ok = ok and seen[0] is None and pipe.flush() is None
+    for s in range(3):
+        members = [r for r in range(world) if r >= s]
+        if members:
+            lo_s, hi_s = zd.shard_range(n, members[0], world)[0], n
+            e_s, i_s = cp.msm(0, 1, pts[lo_s:hi_s], sc[lo_s:hi_s], chunks=1)
+        else:
+            e_s, i_s = None, 1
+        got, ginf = seen[s + 1]
+        ok = ok and ginf == i_s and (i_s == 1 or bool((got == e_s).all()))
     # NTT batches shard by polynomial without any collective
     polys = zd.shard_polys(8, rank, world)
     gathered = [None] * world
@@ -53,6 +71,49 @@ def _worker(rank, world, port, n, out_q):
     dist.barrier()
     dist.destroy_process_group()
     out_q.put((rank, ok))
+
+
+def test_pipeline_defers_wait_and_fold_by_one_step():
+    """AllgatherFoldPipeline on test doubles: the collective of step i is started at push(i), its wait + fold happen at push(i + 1) -- after the
+    next collective was started --, receive buffers alternate, flush drains the last step; a synchronous all_gather (handle None) works too"""
+    conf = __import__("conftest")
+    conf.load_pkg()
+    from crypto3_zk_amd import dist as zd
+
+    log = []
+
+    class Handle:
+        def __init__(self, step):
+            self.step = step
+
+        def wait(self):
+            log.append(("wait", self.step))
+
+    step_of = {}
+
+    def all_gather(out, inp):
+        out[: inp.numel()] = inp
+        out[inp.numel():] = inp * 10
+        step_of[id(out)] = int(inp[0])
+        log.append(("start", int(inp[0]), id(out)))
+        return Handle(int(inp[0]))
+
+    def fold(gathered, w):
+        log.append(("fold", step_of[id(gathered)]))
+        return int(gathered.view(w, -1).sum())
+
+    pipe = zd.AllgatherFoldPipeline(2, all_gather, fold, lambda count: torch.zeros(count, dtype=torch.int64))
+    outs = [pipe.push(torch.full((3,), s, dtype=torch.int64)) for s in (1, 2, 3)]
+    outs.append(pipe.flush())
+    assert outs == [None, 33, 66, 99] and pipe.flush() is None
+    kinds = [(e[0], e[1]) for e in log]
+    assert kinds == [("start", 1), ("start", 2), ("wait", 1), ("fold", 1), ("start", 3), ("wait", 2), ("fold", 2), ("wait", 3), ("fold", 3)]
+    bufs = [e[2] for e in log if e[0] == "start"]
+    assert bufs[0] != bufs[1] and bufs[0] == bufs[2]    # two receive buffers, alternating
+    # synchronous collective
+    pipe = zd.AllgatherFoldPipeline(2, lambda o, i: (o.__setitem__(slice(0, 3), i), o.__setitem__(slice(3, 6), i), None)[2], lambda g, w: int(g.sum()),
+                                    lambda count: torch.zeros(count, dtype=torch.int64))
+    assert [pipe.push(torch.full((3,), 5, dtype=torch.int64)), pipe.flush()] == [None, 30]
 
 
 def test_shard_range():
