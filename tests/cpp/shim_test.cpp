@@ -1873,7 +1873,16 @@ int placeholder_round_t(const uint64_t *srs, size_t n_srs, const uint64_t *evals
     typedef device_polynomial_dfs<Curve> dfs;
     typedef placeholder_quotient_hip<Curve> Q;
     const size_t n = (size_t)1 << log_n, L1 = 2 * A::g1_coord_limbs;
-    context ctx(0);
+    /* g_world > 1: the round's commitment scheme lives on a DEVICE GROUP (the arguments' own kernels on member 0, whose polynomials the
+       scheme's commit(batch) deals over the members device to device): the same T, the same commitments */
+    std::unique_ptr<device_group> grp;
+    std::unique_ptr<context> own;
+    if (g_world > 1) {
+        std::vector<int> devices;
+        for (int k = 0; k < g_world; ++k) devices.push_back(k % g_gpus);
+        grp.reset(new device_group(devices));
+    } else own.reset(new context(0));
+    const context &ctx = grp ? grp->root() : *own;
     auto root = [roots](std::size_t l) { return A::scalar_from_limbs(roots + 4 * l); };
     auto ch = [challenges](size_t i) { return A::scalar_from_limbs(challenges + 4 * i); };
     const uint64_t *at = evals;
@@ -1895,8 +1904,14 @@ int placeholder_round_t(const uint64_t *srs, size_t n_srs, const uint64_t *evals
     /* the commitment scheme: SRS resident, batches fed with device polynomials */
     std::vector<G1> ck;
     for (size_t i = 0; i < n_srs; ++i) ck.push_back(G1::from_affine(srs + i * L1));
-    kzg_params_hip<Curve> params(ctx, ck.begin(), ck.end());
-    kzg_commitment_scheme_v2_hip<Curve, scripted_any_transcript<Curve>> scheme(params, root);
+    typedef kzg_commitment_scheme_v2_hip<Curve, scripted_any_transcript<Curve>> scheme_t;
+    std::unique_ptr<kzg_params_hip<Curve>> own_params;
+    std::unique_ptr<kzg_params_group_hip<Curve>> gparams;
+    if (grp) gparams.reset(new kzg_params_group_hip<Curve>(*grp, ck.begin(), ck.end()));
+    else own_params.reset(new kzg_params_hip<Curve>(ctx, ck.begin(), ck.end()));
+    const kzg_params_hip<Curve> &params = grp ? gparams->root() : *own_params;
+    std::unique_ptr<scheme_t> scheme_p(grp ? new scheme_t(*gparams, root) : new scheme_t(params, root));
+    scheme_t &scheme = *scheme_p;
     constexpr std::size_t PERMUTATION_BATCH = 2, QUOTIENT_BATCH = 3, LOOKUP_BATCH = 4;
     /* 4. permutation argument (prover.hpp:170-190) */
     auto perm = placeholder_permutation_hip<Curve>::prove_eval(ctx, cols, sid, ssig, q_last, q_blind, lagrange_0, ch(0), ch(1), root);

@@ -674,14 +674,26 @@ def test_column_range_polynomials_shim(shim, curve, n):
         assert [po.poly_eval(fr_ints(out[0]), x, C.r) for x in xs] == fr_ints(a[0])
 
 
-@pytest.mark.parametrize("curve,log_n", [(0, 6), (1, 5)])
-def test_placeholder_round_composed_shim(shim, curve, log_n):
+@pytest.mark.parametrize("curve,log_n,world", [(0, 6, 1), (1, 5, 1), (0, 6, 3), (1, 5, 2)])
+def test_placeholder_round_composed_shim(shim, curve, log_n, world):
     """The pieces composed as placeholder_prover::process strings them (prover.hpp:170-218, 262-277, 220-259, 314-317): permutation
     argument, lookup argument and a gate argument over GENUINE instances (copy constraints closed inside the usable rows, inputs drawn
     from the table, w2 = w0 w1 where the selector is on), their eight constraint polynomials -- living on different domains -- consolidated
     with eight alphas, divided by X^n - 1 (exactly: every part vanishes on the rows), split and committed; V_P, V_L, the sorted vectors
     and the quotient parts go to the KZG scheme as device polynomials.  Against the oracle: T coefficient by coefficient, every
-    commitment = polynomial(alpha) G."""
+    commitment = polynomial(alpha) G.
+    world > 1: the round's KZG scheme over a device group of that many members (the arguments' kernels on member 0; commit(batch) deals the
+    resident polynomials over the members device to device): the same T and commitments."""
+    import torch
+    shim.shim_set_world(world)
+    shim.shim_set_gpus(max(1, torch.cuda.device_count()))
+    try:
+        _placeholder_round_composed_shim(shim, curve, log_n)
+    finally:
+        shim.shim_set_world(1)
+
+
+def _placeholder_round_composed_shim(shim, curve, log_n):
     C = CURVES[curve]
     r, alpha, k = C.r, 7, 2
     n = 1 << log_n
