@@ -413,6 +413,41 @@ def fuzz_lpc_group(zk, ctx, rng, stats):
     stats["lpc_commit_leaves"] = stats.get("lpc_commit_leaves", 0) + 1
 
 
+def fuzz_kzg_group(zk, ctx, rng, stats):
+    """both batched KZG schemes through the shim (commit + proof_eval: evaluations, quotient commitments) on a random layout -- 1 .. 6 polynomials in
+    up to three batches, ragged sizes and point sets -- against the oracle, and, for a group of 2 .. 5 members, the same over the device group
+    (columns dealt, quotient commitments cut by point range) against the single-device scheme inside the harness"""
+    import ctypes
+    import torch
+    import test_gpu_shim as tgs
+
+    if "lib" not in _SHIM:
+        _SHIM["lib"] = ctypes.CDLL(os.path.join(ROOT, "tests", "cpp", "libshimtest.so"))
+    shim = _SHIM["lib"]
+    curve = int(rng.integers(0, 2))
+    r = CURVES[curve].r
+    log_n = int(rng.integers(3, 10))
+    pool = [int(rng.integers(1, 1 << 62)) * int(rng.integers(1, 1 << 62)) % r for _ in range(4)]
+    npolys = int(rng.integers(1, 7))
+    layout, batch = [], 0
+    for p in range(npolys):
+        if p and rng.random() < 0.4:
+            batch += int(rng.integers(1, 3))
+        npts = int(rng.integers(1, 4))
+        pts = [pool[i] for i in rng.choice(4, size=npts, replace=False)]
+        layout.append((batch, log_n + int(rng.integers(0, 2)), pts))
+    world = 1 if rng.random() < 0.3 else int(rng.integers(2, 6))
+    shim.shim_set_world(world)
+    shim.shim_set_gpus(max(1, torch.cuda.device_count()))
+    try:
+        tgs._kzg_proof_eval_at_multipass_sizes(shim, curve, log_n, layout, int(rng.integers(0, 1 << 20)))
+    except AssertionError:
+        raise SystemExit("KZG scheme differs: curve %d layout %r world %d" % (curve, [(k, l, len(p)) for k, l, p in layout], world))
+    finally:
+        shim.shim_set_world(1)
+    stats["kzg_schemes"] = stats.get("kzg_schemes", 0) + 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
@@ -425,7 +460,7 @@ def main():
     ctx = zk.Context(0)
     rng = np.random.default_rng(a.seed)
     stats = {"msm": 0, "ntt": 0, "domain": 0, "domain_skipped": 0, "witness_map": 0, "groth16_proof": 0, "argument_kernels": 0}
-    legs = [fuzz_msm, fuzz_msm, fuzz_ntt, fuzz_domain, fuzz_witness, fuzz_proof, fuzz_arguments, fuzz_gate, fuzz_group, fuzz_lpc_group]
+    legs = [fuzz_msm, fuzz_msm, fuzz_ntt, fuzz_domain, fuzz_witness, fuzz_proof, fuzz_arguments, fuzz_gate, fuzz_group, fuzz_lpc_group, fuzz_kzg_group]
     t0 = time.time()
     while time.time() - t0 < a.seconds:
         legs[int(rng.integers(0, len(legs)))](zk, ctx, rng, stats)

@@ -1415,16 +1415,18 @@ def test_lpc_scheme_at_multipass_sizes(shim, curve, log_domain, steps, builder, 
     assert list(o_counts) == [6, len(steps), nfinal, len(challenges), 2 + len(steps), len(steps) + 100 * sum(steps) + 10000 * 2]
 
 
-def _kzg_layout_at(curve, log_n):
-    """five polynomials in two batches, sizes 2^log_n and 2^(log_n + 1), ragged point sets (the shape of test_kzg_v2_proof_eval_shim)"""
+def _kzg_layout_at(curve, log_n, layout=None, seed=0):
+    """five polynomials in two batches, sizes 2^log_n and 2^(log_n + 1), ragged point sets (the shape of test_kzg_v2_proof_eval_shim) -- or the
+    layout given: [(batch id ascending, log2 size, points)]"""
     C = CURVES[curve]
     r = C.r
-    rng = po.SplitMix64(177 + curve + log_n)
+    rng = po.SplitMix64(177 + curve + log_n + seed)
     x1, x2, x3 = (rng.next_mod(r) for _ in range(3))
-    layout = [(0, log_n, [x1, x2]), (0, log_n, [x1, x2]), (0, log_n, [x1, x2]), (2, log_n, [x2]), (2, log_n + 1, [x1, x3])]
+    if layout is None:
+        layout = [(0, log_n, [x1, x2]), (0, log_n, [x1, x2]), (0, log_n, [x1, x2]), (2, log_n, [x2]), (2, log_n + 1, [x1, x3])]
     evals, polys, points = [], {}, {}
     for p, (k, l, pts) in enumerate(layout):
-        e = cp.random_fr(curve, 2500 + p + log_n, 1 << l)
+        e = cp.random_fr(curve, 2500 + p + log_n + 7 * seed, 1 << l)
         evals.append(e)
         polys.setdefault(k, []).append(cp.ntt(curve, e.reshape(1, -1, 4), l, limbs(C.root_of_unity(l), 4), inverse=True)[0])
         points.setdefault(k, []).append(pts)
@@ -1448,10 +1450,10 @@ def test_kzg_proof_eval_at_multipass_sizes(shim, curve, log_n, world):
         shim.shim_set_world(1)
 
 
-def _kzg_proof_eval_at_multipass_sizes(shim, curve, log_n):
+def _kzg_proof_eval_at_multipass_sizes(shim, curve, log_n, layout=None, seed=0):
     C = CURVES[curve]
     r, alpha = C.r, 7
-    layout, evals, polys, points, theta, theta2 = _kzg_layout_at(curve, log_n)
+    layout, evals, polys, points, theta, theta2 = _kzg_layout_at(curve, log_n, layout, seed)
     npolys = len(layout)
     n_srs = 2 << log_n
     srs = _srs(curve, alpha, n_srs)
