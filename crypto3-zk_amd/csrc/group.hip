@@ -339,7 +339,7 @@ int zkhip_group_copy(zkhip_device_group *g, int dst_member, void *d_dst, int src
     if (!d_dst || !d_src) return ZKHIP_ERR_INVALID;
     ZK_TRY(resolve_transport(g));
     zkhip_ctx *src = g->members[src_member], *dst = g->members[dst_member];
-    if (g->transport == ZKHIP_GROUP_STAGED && g->devices[src_member] != g->devices[dst_member]) {
+    if (g->transport == ZKHIP_GROUP_STAGED && src != dst) {  // through the host whatever the devices: the fallback is the same code on every box (and testable on one GPU)
         ZK_TRY(stage_reserve(g, bytes));
         ZK_GROUP_HIP(g, hipSetDevice(src->device));
         ZK_GROUP_HIP(g, hipMemcpyAsync(g->h_stage, d_src, bytes, hipMemcpyDeviceToHost, src->stream));

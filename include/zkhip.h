@@ -403,8 +403,8 @@ const char *zkhip_group_last_error(const zkhip_device_group *g);
  *                       Needs pairwise distinct devices (RCCL refuses two ranks on one GPU): ZKHIP_ERR_INVALID otherwise.
  *   ZKHIP_GROUP_PEER    stream-ordered peer copies (hipMemcpyPeerAsync behind an event per source stream; a plain device-to-device
  *                       copy between members that share a GPU).  No host synchronisation.
- *   ZKHIP_GROUP_STAGED  through one page-locked host buffer: D2H on every member, a host synchronisation, H2D.  The fallback that
- *                       works wherever HIP works.
+ *   ZKHIP_GROUP_STAGED  through one page-locked host buffer: D2H on every member, a host synchronisation, H2D -- also between members
+ *                       that share a GPU (one code path on every box).  The fallback that works wherever HIP works.
  *   ZKHIP_GROUP_AUTO    (default) RCCL when the group has more than one member on pairwise distinct devices and librccl loads,
  *                       PEER otherwise.
  * zkhip_group_transport returns what AUTO resolved to (RCCL is tried at the first exchange). */
