@@ -326,8 +326,8 @@ int zkhip_group_all_gather(zkhip_device_group *g, const void *const *d_send, voi
         for (size_t k = 0; k < n; ++k) {
             if (k != j) ZK_GROUP_HIP(g, hipStreamWaitEvent(s, g->ev[k], 0));
             char *dst = static_cast<char *>(d_recv[j]) + k * bytes;
-            if (g->devices[k] == g->devices[j]) ZK_GROUP_HIP(g, hipMemcpyAsync(dst, d_send[k], bytes, hipMemcpyDeviceToDevice, s));
-            else ZK_GROUP_HIP(g, hipMemcpyPeerAsync(dst, g->devices[j], d_send[k], g->devices[k], bytes, s));
+            // the peer form also between members that share a GPU: the call a multi-GPU box makes is the call the one-GPU tests make
+            ZK_GROUP_HIP(g, hipMemcpyPeerAsync(dst, g->devices[j], d_send[k], g->devices[k], bytes, s));
         }
     }
     return ZKHIP_OK;
@@ -355,8 +355,7 @@ int zkhip_group_copy(zkhip_device_group *g, int dst_member, void *d_dst, int src
     }
     ZK_GROUP_HIP(g, hipSetDevice(dst->device));
     if (src != dst) ZK_GROUP_HIP(g, hipStreamWaitEvent(dst->stream, g->ev[src_member], 0));
-    if (src->device == dst->device) ZK_GROUP_HIP(g, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, dst->stream));
-    else ZK_GROUP_HIP(g, hipMemcpyPeerAsync(d_dst, dst->device, d_src, src->device, bytes, dst->stream));
+    ZK_GROUP_HIP(g, hipMemcpyPeerAsync(d_dst, dst->device, d_src, src->device, bytes, dst->stream));
     return ZKHIP_OK;
 }
 

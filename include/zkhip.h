@@ -401,8 +401,8 @@ const char *zkhip_group_last_error(const zkhip_device_group *g);
  *   ZKHIP_GROUP_RCCL    one single-process RCCL communicator per member (ncclCommInitAll) and a grouped ncclAllGather on the members'
  *                       streams over xGMI; librccl.so is loaded on first use (dlopen), so a single-GPU caller never pays for it.
  *                       Needs pairwise distinct devices (RCCL refuses two ranks on one GPU): ZKHIP_ERR_INVALID otherwise.
- *   ZKHIP_GROUP_PEER    stream-ordered peer copies (hipMemcpyPeerAsync behind an event per source stream; a plain device-to-device
- *                       copy between members that share a GPU).  No host synchronisation.
+ *   ZKHIP_GROUP_PEER    stream-ordered peer copies (hipMemcpyPeerAsync behind an event per source stream -- the same call between members
+ *                       that share a GPU, so a one-GPU box exercises what a multi-GPU box runs).  No host synchronisation.
  *   ZKHIP_GROUP_STAGED  through one page-locked host buffer: D2H on every member, a host synchronisation, H2D -- also between members
  *                       that share a GPU (one code path on every box).  The fallback that works wherever HIP works.
  *   ZKHIP_GROUP_AUTO    (default) RCCL when the group has more than one member on pairwise distinct devices and librccl loads,
